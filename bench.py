@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py -- training samples/sec of the MFM_KL_EF step (MOSI shape, T=20, 3 modalities).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full training step of the reference's hot loop (mfm_mosi.py:424-442): batch
+fetch from the HBM-resident synthetic split + forward + joint loss + backward + (all-reduce) +
+Adam, train mode with the canonical dropouts.  Workload (BASELINE.json configs[1]): canonical
+MOSI sizes (mfm_mosi.py:1239-1286), B=32 per GPU, T=20 (configs/mosi.json seqlength), D=325,
+fp32.  N>1 is weak scaling: every rank processes its own B=32 shard.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, timed with HIP events on
+the launch stream inside the timed region; `cpu_baseline` times the CPU oracle (a restatement of
+the reference's PyTorch-CPU path) on this host for a bounded number of steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (reference batchsize=32)")
+    ap.add_argument("--seq", type=int, default=0, help="sequence length; 0 = read configs/mosi.json")
+    ap.add_argument("--shape", default="mosi", choices=["mosi", "you", "mosei"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=0)
+    ap.add_argument("--breakdown", action="store_true", help="also print a per-kernel time table to stderr")
+    args = ap.parse_args()
+
+    import torch
+    from factorized_amd import configs as C
+    from factorized_amd import engine, synth, train
+
+    rank, local_rank, world = train.dp_env()
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg_fn = {"mosi": C.canonical_configs, "you": C.you_configs, "mosei": C.mosei_configs}[args.shape]
+    cfgs = cfg_fn(dropout=True)
+    cfg = cfgs[0]
+    if args.seq:
+        T = args.seq
+    else:
+        _, T = C.load_json_config(os.path.join(ROOT, "configs", {"mosi": "mosi.json", "you": "you.json",
+                                                                 "mosei": "mosi.json"}[args.shape]))
+    B = args.batch
+
+    e = engine.MFMEngine(cfgs, device="cuda:%d" % local_rank)
+    e.load_weights(synth.make_weights(e.layout.shapes, seed=1234))
+    train.broadcast_params(e, world)
+    n_samples = max(1280, B * world * 8)          # MOSI-scale split (1,284 train utterances)
+    data = train.DeviceDataset(cfg, n_samples, T, B, e.device, seed=11)
+    my_batches = train.shard_batches(data.nb, rank, world)
+    stepper = train.DataParallelStep(e, world, lr=1e-3)
+
+    def run(n, first=0):
+        for i in range(n):
+            x, y = data.batch(my_batches[(first + i) % len(my_batches)])
+            stepper.step(x, y)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up (untimed) + a per-kernel breakdown pass (untimed) to find the dominant kernel
+    run(args.warmup)
+    barrier()
+    e.set_timing(T, B, (1 << 13) - 1)
+    run(10, args.warmup)
+    barrier()
+    table = e.collect_timing(T, B)
+    dom = max(table, key=lambda k: table[k]["ms"])
+    if args.breakdown and rank == 0:
+        tot = sum(v["ms"] for v in table.values()) / 10
+        for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
+            if v["count"]:
+                sys.stderr.write("%-14s %8.2f us/launch  %5.1f%%\n" % (k, 1e3 * v["ms"] / v["count"],
+                                                                      100 * v["ms"] / 10 / tot))
+    e.set_timing(T, B, 1 << table[dom]["kid"])
+
+    # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides, max over ranks
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup + 10)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    timed = e.collect_timing(T, B)[dom]
+    e.set_timing(T, B, 0)
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        value = B * world * args.steps / dt
+        k_ms = timed["ms"] / max(timed["count"], 1)
+        k_flops = timed["flops"]
+        achieved = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 and k_flops > 0 else 0.0
+        work = e.work_per_step(T, B)
+        out = {
+            "metric": "training samples/sec (MOSI-shape, T=%d, 3 modalities)" % T,
+            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": "MFM_KL_EF %s canonical sizes, per-GPU B=%d, T=%d, D=%d, train mode "
+                                   "(fwd + joint loss + bwd + Adam), fp32 HIP" % (args.shape, B, T, sum(cfg["input_dims"])),
+                       "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world,
+                       "params": e.layout.numel},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 4),
+                         "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 6), "traffic": None,
+                         "kernel_us": round(1e3 * k_ms, 2), "kernel_flops": k_flops,
+                         "step_flops": work["flops"], "step_bytes": work["bytes"],
+                         "step_tflops": round(work["flops"] / (ms * 1e-3) / 1e12, 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import mfm_oracle as O
+            import torch as _t
+            cores = os.cpu_count() or 1
+            steps = args.cpu_steps or 60
+            r = O.time_cpu_steps(cfgs, B, T, steps=steps, warmup=3, threads=cores)
+            out["cpu_baseline"] = {"value": round(r["samples_per_s"], 1), "unit": "samples/s", "cores": r["threads"],
+                                   "kind": "port", "ms_per_step": round(r["ms_per_step"], 2),
+                                   "sample": "%d training steps of the torch-CPU oracle (restated reference path: "
+                                             "per-timestep nn.LSTMCell loop, joint loss, optim.Adam), B=%d T=%d, "
+                                             "%d threads" % (steps, B, T, r["threads"])}
+            out["speedup_vs_cpu"] = round(value / r["samples_per_s"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,117 @@
+"""ctypes binding of libmfm_hip.so (the C ABI declared in include/mfm_hip.h).
+
+The HIP library is the product: there is NO CPU fallback.  Importing this module
+without the built library raises immediately with the build instruction.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmfm_hip.so")
+
+MFM_KLEF_NPARAM = 78
+MFM_LOSS_SLOTS = 8
+MFM_MAX_SEQ = 4
+
+
+class MfmError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("c2", C.c_void_p),
+                ("bias", C.c_void_p), ("bias2", C.c_void_p),
+                ("a_sz", C.c_int64), ("a_sm", C.c_int64), ("a_sk", C.c_int64),
+                ("b_sz", C.c_int64), ("b_sk", C.c_int64), ("b_sn", C.c_int64),
+                ("c_sz", C.c_int64), ("ldc", C.c_int64), ("bias_sz", C.c_int64),
+                ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("n_valid", C.c_int32),
+                ("batch", C.c_int32), ("split_k", C.c_int32), ("accumulate", C.c_int32),
+                ("alpha", C.c_float)]
+
+
+class SeqDesc(C.Structure):
+    _fields_ = [("gates", C.c_void_p), ("hs", C.c_void_p), ("cs", C.c_void_p),
+                ("w_hh", C.c_void_p), ("w_ih", C.c_void_p), ("b_ih", C.c_void_p), ("b_hh", C.c_void_p),
+                ("h_init", C.c_void_p), ("ld_init", C.c_int64),
+                ("dh_ext", C.c_void_p), ("ld_dh", C.c_int64),
+                ("d_h_init", C.c_void_p), ("ld_dinit", C.c_int64),
+                ("h", C.c_int32), ("is_dec", C.c_int32)]
+
+
+class PlanConfig(C.Structure):
+    _fields_ = [("d_l", C.c_int32), ("d_a", C.c_int32), ("d_v", C.c_int32),
+                ("zl", C.c_int32), ("za", C.c_int32), ("zv", C.c_int32), ("zy", C.c_int32),
+                ("fl", C.c_int32), ("fa", C.c_int32), ("fv", C.c_int32), ("fy", C.c_int32),
+                ("output_dim", C.c_int32), ("loss_kind", C.c_int32),
+                ("T", C.c_int32), ("B", C.c_int32),
+                ("lda_xl", C.c_float), ("lda_xa", C.c_float), ("lda_xv", C.c_float), ("lda_reg", C.c_float),
+                ("drop_zy", C.c_float), ("drop_zl", C.c_float), ("drop_za", C.c_float),
+                ("drop_zv", C.c_float), ("drop_y", C.c_float),
+                ("reg_scale", C.c_float)]
+
+
+_SIGS = {
+    "mfm_abi_version": (C.c_int, []),
+    "mfm_last_error": (C.c_char_p, []),
+    "mfm_device_cus": (C.c_int, []),
+    "mfm_gemm_grouped_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.c_void_p]),
+    "mfm_lstm_seq_fwd": (C.c_int, [C.POINTER(SeqDesc), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mfm_lstm_seq_bwd": (C.c_int, [C.POINTER(SeqDesc), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mfm_mse_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_float,
+                                  C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mfm_adam_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "mfm_plan_create": (C.c_int, [C.POINTER(PlanConfig), C.POINTER(C.c_int64), C.c_int64,
+                                  C.POINTER(C.c_void_p)]),
+    "mfm_plan_destroy": (None, [C.c_void_p]),
+    "mfm_plan_workspace_bytes": (C.c_int64, [C.c_void_p]),
+    "mfm_plan_init_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mfm_plan_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    "mfm_plan_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    "mfm_plan_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_float,
+                                      C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mfm_plan_flops_per_step": (C.c_double, [C.c_void_p]),
+    "mfm_plan_bytes_per_step": (C.c_double, [C.c_void_p]),
+    "mfm_plan_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "mfm_plan_num_kernels": (C.c_int, []),
+    "mfm_plan_kernel_name": (C.c_char_p, [C.c_int]),
+    "mfm_plan_collect_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "mfm_plan_kernel_flops": (C.c_double, [C.c_void_p, C.c_int]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MfmError(
+                "factorized_amd: %s is missing. Build the gfx950 HIP library first:\n"
+                "    python -c 'import __graft_entry__ as g; g.build()'   (or factorized_amd/csrc/build.sh)\n"
+                "There is no CPU fallback for this package." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)   # AttributeError if the ABI and the binding drift apart
+            fn.restype = res
+            fn.argtypes = args
+        if L.mfm_abi_version() != 1:
+            raise MfmError("libmfm_hip.so ABI version %d, binding expects 1" % L.mfm_abi_version())
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().mfm_last_error()
+        raise MfmError("%s failed (%d): %s" % (what or "libmfm_hip call", rc,
+                                               msg.decode() if msg else "?"))
+
+
+def exported_names():
+    return list(_SIGS)

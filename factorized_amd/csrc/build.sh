@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build libmfm_hip.so for gfx950 in-tree (cross-compiles without a GPU).
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+OUT="$HERE/../libmfm_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function ${MFM_EXTRA_FLAGS:-}"
+mkdir -p "$HERE/build"
+pids=()
+for f in gemm lstm_seq latent elementwise plan; do
+  ( $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/build/$f.o" ) &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$HERE"/build/*.o -o "$OUT"
+echo "built $OUT"

@@ -1,0 +1,81 @@
+// Shared device/host helpers for libmfm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "mfm_hip.h"
+
+namespace mfm {
+
+// ---------------------------------------------------------------- host-side error plumbing
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define MFM_HIP_CHECK(expr)                                   \
+  do {                                                        \
+    hipError_t _e = (expr);                                   \
+    if (_e != hipSuccess) return ::mfm::hip_fail(_e, #expr);  \
+  } while (0)
+
+#define MFM_LAUNCH_CHECK(name)                                \
+  do {                                                        \
+    hipError_t _e = hipGetLastError();                        \
+    if (_e != hipSuccess) return ::mfm::hip_fail(_e, name);   \
+  } while (0)
+
+#define MFM_REQUIRE(cond, ...)                                \
+  do {                                                        \
+    if (!(cond)) {                                            \
+      ::mfm::set_error(__VA_ARGS__);                          \
+      return MFM_ERR_ARG;                                     \
+    }                                                         \
+  } while (0)
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline int64_t round_up64(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- device helpers
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_16x16x4_f32: D = A[16x4] * B[4x16] + C, exact fp32 FMA chain (k ascending).
+// lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
+// result register r of lane l is D[row = (l>>4)*4 + r][col = l&15].
+__device__ __forceinline__ f32x4 mma16x16x4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+#ifndef MFM_FAST_ACT
+#define MFM_FAST_ACT 0
+#endif
+
+__device__ __forceinline__ float act_sigmoid(float x) {
+#if MFM_FAST_ACT
+  return __frcp_rn(1.0f + __expf(-x));
+#else
+  return 1.0f / (1.0f + expf(-x));
+#endif
+}
+__device__ __forceinline__ float act_tanh(float x) {
+#if MFM_FAST_ACT
+  // 2*sigmoid(2x)-1, abs error ~1e-7
+  return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f;
+#else
+  return tanhf(x);
+#endif
+}
+
+// Counter-based RNG for dropout masks: 2 rounds of a 64-bit mix (splitmix64 finaliser) over
+// (seed, call counter, element index) -> uniform in [0,1).  Not torch's Philox stream: dropout
+// parity with the CPU reference is statistical only.
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+}  // namespace mfm

@@ -1,0 +1,170 @@
+// HBM-bound helpers of the MFM step: reconstruction loss (+ its gradient), fused flat Adam, fill.
+#include <math.h>
+#include <stdarg.h>
+
+#include "internal.h"
+
+namespace mfm {
+
+// ---------------------------------------------------------------- error plumbing (host)
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int hip_fail(hipError_t e, const char* what) {
+  set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
+  return MFM_ERR_HIP;
+}
+
+// ---------------------------------------------------------------- block reduction
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over the block; result valid in thread 0.  `scratch` >= 16 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  float r = 0.0f;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += scratch[i];
+  }
+  __syncthreads();
+  return r;
+}
+
+// ---------------------------------------------------------------- MSE fwd+bwd (grouped)
+struct MseGroup { MseItem it[3]; int count; };
+
+__global__ __launch_bounds__(256) void mse_kernel(const MseGroup g) {
+  __shared__ float scratch[16];
+  int gi = 0;
+#pragma unroll 1
+  for (int i = 1; i < g.count; ++i)
+    if ((int)blockIdx.x >= g.it[i].block_begin) gi = i;
+  const MseItem& it = g.it[gi];
+  const int nblk = ((gi + 1 < g.count) ? g.it[gi + 1].block_begin : (int)gridDim.x) - it.block_begin;
+  const int64_t total = it.rows * it.d;
+  float part = 0.0f;
+  for (int64_t i = (int64_t)(blockIdx.x - it.block_begin) * 256 + threadIdx.x; i < total; i += (int64_t)nblk * 256) {
+    const int64_t r = i / it.d;
+    const int c = (int)(i - r * it.d);
+    const float diff = it.xhat[i] - it.x[r * it.ldx + c];
+    part += diff * diff;
+    if (it.dxhat) it.dxhat[i] = it.grad_scale * diff;
+  }
+  const float s = block_sum(part, scratch);
+  if (threadIdx.x == 0 && it.loss_slot) atomicAdd(it.loss_slot, s * it.inv_count);
+}
+
+int mse_group_launch(const MseItem* items, int count, hipStream_t stream) {
+  MseGroup g;
+  memset(&g, 0, sizeof(g));
+  g.count = count;
+  int total = 0;
+  for (int i = 0; i < count; ++i) {
+    g.it[i] = items[i];
+    g.it[i].block_begin = total;
+    int64_t n = items[i].rows * items[i].d;
+    int nb = (int)((n + 1023) / 1024);
+    if (nb < 1) nb = 1;
+    if (nb > 1024) nb = 1024;
+    total += nb;
+  }
+  hipLaunchKernelGGL(mse_kernel, dim3(total), dim3(256), 0, stream, g);
+  MFM_LAUNCH_CHECK("mse_kernel");
+  return MFM_OK;
+}
+
+// ---------------------------------------------------------------- Adam (flat)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   float beta1, float beta2, float eps, float step_size,
+                                                   float bc2_sqrt, float grad_scale) {
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gg = gv[j] * grad_scale;
+      mv[j] = mv[j] + (1.0f - beta1) * (gg - mv[j]);
+      vv[j] = vv[j] * beta2 + (1.0f - beta2) * gg * gg;
+      const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+      pv[j] = pv[j] - step_size * mv[j] / denom;
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gg = g[i] * grad_scale;
+    const float mm = m[i] + (1.0f - beta1) * (gg - m[i]);
+    const float vv = v[i] * beta2 + (1.0f - beta2) * gg * gg;
+    m[i] = mm; v[i] = vv;
+    p[i] = p[i] - step_size * mm / (sqrtf(vv) / bc2_sqrt + eps);
+  }
+}
+
+int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1,
+                float beta2, float eps, float grad_scale, hipStream_t stream) {
+  MFM_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam: bad arguments (n=%lld step=%d)", (long long)n, step);
+  MFM_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  int64_t nb = ((n >> 2) + 255) / 256;
+  if (nb < 1) nb = 1;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(adam_kernel, dim3((int)nb), dim3(256), 0, stream, p, g, m, v, n, beta1, beta2, eps, step_size,
+                     bc2_sqrt, grad_scale);
+  MFM_LAUNCH_CHECK("adam_kernel");
+  return MFM_OK;
+}
+
+// ---------------------------------------------------------------- fill
+__global__ void fill_kernel(float* p, int64_t n, float val) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = val;
+}
+int fill_launch(float* p, int64_t n, float val, hipStream_t stream) {
+  int nb = (int)((n + 255) / 256);
+  if (nb < 1) nb = 1;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(fill_kernel, dim3(nb), dim3(256), 0, stream, p, n, val);
+  MFM_LAUNCH_CHECK("fill_kernel");
+  return MFM_OK;
+}
+
+}  // namespace mfm
+
+extern "C" int mfm_abi_version(void) { return MFM_ABI_VERSION; }
+extern "C" const char* mfm_last_error(void) { return mfm::g_err; }
+
+extern "C" int mfm_mse_fwd_bwd(const float* xhat, const float* x, int64_t ldx, int64_t rows, int32_t d,
+                               float inv_count, float grad_scale, float* dxhat, float* loss_slot, void* stream) {
+  if (!xhat || !x || rows <= 0 || d <= 0) {
+    mfm::set_error("mfm_mse_fwd_bwd: bad arguments");
+    return MFM_ERR_ARG;
+  }
+  mfm::MseItem it;
+  memset(&it, 0, sizeof(it));
+  it.xhat = xhat; it.x = x; it.dxhat = dxhat; it.loss_slot = loss_slot;
+  it.ldx = ldx; it.rows = rows; it.d = d; it.inv_count = inv_count; it.grad_scale = grad_scale;
+  return mfm::mse_group_launch(&it, 1, (hipStream_t)stream);
+}
+
+extern "C" int mfm_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr,
+                             float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  return mfm::adam_launch(p, g, m, v, n, step, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream);
+}

@@ -1,0 +1,59 @@
+// Internal (non-ABI) declarations shared between the .hip translation units of libmfm_hip.so.
+#pragma once
+#include "common.h"
+
+namespace mfm {
+
+// gemm.hip
+int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream);
+int device_cus();
+
+// elementwise.hip
+struct MseItem {
+  const float* xhat; const float* x; float* dxhat; float* loss_slot;
+  int64_t ldx, rows; int d; float inv_count, grad_scale; int block_begin;
+};
+int mse_group_launch(const MseItem* items, int count, hipStream_t stream);
+int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1,
+                float beta2, float eps, float grad_scale, hipStream_t stream);
+int fill_launch(float* p, int64_t n, float val, hipStream_t stream);
+
+// latent.hip -- the fused "latent stack": encoder fc1 heads, mu/logvar heads, z->f MLPs,
+// classifier, KLD and discriminative loss, interpreted from a small op table.
+#define MFM_LAT_MAXOPS 24
+#define MFM_LAT_MAXSTAGES 8
+struct LatOp {
+  int in_off, out_off, K, N;   // record offsets (floats), fan-in, fan-out
+  int64_t w_off, b_off;        // element offsets of weight [N,K] / bias [N] in the flat param buffer
+  int relu;                    // relu on the output
+  int mask_off;                // record offset of the dropout mask (scale) segment, -1 = no dropout
+  float drop_p;
+  int stage;
+};
+struct LatentDev {
+  LatOp op[MFM_LAT_MAXOPS];
+  int nops, nstages;
+  int stage_begin[MFM_LAT_MAXSTAGES + 1];
+  int rec_size;                        // floats per batch row, multiple of 4
+  // inputs: last hidden state of the 4 encoders (l, a, v, fused)
+  const float* enc_h[4]; int64_t enc_ld[4]; int enc_n[4]; int in_off[4];
+  // latent segments (l, a, v, y)
+  int mu_off[4], lv_off[4], z_n[4];
+  int f_off[4], f_n[4];                // post-MLP features (l, a, v, y)
+  int yhat_off, od;
+  // decoder initial inputs [fy | f_m] (l, a, v) and their gradients
+  float* dec_init[3]; const float* d_dec_init[3]; int64_t dec_ld[3];
+  // gradient wrt the encoders' last hidden state
+  float* dh_last[4]; int64_t dh_ld[4];
+  float* rec;                          // [B, rec_size] saved record
+  float* yhat_out;                     // optional [B, od]
+  const void* y; int loss_kind;
+  float* losses;
+  int B, rows_per_wg, train, has_logvar;
+  uint64_t seed;
+  float reg_w, disc_w, gen_w;
+};
+int latent_fwd_launch(const LatentDev& L, const float* params, hipStream_t stream);
+int latent_bwd_launch(const LatentDev& L, const float* params, float* grads, hipStream_t stream);
+
+}  // namespace mfm

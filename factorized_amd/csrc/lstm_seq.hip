@@ -1,0 +1,400 @@
+// Whole-sequence LSTM recurrence, forward and BPTT, for gfx950.
+//
+// Design (MI355X-first, not a cell-at-a-time port of nn.LSTMCell):
+//   * batch rows are independent through the recurrence, so the unit of parallelism is a
+//     16-row batch tile: one persistent workgroup per (LSTM, tile) walks all T steps.  Several
+//     LSTMs (the 4 encoders, or the 3 decoders) share ONE launch; nothing is exchanged between
+//     workgroups, so there is no grid barrier and no inter-CU traffic.
+//   * wave w of the workgroup owns hidden units [16w, 16w+16) for all four gates.  Its slice
+//     of the recurrent weight matrix lives in VGPRs as MFMA A-operands for the whole kernel
+//     (fwd: W[g*h+u][k], 4*ceil(h/4) registers; bwd: W^T, same count) -- weights are read from
+//     HBM/L2 exactly once per launch, never per step.
+//   * gates^T[4h x 16] = W[4h x h] * h_{t-1}^T[h x 16] on v_mfma_f32_16x16x4_f32.  With this
+//     orientation the accumulator of lane l holds gates i,f,g,o of units 16w+4(l>>4)+{0..3}
+//     for batch row l&15: the LSTM pointwise math is lane-local and the cell state c stays in
+//     registers across all steps.  Only h_t crosses waves, through a double-buffered LDS
+//     panel laid out [unit][16 rows] so the B-operand read is lds[64*kk + lane] (linear,
+//     conflict-free) and one barrier per step suffices.
+//   * backward mirrors it: dA_t (pre-activation gate grads) are lane-local, exchanged through
+//     LDS as [gate*HK+unit][16 rows], and dh_{t-1}^T = W^T * dA_t^T runs on the same MFMA with
+//     four independent accumulator chains.  dA overwrites the saved gates in place; the weight
+//     gradients are batched GEMMs over dA afterwards (plan.hip).
+#include <type_traits>
+
+#include "common.h"
+
+namespace mfm {
+
+struct SeqDev {
+  float* gates; float* hs; float* cs;
+  const float* w_hh; const float* w_ih; const float* b_ih; const float* b_hh;
+  const float* h_init; int64_t ld_init;
+  const float* dh_ext; int64_t ld_dh;
+  float* d_h_init; int64_t ld_dinit;
+  int h, Hp, hk4, is_dec, block_begin;
+};
+struct SeqLaunch {
+  SeqDev d[MFM_MAX_SEQ];
+  int count, T, B;
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// --------------------------------------------------------------------------------- forward
+template <int HK4>
+__device__ __forceinline__ void seq_fwd_body(const SeqDev& d, const int T, const int B, const int tile,
+                                             float* lds) {
+  constexpr int HK = HK4 * 4;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int bi = lane & 15, q = lane >> 4;
+  const int h = d.h, Hp = d.Hp;
+  const bool active = wave < (Hp >> 4);
+  const int u0 = wave * 16;
+  const int b = tile * 16 + bi;
+  const bool bvalid = active && (b < B);
+  const bool dec = d.is_dec != 0;
+
+  float w[4][HK4];
+  // Branch-free weight fetch (pad elements read element 0 and are multiplied by 0).
+  // MODE 0: W_hh (encoder)   1: W_ih (decoder step 0)   2: W_ih + W_hh (decoder steps >= 1)
+  auto load_w = [&](auto mode, int zofs) {
+    constexpr int MODE = decltype(mode)::value;
+    const int unit = u0 + bi;
+    const int uc = min(unit, h - 1);
+    const int uok = (int)active & (int)(unit < h);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int kk = 0; kk < HK4; ++kk) {
+        const int k = 4 * kk + q;
+        const int off = (g * h + uc) * h + min(k, h - 1) + zofs;   // always a valid address
+        const float m = (float)(uok & (int)(k < h));            // 0 for pad elements
+        float v;
+        if constexpr (MODE == 0) v = d.w_hh[off];
+        else if constexpr (MODE == 1) v = d.w_ih[off];
+        else v = d.w_ih[off] + d.w_hh[off];
+        w[g][kk] = v * m;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (dec) load_w(std::integral_constant<int, 1>{}, 0); else load_w(std::integral_constant<int, 0>{}, 0);
+
+  f32x4 bias[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bias[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (dec && active) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int unit = u0 + 4 * q + r;
+        if (unit < h) bias[g][r] = d.b_ih[g * h + unit] + d.b_hh[g * h + unit];
+      }
+    }
+  }
+
+  float* hbuf = lds;  // [2][HK*16]
+  if (dec) {
+    for (int idx = tid; idx < HK * 16; idx += blockDim.x) {
+      const int unit = idx >> 4, br = tile * 16 + (idx & 15);
+      hbuf[idx] = (unit < h && br < B) ? d.h_init[(int64_t)br * d.ld_init + unit] : 0.0f;
+    }
+    __syncthreads();
+  }
+
+  const int64_t row4 = 4 * (int64_t)Hp;
+  f32x4 gx[4];
+  if (!dec) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      gx[g] = bvalid ? ld4(d.gates + ((int64_t)b) * row4 + g * Hp + u0 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  int cur = 0;
+  for (int t = 0; t < T; ++t) {
+    f32x4 acc[4];
+    const int64_t rowt = (int64_t)t * B + b;
+    if (dec) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = bias[g];
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = gx[g];
+      if (t + 1 < T && bvalid) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gx[g] = ld4(d.gates + (rowt + B) * row4 + g * Hp + u0 + 4 * q);
+      }
+    }
+    if (active && (dec || t > 0)) {
+      const float* hb = hbuf + cur * (HK * 16) + lane;
+#pragma unroll
+      for (int kk = 0; kk < HK4; ++kk) {
+        const float hv = hb[64 * kk];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = mma16x16x4(w[g][kk], hv, acc[g]);
+      }
+    }
+    if (dec && t == 0 && T > 1) {
+      // opaque zero: keeps LICM from hoisting 4*HK4 loop-invariant addresses (and their spills)
+      // out of the time loop
+      int z = 0;
+      asm volatile("" : "+v"(z));
+      load_w(std::integral_constant<int, 2>{}, z);
+    }
+    if (active) {
+      f32x4 gi, gf, gg, go, cv, hv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        gi[r] = act_sigmoid(acc[0][r]);
+        gf[r] = act_sigmoid(acc[1][r]);
+        gg[r] = act_tanh(acc[2][r]);
+        go[r] = act_sigmoid(acc[3][r]);
+        c[r] = gf[r] * c[r] + gi[r] * gg[r];
+        cv[r] = c[r];
+        hv[r] = go[r] * act_tanh(c[r]);
+      }
+      if (bvalid) {
+        float* gp = d.gates + rowt * row4 + u0 + 4 * q;
+        st4(gp, gi); st4(gp + Hp, gf); st4(gp + 2 * Hp, gg); st4(gp + 3 * Hp, go);
+        st4(d.cs + rowt * Hp + u0 + 4 * q, cv);
+        st4(d.hs + rowt * Hp + u0 + 4 * q, hv);
+      }
+      float* hn = hbuf + (cur ^ 1) * (HK * 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int unit = u0 + 4 * q + r;
+        if (unit < HK) hn[unit * 16 + bi] = (b < B) ? hv[r] : 0.0f;
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+// --------------------------------------------------------------------------------- backward
+template <int HK4>
+__device__ __forceinline__ void seq_bwd_body(const SeqDev& d, const int T, const int B, const int tile,
+                                             float* lds) {
+  constexpr int HK = HK4 * 4;   // padded hidden extent; reduction runs over 4*HK gate columns
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int bi = lane & 15, q = lane >> 4;
+  const int h = d.h, Hp = d.Hp;
+  const bool active = wave < (Hp >> 4);
+  const int u0 = wave * 16;
+  const int b = tile * 16 + bi;
+  const bool bvalid = active && (b < B);
+  const bool dec = d.is_dec != 0;
+
+  float wT[HK];
+  auto load_wT = [&](auto mode, int zofs) {
+    constexpr int MODE = decltype(mode)::value;
+    const int unit = u0 + bi;   // A row = output unit of dh
+    const int uc = min(unit, h - 1);
+    const int uok = (int)active & (int)(unit < h);
+#pragma unroll
+    for (int kk = 0; kk < HK; ++kk) {
+      const int k = 4 * kk + q;           // gate column in the [4][HK] padded numbering
+      const int g = k / HK, up = k % HK;
+      const int off = (g * h + min(up, h - 1)) * h + uc + zofs;   // always a valid address
+      const float m = (float)(uok & (int)(up < h));
+      float v;
+      if constexpr (MODE == 0) v = d.w_hh[off];
+      else if constexpr (MODE == 1) v = d.w_ih[off];
+      else v = d.w_ih[off] + d.w_hh[off];
+      wT[kk] = v * m;
+      if ((kk & 15) == 15) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (dec) load_wT(std::integral_constant<int, 2>{}, 0); else load_wT(std::integral_constant<int, 0>{}, 0);
+
+  float* dabuf = lds;  // [2][4*HK*16]
+  const int64_t row4 = 4 * (int64_t)Hp;
+  f32x4 dh_rec = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dc[4] = {0.f, 0.f, 0.f, 0.f};
+  int cur = 0;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int t = T - 1; t >= 0; --t) {
+    const int64_t rowt = (int64_t)t * B + b;
+    f32x4 dh = dh_rec;
+    if (bvalid) {
+      if (dec) {
+        const f32x4 e = ld4(d.dh_ext + rowt * Hp + u0 + 4 * q);
+        dh += e;
+      } else if (t == T - 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int unit = u0 + 4 * q + r;
+          if (unit < h) dh[r] += d.dh_ext[(int64_t)b * d.ld_dh + unit];
+        }
+      }
+    }
+    f32x4 gi = zero4, gf = zero4, gg = zero4, go = zero4, ct = zero4, cp = zero4;
+    float* gp = d.gates + rowt * row4 + u0 + 4 * q;
+    if (bvalid) {
+      gi = ld4(gp); gf = ld4(gp + Hp); gg = ld4(gp + 2 * Hp); go = ld4(gp + 3 * Hp);
+      ct = ld4(d.cs + rowt * Hp + u0 + 4 * q);
+      if (t > 0) cp = ld4(d.cs + (rowt - B) * Hp + u0 + 4 * q);
+    }
+    f32x4 dai, daf, dag, dao;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float tc = act_tanh(ct[r]);
+      const float dot = dh[r] * tc;
+      const float dct = dh[r] * go[r] * (1.0f - tc * tc) + dc[r];
+      dai[r] = dct * gg[r] * gi[r] * (1.0f - gi[r]);
+      daf[r] = dct * cp[r] * gf[r] * (1.0f - gf[r]);
+      dag[r] = dct * gi[r] * (1.0f - gg[r] * gg[r]);
+      dao[r] = dot * go[r] * (1.0f - go[r]);
+      dc[r] = dct * gf[r];
+    }
+    if (bvalid) { st4(gp, dai); st4(gp + Hp, daf); st4(gp + 2 * Hp, dag); st4(gp + 3 * Hp, dao); }
+
+    const bool need_rec = (t > 0) || dec;
+    if (need_rec) {
+      float* db = dabuf + cur * (4 * HK * 16);
+      if (active) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int up = u0 + 4 * q + r;
+          if (up < HK) {
+            db[(0 * HK + up) * 16 + bi] = dai[r];
+            db[(1 * HK + up) * 16 + bi] = daf[r];
+            db[(2 * HK + up) * 16 + bi] = dag[r];
+            db[(3 * HK + up) * 16 + bi] = dao[r];
+          }
+        }
+      }
+      __syncthreads();
+      if (dec && t == 0) {   // grad wrt the step-0 input goes through W_ih only
+        int z = 0;
+        asm volatile("" : "+v"(z));   // opaque zero: no LICM of the reload's addresses
+        load_wT(std::integral_constant<int, 1>{}, z);
+      }
+      f32x4 a0 = zero4, a1 = zero4, a2 = zero4, a3 = zero4;
+      if (active) {
+        const float* dp = db + lane;
+#pragma unroll
+        for (int kk = 0; kk < HK; kk += 8) {
+          // 8 LDS reads, 8 MFMAs, then a scheduling fence: keeps the compiler from hoisting all
+          // HK operand reads above the MFMA chain (which spills the resident weights).
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = dp[64 * (kk + j)];
+          a0 = mma16x16x4(wT[kk + 0], v[0], a0);
+          a1 = mma16x16x4(wT[kk + 1], v[1], a1);
+          a2 = mma16x16x4(wT[kk + 2], v[2], a2);
+          a3 = mma16x16x4(wT[kk + 3], v[3], a3);
+          a0 = mma16x16x4(wT[kk + 4], v[4], a0);
+          a1 = mma16x16x4(wT[kk + 5], v[5], a1);
+          a2 = mma16x16x4(wT[kk + 6], v[6], a2);
+          a3 = mma16x16x4(wT[kk + 7], v[7], a3);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      dh_rec = (a0 + a1) + (a2 + a3);
+      cur ^= 1;
+    }
+  }
+  if (dec && bvalid && d.d_h_init) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int unit = u0 + 4 * q + r;
+      if (unit < h) d.d_h_init[(int64_t)b * d.ld_dinit + unit] = dh_rec[r];
+    }
+  }
+}
+
+#define MFM_SEQ_CASES(BODY)                                                                  \
+  switch (d.hk4) {                                                                           \
+    case 2: BODY<2>(d, L.T, L.B, tile, lds); break;                                          \
+    case 4: BODY<4>(d, L.T, L.B, tile, lds); break;                                          \
+    case 6: BODY<6>(d, L.T, L.B, tile, lds); break;                                          \
+    case 8: BODY<8>(d, L.T, L.B, tile, lds); break;                                          \
+    case 10: BODY<10>(d, L.T, L.B, tile, lds); break;                                        \
+    case 12: BODY<12>(d, L.T, L.B, tile, lds); break;                                        \
+    case 14: BODY<14>(d, L.T, L.B, tile, lds); break;                                        \
+    case 16: BODY<16>(d, L.T, L.B, tile, lds); break;                                        \
+    case 18: BODY<18>(d, L.T, L.B, tile, lds); break;                                        \
+    case 20: BODY<20>(d, L.T, L.B, tile, lds); break;                                        \
+    case 22: BODY<22>(d, L.T, L.B, tile, lds); break;                                        \
+    case 24: BODY<24>(d, L.T, L.B, tile, lds); break;                                        \
+    case 26: BODY<26>(d, L.T, L.B, tile, lds); break;                                        \
+    case 28: BODY<28>(d, L.T, L.B, tile, lds); break;                                        \
+    case 30: BODY<30>(d, L.T, L.B, tile, lds); break;                                        \
+    case 32: BODY<32>(d, L.T, L.B, tile, lds); break;                                        \
+    default: break;                                                                          \
+  }
+
+template <bool BWD>
+__global__ __launch_bounds__(512) void lstm_seq_kernel(const SeqLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int di = 0;
+  const int bid = blockIdx.x;
+#pragma unroll 1
+  for (int i = 1; i < L.count; ++i)
+    if (bid >= L.d[i].block_begin) di = i;
+  const SeqDev& d = L.d[di];
+  const int tile = bid - d.block_begin;
+  if (BWD) {
+    MFM_SEQ_CASES(seq_bwd_body)
+  } else {
+    MFM_SEQ_CASES(seq_fwd_body)
+  }
+}
+
+static int seq_launch(const MfmSeqDesc* descs, int count, int T, int B, bool bwd, hipStream_t stream) {
+  MFM_REQUIRE(descs && count >= 1 && count <= MFM_MAX_SEQ, "lstm_seq: count %d out of range", count);
+  MFM_REQUIRE(T >= 1 && B >= 1, "lstm_seq: T=%d B=%d", T, B);
+  SeqLaunch L;
+  memset(&L, 0, sizeof(L));
+  L.count = count; L.T = T; L.B = B;
+  const int tiles = cdiv(B, 16);
+  int total = 0, max_waves = 1;
+  size_t lds_bytes = 0;
+  for (int i = 0; i < count; ++i) {
+    const MfmSeqDesc& s = descs[i];
+    MFM_REQUIRE(s.h >= 1, "lstm_seq[%d]: h=%d", i, s.h);
+    if (s.h > 128) {
+      set_error("lstm_seq[%d]: hidden size %d > 128 not supported by the register-resident kernel yet", i, s.h);
+      return MFM_ERR_UNSUPPORTED;
+    }
+    MFM_REQUIRE(s.gates && s.hs && s.cs && s.w_hh, "lstm_seq[%d]: null buffer", i);
+    if (s.is_dec) MFM_REQUIRE(s.w_ih && s.b_ih && s.b_hh && s.h_init, "lstm_seq[%d]: decoder needs w_ih/b/h_init", i);
+    if (bwd) MFM_REQUIRE(s.dh_ext, "lstm_seq_bwd[%d]: dh_ext is null", i);
+    SeqDev& d = L.d[i];
+    d.gates = s.gates; d.hs = s.hs; d.cs = s.cs;
+    d.w_hh = s.w_hh; d.w_ih = s.w_ih; d.b_ih = s.b_ih; d.b_hh = s.b_hh;
+    d.h_init = s.h_init; d.ld_init = s.ld_init;
+    d.dh_ext = s.dh_ext; d.ld_dh = s.ld_dh;
+    d.d_h_init = s.d_h_init; d.ld_dinit = s.ld_dinit;
+    d.h = s.h; d.Hp = round_up(s.h, 16);
+    d.hk4 = round_up(cdiv(s.h, 4), 2);
+    d.is_dec = s.is_dec;
+    d.block_begin = total;
+    total += tiles;
+    if (d.Hp / 16 > max_waves) max_waves = d.Hp / 16;
+    const size_t HK = (size_t)d.hk4 * 4;
+    const size_t need = (bwd ? 2 * 4 * HK * 16 : 2 * HK * 16) * sizeof(float);
+    if (need > lds_bytes) lds_bytes = need;
+  }
+  if (bwd)
+    hipLaunchKernelGGL(lstm_seq_kernel<true>, dim3(total), dim3(64 * max_waves), lds_bytes, stream, L);
+  else
+    hipLaunchKernelGGL(lstm_seq_kernel<false>, dim3(total), dim3(64 * max_waves), lds_bytes, stream, L);
+  MFM_LAUNCH_CHECK(bwd ? "lstm_seq_bwd_kernel" : "lstm_seq_fwd_kernel");
+  return MFM_OK;
+}
+
+}  // namespace mfm
+
+extern "C" int mfm_lstm_seq_fwd(const MfmSeqDesc* descs, int count, int T, int B, void* stream) {
+  return mfm::seq_launch(descs, count, T, B, false, (hipStream_t)stream);
+}
+extern "C" int mfm_lstm_seq_bwd(const MfmSeqDesc* descs, int count, int T, int B, void* stream) {
+  return mfm::seq_launch(descs, count, T, B, true, (hipStream_t)stream);
+}

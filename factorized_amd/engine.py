@@ -1,0 +1,319 @@
+"""Host side of the fused MFM_KL_EF step.
+
+`MFMEngine` owns ONE flat fp32 parameter buffer (every tensor of the reference
+model's `state_dict()` is a view into it, in the reference's order, each start
+padded to 64 floats so kernels can use 16-byte loads), the matching gradient /
+Adam-moment buffers, and per-(T,B) plans + workspaces of libmfm_hip.so.  One
+Python call = one C call = the whole forward/backward/Adam chain enqueued on the
+current HIP stream (reference: MFM_KL_EF.forward mfm_model.py:619-660 plus the
+hot loop mfm_mosi.py:424-442).
+
+PyTorch is used for device memory, streams and torch.distributed only.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ALIGN = 64  # floats
+
+
+def klef_param_shapes(cfg):
+    """Ordered name -> shape of MFM_KL_EF's 78 parameters (reference mfm_model.py:579-617)."""
+    d_l, d_a, d_v = cfg["input_dims"]
+    zl, za, zv, zy = cfg["zl_size"], cfg["za_size"], cfg["zv_size"], cfg["zy_size"]
+    fl, fa, fv, fy = cfg["fl_size"], cfg["fa_size"], cfg["fv_size"], cfg["fy_size"]
+    od = cfg["output_dim"]
+    s = OrderedDict()
+
+    def lstm(prefix, d, h, out):
+        s[prefix + ".lstm.weight_ih"] = (4 * h, d)
+        s[prefix + ".lstm.weight_hh"] = (4 * h, h)
+        s[prefix + ".lstm.bias_ih"] = (4 * h,)
+        s[prefix + ".lstm.bias_hh"] = (4 * h,)
+        s[prefix + ".fc1.weight"] = (out, h)
+        s[prefix + ".fc1.bias"] = (out,)
+
+    def lin(name, i, o):
+        s[name + ".weight"] = (o, i)
+        s[name + ".bias"] = (o,)
+
+    lstm("encoder_l", d_l, zl, zl)
+    lstm("encoder_a", d_a, za, za)
+    lstm("encoder_v", d_v, zv, zv)
+    lstm("decoder_l", fy + fl, fy + fl, d_l)
+    lstm("decoder_a", fy + fa, fy + fa, d_a)
+    lstm("decoder_v", fy + fv, fy + fv, d_v)
+    ze = zl + za + zv
+    lstm("ef_encoder", d_l + d_a + d_v, ze, ze)
+    lin("last_to_zy_fc1", ze, zy)
+    lin("last_to_logvarzy_fc1", ze, zy)
+    lin("last_to_zl_fc1", zl, zl)
+    lin("last_to_za_fc1", za, za)
+    lin("last_to_zv_fc1", zv, zv)
+    lin("last_to_logvarzl_fc1", zl, zl)
+    lin("last_to_logvarza_fc1", za, za)
+    lin("last_to_logvarzv_fc1", zv, zv)
+    for tag, zi, fo in (("zy_to_fy", zy, fy), ("zl_to_fl", zl, fl), ("za_to_fa", za, fa), ("zv_to_fv", zv, fv)):
+        lin(tag + "_fc1", zi, fo)
+        lin(tag + "_fc2", fo, fo)
+    lin("fy_to_y_fc1", fy, fy)
+    lin("fy_to_y_fc2", fy, od)
+    assert len(s) == _lib.MFM_KLEF_NPARAM
+    return s
+
+
+class FlatLayout:
+    def __init__(self, shapes):
+        self.shapes = OrderedDict(shapes)
+        self.offsets = OrderedDict()
+        cur = 0
+        for name, shp in self.shapes.items():
+            self.offsets[name] = cur
+            n = int(np.prod(shp))
+            cur = (cur + n + ALIGN - 1) // ALIGN * ALIGN
+        self.total = cur
+        self.numel = sum(int(np.prod(s)) for s in self.shapes.values())
+
+    def views(self, flat):
+        out = OrderedDict()
+        for name, shp in self.shapes.items():
+            o = self.offsets[name]
+            out[name] = flat[o:o + int(np.prod(shp))].view(*shp)
+        return out
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Plan:
+    def __init__(self, engine, T, B, reg_scale):
+        cfg = engine.cfg
+        pc = _lib.PlanConfig()
+        pc.d_l, pc.d_a, pc.d_v = cfg["input_dims"]
+        pc.zl, pc.za, pc.zv, pc.zy = cfg["zl_size"], cfg["za_size"], cfg["zv_size"], cfg["zy_size"]
+        pc.fl, pc.fa, pc.fv, pc.fy = cfg["fl_size"], cfg["fa_size"], cfg["fv_size"], cfg["fy_size"]
+        pc.output_dim = cfg["output_dim"]
+        pc.loss_kind = 1 if cfg.get("loss", "l1") == "ce" else 0
+        pc.T, pc.B = T, B
+        pc.lda_xl, pc.lda_xa, pc.lda_xv = cfg["lda_xl"], cfg["lda_xa"], cfg["lda_xv"]
+        pc.lda_reg = cfg["lda_mmd"]
+        pc.drop_zy, pc.drop_zl = cfg["zy_to_fy_dropout"], cfg["zl_to_fl_dropout"]
+        pc.drop_za, pc.drop_zv = cfg["za_to_fa_dropout"], cfg["zv_to_fv_dropout"]
+        pc.drop_y = cfg["fy_to_y_dropout"]
+        pc.reg_scale = reg_scale
+        offs = (C.c_int64 * _lib.MFM_KLEF_NPARAM)(*engine.layout.offsets.values())
+        handle = C.c_void_p(0)
+        _lib.check(_lib.lib().mfm_plan_create(C.byref(pc), offs, engine.layout.total, C.byref(handle)),
+                   "mfm_plan_create")
+        self.handle = handle
+        self.T, self.B = T, B
+        nbytes = _lib.lib().mfm_plan_workspace_bytes(handle)
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=engine.device)
+        _lib.check(_lib.lib().mfm_plan_init_workspace(handle, _ptr(self.workspace), _stream()),
+                   "mfm_plan_init_workspace")
+        self.losses = torch.zeros(_lib.MFM_LOSS_SLOTS, dtype=torch.float32, device=engine.device)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().mfm_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class MFMEngine:
+    """Fused MFM_KL_EF on one MI355X.  `configs` is the reference's six-dict list."""
+
+    def __init__(self, configs, device="cuda", reg_scale=1.0):
+        if not torch.cuda.is_available():
+            raise _lib.MfmError("MFMEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                "there is no CPU fallback")
+        _lib.lib()
+        self.configs = configs
+        self.cfg = configs[0]
+        self.device = torch.device(device)
+        self.layout = FlatLayout(klef_param_shapes(self.cfg))
+        n = self.layout.total
+        self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.adam_m = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.adam_v = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.step_count = 0
+        self.reg_scale = float(reg_scale)
+        self.seed = 1234
+        self._plans = {}
+
+    # ------------------------------------------------------------------ parameters
+    def param_views(self):
+        return self.layout.views(self.params)
+
+    def grad_views(self):
+        return self.layout.views(self.grads)
+
+    def load_weights(self, weights):
+        """weights: ordered mapping name -> ndarray/tensor with the reference's state_dict keys."""
+        assert list(weights.keys()) == list(self.layout.shapes.keys()), "state_dict keys differ"
+        host = np.zeros(self.layout.total, dtype=np.float32)
+        for name, w in weights.items():
+            a = w.detach().cpu().numpy() if isinstance(w, torch.Tensor) else np.asarray(w)
+            assert tuple(a.shape) == tuple(self.layout.shapes[name]), name
+            o = self.layout.offsets[name]
+            host[o:o + a.size] = a.ravel()
+        self.params.copy_(torch.from_numpy(host))
+        self.adam_m.zero_(); self.adam_v.zero_(); self.step_count = 0
+
+    def state_dict(self):
+        return OrderedDict((k, v.detach().clone()) for k, v in self.param_views().items())
+
+    # ------------------------------------------------------------------ plans
+    def plan(self, T, B):
+        key = (int(T), int(B), self.reg_scale)
+        p = self._plans.get(key)
+        if p is None:
+            p = _Plan(self, int(T), int(B), self.reg_scale)
+            self._plans[key] = p
+        return p
+
+    def _check_inputs(self, x, y):
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
+        assert x.shape[2] == sum(self.cfg["input_dims"])
+        if y is not None:
+            assert y.is_cuda and y.is_contiguous() and y.shape[0] == x.shape[1]
+            want = torch.int64 if self.cfg.get("loss", "l1") == "ce" else torch.float32
+            assert y.dtype == want, "labels must be %s" % want
+
+    # ------------------------------------------------------------------ the three entry points
+    def forward(self, x, y=None, train=False, want_xhat=True):
+        """x [T,B,D] -> dict(x_l_hat, x_a_hat, x_v_hat, y_hat, losses[8] (device tensor))."""
+        self._check_inputs(x, y)
+        T, B, _ = x.shape
+        p = self.plan(T, B)
+        d_l, d_a, d_v = self.cfg["input_dims"]
+        out = {}
+        xh = [None, None, None]
+        if want_xhat:
+            xh = [torch.empty(T, B, d, dtype=torch.float32, device=self.device) for d in (d_l, d_a, d_v)]
+        y_hat = torch.empty(B, self.cfg["output_dim"], dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().mfm_plan_forward(p.handle, _ptr(self.params), _ptr(x), _ptr(y), int(bool(train)),
+                                               C.c_uint64(self.seed), _ptr(p.workspace), _ptr(xh[0]), _ptr(xh[1]),
+                                               _ptr(xh[2]), _ptr(y_hat), _ptr(p.losses), _stream()),
+                   "mfm_plan_forward")
+        out["x_l_hat"], out["x_a_hat"], out["x_v_hat"] = xh
+        out["y_hat"] = y_hat
+        out["losses"] = p.losses
+        return out
+
+    def backward(self, x, y, stage=0):
+        """Backward of the last forward() with the same (T,B); fills self.grads."""
+        self._check_inputs(x, y)
+        T, B, _ = x.shape
+        p = self.plan(T, B)
+        _lib.check(_lib.lib().mfm_plan_backward(p.handle, _ptr(self.params), _ptr(x), _ptr(y), int(stage),
+                                                _ptr(p.workspace), _ptr(self.grads), _stream()),
+                   "mfm_plan_backward")
+        return self.grads
+
+    def train_step(self, x, y, lr=1e-3, grad_scale=1.0, check=True):
+        """forward(train) + backward(joint loss) + Adam, one enqueue.  Returns the device
+        tensor of loss slots (no sync)."""
+        if check:
+            self._check_inputs(x, y)
+        T, B, _ = x.shape
+        p = self.plan(T, B)
+        self.step_count += 1
+        _lib.check(_lib.lib().mfm_plan_train_step(p.handle, _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m),
+                                                  _ptr(self.adam_v), _ptr(x), _ptr(y), C.c_uint64(self.seed),
+                                                  self.step_count, lr, grad_scale, _ptr(p.workspace),
+                                                  _ptr(p.losses), _stream()),
+                   "mfm_plan_train_step")
+        return p.losses
+
+    def adam(self, lr=1e-3, grad_scale=1.0):
+        self.step_count += 1
+        _lib.check(_lib.lib().mfm_adam_flat(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m),
+                                            _ptr(self.adam_v), self.layout.total, self.step_count, lr,
+                                            0.9, 0.999, 1e-8, grad_scale, _stream()), "mfm_adam_flat")
+
+    def loss_dict(self, losses):
+        """Host view of the loss slots (synchronises)."""
+        l = losses.detach().cpu().numpy()
+        c = self.cfg
+        gen = c["lda_xl"] * l[1] + c["lda_xa"] * l[2] + c["lda_xv"] * l[3]
+        return dict(disc=float(l[0]), gen_l=float(l[1]), gen_a=float(l[2]), gen_v=float(l[3]), gen=float(gen),
+                    reg=float(l[4]), loss=float(l[0] + gen + c["lda_mmd"] * l[4]))
+
+    # ------------------------------------------------------------------ timing (bench.py)
+    def set_timing(self, T, B, mask):
+        _lib.check(_lib.lib().mfm_plan_set_timing(self.plan(T, B).handle, int(mask)), "mfm_plan_set_timing")
+
+    def collect_timing(self, T, B):
+        L = _lib.lib()
+        n = L.mfm_plan_num_kernels()
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        p = self.plan(T, B)
+        _lib.check(L.mfm_plan_collect_timing(p.handle, ms, cnt), "mfm_plan_collect_timing")
+        return {L.mfm_plan_kernel_name(i).decode(): dict(ms=ms[i], count=cnt[i], kid=i,
+                                                         flops=L.mfm_plan_kernel_flops(p.handle, i))
+                for i in range(n)}
+
+    def work_per_step(self, T, B):
+        p = self.plan(T, B)
+        return dict(flops=_lib.lib().mfm_plan_flops_per_step(p.handle),
+                    bytes=_lib.lib().mfm_plan_bytes_per_step(p.handle))
+
+
+# ---------------------------------------------------------------------- granular ops (tests, module path)
+def gemm_grouped(descs):
+    arr = (_lib.GemmDesc * len(descs))(*descs)
+    _lib.check(_lib.lib().mfm_gemm_grouped_f32(arr, len(descs), _stream()), "mfm_gemm_grouped_f32")
+
+
+def make_gemm(a, b, c, m, n, k, a_sm, a_sk, b_sk, b_sn, ldc, bias=None, bias2=None, n_valid=None, batch=1,
+              a_sz=0, b_sz=0, c_sz=0, bias_sz=0, accumulate=0, split_k=1, alpha=1.0, c2=None):
+    d = _lib.GemmDesc()
+    d.a, d.b, d.c = a.data_ptr(), b.data_ptr(), c.data_ptr()
+    d.c2 = c2.data_ptr() if c2 is not None else None
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.bias2 = bias2.data_ptr() if bias2 is not None else None
+    d.a_sz, d.a_sm, d.a_sk = a_sz, a_sm, a_sk
+    d.b_sz, d.b_sk, d.b_sn = b_sz, b_sk, b_sn
+    d.c_sz, d.ldc, d.bias_sz = c_sz, ldc, bias_sz
+    d.m, d.n, d.k = m, n, k
+    d.n_valid = n if n_valid is None else n_valid
+    d.batch, d.split_k, d.accumulate, d.alpha = batch, split_k, accumulate, alpha
+    return d
+
+
+def make_seq(gates, hs, cs, w_hh, h, w_ih=None, b_ih=None, b_hh=None, h_init=None, is_dec=False,
+             dh_ext=None, ld_dh=0, d_h_init=None):
+    d = _lib.SeqDesc()
+    d.gates, d.hs, d.cs = gates.data_ptr(), hs.data_ptr(), cs.data_ptr()
+    d.w_hh = w_hh.data_ptr()
+    d.w_ih = w_ih.data_ptr() if w_ih is not None else None
+    d.b_ih = b_ih.data_ptr() if b_ih is not None else None
+    d.b_hh = b_hh.data_ptr() if b_hh is not None else None
+    if h_init is not None:
+        d.h_init, d.ld_init = h_init.data_ptr(), h_init.stride(0)
+    if dh_ext is not None:
+        d.dh_ext, d.ld_dh = dh_ext.data_ptr(), ld_dh
+    if d_h_init is not None:
+        d.d_h_init, d.ld_dinit = d_h_init.data_ptr(), d_h_init.stride(0)
+    d.h, d.is_dec = h, int(is_dec)
+    return d
+
+
+def lstm_seq(descs, T, B, backward=False):
+    arr = (_lib.SeqDesc * len(descs))(*descs)
+    fn = _lib.lib().mfm_lstm_seq_bwd if backward else _lib.lib().mfm_lstm_seq_fwd
+    _lib.check(fn(arr, len(descs), T, B, _stream()), "mfm_lstm_seq_bwd" if backward else "mfm_lstm_seq_fwd")

@@ -1,0 +1,75 @@
+"""Training-loop pieces around MFMEngine: device-resident batching, the data-parallel step and
+the reference's epoch loop (train_mfm, reference mfm_mosi.py:386-503) restated for Python 3.
+
+Data parallelism (the reference has none): one process per GPU, each rank
+draws its own B-sample shard, ONE all-reduce of the flat gradient buffer per step over RCCL/xGMI.
+The joint loss mixes batch-MEAN terms (L1/CE, MSE) with a batch-SUM term (KLD, mfm_model.py:37),
+so to equal a single-process step at the global batch W*B each rank back-propagates
+`mean-terms + W * KLD` (reg_scale = W inside the plan) and the summed gradients are divided by W
+(grad_scale = 1/W inside the fused Adam).  tests/test_dp_gloo.py checks that algebra on CPU.
+"""
+import numpy as np
+import torch
+
+from . import synth
+
+
+def dp_env():
+    import os
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def shard_batches(n_batches, rank, world):
+    """Rank r takes batches r, r+W, r+2W, ... (equal count on every rank: the tail that does not
+    fill a round is dropped, like the reference drops the tail samples, mfm_mosi.py:423)."""
+    per = n_batches // world
+    return [rank + i * world for i in range(per)]
+
+
+class DeviceDataset:
+    """Synthetic MOSI-shape split kept resident in HBM as contiguous [nb, T, B, D] batches
+    (the reference slices a host array and copies H2D every step, mfm_mosi.py:428-429)."""
+
+    def __init__(self, cfg, n_samples, T, batchsize, device, seed=11):
+        loss = cfg.get("loss", "l1")
+        classes = cfg["output_dim"] if loss == "ce" else 0
+        X, y = synth.make_dataset(cfg["input_dims"], n_samples, T, seed=seed, output_dim=cfg["output_dim"],
+                                  classes=classes)
+        nb = n_samples // batchsize                       # floor: tail dropped (mfm_mosi.py:423)
+        X = X[:, :nb * batchsize].reshape(T, nb, batchsize, -1).transpose(1, 0, 2, 3)
+        y = y[:nb * batchsize].reshape((nb, batchsize) + y.shape[1:])
+        self.X = torch.from_numpy(np.ascontiguousarray(X)).to(device)
+        self.y = torch.from_numpy(np.ascontiguousarray(y)).to(device)
+        self.nb = nb
+
+    def batch(self, i):
+        return self.X[i], self.y[i]
+
+
+class DataParallelStep:
+    """step(x, y): fused single-GPU step, or fwd/bwd + all-reduce + Adam when world > 1."""
+
+    def __init__(self, engine, world=1, lr=1e-3):
+        self.e = engine
+        self.world = world
+        self.lr = lr
+        if world > 1:
+            engine.reg_scale = float(world)
+
+    def step(self, x, y):
+        e = self.e
+        if self.world == 1:
+            return e.train_step(x, y, lr=self.lr, check=False)
+        import torch.distributed as dist
+        out = e.forward(x, y, train=True, want_xhat=False)
+        e.backward(x, y, stage=0)
+        dist.all_reduce(e.grads)                          # one flat buffer, one collective
+        e.adam(lr=self.lr, grad_scale=1.0 / self.world)
+        return out["losses"]
+
+
+def broadcast_params(engine, world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.broadcast(engine.params, src=0)

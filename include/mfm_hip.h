@@ -1,0 +1,191 @@
+/*
+ * mfm_hip.h -- C ABI of libmfm_hip.so: the MI355X (gfx950 / CDNA4) implementation of the
+ * MFM training hot path of pliang279/factorized.
+ *
+ * The reference has no FFI / plugin boundary: it is pure Python and all arithmetic lives in
+ * PyTorch ops (nn.LSTMCell, nn.Linear, autograd, optim.Adam).  The drop-in boundary is
+ * therefore the Python class surface (factorized_amd/mfm_model.py mirrors mfm_model.py); THIS
+ * header is the native boundary underneath it -- what a maintainer of the reference would bind
+ * with ctypes.  Each entry point names the reference code it replaces
+ * (file:line into the reference repo).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless it says host.
+ *   - caller owns every buffer (PyTorch caching allocator); nothing here allocates device memory
+ *     that outlives a call.  Workspace sizes come from mfm_plan_workspace_bytes().
+ *   - all work is enqueued on the hipStream_t passed as `stream` (void*, 0 = default stream) and
+ *     the call returns immediately; no hidden synchronisation (the reference only syncs at
+ *     `.item()`, mfm_mosi.py:442).
+ *   - return 0 on success, negative MFM_ERR_* otherwise; mfm_last_error() gives the text.
+ *     No C++ exception crosses this boundary.
+ *   - fp32 everywhere; LSTM gate order is torch's i,f,g,o; weight layouts are torch's
+ *     (weight_ih [4h,d], weight_hh [4h,h], Linear.weight [out,in]), row-major.
+ *   - "padded hidden" Hp = round_up(h,16).  Sequence state buffers use the padded layouts
+ *       gates [T,B,4,Hp]   hs [T,B,Hp]   cs [T,B,Hp]
+ *     pad units hold exact zeros for h/c (0.5/0/0.5 gates); pad rows do not exist (B is exact).
+ */
+#ifndef MFM_HIP_H_
+#define MFM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFM_OK 0
+#define MFM_ERR_ARG (-1)
+#define MFM_ERR_HIP (-2)
+#define MFM_ERR_UNSUPPORTED (-3)
+
+#define MFM_ABI_VERSION 1
+
+int mfm_abi_version(void);
+const char* mfm_last_error(void);
+/* number of CUs of the current device (for grid heuristics / reporting). */
+int mfm_device_cus(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Grouped fp32 GEMM on the f32 MFMA (v_mfma_f32_16x16x4_f32), exact fp32 FMA chains.
+ *   for z in [0,batch):  C[z][m][n] (+)= alpha * sum_k A(z,m,k) * B(z,k,n) + bias[z][n] + bias2[z][n]
+ * A(z,m,k) = a[z*a_sz + m*a_sm + k*a_sk], B(z,k,n) = b[z*b_sz + k*b_sk + n*b_sn],
+ * C element at c[z*c_sz + m*ldc + n].  Columns n in [n_valid, n) are produced as exact zeros
+ * (pad units).  accumulate!=0 -> atomic += into c (and c2 if non-null), needed for split_k>1.
+ * Replaces every nn.Linear / LSTMCell addmm and its AddmmBackward on the path:
+ * mfm_model.py:56,83,85 (x W_ih^T hoisted over all T), :61,90 (fc1), autograd of the same.
+ */
+typedef struct MfmGemmDesc {
+  const float* a; const float* b; float* c; float* c2;
+  const float* bias; const float* bias2;
+  int64_t a_sz, a_sm, a_sk;
+  int64_t b_sz, b_sk, b_sn;
+  int64_t c_sz, ldc, bias_sz;
+  int32_t m, n, k, n_valid, batch, split_k, accumulate;
+  float alpha;
+} MfmGemmDesc;
+
+int mfm_gemm_grouped_f32(const MfmGemmDesc* descs /*host*/, int count, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-sequence LSTM recurrence (one persistent workgroup per 16 batch rows per LSTM; weights
+ * stay in VGPRs for all T steps, h is exchanged through LDS, c never leaves registers).
+ * Up to MFM_MAX_SEQ independent LSTMs run in ONE launch.
+ *
+ * Encoder form (is_dec=0), replaces encoderLSTM.forward's time loop mfm_model.py:47-58:
+ *   in : gates = x_t W_ih^T + b_ih + b_hh for all t (from mfm_gemm_grouped_f32), w_hh
+ *   out: gates <- activated (i,f,g,o), hs, cs.
+ * Decoder form (is_dec=1), replaces decoderLSTM.forward's loop mfm_model.py:72-88:
+ *   step 0 consumes h_init [B, ld_init] through w_ih from zero state; steps >=1 feed the
+ *   hidden state back as the input, i.e. gates = h (W_ih+W_hh)^T + b_ih + b_hh.
+ */
+#define MFM_MAX_SEQ 4
+typedef struct MfmSeqDesc {
+  float* gates; float* hs; float* cs;
+  const float* w_hh; const float* w_ih; const float* b_ih; const float* b_hh;
+  const float* h_init; int64_t ld_init;
+  /* backward only */
+  const float* dh_ext;   /* dec: [T,B,Hp] grad wrt every h_t; enc: [B, ld_dh] grad wrt h_{T-1} */
+  int64_t ld_dh;
+  float* d_h_init;       /* dec: [B, ld_dinit] out (grad wrt h_init); enc: unused */
+  int64_t ld_dinit;
+  int32_t h, is_dec;
+} MfmSeqDesc;
+
+int mfm_lstm_seq_fwd(const MfmSeqDesc* descs /*host*/, int count, int T, int B, void* stream);
+
+/* BPTT over the saved gates/cs (autograd of the loops above).  On return `gates` holds the
+ * pre-activation gate gradients dA[T,B,4,Hp] (in place); weight/bias gradients are then plain
+ * GEMMs over dA (see plan.hip).  For decoders d_h_init receives dA_0 W_ih. */
+int mfm_lstm_seq_bwd(const MfmSeqDesc* descs /*host*/, int count, int T, int B, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Reconstruction loss + gradient, replaces nn.MSELoss over x_hat vs the input slices and its
+ * backward (mfm_mosi.py:412,437):  loss_slot += sum((xhat-x)^2) * inv_count (un-weighted mean),
+ * dxhat = grad_scale * (xhat - x).  x is a column slice of the [T,B,D] batch (row stride ldx).
+ */
+int mfm_mse_fwd_bwd(const float* xhat, const float* x, int64_t ldx, int64_t rows, int32_t d,
+                    float inv_count, float grad_scale, float* dxhat, float* loss_slot, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused Adam on one flat parameter buffer (torch.optim.Adam defaults semantics,
+ * mfm_mosi.py:403,441): m,v,p updated in place; g is multiplied by grad_scale first (DP
+ * averaging).  `step` is the 1-based step count used for bias correction.
+ */
+int mfm_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr,
+                  float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The fused MFM_KL_EF training / inference plan (mfm_model.py:557-660 + mfm_mosi.py:424-442).
+ * One call enqueues the whole step: input projections -> 4 encoder recurrences -> latent
+ * heads/MLPs/classifier + KLD + L1|CE -> 3 decoder recurrences -> fc1 + MSE -> full backward
+ * -> (optional) Adam.  Parameters live in ONE flat fp32 buffer; `param_offsets` gives the
+ * element offset of each of the MFM_KLEF_NPARAM tensors in reference state_dict order
+ * (encoder_l.lstm.weight_ih ... fy_to_y_fc2.bias; 78 tensors).
+ */
+#define MFM_KLEF_NPARAM 78
+#define MFM_LOSS_SLOTS 8  /* [0]=disc [1]=mse_l [2]=mse_a [3]=mse_v [4]=kld [5]=total loss */
+
+typedef struct MfmPlanConfig {
+  int32_t d_l, d_a, d_v;
+  int32_t zl, za, zv, zy;
+  int32_t fl, fa, fv, fy;
+  int32_t output_dim;
+  int32_t loss_kind;      /* 0 = L1 (mfm_mosi.py:411,438), 1 = cross-entropy (mfm_you.py:451,484) */
+  int32_t T, B;
+  float lda_xl, lda_xa, lda_xv, lda_reg;   /* mfm_mosi.py:433,437 */
+  float drop_zy, drop_zl, drop_za, drop_zv, drop_y;
+  float reg_scale;        /* extra factor on the KLD term (DP: world size) */
+} MfmPlanConfig;
+
+typedef struct MfmPlan MfmPlan;
+
+/* host-side: builds the op tables; no device allocation. */
+int mfm_plan_create(const MfmPlanConfig* cfg, const int64_t* param_offsets /*[MFM_KLEF_NPARAM]*/,
+                    int64_t n_params_total, MfmPlan** out);
+void mfm_plan_destroy(MfmPlan* plan);
+int64_t mfm_plan_workspace_bytes(const MfmPlan* plan);
+
+/* zero the workspace and write its constant regions (a ones vector used for bias-gradient
+ * column sums).  Call once after allocating `workspace` (and again if it is re-allocated). */
+int mfm_plan_init_workspace(MfmPlan* plan, void* workspace, void* stream);
+
+/* Forward only (evaluate/predict, mfm_mosi.py:445-465; also the first half of a step).
+ * x [T,B,D] time-major contiguous, y [B] (L1, output_dim 1) / [B,output_dim] (L1) / int64 [B] (CE).
+ * train!=0 applies dropout with the counter-based generator keyed by (seed, call counter).
+ * Outputs (any may be NULL): xhat_l/a/v [T,B,d_*], y_hat [B,output_dim], losses[MFM_LOSS_SLOTS]. */
+int mfm_plan_forward(MfmPlan* plan, const float* params, const float* x, const void* y, int train,
+                     uint64_t seed, void* workspace, float* xhat_l, float* xhat_a, float* xhat_v,
+                     float* y_hat, float* losses, void* stream);
+
+/* Backward of the last mfm_plan_forward on the same workspace: fills grads (same flat layout,
+ * zeroed first).  stage: 0 joint loss (mfm_mosi.py:439), 1 gen+reg, 2 disc+reg (train_beta_vae,
+ * mfm_mosi.py:278-281). */
+int mfm_plan_backward(MfmPlan* plan, const float* params, const float* x, const void* y, int stage,
+                      void* workspace, float* grads, void* stream);
+
+/* forward + backward + Adam in one enqueue (no host work in between). */
+int mfm_plan_train_step(MfmPlan* plan, float* params, float* grads, float* adam_m, float* adam_v,
+                        const float* x, const void* y, uint64_t seed, int32_t step, float lr,
+                        float grad_scale, void* workspace, float* losses, void* stream);
+
+/* Algorithmic work of one training step at this plan's (T,B):
+ * 3 x forward FLOPs; activation+input bytes per sample plus 10 P 4 parameter/optimizer bytes. */
+double mfm_plan_flops_per_step(const MfmPlan* plan);
+double mfm_plan_bytes_per_step(const MfmPlan* plan);
+
+/* Per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline object).
+ * mask bit k enables kernel id k (ids 0..mfm_plan_num_kernels()-1, names from
+ * mfm_plan_kernel_name); mfm_plan_collect_timing synchronises on the recorded events, returns
+ * summed milliseconds and launch counts per kernel id and resets the recorder. */
+int mfm_plan_set_timing(MfmPlan* plan, int mask);
+int mfm_plan_num_kernels(void);
+const char* mfm_plan_kernel_name(int kid);
+int mfm_plan_collect_timing(MfmPlan* plan, double* sum_ms, int64_t* count);
+/* algorithmic FLOPs of ONE launch of kernel `kid` (matrix work only). */
+double mfm_plan_kernel_flops(const MfmPlan* plan, int kid);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFM_HIP_H_ */

@@ -1,0 +1,280 @@
+"""GPU parity of the individual C-ABI ops against CPU references (numpy fp64 / the torch-CPU
+oracle recurrences).  Run on the MI355X box: pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from tests.cases import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4   # BASELINE.json north_star: 1e-4 relative fp32 tolerance
+
+
+@pytest.fixture(scope="module")
+def eng():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from factorized_amd import engine
+    return engine
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+# ---------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("m,n,k", [(640, 128, 300), (37, 5, 11), (64, 64, 16), (1, 1, 1), (130, 70, 325)])
+def test_gemm_nt_bias(eng, m, n, k):
+    rs = np.random.RandomState(m + n + k)
+    A = rs.normal(size=(m, k + 3)).astype(np.float32)     # row stride k+3: a strided slice
+    W = rs.normal(size=(n, k)).astype(np.float32)
+    b1 = rs.normal(size=n).astype(np.float32)
+    b2 = rs.normal(size=n).astype(np.float32)
+    a_d, w_d, b1_d, b2_d = dev(A), dev(W), dev(b1), dev(b2)
+    npad = n + 3
+    c_d = torch.full((m, npad), 7.0, device="cuda")
+    d = eng.make_gemm(a_d, w_d, c_d, m, npad, k, a_sm=k + 3, a_sk=1, b_sk=1, b_sn=k, ldc=npad,
+                      bias=b1_d, bias2=b2_d, n_valid=n)
+    eng.gemm_grouped([d])
+    ref = A[:, :k].astype(np.float64) @ W.T.astype(np.float64) + b1 + b2
+    out = c_d.cpu().numpy()
+    assert rel_err(out[:, :n], ref) < 2e-6
+    assert np.all(out[:, n:] == 0.0)            # pad columns are exact zeros
+
+
+def test_gemm_tn_splitk_accumulate_dual_output(eng):
+    rs = np.random.RandomState(5)
+    R, M, N = 640, 120, 325
+    dA = rs.normal(size=(R, 4, 128)).astype(np.float32)      # [rows, gate, Hp]
+    X = rs.normal(size=(R, N)).astype(np.float32)
+    da_d, x_d = dev(dA), dev(X)
+    c1 = torch.zeros(4, M, N, device="cuda")
+    c2 = torch.zeros(4, M, N, device="cuda")
+    d = eng.make_gemm(da_d, x_d, c1, M, N, R, a_sm=1, a_sk=4 * 128, b_sk=N, b_sn=1, ldc=N, batch=4,
+                      a_sz=128, c_sz=M * N, accumulate=1, split_k=0, c2=c2)
+    eng.gemm_grouped([d])
+    ref = np.einsum("rgm,rn->gmn", dA[:, :, :M].astype(np.float64), X.astype(np.float64))
+    assert rel_err(c1.cpu().numpy(), ref) < 5e-6
+    assert rel_err(c2.cpu().numpy(), ref) < 5e-6
+
+
+def test_gemm_nn_and_group_of_many(eng):
+    rs = np.random.RandomState(9)
+    descs, refs, outs = [], [], []
+    for i in range(7):
+        m, n, k = 50 + 13 * i, 20 + 9 * i, 5 + 31 * i
+        A = rs.normal(size=(m, k)).astype(np.float32)
+        B = rs.normal(size=(k, n)).astype(np.float32)
+        a_d, b_d = dev(A), dev(B)
+        c_d = torch.empty(m, n, device="cuda")
+        descs.append(eng.make_gemm(a_d, b_d, c_d, m, n, k, a_sm=k, a_sk=1, b_sk=n, b_sn=1, ldc=n, alpha=0.5))
+        refs.append(0.5 * A.astype(np.float64) @ B.astype(np.float64))
+        outs.append((a_d, b_d, c_d))
+    eng.gemm_grouped(descs)
+    for (_, _, c_d), ref in zip(outs, refs):
+        assert rel_err(c_d.cpu().numpy(), ref) < 2e-6
+
+
+def test_gemm_column_sums_with_ones(eng):
+    rs = np.random.RandomState(3)
+    R, M = 333, 96
+    dA = rs.normal(size=(R, M)).astype(np.float32)
+    da_d = dev(dA)
+    ones = torch.ones(R, device="cuda")
+    c = torch.zeros(M, device="cuda")
+    d = eng.make_gemm(da_d, ones, c, M, 1, R, a_sm=1, a_sk=M, b_sk=1, b_sn=1, ldc=1, accumulate=1, split_k=0)
+    eng.gemm_grouped([d])
+    assert rel_err(c.cpu().numpy(), dA.astype(np.float64).sum(0)) < 5e-6
+
+
+# ---------------------------------------------------------------------------------- LSTM sequences
+def _cpu_lstm(x, w_ih, w_hh, b_ih, b_hh, dec_init=None, T=None):
+    """torch-CPU recurrence with autograd (reference semantics mfm_model.py:47-58 / 72-88)."""
+    h = w_hh.shape[1]
+    cell = torch.nn.LSTMCell(w_ih.shape[1], h)
+    with torch.no_grad():
+        cell.weight_ih.copy_(torch.from_numpy(w_ih)); cell.weight_hh.copy_(torch.from_numpy(w_hh))
+        cell.bias_ih.copy_(torch.from_numpy(b_ih)); cell.bias_hh.copy_(torch.from_numpy(b_hh))
+    hs, cs = [], []
+    if dec_init is None:
+        xt = torch.from_numpy(x)
+        B = xt.shape[1]
+        hx, cx = torch.zeros(B, h), torch.zeros(B, h)
+        for t in range(xt.shape[0]):
+            hx, cx = cell(xt[t], (hx, cx))
+            hs.append(hx); cs.append(cx)
+        return cell, None, torch.stack(hs), torch.stack(cs)
+    init = torch.from_numpy(dec_init).clone().requires_grad_(True)
+    B = init.shape[0]
+    hx, cx = torch.zeros(B, h), torch.zeros(B, h)
+    inp = init
+    for t in range(T):
+        hx, cx = cell(inp, (hx, cx))
+        inp = hx
+        hs.append(hx); cs.append(cx)
+    return cell, init, torch.stack(hs), torch.stack(cs)
+
+
+def _pad_gates(g, h, Hp):
+    """[T,B,4h] -> [T,B,4,Hp] zero padded."""
+    T, B = g.shape[:2]
+    out = np.zeros((T, B, 4, Hp), dtype=np.float32)
+    out[:, :, :, :h] = g.reshape(T, B, 4, h)
+    return out
+
+
+SEQ_SHAPES = [(8, 5, 1, 3), (8, 5, 32, 20), (24, 7, 33, 4), (32, 300, 32, 20), (80, 20, 17, 6),
+              (104, 9, 16, 5), (120, 325, 32, 20), (20, 6, 5, 1), (128, 4, 3, 2), (36, 10, 40, 3)]
+
+
+@pytest.mark.parametrize("h,d,B,T", SEQ_SHAPES)
+def test_lstm_seq_encoder_fwd_bwd(eng, h, d, B, T):
+    rs = np.random.RandomState(h * 7 + B)
+    k = 1.0 / np.sqrt(h)
+    w_ih = rs.uniform(-k, k, size=(4 * h, d)).astype(np.float32)
+    w_hh = rs.uniform(-k, k, size=(4 * h, h)).astype(np.float32)
+    b_ih = rs.uniform(-k, k, size=4 * h).astype(np.float32)
+    b_hh = rs.uniform(-k, k, size=4 * h).astype(np.float32)
+    x = rs.normal(size=(T, B, d)).astype(np.float32)
+    cell, _, hs_ref, cs_ref = _cpu_lstm(x, w_ih, w_hh, b_ih, b_hh)
+    Hp = (h + 15) // 16 * 16
+    gx = x.astype(np.float64) @ w_ih.T.astype(np.float64) + b_ih + b_hh
+    gates = dev(_pad_gates(gx.astype(np.float32), h, Hp))
+    hs = torch.full((T, B, Hp), 9.0, device="cuda")
+    cs = torch.full((T, B, Hp), 9.0, device="cuda")
+    w_d = dev(w_hh)
+    desc = eng.make_seq(gates, hs, cs, w_d, h)
+    eng.lstm_seq([desc], T, B)
+    hs_o, cs_o = hs.cpu().numpy(), cs.cpu().numpy()
+    assert rel_err(hs_o[:, :, :h], hs_ref.detach().numpy()) < TOL
+    assert rel_err(cs_o[:, :, :h], cs_ref.detach().numpy()) < TOL
+    assert np.all(hs_o[:, :, h:] == 0.0) and np.all(cs_o[:, :, h:] == 0.0)
+
+    # ---- backward: external grad on the last hidden state only (encoder form)
+    dh_last = rs.normal(size=(B, h)).astype(np.float32)
+    (hs_ref[-1] * torch.from_numpy(dh_last)).sum().backward()
+    dh_d = dev(dh_last)
+    desc = eng.make_seq(gates, hs, cs, w_d, h, dh_ext=dh_d, ld_dh=h)
+    eng.lstm_seq([desc], T, B, backward=True)
+    dA = gates.cpu().numpy().astype(np.float64)[:, :, :, :h].reshape(T, B, 4 * h)
+    db = dA.sum((0, 1))
+    dW_ih = np.einsum("tbg,tbd->gd", dA, x.astype(np.float64))
+    hprev = np.concatenate([np.zeros((1, B, h)), hs_ref.detach().numpy()[:-1]], 0)
+    dW_hh = np.einsum("tbg,tbh->gh", dA, hprev)
+    assert rel_err(db, cell.bias_ih.grad.numpy()) < TOL
+    assert rel_err(dW_ih, cell.weight_ih.grad.numpy()) < TOL
+    assert rel_err(dW_hh, cell.weight_hh.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("h,B,T", [(24, 32, 20), (104, 32, 20), (24, 5, 1), (40, 19, 3), (112, 33, 7)])
+def test_lstm_seq_decoder_fwd_bwd(eng, h, B, T):
+    rs = np.random.RandomState(h + B + T)
+    k = 1.0 / np.sqrt(h)
+    w_ih = rs.uniform(-k, k, size=(4 * h, h)).astype(np.float32)
+    w_hh = rs.uniform(-k, k, size=(4 * h, h)).astype(np.float32)
+    b_ih = rs.uniform(-k, k, size=4 * h).astype(np.float32)
+    b_hh = rs.uniform(-k, k, size=4 * h).astype(np.float32)
+    init = rs.normal(size=(B, h)).astype(np.float32)
+    cell, init_t, hs_ref, cs_ref = _cpu_lstm(None, w_ih, w_hh, b_ih, b_hh, dec_init=init, T=T)
+    Hp = (h + 15) // 16 * 16
+    gates = torch.full((T, B, 4, Hp), 3.0, device="cuda")
+    hs = torch.full((T, B, Hp), 9.0, device="cuda")
+    cs = torch.full((T, B, Hp), 9.0, device="cuda")
+    wi, wh, bi, bh, init_d = dev(w_ih), dev(w_hh), dev(b_ih), dev(b_hh), dev(init)
+    desc = eng.make_seq(gates, hs, cs, wh, h, w_ih=wi, b_ih=bi, b_hh=bh, h_init=init_d, is_dec=True)
+    eng.lstm_seq([desc], T, B)
+    hs_o = hs.cpu().numpy()
+    assert rel_err(hs_o[:, :, :h], hs_ref.detach().numpy()) < TOL
+    assert rel_err(cs.cpu().numpy()[:, :, :h], cs_ref.detach().numpy()) < TOL
+    assert np.all(hs_o[:, :, h:] == 0.0)
+
+    dH = rs.normal(size=(T, B, h)).astype(np.float32)
+    (hs_ref * torch.from_numpy(dH)).sum().backward()
+    dH_p = np.zeros((T, B, Hp), dtype=np.float32)
+    dH_p[:, :, :h] = dH
+    dh_d = dev(dH_p)
+    dinit = torch.full((B, h), 5.0, device="cuda")
+    desc = eng.make_seq(gates, hs, cs, wh, h, w_ih=wi, b_ih=bi, b_hh=bh, h_init=init_d, is_dec=True,
+                        dh_ext=dh_d, ld_dh=Hp, d_h_init=dinit)
+    eng.lstm_seq([desc], T, B, backward=True)
+    dA = gates.cpu().numpy().astype(np.float64)[:, :, :, :h].reshape(T, B, 4 * h)
+    hsr = hs_ref.detach().numpy().astype(np.float64)
+    S = np.einsum("tbg,tbh->gh", dA[1:], hsr[:-1]) if T > 1 else np.zeros((4 * h, h))
+    dW_hh = S
+    dW_ih = S + np.einsum("bg,bh->gh", dA[0], init.astype(np.float64))
+    assert rel_err(dinit.cpu().numpy(), init_t.grad.numpy()) < TOL
+    assert rel_err(dA.sum((0, 1)), cell.bias_hh.grad.numpy()) < TOL
+    assert rel_err(dW_ih, cell.weight_ih.grad.numpy()) < TOL
+    if T > 1:
+        assert rel_err(dW_hh, cell.weight_hh.grad.numpy()) < TOL
+
+
+def test_lstm_seq_four_in_one_launch(eng):
+    """The 4 encoders of the canonical model share one launch; results must equal solo launches."""
+    rs = np.random.RandomState(0)
+    T, B = 20, 32
+    keep, solo, descs = [], [], []
+    for h in (32, 8, 80, 120):
+        Hp = (h + 15) // 16 * 16
+        k = 1.0 / np.sqrt(h)
+        w = dev(rs.uniform(-k, k, size=(4 * h, h)))
+        g0 = _pad_gates(rs.normal(size=(T, B, 4 * h)).astype(np.float32), h, Hp)
+        bufs = []
+        for _ in range(2):
+            gates = dev(g0)
+            hs = torch.zeros(T, B, Hp, device="cuda")
+            cs = torch.zeros(T, B, Hp, device="cuda")
+            bufs.append((gates, hs, cs))
+        keep.append((w, bufs))
+        descs.append(eng.make_seq(*bufs[0], w, h))
+        solo.append(eng.make_seq(*bufs[1], w, h))
+    eng.lstm_seq(descs, T, B)
+    for s in solo:
+        eng.lstm_seq([s], T, B)
+    torch.cuda.synchronize()
+    for w, bufs in keep:
+        for a, b in zip(bufs[0], bufs[1]):
+            assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------- MSE / Adam
+def test_mse_fwd_bwd(eng):
+    import ctypes as C
+    from factorized_amd import _lib
+    rs = np.random.RandomState(1)
+    rows, d, D = 640, 20, 325
+    X = rs.normal(size=(rows, D)).astype(np.float32)
+    xh = rs.normal(size=(rows, d)).astype(np.float32)
+    x_d, xh_d = dev(X), dev(xh)
+    dx = torch.empty(rows, d, device="cuda")
+    slot = torch.zeros(1, device="cuda")
+    off = 305
+    xs = x_d.view(-1)[off:]
+    _lib.check(_lib.lib().mfm_mse_fwd_bwd(xh_d.data_ptr(), xs.data_ptr(), D, rows, d, 1.0 / (rows * d),
+                                          2.0 * 0.5 / (rows * d), dx.data_ptr(), slot.data_ptr(),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    diff = xh.astype(np.float64) - X[:, off:off + d]
+    assert abs(slot.item() - (diff ** 2).mean()) < 1e-5 * (diff ** 2).mean()
+    assert rel_err(dx.cpu().numpy(), diff / (rows * d)) < 1e-6
+
+
+def test_adam_matches_torch(eng):
+    import ctypes as C
+    from factorized_amd import _lib
+    rs = np.random.RandomState(2)
+    n = 4099
+    p0 = rs.normal(size=n).astype(np.float32)
+    p_ref = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([p_ref])
+    p = dev(np.concatenate([p0, np.zeros(1, np.float32)]))[:n]
+    m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    for step in range(1, 6):
+        g = rs.normal(size=n).astype(np.float32) * (10.0 ** rs.randint(-4, 2))
+        p_ref.grad = torch.from_numpy(g.copy())
+        opt.step()
+        g_d = dev(g)
+        _lib.check(_lib.lib().mfm_adam_flat(p.data_ptr(), g_d.data_ptr(), m.data_ptr(), v.data_ptr(), n, step,
+                                            1e-3, 0.9, 0.999, 1e-8, 1.0,
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert rel_err(p.cpu().numpy(), p_ref.detach().numpy()) < 1e-6

