@@ -37,7 +37,6 @@ def main():
     ap.add_argument("--seq", type=int, default=0, help="sequence length; 0 = read configs/mosi.json")
     ap.add_argument("--shape", default="mosi", choices=["mosi", "you", "mosei"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=0)
     ap.add_argument("--breakdown", action="store_true", help="also print a per-kernel time table to stderr")
     args = ap.parse_args()
 
@@ -84,8 +83,13 @@ def main():
         torch.cuda.synchronize()
 
     # ---- warm-up (untimed) + a per-kernel breakdown pass (untimed) to find the dominant kernel
+    dbg = os.environ.get("MFM_BENCH_DEBUG")
+    if dbg:
+        sys.stderr.write("setup done, warmup...\n"); sys.stderr.flush()
     run(args.warmup)
     barrier()
+    if dbg:
+        sys.stderr.write("warmup done\n"); sys.stderr.flush()
     e.set_timing(T, B, (1 << 13) - 1)
     run(10, args.warmup)
     barrier()
@@ -140,13 +144,20 @@ def main():
             from oracle import mfm_oracle as O
             import torch as _t
             cores = os.cpu_count() or 1
-            steps = args.cpu_steps or 60
-            r = O.time_cpu_steps(cfgs, B, T, steps=steps, warmup=3, threads=cores)
+            # the reference step is ~165 tiny ops: it stops scaling at a handful of threads, so time
+            # it at 1 thread and at min(cores, 8) threads (bounded ~8 s each) and report the faster.
+            runs = [O.time_cpu_steps(cfgs, B, T, budget_s=8.0, threads=1)]
+            if cores > 1:
+                runs.append(O.time_cpu_steps(cfgs, B, T, budget_s=8.0, threads=min(cores, 8)))
+            r = max(runs, key=lambda q: q["samples_per_s"])
             out["cpu_baseline"] = {"value": round(r["samples_per_s"], 1), "unit": "samples/s", "cores": r["threads"],
                                    "kind": "port", "ms_per_step": round(r["ms_per_step"], 2),
-                                   "sample": "%d training steps of the torch-CPU oracle (restated reference path: "
-                                             "per-timestep nn.LSTMCell loop, joint loss, optim.Adam), B=%d T=%d, "
-                                             "%d threads" % (steps, B, T, r["threads"])}
+                                   "host_cores": cores,
+                                   "all_runs": [{"threads": q["threads"], "samples_per_s": round(q["samples_per_s"], 1),
+                                                 "steps": q["steps"]} for q in runs],
+                                   "sample": "%d training steps (~8 s) of the torch-CPU oracle (restated reference "
+                                             "path: per-timestep nn.LSTMCell loop, joint loss, optim.Adam), B=%d T=%d, "
+                                             "%d threads" % (r["steps"], B, T, r["threads"])}
             out["speedup_vs_cpu"] = round(value / r["samples_per_s"], 1)
         print(json.dumps(out))
     if world > 1:

@@ -48,6 +48,8 @@ struct LatentDev {
   float* rec;                          // [B, rec_size] saved record
   float* yhat_out;                     // optional [B, od]
   const void* y; int loss_kind;
+  const float* d_yhat_ext;             // optional upstream gradient wrt y_hat [B, od] (module path)
+  const float* reg_w_ptr;              // optional device scalar: upstream gradient wrt the KLD sum
   float* losses;
   int B, rows_per_wg, train, has_logvar;
   uint64_t seed;

@@ -165,7 +165,12 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const LatentDev L, cons
   __syncthreads();
 
   // ---- seeds
-  if (L.y && L.disc_w != 0.0f) {
+  if (L.d_yhat_ext) {
+    for (int idx = tid; idx < nrows * L.od; idx += nt) {
+      const int r = idx / L.od, o = idx - r * L.od;
+      grd[r * RS + L.yhat_off + o] = L.d_yhat_ext[(int64_t)(row0 + r) * L.od + o];
+    }
+  } else if (L.y && L.disc_w != 0.0f) {
     if (L.loss_kind == 0) {
       const float* y = reinterpret_cast<const float*>(L.y);
       const float sc = L.disc_w / ((float)L.B * (float)L.od);
@@ -207,14 +212,15 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const LatentDev L, cons
       }
     }
   }
-  if (L.has_logvar && L.reg_w != 0.0f) {
+  const float reg_w = L.reg_w_ptr ? *L.reg_w_ptr : L.reg_w;
+  if (L.has_logvar && (L.reg_w_ptr || reg_w != 0.0f)) {
     for (int m = 0; m < 4; ++m) {
       const int n = L.z_n[m];
       for (int idx = tid; idx < nrows * n; idx += nt) {
         const int r = idx / n, j = idx - r * n;
         const float mu = rec[r * RS + L.mu_off[m] + j], lv = rec[r * RS + L.lv_off[m] + j];
-        grd[r * RS + L.mu_off[m] + j] = L.reg_w * mu;
-        grd[r * RS + L.lv_off[m] + j] = L.reg_w * (-0.5f) * (1.0f - expf(lv));
+        grd[r * RS + L.mu_off[m] + j] = reg_w * mu;
+        grd[r * RS + L.lv_off[m] + j] = reg_w * (-0.5f) * (1.0f - expf(lv));
       }
     }
   }

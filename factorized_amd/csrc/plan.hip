@@ -344,8 +344,14 @@ static void dA_gemms(const MfmPlan* P, const SeqBuf& sb, int pb, float* W, float
   }
 }
 
+struct ExtGrads {           // upstream gradients supplied by the caller (autograd module path)
+  const float* d_xhat[3];
+  const float* d_yhat;
+  const float* d_reg;       // device scalar
+};
+
 static int backward(MfmPlan* P, const float* params, const float* x, const void* y, int stage, float* W,
-                    float* grads, hipStream_t s) {
+                    float* grads, hipStream_t s, const ExtGrads* ext = nullptr) {
   const MfmPlanConfig& c = P->cfg;
   const int T = P->T, B = P->B;
   const int64_t TB = (int64_t)T * B;
@@ -361,7 +367,8 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       memset(&d, 0, sizeof(d));
       d.alpha = 1.0f; d.batch = 1;
       // dH = dx_hat Wfc  (pad units -> exact zeros)
-      d.a = W + P->dxhat[m]; d.a_sm = P->dec_d[m]; d.a_sk = 1;
+      const float* dxh = (ext && ext->d_xhat[m]) ? ext->d_xhat[m] : W + P->dxhat[m];
+      d.a = dxh; d.a_sm = P->dec_d[m]; d.a_sk = 1;
       d.b = params + P->off[pb + FC_W]; d.b_sk = sb.h; d.b_sn = 1;
       d.c = W + P->dec_dhs[m]; d.ldc = sb.Hp;
       d.m = (int)TB; d.n = sb.Hp; d.n_valid = sb.h; d.k = P->dec_d[m]; d.split_k = 1;
@@ -370,7 +377,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       MfmGemmDesc w;
       memset(&w, 0, sizeof(w));
       w.alpha = 1.0f; w.batch = 1; w.accumulate = 1; w.split_k = 0;
-      w.a = W + P->dxhat[m]; w.a_sm = 1; w.a_sk = P->dec_d[m];
+      w.a = dxh; w.a_sm = 1; w.a_sk = P->dec_d[m];
       w.b = W + sb.hs; w.b_sk = sb.Hp; w.b_sn = 1;
       w.c = grads + P->off[pb + FC_W]; w.ldc = sb.h;
       w.m = P->dec_d[m]; w.n = sb.h; w.n_valid = sb.h; w.k = (int)TB;
@@ -411,6 +418,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     for (int e = 0; e < 4; ++e) { L.dh_last[e] = W + P->dh_last[e]; L.dh_ld[e] = P->enc_h[e]; }
     L.rec = W + P->lat_rec;
     L.y = y;
+    if (ext) { L.d_yhat_ext = ext->d_yhat; L.reg_w_ptr = ext->d_reg; }
     L.reg_w = c.lda_reg * c.reg_scale;
     L.disc_w = disc_on ? 1.0f : 0.0f;
     L.gen_w = gen_on ? 1.0f : 0.0f;
@@ -503,6 +511,19 @@ extern "C" int mfm_plan_backward(MfmPlan* P, const float* params, const float* x
   MFM_REQUIRE(stage >= 0 && stage <= 2, "mfm_plan_backward: stage %d", stage);
   MFM_REQUIRE(y || stage == 1, "mfm_plan_backward: labels required unless stage==1");
   return backward(P, params, x, y, stage, (float*)workspace, grads, (hipStream_t)stream);
+}
+
+extern "C" int mfm_plan_backward_ext(MfmPlan* P, const float* params, const float* x, const float* d_xhat_l,
+                                     const float* d_xhat_a, const float* d_xhat_v, const float* d_yhat,
+                                     const float* d_reg, void* workspace, float* grads, void* stream) {
+  if (!P || !params || !x || !workspace || !grads || !d_xhat_l || !d_xhat_a || !d_xhat_v || !d_yhat || !d_reg) {
+    set_error("mfm_plan_backward_ext: null argument");
+    return MFM_ERR_ARG;
+  }
+  ExtGrads ext;
+  ext.d_xhat[0] = d_xhat_l; ext.d_xhat[1] = d_xhat_a; ext.d_xhat[2] = d_xhat_v;
+  ext.d_yhat = d_yhat; ext.d_reg = d_reg;
+  return backward(P, params, x, nullptr, 0, (float*)workspace, grads, (hipStream_t)stream, &ext);
 }
 
 extern "C" int mfm_plan_train_step(MfmPlan* P, float* params, float* grads, float* adam_m, float* adam_v,

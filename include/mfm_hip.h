@@ -164,6 +164,13 @@ int mfm_plan_forward(MfmPlan* plan, const float* params, const float* x, const v
 int mfm_plan_backward(MfmPlan* plan, const float* params, const float* x, const void* y, int stage,
                       void* workspace, float* grads, void* stream);
 
+/* Backward of the last mfm_plan_forward for ARBITRARY upstream gradients (the autograd path of the
+ * nn.Module mirror: the caller's own loss.backward(), mfm_mosi.py:440): d_xhat_* [T,B,d_*],
+ * d_yhat [B,output_dim], d_reg = device scalar dLoss/dKLD. */
+int mfm_plan_backward_ext(MfmPlan* plan, const float* params, const float* x, const float* d_xhat_l,
+                          const float* d_xhat_a, const float* d_xhat_v, const float* d_yhat,
+                          const float* d_reg, void* workspace, float* grads, void* stream);
+
 /* forward + backward + Adam in one enqueue (no host work in between). */
 int mfm_plan_train_step(MfmPlan* plan, float* params, float* grads, float* adam_m, float* adam_v,
                         const float* x, const void* y, uint64_t seed, int32_t step, float lr,

@@ -301,11 +301,10 @@ def train_step(model, optimizer, x, y, cfg, stage=0, loss_kind="l1"):
     return terms, loss
 
 
-def time_cpu_steps(configs, B, T, steps, warmup=3, threads=None, variant="kl_ef"):
-    """Reference-CPU-path timing for bench.py's cpu_baseline leg: train mode,
-    joint loss, Adam defaults -- the op sequence of mfm_mosi.py:424-442."""
+def time_cpu_steps(configs, B, T, budget_s=10.0, max_steps=200, warmup=2, threads=None, variant="kl_ef"):
+    """Reference-CPU-path timing for bench.py's cpu_baseline leg: train mode, joint loss, Adam
+    defaults -- the op sequence of mfm_mosi.py:424-442.  Bounded by wall time (`budget_s`)."""
     import time
-    import numpy as np
     from factorized_amd import synth  # data recipe only (numpy)
     if threads:
         torch.set_num_threads(int(threads))
@@ -318,8 +317,12 @@ def time_cpu_steps(configs, B, T, steps, warmup=3, threads=None, variant="kl_ef"
     for _ in range(warmup):
         train_step(model, opt, x, y, cfg)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    steps = 0
+    while steps < max_steps:
         train_step(model, opt, x, y, cfg)
+        steps += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
     dt = time.perf_counter() - t0
     return dict(ms_per_step=1e3 * dt / steps, samples_per_s=B * steps / dt,
                 threads=torch.get_num_threads(), steps=steps)
