@@ -47,13 +47,16 @@ __device__ __forceinline__ f32x4 mma16x16x4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// MFM_FAST_ACT=1 (default): sigmoid/tanh on the hardware transcendentals v_exp_f32 / v_rcp_f32
+// (~1 ulp each; absolute error ~1e-7, far inside the 1e-4 parity budget).  MFM_FAST_ACT=0 uses
+// the ocml expf/tanhf, which cost ~5x more VALU issue slots per LSTM step.
 #ifndef MFM_FAST_ACT
-#define MFM_FAST_ACT 0
+#define MFM_FAST_ACT 1
 #endif
 
 __device__ __forceinline__ float act_sigmoid(float x) {
 #if MFM_FAST_ACT
-  return __frcp_rn(1.0f + __expf(-x));
+  return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 #else
   return 1.0f / (1.0f + expf(-x));
 #endif
@@ -61,7 +64,7 @@ __device__ __forceinline__ float act_sigmoid(float x) {
 __device__ __forceinline__ float act_tanh(float x) {
 #if MFM_FAST_ACT
   // 2*sigmoid(2x)-1, abs error ~1e-7
-  return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f;
+  return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f;
 #else
   return tanhf(x);
 #endif

@@ -29,12 +29,19 @@ struct LatOp {
   int mask_off;                // record offset of the dropout mask (scale) segment, -1 = no dropout
   float drop_p;
   int stage;
+  int pad_[3];
 };
 struct LatentDev {
-  LatOp op[MFM_LAT_MAXOPS];
+  // Op table in DEVICE memory (uploaded once by mfm_plan_init_workspace).  It must not live in the
+  // kernel-argument segment: the kernels index it with a per-lane op id, and a divergent index
+  // into kernarg makes the compiler copy the whole struct to scratch in every thread.
+  const LatOp* ops;
   int nops, nstages;
   int stage_begin[MFM_LAT_MAXSTAGES + 1];
   int rec_size;                        // floats per batch row, multiple of 4
+  int wpanel;                          // floats of LDS reserved for one stage's weights (0 = read from L2)
+  int64_t span_off[MFM_LAT_MAXSTAGES]; // first parameter element of each stage's contiguous tensor span
+  int span_len[MFM_LAT_MAXSTAGES];     // span length in floats (multiple of 4)
   // inputs: last hidden state of the 4 encoders (l, a, v, fused)
   const float* enc_h[4]; int64_t enc_ld[4]; int enc_n[4]; int in_off[4];
   // latent segments (l, a, v, y)

@@ -19,6 +19,7 @@
 //   A  adam           fused, one flat buffer
 #include <math.h>
 
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -57,6 +58,8 @@ struct MfmPlan {
   int64_t lat_rec, dh_last[4], yhat, ones, losses;
   int64_t ws_floats;
   mfm::LatentDev lat;
+  mfm::LatOp lat_ops[MFM_LAT_MAXOPS];
+  int64_t lat_ops_off;
   // timing
   int timing_mask;
   std::vector<mfm::TimingPair> pool;
@@ -72,9 +75,9 @@ static int64_t carve(int64_t& cursor, int64_t n) {
   return at;
 }
 
-static void add_op(LatentDev& L, int stage, int in_off, int out_off, int K, int N, int64_t w_off, int64_t b_off,
+static void add_op(LatOp* ops, LatentDev& L, int stage, int in_off, int out_off, int K, int N, int64_t w_off, int64_t b_off,
                    int relu, int mask_off, float p) {
-  LatOp& o = L.op[L.nops++];
+  LatOp& o = ops[L.nops++];
   o.in_off = in_off; o.out_off = out_off; o.K = K; o.N = N; o.w_off = w_off; o.b_off = b_off;
   o.relu = relu; o.mask_off = mask_off; o.drop_p = p; o.stage = stage;
 }
@@ -135,41 +138,66 @@ static int build(MfmPlan* P) {
   const int64_t* o = P->off;
   // stage 0: encoder fc1 (mfm_model.py:60-61)
   for (int e = 0; e < 4; ++e)
-    add_op(L, 0, L.in_off[e], last_off[e], eh[e], eh[e], o[ep[e] + FC_W], o[ep[e] + FC_B], 0, -1, 0.f);
+    add_op(P->lat_ops, L, 0, L.in_off[e], last_off[e], eh[e], eh[e], o[ep[e] + FC_W], o[ep[e] + FC_B], 0, -1, 0.f);
   // stage 1: mu / logvar heads (mfm_model.py:630-639)
   const int pmu[4] = {P_TO_ZL, P_TO_ZA, P_TO_ZV, P_TO_ZY};
   const int plv[4] = {P_TO_LVL, P_TO_LVA, P_TO_LVV, P_TO_LVY};
   for (int e = 0; e < 4; ++e) {
-    add_op(L, 1, last_off[e], L.mu_off[e], eh[e], zn[e], o[pmu[e]], o[pmu[e] + 1], 0, -1, 0.f);
-    add_op(L, 1, last_off[e], L.lv_off[e], eh[e], zn[e], o[plv[e]], o[plv[e] + 1], 0, -1, 0.f);
+    add_op(P->lat_ops, L, 1, last_off[e], L.mu_off[e], eh[e], zn[e], o[pmu[e]], o[pmu[e] + 1], 0, -1, 0.f);
+    add_op(P->lat_ops, L, 1, last_off[e], L.lv_off[e], eh[e], zn[e], o[plv[e]], o[plv[e] + 1], 0, -1, 0.f);
   }
   // stage 2/3: z -> f MLPs (mfm_model.py:644-647)
   const int pf1[4] = {P_ZL_F1, P_ZA_F1, P_ZV_F1, P_ZY_F1};
   const int pf2[4] = {P_ZL_F2, P_ZA_F2, P_ZV_F2, P_ZY_F2};
   const float pd[4] = {c.drop_zl, c.drop_za, c.drop_zv, c.drop_zy};
   for (int e = 0; e < 4; ++e)
-    add_op(L, 2, L.mu_off[e], f1_off[e], zn[e], fn[e], o[pf1[e]], o[pf1[e] + 1], 1, m1_off[e], pd[e]);
+    add_op(P->lat_ops, L, 2, L.mu_off[e], f1_off[e], zn[e], fn[e], o[pf1[e]], o[pf1[e] + 1], 1, m1_off[e], pd[e]);
   for (int e = 0; e < 4; ++e)
-    add_op(L, 3, f1_off[e], L.f_off[e], fn[e], fn[e], o[pf2[e]], o[pf2[e] + 1], 1, -1, 0.f);
+    add_op(P->lat_ops, L, 3, f1_off[e], L.f_off[e], fn[e], fn[e], o[pf2[e]], o[pf2[e] + 1], 1, -1, 0.f);
   // stage 4/5: classifier (mfm_model.py:657)
-  add_op(L, 4, L.f_off[3], c1_off, c.fy, c.fy, o[P_Y_F1], o[P_Y_F1 + 1], 1, mc_off, c.drop_y);
-  add_op(L, 5, c1_off, L.yhat_off, c.fy, c.output_dim, o[P_Y_F2], o[P_Y_F2 + 1], 0, -1, 0.f);
+  add_op(P->lat_ops, L, 4, L.f_off[3], c1_off, c.fy, c.fy, o[P_Y_F1], o[P_Y_F1 + 1], 1, mc_off, c.drop_y);
+  add_op(P->lat_ops, L, 5, c1_off, L.yhat_off, c.fy, c.output_dim, o[P_Y_F2], o[P_Y_F2 + 1], 0, -1, 0.f);
   L.nstages = 6;
   {
     int s = 0;
     L.stage_begin[0] = 0;
     for (int i = 0; i < L.nops; ++i)
-      while (L.op[i].stage > s) L.stage_begin[++s] = i;
+      while (P->lat_ops[i].stage > s) L.stage_begin[++s] = i;
     L.stage_begin[L.nstages] = L.nops;
   }
   L.has_logvar = 1;
   L.B = c.B;
   L.loss_kind = c.loss_kind;
+  // LDS weight panel: the tensors of one stage are expected to be contiguous in the flat buffer
+  // (engine.py FlatLayout groups them); the span [min offset, max end) is copied linearly.
+  int panel = 0;
+  for (int st = 0; st < L.nstages; ++st) {
+    int64_t lo = INT64_MAX, hi = 0;
+    for (int i = L.stage_begin[st]; i < L.stage_begin[st + 1]; ++i) {
+      const LatOp& op = P->lat_ops[i];
+      lo = std::min(lo, std::min(op.w_off, op.b_off));
+      hi = std::max(hi, std::max(op.w_off + (int64_t)op.N * op.K, op.b_off + (int64_t)op.N));
+    }
+    lo = lo / 4 * 4;
+    int64_t len = round_up64(hi - lo, 4);
+    if (lo + len > P->n_params) len = (P->n_params - lo) / 4 * 4;
+    L.span_off[st] = lo;
+    L.span_len[st] = (len > INT32_MAX) ? INT32_MAX : (int)len;
+    if (L.span_len[st] > panel) panel = L.span_len[st];
+  }
   // rows per workgroup: small batches want many workgroups, large ones fewer atomics
+  const size_t LDS_BUDGET = 150 * 1024;
   int R = (c.B <= 64) ? 4 : ((c.B <= 1024) ? 8 : 16);
-  while (R > 1 && 2 * (size_t)R * rs * sizeof(float) > 60 * 1024) R >>= 1;
+  if (((size_t)panel + 2 * (size_t)rs) * sizeof(float) <= LDS_BUDGET) {
+    L.wpanel = panel;
+    while (R > 1 && (2 * (size_t)R * rs + panel) * sizeof(float) > LDS_BUDGET) R >>= 1;
+  } else {
+    L.wpanel = 0;   // stage tensors not contiguous / too large to stage: kernels read them from L2
+    while (R > 1 && 2 * (size_t)R * rs * sizeof(float) > LDS_BUDGET) R >>= 1;
+  }
   L.rows_per_wg = R;
 
+  P->lat_ops_off = carve(cur, (int64_t)(sizeof(P->lat_ops) / sizeof(float)));
   P->lat_rec = carve(cur, (int64_t)c.B * rs);
   P->yhat = carve(cur, (int64_t)c.B * c.output_dim);
   P->ones = carve(cur, TB);
@@ -249,6 +277,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
   // F2: latent stack
   {
     LatentDev L = P->lat;
+    L.ops = reinterpret_cast<const LatOp*>(W + P->lat_ops_off);
     for (int e = 0; e < 4; ++e) {
       L.enc_h[e] = W + P->enc[e].hs + (int64_t)(T - 1) * B * P->enc[e].Hp;
       L.enc_ld[e] = P->enc[e].Hp;
@@ -411,6 +440,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
   // B3: latent stack
   {
     LatentDev L = P->lat;
+    L.ops = reinterpret_cast<const LatOp*>(W + P->lat_ops_off);
     for (int m = 0; m < 3; ++m) {
       L.d_dec_init[m] = gen_on ? W + P->dec_dinit[m] : nullptr;
       L.dec_ld[m] = P->dec_h[m];
@@ -494,6 +524,7 @@ extern "C" int mfm_plan_init_workspace(MfmPlan* P, void* workspace, void* stream
   float* W = (float*)workspace;
   hipStream_t s = (hipStream_t)stream;
   MFM_HIP_CHECK(hipMemsetAsync(W, 0, (size_t)P->ws_floats * sizeof(float), s));
+  MFM_HIP_CHECK(hipMemcpyAsync(W + P->lat_ops_off, P->lat_ops, sizeof(P->lat_ops), hipMemcpyHostToDevice, s));
   return fill_launch(W + P->ones, (int64_t)P->T * P->B, 1.0f, s);
 }
 
@@ -583,7 +614,7 @@ static double fwd_flops_per_sample(const MfmPlan* P) {
     const double h = P->dec_h[m], d = P->dec_d[m];
     f += P->T * (2.0 * 4.0 * h * (h + h) + 2.0 * h * d);
   }
-  for (int i = 4; i < P->lat.nops; ++i) f += 2.0 * P->lat.op[i].K * P->lat.op[i].N;
+  for (int i = 4; i < P->lat.nops; ++i) f += 2.0 * P->lat_ops[i].K * P->lat_ops[i].N;
   (void)c;
   return f;
 }

@@ -66,15 +66,42 @@ def klef_param_shapes(cfg):
     return s
 
 
+# Latent-stack tensors grouped by the stage of the fused latent kernel that consumes them
+# (csrc/latent.hip): each group is laid out contiguously so a stage's weights are ONE linear
+# global->LDS copy.  Everything else (the LSTM tensors) keeps state_dict order in front.
+_LATENT_STAGE_KEYS = [
+    ("encoder_l.fc1", "encoder_a.fc1", "encoder_v.fc1", "ef_encoder.fc1"),
+    ("last_to_zl_fc1", "last_to_za_fc1", "last_to_zv_fc1", "last_to_zy_fc1",
+     "last_to_logvarzl_fc1", "last_to_logvarza_fc1", "last_to_logvarzv_fc1", "last_to_logvarzy_fc1"),
+    ("zl_to_fl_fc1", "za_to_fa_fc1", "zv_to_fv_fc1", "zy_to_fy_fc1"),
+    ("zl_to_fl_fc2", "za_to_fa_fc2", "zv_to_fv_fc2", "zy_to_fy_fc2"),
+    ("fy_to_y_fc1",),
+    ("fy_to_y_fc2",),
+]
+
+
 class FlatLayout:
+    """Placement of the named tensors in one flat fp32 buffer.  `shapes`/`offsets` iterate in the
+    reference's state_dict order (what the C plan expects); the PHYSICAL order is chosen here."""
+
     def __init__(self, shapes):
         self.shapes = OrderedDict(shapes)
-        self.offsets = OrderedDict()
+        stage_of = {}
+        for st, prefixes in enumerate(_LATENT_STAGE_KEYS):
+            for pre in prefixes:
+                stage_of[pre + ".weight"] = st
+                stage_of[pre + ".bias"] = st
+        order = [n for n in self.shapes if n not in stage_of]
+        for st in range(len(_LATENT_STAGE_KEYS)):
+            order += [n for n in self.shapes if stage_of.get(n) == st]
+        assert sorted(order) == sorted(self.shapes)
+        placed = {}
         cur = 0
-        for name, shp in self.shapes.items():
-            self.offsets[name] = cur
-            n = int(np.prod(shp))
+        for name in order:
+            placed[name] = cur
+            n = int(np.prod(self.shapes[name]))
             cur = (cur + n + ALIGN - 1) // ALIGN * ALIGN
+        self.offsets = OrderedDict((n, placed[n]) for n in self.shapes)
         self.total = cur
         self.numel = sum(int(np.prod(s)) for s in self.shapes.values())
 
