@@ -8,8 +8,12 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function ${MFM_EXTRA_FLAGS:-}"
 mkdir -p "$HERE/build"
 pids=()
-for f in gemm lstm_seq latent elementwise plan; do
-  ( $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/build/$f.o" ) &
+for f in gemm lstm_seq lstm_seq_small latent elementwise plan; do
+  extra=""
+  # the SLP vectoriser packs the recurrent FMAs into v_pk_fma_f32, whose even-aligned register
+  # pairs push the weight-resident LSTM kernels over their VGPR budget (spills in the time loop)
+  case "$f" in lstm_seq*) extra="-fno-slp-vectorize" ;; esac
+  ( $HIPCC $FLAGS $extra -c "$HERE/$f.hip" -o "$HERE/build/$f.o" ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done

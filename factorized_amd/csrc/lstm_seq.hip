@@ -21,22 +21,12 @@
 //     gradients are batched GEMMs over dA afterwards (plan.hip).
 #include <type_traits>
 
+#include <stdlib.h>
+
 #include "common.h"
+#include "lstm_seq_dev.h"
 
 namespace mfm {
-
-struct SeqDev {
-  float* gates; float* hs; float* cs;
-  const float* w_hh; const float* w_ih; const float* b_ih; const float* b_hh;
-  const float* h_init; int64_t ld_init;
-  const float* dh_ext; int64_t ld_dh;
-  float* d_h_init; int64_t ld_dinit;
-  int h, Hp, hk4, is_dec, block_begin;
-};
-struct SeqLaunch {
-  SeqDev d[MFM_MAX_SEQ];
-  int count, T, B;
-};
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
@@ -347,6 +337,16 @@ __global__ __launch_bounds__(512) void lstm_seq_kernel(const SeqLaunch L) {
   }
 }
 
+// Path choice.  The VALU kernels (lstm_seq_small.hip, 4 rows per workgroup) win while the chip
+// is under-filled; the MFMA kernels (16 rows per workgroup) are the throughput path.  Override with
+// MFM_SEQ_PATH=mfma|small (tests run both).
+static bool use_small_path(int B) {
+  const char* e = getenv("MFM_SEQ_PATH");
+  if (e && e[0] == 'm') return false;
+  if (e && e[0] == 's') return true;
+  return B <= 512;
+}
+
 static int seq_launch(const MfmSeqDesc* descs, int count, int T, int B, bool bwd, hipStream_t stream) {
   MFM_REQUIRE(descs && count >= 1 && count <= MFM_MAX_SEQ, "lstm_seq: count %d out of range", count);
   MFM_REQUIRE(T >= 1 && B >= 1, "lstm_seq: T=%d B=%d", T, B);
@@ -382,6 +382,7 @@ static int seq_launch(const MfmSeqDesc* descs, int count, int T, int B, bool bwd
     const size_t need = (bwd ? 2 * 4 * HK * 16 : 2 * HK * 16) * sizeof(float);
     if (need > lds_bytes) lds_bytes = need;
   }
+  if (use_small_path(B)) return seq_small_launch(L, bwd, stream);
   if (bwd)
     hipLaunchKernelGGL(lstm_seq_kernel<true>, dim3(total), dim3(64 * max_waves), lds_bytes, stream, L);
   else

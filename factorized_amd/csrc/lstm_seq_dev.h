@@ -1,0 +1,22 @@
+// Device-side descriptors shared by the two LSTM sequence kernel families.
+#pragma once
+#include "common.h"
+
+namespace mfm {
+
+struct SeqDev {
+  float* gates; float* hs; float* cs;
+  const float* w_hh; const float* w_ih; const float* b_ih; const float* b_hh;
+  const float* h_init; int64_t ld_init;
+  const float* dh_ext; int64_t ld_dh;
+  float* d_h_init; int64_t ld_dinit;
+  int h, Hp, hk4, is_dec, block_begin;
+};
+struct SeqLaunch {
+  SeqDev d[MFM_MAX_SEQ];
+  int count, T, B;
+};
+
+int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream);
+
+}  // namespace mfm

@@ -1,0 +1,389 @@
+// Whole-sequence LSTM recurrence for SMALL batch tiles (latency regime), forward and BPTT.
+//
+// Why a second kernel family.  The MFMA kernels of lstm_seq.hip need 16 batch rows per
+// workgroup (the N dimension of v_mfma_f32_16x16x4_f32), so the reference's B=32 minibatch gives
+// two workgroups per LSTM: 14 of 256 CUs busy, ~6 us per time step (profiles/r01a).  The fp32
+// MFMA and the fp32 VALU have the SAME peak on gfx950 (64 FLOP/clk/SIMD), so when CUs are idle
+// nothing is lost by running the recurrent product on the VALU with a finer batch tile and 4x
+// more workgroups.  One workgroup owns R=4 batch rows of one LSTM and up to 1024 threads
+// (16 waves: four per SIMD hide the LDS latency; <=128 VGPRs each, ~60 of them resident weights):
+//   * forward: thread (unit u, gate pair p, k-slice q of 4) keeps W[(2p+{0,1})*h+u][4j+q] in VGPRs
+//     for all T steps; h_{t-1} sits in LDS as [k][4 rows], read as one broadcast ds_read_b128
+//     per k (8 FMAs per LDS read); the four partial sums of a quad are all-reduced with two DPP
+//     quad_perm adds; the two gate-pair lanes of (u, row q) swap their two pre-activations (DPP)
+//     and both run the pointwise LSTM math, so c stays in registers.
+//   * backward: thread (unit pair p, k-slice q of 16) keeps W^T for its two units; dA_t sits in
+//     LDS as [gate][HKB][4 rows]; partial dh are all-reduced over 16 lanes (quad_perm x2,
+//     row_half_mirror, row_mirror); lane q<8 owns (unit 2p+(q>>2), row q&3) for the gate-gradient
+//     math.
+//   * weights reach the registers through LDS: each gate's [h x h] block is copied coalesced into
+//     a panel and every thread picks its (strided / transposed) elements from there -- per-thread
+//     global gathers of W^T cost ~30-90 us per launch (profiles/r01 seq micro-benchmark).
+// Buffers, layouts and the encoder/decoder forms are exactly those of lstm_seq.hip.
+#include <type_traits>
+
+#include "internal.h"
+#include "lstm_seq_dev.h"
+
+namespace mfm {
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;        // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;        // quad_perm:[2,3,0,1]
+constexpr int DPP_QUAD_REV = 0x1B;         // quad_perm:[3,2,1,0]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+// lane i <-> lane i^4 inside each group of 8: half-mirror (i -> 7-i) then quad reverse (i -> i^3)
+__device__ __forceinline__ float dpp_xor4(float x) { return dpp_f<DPP_QUAD_REV>(dpp_f<DPP_ROW_HALF_MIRROR>(x)); }
+
+// Copy one gate's [h x h] weight block into the LDS panel, coalesced, 4 loads in flight per thread.
+// mode 0: W_hh   1: W_ih   2: W_ih + W_hh (decoder steps >= 1, mfm_model.py:85)
+__device__ __forceinline__ void stage_gate(const SeqDev& d, int mode, int g, float* __restrict__ panel, int tid,
+                                           int nt) {
+  const int n = d.h * d.h;
+  const float* __restrict__ a = (mode == 0 ? d.w_hh : d.w_ih) + (int64_t)g * n;
+  const float* __restrict__ b2 = d.w_hh + (int64_t)g * n;
+  if ((n & 3) == 0) {
+    const int n4 = n >> 2;
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(b2);
+    f32x4* p4 = reinterpret_cast<f32x4*>(panel);
+    for (int base = tid; base < n4; base += 4 * nt) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = min(base + u * nt, n4 - 1);
+        v[u] = a4[i];
+        if (mode == 2) v[u] += b4[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (base + u * nt < n4) p4[base + u * nt] = v[u];
+    }
+  } else {
+    for (int i = tid; i < n; i += nt) panel[i] = (mode == 2) ? a[i] + b2[i] : a[i];
+  }
+}
+
+// --------------------------------------------------------------------------------- forward
+template <int KQ>
+__device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds) {
+  constexpr int R = 4;
+  constexpr int HK = 4 * KQ;        // padded hidden extent
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int q = tid & 3, gp = (tid >> 2) & 1, u = tid >> 3;
+  const int h = d.h, Hp = d.Hp;
+  const bool dec = d.is_dec != 0;
+  const bool uact = u < Hp;
+  const int b = tile * R + q;
+  const bool bvalid = uact && (b < B);
+
+  float* hbuf = lds;                 // [2][HK][R]
+  float* panel = lds + 2 * HK * R;   // [2][h][h] weight staging (two gates at a time)
+
+  float w[2][KQ];
+  // round gl stages gates gl (for the p=0 lanes) and 2+gl (p=1 lanes) side by side, so every
+  // lane picks its own gate with an address, not a predicate
+  auto load_w = [&](int mode) {
+    const int n = h * h;
+    const int uc = min(u, h - 1);
+#pragma unroll
+    for (int gl = 0; gl < 2; ++gl) {
+      stage_gate(d, mode, gl, panel, tid, nt);
+      stage_gate(d, mode, 2 + gl, panel + n, tid, nt);
+      __syncthreads();
+      const float* src = panel + gp * n + uc * h;
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) {
+        const int k = 4 * j + q;
+        const float v = src[min(k, h - 1)];
+        w[gl][j] = (u < h && k < h) ? v : 0.0f;
+      }
+      __syncthreads();
+    }
+  };
+  load_w(dec ? 1 : 0);
+
+  // per-lane constant (decoder: bias) or per-step prefetched (encoder: x projection) additive term
+  float gxb[2] = {0.f, 0.f};
+  if (dec && u < h) {
+#pragma unroll
+    for (int gl = 0; gl < 2; ++gl) gxb[gl] = d.b_ih[(2 * gp + gl) * h + u] + d.b_hh[(2 * gp + gl) * h + u];
+  }
+  if (dec) {
+    for (int idx = tid; idx < HK * R; idx += nt) {
+      const int k = idx >> 2, br = tile * R + (idx & 3);
+      hbuf[idx] = (k < h && br < B) ? d.h_init[(int64_t)br * d.ld_init + k] : 0.0f;
+    }
+    __syncthreads();
+  }
+
+  const int64_t row4 = 4 * (int64_t)Hp;
+  if (!dec && bvalid) {
+#pragma unroll
+    for (int gl = 0; gl < 2; ++gl) gxb[gl] = d.gates[(int64_t)b * row4 + (2 * gp + gl) * Hp + u];
+  }
+
+  float c = 0.0f;
+  int cur = 0;
+  auto step = [&](const int t) {
+    const int64_t rowt = (int64_t)t * B + b;
+    float acc[2][R];
+#pragma unroll
+    for (int gl = 0; gl < 2; ++gl)
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[gl][r] = 0.0f;
+    if (dec || t > 0) {
+      const float* hb = hbuf + cur * (HK * R) + q * R;
+      constexpr int RING = (KQ < 4) ? KQ : 4;      // LDS reads kept in flight ahead of their FMAs
+      f32x4 ring[RING];
+#pragma unroll
+      for (int j = 0; j < RING; ++j) ring[j] = *reinterpret_cast<const f32x4*>(hb + 16 * j);
+#pragma unroll
+      for (int j = 0; j < KQ; ++j) {
+        const f32x4 hv = ring[j % RING];                                   // rows 0..3 of k = 4j+q
+        if (j + RING < KQ) ring[j % RING] = *reinterpret_cast<const f32x4*>(hb + 16 * (j + RING));
+#pragma unroll
+        for (int gl = 0; gl < 2; ++gl)
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc[gl][r] = fmaf(w[gl][j], hv[r], acc[gl][r]);
+      }
+    }
+    // all-reduce the four k-slices of the quad, keep the sums of batch row q, add bias / x-projection
+    float mine[2];
+#pragma unroll
+    for (int gl = 0; gl < 2; ++gl) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float v = acc[gl][r];
+        v += dpp_f<DPP_QUAD_XOR1>(v);
+        v += dpp_f<DPP_QUAD_XOR2>(v);
+        acc[gl][r] = v;
+      }
+      const float lo = (q & 1) ? acc[gl][1] : acc[gl][0];
+      const float hi = (q & 1) ? acc[gl][3] : acc[gl][2];
+      mine[gl] = ((q & 2) ? hi : lo) + gxb[gl];
+    }
+    if (!dec && t + 1 < T && bvalid) {
+#pragma unroll
+      for (int gl = 0; gl < 2; ++gl) gxb[gl] = d.gates[(rowt + B) * row4 + (2 * gp + gl) * Hp + u];
+    }
+    // the partner lane (same unit and row, other gate pair) holds the other two pre-activations
+    const float o0 = dpp_xor4(mine[0]), o1 = dpp_xor4(mine[1]);
+    const float pi = gp ? o0 : mine[0], pf = gp ? o1 : mine[1];
+    const float pg = gp ? mine[0] : o0, po = gp ? mine[1] : o1;
+    const float gi = act_sigmoid(pi);
+    const float gf = act_sigmoid(pf);
+    const float gg = act_tanh(pg);
+    const float go = act_sigmoid(po);
+    c = gf * c + gi * gg;
+    const float hv = go * act_tanh(c);
+    if (bvalid) {
+      float* gpt = d.gates + rowt * row4 + u;
+      if (gp == 0) { gpt[0] = gi; gpt[Hp] = gf; d.cs[rowt * Hp + u] = c; }
+      else { gpt[2 * Hp] = gg; gpt[3 * Hp] = go; d.hs[rowt * Hp + u] = hv; }
+    }
+    if (uact && gp == 0 && u < HK) hbuf[(cur ^ 1) * (HK * R) + u * R + q] = (b < B) ? hv : 0.0f;
+    __syncthreads();
+    cur ^= 1;
+  };
+  // The decoder's step 0 (W_ih on the embedding) is peeled so that the weight reload sits between
+  // two clean loops instead of inside one (keeps its temporaries out of the hot loop's registers).
+  if (dec) {
+    step(0);
+    if (T > 1) {
+      load_w(2);                       // steps >= 1 feed h back as the input: W_ih + W_hh
+      for (int t = 1; t < T; ++t) step(t);
+    }
+  } else {
+    for (int t = 0; t < T; ++t) step(t);
+  }
+}
+
+// --------------------------------------------------------------------------------- backward
+template <int KQ>
+__device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds) {
+  constexpr int R = 4;
+  constexpr int HK = 4 * KQ;                       // padded hidden extent
+  constexpr int HKB = (HK + 15) / 16 * 16;         // per-gate extent of the dA panel (multiple of 16)
+  constexpr int NG = HKB / 16;                     // gate columns per thread and gate
+  constexpr int NW = 4 * NG;                       // gate columns per thread: k = g*HKB + 16 i + q
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int q = tid & 15, up = tid >> 4;
+  const int h = d.h, Hp = d.Hp;
+  const bool dec = d.is_dec != 0;
+  const int ua = 2 * up, ub = 2 * up + 1;           // the two output units whose W^T rows this thread holds
+  const int mu = 2 * up + ((q >> 2) & 1), mr = q & 3;   // the (unit,row) lanes q<8 own in the pointwise part
+  const bool own = (q < 8) && (mu < Hp);
+  const int b = tile * R + mr;
+  const bool bvalid = own && (b < B);
+
+  float* dabuf = lds;                       // [2][4][HKB][R]
+  float* panel = lds + 2 * 4 * HKB * R;     // [h][h] weight staging
+
+  float wa[NW], wb[NW];
+  auto load_wT = [&](int mode) {
+    const int uac = min(ua, h - 1), ubc = min(ub, h - 1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      stage_gate(d, mode, g, panel, tid, nt);
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NG; ++i) {
+        const int j = 16 * i + q;                    // unit index of this gate column
+        const int jc = min(j, h - 1);
+        const float va = panel[jc * h + uac], vb = panel[jc * h + ubc];
+        wa[g * NG + i] = (j < h && ua < h) ? va : 0.0f;
+        wb[g * NG + i] = (j < h && ub < h) ? vb : 0.0f;
+      }
+      __syncthreads();
+    }
+  };
+  load_wT(dec ? 2 : 0);
+
+  const int64_t row4 = 4 * (int64_t)Hp;
+  float dh_rec = 0.0f, dc = 0.0f;
+  int cur = 0;
+
+  auto step = [&](const int t) {
+    const int64_t rowt = (int64_t)t * B + b;
+    float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, ct = 0.f, cp = 0.f, ext = 0.f;
+    float* gpt = d.gates + rowt * row4 + mu;
+    if (bvalid) {
+      gi = gpt[0]; gf = gpt[Hp]; gg = gpt[2 * Hp]; go = gpt[3 * Hp];
+      ct = d.cs[rowt * Hp + mu];
+      if (t > 0) cp = d.cs[(rowt - B) * Hp + mu];
+      if (dec) ext = d.dh_ext[rowt * Hp + mu];
+      else if (t == T - 1 && mu < h) ext = d.dh_ext[(int64_t)b * d.ld_dh + mu];
+    }
+    const float dh = dh_rec + ext;
+    const float tc = act_tanh(ct);
+    const float dot = dh * tc;
+    const float dct = dh * go * (1.0f - tc * tc) + dc;
+    float da[4];
+    da[0] = dct * gg * gi * (1.0f - gi);
+    da[1] = dct * cp * gf * (1.0f - gf);
+    da[2] = dct * gi * (1.0f - gg * gg);
+    da[3] = dot * go * (1.0f - go);
+    dc = dct * gf;
+    if (bvalid) { gpt[0] = da[0]; gpt[Hp] = da[1]; gpt[2 * Hp] = da[2]; gpt[3 * Hp] = da[3]; }
+
+    const bool need_rec = (t > 0) || dec;
+    if (need_rec) {
+      float* db = dabuf + cur * (4 * HKB * R);
+      if (own && mu < HKB) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) db[(g * HKB + mu) * R + mr] = da[g];
+      }
+      __syncthreads();
+      float aa[R] = {0.f, 0.f, 0.f, 0.f}, ab[R] = {0.f, 0.f, 0.f, 0.f};
+      const float* dp = db + q * R;
+      constexpr int RING = (NW < 4) ? NW : 4;
+      f32x4 ring[RING];
+#pragma unroll
+      for (int i = 0; i < RING; ++i) ring[i] = *reinterpret_cast<const f32x4*>(dp + 64 * i);
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const f32x4 dv = ring[i % RING];                                   // rows 0..3 of column 16i+q
+        if (i + RING < NW) ring[i % RING] = *reinterpret_cast<const f32x4*>(dp + 64 * (i + RING));
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          aa[r] = fmaf(wa[i], dv[r], aa[r]);
+          ab[r] = fmaf(wb[i], dv[r], ab[r]);
+        }
+      }
+      // all-reduce over the 16 k-slices
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float v = aa[r];
+        v += dpp_f<DPP_QUAD_XOR1>(v); v += dpp_f<DPP_QUAD_XOR2>(v);
+        v += dpp_f<DPP_ROW_HALF_MIRROR>(v); v += dpp_f<DPP_ROW_MIRROR>(v);
+        aa[r] = v;
+        v = ab[r];
+        v += dpp_f<DPP_QUAD_XOR1>(v); v += dpp_f<DPP_QUAD_XOR2>(v);
+        v += dpp_f<DPP_ROW_HALF_MIRROR>(v); v += dpp_f<DPP_ROW_MIRROR>(v);
+        ab[r] = v;
+      }
+      const float la = (mr & 1) ? aa[1] : aa[0], ha = (mr & 1) ? aa[3] : aa[2];
+      const float lb = (mr & 1) ? ab[1] : ab[0], hb = (mr & 1) ? ab[3] : ab[2];
+      const float sa = (mr & 2) ? ha : la, sb = (mr & 2) ? hb : lb;
+      dh_rec = (q & 4) ? sb : sa;
+      cur ^= 1;
+    }
+  };
+  for (int t = T - 1; t >= 1; --t) step(t);
+  if (dec) load_wT(1);                 // grad wrt the step-0 input goes through W_ih only (peeled)
+  step(0);
+  if (dec && bvalid && d.d_h_init && mu < h) d.d_h_init[(int64_t)b * d.ld_dinit + mu] = dh_rec;
+}
+
+#define MFM_SMALL_CASES(BODY)                                                                \
+  switch (d.hk4) {                                                                           \
+    case 2: BODY<2>(d, L.T, L.B, tile, lds); break;                                          \
+    case 4: BODY<4>(d, L.T, L.B, tile, lds); break;                                          \
+    case 6: BODY<6>(d, L.T, L.B, tile, lds); break;                                          \
+    case 8: BODY<8>(d, L.T, L.B, tile, lds); break;                                          \
+    case 10: BODY<10>(d, L.T, L.B, tile, lds); break;                                        \
+    case 12: BODY<12>(d, L.T, L.B, tile, lds); break;                                        \
+    case 14: BODY<14>(d, L.T, L.B, tile, lds); break;                                        \
+    case 16: BODY<16>(d, L.T, L.B, tile, lds); break;                                        \
+    case 18: BODY<18>(d, L.T, L.B, tile, lds); break;                                        \
+    case 20: BODY<20>(d, L.T, L.B, tile, lds); break;                                        \
+    case 22: BODY<22>(d, L.T, L.B, tile, lds); break;                                        \
+    case 24: BODY<24>(d, L.T, L.B, tile, lds); break;                                        \
+    case 26: BODY<26>(d, L.T, L.B, tile, lds); break;                                        \
+    case 28: BODY<28>(d, L.T, L.B, tile, lds); break;                                        \
+    case 30: BODY<30>(d, L.T, L.B, tile, lds); break;                                        \
+    case 32: BODY<32>(d, L.T, L.B, tile, lds); break;                                        \
+    default: break;                                                                          \
+  }
+
+template <bool BWD>
+__global__ __launch_bounds__(1024) void lstm_seq_small_kernel(const SeqLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int di = 0;
+  const int bid = blockIdx.x;
+#pragma unroll 1
+  for (int i = 1; i < L.count; ++i)
+    if (bid >= L.d[i].block_begin) di = i;
+  const SeqDev& d = L.d[di];
+  const int tile = bid - d.block_begin;
+  if (BWD) {
+    MFM_SMALL_CASES(small_bwd_body)
+  } else {
+    MFM_SMALL_CASES(small_fwd_body)
+  }
+}
+
+int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
+  const int tiles = cdiv(L.B, 4);
+  int total = 0, max_threads = 64;
+  size_t lds_bytes = 0;
+  for (int i = 0; i < L.count; ++i) {
+    SeqDev& d = L.d[i];
+    d.block_begin = total;
+    total += tiles;
+    if (8 * d.Hp > max_threads) max_threads = 8 * d.Hp;
+    const size_t HK = (size_t)d.hk4 * 4;
+    const size_t HKB = (HK + 15) / 16 * 16;
+    const size_t need = (bwd ? 2 * 4 * HKB * 4 + (size_t)d.h * d.h : 2 * HK * 4 + 2 * (size_t)d.h * d.h) * sizeof(float);
+    if (need > lds_bytes) lds_bytes = need;
+  }
+  if (lds_bytes > 64 * 1024) {
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_kernel<true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_kernel<false>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  }
+  if (bwd)
+    hipLaunchKernelGGL(lstm_seq_small_kernel<true>, dim3(total), dim3(max_threads), lds_bytes, stream, L);
+  else
+    hipLaunchKernelGGL(lstm_seq_small_kernel<false>, dim3(total), dim3(max_threads), lds_bytes, stream, L);
+  MFM_LAUNCH_CHECK(bwd ? "lstm_seq_small_bwd_kernel" : "lstm_seq_small_fwd_kernel");
+  return MFM_OK;
+}
+
+}  // namespace mfm

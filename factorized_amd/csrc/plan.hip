@@ -197,7 +197,7 @@ static int build(MfmPlan* P) {
   }
   L.rows_per_wg = R;
 
-  P->lat_ops_off = carve(cur, (int64_t)(sizeof(P->lat_ops) / sizeof(float)));
+  P->lat_ops_off = carve(cur, (int64_t)(sizeof(P->lat_ops) / (sizeof(float))));
   P->lat_rec = carve(cur, (int64_t)c.B * rs);
   P->yhat = carve(cur, (int64_t)c.B * c.output_dim);
   P->ones = carve(cur, TB);

@@ -128,8 +128,15 @@ SEQ_SHAPES = [(8, 5, 1, 3), (8, 5, 32, 20), (24, 7, 33, 4), (32, 300, 32, 20), (
               (104, 9, 16, 5), (120, 325, 32, 20), (20, 6, 5, 1), (128, 4, 3, 2), (36, 10, 40, 3)]
 
 
+@pytest.fixture(params=["mfma", "small"])
+def seq_path(request, monkeypatch):
+    """Both recurrent kernel families: MFMA (16 rows/workgroup) and VALU small-tile (4 rows)."""
+    monkeypatch.setenv("MFM_SEQ_PATH", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("h,d,B,T", SEQ_SHAPES)
-def test_lstm_seq_encoder_fwd_bwd(eng, h, d, B, T):
+def test_lstm_seq_encoder_fwd_bwd(eng, seq_path, h, d, B, T):
     rs = np.random.RandomState(h * 7 + B)
     k = 1.0 / np.sqrt(h)
     w_ih = rs.uniform(-k, k, size=(4 * h, d)).astype(np.float32)
@@ -168,7 +175,7 @@ def test_lstm_seq_encoder_fwd_bwd(eng, h, d, B, T):
 
 
 @pytest.mark.parametrize("h,B,T", [(24, 32, 20), (104, 32, 20), (24, 5, 1), (40, 19, 3), (112, 33, 7)])
-def test_lstm_seq_decoder_fwd_bwd(eng, h, B, T):
+def test_lstm_seq_decoder_fwd_bwd(eng, seq_path, h, B, T):
     rs = np.random.RandomState(h + B + T)
     k = 1.0 / np.sqrt(h)
     w_ih = rs.uniform(-k, k, size=(4 * h, h)).astype(np.float32)
@@ -210,7 +217,7 @@ def test_lstm_seq_decoder_fwd_bwd(eng, h, B, T):
         assert rel_err(dW_hh, cell.weight_hh.grad.numpy()) < TOL
 
 
-def test_lstm_seq_four_in_one_launch(eng):
+def test_lstm_seq_four_in_one_launch(eng, seq_path):
     """The 4 encoders of the canonical model share one launch; results must equal solo launches."""
     rs = np.random.RandomState(0)
     T, B = 20, 32

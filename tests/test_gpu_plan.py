@@ -51,8 +51,14 @@ def test_forward_matches_reference_golden(name):
     assert np.allclose(cases.summarize(xl)[:2], gold["x_l_hat_sum"][:2], rtol=TOL, atol=1e-4)
 
 
+@pytest.fixture(params=["mfma", "small"])
+def seq_path(request, monkeypatch):
+    monkeypatch.setenv("MFM_SEQ_PATH", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("name", cases.KLEF_CASES)
-def test_gradients_match_oracle_and_golden(name):
+def test_gradients_match_oracle_and_golden(name, seq_path):
     cs = cases.load_case(name)
     e, w = _engine(cs)
     cfg = cs["cfg"]
