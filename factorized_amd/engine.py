@@ -250,6 +250,15 @@ class MFMEngine:
                    "mfm_plan_backward")
         return self.grads
 
+    def backward_ext(self, x, d_xl, d_xa, d_xv, d_yhat, d_reg):
+        """Backward of the last forward() for arbitrary upstream gradients (autograd module path)."""
+        T, B, _ = x.shape
+        p = self.plan(T, B)
+        _lib.check(_lib.lib().mfm_plan_backward_ext(p.handle, _ptr(self.params), _ptr(x), _ptr(d_xl), _ptr(d_xa),
+                                                    _ptr(d_xv), _ptr(d_yhat), _ptr(d_reg), _ptr(p.workspace),
+                                                    _ptr(self.grads), _stream()), "mfm_plan_backward_ext")
+        return self.grads
+
     def train_step(self, x, y, lr=1e-3, grad_scale=1.0, check=True):
         """forward(train) + backward(joint loss) + Adam, one enqueue.  Returns the device
         tensor of loss slots (no sync)."""

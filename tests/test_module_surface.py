@@ -1,0 +1,42 @@
+"""The nn.Module mirror keeps the reference's class surface: constructor signature, attribute /
+state_dict names and shapes (CPU-only checks; the compute runs in tests/test_gpu_module.py)."""
+import pytest
+import torch
+
+from factorized_amd import configs, mfm_model as M
+from oracle import mfm_oracle as O
+
+
+def test_state_dict_matches_reference_keys_and_shapes():
+    cfgs = configs.canonical_configs()
+    m = M.MFM_KL_EF(*cfgs)
+    ref = O.build("kl_ef", cfgs)          # pinned to the reference by tests/test_oracle_golden.py
+    sd, rd = m.state_dict(), ref.state_dict()
+    assert list(sd.keys()) == list(rd.keys())
+    assert all(tuple(sd[k].shape) == tuple(rd[k].shape) for k in sd)
+    m.load_state_dict(rd)                 # a reference checkpoint loads cleanly
+
+
+def test_blocks_have_reference_attributes():
+    e = M.encoderLSTM(5, 8)
+    d = M.decoderLSTM(24, 5)
+    assert isinstance(e.lstm, torch.nn.LSTMCell) and isinstance(e.fc1, torch.nn.Linear) and e.h == 8
+    assert d.lstm.weight_ih.shape == (96, 24) and d.fc1.weight.shape == (5, 24) and d.h == 24 and d.d == 5
+
+
+def test_no_cpu_fallback():
+    cfgs = configs.canonical_configs()
+    m = M.MFM_KL_EF(*cfgs)
+    with pytest.raises(Exception) as ei:
+        m.forward(torch.zeros(3, 2, 325))
+    assert "no CPU fallback" in str(ei.value) or "GPU" in str(ei.value)
+    with pytest.raises(Exception):
+        M.encoderLSTM(5, 8).forward(torch.zeros(3, 2, 5))
+
+
+def test_loss_helpers_match_oracle():
+    g = torch.Generator().manual_seed(0)
+    mu, lv = torch.randn(7, 5, generator=g), torch.randn(7, 5, generator=g)
+    assert torch.allclose(M.loss_KLD(mu, lv), O.kld_sum(mu, lv))
+    z, gs = torch.randn(6, 4, generator=g), torch.randn(6, 4, generator=g)
+    assert torch.allclose(M.loss_MMD(z, gs), O.mmd(z, gs))
