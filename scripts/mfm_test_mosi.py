@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Python-3 restatement of the reference's MOSI driver loop on the MI355X path.
+
+The reference README tells users to run `mfm_test_mosi.py --config configs/mosi.json`
+(README.md:36); the nearest real file is the Python-2 `mfm_mosi.py`.  This script keeps its
+shape -- argparse `--config`, `seqlength` read from the JSON (mfm_mosi.py:33-47), one shuffle with
+numpy seed 123 (:387-389), floor-division batch count (:423), Adam defaults (:403),
+ReduceLROnPlateau('min') on the validation L1 (:417,472), best-checkpoint rule (:473-477), the
+`epoch train valid` log line (:476-479) and score() metrics (:483-499) -- but trains on synthetic
+MOSI-shape data (the CMU-MOSI pickles are private) with the fused MI355X step.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from factorized_amd import configs as C, synth  # noqa: E402
+from factorized_amd.mfm_model import MFM_KL_EF  # noqa: E402
+
+
+def score(pred, y):
+    mae = float(np.mean(np.absolute(pred - y)))
+    corr = float(np.corrcoef(pred, y)[0][1])
+    mult = round(float(np.sum(np.round(pred) == np.round(y))) / float(len(y)), 5)
+    acc = float(np.mean((pred >= 0) == (y >= 0)))
+    print("mae: ", mae); print("corr: ", corr); print("mult_acc: ", mult); print("Accuracy ", acc)
+    sys.stdout.flush()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default=os.path.join(os.path.dirname(__file__), "..", "configs", "mosi.json"))
+    ap.add_argument("--epochs", type=int, default=5)
+    ap.add_argument("--n-train", type=int, default=1280)
+    args = ap.parse_args()
+    _, T = C.load_json_config(args.config)                  # only `seqlength` is read, as in the reference
+    cfgs = C.canonical_configs(dropout=True)
+    cfg = cfgs[0]
+    np.random.seed(123)
+    Xtr, ytr = synth.make_dataset(cfg["input_dims"], args.n_train, T, seed=11)
+    Xva, yva = synth.make_dataset(cfg["input_dims"], 229, T, seed=12)
+    Xte, yte = synth.make_dataset(cfg["input_dims"], 686, T, seed=13)
+    p = np.random.permutation(Xtr.shape[1])
+    Xtr, ytr = Xtr[:, p], ytr[p]
+    dev = torch.device("cuda")
+    model = MFM_KL_EF(*cfgs).to(dev)
+    eng = model.engine                                     # fused step on the module's own storage
+    lr = 1e-3
+    best, bad, factor, patience = 999999.0, 0, 0.1, 10     # ReduceLROnPlateau('min') defaults
+    bs = cfg["batchsize"]
+    nb = Xtr.shape[1] // bs
+    Xd = torch.from_numpy(np.ascontiguousarray(Xtr[:, :nb * bs].reshape(T, nb, bs, -1).transpose(1, 0, 2, 3))).to(dev)
+    yd = torch.from_numpy(ytr[:nb * bs].reshape(nb, bs)).to(dev)
+    xv, yv = torch.from_numpy(Xva).to(dev), torch.from_numpy(yva).to(dev)
+    for epoch in range(args.epochs):
+        model.train()
+        acc = torch.zeros((), device=dev)
+        for b in range(nb):
+            losses = eng.train_step(Xd[b], yd[b], lr=lr)
+            acc += losses[0]                               # disc loss, accumulated on device (no per-step sync)
+        train_loss = acc.item() / nb
+        model.eval()
+        out = eng.forward(xv, yv, train=False, want_xhat=False)
+        valid_loss = eng.loss_dict(out["losses"])["disc"]
+        if valid_loss < best * (1 - 1e-4):
+            bad = 0
+        else:
+            bad += 1
+            if bad > patience:
+                lr, bad = lr * factor, 0
+        if valid_loss <= best:
+            best = valid_loss
+            print(epoch, train_loss, valid_loss, "saving model")
+            best_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        else:
+            print(epoch, train_loss, valid_loss)
+        sys.stdout.flush()
+    model.load_state_dict(best_state)
+    model.eval()
+    with torch.no_grad():
+        decoded, _, _ = model.forward(torch.from_numpy(Xte).to(dev))
+    print("scoring y_hat")
+    score(decoded[3].squeeze(1).cpu().numpy(), yte)
+
+
+if __name__ == "__main__":
+    main()
