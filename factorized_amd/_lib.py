@@ -65,6 +65,7 @@ _SIGS = {
                                   C.POINTER(C.c_void_p)]),
     "mfm_plan_destroy": (None, [C.c_void_p]),
     "mfm_plan_workspace_bytes": (C.c_int64, [C.c_void_p]),
+    "mfm_plan_debug_offset": (C.c_int64, [C.c_void_p]),
     "mfm_plan_init_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mfm_plan_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

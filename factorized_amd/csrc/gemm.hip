@@ -11,7 +11,7 @@
 
 namespace mfm {
 
-#define MFM_GEMM_MAXP 16
+#define MFM_GEMM_MAXP 24   // 24 x 168 B of descriptors stay inside the 4 KB kernel-argument segment
 constexpr int BK = 16;
 
 struct GemmProblem {
@@ -59,16 +59,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   const bool a_mcontig = (d.a_sm == 1 && d.a_sk != 1);
   const bool b_ncontig = (d.b_sn == 1 && d.b_sk != 1);
 
-  float ra[EPT_A], rb[EPT_B];
+  // Register ring of DEPTH K-tiles in flight: at these sizes (K = 300..640, a handful of MFMAs per
+  // tile) the K loop is a chain of global-load round trips, so the loads of tile kt+DEPTH are
+  // issued as soon as tile kt has been copied to LDS.
+  constexpr int DEPTH = 4;
+  float ra[DEPTH][EPT_A], rb[DEPTH][EPT_B];
 
-  auto load_tiles = [&](int k0) {
+  auto load_tiles = [&](int slot, int k0) {
 #pragma unroll
     for (int j = 0; j < EPT_A; ++j) {
       const int idx = tid * EPT_A + j;
       int m, k;
       if (a_mcontig) { k = idx / BM; m = idx % BM; } else { m = idx / BK; k = idx % BK; }
       const int gm = m0 + m, gk = k0 + k;
-      ra[j] = (gm < d.m && gk < kend) ? A[(int64_t)gm * d.a_sm + (int64_t)gk * d.a_sk] : 0.0f;
+      // unconditional load from a clamped (always valid) address + select: no branch, so the
+      // compiler can keep several tiles' loads in flight with counted vmcnt waits
+      const float v = A[(int64_t)min(gm, d.m - 1) * d.a_sm + (int64_t)min(gk, kend - 1) * d.a_sk];
+      ra[slot][j] = v * (float)((int)(gm < d.m) & (int)(gk < kend));   // multiply, not select: stays branch-free
     }
 #pragma unroll
     for (int j = 0; j < EPT_B; ++j) {
@@ -76,23 +83,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
       int n, k;
       if (b_ncontig) { k = idx / BN; n = idx % BN; } else { n = idx / BK; k = idx % BK; }
       const int gn = n0 + n, gk = k0 + k;
-      rb[j] = (gn < d.n_valid && gk < kend) ? Bm[(int64_t)gk * d.b_sk + (int64_t)gn * d.b_sn] : 0.0f;
+      const float v = Bm[(int64_t)min(gk, kend - 1) * d.b_sk + (int64_t)min(gn, d.n_valid - 1) * d.b_sn];
+      rb[slot][j] = v * (float)((int)(gn < d.n_valid) & (int)(gk < kend));
     }
   };
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](int slot) {
 #pragma unroll
     for (int j = 0; j < EPT_A; ++j) {
       const int idx = tid * EPT_A + j;
       int m, k;
       if (a_mcontig) { k = idx / BM; m = idx % BM; } else { m = idx / BK; k = idx % BK; }
-      As[k * LDA + m] = ra[j];
+      As[k * LDA + m] = ra[slot][j];
     }
 #pragma unroll
     for (int j = 0; j < EPT_B; ++j) {
       const int idx = tid * EPT_B + j;
       int n, k;
       if (b_ncontig) { k = idx / BN; n = idx % BN; } else { n = idx / BK; k = idx % BK; }
-      Bs[k * LDB + n] = rb[j];
+      Bs[k * LDB + n] = rb[slot][j];
     }
   };
 
@@ -103,25 +111,33 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
     for (int j = 0; j < FR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (kend - kbeg + BK - 1) / BK;
-  if (nkt > 0) load_tiles(kbeg);
-  for (int kt = 0; kt < nkt; ++kt) {
-    store_tiles();
-    __syncthreads();
-    if (kt + 1 < nkt) load_tiles(kbeg + (kt + 1) * BK);
 #pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      float af[FR], bf[FR];
+  for (int s = 0; s < DEPTH; ++s)
+    if (s < nkt) load_tiles(s, kbeg + s * BK);
+  for (int kt0 = 0; kt0 < nkt; kt0 += DEPTH) {
 #pragma unroll
-      for (int f = 0; f < FR; ++f) {
-        af[f] = As[(ks * 4 + q) * LDA + wm * 16 * FR + f * 16 + bi];
-        bf[f] = Bs[(ks * 4 + q) * LDB + wn * 16 * FR + f * 16 + bi];
+    for (int s = 0; s < DEPTH; ++s) {
+      const int kt = kt0 + s;
+      if (kt < nkt) {
+        store_tiles(s);
+        __syncthreads();
+        if (kt + DEPTH < nkt) load_tiles(s, kbeg + (kt + DEPTH) * BK);
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+          float af[FR], bf[FR];
+#pragma unroll
+          for (int f = 0; f < FR; ++f) {
+            af[f] = As[(ks * 4 + q) * LDA + wm * 16 * FR + f * 16 + bi];
+            bf[f] = Bs[(ks * 4 + q) * LDB + wn * 16 * FR + f * 16 + bi];
+          }
+#pragma unroll
+          for (int fm = 0; fm < FR; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FR; ++fn) acc[fm][fn] = mma16x16x4(af[fm], bf[fn], acc[fm][fn]);
+        }
+        __syncthreads();
       }
-#pragma unroll
-      for (int fm = 0; fm < FR; ++fm)
-#pragma unroll
-        for (int fn = 0; fn < FR; ++fn) acc[fm][fn] = mma16x16x4(af[fm], bf[fn], acc[fm][fn]);
     }
-    __syncthreads();
   }
 
   // ---- epilogue

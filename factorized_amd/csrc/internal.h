@@ -58,6 +58,8 @@ struct LatentDev {
   const float* d_yhat_ext;             // optional upstream gradient wrt y_hat [B, od] (module path)
   const float* reg_w_ptr;              // optional device scalar: upstream gradient wrt the KLD sum
   float* losses;
+  float* grd_out;                      // [B, rec_size] gradient record written by the backward
+  unsigned long long* dbg;             // optional: block 0 / thread 0 writes s_memtime at phase marks
   int B, rows_per_wg, train, has_logvar;
   uint64_t seed;
   float reg_w, disc_w, gen_w;

@@ -33,6 +33,11 @@ __device__ __forceinline__ float wave_sum_l(float v) {
   return v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+
 // linear global -> LDS copy of `n4` 16-byte chunks, 8 loads in flight per thread
 __device__ __forceinline__ void copy_span(const float* __restrict__ src, float* __restrict__ dst, int n4, int tid,
                                           int nt) {
@@ -49,21 +54,75 @@ __device__ __forceinline__ void copy_span(const float* __restrict__ src, float* 
   }
 }
 
+// Register prefetch of a stage's weight span: the loads are issued one stage ahead (they overlap the
+// previous stage's compute), the LDS writes happen when the panel is free.  Covers the first
+// 8*nt chunks; copy_span handles a longer tail.
+constexpr int PRE_U = 8;
+__device__ __forceinline__ void span_load(const float* __restrict__ src, int n4, int tid, int nt, f32x4 (&pre)[PRE_U]) {
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+  for (int u = 0; u < PRE_U; ++u) pre[u] = s4[min(tid + u * nt, max(n4 - 1, 0))];
+}
+__device__ __forceinline__ void span_store(const float* __restrict__ src, float* __restrict__ dst, int n4, int tid,
+                                           int nt, const f32x4 (&pre)[PRE_U]) {
+  f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+#pragma unroll
+  for (int u = 0; u < PRE_U; ++u)
+    if (tid + u * nt < n4) d4[tid + u * nt] = pre[u];
+  if (n4 > PRE_U * nt) copy_span(src + 4 * PRE_U * nt, dst + 4 * PRE_U * nt, n4 - PRE_U * nt, tid, nt);
+}
+
+// debug: phase timestamps of workgroup 0 (shader clock), enabled with MFM_LATENT_DBG=1
+__device__ __forceinline__ void mark(const LatentDev& L, int slot) {
+  if (L.dbg && blockIdx.x == 0 && threadIdx.x == 0) L.dbg[slot] = __builtin_readcyclecounter();
+}
+
 __device__ __forceinline__ void load_ops(const LatentDev& L, LatOp* ops) {
   for (int i = threadIdx.x; i < L.nops * (int)(sizeof(LatOp) / 4); i += blockDim.x)
     reinterpret_cast<int*>(ops)[i] = reinterpret_cast<const int*>(L.ops)[i];
 }
 
+// Per-stage exclusive prefix sums of the ops' N and K (read from the global table, so no barrier
+// is needed before this).  find_op() then maps a work-item index to its op with <= 7 INDEPENDENT
+// LDS reads and compares: a per-lane "while (local >= n) ++o" walk costs one dependent LDS round
+// trip per step, ~2000 cycles per item in the 8-op stages.
+__device__ __forceinline__ void build_prefix(const LatentDev& L, int* pfxN, int* pfxK) {
+  if (threadIdx.x == 0) {
+    for (int s = 0; s < L.nstages; ++s) {
+      int an = 0, ak = 0;
+      for (int o = L.stage_begin[s]; o < L.stage_begin[s + 1]; ++o) {
+        pfxN[o] = an; pfxK[o] = ak;
+        an += L.ops[o].N; ak += L.ops[o].K;
+      }
+    }
+  }
+}
+__device__ __forceinline__ int find_op(const int* pfx, int ob, int oe, int x, int mult) {
+  int o = ob;
+#pragma unroll
+  for (int i = 1; i < 8; ++i) {
+    const int idx = min(ob + i, oe - 1);
+    const int p = pfx[idx] * mult;
+    o += (int)((ob + i < oe) & (x >= p));
+  }
+  return o;
+}
+
+// STAGED is a template parameter (not a runtime flag) so that the weight pointer has a static address
+// space: a pointer that may be LDS or global compiles to flat_load + full waitcnt per access.
+template <bool STAGED>
 __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(const LatentDev L, const float* __restrict__ params) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ LatOp ops[MFM_LAT_MAXOPS];
+  __shared__ int pfxN[MFM_LAT_MAXOPS], pfxK[MFM_LAT_MAXOPS];
   __shared__ float red[2][16];
   load_ops(L, ops);
+  build_prefix(L, pfxN, pfxK);
   float* rec = lds;
   const int RS = L.rec_size;
   const int R = L.rows_per_wg;
   float* wp = lds + R * RS;
-  const bool staged = L.wpanel > 0;
+  constexpr bool staged = STAGED;
   const int row0 = blockIdx.x * R;
   const int nrows = min(R, L.B - row0);
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -75,47 +134,77 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(const LatentDev
       rec[r * RS + L.in_off[m] + k] = L.enc_h[m][(int64_t)(row0 + r) * L.enc_ld[m] + k];
     }
   }
+  f32x4 pre[PRE_U];
+  if (staged) span_load(params + L.span_off[0], L.span_len[0] >> 2, tid, nt, pre);
+  mark(L, 0);
   __syncthreads();   // record inputs + LDS op table
+  mark(L, 1);
 
   for (int s = 0; s < L.nstages; ++s) {
     const int ob = L.stage_begin[s], oe = L.stage_begin[s + 1];
-    const float* wbase = params;          // weights addressed as wbase[w_off - woff0]
-    int64_t woff0 = 0;
+    const int64_t woff0 = staged ? L.span_off[s] : 0;   // weights addressed as base[w_off - woff0]
     if (staged) {
-      copy_span(params + L.span_off[s], wp, L.span_len[s] >> 2, tid, nt);
+      span_store(params + L.span_off[s], wp, L.span_len[s] >> 2, tid, nt, pre);
       __syncthreads();
-      wbase = wp; woff0 = L.span_off[s];
+      if (s + 1 < L.nstages) span_load(params + L.span_off[s + 1], L.span_len[s + 1] >> 2, tid, nt, pre);
     }
-    // one item = one output column n of one op for a chunk of 4 batch rows: the weight row is
-    // read once per 4 rows, the 4 accumulator chains are independent, lanes run over n.
+    mark(L, 2 + 2 * s);
+    // one work item = (output column n of one op, k-quarter q, chunk of 4 batch rows): the four lanes of
+    // a quad split the reduction dim in interleaved 16-byte chunks (ds_read_b128 for the weight row
+    // and for each of the 4 activation rows: 5 LDS reads per 16 FMAs), all-reduce with two DPP adds,
+    // then lane q finishes batch row q.  All 1024 threads have work (sum N x 4 ~ 1000 items).
     const int nch = (nrows + 3) >> 2;
-    int total = 0;
-    for (int o = ob; o < oe; ++o) total += nch * ops[o].N;
-    for (int item = tid; item < total; item += nt) {
-      int o = ob, local = item;
-      while (local >= nch * ops[o].N) { local -= nch * ops[o].N; ++o; }
+    const int total = 4 * nch * (pfxN[oe - 1] + ops[oe - 1].N);
+    for (int item4 = tid; item4 < ((total + 3) & ~3); item4 += nt) {
+      const int q = item4 & 3;
+      const int item = min(item4 >> 2, (total >> 2) - 1);
+      const bool live = item4 < total;
+      const int o = find_op(pfxN, ob, oe, item, nch);
+      const int local = item - nch * pfxN[o];
       const LatOp op = ops[o];
-      const int ch = local / op.N, n = local - ch * op.N;
+      const int ch = (nch == 1) ? 0 : local / op.N, n = local - ch * op.N;
       const int r0 = ch * 4;
       const float* in[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) in[j] = rec + min(r0 + j, nrows - 1) * RS + op.in_off;
-      const float* w = wbase + (op.w_off - woff0) + (int64_t)n * op.K;
-      const float bv = wbase[(op.b_off - woff0) + n];
-      float acc[4] = {bv, bv, bv, bv};
-      int k = n % op.K;                    // rotated start: conflict-free LDS columns
-#pragma unroll 4
-      for (int kk = 0; kk < op.K; ++kk) {
-        const float wv = w[k];
+      const float* w;
+      float bv;
+      if constexpr (STAGED) {
+        w = wp + (op.w_off - woff0) + (int64_t)n * op.K;
+        bv = wp[(op.b_off - woff0) + n];
+      } else {
+        w = params + op.w_off + (int64_t)n * op.K;
+        bv = params[op.b_off + n];
+      }
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      if ((op.K & 3) == 0 && (STAGED || ((op.w_off & 3) == 0))) {
+        for (int k = 4 * q; k < op.K; k += 16) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = fmaf(in[j][k], wv, acc[j]);
-        k = (k + 1 == op.K) ? 0 : k + 1;
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(in[j] + k);
+            acc[j] = fmaf(xv[0], wv[0], acc[j]); acc[j] = fmaf(xv[1], wv[1], acc[j]);
+            acc[j] = fmaf(xv[2], wv[2], acc[j]); acc[j] = fmaf(xv[3], wv[3], acc[j]);
+          }
+        }
+      } else {
+        for (int k = q; k < op.K; k += 4) {
+          const float wv = w[k];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(in[j][k], wv, acc[j]);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int r = r0 + j;
-        if (r >= nrows) continue;
         float v = acc[j];
+        v += dpp_quad<0xB1>(v);
+        v += dpp_quad<0x4E>(v);
+        acc[j] = v;
+      }
+      const float lo = (q & 1) ? acc[1] : acc[0], hi = (q & 1) ? acc[3] : acc[2];
+      float v = ((q & 2) ? hi : lo) + bv;
+      const int r = r0 + q;
+      if (live && r < nrows) {
         if (op.relu) v = fmaxf(v, 0.0f);
         if (op.mask_off >= 0) {
           float mk = 1.0f;
@@ -130,6 +219,7 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(const LatentDev
       }
     }
     __syncthreads();
+    mark(L, 3 + 2 * s);
   }
 
   // ---- losses (partials per workgroup, one atomic each)
@@ -202,19 +292,23 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(const LatentDev
       atomicAdd(L.losses + 0, dsum * inv);
     }
   }
+  mark(L, 15);
 }
 
+template <bool STAGED>
 __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_kernel(const LatentDev L, const float* __restrict__ params,
                                                                  float* __restrict__ grads) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ LatOp ops[MFM_LAT_MAXOPS];
+  __shared__ int pfxN[MFM_LAT_MAXOPS], pfxK[MFM_LAT_MAXOPS];
   load_ops(L, ops);
+  build_prefix(L, pfxN, pfxK);
   const int RS = L.rec_size;
   const int R = L.rows_per_wg;
   float* rec = lds;
   float* grd = lds + R * RS;
   float* wp = lds + 2 * R * RS;
-  const bool staged = L.wpanel > 0;
+  constexpr bool staged = STAGED;
   const int row0 = blockIdx.x * R;
   const int nrows = min(R, L.B - row0);
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -288,22 +382,23 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_kernel(const LatentDev
       }
     }
   }
+  f32x4 pre[PRE_U];
+  if (staged) span_load(params + L.span_off[L.nstages - 1], L.span_len[L.nstages - 1] >> 2, tid, nt, pre);
   __syncthreads();
+  mark(L, 16);
 
   for (int s = L.nstages - 1; s >= 0; --s) {
     const int ob = L.stage_begin[s], oe = L.stage_begin[s + 1];
-    const float* wbase = params;
-    int64_t woff0 = 0;
-    if (staged) {     // becomes visible at pass 1's barrier
-      copy_span(params + L.span_off[s], wp, L.span_len[s] >> 2, tid, nt);
-      wbase = wp; woff0 = L.span_off[s];
+    const int64_t woff0 = staged ? L.span_off[s] : 0;
+    if (staged) {     // becomes visible at pass 1's barrier; the next stage's span is fetched meanwhile
+      span_store(params + L.span_off[s], wp, L.span_len[s] >> 2, tid, nt, pre);
+      if (s > 0) span_load(params + L.span_off[s - 1], L.span_len[s - 1] >> 2, tid, nt, pre);
     }
     // pass 1: gradient wrt the pre-activation, in place
-    int total = 0;
-    for (int o = ob; o < oe; ++o) total += nrows * ops[o].N;
+    int total = nrows * (pfxN[oe - 1] + ops[oe - 1].N);
     for (int item = tid; item < total; item += nt) {
-      int o = ob, local = item;
-      while (local >= nrows * ops[o].N) { local -= nrows * ops[o].N; ++o; }
+      const int o = find_op(pfxN, ob, oe, item, nrows);
+      const int local = item - nrows * pfxN[o];
       const LatOp& op = ops[o];
       if (!op.relu && op.mask_off < 0) continue;
       const int r = local / op.N, n = local - r * op.N;
@@ -313,59 +408,73 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_kernel(const LatentDev
       grd[r * RS + op.out_off + n] = gv;
     }
     __syncthreads();
+    mark(L, 17 + 3 * s);
     // pass 2a: grad wrt the input segment (LDS atomics: several ops may share an input).
-    // one item = one input column k of one op for a chunk of 4 rows; lanes run over k.
+    // work item = (input column k of one op, n-quarter q, chunk of 4 rows): the quad splits the output
+    // dim in interleaved chunks of 4, all-reduces with DPP, lane q adds batch row q.
     const int nch = (nrows + 3) >> 2;
-    total = 0;
-    for (int o = ob; o < oe; ++o) total += nch * ops[o].K;
-    for (int item = tid; item < total; item += nt) {
-      int o = ob, local = item;
-      while (local >= nch * ops[o].K) { local -= nch * ops[o].K; ++o; }
+    total = 4 * nch * (pfxK[oe - 1] + ops[oe - 1].K);
+    for (int item4 = tid; item4 < ((total + 3) & ~3); item4 += nt) {
+      const int q = item4 & 3;
+      const int item = min(item4 >> 2, (total >> 2) - 1);
+      const bool live = item4 < total;
+      const int o = find_op(pfxK, ob, oe, item, nch);
+      const int local = item - nch * pfxK[o];
       const LatOp op = ops[o];
-      const int ch = local / op.K, k = local - ch * op.K;
+      const int ch = (nch == 1) ? 0 : local / op.K, k = local - ch * op.K;
       const int r0 = ch * 4;
       const float* go[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) go[j] = grd + min(r0 + j, nrows - 1) * RS + op.out_off;
-      const float* w = wbase + (op.w_off - woff0) + k;
+      const float* w;
+      if constexpr (STAGED) w = wp + (op.w_off - woff0) + k; else w = params + op.w_off + k;
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int n = 0; n < op.N; ++n) {
-        const float wv = w[(int64_t)n * op.K];
+      if ((op.N & 3) == 0) {
+        for (int n = 4 * q; n < op.N; n += 16) {
+          float wv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = fmaf(go[j][n], wv, acc[j]);
-      }
+          for (int i = 0; i < 4; ++i) wv[i] = w[(int64_t)(n + i) * op.K];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (r0 + j < nrows) atomicAdd(&grd[(r0 + j) * RS + op.in_off + k], acc[j]);
-    }
-    // pass 2b: parameter gradients, reduced over this workgroup's rows, one global atomic each
-    total = 0;
-    for (int o = ob; o < oe; ++o) total += ops[o].N * (ops[o].K + 1);
-    for (int item = tid; item < total; item += nt) {
-      int o = ob, local = item;
-      while (local >= ops[o].N * (ops[o].K + 1)) { local -= ops[o].N * (ops[o].K + 1); ++o; }
-      const LatOp op = ops[o];
-      const int NK = op.N * op.K;
-      float a0 = 0.0f, a1 = 0.0f;
-      if (local < NK) {
-        const int n = local / op.K, k = local - n * op.K;
-        const float* g = grd + op.out_off + n;
-        const float* x = rec + op.in_off + k;
-        int r = 0;
-        for (; r + 1 < nrows; r += 2) {
-          a0 = fmaf(g[r * RS], x[r * RS], a0);
-          a1 = fmaf(g[(r + 1) * RS], x[(r + 1) * RS], a1);
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(go[j] + n);
+            acc[j] = fmaf(gv[0], wv[0], acc[j]); acc[j] = fmaf(gv[1], wv[1], acc[j]);
+            acc[j] = fmaf(gv[2], wv[2], acc[j]); acc[j] = fmaf(gv[3], wv[3], acc[j]);
+          }
         }
-        if (r < nrows) a0 = fmaf(g[r * RS], x[r * RS], a0);
-        atomicAdd(grads + op.w_off + local, a0 + a1);
       } else {
-        const int n = local - NK;
-        for (int r = 0; r < nrows; ++r) a0 += grd[r * RS + op.out_off + n];
-        atomicAdd(grads + op.b_off + n, a0);
+        for (int n = q; n < op.N; n += 4) {
+          const float wv = w[(int64_t)n * op.K];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = fmaf(go[j][n], wv, acc[j]);
+        }
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = acc[j];
+        v += dpp_quad<0xB1>(v);
+        v += dpp_quad<0x4E>(v);
+        acc[j] = v;
+      }
+      const float lo = (q & 1) ? acc[1] : acc[0], hi = (q & 1) ? acc[3] : acc[2];
+      const float v = (q & 2) ? hi : lo;
+      if (live && r0 + q < nrows) atomicAdd(&grd[(r0 + q) * RS + op.in_off + k], v);
+    }
+    mark(L, 18 + 3 * s);
+    // pass 2b: bias gradients (column sums over this workgroup's rows).  The WEIGHT gradients
+    // dW = G^T X are left to a grouped MFMA GEMM over the two records (plan.hip): writing 57k
+    // floats per workgroup from here is store-issue bound (~7 B/clk/CU: 25 us at B=32), and
+    // cross-XCD atomics on them were worse.
+    total = pfxN[oe - 1] + ops[oe - 1].N;
+    for (int item = tid; item < total; item += nt) {
+      const int o = find_op(pfxN, ob, oe, item, 1);
+      const LatOp& op = ops[o];
+      const int n = item - pfxN[o];
+      float a0 = 0.0f;
+      for (int r = 0; r < nrows; ++r) a0 += grd[r * RS + op.out_off + n];
+      atomicAdd(grads + op.b_off + n, a0);
     }
     __syncthreads();
+    mark(L, 19 + 3 * s);
   }
 
   for (int m = 0; m < 4; ++m) {
@@ -375,6 +484,12 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_kernel(const LatentDev
       const int r = idx / n, k = idx - r * n;
       L.dh_last[m][(int64_t)(row0 + r) * L.dh_ld[m] + k] = grd[r * RS + L.in_off[m] + k];
     }
+  }
+  if (L.grd_out) {     // pre-activation gradients of every layer, for the dW GEMMs
+    const int n4 = (nrows * RS) >> 2;
+    f32x4* d4 = reinterpret_cast<f32x4*>(L.grd_out + (int64_t)row0 * RS);
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(grd);
+    for (int idx = tid; idx < n4; idx += nt) d4[idx] = s4[idx];
   }
 }
 
@@ -389,9 +504,12 @@ int latent_fwd_launch(const LatentDev& L, const float* params, hipStream_t strea
   const int R = L.rows_per_wg;
   const size_t lds = ((size_t)R * L.rec_size + L.wpanel) * sizeof(float);
   MFM_REQUIRE(lds <= 156 * 1024, "latent_fwd: record + weight panel too large for LDS (%zu bytes)", lds);
-  int rc = set_lds_limit((const void*)latent_fwd_kernel, lds);
+  int rc = set_lds_limit(L.wpanel > 0 ? (const void*)latent_fwd_kernel<true> : (const void*)latent_fwd_kernel<false>, lds);
   if (rc != MFM_OK) return rc;
-  hipLaunchKernelGGL(latent_fwd_kernel, dim3(cdiv(L.B, R)), dim3(LAT_THREADS), lds, stream, L, params);
+  if (L.wpanel > 0)
+    hipLaunchKernelGGL(latent_fwd_kernel<true>, dim3(cdiv(L.B, R)), dim3(LAT_THREADS), lds, stream, L, params);
+  else
+    hipLaunchKernelGGL(latent_fwd_kernel<false>, dim3(cdiv(L.B, R)), dim3(LAT_THREADS), lds, stream, L, params);
   MFM_LAUNCH_CHECK("latent_fwd_kernel");
   return MFM_OK;
 }
@@ -399,9 +517,12 @@ int latent_bwd_launch(const LatentDev& L, const float* params, float* grads, hip
   const int R = L.rows_per_wg;
   const size_t lds = (2 * (size_t)R * L.rec_size + L.wpanel) * sizeof(float);
   MFM_REQUIRE(lds <= 156 * 1024, "latent_bwd: records + weight panel too large for LDS (%zu bytes)", lds);
-  int rc = set_lds_limit((const void*)latent_bwd_kernel, lds);
+  int rc = set_lds_limit(L.wpanel > 0 ? (const void*)latent_bwd_kernel<true> : (const void*)latent_bwd_kernel<false>, lds);
   if (rc != MFM_OK) return rc;
-  hipLaunchKernelGGL(latent_bwd_kernel, dim3(cdiv(L.B, R)), dim3(LAT_THREADS), lds, stream, L, params, grads);
+  if (L.wpanel > 0)
+    hipLaunchKernelGGL(latent_bwd_kernel<true>, dim3(cdiv(L.B, R)), dim3(LAT_THREADS), lds, stream, L, params, grads);
+  else
+    hipLaunchKernelGGL(latent_bwd_kernel<false>, dim3(cdiv(L.B, R)), dim3(LAT_THREADS), lds, stream, L, params, grads);
   MFM_LAUNCH_CHECK("latent_bwd_kernel");
   return MFM_OK;
 }

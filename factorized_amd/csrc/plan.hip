@@ -18,6 +18,7 @@
 //   B5 grouped GEMM   encoder dW_ih/dW_hh/db over dA                         (12 problems)
 //   A  adam           fused, one flat buffer
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <new>
@@ -29,7 +30,7 @@ namespace mfm {
 
 enum KernelId {
   K_PROJ = 0, K_ENC_FWD, K_LAT_FWD, K_DEC_FWD, K_FC1_FWD, K_MSE, K_FC1_BWD, K_DEC_BWD, K_DEC_DW,
-  K_LAT_BWD, K_ENC_BWD, K_ENC_DW, K_ADAM, K_COUNT
+  K_LAT_BWD, K_ENC_BWD, K_ENC_DW, K_ADAM, K_LAT_DW, K_COUNT
 };
 
 // state_dict order of MFM_KL_EF (78 tensors), see include/mfm_hip.h
@@ -59,7 +60,7 @@ struct MfmPlan {
   int64_t ws_floats;
   mfm::LatentDev lat;
   mfm::LatOp lat_ops[MFM_LAT_MAXOPS];
-  int64_t lat_ops_off;
+  int64_t lat_ops_off, dbg_off, lat_grd;
   // timing
   int timing_mask;
   std::vector<mfm::TimingPair> pool;
@@ -198,6 +199,8 @@ static int build(MfmPlan* P) {
   L.rows_per_wg = R;
 
   P->lat_ops_off = carve(cur, (int64_t)(sizeof(P->lat_ops) / (sizeof(float))));
+  P->dbg_off = carve(cur, 128);     // 64 x u64 debug timestamps
+  P->lat_grd = carve(cur, (int64_t)c.B * rs);
   P->lat_rec = carve(cur, (int64_t)c.B * rs);
   P->yhat = carve(cur, (int64_t)c.B * c.output_dim);
   P->ones = carve(cur, TB);
@@ -278,6 +281,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
   {
     LatentDev L = P->lat;
     L.ops = reinterpret_cast<const LatOp*>(W + P->lat_ops_off);
+    if (getenv("MFM_LATENT_DBG")) L.dbg = reinterpret_cast<unsigned long long*>(W + P->dbg_off);
     for (int e = 0; e < 4; ++e) {
       L.enc_h[e] = W + P->enc[e].hs + (int64_t)(T - 1) * B * P->enc[e].Hp;
       L.enc_ld[e] = P->enc[e].Hp;
@@ -441,6 +445,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
   {
     LatentDev L = P->lat;
     L.ops = reinterpret_cast<const LatOp*>(W + P->lat_ops_off);
+    if (getenv("MFM_LATENT_DBG")) L.dbg = reinterpret_cast<unsigned long long*>(W + P->dbg_off);
     for (int m = 0; m < 3; ++m) {
       L.d_dec_init[m] = gen_on ? W + P->dec_dinit[m] : nullptr;
       L.dec_ld[m] = P->dec_h[m];
@@ -448,11 +453,27 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     for (int e = 0; e < 4; ++e) { L.dh_last[e] = W + P->dh_last[e]; L.dh_ld[e] = P->enc_h[e]; }
     L.rec = W + P->lat_rec;
     L.y = y;
+    L.grd_out = W + P->lat_grd;
     if (ext) { L.d_yhat_ext = ext->d_yhat; L.reg_w_ptr = ext->d_reg; }
     L.reg_w = c.lda_reg * c.reg_scale;
     L.disc_w = disc_on ? 1.0f : 0.0f;
     L.gen_w = gen_on ? 1.0f : 0.0f;
     RUN(K_LAT_BWD, latent_bwd_launch(L, params, grads, s));
+    // weight gradients of the 22 latent Linears: dW[n][k] = sum_r G[r][out+n] X[r][in+k], one grouped GEMM
+    std::vector<MfmGemmDesc> gw;
+    const int rs = P->lat.rec_size;
+    for (int i = 0; i < P->lat.nops; ++i) {
+      const LatOp& op = P->lat_ops[i];
+      MfmGemmDesc d;
+      memset(&d, 0, sizeof(d));
+      d.alpha = 1.0f; d.batch = 1; d.split_k = 1; d.accumulate = 0;
+      d.a = W + P->lat_grd + op.out_off; d.a_sm = 1; d.a_sk = rs;
+      d.b = W + P->lat_rec + op.in_off; d.b_sk = rs; d.b_sn = 1;
+      d.c = grads + op.w_off; d.ldc = op.K;
+      d.m = op.N; d.n = op.K; d.n_valid = op.K; d.k = P->B;
+      gw.push_back(d);
+    }
+    RUN(K_LAT_DW, mfm_gemm_grouped_f32(gw.data(), (int)gw.size(), s));
   }
   // B4: encoder BPTT
   {
@@ -516,6 +537,8 @@ extern "C" void mfm_plan_destroy(MfmPlan* P) {
   for (auto& t : P->pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   delete P;
 }
+
+extern "C" int64_t mfm_plan_debug_offset(const MfmPlan* P) { return P ? P->dbg_off * (int64_t)sizeof(float) : -1; }
 
 extern "C" int64_t mfm_plan_workspace_bytes(const MfmPlan* P) { return P ? P->ws_floats * (int64_t)sizeof(float) : 0; }
 
@@ -584,7 +607,7 @@ extern "C" int mfm_plan_num_kernels(void) { return K_COUNT; }
 extern "C" const char* mfm_plan_kernel_name(int kid) {
   static const char* names[K_COUNT] = {"proj_gemm", "enc_seq_fwd", "latent_fwd", "dec_seq_fwd", "fc1_gemm", "mse",
                                        "fc1_bwd_gemm", "dec_seq_bwd", "dec_dw_gemm", "latent_bwd", "enc_seq_bwd",
-                                       "enc_dw_gemm", "adam"};
+                                       "enc_dw_gemm", "adam", "latent_dw_gemm"};
   return (kid >= 0 && kid < K_COUNT) ? names[kid] : "?";
 }
 // Synchronises on the recorded events, adds elapsed ms / launch counts per kernel id, resets the pool.

@@ -145,6 +145,9 @@ int mfm_plan_create(const MfmPlanConfig* cfg, const int64_t* param_offsets /*[MF
                     int64_t n_params_total, MfmPlan** out);
 void mfm_plan_destroy(MfmPlan* plan);
 int64_t mfm_plan_workspace_bytes(const MfmPlan* plan);
+/* byte offset inside the workspace of 64 uint64 shader-clock stamps the latent kernels write when
+ * the environment variable MFM_LATENT_DBG is set (kernel tuning aid, scripts/latent_phases.py). */
+int64_t mfm_plan_debug_offset(const MfmPlan* plan);
 
 /* zero the workspace and write its constant regions (a ones vector used for bias-gradient
  * column sums).  Call once after allocating `workspace` (and again if it is re-allocated). */
