@@ -35,7 +35,7 @@ class SeqDesc(C.Structure):
                 ("h_init", C.c_void_p), ("ld_init", C.c_int64),
                 ("dh_ext", C.c_void_p), ("ld_dh", C.c_int64),
                 ("d_h_init", C.c_void_p), ("ld_dinit", C.c_int64),
-                ("h", C.c_int32), ("is_dec", C.c_int32)]
+                ("h", C.c_int32), ("is_dec", C.c_int32), ("dc_ext", C.c_void_p)]
 
 
 class PlanConfig(C.Structure):

@@ -230,12 +230,14 @@ __device__ __forceinline__ void seq_bwd_body(const SeqDev& d, const int T, const
       ct = ld4(d.cs + rowt * Hp + u0 + 4 * q);
       if (t > 0) cp = ld4(d.cs + (rowt - B) * Hp + u0 + 4 * q);
     }
+    f32x4 dce = zero4;
+    if (bvalid && d.dc_ext) dce = ld4(d.dc_ext + rowt * Hp + u0 + 4 * q);
     f32x4 dai, daf, dag, dao;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float tc = act_tanh(ct[r]);
       const float dot = dh[r] * tc;
-      const float dct = dh[r] * go[r] * (1.0f - tc * tc) + dc[r];
+      const float dct = dh[r] * go[r] * (1.0f - tc * tc) + dc[r] + dce[r];
       dai[r] = dct * gg[r] * gi[r] * (1.0f - gi[r]);
       daf[r] = dct * cp[r] * gf[r] * (1.0f - gf[r]);
       dag[r] = dct * gi[r] * (1.0f - gg[r] * gg[r]);
@@ -372,6 +374,7 @@ static int seq_launch(const MfmSeqDesc* descs, int count, int T, int B, bool bwd
     d.h_init = s.h_init; d.ld_init = s.ld_init;
     d.dh_ext = s.dh_ext; d.ld_dh = s.ld_dh;
     d.d_h_init = s.d_h_init; d.ld_dinit = s.ld_dinit;
+    d.dc_ext = s.dc_ext;
     d.h = s.h; d.Hp = round_up(s.h, 16);
     d.hk4 = round_up(cdiv(s.h, 4), 2);
     d.is_dec = s.is_dec;

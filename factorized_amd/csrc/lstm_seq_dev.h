@@ -10,6 +10,7 @@ struct SeqDev {
   const float* h_init; int64_t ld_init;
   const float* dh_ext; int64_t ld_dh;
   float* d_h_init; int64_t ld_dinit;
+  const float* dc_ext;
   int h, Hp, hk4, is_dec, block_begin;
 };
 struct SeqLaunch {

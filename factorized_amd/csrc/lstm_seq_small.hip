@@ -250,7 +250,7 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
 
   auto step = [&](const int t) {
     const int64_t rowt = (int64_t)t * B + b;
-    float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, ct = 0.f, cp = 0.f, ext = 0.f;
+    float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, ct = 0.f, cp = 0.f, ext = 0.f, dce = 0.f;
     float* gpt = d.gates + rowt * row4 + mu;
     if (bvalid) {
       gi = gpt[0]; gf = gpt[Hp]; gg = gpt[2 * Hp]; go = gpt[3 * Hp];
@@ -258,11 +258,12 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
       if (t > 0) cp = d.cs[(rowt - B) * Hp + mu];
       if (dec) ext = d.dh_ext[rowt * Hp + mu];
       else if (t == T - 1 && mu < h) ext = d.dh_ext[(int64_t)b * d.ld_dh + mu];
+      if (d.dc_ext) dce = d.dc_ext[rowt * Hp + mu];
     }
     const float dh = dh_rec + ext;
     const float tc = act_tanh(ct);
     const float dot = dh * tc;
-    const float dct = dh * go * (1.0f - tc * tc) + dc;
+    const float dct = dh * go * (1.0f - tc * tc) + dc + dce;
     float da[4];
     da[0] = dct * gg * gi * (1.0f - gi);
     da[1] = dct * cp * gf * (1.0f - gf);

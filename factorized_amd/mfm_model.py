@@ -10,6 +10,9 @@ checkpoints `load_state_dict` cleanly), same `forward` contracts:
     decoderLSTM(h, d).forward(hT[B,h], t)          -> [t,B,d]              (mfm_model.py:64-91)
     MFM_KL_EF(...).forward(x[T,B,D])               -> ([x_l_hat,x_a_hat,x_v_hat,y_hat], kld, 0.0)
                                                                            (mfm_model.py:619-660)
+    MFM_KL(...) / MFM(...).forward(x)              -> same contract, zy from the MFN encoder
+                                                                           (mfm_model.py:723-764 / 522-555)
+    MFN(...).forward(x[T,B,D])                     -> [B, sum(h_dims)+memsize] (mfm_model.py:140-199)
 
 Modules are ordinary `nn.Module`s: `.train()/.eval()/.parameters()`, `optim.Adam(model.parameters())`
 and `loss.backward()` of a reference-style driver work unchanged.  Underneath, every forward and
@@ -337,22 +340,262 @@ class MFM_KL_EF(nn.Module):
         return decoded, kld, missing_loss
 
 
+# ----------------------------------------------------------------------------------- Linear on the HIP GEMM
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b on mfm_gemm_grouped_f32 (forward NT, backward NN for dx and TN for dW, db)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous().float()
+        M, K = x2.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        E.gemm_grouped([E.make_gemm(x2, w, y, M, N, K, a_sm=K, a_sk=1, b_sk=1, b_sn=K, ldc=N, bias=b)])
+        ctx.save_for_backward(x2, w)
+        ctx.shp = shp
+        return y.reshape(shp[:-1] + (N,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        M, K = x2.shape
+        N = w.shape[0]
+        dy2 = dy.reshape(M, N).contiguous().float()
+        dev = dy.device
+        dx = torch.empty(M, K, device=dev)
+        dw = torch.zeros_like(w)
+        db = torch.zeros(N, device=dev)
+        ones = torch.ones(M, device=dev)
+        E.gemm_grouped([
+            E.make_gemm(dy2, w, dx, M, K, N, a_sm=N, a_sk=1, b_sk=K, b_sn=1, ldc=K),
+            E.make_gemm(dy2, x2, dw, N, K, M, a_sm=1, a_sk=N, b_sk=K, b_sn=1, ldc=K, accumulate=1, split_k=0),
+            E.make_gemm(dy2, ones, db, N, 1, M, a_sm=1, a_sk=N, b_sk=1, b_sn=1, ldc=1, accumulate=1, split_k=0)])
+        return dx.reshape(ctx.shp), dw, db
+
+
+class HipLinear(nn.Linear):
+    """nn.Linear (same parameters / state_dict keys) whose matmuls run on the HIP GEMM."""
+
+    def forward(self, x):
+        _require_cuda(x, "Linear.forward")
+        return _LinearFn.apply(x, self.weight, self.bias)
+
+
+# ----------------------------------------------------------------------------------- MFN
+class _LstmSeqStatesFn(torch.autograd.Function):
+    """One LSTM over the whole sequence returning (h_T [B,h], c_all [T,B,h]); differentiable in both
+    (the MFN attention reads every c_t, reference mfm_model.py:171-173)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        T, B, d = x.shape
+        h = w_hh.shape[1]
+        Hp = _hp(h)
+        xr, ldx = _rows(x)
+        dev = x.device
+        gates = torch.empty(T, B, 4, Hp, device=dev, dtype=torch.float32)
+        hs = torch.empty(T, B, Hp, device=dev, dtype=torch.float32)
+        cs = torch.empty(T, B, Hp, device=dev, dtype=torch.float32)
+        E.gemm_grouped([E.make_gemm(xr, w_ih, gates, T * B, Hp, d, a_sm=ldx, a_sk=1, b_sk=1, b_sn=d,
+                                    ldc=4 * Hp, bias=b_ih, bias2=b_hh, n_valid=h, batch=4, b_sz=h * d,
+                                    c_sz=Hp, bias_sz=h)])
+        E.lstm_seq([E.make_seq(gates, hs, cs, w_hh, h)], T, B)
+        ctx.save_for_backward(xr, w_ih, w_hh, gates, hs, cs)
+        ctx.dims = (T, B, d, h, Hp, ldx)
+        return hs[T - 1, :, :h].clone(), cs[:, :, :h].clone()
+
+    @staticmethod
+    def backward(ctx, d_hT, d_cs):
+        xr, w_ih, w_hh, gates, hs, cs = ctx.saved_tensors
+        T, B, d, h, Hp, ldx = ctx.dims
+        dev = xr.device
+        dh = torch.zeros(B, h, device=dev) if d_hT is None else d_hT.contiguous().float()
+        dc = torch.zeros(T, B, Hp, device=dev)
+        if d_cs is not None:
+            dc[:, :, :h] = d_cs
+        E.lstm_seq([E.make_seq(gates, hs, cs, w_hh, h, dh_ext=dh, ld_dh=h, dc_ext=dc)], T, B, backward=True)
+        g_wih = torch.zeros_like(w_ih); g_whh = torch.zeros_like(w_hh)
+        g_bih = torch.zeros(4 * h, device=dev); g_bhh = torch.zeros(4 * h, device=dev)
+        ones = torch.ones(T * B, device=dev)
+        descs = [E.make_gemm(gates, xr, g_wih, h, d, T * B, a_sm=1, a_sk=4 * Hp, b_sk=ldx, b_sn=1, ldc=d,
+                             batch=4, a_sz=Hp, c_sz=h * d, accumulate=1, split_k=0),
+                 E.make_gemm(gates, ones, g_bih, h, 1, T * B, a_sm=1, a_sk=4 * Hp, b_sk=1, b_sn=1, ldc=1,
+                             batch=4, a_sz=Hp, c_sz=h, accumulate=1, split_k=0, c2=g_bhh)]
+        if T > 1:
+            descs.append(E.make_gemm(gates[1:], hs, g_whh, h, h, (T - 1) * B, a_sm=1, a_sk=4 * Hp, b_sk=Hp,
+                                     b_sn=1, ldc=h, batch=4, a_sz=Hp, c_sz=h * h, accumulate=1, split_k=0))
+        E.gemm_grouped(descs)
+        return None, g_wih, g_whh, g_bih, g_bhh
+
+
 class MFN(nn.Module):
-    """Memory Fusion Network encoder (reference mfm_model.py:93-199): scheduled, see DESIGN.md."""
+    """Memory Fusion Network encoder, reference mfm_model.py:93-199 (same attribute names; `out_fc1/
+    out_fc2/out_dropout` exist but are unused in forward, as in the reference).
 
-    def __init__(self, *a, **k):
+    MI355X restructuring: the three LSTMs do NOT depend on the memory, so they run as whole-sequence
+    HIP recurrences first (one launch); the attention and the c-hat proposal depend only on the cell
+    states, so they are evaluated for ALL timesteps at once as [T*B, .] GEMMs; only the two gamma gates
+    and the memory update are sequential in t (20 tiny steps).  Matmuls run on the HIP GEMM
+    (`HipLinear`); the elementwise glue (softmax/relu/tanh/sigmoid/dropout/concat) uses torch device ops
+    -- a fused memory-recurrence kernel is the next step."""
+
+    def __init__(self, config, NN1Config, NN2Config, gamma1Config, gamma2Config, outConfig):
         super(MFN, self).__init__()
-        raise NotImplementedError("factorized_amd: MFN (and MFM / MFM_KL which embed it) is not built yet; "
-                                  "MFM_KL_EF is the implemented model (SURVEY.md section 8f)")
+        [self.d_l, self.d_a, self.d_v] = config["input_dims"]
+        [self.dh_l, self.dh_a, self.dh_v] = config["h_dims"]
+        total_h_dim = self.dh_l + self.dh_a + self.dh_v
+        self.mem_dim = config["memsize"]
+        window_dim = config["windowsize"]
+        output_dim = config['output_dim']
+        attInShape = total_h_dim * window_dim
+        gammaInShape = attInShape + self.mem_dim
+        final_out = total_h_dim + self.mem_dim
+        self.lstm_l = nn.LSTMCell(self.d_l, self.dh_l)
+        self.lstm_a = nn.LSTMCell(self.d_a, self.dh_a)
+        self.lstm_v = nn.LSTMCell(self.d_v, self.dh_v)
+        self.att1_fc1 = HipLinear(attInShape, NN1Config["shapes"])
+        self.att1_fc2 = HipLinear(NN1Config["shapes"], attInShape)
+        self.att1_dropout = nn.Dropout(NN1Config["drop"])
+        self.att2_fc1 = HipLinear(attInShape, NN2Config["shapes"])
+        self.att2_fc2 = HipLinear(NN2Config["shapes"], self.mem_dim)
+        self.att2_dropout = nn.Dropout(NN2Config["drop"])
+        self.gamma1_fc1 = HipLinear(gammaInShape, gamma1Config["shapes"])
+        self.gamma1_fc2 = HipLinear(gamma1Config["shapes"], self.mem_dim)
+        self.gamma1_dropout = nn.Dropout(gamma1Config["drop"])
+        self.gamma2_fc1 = HipLinear(gammaInShape, gamma2Config["shapes"])
+        self.gamma2_fc2 = HipLinear(gamma2Config["shapes"], self.mem_dim)
+        self.gamma2_dropout = nn.Dropout(gamma2Config["drop"])
+        self.out_fc1 = HipLinear(final_out, outConfig["shapes"])
+        self.out_fc2 = HipLinear(outConfig["shapes"], output_dim)
+        self.out_dropout = nn.Dropout(outConfig["drop"])
+
+    def forward(self, x):
+        _require_cuda(x, "MFN.forward")
+        T, B = x.shape[0], x.shape[1]
+        x_l = x[:, :, :self.d_l]
+        x_a = x[:, :, self.d_l:self.d_l + self.d_a]
+        x_v = x[:, :, self.d_l + self.d_a:]
+        hl, cl = _LstmSeqStatesFn.apply(x_l, self.lstm_l.weight_ih, self.lstm_l.weight_hh,
+                                        self.lstm_l.bias_ih, self.lstm_l.bias_hh)
+        ha, ca = _LstmSeqStatesFn.apply(x_a, self.lstm_a.weight_ih, self.lstm_a.weight_hh,
+                                        self.lstm_a.bias_ih, self.lstm_a.bias_hh)
+        hv, cv = _LstmSeqStatesFn.apply(x_v, self.lstm_v.weight_ih, self.lstm_v.weight_hh,
+                                        self.lstm_v.bias_ih, self.lstm_v.bias_hh)
+        new_cs = torch.cat([cl, ca, cv], dim=2)                                   # [T,B,tot]
+        prev_cs = torch.cat([torch.zeros_like(new_cs[:1]), new_cs[:-1]], dim=0)   # c_{t-1}, zeros at t=0
+        cStar = torch.cat([prev_cs, new_cs], dim=2)                               # mfm_model.py:171-173
+        attention = torch.softmax(self.att1_fc2(self.att1_dropout(torch.relu(self.att1_fc1(cStar)))), dim=2)
+        attended = attention * cStar                                              # :174-175, all t at once
+        cHat = torch.tanh(self.att2_fc2(self.att2_dropout(torch.relu(self.att2_fc1(attended)))))   # :176
+        # gamma gates: split W = [W_att | W_mem]; the attended part is batched over T, only the memory
+        # part is sequential (:177-180)
+        na = attended.shape[2]
+        g1_att = _LinearFn.apply(attended, self.gamma1_fc1.weight[:, :na].contiguous(), self.gamma1_fc1.bias)
+        g2_att = _LinearFn.apply(attended, self.gamma2_fc1.weight[:, :na].contiguous(), self.gamma2_fc1.bias)
+        w1m = self.gamma1_fc1.weight[:, na:].contiguous()
+        w2m = self.gamma2_fc1.weight[:, na:].contiguous()
+        zb1 = torch.zeros(w1m.shape[0], device=x.device)
+        zb2 = torch.zeros(w2m.shape[0], device=x.device)
+        mem = torch.zeros(B, self.mem_dim, device=x.device)
+        for t in range(T):
+            a1 = torch.relu(g1_att[t] + _LinearFn.apply(mem, w1m, zb1))
+            a2 = torch.relu(g2_att[t] + _LinearFn.apply(mem, w2m, zb2))
+            gamma1 = torch.sigmoid(self.gamma1_fc2(self.gamma1_dropout(a1)))
+            gamma2 = torch.sigmoid(self.gamma2_fc2(self.gamma2_dropout(a2)))
+            mem = gamma1 * mem + gamma2 * cHat[t]
+        return torch.cat([hl, ha, hv, mem], dim=1)
 
 
-class MFM(nn.Module):
-    def __init__(self, *a, **k):
-        super(MFM, self).__init__()
-        raise NotImplementedError("factorized_amd: MFM needs the MFN encoder, not built yet (use MFM_KL_EF)")
+class _FactorizedMFN(nn.Module):
+    """Shared body of MFM (MMD regulariser, mfm_model.py:469-555) and MFM_KL (KLD, :662-764): the
+    three HIP sequence encoders/decoders around the MFN fusion encoder."""
+
+    def __init__(self, use_kl, config, NN1Config, NN2Config, gamma1Config, gamma2Config, outConfig):
+        super(_FactorizedMFN, self).__init__()
+        self._use_kl = use_kl
+        [self.d_l, self.d_a, self.d_v] = config["input_dims"]
+        [self.dh_l, self.dh_a, self.dh_v] = config["h_dims"]
+        zy, zl, za, zv = config['zy_size'], config['zl_size'], config['za_size'], config['zv_size']
+        fy, fl, fa, fv = config['fy_size'], config['fl_size'], config['fa_size'], config['fv_size']
+        last_mfn_size = self.dh_l + self.dh_a + self.dh_v + config["memsize"]
+        output_dim = config['output_dim']
+        self.encoder_l = encoderLSTM(self.d_l, zl)
+        self.encoder_a = encoderLSTM(self.d_a, za)
+        self.encoder_v = encoderLSTM(self.d_v, zv)
+        self.decoder_l = decoderLSTM(fy + fl, self.d_l)
+        self.decoder_a = decoderLSTM(fy + fa, self.d_a)
+        self.decoder_v = decoderLSTM(fy + fv, self.d_v)
+        self.mfn_encoder = MFN(config, NN1Config, NN2Config, gamma1Config, gamma2Config, outConfig)
+        self.last_to_zy_fc1 = HipLinear(last_mfn_size, zy)
+        if use_kl:
+            self.last_to_logvarzy_fc1 = HipLinear(last_mfn_size, zy)
+            self.last_to_zl_fc1 = HipLinear(zl, zl)
+            self.last_to_za_fc1 = HipLinear(za, za)
+            self.last_to_zv_fc1 = HipLinear(zv, zv)
+            self.last_to_logvarzl_fc1 = HipLinear(zl, zl)
+            self.last_to_logvarza_fc1 = HipLinear(za, za)
+            self.last_to_logvarzv_fc1 = HipLinear(zv, zv)
+        self.zy_to_fy_fc1 = HipLinear(zy, fy)
+        self.zy_to_fy_fc2 = HipLinear(fy, fy)
+        self.zy_to_fy_dropout = nn.Dropout(config['zy_to_fy_dropout'])
+        self.zl_to_fl_fc1 = HipLinear(zl, fl)
+        self.zl_to_fl_fc2 = HipLinear(fl, fl)
+        self.zl_to_fl_dropout = nn.Dropout(config['zl_to_fl_dropout'])
+        self.za_to_fa_fc1 = HipLinear(za, fa)
+        self.za_to_fa_fc2 = HipLinear(fa, fa)
+        self.za_to_fa_dropout = nn.Dropout(config['za_to_fa_dropout'])
+        self.zv_to_fv_fc1 = HipLinear(zv, fv)
+        self.zv_to_fv_fc2 = HipLinear(fv, fv)
+        self.zv_to_fv_dropout = nn.Dropout(config['zv_to_fv_dropout'])
+        self.fy_to_y_fc1 = HipLinear(fy, fy)
+        self.fy_to_y_fc2 = HipLinear(fy, output_dim)
+        self.fy_to_y_dropout = nn.Dropout(config['fy_to_y_dropout'])
+        self.mmd_gauss = None      # optional injected N(0,1) samples [zl, za, zv, zy] (parity tests)
+
+    def forward(self, x):
+        _require_cuda(x, "%s.forward" % type(self).__name__)
+        x_l = x[:, :, :self.d_l]
+        x_a = x[:, :, self.d_l:self.d_l + self.d_a]
+        x_v = x[:, :, self.d_l + self.d_a:]
+        t = x.shape[0]
+        zl_last = self.encoder_l.forward(x_l)
+        za_last = self.encoder_a.forward(x_a)
+        zv_last = self.encoder_v.forward(x_v)
+        mfn_last = self.mfn_encoder.forward(x)
+        zy = self.last_to_zy_fc1(mfn_last)
+        if self._use_kl:
+            zl = self.last_to_zl_fc1(zl_last)
+            za = self.last_to_za_fc1(za_last)
+            zv = self.last_to_zv_fc1(zv_last)
+            reg = loss_KLD(zl, self.last_to_logvarzl_fc1(zl_last)) + loss_KLD(za, self.last_to_logvarza_fc1(za_last)) \
+                + loss_KLD(zv, self.last_to_logvarzv_fc1(zv_last)) + loss_KLD(zy, self.last_to_logvarzy_fc1(mfn_last))
+        else:
+            zl, za, zv = zl_last, za_last, zv_last
+            g = self.mmd_gauss if self.mmd_gauss is not None else [None] * 4
+            reg = loss_MMD(zl, g[0]) + loss_MMD(za, g[1]) + loss_MMD(zv, g[2]) + loss_MMD(zy, g[3])
+        missing_loss = 0.0
+        relu = torch.relu
+        fy = relu(self.zy_to_fy_fc2(self.zy_to_fy_dropout(relu(self.zy_to_fy_fc1(zy)))))
+        fl = relu(self.zl_to_fl_fc2(self.zl_to_fl_dropout(relu(self.zl_to_fl_fc1(zl)))))
+        fa = relu(self.za_to_fa_fc2(self.za_to_fa_dropout(relu(self.za_to_fa_fc1(za)))))
+        fv = relu(self.zv_to_fv_fc2(self.zv_to_fv_dropout(relu(self.zv_to_fv_fc1(zv)))))
+        x_l_hat = self.decoder_l.forward(torch.cat([fy, fl], dim=1), t)
+        x_a_hat = self.decoder_a.forward(torch.cat([fy, fa], dim=1), t)
+        x_v_hat = self.decoder_v.forward(torch.cat([fy, fv], dim=1), t)
+        y_hat = self.fy_to_y_fc2(self.fy_to_y_dropout(relu(self.fy_to_y_fc1(fy))))
+        return [x_l_hat, x_a_hat, x_v_hat, y_hat], reg, missing_loss
 
 
-class MFM_KL(nn.Module):
-    def __init__(self, *a, **k):
-        super(MFM_KL, self).__init__()
-        raise NotImplementedError("factorized_amd: MFM_KL needs the MFN encoder, not built yet (use MFM_KL_EF)")
+class MFM(_FactorizedMFN):
+    """reference mfm_model.py:469-555 (MMD-regularised, no logvar heads)."""
+
+    def __init__(self, config, NN1Config, NN2Config, gamma1Config, gamma2Config, outConfig):
+        super(MFM, self).__init__(False, config, NN1Config, NN2Config, gamma1Config, gamma2Config, outConfig)
+
+
+class MFM_KL(_FactorizedMFN):
+    """reference mfm_model.py:662-764 (KLD-regularised, zy from the MFN encoder)."""
+
+    def __init__(self, config, NN1Config, NN2Config, gamma1Config, gamma2Config, outConfig):
+        super(MFM_KL, self).__init__(True, config, NN1Config, NN2Config, gamma1Config, gamma2Config, outConfig)

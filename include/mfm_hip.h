@@ -90,6 +90,8 @@ typedef struct MfmSeqDesc {
   float* d_h_init;       /* dec: [B, ld_dinit] out (grad wrt h_init); enc: unused */
   int64_t ld_dinit;
   int32_t h, is_dec;
+  const float* dc_ext;   /* optional [T,B,Hp]: external grad wrt every CELL state c_t (the MFN encoder
+                            reads c_t, mfm_model.py:171-173); NULL for the plain encoders/decoders */
 } MfmSeqDesc;
 
 int mfm_lstm_seq_fwd(const MfmSeqDesc* descs /*host*/, int count, int T, int B, void* stream);

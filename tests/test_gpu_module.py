@@ -111,3 +111,63 @@ def test_module_and_fused_engine_share_storage():
     eng.train_step(x, y)                           # fused step updates the module's own parameters
     torch.cuda.synchronize()
     assert not torch.equal(before, model.fy_to_y_fc2.weight.detach())
+
+
+def _ref_loss_generic(model, x, y, cfg):
+    d_l, d_a, _ = cfg["input_dims"]
+    decoded, reg, missing = model.forward(x)
+    x_l_hat, x_a_hat, x_v_hat, y_hat = decoded
+    gen = cfg["lda_xl"] * F.mse_loss(x_l_hat, x[:, :, :d_l]) + cfg["lda_xa"] * F.mse_loss(x_a_hat, x[:, :, d_l:d_l + d_a]) \
+        + cfg["lda_xv"] * F.mse_loss(x_v_hat, x[:, :, d_l + d_a:])
+    disc = F.l1_loss(y_hat.squeeze(1), y)
+    return disc + gen + cfg["lda_mmd"] * reg + missing, decoded, reg
+
+
+@pytest.mark.parametrize("name", ["kl_b32_t20", "mmd_b32_t20"])
+def test_mfn_based_models_match_reference(name):
+    """MFM_KL / MFM (with the MFN fusion encoder) against the reference's golden outputs and the
+    oracle's gradients; trained 5 steps with torch.optim.Adam like mfm_mosi.py:403-441."""
+    _need_gpu()
+    from factorized_amd import mfm_model as M
+    cs = cases.load_case(name)
+    cfg, gold = cs["cfg"], cs["gold"]
+    variant = cs["variant"]
+    ref = O.build(variant, cs["cfgs"])
+    w = synth.make_weights(O.state_shapes(ref), seed=1234)
+    O.load_numpy_weights(ref, w)
+    ref.train()
+    model = (M.MFM_KL if variant == "kl" else M.MFM)(*cs["cfgs"])
+    model.load_state_dict(ref.state_dict())
+    model = model.cuda()
+    model.train()
+    x, y = torch.from_numpy(cs["x"]), torch.from_numpy(cs["y"])
+    xd, yd = x.cuda(), y.cuda()
+    if variant == "mmd":
+        g = torch.from_numpy(gold["mmd_gauss"])
+        sizes = [cfg["zl_size"], cfg["za_size"], cfg["zv_size"], cfg["zy_size"]]
+        ref.mmd_gauss = list(torch.split(g, sizes, dim=1))
+        model.mmd_gauss = [t.cuda() for t in ref.mmd_gauss]
+    opt = torch.optim.Adam(model.parameters())
+    trace = []
+    for step in range(cs["steps"]):
+        opt.zero_grad()
+        loss, decoded, reg = _ref_loss_generic(model, xd, yd, cfg)
+        loss.backward()
+        trace.append(loss.item())
+        if step == 0:
+            assert abs(loss.item() - float(gold["fwd_loss"])) < TOL * abs(float(gold["fwd_loss"]))
+            assert abs(reg.item() - float(gold["fwd_reg"])) < 5 * TOL * max(abs(float(gold["fwd_reg"])), 1e-2)
+            assert rel_err(decoded[3].detach().cpu().numpy(), gold["y_hat"]) < TOL
+            assert rel_err(decoded[1].detach().cpu().numpy(), gold["x_a_hat"]) < TOL
+            rloss, _, _ = _ref_loss_generic(ref, x, y, cfg)
+            rloss.backward()
+            rp = dict(ref.named_parameters())
+            for n, p in model.named_parameters():
+                q = rp[n]
+                if q.grad is None:
+                    assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+                else:
+                    assert rel_err(p.grad.cpu().numpy(), q.grad.numpy()) < 2 * TOL, n
+        opt.step()
+    ref_trace = gold["trace"][:, 0]
+    assert np.max(np.abs(np.array(trace) - ref_trace) / np.abs(ref_trace)) < 20 * TOL

@@ -17,6 +17,15 @@ def test_state_dict_matches_reference_keys_and_shapes():
     m.load_state_dict(rd)                 # a reference checkpoint loads cleanly
 
 
+def test_mfn_models_state_dict_matches_reference():
+    cfgs = configs.canonical_configs()
+    for cls, variant, nparam in ((M.MFM_KL, "kl", 741415), (M.MFM, "mmd", 717719)):
+        m, ref = cls(*cfgs), O.build(variant, cfgs)
+        assert list(m.state_dict().keys()) == list(ref.state_dict().keys())
+        assert sum(v.numel() for v in m.state_dict().values()) == nparam
+        m.load_state_dict(ref.state_dict())
+
+
 def test_blocks_have_reference_attributes():
     e = M.encoderLSTM(5, 8)
     d = M.decoderLSTM(24, 5)
