@@ -159,7 +159,7 @@ __device__ __forceinline__ void seq_fwd_body(const SeqDev& d, const int T, const
         if (unit < HK) hn[unit * 16 + bi] = (b < B) ? hv[r] : 0.0f;
       }
     }
-    __syncthreads();
+    lds_barrier();
     cur ^= 1;
   }
 }
@@ -261,7 +261,7 @@ __device__ __forceinline__ void seq_bwd_body(const SeqDev& d, const int T, const
           }
         }
       }
-      __syncthreads();
+      lds_barrier();
       if (dec && t == 0) {   // grad wrt the step-0 input goes through W_ih only
         int z = 0;
         asm volatile("" : "+v"(z));   // opaque zero: no LICM of the reload's addresses

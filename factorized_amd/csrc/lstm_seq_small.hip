@@ -20,6 +20,8 @@
 //     a panel and every thread picks its (strided / transposed) elements from there -- per-thread
 //     global gathers of W^T cost ~30-90 us per launch (profiles/r01 seq micro-benchmark).
 // Buffers, layouts and the encoder/decoder forms are exactly those of lstm_seq.hip.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "internal.h"
@@ -187,7 +189,7 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
       else { gpt[2 * Hp] = gg; gpt[3 * Hp] = go; d.hs[rowt * Hp + u] = hv; }
     }
     if (uact && gp == 0 && u < HK) hbuf[(cur ^ 1) * (HK * R) + u * R + q] = (b < B) ? hv : 0.0f;
-    __syncthreads();
+    lds_barrier();
     cur ^= 1;
   };
   // The decoder's step 0 (W_ih on the embedding) is peeled so that the weight reload sits between
@@ -279,7 +281,7 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
 #pragma unroll
         for (int g = 0; g < 4; ++g) db[(g * HKB + mu) * R + mr] = da[g];
       }
-      __syncthreads();
+      lds_barrier();
       float aa[R] = {0.f, 0.f, 0.f, 0.f}, ab[R] = {0.f, 0.f, 0.f, 0.f};
       const float* dp = db + q * R;
       constexpr int RING = (NW < 4) ? NW : 4;
@@ -359,6 +361,53 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_kernel(const SeqLaunch L)
   }
 }
 
+// Specialised launch for a fixed tuple of per-LSTM variants: with 4 bodies in the kernel instead of
+// 16 the register allocator reaches single-variant quality (the 16-way switch spills ~80 VGPRs in the
+// forward time loop, 4x slower).  The canonical MFM sizes (encoders 32/8/80/120, decoders 104/24/24)
+// are pre-instantiated; any other size combination takes the generic kernel above.
+template <bool BWD, int K0, int K1, int K2, int K3>
+__global__ __launch_bounds__(1024) void lstm_seq_small_kernel4(const SeqLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int di = 0;
+  const int bid = blockIdx.x;
+#pragma unroll 1
+  for (int i = 1; i < L.count; ++i)
+    if (bid >= L.d[i].block_begin) di = i;
+  const SeqDev& d = L.d[di];
+  const int tile = bid - d.block_begin;
+#define MFM_ONE(IDX, KK)                                                         \
+  if (KK > 0 && di == IDX) {                                                     \
+    if (BWD) small_bwd_body<(KK > 0 ? KK : 2)>(d, L.T, L.B, tile, lds);          \
+    else small_fwd_body<(KK > 0 ? KK : 2)>(d, L.T, L.B, tile, lds);              \
+    return;                                                                      \
+  }
+  MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3)
+#undef MFM_ONE
+}
+
+template <int K0, int K1, int K2, int K3>
+static bool try_launch4(const SeqLaunch& L, bool bwd, int total, int threads, size_t lds_bytes, hipStream_t stream,
+                        hipError_t* err) {
+  const int want[4] = {K0, K1, K2, K3};
+  int n = 0;
+  for (int i = 0; i < 4; ++i) if (want[i] > 0) n = i + 1;
+  if (L.count != n) return false;
+  for (int i = 0; i < n; ++i) if (L.d[i].hk4 != want[i]) return false;
+  *err = hipSuccess;
+  if (lds_bytes > 64 * 1024) {
+    *err = bwd ? hipFuncSetAttribute((const void*)lstm_seq_small_kernel4<true, K0, K1, K2, K3>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
+               : hipFuncSetAttribute((const void*)lstm_seq_small_kernel4<false, K0, K1, K2, K3>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (*err != hipSuccess) return true;
+  }
+  if (bwd)
+    hipLaunchKernelGGL((lstm_seq_small_kernel4<true, K0, K1, K2, K3>), dim3(total), dim3(threads), lds_bytes, stream, L);
+  else
+    hipLaunchKernelGGL((lstm_seq_small_kernel4<false, K0, K1, K2, K3>), dim3(total), dim3(threads), lds_bytes, stream, L);
+  return true;
+}
+
 int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
   const int tiles = cdiv(L.B, 4);
   int total = 0, max_threads = 64;
@@ -372,6 +421,18 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
     const size_t HKB = (HK + 15) / 16 * 16;
     const size_t need = (bwd ? 2 * 4 * HKB * 4 + (size_t)d.h * d.h : 2 * HK * 4 + 2 * (size_t)d.h * d.h) * sizeof(float);
     if (need > lds_bytes) lds_bytes = need;
+  }
+  {
+    hipError_t err = hipSuccess;
+    if (try_launch4<8, 2, 20, 30>(L, bwd, total, max_threads, lds_bytes, stream, &err) ||     // MFM_KL_EF encoders
+        try_launch4<26, 6, 6, 0>(L, bwd, total, max_threads, lds_bytes, stream, &err) ||      // decoders
+        try_launch4<30, 0, 0, 0>(L, bwd, total, max_threads, lds_bytes, stream, &err) ||      // single-LSTM launches
+        try_launch4<26, 0, 0, 0>(L, bwd, total, max_threads, lds_bytes, stream, &err) ||
+        try_launch4<8, 0, 0, 0>(L, bwd, total, max_threads, lds_bytes, stream, &err)) {
+      if (err != hipSuccess) return hip_fail(err, "hipFuncSetAttribute(lstm_seq_small_kernel4)");
+      MFM_LAUNCH_CHECK(bwd ? "lstm_seq_small_bwd_kernel4" : "lstm_seq_small_fwd_kernel4");
+      return MFM_OK;
+    }
   }
   if (lds_bytes > 64 * 1024) {
     MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_kernel<true>,
@@ -388,3 +449,4 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
 }
 
 }  // namespace mfm
+
