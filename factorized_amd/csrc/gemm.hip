@@ -4,15 +4,17 @@
 // encoders; the 12 weight-gradient products of the encoder backward; ...), because at the
 // MOSI batch size every one of them is far too small to fill 256 CUs on its own and a launch
 // boundary costs ~1.5 us.  Tiles are 32x32 or 64x64 (picked so the group yields >= ~2 blocks
-// per CU), K is staged 16 deep through LDS in [k][m] / [k][n] order so that the MFMA operand
+// per CU), K is staged 32 deep through LDS in [k][m] / [k][n] order so that the MFMA operand
 // reads (16 consecutive m at one k) are bank-conflict free (row stride = tile+16 dwords, i.e.
 // == 16 mod 32 banks for the two k rows a 32-lane group touches).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mfm {
 
 #define MFM_GEMM_MAXP 24   // 24 x 168 B of descriptors stay inside the 4 KB kernel-argument segment
-constexpr int BK = 16;
+constexpr int BK = 32;   // K depth of one LDS stage: 8 MFMA k-steps between barriers
 
 struct GemmProblem {
   MfmGemmDesc d;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   // Register ring of DEPTH K-tiles in flight: at these sizes (K = 300..640, a handful of MFMAs per
   // tile) the K loop is a chain of global-load round trips, so the loads of tile kt+DEPTH are
   // issued as soon as tile kt has been copied to LDS.
-  constexpr int DEPTH = 4;
+  constexpr int DEPTH = 3;
   float ra[DEPTH][EPT_A], rb[DEPTH][EPT_B];
 
   auto load_tiles = [&](int slot, int k0) {
@@ -202,7 +204,8 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream) {
     MFM_REQUIRE(d.split_k <= 1 || d.accumulate, "gemm[%d]: split_k needs accumulate", i);
     blocks64 += (long)cdiv(d.m, 64) * cdiv(d.n, 64) * d.batch;
   }
-  const int FR = (blocks64 >= 2L * cus) ? 2 : 1;
+  int FR = (blocks64 >= 2L * cus) ? 2 : 1;
+  if (const char* e = getenv("MFM_GEMM_FR")) FR = (e[0] == '2') ? 2 : 1;   // tuning override
   const int BT = 32 * FR;
   long base_blocks = 0;
   for (int i = 0; i < count; ++i)
@@ -215,11 +218,16 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream) {
     P.tiles_n = cdiv(P.d.n, BT);
     int split = P.d.split_k;
     if (split <= 0) {
-      // auto: only for accumulate problems with a long reduction; aim at ~3 blocks per CU
+      // auto (accumulate problems only).  Two reasons to split K: (a) fill the chip when the whole
+      // group has few blocks; (b) bound the serial K loop of ONE block -- a weight-gradient product
+      // has a small output and K = T*B rows, and must not run as 10 blocks x 40960 deep just because
+      // a large sibling problem already fills the grid.
       split = 1;
       if (P.d.accumulate && P.d.k >= 128) {
-        long want = (3L * cus + base_blocks - 1) / base_blocks;
-        long maxs = P.d.k / 64;
+        const long want_fill = (3L * cus + base_blocks - 1) / base_blocks;
+        const long want_depth = (P.d.k + 1023) / 1024;
+        long want = want_fill > want_depth ? want_fill : want_depth;
+        const long maxs = P.d.k / 64;
         split = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
         if (split < 1) split = 1;
       }

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Batch sweep of the fused MFM_KL_EF training step on one MI355X: samples/s, step TFLOP/s and the
+fraction of the fp32 matrix/vector peak (157.3 TF) versus per-GPU batch size, for both recurrent
+kernel families.  At the reference's B=32 the step is latency-bound (80 serial LSTM steps); the
+roofline fraction only becomes meaningful as B grows."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from factorized_amd import configs as C, engine, synth  # noqa: E402
+
+PEAK = 157.3
+
+
+def run(B, path, steps):
+    os.environ["MFM_SEQ_PATH"] = path
+    cfgs = C.canonical_configs(dropout=True)
+    e = engine.MFMEngine(cfgs)
+    e.load_weights(synth.make_weights(e.layout.shapes, seed=1234))
+    xn, yn = synth.make_batch(cfgs[0]["input_dims"], B, 20, seed=3)
+    x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
+    for _ in range(5):
+        e.train_step(x, y, check=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e.train_step(x, y, check=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    w = e.work_per_step(20, B)
+    return dict(B=B, path=path, ms=1e3 * dt, samples_per_s=B / dt, tflops=w["flops"] / dt / 1e12,
+                frac=w["flops"] / dt / 1e12 / PEAK, hbm_gbs=w["bytes"] / dt / 1e9)
+
+
+if __name__ == "__main__":
+    Bs = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [32, 128, 512, 2048, 8192]
+    print("%6s %6s %9s %12s %8s %8s %9s" % ("B", "path", "ms/step", "samples/s", "TFLOP/s", "frac", "alg GB/s"))
+    for B in Bs:
+        for path in ("small", "mfma"):
+            r = run(B, path, steps=50 if B <= 2048 else 10)
+            print("%6d %6s %9.3f %12.0f %8.2f %8.4f %9.1f" % (r["B"], r["path"], r["ms"], r["samples_per_s"],
+                                                              r["tflops"], r["frac"], r["hbm_gbs"]))
+            sys.stdout.flush()
