@@ -124,6 +124,16 @@ def main():
         k_flops = timed["flops"]
         achieved = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 and k_flops > 0 else 0.0
         work = e.work_per_step(T, B)
+        # HBM bytes per launch of the dominant kernel: measured in a SEPARATE rocprofv3 --pmc pass of this
+        # command (scripts/profile_round.sh -> profiles/r01_traffic.json); only valid for the workload it
+        # was measured on, otherwise null.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and args.shape == "mosi" and B == 32 and T == 20:
+            try:
+                traffic = json.load(open(tpath)).get(dom, {}).get("total_bytes")
+            except Exception:
+                traffic = None
         out = {
             "metric": "training samples/sec (MOSI-shape, T=%d, 3 modalities)" % T,
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -135,7 +145,9 @@ def main():
                        "params": e.layout.numel},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 4),
                          "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 6), "traffic": None,
+                         "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 6), "traffic": traffic,
+                         "note": "fp32 matrix peak == fp32 vector peak on gfx950 (157.3 TF); at B<=512 the "
+                                 "recurrent products run on the VALU small-tile kernels, above on the MFMA",
                          "kernel_us": round(1e3 * k_ms, 2), "kernel_flops": k_flops,
                          "step_flops": work["flops"], "step_bytes": work["bytes"],
                          "step_tflops": round(work["flops"] / (ms * 1e-3) / 1e12, 4)},
