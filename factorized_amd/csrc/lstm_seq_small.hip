@@ -41,6 +41,24 @@ constexpr int DPP_ROW_MIRROR = 0x140;
 // lane i <-> lane i^4 inside each group of 8: half-mirror (i -> 7-i) then quad reverse (i -> i^3)
 __device__ __forceinline__ float dpp_xor4(float x) { return dpp_f<DPP_QUAD_REV>(dpp_f<DPP_ROW_HALF_MIRROR>(x)); }
 
+// R consecutive floats from LDS (one ds_read_b32/b64/b128)
+template <int R> struct RowVec { float v[R]; };
+template <int R>
+__device__ __forceinline__ RowVec<R> ld_rows(const float* p) {
+  RowVec<R> o;
+  if constexpr (R == 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); o.v[0] = t[0]; o.v[1] = t[1]; o.v[2] = t[2]; o.v[3] = t[3]; }
+  else if constexpr (R == 2) { typedef float f32x2 __attribute__((ext_vector_type(2))); const f32x2 t = *reinterpret_cast<const f32x2*>(p); o.v[0] = t[0]; o.v[1] = t[1]; }
+  else { o.v[0] = p[0]; }
+  return o;
+}
+// element `r` (lane-dependent, r < R) of a register array without dynamic indexing
+template <int R>
+__device__ __forceinline__ float sel_row(const float (&a)[R], int r) {
+  if constexpr (R == 4) { const float lo = (r & 1) ? a[1] : a[0], hi = (r & 1) ? a[3] : a[2]; return (r & 2) ? hi : lo; }
+  else if constexpr (R == 2) { return (r & 1) ? a[1] : a[0]; }
+  else { return a[0]; }
+}
+
 // Copy one gate's [h x h] weight block into the LDS panel, coalesced, 4 loads in flight per thread.
 // mode 0: W_hh   1: W_ih   2: W_ih + W_hh (decoder steps >= 1, mfm_model.py:85)
 __device__ __forceinline__ void stage_gate(const SeqDev& d, int mode, int g, float* __restrict__ panel, int tid,
@@ -71,17 +89,18 @@ __device__ __forceinline__ void stage_gate(const SeqDev& d, int mode, int g, flo
 }
 
 // --------------------------------------------------------------------------------- forward
-template <int KQ>
+template <int KQ, int R>
 __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds) {
-  constexpr int R = 4;
   constexpr int HK = 4 * KQ;        // padded hidden extent
   const int tid = threadIdx.x, nt = blockDim.x;
   const int q = tid & 3, gp = (tid >> 2) & 1, u = tid >> 3;
   const int h = d.h, Hp = d.Hp;
   const bool dec = d.is_dec != 0;
   const bool uact = u < Hp;
-  const int b = tile * R + q;
-  const bool bvalid = uact && (b < B);
+  const int myrow = q & (R - 1);              // lanes q >= R duplicate row q % R (compute only, no stores)
+  const bool rowner = q < R;
+  const int b = tile * R + myrow;
+  const bool bvalid = uact && rowner && (b < B);
 
   float* hbuf = lds;                 // [2][HK][R]
   float* panel = lds + 2 * HK * R;   // [2][h][h] weight staging (two gates at a time)
@@ -117,7 +136,7 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
   }
   if (dec) {
     for (int idx = tid; idx < HK * R; idx += nt) {
-      const int k = idx >> 2, br = tile * R + (idx & 3);
+      const int k = idx / R, br = tile * R + (idx % R);
       hbuf[idx] = (k < h && br < B) ? d.h_init[(int64_t)br * d.ld_init + k] : 0.0f;
     }
     __syncthreads();
@@ -141,17 +160,17 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
     if (dec || t > 0) {
       const float* hb = hbuf + cur * (HK * R) + q * R;
       constexpr int RING = (KQ < 4) ? KQ : 4;      // LDS reads kept in flight ahead of their FMAs
-      f32x4 ring[RING];
+      RowVec<R> ring[RING];
 #pragma unroll
-      for (int j = 0; j < RING; ++j) ring[j] = *reinterpret_cast<const f32x4*>(hb + 16 * j);
+      for (int j = 0; j < RING; ++j) ring[j] = ld_rows<R>(hb + 4 * R * j);
 #pragma unroll
       for (int j = 0; j < KQ; ++j) {
-        const f32x4 hv = ring[j % RING];                                   // rows 0..3 of k = 4j+q
-        if (j + RING < KQ) ring[j % RING] = *reinterpret_cast<const f32x4*>(hb + 16 * (j + RING));
+        const RowVec<R> hv = ring[j % RING];                               // the R rows of k = 4j+q
+        if (j + RING < KQ) ring[j % RING] = ld_rows<R>(hb + 4 * R * (j + RING));
 #pragma unroll
         for (int gl = 0; gl < 2; ++gl)
 #pragma unroll
-          for (int r = 0; r < R; ++r) acc[gl][r] = fmaf(w[gl][j], hv[r], acc[gl][r]);
+          for (int r = 0; r < R; ++r) acc[gl][r] = fmaf(w[gl][j], hv.v[r], acc[gl][r]);
       }
     }
     // all-reduce the four k-slices of the quad, keep the sums of batch row q, add bias / x-projection
@@ -165,9 +184,7 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
         v += dpp_f<DPP_QUAD_XOR2>(v);
         acc[gl][r] = v;
       }
-      const float lo = (q & 1) ? acc[gl][1] : acc[gl][0];
-      const float hi = (q & 1) ? acc[gl][3] : acc[gl][2];
-      mine[gl] = ((q & 2) ? hi : lo) + gxb[gl];
+      mine[gl] = sel_row<R>(acc[gl], myrow) + gxb[gl];
     }
     if (!dec && t + 1 < T && bvalid) {
 #pragma unroll
@@ -188,7 +205,7 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
       if (gp == 0) { gpt[0] = gi; gpt[Hp] = gf; d.cs[rowt * Hp + u] = c; }
       else { gpt[2 * Hp] = gg; gpt[3 * Hp] = go; d.hs[rowt * Hp + u] = hv; }
     }
-    if (uact && gp == 0 && u < HK) hbuf[(cur ^ 1) * (HK * R) + u * R + q] = (b < B) ? hv : 0.0f;
+    if (uact && rowner && gp == 0 && u < HK) hbuf[(cur ^ 1) * (HK * R) + u * R + myrow] = (b < B) ? hv : 0.0f;
     lds_barrier();
     cur ^= 1;
   };
@@ -206,9 +223,8 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
 }
 
 // --------------------------------------------------------------------------------- backward
-template <int KQ>
+template <int KQ, int R>
 __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds) {
-  constexpr int R = 4;
   constexpr int HK = 4 * KQ;                       // padded hidden extent
   constexpr int HKB = (HK + 15) / 16 * 16;         // per-gate extent of the dA panel (multiple of 16)
   constexpr int NG = HKB / 16;                     // gate columns per thread and gate
@@ -219,7 +235,7 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
   const bool dec = d.is_dec != 0;
   const int ua = 2 * up, ub = 2 * up + 1;           // the two output units whose W^T rows this thread holds
   const int mu = 2 * up + ((q >> 2) & 1), mr = q & 3;   // the (unit,row) lanes q<8 own in the pointwise part
-  const bool own = (q < 8) && (mu < Hp);
+  const bool own = (q < 8) && (mr < R) && (mu < Hp);
   const int b = tile * R + mr;
   const bool bvalid = own && (b < B);
 
@@ -282,20 +298,22 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
         for (int g = 0; g < 4; ++g) db[(g * HKB + mu) * R + mr] = da[g];
       }
       lds_barrier();
-      float aa[R] = {0.f, 0.f, 0.f, 0.f}, ab[R] = {0.f, 0.f, 0.f, 0.f};
+      float aa[R], ab[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) { aa[r] = 0.0f; ab[r] = 0.0f; }
       const float* dp = db + q * R;
       constexpr int RING = (NW < 4) ? NW : 4;
-      f32x4 ring[RING];
+      RowVec<R> ring[RING];
 #pragma unroll
-      for (int i = 0; i < RING; ++i) ring[i] = *reinterpret_cast<const f32x4*>(dp + 64 * i);
+      for (int i = 0; i < RING; ++i) ring[i] = ld_rows<R>(dp + 16 * R * i);
 #pragma unroll
       for (int i = 0; i < NW; ++i) {
-        const f32x4 dv = ring[i % RING];                                   // rows 0..3 of column 16i+q
-        if (i + RING < NW) ring[i % RING] = *reinterpret_cast<const f32x4*>(dp + 64 * (i + RING));
+        const RowVec<R> dv = ring[i % RING];                               // the R rows of column 16i+q
+        if (i + RING < NW) ring[i % RING] = ld_rows<R>(dp + 16 * R * (i + RING));
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          aa[r] = fmaf(wa[i], dv[r], aa[r]);
-          ab[r] = fmaf(wb[i], dv[r], ab[r]);
+          aa[r] = fmaf(wa[i], dv.v[r], aa[r]);
+          ab[r] = fmaf(wb[i], dv.v[r], ab[r]);
         }
       }
       // all-reduce over the 16 k-slices
@@ -310,9 +328,7 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
         v += dpp_f<DPP_ROW_HALF_MIRROR>(v); v += dpp_f<DPP_ROW_MIRROR>(v);
         ab[r] = v;
       }
-      const float la = (mr & 1) ? aa[1] : aa[0], ha = (mr & 1) ? aa[3] : aa[2];
-      const float lb = (mr & 1) ? ab[1] : ab[0], hb = (mr & 1) ? ab[3] : ab[2];
-      const float sa = (mr & 2) ? ha : la, sb = (mr & 2) ? hb : lb;
+      const float sa = sel_row<R>(aa, mr & (R - 1)), sb = sel_row<R>(ab, mr & (R - 1));
       dh_rec = (q & 4) ? sb : sa;
       cur ^= 1;
     }
@@ -325,22 +341,22 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
 
 #define MFM_SMALL_CASES(BODY)                                                                \
   switch (d.hk4) {                                                                           \
-    case 2: BODY<2>(d, L.T, L.B, tile, lds); break;                                          \
-    case 4: BODY<4>(d, L.T, L.B, tile, lds); break;                                          \
-    case 6: BODY<6>(d, L.T, L.B, tile, lds); break;                                          \
-    case 8: BODY<8>(d, L.T, L.B, tile, lds); break;                                          \
-    case 10: BODY<10>(d, L.T, L.B, tile, lds); break;                                        \
-    case 12: BODY<12>(d, L.T, L.B, tile, lds); break;                                        \
-    case 14: BODY<14>(d, L.T, L.B, tile, lds); break;                                        \
-    case 16: BODY<16>(d, L.T, L.B, tile, lds); break;                                        \
-    case 18: BODY<18>(d, L.T, L.B, tile, lds); break;                                        \
-    case 20: BODY<20>(d, L.T, L.B, tile, lds); break;                                        \
-    case 22: BODY<22>(d, L.T, L.B, tile, lds); break;                                        \
-    case 24: BODY<24>(d, L.T, L.B, tile, lds); break;                                        \
-    case 26: BODY<26>(d, L.T, L.B, tile, lds); break;                                        \
-    case 28: BODY<28>(d, L.T, L.B, tile, lds); break;                                        \
-    case 30: BODY<30>(d, L.T, L.B, tile, lds); break;                                        \
-    case 32: BODY<32>(d, L.T, L.B, tile, lds); break;                                        \
+    case 2: BODY<2, 4>(d, L.T, L.B, tile, lds); break;                                          \
+    case 4: BODY<4, 4>(d, L.T, L.B, tile, lds); break;                                          \
+    case 6: BODY<6, 4>(d, L.T, L.B, tile, lds); break;                                          \
+    case 8: BODY<8, 4>(d, L.T, L.B, tile, lds); break;                                          \
+    case 10: BODY<10, 4>(d, L.T, L.B, tile, lds); break;                                        \
+    case 12: BODY<12, 4>(d, L.T, L.B, tile, lds); break;                                        \
+    case 14: BODY<14, 4>(d, L.T, L.B, tile, lds); break;                                        \
+    case 16: BODY<16, 4>(d, L.T, L.B, tile, lds); break;                                        \
+    case 18: BODY<18, 4>(d, L.T, L.B, tile, lds); break;                                        \
+    case 20: BODY<20, 4>(d, L.T, L.B, tile, lds); break;                                        \
+    case 22: BODY<22, 4>(d, L.T, L.B, tile, lds); break;                                        \
+    case 24: BODY<24, 4>(d, L.T, L.B, tile, lds); break;                                        \
+    case 26: BODY<26, 4>(d, L.T, L.B, tile, lds); break;                                        \
+    case 28: BODY<28, 4>(d, L.T, L.B, tile, lds); break;                                        \
+    case 30: BODY<30, 4>(d, L.T, L.B, tile, lds); break;                                        \
+    case 32: BODY<32, 4>(d, L.T, L.B, tile, lds); break;                                        \
     default: break;                                                                          \
   }
 
@@ -365,7 +381,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_kernel(const SeqLaunch L)
 // 16 the register allocator reaches single-variant quality (the 16-way switch spills ~80 VGPRs in the
 // forward time loop, 4x slower).  The canonical MFM sizes (encoders 32/8/80/120, decoders 104/24/24)
 // are pre-instantiated; any other size combination takes the generic kernel above.
-template <bool BWD, int K0, int K1, int K2, int K3>
+template <bool BWD, int R, int K0, int K1, int K2, int K3>
 __global__ __launch_bounds__(1024) void lstm_seq_small_kernel4(const SeqLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int di = 0;
@@ -377,15 +393,15 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_kernel4(const SeqLaunch L
   const int tile = bid - d.block_begin;
 #define MFM_ONE(IDX, KK)                                                         \
   if (KK > 0 && di == IDX) {                                                     \
-    if (BWD) small_bwd_body<(KK > 0 ? KK : 2)>(d, L.T, L.B, tile, lds);          \
-    else small_fwd_body<(KK > 0 ? KK : 2)>(d, L.T, L.B, tile, lds);              \
+    if (BWD) small_bwd_body<(KK > 0 ? KK : 2), R>(d, L.T, L.B, tile, lds);       \
+    else small_fwd_body<(KK > 0 ? KK : 2), R>(d, L.T, L.B, tile, lds);           \
     return;                                                                      \
   }
   MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3)
 #undef MFM_ONE
 }
 
-template <int K0, int K1, int K2, int K3>
+template <int R, int K0, int K1, int K2, int K3>
 static bool try_launch4(const SeqLaunch& L, bool bwd, int total, int threads, size_t lds_bytes, hipStream_t stream,
                         hipError_t* err) {
   const int want[4] = {K0, K1, K2, K3};
@@ -395,45 +411,74 @@ static bool try_launch4(const SeqLaunch& L, bool bwd, int total, int threads, si
   for (int i = 0; i < n; ++i) if (L.d[i].hk4 != want[i]) return false;
   *err = hipSuccess;
   if (lds_bytes > 64 * 1024) {
-    *err = bwd ? hipFuncSetAttribute((const void*)lstm_seq_small_kernel4<true, K0, K1, K2, K3>,
+    *err = bwd ? hipFuncSetAttribute((const void*)lstm_seq_small_kernel4<true, R, K0, K1, K2, K3>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
-               : hipFuncSetAttribute((const void*)lstm_seq_small_kernel4<false, K0, K1, K2, K3>,
+               : hipFuncSetAttribute((const void*)lstm_seq_small_kernel4<false, R, K0, K1, K2, K3>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (*err != hipSuccess) return true;
   }
   if (bwd)
-    hipLaunchKernelGGL((lstm_seq_small_kernel4<true, K0, K1, K2, K3>), dim3(total), dim3(threads), lds_bytes, stream, L);
+    hipLaunchKernelGGL((lstm_seq_small_kernel4<true, R, K0, K1, K2, K3>), dim3(total), dim3(threads), lds_bytes, stream, L);
   else
-    hipLaunchKernelGGL((lstm_seq_small_kernel4<false, K0, K1, K2, K3>), dim3(total), dim3(threads), lds_bytes, stream, L);
+    hipLaunchKernelGGL((lstm_seq_small_kernel4<false, R, K0, K1, K2, K3>), dim3(total), dim3(threads), lds_bytes, stream, L);
   return true;
 }
 
-int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
-  const int tiles = cdiv(L.B, 4);
-  int total = 0, max_threads = 64;
+template <int R>
+static bool try_all(const SeqLaunch& L, bool bwd, int total, int threads, size_t lds_bytes, hipStream_t stream,
+                    hipError_t* err) {
+  return try_launch4<R, 8, 2, 20, 30>(L, bwd, total, threads, lds_bytes, stream, err) ||     // MFM_KL_EF encoders
+         try_launch4<R, 26, 6, 6, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||      // decoders
+         try_launch4<R, 30, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||      // single-LSTM launches
+         try_launch4<R, 26, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||
+         try_launch4<R, 8, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err);
+}
+
+static size_t small_lds_bytes(const SeqLaunch& L, bool bwd, int R) {
   size_t lds_bytes = 0;
   for (int i = 0; i < L.count; ++i) {
-    SeqDev& d = L.d[i];
-    d.block_begin = total;
-    total += tiles;
-    if (8 * d.Hp > max_threads) max_threads = 8 * d.Hp;
+    const SeqDev& d = L.d[i];
     const size_t HK = (size_t)d.hk4 * 4;
     const size_t HKB = (HK + 15) / 16 * 16;
-    const size_t need = (bwd ? 2 * 4 * HKB * 4 + (size_t)d.h * d.h : 2 * HK * 4 + 2 * (size_t)d.h * d.h) * sizeof(float);
+    const size_t need = (bwd ? 2 * 4 * HKB * R + (size_t)d.h * d.h : 2 * HK * R + 2 * (size_t)d.h * d.h) * sizeof(float);
     if (need > lds_bytes) lds_bytes = need;
   }
-  {
+  return (lds_bytes + 15) / 16 * 16;
+}
+
+int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
+  int max_threads = 64;
+  for (int i = 0; i < L.count; ++i)
+    if (8 * L.d[i].Hp > max_threads) max_threads = 8 * L.d[i].Hp;
+  // Row-tile size: the finest tile that still gives at most ~1 workgroup per CU.  Fewer rows per
+  // workgroup = shorter serial chain per time step (the step time is VALU-issue bound: ~60 FMAs per
+  // thread and row); only the pre-instantiated size tuples have R < 4 variants.
+  const int cus = device_cus();
+  int R = 4;
+  if ((long)L.count * cdiv(L.B, 1) <= (long)cus + cus / 8) R = 1;
+  else if ((long)L.count * cdiv(L.B, 2) <= (long)cus + cus / 8) R = 2;
+  if (const char* e = getenv("MFM_SEQ_ROWS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) R = v; }
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const int tiles = cdiv(L.B, R);
+    int total = 0;
+    for (int i = 0; i < L.count; ++i) { L.d[i].block_begin = total; total += tiles; }
+    const size_t lds_bytes = small_lds_bytes(L, bwd, R);
     hipError_t err = hipSuccess;
-    if (try_launch4<8, 2, 20, 30>(L, bwd, total, max_threads, lds_bytes, stream, &err) ||     // MFM_KL_EF encoders
-        try_launch4<26, 6, 6, 0>(L, bwd, total, max_threads, lds_bytes, stream, &err) ||      // decoders
-        try_launch4<30, 0, 0, 0>(L, bwd, total, max_threads, lds_bytes, stream, &err) ||      // single-LSTM launches
-        try_launch4<26, 0, 0, 0>(L, bwd, total, max_threads, lds_bytes, stream, &err) ||
-        try_launch4<8, 0, 0, 0>(L, bwd, total, max_threads, lds_bytes, stream, &err)) {
+    bool done = false;
+    if (R == 1) done = try_all<1>(L, bwd, total, max_threads, lds_bytes, stream, &err);
+    else if (R == 2) done = try_all<2>(L, bwd, total, max_threads, lds_bytes, stream, &err);
+    else done = try_all<4>(L, bwd, total, max_threads, lds_bytes, stream, &err);
+    if (done) {
       if (err != hipSuccess) return hip_fail(err, "hipFuncSetAttribute(lstm_seq_small_kernel4)");
       MFM_LAUNCH_CHECK(bwd ? "lstm_seq_small_bwd_kernel4" : "lstm_seq_small_fwd_kernel4");
       return MFM_OK;
     }
+    R = 4;    // no specialised kernel for this size tuple: generic 16-variant kernel, 4-row tiles
   }
+  const int tiles = cdiv(L.B, 4);
+  int total = 0;
+  for (int i = 0; i < L.count; ++i) { L.d[i].block_begin = total; total += tiles; }
+  const size_t lds_bytes = small_lds_bytes(L, bwd, 4);
   if (lds_bytes > 64 * 1024) {
     MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_kernel<true>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -51,9 +51,14 @@ def test_forward_matches_reference_golden(name):
     assert np.allclose(cases.summarize(xl)[:2], gold["x_l_hat_sum"][:2], rtol=TOL, atol=1e-4)
 
 
-@pytest.fixture(params=["mfma", "small"])
+@pytest.fixture(params=["mfma", "small", "small:1", "small:2", "small:4"])
 def seq_path(request, monkeypatch):
-    monkeypatch.setenv("MFM_SEQ_PATH", request.param)
+    path, _, rows = request.param.partition(":")
+    monkeypatch.setenv("MFM_SEQ_PATH", path)
+    if rows:
+        monkeypatch.setenv("MFM_SEQ_ROWS", rows)      # force the row-tile size of the VALU kernels
+    else:
+        monkeypatch.delenv("MFM_SEQ_ROWS", raising=False)
     return request.param
 
 
