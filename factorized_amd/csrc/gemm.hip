@@ -4,9 +4,10 @@
 // encoders; the 12 weight-gradient products of the encoder backward; ...), because at the
 // MOSI batch size every one of them is far too small to fill 256 CUs on its own and a launch
 // boundary costs ~1.5 us.  Tiles are 32x32 or 64x64 (picked so the group yields >= ~2 blocks
-// per CU), K is staged 32 deep through LDS in [k][m] / [k][n] order so that the MFMA operand
-// reads (16 consecutive m at one k) are bank-conflict free (row stride = tile+16 dwords, i.e.
-// == 16 mod 32 banks for the two k rows a 32-lane group touches).
+// per CU), K is staged 32 deep through LDS.  The LDS image follows the operand's memory order so that
+// a thread's 4-element group is ONE ds_write_b128: [k][m+16] for m-/n-contiguous operands (MFMA
+// operand reads conflict-free: row stride == 16 mod 32 banks), [m][k+4] for k-contiguous ones (reads
+// at most 2-way).  Writing k-contiguous groups into a [k][m] image cost 8-way-conflicted ds_write_b32.
 #include <stdlib.h>
 
 #include "common.h"
@@ -25,13 +26,19 @@ struct GemmGroup {
   int count;
 };
 
-template <int FR>
+// VEC: every operand of every problem in the group is unit-stride along its 4-element load groups
+// (true for all products of the MFM step); the 16-byte path is then unconditional.  A launch with
+// an oddly strided operand uses the VEC=false instantiation (dword buffer loads) for the whole group.
+template <int FR, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   constexpr int BM = 32 * FR, BN = 32 * FR;
-  constexpr int LDA = BM + 16, LDB = BN + 16;
+  constexpr int LDA = BM + 16, LDB = BN + 16;     // [k][m] layout (m-/n-contiguous operands)
+  constexpr int LDK = BK + 4;                     // [m][k] layout (k-contiguous operands)
   constexpr int EPT_A = BM * BK / 256, EPT_B = BN * BK / 256;
-  __shared__ float As[BK * LDA];
-  __shared__ float Bs[BK * LDB];
+  constexpr int ASZ = (BK * LDA > BM * LDK) ? BK * LDA : BM * LDK;
+  constexpr int BSZ = (BK * LDB > BN * LDK) ? BK * LDB : BN * LDK;
+  __shared__ __attribute__((aligned(16))) float As[ASZ];
+  __shared__ __attribute__((aligned(16))) float Bs[BSZ];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -61,49 +68,110 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   const bool a_mcontig = (d.a_sm == 1 && d.a_sk != 1);
   const bool b_ncontig = (d.b_sn == 1 && d.b_sk != 1);
 
-  // Register ring of DEPTH K-tiles in flight: at these sizes (K = 300..640, a handful of MFMAs per
-  // tile) the K loop is a chain of global-load round trips, so the loads of tile kt+DEPTH are
-  // issued as soon as tile kt has been copied to LDS.
+  // Register ring of DEPTH K-tiles in flight.  At these sizes (K = 300..640, 8 MFMAs per wave and
+  // tile) one workgroup's K loop is a chain of latencies and, above all, of vector-memory instructions:
+  // measured ~10 B/clk/CU with dword loads whatever else was tuned.  So:
+  //   (a) tiles are fetched with BUFFER loads, 16 bytes per lane wherever the operand is unit-stride
+  //       along the thread's 4-element group (buffer_load_dwordx4 needs only 4-byte alignment); the
+  //       descriptor's num_records makes reads past the end of the operand return 0, so a group may
+  //       straddle a row end or the K tail without any branch -- invalid elements are zeroed by a
+  //       MULTIPLY (a select/branch makes hipcc wait vmcnt(0) right behind the load);
+  //   (b) the barriers are LDS-only (lds_barrier): __syncthreads() drains the ring with vmcnt(0);
+  //   (c) the operand fragments of a tile are read from LDS before the first MFMA.
   constexpr int DEPTH = 3;
+  constexpr int GA = EPT_A / 4, GB = EPT_B / 4;
   float ra[DEPTH][EPT_A], rb[DEPTH][EPT_B];
-
+  const int a_sm = (int)d.a_sm, a_sk = (int)d.a_sk, b_sk = (int)d.b_sk, b_sn = (int)d.b_sn;
+  // extents in bytes for the bounds-checked descriptors (host guarantees < 2^31)
+  const int a_bytes = ((d.m - 1) * a_sm + (max(d.k, 1) - 1) * a_sk + 1) * 4;
+  const int b_bytes = ((max(d.k, 1) - 1) * b_sk + (max(d.n_valid, 1) - 1) * b_sn + 1) * 4;
+  const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc((void*)Bm, 0, b_bytes, 0x00020000);
+  // loop-invariant group coordinates
+  int a_base[GA], a_gk[GA], a_gm[GA], b_base[GB], b_gk[GB], b_gn[GB];
+#pragma unroll
+  for (int g = 0; g < GA; ++g) {
+    const int idx = (tid * GA + g) * 4;
+    const int k = a_mcontig ? idx / BM : idx % BK;
+    const int m = a_mcontig ? idx % BM : idx / BK;
+    a_gk[g] = k; a_gm[g] = m0 + m;
+    a_base[g] = min(m0 + m, d.m - 1) * a_sm;
+  }
+#pragma unroll
+  for (int g = 0; g < GB; ++g) {
+    const int idx = (tid * GB + g) * 4;
+    const int k = b_ncontig ? idx / BN : idx % BK;
+    const int n = b_ncontig ? idx % BN : idx / BK;
+    b_gk[g] = k; b_gn[g] = n0 + n;
+    b_base[g] = min(n0 + n, max(d.n_valid - 1, 0)) * b_sn;
+  }
+  const int klast = max(kend - 1, 0);
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   auto load_tiles = [&](int slot, int k0) {
 #pragma unroll
-    for (int j = 0; j < EPT_A; ++j) {
-      const int idx = tid * EPT_A + j;
-      int m, k;
-      if (a_mcontig) { k = idx / BM; m = idx % BM; } else { m = idx / BK; k = idx % BK; }
-      const int gm = m0 + m, gk = k0 + k;
-      // unconditional load from a clamped (always valid) address + select: no branch, so the
-      // compiler can keep several tiles' loads in flight with counted vmcnt waits
-      const float v = A[(int64_t)min(gm, d.m - 1) * d.a_sm + (int64_t)min(gk, kend - 1) * d.a_sk];
-      ra[slot][j] = v * (float)((int)(gm < d.m) & (int)(gk < kend));   // multiply, not select: stays branch-free
+    for (int g = 0; g < GA; ++g) {
+      const int gk = k0 + a_gk[g], gm = a_gm[g];
+      f32x4 v;
+      if constexpr (VEC) {
+        const int off = a_base[g] + min(gk, klast) * a_sk;
+        v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ares, off * 4, 0, 0));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                     ares, (a_base[g] + min(gk + e, klast) * a_sk) * 4, 0, 0));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int em = a_mcontig ? gm + e : gm, ek = a_mcontig ? gk : gk + e;
+        ra[slot][4 * g + e] = v[e] * (float)((int)(em < d.m) & (int)(ek < kend));
+      }
     }
 #pragma unroll
-    for (int j = 0; j < EPT_B; ++j) {
-      const int idx = tid * EPT_B + j;
-      int n, k;
-      if (b_ncontig) { k = idx / BN; n = idx % BN; } else { n = idx / BK; k = idx % BK; }
-      const int gn = n0 + n, gk = k0 + k;
-      const float v = Bm[(int64_t)min(gk, kend - 1) * d.b_sk + (int64_t)min(gn, d.n_valid - 1) * d.b_sn];
-      rb[slot][j] = v * (float)((int)(gn < d.n_valid) & (int)(gk < kend));
+    for (int g = 0; g < GB; ++g) {
+      const int gk = k0 + b_gk[g], gn = b_gn[g];
+      f32x4 v;
+      if constexpr (VEC) {
+        const int off = b_base[g] + min(gk, klast) * b_sk;
+        v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bres, off * 4, 0, 0));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                     bres, (b_base[g] + min(gk + e, klast) * b_sk) * 4, 0, 0));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int en = b_ncontig ? gn + e : gn, ek = b_ncontig ? gk : gk + e;
+        rb[slot][4 * g + e] = v[e] * (float)((int)(en < d.n_valid) & (int)(ek < kend));
+      }
     }
   };
+  // LDS strides of the two images (block-uniform values, no divergent control flow)
+  const int a_lm = a_mcontig ? 1 : LDK, a_lk = a_mcontig ? LDA : 1;
+  const int b_ln = b_ncontig ? 1 : LDK, b_lk = b_ncontig ? LDB : 1;
+  int a_st[GA], b_st[GB];
+#pragma unroll
+  for (int g = 0; g < GA; ++g) {
+    const int idx = (tid * GA + g) * 4;
+    const int k = a_mcontig ? idx / BM : idx % BK;
+    const int m = a_mcontig ? idx % BM : idx / BK;
+    a_st[g] = m * a_lm + k * a_lk;
+  }
+#pragma unroll
+  for (int g = 0; g < GB; ++g) {
+    const int idx = (tid * GB + g) * 4;
+    const int k = b_ncontig ? idx / BN : idx % BK;
+    const int n = b_ncontig ? idx % BN : idx / BK;
+    b_st[g] = n * b_ln + k * b_lk;
+  }
   auto store_tiles = [&](int slot) {
 #pragma unroll
-    for (int j = 0; j < EPT_A; ++j) {
-      const int idx = tid * EPT_A + j;
-      int m, k;
-      if (a_mcontig) { k = idx / BM; m = idx % BM; } else { m = idx / BK; k = idx % BK; }
-      As[k * LDA + m] = ra[slot][j];
-    }
+    for (int g = 0; g < GA; ++g)
+      *reinterpret_cast<f32x4*>(As + a_st[g]) = f32x4{ra[slot][4 * g], ra[slot][4 * g + 1], ra[slot][4 * g + 2], ra[slot][4 * g + 3]};
 #pragma unroll
-    for (int j = 0; j < EPT_B; ++j) {
-      const int idx = tid * EPT_B + j;
-      int n, k;
-      if (b_ncontig) { k = idx / BN; n = idx % BN; } else { n = idx / BK; k = idx % BK; }
-      Bs[k * LDB + n] = rb[slot][j];
-    }
+    for (int g = 0; g < GB; ++g)
+      *reinterpret_cast<f32x4*>(Bs + b_st[g]) = f32x4{rb[slot][4 * g], rb[slot][4 * g + 1], rb[slot][4 * g + 2], rb[slot][4 * g + 3]};
   };
 
   f32x4 acc[FR][FR];
@@ -113,32 +181,32 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
     for (int j = 0; j < FR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (kend - kbeg + BK - 1) / BK;
+  // the ring is always filled DEPTH deep (tiles past the end load clamped addresses and are masked
+  // to zero): no branch around a load anywhere
 #pragma unroll
-  for (int s = 0; s < DEPTH; ++s)
-    if (s < nkt) load_tiles(s, kbeg + s * BK);
+  for (int s = 0; s < DEPTH; ++s) load_tiles(s, kbeg + s * BK);
   for (int kt0 = 0; kt0 < nkt; kt0 += DEPTH) {
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s) {
       const int kt = kt0 + s;
-      if (kt < nkt) {
-        store_tiles(s);
-        __syncthreads();
-        if (kt + DEPTH < nkt) load_tiles(s, kbeg + (kt + DEPTH) * BK);
+      store_tiles(s);                       // tiles beyond nkt are all-zero: harmless extra MFMAs
+      lds_barrier();
+      load_tiles(s, kbeg + (kt + DEPTH) * BK);
+      float af[BK / 4][FR], bf[BK / 4][FR];
 #pragma unroll
-        for (int ks = 0; ks < BK / 4; ++ks) {
-          float af[FR], bf[FR];
+      for (int ks = 0; ks < BK / 4; ++ks)
 #pragma unroll
-          for (int f = 0; f < FR; ++f) {
-            af[f] = As[(ks * 4 + q) * LDA + wm * 16 * FR + f * 16 + bi];
-            bf[f] = Bs[(ks * 4 + q) * LDB + wn * 16 * FR + f * 16 + bi];
-          }
-#pragma unroll
-          for (int fm = 0; fm < FR; ++fm)
-#pragma unroll
-            for (int fn = 0; fn < FR; ++fn) acc[fm][fn] = mma16x16x4(af[fm], bf[fn], acc[fm][fn]);
+        for (int f = 0; f < FR; ++f) {
+          af[ks][f] = As[(ks * 4 + q) * a_lk + (wm * 16 * FR + f * 16 + bi) * a_lm];
+          bf[ks][f] = Bs[(ks * 4 + q) * b_lk + (wn * 16 * FR + f * 16 + bi) * b_ln];
         }
-        __syncthreads();
-      }
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ++ks)
+#pragma unroll
+        for (int fm = 0; fm < FR; ++fm)
+#pragma unroll
+          for (int fn = 0; fn < FR; ++fn) acc[fm][fn] = mma16x16x4(af[ks][fm], bf[ks][fn], acc[fm][fn]);
+      lds_barrier();
     }
   }
 
@@ -202,6 +270,12 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream) {
     MFM_REQUIRE(d.a && d.b && d.c, "gemm[%d]: null operand", i);
     MFM_REQUIRE(d.n_valid >= 0 && d.n_valid <= d.n, "gemm[%d]: n_valid %d > n %d", i, d.n_valid, d.n);
     MFM_REQUIRE(d.split_k <= 1 || d.accumulate, "gemm[%d]: split_k needs accumulate", i);
+    {
+      const int64_t lim = (int64_t)1 << 31;
+      const int64_t ea = (int64_t)(d.m - 1) * d.a_sm + (int64_t)(d.k > 0 ? d.k - 1 : 0) * d.a_sk;
+      const int64_t eb = (int64_t)(d.k > 0 ? d.k - 1 : 0) * d.b_sk + (int64_t)(d.n_valid > 0 ? d.n_valid - 1 : 0) * d.b_sn;
+      MFM_REQUIRE(ea < lim && eb < lim && ea >= 0 && eb >= 0, "gemm[%d]: operand spans >= 2^31 elements (32-bit tile offsets)", i);
+    }
     blocks64 += (long)cdiv(d.m, 64) * cdiv(d.n, 64) * d.batch;
   }
   int FR = (blocks64 >= 2L * cus) ? 2 : 1;
@@ -239,10 +313,19 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream) {
     P.block_begin = total;
     total += P.tiles_m * P.tiles_n * P.d.batch * split;
   }
-  if (FR == 2)
-    hipLaunchKernelGGL(gemm_f32_kernel<2>, dim3(total), dim3(256), 0, stream, g);
-  else
-    hipLaunchKernelGGL(gemm_f32_kernel<1>, dim3(total), dim3(256), 0, stream, g);
+  bool vec = true;
+  for (int i = 0; i < count; ++i) {
+    const MfmGemmDesc& d = descs[i];
+    const bool a_mcontig = (d.a_sm == 1 && d.a_sk != 1), b_ncontig = (d.b_sn == 1 && d.b_sk != 1);
+    if (!(a_mcontig || d.a_sk == 1) || !(b_ncontig || d.b_sk == 1)) vec = false;
+  }
+  if (FR == 2) {
+    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<2, true>), dim3(total), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<2, false>), dim3(total), dim3(256), 0, stream, g);
+  } else {
+    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<1, true>), dim3(total), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<1, false>), dim3(total), dim3(256), 0, stream, g);
+  }
   MFM_LAUNCH_CHECK("gemm_f32_kernel");
   return MFM_OK;
 }
