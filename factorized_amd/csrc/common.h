@@ -79,6 +79,15 @@ __device__ __forceinline__ float act_tanh(float x) {
 #endif
 }
 
+// sc == 1: sigmoid(x); sc == 2: tanh(x).  One instruction stream for lanes that need different gates.
+__device__ __forceinline__ float act_scaled(float x, float sc) {
+#if MFM_FAST_ACT
+  return fmaf(__builtin_amdgcn_rcpf(1.0f + __expf(-sc * x)), sc, 1.0f - sc);
+#else
+  return sc == 2.0f ? tanhf(x) : 1.0f / (1.0f + expf(-x));
+#endif
+}
+
 // Counter-based RNG for dropout masks: 2 rounds of a 64-bit mix (splitmix64 finaliser) over
 // (seed, call counter, element index) -> uniform in [0,1).  Not torch's Philox stream: dropout
 // parity with the CPU reference is statistical only.

@@ -106,7 +106,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
     b_base[g] = min(n0 + n, max(d.n_valid - 1, 0)) * b_sn;
   }
   const int klast = max(kend - 1, 0);
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   auto load_tiles = [&](int slot, int k0) {
 #pragma unroll
     for (int g = 0; g < GA; ++g) {

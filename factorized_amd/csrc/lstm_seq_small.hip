@@ -41,6 +41,12 @@ constexpr int DPP_ROW_MIRROR = 0x140;
 // lane i <-> lane i^4 inside each group of 8: half-mirror (i -> 7-i) then quad reverse (i -> i^3)
 __device__ __forceinline__ float dpp_xor4(float x) { return dpp_f<DPP_QUAD_REV>(dpp_f<DPP_ROW_HALF_MIRROR>(x)); }
 
+// Pin a descriptor field in scalar registers.  A lane-dependent choice between two fields of the by-value
+// launch descriptor otherwise becomes a load from a lane-dependent kernarg address, and the compiler
+// then copies the whole descriptor to scratch.
+template <class P>
+__device__ __forceinline__ P pin_s(P p) { asm volatile("" : "+s"(p)); return p; }
+
 // R consecutive floats from LDS (one ds_read_b32/b64/b128)
 template <int R> struct RowVec { float v[R]; };
 template <int R>
@@ -89,9 +95,19 @@ __device__ __forceinline__ void stage_gate(const SeqDev& d, int mode, int g, flo
 }
 
 // --------------------------------------------------------------------------------- forward
+// Global traffic goes through LDS so that it is issued by full, coalesced waves: a vector-memory
+// instruction occupies the CU's address unit for ~16 clocks per wave whether 2 or 64 lanes carry data,
+// and with one (unit, gate pair, k-slice) thread layout every wave would issue its own 3 stores and
+// 2 loads per step (80 instructions per step, ~0.5 us of a 1.4 us step; profiles/r01 seq experiments).
+// Instead the owners drop (i, f, g, o, c, h) into an LDS record and 6*Hp*R/64 waves write it out after
+// the step's barrier; the encoders' x-projections are fetched two steps ahead by 4*Hp*R/64 waves.
 template <int KQ, int R>
 __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds) {
-  constexpr int HK = 4 * KQ;        // padded hidden extent
+  constexpr int HK = 4 * KQ;                    // padded hidden extent of the matvec
+  constexpr int HKB = (HK + 15) / 16 * 16;      // == Hp
+  constexpr int NTH = 8 * HKB;                  // threads this LSTM uses (blockDim may be larger)
+  constexpr int NXL = (4 * R + 7) / 8;          // x-projection elements fetched per thread and step
+  constexpr int NOS = (6 * R + 7) / 8;          // output elements written per thread and step
   const int tid = threadIdx.x, nt = blockDim.x;
   const int q = tid & 3, gp = (tid >> 2) & 1, u = tid >> 3;
   const int h = d.h, Hp = d.Hp;
@@ -99,11 +115,13 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
   const bool uact = u < Hp;
   const int myrow = q & (R - 1);              // lanes q >= R duplicate row q % R (compute only, no stores)
   const bool rowner = q < R;
-  const int b = tile * R + myrow;
-  const bool bvalid = uact && rowner && (b < B);
+  const int b0 = tile * R;
+  const int b = b0 + myrow;
 
-  float* hbuf = lds;                 // [2][HK][R]
-  float* panel = lds + 2 * HK * R;   // [2][h][h] weight staging (two gates at a time)
+  float* hbuf = lds;                       // [2][HK][R]
+  float* panel = lds + 2 * HK * R;         // [2][h][h] weight staging (two gates at a time)
+  float* obuf = panel;                     // [2][6][HKB][R] step outputs; aliases the panel (barriers below)
+  float* xbuf = obuf + 2 * 6 * HKB * R;    // [2][4][HKB][R] x-projections of the next step (encoders)
 
   float w[2][KQ];
   // round gl stages gates gl (for the p=0 lanes) and 2+gl (p=1 lanes) side by side, so every
@@ -128,7 +146,7 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
   };
   load_w(dec ? 1 : 0);
 
-  // per-lane constant (decoder: bias) or per-step prefetched (encoder: x projection) additive term
+  // decoder: constant bias per lane; encoder: x projection (bias folded in by the GEMM) via xbuf
   float gxb[2] = {0.f, 0.f};
   if (dec && u < h) {
 #pragma unroll
@@ -136,22 +154,70 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
   }
   if (dec) {
     for (int idx = tid; idx < HK * R; idx += nt) {
-      const int k = idx / R, br = tile * R + (idx % R);
+      const int k = idx / R, br = b0 + (idx % R);
       hbuf[idx] = (k < h && br < B) ? d.h_init[(int64_t)br * d.ld_init + k] : 0.0f;
     }
-    __syncthreads();
   }
 
   const int64_t row4 = 4 * (int64_t)Hp;
-  if (!dec && bvalid) {
+  const int64_t gstep = (int64_t)B * row4, sstep = (int64_t)B * Hp;
+  // x-projection fetch elements: e -> (gate g, row r, unit), unit fastest (coalesced)
+  const float* xp[NXL];
+  int xl[NXL];
+  bool xok[NXL];
+  float xpf[NXL];
 #pragma unroll
-    for (int gl = 0; gl < 2; ++gl) gxb[gl] = d.gates[(int64_t)b * row4 + (2 * gp + gl) * Hp + u];
+  for (int i = 0; i < NXL; ++i) {
+    const int e = tid + i * NTH;
+    xok[i] = !dec && tid < NTH && e < 4 * HKB * R;
+    const int ec = xok[i] ? e : 0;
+    const int sr = ec / HKB, unit = ec % HKB, r = sr % R, g = sr / R;
+    xp[i] = d.gates + ((int64_t)min(b0 + r, B - 1) * 4 + g) * Hp + unit;
+    xl[i] = (g * HKB + unit) * R + r;
+    xpf[i] = 0.0f;
   }
+  if (!dec) {
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+      const float v0 = xp[i][0];
+      xpf[i] = xp[i][(T > 1) ? gstep : 0];
+      if (xok[i]) xbuf[xl[i]] = v0;
+    }
+  }
+  // output elements: e -> (slot s in i,f,g,o,c,h ; row r ; unit)
+  float* const p_gates = pin_s(d.gates);
+  float* const p_cs = pin_s(d.cs);
+  float* const p_hs = pin_s(d.hs);
+  float* op[NOS];
+  int64_t ostr[NOS];
+  int ol[NOS];
+  bool ook[NOS];
+#pragma unroll
+  for (int i = 0; i < NOS; ++i) {
+    const int e = tid + i * NTH;
+    const bool in = tid < NTH && e < 6 * HKB * R;
+    const int ec = in ? e : 0;
+    const int sr = ec / HKB, unit = ec % HKB, r = sr % R, sl = sr / R;
+    ook[i] = in && (b0 + r < B);
+    const int br = min(b0 + r, B - 1);
+    op[i] = sl < 4 ? p_gates + ((int64_t)br * 4 + sl) * Hp + unit : (sl == 4 ? p_cs : p_hs) + (int64_t)br * Hp + unit;
+    ostr[i] = sl < 4 ? gstep : sstep;
+    ol[i] = (sl * HKB + unit) * R + r;
+  }
+  const int ucl = min(u, HKB - 1);
+  const int my_o = (2 * gp * HKB + ucl) * R + myrow;       // this lane's slots: 2gp, 2gp+1 and 4+gp
+  const float sc0 = gp ? 2.0f : 1.0f;                      // gate 0 of the pair: sigmoid(i) / tanh(g)
+  __syncthreads();
 
   float c = 0.0f;
   int cur = 0;
   auto step = [&](const int t) {
-    const int64_t rowt = (int64_t)t * B + b;
+    const int par = t & 1;
+    float gx0 = gxb[0], gx1 = gxb[1];
+    if (!dec) {
+      const float* xb = xbuf + par * (4 * HKB * R) + my_o;
+      gx0 = xb[0]; gx1 = xb[HKB * R];
+    }
     float acc[2][R];
 #pragma unroll
     for (int gl = 0; gl < 2; ++gl)
@@ -173,6 +239,15 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
           for (int r = 0; r < R; ++r) acc[gl][r] = fmaf(w[gl][j], hv.v[r], acc[gl][r]);
       }
     }
+    // x-projections of step t+2 (clamped re-read at the tail), issued well ahead of their LDS hand-over
+    float xn[NXL];
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) xn[i] = 0.0f;
+    if (!dec) {
+      const int64_t off = (int64_t)min(t + 2, T - 1) * gstep;
+#pragma unroll
+      for (int i = 0; i < NXL; ++i) xn[i] = xp[i][off];
+    }
     // all-reduce the four k-slices of the quad, keep the sums of batch row q, add bias / x-projection
     float mine[2];
 #pragma unroll
@@ -184,29 +259,35 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
         v += dpp_f<DPP_QUAD_XOR2>(v);
         acc[gl][r] = v;
       }
-      mine[gl] = sel_row<R>(acc[gl], myrow) + gxb[gl];
+      mine[gl] = sel_row<R>(acc[gl], myrow) + (gl ? gx1 : gx0);
     }
-    if (!dec && t + 1 < T && bvalid) {
-#pragma unroll
-      for (int gl = 0; gl < 2; ++gl) gxb[gl] = d.gates[(rowt + B) * row4 + (2 * gp + gl) * Hp + u];
-    }
-    // the partner lane (same unit and row, other gate pair) holds the other two pre-activations
-    const float o0 = dpp_xor4(mine[0]), o1 = dpp_xor4(mine[1]);
-    const float pi = gp ? o0 : mine[0], pf = gp ? o1 : mine[1];
-    const float pg = gp ? mine[0] : o0, po = gp ? mine[1] : o1;
-    const float gi = act_sigmoid(pi);
-    const float gf = act_sigmoid(pf);
-    const float gg = act_tanh(pg);
-    const float go = act_sigmoid(po);
-    c = gf * c + gi * gg;
+    // each lane activates its own two gates; the partner lane (same unit and row, other gate pair)
+    // supplies the other two.  i*g is symmetric in the exchange, so both lanes carry c.
+    const float a0 = act_scaled(mine[0], sc0);     // gp 0: i   gp 1: g
+    const float a1 = act_sigmoid(mine[1]);         // gp 0: f   gp 1: o
+    const float p0 = dpp_xor4(a0), p1 = dpp_xor4(a1);
+    const float gf = gp ? p1 : a1, go = gp ? a1 : p1;
+    c = fmaf(gf, c, a0 * p0);          // explicit: every instantiation must round the same way
     const float hv = go * act_tanh(c);
-    if (bvalid) {
-      float* gpt = d.gates + rowt * row4 + u;
-      if (gp == 0) { gpt[0] = gi; gpt[Hp] = gf; d.cs[rowt * Hp + u] = c; }
-      else { gpt[2 * Hp] = gg; gpt[3 * Hp] = go; d.hs[rowt * Hp + u] = hv; }
+    if (uact && rowner) {
+      float* ob = obuf + par * (6 * HKB * R) + my_o;
+      ob[0] = a0; ob[HKB * R] = a1;
+      ob[(4 - gp) * HKB * R] = gp ? hv : c;        // slot 4 (c) from gp 0, slot 5 (h) from gp 1
+      if (gp == 0 && u < HK) hbuf[(cur ^ 1) * (HK * R) + u * R + myrow] = (b < B) ? hv : 0.0f;
     }
-    if (uact && rowner && gp == 0 && u < HK) hbuf[(cur ^ 1) * (HK * R) + u * R + myrow] = (b < B) ? hv : 0.0f;
+    if (!dec) {
+#pragma unroll
+      for (int i = 0; i < NXL; ++i)
+        if (xok[i]) xbuf[(par ^ 1) * (4 * HKB * R) + xl[i]] = xpf[i];
+    }
     lds_barrier();
+#pragma unroll
+    for (int i = 0; i < NOS; ++i) {
+      if (ook[i]) *op[i] = obuf[par * (6 * HKB * R) + ol[i]];
+      op[i] += ostr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) xpf[i] = xn[i];
     cur ^= 1;
   };
   // The decoder's step 0 (W_ih on the embedding) is peeled so that the weight reload sits between
@@ -214,6 +295,7 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
   if (dec) {
     step(0);
     if (T > 1) {
+      __syncthreads();                 // the record of step 0 lives in the panel about to be refilled
       load_w(2);                       // steps >= 1 feed h back as the input: W_ih + W_hh
       for (int t = 1; t < T; ++t) step(t);
     }
@@ -223,24 +305,33 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
 }
 
 // --------------------------------------------------------------------------------- backward
+// Same LDS hand-over as the forward: the saved activations of step t-2 are fetched by 7*Hp*R/64 full waves
+// during step t and published one step later; dA_t leaves through the dA panel the matvec reads anyway.
 template <int KQ, int R>
 __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds) {
   constexpr int HK = 4 * KQ;                       // padded hidden extent
-  constexpr int HKB = (HK + 15) / 16 * 16;         // per-gate extent of the dA panel (multiple of 16)
+  constexpr int HKB = (HK + 15) / 16 * 16;         // per-gate extent of the dA panel (multiple of 16) == Hp
   constexpr int NG = HKB / 16;                     // gate columns per thread and gate
   constexpr int NW = 4 * NG;                       // gate columns per thread: k = g*HKB + 16 i + q
+  constexpr int NTH = 8 * HKB;
+  constexpr int NV = 7;                            // staged values per (unit,row): gi gf gg go c_{t-1} dh_ext dc_ext
+  constexpr int NLD = (NV * R + 7) / 8;            // fetch elements per thread and step
+  constexpr int NST = (4 * R + 7) / 8;             // dA elements written per thread and step
   const int tid = threadIdx.x, nt = blockDim.x;
   const int q = tid & 15, up = tid >> 4;
   const int h = d.h, Hp = d.Hp;
   const bool dec = d.is_dec != 0;
+  const bool has_dc = d.dc_ext != nullptr;
   const int ua = 2 * up, ub = 2 * up + 1;           // the two output units whose W^T rows this thread holds
   const int mu = 2 * up + ((q >> 2) & 1), mr = q & 3;   // the (unit,row) lanes q<8 own in the pointwise part
   const bool own = (q < 8) && (mr < R) && (mu < Hp);
-  const int b = tile * R + mr;
+  const int b0 = tile * R;
+  const int b = b0 + mr;
   const bool bvalid = own && (b < B);
 
   float* dabuf = lds;                       // [2][4][HKB][R]
-  float* panel = lds + 2 * 4 * HKB * R;     // [h][h] weight staging
+  float* sbuf = lds + 2 * 4 * HKB * R;      // [2][NV][HKB][R] saved activations of the coming step
+  float* panel = sbuf + 2 * NV * HKB * R;   // [h][h] weight staging
 
   float wa[NW], wb[NW];
   auto load_wT = [&](int mode) {
@@ -263,21 +354,81 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
   load_wT(dec ? 2 : 0);
 
   const int64_t row4 = 4 * (int64_t)Hp;
+  const int64_t gstep = (int64_t)B * row4, sstep = (int64_t)B * Hp;
+  const int nv = has_dc ? 7 : (dec ? 6 : 5);       // slots actually fetched
+  // fetch elements: e -> (slot v, row r, unit), unit fastest.  Every fetch is unconditional (inactive
+  // elements re-read element 0): a load under a branch makes the compiler's in-order vmcnt bookkeeping
+  // conservative and the wait for the older prefetch would also cover the younger one.
+  float* const p_gates = pin_s(d.gates);
+  const float* const p_cs = pin_s(d.cs);
+  const float* const p_dh = pin_s(d.dh_ext);
+  const float* const p_dc = pin_s(d.dc_ext);
+  const float* fp[NLD];
+  int64_t fstr[NLD];
+  int fl[NLD];
+  bool fok[NLD], fcp[NLD];
+  float pf[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int e = tid + i * NTH;
+    fok[i] = tid < NTH && e < nv * HKB * R;
+    const int ec = fok[i] ? e : 0;
+    const int sr = ec / HKB, unit = ec % HKB, r = sr % R, v = sr / R;
+    const int br = min(b0 + r, B - 1);
+    fcp[i] = (v == 4);
+    const float* src = (v == 5 && dec) ? p_dh : (v == 6 && has_dc) ? p_dc : p_cs;
+    fp[i] = v < 4 ? p_gates + ((int64_t)br * 4 + v) * Hp + unit : src + (int64_t)br * Hp + unit;
+    fstr[i] = v < 4 ? gstep : sstep;
+    fl[i] = (v * HKB + unit) * R + r;
+    if (v == 5 && !dec) fok[i] = false;            // encoders take dL/dh_T only (below)
+  }
+  // element i at step tt: slot 4 holds c_{tt-1} (zero at tt == 0), everything else is indexed by tt itself
+  auto fetch = [&](int i, int tt) {
+    const int ti = fcp[i] ? max(tt - 1, 0) : tt;
+    const float v = fp[i][(int64_t)ti * fstr[i]];
+    return (fcp[i] && tt == 0) ? 0.0f : v;
+  };
+  // dA write-out elements: e -> (row r, gate g, unit): one contiguous 4*Hp run per row
+  float* sp[NST];
+  int sl[NST];
+  bool sok[NST];
+#pragma unroll
+  for (int i = 0; i < NST; ++i) {
+    const int e = tid + i * NTH;
+    const bool in = tid < NTH && e < 4 * HKB * R;
+    const int ec = in ? e : 0;
+    const int r = ec / (4 * HKB), rem = ec % (4 * HKB);
+    sok[i] = in && (b0 + r < B);
+    sp[i] = p_gates + ((int64_t)(T - 1) * B + min(b0 + r, B - 1)) * row4 + rem;
+    sl[i] = rem * R + r;
+  }
+  // pipeline prologue: step T-1 goes straight to LDS, step T-2 waits in registers
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const float v0 = fetch(i, T - 1);
+    pf[i] = fetch(i, max(T - 2, 0));
+    if (fok[i]) sbuf[((T - 1) & 1) * (NV * HKB * R) + fl[i]] = v0;
+  }
+  const int muc = min(mu, HKB - 1), mrc = mr & (R - 1);
+  const int my_s = muc * R + mrc;
+  float ct = d.cs[((int64_t)(T - 1) * B + min(b, B - 1)) * Hp + muc];
+  float ext0 = 0.0f;
+  if (!dec && mu < h) ext0 = d.dh_ext[(int64_t)min(b, B - 1) * d.ld_dh + mu];   // dL/dh_T only
   float dh_rec = 0.0f, dc = 0.0f;
   int cur = 0;
+  __syncthreads();
 
   auto step = [&](const int t) {
-    const int64_t rowt = (int64_t)t * B + b;
-    float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, ct = 0.f, cp = 0.f, ext = 0.f, dce = 0.f;
-    float* gpt = d.gates + rowt * row4 + mu;
-    if (bvalid) {
-      gi = gpt[0]; gf = gpt[Hp]; gg = gpt[2 * Hp]; go = gpt[3 * Hp];
-      ct = d.cs[rowt * Hp + mu];
-      if (t > 0) cp = d.cs[(rowt - B) * Hp + mu];
-      if (dec) ext = d.dh_ext[rowt * Hp + mu];
-      else if (t == T - 1 && mu < h) ext = d.dh_ext[(int64_t)b * d.ld_dh + mu];
-      if (d.dc_ext) dce = d.dc_ext[rowt * Hp + mu];
-    }
+    const int par = t & 1;
+    const float* sb = sbuf + par * (NV * HKB * R) + my_s;
+    const float gi = sb[0], gf = sb[HKB * R], gg = sb[2 * HKB * R], go = sb[3 * HKB * R], cp = sb[4 * HKB * R];
+    float ext = ext0, dce = 0.0f;
+    if (dec) ext = sb[5 * HKB * R];
+    if (has_dc) dce = sb[6 * HKB * R];
+    ext0 = 0.0f;
+    float pn[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) pn[i] = fetch(i, max(t - 2, 0));
     const float dh = dh_rec + ext;
     const float tc = act_tanh(ct);
     const float dot = dh * tc;
@@ -288,16 +439,27 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
     da[2] = dct * gi * (1.0f - gg * gg);
     da[3] = dot * go * (1.0f - go);
     dc = dct * gf;
-    if (bvalid) { gpt[0] = da[0]; gpt[Hp] = da[1]; gpt[2 * Hp] = da[2]; gpt[3 * Hp] = da[3]; }
-
-    const bool need_rec = (t > 0) || dec;
-    if (need_rec) {
-      float* db = dabuf + cur * (4 * HKB * R);
-      if (own && mu < HKB) {
+    ct = cp;                            // c_{t-1} is the cell state of the next (earlier) step
+    if (!bvalid) { da[0] = 0.0f; da[1] = 0.0f; da[2] = 0.0f; da[3] = 0.0f; }
+    float* db = dabuf + cur * (4 * HKB * R);
+    if (own) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) db[(g * HKB + mu) * R + mr] = da[g];
-      }
-      lds_barrier();
+      for (int g = 0; g < 4; ++g) db[(g * HKB + muc) * R + mr] = da[g];
+    }
+    if (t > 0) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i)
+        if (fok[i]) sbuf[(par ^ 1) * (NV * HKB * R) + fl[i]] = pf[i];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      if (sok[i]) *sp[i] = db[sl[i]];
+      sp[i] -= gstep;
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) pf[i] = pn[i];
+    if ((t > 0) || dec) {
       float aa[R], ab[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) { aa[r] = 0.0f; ab[r] = 0.0f; }
@@ -328,10 +490,10 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
         v += dpp_f<DPP_ROW_HALF_MIRROR>(v); v += dpp_f<DPP_ROW_MIRROR>(v);
         ab[r] = v;
       }
-      const float sa = sel_row<R>(aa, mr & (R - 1)), sb = sel_row<R>(ab, mr & (R - 1));
-      dh_rec = (q & 4) ? sb : sa;
-      cur ^= 1;
+      const float sa = sel_row<R>(aa, mrc), sb2 = sel_row<R>(ab, mrc);
+      dh_rec = (q & 4) ? sb2 : sa;
     }
+    cur ^= 1;
   };
   for (int t = T - 1; t >= 1; --t) step(t);
   if (dec) load_wT(1);                 // grad wrt the step-0 input goes through W_ih only (peeled)
@@ -440,7 +602,11 @@ static size_t small_lds_bytes(const SeqLaunch& L, bool bwd, int R) {
     const SeqDev& d = L.d[i];
     const size_t HK = (size_t)d.hk4 * 4;
     const size_t HKB = (HK + 15) / 16 * 16;
-    const size_t need = (bwd ? 2 * 4 * HKB * R + (size_t)d.h * d.h : 2 * HK * R + 2 * (size_t)d.h * d.h) * sizeof(float);
+    const size_t hh = (size_t)d.h * d.h;
+    // forward: h ring + max(weight panel, output record + x-projection record); backward: dA ring +
+    // saved-activation record + weight panel (see the bodies)
+    const size_t rec = (2 * 6 + 2 * 4) * HKB * R;
+    const size_t need = (bwd ? (2 * 4 + 2 * 7) * HKB * R + hh : 2 * HK * R + (2 * hh > rec ? 2 * hh : rec)) * sizeof(float);
     if (need > lds_bytes) lds_bytes = need;
   }
   return (lds_bytes + 15) / 16 * 16;

@@ -45,8 +45,8 @@ if __name__ == "__main__":
     print("%5s %5s %4s %6s %4s %4s %10s" % ("h", "B", "T", "path", "bwd", "dec", "us"))
     for h in hs_:
         for B in Bs:
-            for path in ("mfma", "small"):
-                for bwd in (False, True):
+            for path in os.environ.get("BENCH_SEQ_PATHS", "mfma,small").split(","):
+                for bwd in [bool(int(v)) for v in os.environ.get("BENCH_SEQ_BWD", "0,1").split(",")]:
                     for dec in (False, True):
                         for T in (1, 20, 40):
                             us = run(h, B, T, path, bwd, dec)
