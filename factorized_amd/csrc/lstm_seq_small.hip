@@ -44,8 +44,13 @@ __device__ __forceinline__ float dpp_xor4(float x) { return dpp_f<DPP_QUAD_REV>(
 // Pin a descriptor field in scalar registers.  A lane-dependent choice between two fields of the by-value
 // launch descriptor otherwise becomes a load from a lane-dependent kernarg address, and the compiler
 // then copies the whole descriptor to scratch.
-template <class P>
-__device__ __forceinline__ P pin_s(P p) { asm volatile("" : "+s"(p)); return p; }
+// The result is typed as a global-memory pointer: behind the asm the compiler no longer sees that the
+// value came from a kernel argument and would fall back to flat_load / flat_store.
+typedef __attribute__((address_space(1))) float gfloat;
+__device__ __forceinline__ gfloat* pin_s(const float* p) {
+  asm volatile("" : "+s"(p));
+  return (gfloat*)p;
+}
 
 // R consecutive floats from LDS (one ds_read_b32/b64/b128)
 template <int R> struct RowVec { float v[R]; };
@@ -162,7 +167,7 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
   const int64_t row4 = 4 * (int64_t)Hp;
   const int64_t gstep = (int64_t)B * row4, sstep = (int64_t)B * Hp;
   // x-projection fetch elements: e -> (gate g, row r, unit), unit fastest (coalesced)
-  const float* xp[NXL];
+  const gfloat* xp[NXL];
   int xl[NXL];
   bool xok[NXL];
   float xpf[NXL];
@@ -172,7 +177,7 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
     xok[i] = !dec && tid < NTH && e < 4 * HKB * R;
     const int ec = xok[i] ? e : 0;
     const int sr = ec / HKB, unit = ec % HKB, r = sr % R, g = sr / R;
-    xp[i] = d.gates + ((int64_t)min(b0 + r, B - 1) * 4 + g) * Hp + unit;
+    xp[i] = (const gfloat*)d.gates + ((int64_t)min(b0 + r, B - 1) * 4 + g) * Hp + unit;
     xl[i] = (g * HKB + unit) * R + r;
     xpf[i] = 0.0f;
   }
@@ -185,10 +190,10 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
     }
   }
   // output elements: e -> (slot s in i,f,g,o,c,h ; row r ; unit)
-  float* const p_gates = pin_s(d.gates);
-  float* const p_cs = pin_s(d.cs);
-  float* const p_hs = pin_s(d.hs);
-  float* op[NOS];
+  gfloat* const p_gates = pin_s(d.gates);
+  gfloat* const p_cs = pin_s(d.cs);
+  gfloat* const p_hs = pin_s(d.hs);
+  gfloat* op[NOS];
   int64_t ostr[NOS];
   int ol[NOS];
   bool ook[NOS];
@@ -359,11 +364,11 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
   // fetch elements: e -> (slot v, row r, unit), unit fastest.  Every fetch is unconditional (inactive
   // elements re-read element 0): a load under a branch makes the compiler's in-order vmcnt bookkeeping
   // conservative and the wait for the older prefetch would also cover the younger one.
-  float* const p_gates = pin_s(d.gates);
-  const float* const p_cs = pin_s(d.cs);
-  const float* const p_dh = pin_s(d.dh_ext);
-  const float* const p_dc = pin_s(d.dc_ext);
-  const float* fp[NLD];
+  gfloat* const p_gates = pin_s(d.gates);
+  const gfloat* const p_cs = pin_s(d.cs);
+  const gfloat* const p_dh = pin_s(d.dh_ext);
+  const gfloat* const p_dc = pin_s(d.dc_ext);
+  const gfloat* fp[NLD];
   int64_t fstr[NLD];
   int fl[NLD];
   bool fok[NLD], fcp[NLD];
@@ -376,7 +381,7 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
     const int sr = ec / HKB, unit = ec % HKB, r = sr % R, v = sr / R;
     const int br = min(b0 + r, B - 1);
     fcp[i] = (v == 4);
-    const float* src = (v == 5 && dec) ? p_dh : (v == 6 && has_dc) ? p_dc : p_cs;
+    const gfloat* src = (v == 5 && dec) ? p_dh : (v == 6 && has_dc) ? p_dc : p_cs;
     fp[i] = v < 4 ? p_gates + ((int64_t)br * 4 + v) * Hp + unit : src + (int64_t)br * Hp + unit;
     fstr[i] = v < 4 ? gstep : sstep;
     fl[i] = (v * HKB + unit) * R + r;
@@ -389,7 +394,7 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
     return (fcp[i] && tt == 0) ? 0.0f : v;
   };
   // dA write-out elements: e -> (row r, gate g, unit): one contiguous 4*Hp run per row
-  float* sp[NST];
+  gfloat* sp[NST];
   int sl[NST];
   bool sok[NST];
 #pragma unroll
