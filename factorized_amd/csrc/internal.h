@@ -29,7 +29,8 @@ struct LatOp {
   int mask_off;                // record offset of the dropout mask (scale) segment, -1 = no dropout
   float drop_p;
   int stage;
-  int pad_[3];
+  int pfx_n, pfx_k;             // exclusive prefix sums of N / K over the ops of the same stage (host-filled)
+  int pad_;
 };
 struct LatentDev {
   // Op table in DEVICE memory (uploaded once by mfm_plan_init_workspace).  It must not live in the
@@ -61,6 +62,7 @@ struct LatentDev {
   float* grd_out;                      // [B, rec_size] gradient record written by the backward
   unsigned long long* dbg;             // optional: block 0 / thread 0 writes s_memtime at phase marks
   int B, rows_per_wg, train, has_logvar;
+  int row_path;                        // 1: one batch row per workgroup, weights read straight from L2 (latent.hip)
   uint64_t seed;
   float reg_w, disc_w, gen_w;
 };

@@ -140,31 +140,39 @@ static int build(MfmPlan* P) {
   // stage 0: encoder fc1 (mfm_model.py:60-61)
   for (int e = 0; e < 4; ++e)
     add_op(P->lat_ops, L, 0, L.in_off[e], last_off[e], eh[e], eh[e], o[ep[e] + FC_W], o[ep[e] + FC_B], 0, -1, 0.f);
-  // stage 1: mu / logvar heads (mfm_model.py:630-639)
+  // stages 1, 2: mu / logvar heads (mfm_model.py:630-639)
   const int pmu[4] = {P_TO_ZL, P_TO_ZA, P_TO_ZV, P_TO_ZY};
   const int plv[4] = {P_TO_LVL, P_TO_LVA, P_TO_LVV, P_TO_LVY};
-  for (int e = 0; e < 4; ++e) {
+  // (two stages although independent: the row kernels give every thread one work item per stage)
+  for (int e = 0; e < 4; ++e)
     add_op(P->lat_ops, L, 1, last_off[e], L.mu_off[e], eh[e], zn[e], o[pmu[e]], o[pmu[e] + 1], 0, -1, 0.f);
-    add_op(P->lat_ops, L, 1, last_off[e], L.lv_off[e], eh[e], zn[e], o[plv[e]], o[plv[e] + 1], 0, -1, 0.f);
-  }
-  // stage 2/3: z -> f MLPs (mfm_model.py:644-647)
+  for (int e = 0; e < 4; ++e)
+    add_op(P->lat_ops, L, 2, last_off[e], L.lv_off[e], eh[e], zn[e], o[plv[e]], o[plv[e] + 1], 0, -1, 0.f);
+  // stages 3, 4: z -> f MLPs (mfm_model.py:644-647)
   const int pf1[4] = {P_ZL_F1, P_ZA_F1, P_ZV_F1, P_ZY_F1};
   const int pf2[4] = {P_ZL_F2, P_ZA_F2, P_ZV_F2, P_ZY_F2};
   const float pd[4] = {c.drop_zl, c.drop_za, c.drop_zv, c.drop_zy};
   for (int e = 0; e < 4; ++e)
-    add_op(P->lat_ops, L, 2, L.mu_off[e], f1_off[e], zn[e], fn[e], o[pf1[e]], o[pf1[e] + 1], 1, m1_off[e], pd[e]);
+    add_op(P->lat_ops, L, 3, L.mu_off[e], f1_off[e], zn[e], fn[e], o[pf1[e]], o[pf1[e] + 1], 1, m1_off[e], pd[e]);
   for (int e = 0; e < 4; ++e)
-    add_op(P->lat_ops, L, 3, f1_off[e], L.f_off[e], fn[e], fn[e], o[pf2[e]], o[pf2[e] + 1], 1, -1, 0.f);
-  // stage 4/5: classifier (mfm_model.py:657)
-  add_op(P->lat_ops, L, 4, L.f_off[3], c1_off, c.fy, c.fy, o[P_Y_F1], o[P_Y_F1 + 1], 1, mc_off, c.drop_y);
-  add_op(P->lat_ops, L, 5, c1_off, L.yhat_off, c.fy, c.output_dim, o[P_Y_F2], o[P_Y_F2 + 1], 0, -1, 0.f);
-  L.nstages = 6;
+    add_op(P->lat_ops, L, 4, f1_off[e], L.f_off[e], fn[e], fn[e], o[pf2[e]], o[pf2[e] + 1], 1, -1, 0.f);
+  // stages 5, 6: classifier (mfm_model.py:657)
+  add_op(P->lat_ops, L, 5, L.f_off[3], c1_off, c.fy, c.fy, o[P_Y_F1], o[P_Y_F1 + 1], 1, mc_off, c.drop_y);
+  add_op(P->lat_ops, L, 6, c1_off, L.yhat_off, c.fy, c.output_dim, o[P_Y_F2], o[P_Y_F2 + 1], 0, -1, 0.f);
+  L.nstages = 7;
   {
     int s = 0;
     L.stage_begin[0] = 0;
     for (int i = 0; i < L.nops; ++i)
       while (P->lat_ops[i].stage > s) L.stage_begin[++s] = i;
     L.stage_begin[L.nstages] = L.nops;
+    for (int st = 0; st < L.nstages; ++st) {
+      int an = 0, ak = 0;
+      for (int i = L.stage_begin[st]; i < L.stage_begin[st + 1]; ++i) {
+        P->lat_ops[i].pfx_n = an; P->lat_ops[i].pfx_k = ak;
+        an += P->lat_ops[i].N; ak += P->lat_ops[i].K;
+      }
+    }
   }
   L.has_logvar = 1;
   L.B = c.B;
@@ -197,6 +205,22 @@ static int build(MfmPlan* P) {
     while (R > 1 && 2 * (size_t)R * rs * sizeof(float) > LDS_BUDGET) R >>= 1;
   }
   L.rows_per_wg = R;
+  // Latency path (latent.hip, row kernels): one row per workgroup while that still fits the chip in one
+  // wave of workgroups and every layer meets the vector-load shape requirements.
+  {
+    bool ok = c.B <= 256 && (size_t)2 * rs * sizeof(float) <= 60 * 1024;
+    for (int i = 0; i < L.nops && ok; ++i) {
+      const LatOp& op = P->lat_ops[i];
+      ok = (op.K % 4 == 0) && op.K >= 4 && op.K <= 128 && op.N <= 128 && (op.w_off % 4 == 0);
+    }
+    for (int st = 0; st < L.nstages && ok; ++st) {
+      int sn = 0, sk = 0;
+      for (int i = L.stage_begin[st]; i < L.stage_begin[st + 1]; ++i) { sn += P->lat_ops[i].N; sk += P->lat_ops[i].K; }
+      ok = 4 * sn <= 1024 && 4 * sk <= 1024;      // one work item per thread and stage
+    }
+    if (const char* e = getenv("MFM_LATENT_PATH")) { if (!strcmp(e, "staged")) ok = false; }
+    L.row_path = ok ? 1 : 0;
+  }
 
   P->lat_ops_off = carve(cur, (int64_t)(sizeof(P->lat_ops) / (sizeof(float))));
   P->dbg_off = carve(cur, 128);     // 64 x u64 debug timestamps

@@ -23,18 +23,19 @@ torch.cuda.synchronize()
 p = e.plan(20, B)
 off = _lib.lib().mfm_plan_debug_offset(p.handle)
 ts = p.workspace[off:off + 64 * 8].view(torch.int64).cpu().numpy()
-f = ts[:16]
+NS = 7
+f = ts[:24]
 print("latent_fwd (cycles, workgroup 0):")
 print("  prologue(load inputs+ops) %d" % (f[1] - f[0]))
 prev = f[1]
-for s in range(6):
-    print("  stage %d: copy %6d   compute %6d" % (s, f[2 + 2 * s] - prev, f[3 + 2 * s] - f[2 + 2 * s]))
+for s in range(NS):
+    print("  stage %d: issue/copy %6d   compute %6d" % (s, f[2 + 2 * s] - prev, f[3 + 2 * s] - f[2 + 2 * s]))
     prev = f[3 + 2 * s]
-print("  epilogue %d   total %d" % (f[15] - prev, f[15] - f[0]))
-b = ts[16:40]
+print("  epilogue %d   total %d" % (f[20] - prev, f[20] - f[0]))
+b = ts[24:24 + 1 + 3 * NS]
 print("latent_bwd:")
 prev = b[0]
-for s in range(5, -1, -1):
+for s in range(NS - 1, -1, -1):
     m1, m2, m3 = b[1 + 3 * s], b[2 + 3 * s], b[3 + 3 * s]
     print("  stage %d: copy+pass1 %6d   pass2a %6d   pass2b %6d" % (s, m1 - prev, m2 - m1, m3 - m2))
     prev = m3

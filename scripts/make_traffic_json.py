@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""HBM bytes per launch of every kernel of the fused step, from two rocprofv3 --pmc passes of bench.py
+(FETCH_SIZE and WRITE_SIZE, collected separately: scripts/profile_round.sh).
+
+Usage: scripts/make_traffic_json.py pmc_fetch_results.db pmc_write_results.db > profiles/r01_traffic.json
+
+read  = 2 x FETCH_SIZE KiB (on gfx950 FETCH_SIZE counts 128-B requests as 64 B: MI355X_MICROARCH.md, HBM)
+write = WRITE_SIZE KiB (uncalibrated)
+The six grouped-GEMM launches of a step share one kernel symbol; they are told apart by their position
+between two Adam launches (plan.hip issues them in a fixed order)."""
+import json
+import sqlite3
+import sys
+
+GEMM_ORDER = ["proj_gemm", "fc1_gemm", "fc1_bwd_gemm", "dec_dw_gemm", "latent_dw_gemm", "enc_dw_gemm"]
+
+
+def classify(name):
+    if "lstm_seq_small_kernel4<false" in name or "lstm_seq_fwd" in name or "lstm_seq_small_kernel<false" in name:
+        return "enc_seq_fwd" if ("8, 2, 20, 30" in name) else "dec_seq_fwd"
+    if "lstm_seq_small_kernel4<true" in name or "lstm_seq_bwd" in name or "lstm_seq_small_kernel<true" in name:
+        return "enc_seq_bwd" if ("8, 2, 20, 30" in name) else "dec_seq_bwd"
+    if "latent_fwd_kernel" in name:
+        return "latent_fwd"
+    if "latent_bwd_kernel" in name:
+        return "latent_bwd"
+    if "gemm_f32_kernel" in name:
+        return "gemm"
+    if "mse_kernel" in name:
+        return "mse"
+    if "adam_kernel" in name:
+        return "adam"
+    return None
+
+
+def per_kernel(path, counter):
+    c = sqlite3.connect(path)
+    rows = c.execute("select dispatch_id, kernel_name, value from counters_collection where counter_name=? "
+                     "order by dispatch_id", (counter,)).fetchall()
+    acc, gemm_pos = {}, 0
+    for _, name, value in rows:
+        k = classify(name)
+        if k is None:
+            continue
+        if k == "gemm":
+            k = GEMM_ORDER[gemm_pos % len(GEMM_ORDER)]
+            gemm_pos += 1
+        elif k == "adam":
+            gemm_pos = 0
+        acc.setdefault(k, []).append(value)
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def main(fetch_db, write_db):
+    rd = per_kernel(fetch_db, "FETCH_SIZE")
+    wr = per_kernel(write_db, "WRITE_SIZE")
+    out = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes of "
+                       "bench.py, B=32 T=20; scripts/profile_round.sh + scripts/make_traffic_json.py); read = 2 x "
+                       "FETCH_SIZE KiB (gfx950 correction, MI355X_MICROARCH.md section HBM), write = WRITE_SIZE KiB "
+                       "(uncalibrated)",
+           "workload": "mosi B=32 T=20"}
+    for k in sorted(set(rd) | set(wr)):
+        r = int(round(2.0 * rd.get(k, 0.0) * 1024))
+        w = int(round(wr.get(k, 0.0) * 1024))
+        out[k] = {"read_bytes": r, "write_bytes": w, "total_bytes": r + w}
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
