@@ -22,6 +22,7 @@ int fill_launch(float* p, int64_t n, float val, hipStream_t stream);
 // classifier, KLD and discriminative loss, interpreted from a small op table.
 #define MFM_LAT_MAXOPS 24
 #define MFM_LAT_MAXSTAGES 8
+#define MFM_LAT_ROW_THREADS 1024
 struct LatOp {
   int in_off, out_off, K, N;   // record offsets (floats), fan-in, fan-out
   int64_t w_off, b_off;        // element offsets of weight [N,K] / bias [N] in the flat param buffer
@@ -63,6 +64,10 @@ struct LatentDev {
   unsigned long long* dbg;             // optional: block 0 / thread 0 writes s_memtime at phase marks
   int B, rows_per_wg, train, has_logvar;
   int row_path;                        // 1: one batch row per workgroup, weights read straight from L2 (latent.hip)
+  // row path: per-thread work items of every stage, precomputed by the host ([nstages][MFM_LAT_ROW_THREADS] int4,
+  // encoding in latent.hip) and the number of threads that have an item in each stage
+  const int* items_fwd; const int* items_bwd;
+  int nitems_fwd[MFM_LAT_MAXSTAGES], nitems_bwd[MFM_LAT_MAXSTAGES];
   uint64_t seed;
   float reg_w, disc_w, gen_w;
 };

@@ -488,47 +488,68 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_kernel(const LatentDev
 // =====================================================================================================
 // Latency path: ONE batch row per workgroup, weights straight from L2 into registers.
 //
-// At the reference's minibatch (B=32) the stack is a chain of six dependent stages of tiny matvecs;
-// what costs time is the chain, not the arithmetic.  The staged kernels above put 4 rows in a workgroup
-// (8 workgroups at B=32), copy each stage's weights into LDS and walk k in a dependent loop: ~4.5 us per
-// stage (profiles/r01 latent phase timeline).  Here every row gets its own workgroup (B workgroups), each
-// weight element is used exactly once per workgroup, so it goes global -> register with all loads of a
-// stage in flight at once, and the only LDS traffic is the activation / gradient record:
+// At the reference's minibatch (B=32) the stack is a chain of dependent stages of tiny matvecs; what costs
+// time is the chain, not the arithmetic.  The staged kernels above put 4 rows in a workgroup (8 workgroups
+// at B=32), copy each stage's weights into LDS and walk k in a dependent loop: ~4.5 us per stage
+// (profiles/r01 latent phase timeline).  Here every row gets its own workgroup (B workgroups), each weight
+// element is used exactly once per workgroup, so it goes global -> register with all loads of a stage in
+// flight at once, and the only LDS traffic is the activation / gradient record:
 //   forward : lane (n, q) of a quad holds W[n][4q+16j .. +3], j < 8, dots it with the input segment,
 //             quad all-reduce with two DPP adds.
 //   backward: lane (kc, l) of a 16-lane group holds W[l+16j][4kc .. +3], j < 8, accumulates g[n]*W[n][k],
 //             16-lane all-reduce with four DPP adds per value, lanes 0..3 add dX[4kc+l] into the record.
-// While a stage computes, each thread also touches one 128-byte line of the NEXT stage's span so that it
-// is in this XCD's L2 when that stage asks for it (after Adam every step starts with cold weights).
+// Which (layer, column) a thread owns in a stage is static; the host tabulates it (plan.hip) as one int4 per
+// thread and stage, the prologue copies the table into LDS, so a stage starts with one LDS read instead of
+// a search through the op table:
+//   forward  x = element offset of weight row n          y = element offset of bias[n]
+//            z = in_off | K << 16                         w = (out_off + n) | op << 16 | relu << 24 | mask << 25 | live << 26
+//   backward x = element offset of W[0][kc]               y = K | N << 8
+//            z = out_off | (in_off + kc) << 16            w = live | producer relu << 1 | (producer mask index + 1) << 2
+// Weights of stage s+1 are requested while stage s computes (two register slots whose roles swap by
+// unrolling the stage loop twice: copying a slot would need the data, i.e. wait for the prefetch).
 // Requirements (checked on the host, otherwise the staged kernels run): K % 4 == 0, K, N <= 128, weights
-// 16-byte aligned, at most one work item per thread and stage (4*sum N, 4*sum K <= 1024).
+// 16-byte aligned, one work item per thread and stage (4*sum N, 4*sum K <= 1024), B <= 256.
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_row(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
 }
+// sum over the 64 lanes of a wave, result valid in every lane's return value only for lane groups' leaders:
+// 16-lane all-reduce with DPP, then the four row leaders are combined through scalar registers
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_row<0xB1>(v); v += dpp_row<0x4E>(v);
+  v += dpp_row<0x141>(v); v += dpp_row<0x140>(v);
+  const int iv = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+}
 
-// Returns the touched dword: the caller folds it into a sink AFTER the stage's compute.  Consuming it at
-// the load site would put an s_waitcnt right there, and because vmcnt retires in order that wait would
-// also cover every weight load issued before it.
-__device__ __forceinline__ float touch_span(const float* __restrict__ params, int64_t off, int len, int tid) {
-  const int i = min(tid * 32, max(len - 1, 0));   // one dword per 128-byte line (clamped: unconditional load)
-  return params[off + i];
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// copy this thread's items of all stages (one coalesced 16-byte load each) into the LDS table
+__device__ __forceinline__ void load_items(const int* __restrict__ items, int nstages, i32x4* tab, int tid) {
+  const i32x4* src = reinterpret_cast<const i32x4*>(items);
+  i32x4 v[MFM_LAT_MAXSTAGES];
+#pragma unroll
+  for (int s = 0; s < MFM_LAT_MAXSTAGES; ++s) v[s] = src[min(s, nstages - 1) * MFM_LAT_ROW_THREADS + tid];
+#pragma unroll
+  for (int s = 0; s < MFM_LAT_MAXSTAGES; ++s) tab[s * MFM_LAT_ROW_THREADS + tid] = v[s];
 }
 
 __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_row_kernel(const LatentDev L, const float* __restrict__ params) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ LatOp ops[MFM_LAT_MAXOPS];
-  __shared__ int pfxN[MFM_LAT_MAXOPS], pfxK[MFM_LAT_MAXOPS];
   __shared__ float red[2][16];
-  float* rec = lds;
+  i32x4* tab = reinterpret_cast<i32x4*>(lds);                        // [MAXSTAGES][1024] items
+  float* rec = lds + MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
   const int row = blockIdx.x;
   const int tid = threadIdx.x, nt = blockDim.x;
-  // prologue: op table, prefix tables and the four encoder states are requested together (one round trip)
+  // prologue: op table, item table and the four encoder states are requested together (one round trip)
+  float yv = 0.0f;
+  int ylab = 0;
   {
     const int nw = L.nops * (int)(sizeof(LatOp) / 4);
-    const int ow = min(tid, nw - 1);
-    const int opv = reinterpret_cast<const int*>(L.ops)[ow];
+    const int opv = reinterpret_cast<const int*>(L.ops)[min(tid, nw - 1)];
     const int e0 = L.enc_n[0], e1 = e0 + L.enc_n[1], e2 = e1 + L.enc_n[2], e3 = e2 + L.enc_n[3];
     const int tt = min(tid, e3 - 1);
     const int m = (tt >= e0) + (tt >= e1) + (tt >= e2);
@@ -537,79 +558,75 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_row_kernel(const Laten
     const int64_t ld = m == 0 ? L.enc_ld[0] : (m == 1 ? L.enc_ld[1] : (m == 2 ? L.enc_ld[2] : L.enc_ld[3]));
     const int io = m == 0 ? L.in_off[0] : (m == 1 ? L.in_off[1] : (m == 2 ? L.in_off[2] : L.in_off[3]));
     const float hv = src[(int64_t)row * ld + kk];
+    if (L.y) {      // the target is needed only by the loss at the very end: fetch it now, not there
+      if (L.loss_kind == 0) yv = reinterpret_cast<const float*>(L.y)[(int64_t)row * L.od + min(tid, L.od - 1)];
+      else ylab = (int)reinterpret_cast<const int64_t*>(L.y)[row];
+    }
+    load_items(L.items_fwd, L.nstages, tab, tid);
     if (tid < nw) reinterpret_cast<int*>(ops)[tid] = opv;
     if (tid < e3) rec[io + kk] = hv;
-    if (tid < L.nops) { pfxN[tid] = L.ops[tid].pfx_n; pfxK[tid] = L.ops[tid].pfx_k; }
   }
   const int q = tid & 3;
-  struct Slot { f32x4 w[8]; float bias, tv; int o, n; bool live; };
-  auto fetch = [&](int s, Slot& t) {          // item of stage s + all its loads (unconditional, see below)
-    const int s2 = min(s + 1, L.nstages - 1);
-    t.tv = touch_span(params, L.span_off[s2], L.span_len[s2], tid);     // oldest load of the batch
-    const int ob = L.stage_begin[s], oe = L.stage_begin[s + 1];
-    const int total = 4 * (pfxN[oe - 1] + ops[oe - 1].N);
-    t.live = tid < total;
-    const int item = min(tid, total - 1) >> 2;
-    t.o = find_op(pfxN, ob, oe, item, 1);
-    t.n = item - pfxN[t.o];
-    const int K = ops[t.o].K;
-    const float* wr = params + ops[t.o].w_off + (int64_t)t.n * K;
+  const int wave0 = tid & ~63;
+  struct Slot { f32x4 w[8]; float bias; i32x4 e; };
+  auto fetch = [&](int s, Slot& t) {          // weights + bias of this thread's item in stage s
+    t.e = tab[s * MFM_LAT_ROW_THREADS + tid];
+    const int K = (t.e[2] >> 16) & 0xFF;
+    const float* wr = params + (unsigned)t.e[0];
 #pragma unroll
     for (int j = 0; j < 8; ++j) t.w[j] = *reinterpret_cast<const f32x4*>(wr + min(4 * q + 16 * j, K - 4));
-    t.bias = params[ops[t.o].b_off + t.n];
+    t.bias = params[(unsigned)t.e[1]];
   };
-  float sink = 0.0f;
   mark(L, 0);
   lds_barrier();
   mark(L, 1);
-  // Stage s runs on slot `cur` while the loads of stage s+1 fill slot `nxt`.  The two slots swap roles by
-  // unrolling the stage loop twice: copying registers would need the data, i.e. wait for the prefetch.  The
-  // last stage prefetches itself again so that every load stays unconditional (a load under a branch makes
-  // the compiler's in-order vmcnt accounting conservative: the wait for `cur` would also cover `nxt`).
-  const int wave0 = tid & ~63;
-  auto items4 = [&](int s) { const int oe = L.stage_begin[s + 1]; return 4 * (pfxN[oe - 1] + ops[oe - 1].N); };
   auto stage = [&](int s, Slot& cur, Slot& nxt) {
-    // a wave with no item in this stage nor in the next skips the whole body (the instruction stream of
-    // 16 waves, not the loads, is what a stage costs); the skip is per wave, so inside the body the loads
-    // are still unconditional relative to each other
+    // A wave with no item in this stage nor in the next skips the body.  Inside the body every load is
+    // unconditional (the last stage requests its own weights again): a load under a branch would make the
+    // compiler's in-order vmcnt accounting conservative and the wait for `cur` would also cover `nxt`.
     const int sn = min(s + 1, L.nstages - 1);
-    if (wave0 < max(items4(s), items4(sn))) {
-    fetch(sn, nxt);
-    mark(L, 2 + 2 * s);
-    if (wave0 < items4(s)) {         // `cur` was fetched one stage ago exactly when this holds
-    const LatOp op = ops[cur.o];
-    const float* in = rec + op.in_off;
-    f32x4 xv[8];
+    if (wave0 < max(L.nitems_fwd[s], L.nitems_fwd[sn])) {
+      const int in_off = cur.e[2] & 0xFFFF, K = (cur.e[2] >> 16) & 0xFF;
+      f32x4 xv[8];
+      if (wave0 < L.nitems_fwd[s]) {          // `cur` was fetched one stage ago exactly when this holds
 #pragma unroll
-    for (int j = 0; j < 8; ++j) xv[j] = *reinterpret_cast<const f32x4*>(in + min(4 * q + 16 * j, op.K - 4));
-    float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const f32x4 w4 = cur.w[j], x4 = xv[j];
-      float p = w4[0] * x4[0];
-      p = fmaf(w4[1], x4[1], p); p = fmaf(w4[2], x4[2], p); p = fmaf(w4[3], x4[3], p);
-      p = (4 * q + 16 * j < op.K) ? p : 0.0f;
-      if (j & 1) a1 += p; else a0 += p;
-    }
-    float v = a0 + a1;
-    v += dpp_quad<0xB1>(v);
-    v += dpp_quad<0x4E>(v);
-    v += cur.bias;
-    sink += cur.tv;
-    if (cur.live && q == 0) {
-      if (op.relu) v = fmaxf(v, 0.0f);
-      if (op.mask_off >= 0) {
-        float mk = 1.0f;
-        if (L.train && op.drop_p > 0.0f) {
-          const uint64_t idx = ((uint64_t)cur.o << 40) + (uint64_t)row * (uint64_t)op.N + (uint64_t)cur.n;
-          mk = (rng_uniform(L.seed, idx) < op.drop_p) ? 0.0f : 1.0f / (1.0f - op.drop_p);
-        }
-        v *= mk;
-        rec[op.mask_off + cur.n] = mk;
+        for (int j = 0; j < 8; ++j) xv[j] = *reinterpret_cast<const f32x4*>(rec + in_off + min(4 * q + 16 * j, K - 4));
       }
-      rec[op.out_off + cur.n] = v;
-    }
-    }
+      fetch(sn, nxt);
+      mark(L, 2 + 2 * s);
+      if (wave0 < L.nitems_fwd[s]) {
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const f32x4 w4 = cur.w[j], x4 = xv[j];
+          float p = w4[0] * x4[0];
+          p = fmaf(w4[1], x4[1], p); p = fmaf(w4[2], x4[2], p); p = fmaf(w4[3], x4[3], p);
+          p = (4 * q + 16 * j < K) ? p : 0.0f;
+          if (j & 1) a1 += p; else a0 += p;
+        }
+        float v = a0 + a1;
+        v += dpp_quad<0xB1>(v);
+        v += dpp_quad<0x4E>(v);
+        v += cur.bias;
+        const int ew = cur.e[3];
+        if (((ew >> 26) & 1) && q == 0) {
+          const int out_idx = ew & 0xFFFF;
+          if ((ew >> 24) & 1) v = fmaxf(v, 0.0f);
+          if ((ew >> 25) & 1) {
+            const int o = (ew >> 16) & 0xFF;
+            const LatOp& op = ops[o];
+            const int n = out_idx - op.out_off;
+            float mk = 1.0f;
+            if (L.train && op.drop_p > 0.0f) {
+              const uint64_t idx = ((uint64_t)o << 40) + (uint64_t)row * (uint64_t)op.N + (uint64_t)n;
+              mk = (rng_uniform(L.seed, idx) < op.drop_p) ? 0.0f : 1.0f / (1.0f - op.drop_p);
+            }
+            v *= mk;
+            rec[op.mask_off + n] = mk;
+          }
+          rec[out_idx] = v;
+        }
+      }
     }
     lds_barrier();
     mark(L, 3 + 2 * s);
@@ -621,7 +638,6 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_row_kernel(const Laten
     if (s + 1 < L.nstages) stage(s + 1, sb, sa);
   }
 
-  if (sink == 1.2345e38f) rec[0] = sink;     // never true: keeps the touch loads alive
   // ---- losses (one partial per workgroup, one atomic each)
   float kld = 0.0f;
   if (L.has_logvar) {
@@ -634,30 +650,28 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_row_kernel(const Laten
   float disc = 0.0f;
   if (L.y) {
     if (L.loss_kind == 0) {
-      const float* y = reinterpret_cast<const float*>(L.y);
-      for (int o = tid; o < L.od; o += nt) disc += fabsf(rec[L.yhat_off + o] - y[(int64_t)row * L.od + o]);
+      if (tid < L.od) disc += fabsf(rec[L.yhat_off + tid] - yv);
     } else if (tid == 0) {
-      const int64_t* y = reinterpret_cast<const int64_t*>(L.y);
       const float* z = rec + L.yhat_off;
       float mx = z[0];
       for (int o = 1; o < L.od; ++o) mx = fmaxf(mx, z[o]);
       float se = 0.0f;
       for (int o = 0; o < L.od; ++o) se += expf(z[o] - mx);
-      disc += (logf(se) + mx) - z[(int)y[row]];
+      disc += (logf(se) + mx) - z[ylab];
     }
   }
-  kld = wave_sum_l(kld);
-  disc = wave_sum_l(disc);
-  if ((tid & 63) == 0) { red[0][tid >> 6] = kld; red[1][tid >> 6] = disc; }
+  // only the first two waves can hold non-zero partials (z_n, od <= 128)
+  if (tid < 128) {
+    kld = wave_sum_dpp(kld);
+    disc = wave_sum_dpp(disc);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = kld; red[1][tid >> 6] = disc; }
+  }
   lds_barrier();
   if (tid == 0 && L.losses) {
-    const int nw = (nt + 63) >> 6;
-    float k = 0.0f, dsum = 0.0f;
-    for (int i = 0; i < nw; ++i) { k += red[0][i]; dsum += red[1][i]; }
-    if (L.has_logvar) atomicAdd(L.losses + 4, -0.5f * k);
+    if (L.has_logvar) atomicAdd(L.losses + 4, -0.5f * (red[0][0] + red[0][1]));
     if (L.y) {
       const float inv = (L.loss_kind == 0) ? 1.0f / ((float)L.B * (float)L.od) : 1.0f / (float)L.B;
-      atomicAdd(L.losses + 0, dsum * inv);
+      atomicAdd(L.losses + 0, (red[1][0] + red[1][1]) * inv);
     }
   }
   // ---- outputs: plain stores, nothing in this kernel waits for them
@@ -683,14 +697,14 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_row_kernel(const Laten
                                                                      float* __restrict__ grads) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ LatOp ops[MFM_LAT_MAXOPS];
-  __shared__ int pfxN[MFM_LAT_MAXOPS], pfxK[MFM_LAT_MAXOPS];
+  __shared__ int pfxN[MFM_LAT_MAXOPS];
   const int RS = L.rec_size;
-  float* rec = lds;
-  float* grd = lds + RS;
+  i32x4* tab = reinterpret_cast<i32x4*>(lds);                        // [MAXSTAGES][1024] items
+  float* rec = lds + MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
+  float* grd = rec + RS;
   const int row = blockIdx.x;
   const int tid = threadIdx.x, nt = blockDim.x;
-  float sink = 0.0f;
-  {   // op table, prefix tables and the saved record are requested together (one round trip)
+  {   // op table, item table and the saved record are requested together (one round trip)
     const int nw = L.nops * (int)(sizeof(LatOp) / 4);
     const int opv = reinterpret_cast<const int*>(L.ops)[min(tid, nw - 1)];
     const int n4 = RS >> 2;
@@ -698,28 +712,22 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_row_kernel(const Laten
     f32x4* r4 = reinterpret_cast<f32x4*>(rec);
     f32x4* g4 = reinterpret_cast<f32x4*>(grd);
     const f32x4 rv = s4[min(tid, n4 - 1)];
+    load_items(L.items_bwd, L.nstages, tab, tid);
     if (tid < nw) reinterpret_cast<int*>(ops)[tid] = opv;
-    if (tid < L.nops) { pfxN[tid] = L.ops[tid].pfx_n; pfxK[tid] = L.ops[tid].pfx_k; }
+    if (tid < L.nops) pfxN[tid] = L.ops[tid].pfx_n;
     if (tid < n4) { r4[tid] = rv; g4[tid] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     for (int idx = tid + nt; idx < n4; idx += nt) { r4[idx] = s4[idx]; g4[idx] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   }
   lds_barrier();
-  // prefetch pipeline as in the forward: lane (4-column chunk, l) of a 16-lane group, rows l + 16j
   const int l = tid & 15;
-  struct Slot { f32x4 w[8]; float tv; int o, kc; bool live; };
+  const int wave0 = tid & ~63;
+  struct Slot { f32x4 w[8]; i32x4 e; };
   auto fetch = [&](int s, Slot& t) {
-    const int s2 = max(s - 1, 0);
-    t.tv = touch_span(params, L.span_off[s2], L.span_len[s2], tid);     // oldest load of the batch
-    const int ob = L.stage_begin[s], oe = L.stage_begin[s + 1];
-    const int total = 4 * (pfxK[oe - 1] + ops[oe - 1].K);     // 16 lanes per chunk of 4 columns
-    t.live = tid < total;
-    const int col = (min(tid, total - 1) >> 4) * 4;
-    t.o = find_op(pfxK, ob, oe, col, 1);
-    t.kc = col - pfxK[t.o];
-    const int K = ops[t.o].K, N = ops[t.o].N;
-    const float* wr = params + ops[t.o].w_off + t.kc;
+    t.e = tab[s * MFM_LAT_ROW_THREADS + tid];
+    const int K = t.e[1] & 0xFF, N = (t.e[1] >> 8) & 0xFF;
+    const float* wr = params + (unsigned)t.e[0];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t.w[j] = *reinterpret_cast<const f32x4*>(wr + (int64_t)min(l + 16 * j, N - 1) * K);
+    for (int j = 0; j < 8; ++j) t.w[j] = *reinterpret_cast<const f32x4*>(wr + min(l + 16 * j, N - 1) * K);
   };
   Slot sa, sb;
   fetch(L.nstages - 1, sa);
@@ -758,6 +766,12 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_row_kernel(const Laten
       if (!L.d_dec_init[m]) continue;
       for (int j = tid; j < L.f_n[m]; j += nt) grd[L.f_off[m] + j] = L.d_dec_init[m][(int64_t)row * L.dec_ld[m] + fy + j];
     }
+    // the f segments come out of a relu layer (z -> f, second Linear): the record holds gradients wrt
+    // PRE-activations throughout (what the bias / weight gradients need), so the seeds are masked here and
+    // every later contribution is masked where it is accumulated (stage loop)
+    for (int m = 0; m < 4; ++m)
+      for (int j = tid; j < L.f_n[m]; j += nt)
+        if (!(rec[L.f_off[m] + j] > 0.0f)) grd[L.f_off[m] + j] = 0.0f;
   }
   const float reg_w = L.reg_w_ptr ? *L.reg_w_ptr : L.reg_w;
   if (L.has_logvar && (L.reg_w_ptr || reg_w != 0.0f)) {
@@ -771,54 +785,43 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_row_kernel(const Laten
   lds_barrier();
   mark(L, 24);
 
-
-  const int wave0 = tid & ~63;
-  auto items16 = [&](int s) { const int oe2 = L.stage_begin[s + 1]; return 4 * (pfxK[oe2 - 1] + ops[oe2 - 1].K); };
   auto stage = [&](int s, Slot& cur, Slot& nxt) {
-    const int ob = L.stage_begin[s], oe = L.stage_begin[s + 1];
     const int sn = max(s - 1, 0);
-    const bool wave_on = wave0 < max(items16(s), items16(sn));   // per-wave skip, see the forward kernel
-    // ---- pass 1: gradient wrt the pre-activation, in place
-    const int totn = pfxN[oe - 1] + ops[oe - 1].N;
-    for (int item = tid; item < totn; item += nt) {
-      const int o = find_op(pfxN, ob, oe, item, 1);
-      const LatOp& op = ops[o];
-      if (!op.relu && op.mask_off < 0) continue;
-      const int n = item - pfxN[o];
-      float gv = grd[op.out_off + n];
-      if (op.relu && !(rec[op.out_off + n] > 0.0f)) gv = 0.0f;
-      if (op.mask_off >= 0) gv *= rec[op.mask_off + n];
-      grd[op.out_off + n] = gv;
-    }
-    lds_barrier();
     mark(L, 25 + 3 * s);
-    // ---- pass 2a: dX[k] += sum_n g[n] W[n][k]
-    if (wave_on) {
-      fetch(sn, nxt);                // stage 0 prefetches itself again: every load stays unconditional
-      if (wave0 < items16(s)) {      // `cur` was fetched one stage ago exactly when this holds
-      const LatOp op = ops[cur.o];
-      const float* g = grd + op.out_off;
+    // ---- pass 2a: dX[k] += sum_n g[n] W[n][k]   (per-wave skip and unconditional loads as in the forward)
+    if (wave0 < max(L.nitems_bwd[s], L.nitems_bwd[sn])) {
+      const int N = (cur.e[1] >> 8) & 0xFF;
+      const int out_off = cur.e[2] & 0xFFFF, in_idx = (cur.e[2] >> 16) & 0xFFFF;
       float gv[8];
+      if (wave0 < L.nitems_bwd[s]) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) gv[j] = g[min(l + 16 * j, op.N - 1)];
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float gj = (l + 16 * j < op.N) ? gv[j] : 0.0f;
-        acc += gj * cur.w[j];
+        for (int j = 0; j < 8; ++j) gv[j] = grd[out_off + min(l + 16 * j, N - 1)];
       }
-      sink += cur.tv;
-      float out[4];
+      fetch(sn, nxt);                // stage 0 requests its own weights again
+      if (wave0 < L.nitems_bwd[s]) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float v = acc[c];
-        v += dpp_row<0xB1>(v); v += dpp_row<0x4E>(v);
-        v += dpp_row<0x141>(v); v += dpp_row<0x140>(v);
-        out[c] = v;
-      }
-      const float lo = (l & 1) ? out[1] : out[0], hi = (l & 1) ? out[3] : out[2];
-      const float v = (l & 2) ? hi : lo;
-      if (cur.live && l < 4) atomicAdd(&grd[op.in_off + cur.kc + l], v);
+        for (int j = 0; j < 8; ++j) {
+          const float gj = (l + 16 * j < N) ? gv[j] : 0.0f;
+          acc += gj * cur.w[j];
+        }
+        float out[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float v = acc[c];
+          v += dpp_row<0xB1>(v); v += dpp_row<0x4E>(v);
+          v += dpp_row<0x141>(v); v += dpp_row<0x140>(v);
+          out[c] = v;
+        }
+        const float lo = (l & 1) ? out[1] : out[0], hi = (l & 1) ? out[3] : out[2];
+        const float v = (l & 2) ? hi : lo;
+        const int ew = cur.e[3];
+        if ((ew & 1) && l < 4) {
+          float f = 1.0f;
+          if ((ew & 2) && !(rec[in_idx + l] > 0.0f)) f = 0.0f;          // producer's relu
+          if (ew >> 2) f *= rec[(ew >> 2) - 1 + l];                     // producer's dropout mask (scaled)
+          atomicAdd(&grd[in_idx + l], v * f);
+        }
       }
     }
     mark(L, 26 + 3 * s);
@@ -830,13 +833,12 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_row_kernel(const Laten
     if (s >= 1) stage(s - 1, sb, sa);
   }
 
-  if (sink == 1.2345e38f) grd[0] = sink;     // never true: keeps the touch loads alive
   // ---- bias gradients of all layers in one go (the record keeps every pre-activation gradient).  Inside
   // the stage loop these atomics would sit between two weight prefetches in the in-order vmcnt queue, and
   // every wait for weights would also wait for them.  Weight gradients: grouped GEMM over the two records.
   for (int st = 0; st < L.nstages; ++st) {
     const int ob = L.stage_begin[st], oe = L.stage_begin[st + 1];
-    const int totn = pfxN[oe - 1] + ops[oe - 1].N;
+    const int totn = L.nitems_fwd[st] >> 2;
     for (int item = tid; item < totn; item += nt) {
       const int o = find_op(pfxN, ob, oe, item, 1);
       const LatOp& op = ops[o];
@@ -865,7 +867,8 @@ static int set_lds_limit(const void* fn, size_t bytes) {
 
 int latent_fwd_launch(const LatentDev& L, const float* params, hipStream_t stream) {
   if (L.row_path) {
-    const size_t lds1 = (size_t)L.rec_size * sizeof(float);
+    const size_t lds1 = ((size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + L.rec_size) * sizeof(float);
+    if (int rc1 = set_lds_limit((const void*)latent_fwd_row_kernel, lds1)) return rc1;
     hipLaunchKernelGGL(latent_fwd_row_kernel, dim3(L.B), dim3(LAT_THREADS), lds1, stream, L, params);
     MFM_LAUNCH_CHECK("latent_fwd_row_kernel");
     return MFM_OK;
@@ -884,7 +887,8 @@ int latent_fwd_launch(const LatentDev& L, const float* params, hipStream_t strea
 }
 int latent_bwd_launch(const LatentDev& L, const float* params, float* grads, hipStream_t stream) {
   if (L.row_path) {
-    const size_t lds1 = 2 * (size_t)L.rec_size * sizeof(float);
+    const size_t lds1 = ((size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + 2 * (size_t)L.rec_size) * sizeof(float);
+    if (int rc1 = set_lds_limit((const void*)latent_bwd_row_kernel, lds1)) return rc1;
     hipLaunchKernelGGL(latent_bwd_row_kernel, dim3(L.B), dim3(LAT_THREADS), lds1, stream, L, params, grads);
     MFM_LAUNCH_CHECK("latent_bwd_row_kernel");
     return MFM_OK;

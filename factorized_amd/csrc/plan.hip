@@ -60,7 +60,8 @@ struct MfmPlan {
   int64_t ws_floats;
   mfm::LatentDev lat;
   mfm::LatOp lat_ops[MFM_LAT_MAXOPS];
-  int64_t lat_ops_off, dbg_off, lat_grd;
+  int64_t lat_ops_off, dbg_off, lat_grd, lat_items_off;
+  std::vector<int> lat_items;       // row-path item tables: forward then backward, [MAXSTAGES][1024][4] each
   // timing
   int timing_mask;
   std::vector<mfm::TimingPair> pool;
@@ -208,7 +209,7 @@ static int build(MfmPlan* P) {
   // Latency path (latent.hip, row kernels): one row per workgroup while that still fits the chip in one
   // wave of workgroups and every layer meets the vector-load shape requirements.
   {
-    bool ok = c.B <= 256 && (size_t)2 * rs * sizeof(float) <= 60 * 1024;
+    bool ok = c.B <= 256 && (size_t)2 * rs * sizeof(float) <= 24 * 1024 && P->n_params < (1ll << 31);
     for (int i = 0; i < L.nops && ok; ++i) {
       const LatOp& op = P->lat_ops[i];
       ok = (op.K % 4 == 0) && op.K >= 4 && op.K <= 128 && op.N <= 128 && (op.w_off % 4 == 0);
@@ -221,9 +222,64 @@ static int build(MfmPlan* P) {
     if (const char* e = getenv("MFM_LATENT_PATH")) { if (!strcmp(e, "staged")) ok = false; }
     L.row_path = ok ? 1 : 0;
   }
+  // row path: the work item of thread t in stage s is static, so it is tabulated here once (encoding: latent.hip)
+  const int NT = MFM_LAT_ROW_THREADS;
+  P->lat_items.assign((size_t)2 * MFM_LAT_MAXSTAGES * NT * 4, 0);
+  if (L.row_path) {
+    int* fw = P->lat_items.data();
+    int* bw = fw + (size_t)MFM_LAT_MAXSTAGES * NT * 4;
+    for (int st = 0; st < L.nstages; ++st) {
+      const int ob = L.stage_begin[st], oe = L.stage_begin[st + 1];
+      int sn = 0, sk = 0;
+      for (int i = ob; i < oe; ++i) { sn += P->lat_ops[i].N; sk += P->lat_ops[i].K; }
+      L.nitems_fwd[st] = 4 * sn;
+      L.nitems_bwd[st] = 4 * sk;
+      for (int t = 0; t < NT; ++t) {
+        {   // forward: quad (n, q) -> output column n of op o
+          const bool live = t < 4 * sn;
+          const int item = std::min(t, 4 * sn - 1) >> 2;
+          int o = ob;
+          while (o + 1 < oe && item >= P->lat_ops[o + 1].pfx_n) ++o;
+          const LatOp& op = P->lat_ops[o];
+          const int n = item - op.pfx_n;
+          int* e = fw + ((size_t)st * NT + t) * 4;
+          e[0] = (int)(op.w_off + (int64_t)n * op.K);
+          e[1] = (int)(op.b_off + n);
+          e[2] = op.in_off | (op.K << 16);
+          e[3] = (op.out_off + n) | (o << 16) | ((op.relu ? 1 : 0) << 24) | ((op.mask_off >= 0 ? 1 : 0) << 25) |
+                 ((live ? 1 : 0) << 26);
+        }
+        {   // backward: 16 lanes (kc, l) -> input columns kc..kc+3 of op o
+          const bool live = t < 4 * sk;
+          const int col = (std::min(t, 4 * sk - 1) >> 4) * 4;
+          int o = ob;
+          while (o + 1 < oe && col >= P->lat_ops[o + 1].pfx_k) ++o;
+          const LatOp& op = P->lat_ops[o];
+          const int kc = col - op.pfx_k;
+          int* e = bw + ((size_t)st * NT + t) * 4;
+          e[0] = (int)(op.w_off + kc);
+          e[1] = op.K | (op.N << 8);
+          e[2] = op.out_off | ((op.in_off + kc) << 16);
+          // the layer that PRODUCED these input columns: its relu / dropout mask is applied to the gradient
+          // as it is accumulated (they are linear, so masking each contribution == masking the sum)
+          int prelu = 0, pmask = 0;
+          for (int pi = 0; pi < ob; ++pi) {
+            const LatOp& pr = P->lat_ops[pi];
+            const int idx = op.in_off + kc;
+            if (idx >= pr.out_off && idx < pr.out_off + pr.N) {
+              prelu = pr.relu ? 1 : 0;
+              pmask = pr.mask_off >= 0 ? pr.mask_off + (idx - pr.out_off) + 1 : 0;
+            }
+          }
+          e[3] = (live ? 1 : 0) | (prelu << 1) | (pmask << 2);
+        }
+      }
+    }
+  }
 
   P->lat_ops_off = carve(cur, (int64_t)(sizeof(P->lat_ops) / (sizeof(float))));
   P->dbg_off = carve(cur, 128);     // 64 x u64 debug timestamps
+  P->lat_items_off = carve(cur, (int64_t)P->lat_items.size());
   P->lat_grd = carve(cur, (int64_t)c.B * rs);
   P->lat_rec = carve(cur, (int64_t)c.B * rs);
   P->yhat = carve(cur, (int64_t)c.B * c.output_dim);
@@ -305,6 +361,8 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
   {
     LatentDev L = P->lat;
     L.ops = reinterpret_cast<const LatOp*>(W + P->lat_ops_off);
+    L.items_fwd = reinterpret_cast<const int*>(W + P->lat_items_off);
+    L.items_bwd = L.items_fwd + (size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
     if (getenv("MFM_LATENT_DBG")) L.dbg = reinterpret_cast<unsigned long long*>(W + P->dbg_off);
     for (int e = 0; e < 4; ++e) {
       L.enc_h[e] = W + P->enc[e].hs + (int64_t)(T - 1) * B * P->enc[e].Hp;
@@ -469,6 +527,8 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
   {
     LatentDev L = P->lat;
     L.ops = reinterpret_cast<const LatOp*>(W + P->lat_ops_off);
+    L.items_fwd = reinterpret_cast<const int*>(W + P->lat_items_off);
+    L.items_bwd = L.items_fwd + (size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
     if (getenv("MFM_LATENT_DBG")) L.dbg = reinterpret_cast<unsigned long long*>(W + P->dbg_off);
     for (int m = 0; m < 3; ++m) {
       L.d_dec_init[m] = gen_on ? W + P->dec_dinit[m] : nullptr;
@@ -572,6 +632,8 @@ extern "C" int mfm_plan_init_workspace(MfmPlan* P, void* workspace, void* stream
   hipStream_t s = (hipStream_t)stream;
   MFM_HIP_CHECK(hipMemsetAsync(W, 0, (size_t)P->ws_floats * sizeof(float), s));
   MFM_HIP_CHECK(hipMemcpyAsync(W + P->lat_ops_off, P->lat_ops, sizeof(P->lat_ops), hipMemcpyHostToDevice, s));
+  MFM_HIP_CHECK(hipMemcpyAsync(W + P->lat_items_off, P->lat_items.data(), P->lat_items.size() * sizeof(int),
+                               hipMemcpyHostToDevice, s));
   return fill_launch(W + P->ones, (int64_t)P->T * P->B, 1.0f, s);
 }
 
