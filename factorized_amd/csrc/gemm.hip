@@ -10,7 +10,7 @@
 // at most 2-way).  Writing k-contiguous groups into a [k][m] image cost 8-way-conflicted ds_write_b32.
 #include <stdlib.h>
 
-#include "common.h"
+#include "internal.h"
 
 namespace mfm {
 
@@ -24,6 +24,10 @@ struct GemmProblem {
 struct GemmGroup {
   GemmProblem p[MFM_GEMM_MAXP];
   int count;
+  // optional: spans the launch also clears (the fused step's loss slots and gradient buffer ride on its
+  // first GEMM instead of two memset launches of ~4.7 us each)
+  float* zero_ptr[2];
+  int64_t zero_n[2];
 };
 
 // VEC: every operand of every problem in the group is unit-stride along its 4-element load groups
@@ -44,6 +48,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   const int lane = tid & 63, wave = tid >> 6;
   const int bi = lane & 15, q = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
+
+#pragma unroll
+  for (int zi = 0; zi < 2; ++zi) {
+    if (g.zero_n[zi] > 0) {          // 16-byte aligned, multiple of 4 floats (checked by the host)
+      f32x4* z4 = reinterpret_cast<f32x4*>(g.zero_ptr[zi]);
+      const int64_t n4 = g.zero_n[zi] >> 2;
+      for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n4; i += (int64_t)gridDim.x * 256) z4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
 
   // ---- locate problem / tile (wave-uniform)
   int pi = 0;
@@ -255,12 +268,19 @@ int device_cus() {
 }
 
 // Host-side launch of one group (count <= MFM_GEMM_MAXP).
-int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream) {
+int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, const ZeroSpans* zs) {
   MFM_REQUIRE(count >= 1 && count <= MFM_GEMM_MAXP, "gemm group: count %d out of range", count);
   const int cus = device_cus();
   GemmGroup g;
   memset(&g, 0, sizeof(g));
   g.count = count;
+  if (zs) {
+    for (int i = 0; i < 2; ++i) {
+      if (zs->n[i] <= 0) continue;
+      MFM_REQUIRE((zs->n[i] & 3) == 0 && (((uintptr_t)zs->ptr[i]) & 15) == 0, "gemm group: zero span %d not 16-byte shaped", i);
+      g.zero_ptr[i] = zs->ptr[i]; g.zero_n[i] = zs->n[i];
+    }
+  }
   // pass 1: block count with 64x64 tiles and no split; decide tile size
   long blocks64 = 0;
   for (int i = 0; i < count; ++i) {

@@ -5,7 +5,8 @@
 namespace mfm {
 
 // gemm.hip
-int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream);
+struct ZeroSpans { float* ptr[2]; int64_t n[2]; };   // spans (multiples of 4 floats, 16-byte aligned) a GEMM launch also clears
+int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, const ZeroSpans* zs = nullptr);
 int device_cus();
 
 // elementwise.hip

@@ -67,6 +67,7 @@ struct MfmPlan {
   std::vector<mfm::TimingPair> pool;
   size_t pool_used;
   uint64_t calls;
+  const float* grads_prezeroed;     // gradient buffer cleared by the forward pass of the running fused step
 };
 
 namespace mfm {
@@ -326,12 +327,22 @@ static MfmSeqDesc seq_desc(const MfmPlan* P, const SeqBuf& sb, int pbase, const 
 }
 
 static int forward(MfmPlan* P, const float* params, const float* x, const void* y, int train, uint64_t seed,
-                   float* W, float* xhat_out[3], float* yhat_out, float* losses_out, hipStream_t s) {
+                   float* W, float* xhat_out[3], float* yhat_out, float* losses_out, hipStream_t s,
+                   float* grads_to_zero = nullptr) {
   const MfmPlanConfig& c = P->cfg;
   const int T = P->T, B = P->B;
   const int64_t TB = (int64_t)T * B;
   float* losses = losses_out ? losses_out : W + P->losses;
-  MFM_HIP_CHECK(hipMemsetAsync(losses, 0, MFM_LOSS_SLOTS * sizeof(float), s));
+  // the loss slots (and, in the fused step, the gradient buffer) are cleared by the first GEMM launch
+  ZeroSpans zs;
+  memset(&zs, 0, sizeof(zs));
+  if ((((uintptr_t)losses) & 15) == 0) { zs.ptr[0] = losses; zs.n[0] = MFM_LOSS_SLOTS; }
+  else MFM_HIP_CHECK(hipMemsetAsync(losses, 0, MFM_LOSS_SLOTS * sizeof(float), s));
+  P->grads_prezeroed = nullptr;
+  if (grads_to_zero && (((uintptr_t)grads_to_zero) & 15) == 0 && (P->n_params & 3) == 0) {
+    zs.ptr[1] = grads_to_zero; zs.n[1] = P->n_params;
+    P->grads_prezeroed = grads_to_zero;
+  }
   P->calls++;
 
   // F0: input projections
@@ -349,7 +360,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       d.m = (int)TB; d.n = sb.Hp; d.n_valid = sb.h; d.k = P->enc_d[e]; d.batch = 4; d.split_k = 1;
       d.alpha = 1.0f;
     }
-    RUN(K_PROJ, gemm_group_launch(g, 4, s));
+    RUN(K_PROJ, gemm_group_launch(g, 4, s, &zs));
   }
   // F1: encoder recurrences
   {
@@ -470,7 +481,8 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
   const MfmPlanConfig& c = P->cfg;
   const int T = P->T, B = P->B;
   const int64_t TB = (int64_t)T * B;
-  MFM_HIP_CHECK(hipMemsetAsync(grads, 0, (size_t)P->n_params * sizeof(float), s));
+  if (P->grads_prezeroed != grads) MFM_HIP_CHECK(hipMemsetAsync(grads, 0, (size_t)P->n_params * sizeof(float), s));
+  P->grads_prezeroed = nullptr;
   const bool gen_on = (stage != 2), disc_on = (stage != 1);
   if (gen_on) {
     // B0: through decoder fc1
@@ -515,13 +527,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       }
       RUN(K_DEC_BWD, mfm_lstm_seq_bwd(q, 3, T, B, s));
     }
-    // B2: decoder weight gradients
-    {
-      std::vector<MfmGemmDesc> gw;
-      for (int m = 0; m < 3; ++m)
-        dA_gemms(P, P->dec[m], P->dec_p[m], W, grads, gw, W + P->dec_init[m], P->dec_h[m], P->dec_h[m], true);
-      RUN(K_DEC_DW, gemm_group_launch(gw.data(), (int)gw.size(), s));
-    }
+    // (B2: the decoder weight gradients only feed Adam; they share the encoders' launch at the end)
   }
   // B3: latent stack
   {
@@ -573,7 +579,10 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     std::vector<MfmGemmDesc> gw;
     for (int e = 0; e < 4; ++e)
       dA_gemms(P, P->enc[e], P->enc_p[e], W, grads, gw, x + P->enc_xoff[e], P->D, P->enc_d[e], false);
-    RUN(K_ENC_DW, gemm_group_launch(gw.data(), (int)gw.size(), s));
+    if (gen_on)
+      for (int m = 0; m < 3; ++m)
+        dA_gemms(P, P->dec[m], P->dec_p[m], W, grads, gw, W + P->dec_init[m], P->dec_h[m], P->dec_h[m], true);
+    RUN(K_ENC_DW, mfm_gemm_grouped_f32(gw.data(), (int)gw.size(), s));
   }
   return MFM_OK;
 }
@@ -609,7 +618,7 @@ extern "C" int mfm_plan_create(const MfmPlanConfig* cfg, const int64_t* param_of
     }
   }
   P->n_params = n_params_total;
-  P->timing_mask = 0; P->pool_used = 0; P->calls = 0;
+  P->timing_mask = 0; P->pool_used = 0; P->calls = 0; P->grads_prezeroed = nullptr;
   int rc = build(P);
   if (rc != MFM_OK) { delete P; return rc; }
   *out = P;
@@ -675,7 +684,7 @@ extern "C" int mfm_plan_train_step(MfmPlan* P, float* params, float* grads, floa
   }
   hipStream_t s = (hipStream_t)stream;
   float* xo[3] = {nullptr, nullptr, nullptr};
-  int rc = forward(P, params, x, y, 1, seed, (float*)workspace, xo, nullptr, losses, s);
+  int rc = forward(P, params, x, y, 1, seed, (float*)workspace, xo, nullptr, losses, s, grads);
   if (rc != MFM_OK) return rc;
   rc = backward(P, params, x, y, 0, (float*)workspace, grads, s);
   if (rc != MFM_OK) return rc;
@@ -693,7 +702,7 @@ extern "C" int mfm_plan_num_kernels(void) { return K_COUNT; }
 extern "C" const char* mfm_plan_kernel_name(int kid) {
   static const char* names[K_COUNT] = {"proj_gemm", "enc_seq_fwd", "latent_fwd", "dec_seq_fwd", "fc1_gemm", "mse",
                                        "fc1_bwd_gemm", "dec_seq_bwd", "dec_dw_gemm", "latent_bwd", "enc_seq_bwd",
-                                       "enc_dw_gemm", "adam", "latent_dw_gemm"};
+                                       "lstm_dw_gemm", "adam", "latent_dw_gemm"};
   return (kid >= 0 && kid < K_COUNT) ? names[kid] : "?";
 }
 // Synchronises on the recorded events, adds elapsed ms / launch counts per kernel id, resets the pool.
@@ -747,8 +756,11 @@ extern "C" double mfm_plan_kernel_flops(const MfmPlan* P, int kid) {
     case K_DEC_FWD: case K_DEC_BWD: for (int m = 0; m < 3; ++m) f += TB * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m]; break;
     case K_FC1_FWD: for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m]; break;
     case K_FC1_BWD: for (int m = 0; m < 3; ++m) f += 2.0 * TB * 2.0 * P->dec_h[m] * P->dec_d[m]; break;
-    case K_DEC_DW: for (int m = 0; m < 3; ++m) f += TB * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m]; break;
-    case K_ENC_DW: for (int e = 0; e < 4; ++e) f += TB * 2.0 * 4.0 * P->enc_h[e] * (P->enc_d[e] + P->enc_h[e]); break;
+    case K_DEC_DW: break;   // merged into K_ENC_DW
+    case K_ENC_DW:
+      for (int e = 0; e < 4; ++e) f += TB * 2.0 * 4.0 * P->enc_h[e] * (P->enc_d[e] + P->enc_h[e]);
+      for (int m = 0; m < 3; ++m) f += TB * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m];
+      break;
     default: break;
   }
   return f;
