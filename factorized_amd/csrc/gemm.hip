@@ -14,7 +14,7 @@
 
 namespace mfm {
 
-#define MFM_GEMM_MAXP 24   // 24 x 168 B of descriptors stay inside the 4 KB kernel-argument segment
+#define MFM_GEMM_MAXP 22   // 22 x 168 B of descriptors + the group extras stay inside the 4 KB kernel-argument segment
 constexpr int BK = 32;   // K depth of one LDS stage: 8 MFMA k-steps between barriers
 
 struct GemmProblem {
@@ -28,6 +28,11 @@ struct GemmGroup {
   // first GEMM instead of two memset launches of ~4.7 us each)
   float* zero_ptr[2];
   int64_t zero_n[2];
+  // optional: squared-error epilogue for the first mse_count problems (decoder fc1 -> x_hat): the tile that
+  // produced x_hat also forms d x_hat and its share of the reconstruction loss (mfm_mosi.py:441-446), so the
+  // separate elementwise launch and its re-read of x_hat disappear
+  MseEpi mse[3];
+  int mse_count;
 };
 
 // VEC: every operand of every problem in the group is unit-stride along its 4-element load groups
@@ -186,6 +191,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
       *reinterpret_cast<f32x4*>(Bs + b_st[g]) = f32x4{rb[slot][4 * g], rb[slot][4 * g + 1], rb[slot][4 * g + 2], rb[slot][4 * g + 3]};
   };
 
+  // squared-error epilogue: the targets of this thread's outputs are requested before the K loop
+  const bool do_mse = pi < g.mse_count;          // wave-uniform
+  const MseEpi& me = g.mse[do_mse ? pi : 0];
+  float tgt[FR][FR][4];
+  if (do_mse) {
+#pragma unroll
+    for (int fm = 0; fm < FR; ++fm)
+#pragma unroll
+      for (int fn = 0; fn < FR; ++fn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = min(m0 + wm * 16 * FR + fm * 16 + q * 4 + r, d.m - 1);
+          const int col = min(n0 + wn * 16 * FR + fn * 16 + bi, max(d.n_valid - 1, 0));
+          tgt[fm][fn][r] = me.x[(int64_t)row * me.ldx + col];
+        }
+  }
   f32x4 acc[FR][FR];
 #pragma unroll
   for (int i = 0; i < FR; ++i)
@@ -225,6 +246,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   // ---- epilogue
   float* __restrict__ C = d.c + (int64_t)z * d.c_sz;
   float* __restrict__ C2 = d.c2 ? d.c2 + (int64_t)z * d.c_sz : nullptr;
+  float sq = 0.0f;
 #pragma unroll
   for (int fm = 0; fm < FR; ++fm)
 #pragma unroll
@@ -250,9 +272,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
         } else {
           C[off] = v;
           if (C2) C2[off] = v;
+          if (do_mse && col < d.n_valid) {
+            const float diff = v - tgt[fm][fn][r];
+            sq += diff * diff;
+            if (me.dxhat) me.dxhat[off] = me.grad_scale * diff;
+          }
         }
       }
     }
+  if (do_mse && me.loss) {
+    __shared__ float sqsum[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    if (lane == 0) sqsum[wave] = sq;
+    lds_barrier();
+    if (tid == 0) atomicAdd(me.loss, (sqsum[0] + sqsum[1] + sqsum[2] + sqsum[3]) * me.inv_count);
+  }
 }
 
 static int g_cus = 0;
@@ -268,12 +303,19 @@ int device_cus() {
 }
 
 // Host-side launch of one group (count <= MFM_GEMM_MAXP).
-int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, const ZeroSpans* zs) {
+int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, const ZeroSpans* zs, const MseEpi* mse,
+                      int mse_count) {
   MFM_REQUIRE(count >= 1 && count <= MFM_GEMM_MAXP, "gemm group: count %d out of range", count);
   const int cus = device_cus();
   GemmGroup g;
   memset(&g, 0, sizeof(g));
   g.count = count;
+  MFM_REQUIRE(mse_count >= 0 && mse_count <= 3 && mse_count <= count && (mse_count == 0 || mse), "gemm group: bad mse epilogue count %d", mse_count);
+  g.mse_count = mse_count;
+  for (int i = 0; i < mse_count; ++i) {
+    MFM_REQUIRE(mse[i].x && !descs[i].accumulate && descs[i].batch == 1, "gemm group: mse epilogue %d needs a plain (non-accumulating, unbatched) product", i);
+    g.mse[i] = mse[i];
+  }
   if (zs) {
     for (int i = 0; i < 2; ++i) {
       if (zs->n[i] <= 0) continue;

@@ -6,7 +6,11 @@ namespace mfm {
 
 // gemm.hip
 struct ZeroSpans { float* ptr[2]; int64_t n[2]; };   // spans (multiples of 4 floats, 16-byte aligned) a GEMM launch also clears
-int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, const ZeroSpans* zs = nullptr);
+struct MseEpi {          // squared-error epilogue of one product: target, d(output), loss slot, scales
+  const float* x; int64_t ldx; float* dxhat; float* loss; float inv_count, grad_scale;
+};
+int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, const ZeroSpans* zs = nullptr,
+                      const MseEpi* mse = nullptr, int mse_count = 0);
 int device_cus();
 
 // elementwise.hip

@@ -411,22 +411,19 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       d.bias = params + P->off[pb + FC_B];
       d.m = (int)TB; d.n = P->dec_d[m]; d.n_valid = d.n; d.k = sb.h; d.batch = 1; d.split_k = 1; d.alpha = 1.0f;
     }
-    RUN(K_FC1_FWD, gemm_group_launch(g, 3, s));
-  }
-  // F5: reconstruction losses + d x_hat
-  {
+    // reconstruction losses + d x_hat in the same tiles (F5 of the first versions was its own launch)
     const float lda[3] = {c.lda_xl, c.lda_xa, c.lda_xv};
-    MseItem it[3];
-    memset(it, 0, sizeof(it));
+    MseEpi me[3];
+    memset(me, 0, sizeof(me));
     for (int m = 0; m < 3; ++m) {
       const double cnt = (double)TB * P->dec_d[m];
-      it[m].xhat = xh[m]; it[m].x = x + P->dec_xoff[m]; it[m].ldx = P->D; it[m].rows = TB; it[m].d = P->dec_d[m];
-      it[m].inv_count = (float)(1.0 / cnt);
-      it[m].grad_scale = (float)(2.0 * lda[m] / cnt);
-      it[m].dxhat = W + P->dxhat[m];
-      it[m].loss_slot = losses + 1 + m;
+      me[m].x = x + P->dec_xoff[m]; me[m].ldx = P->D;
+      me[m].dxhat = W + P->dxhat[m];
+      me[m].loss = losses + 1 + m;
+      me[m].inv_count = (float)(1.0 / cnt);
+      me[m].grad_scale = (float)(2.0 * lda[m] / cnt);
     }
-    RUN(K_MSE, mse_group_launch(it, 3, s));
+    RUN(K_FC1_FWD, gemm_group_launch(g, 3, s, nullptr, me, 3));
   }
   return MFM_OK;
 }
@@ -700,7 +697,7 @@ extern "C" int mfm_plan_set_timing(MfmPlan* P, int mask) {
 }
 extern "C" int mfm_plan_num_kernels(void) { return K_COUNT; }
 extern "C" const char* mfm_plan_kernel_name(int kid) {
-  static const char* names[K_COUNT] = {"proj_gemm", "enc_seq_fwd", "latent_fwd", "dec_seq_fwd", "fc1_gemm", "mse",
+  static const char* names[K_COUNT] = {"proj_gemm", "enc_seq_fwd", "latent_fwd", "dec_seq_fwd", "fc1_mse_gemm", "mse",
                                        "fc1_bwd_gemm", "dec_seq_bwd", "dec_dw_gemm", "latent_bwd", "enc_seq_bwd",
                                        "lstm_dw_gemm", "adam", "latent_dw_gemm"};
   return (kid >= 0 && kid < K_COUNT) ? names[kid] : "?";
