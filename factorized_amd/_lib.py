@@ -73,6 +73,8 @@ _SIGS = {
     "mfm_plan_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
     "mfm_plan_backward_ext": (C.c_int, [C.c_void_p] * 11),
+    "mfm_plan_grad_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "mfm_plan_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_float,
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -672,6 +672,19 @@ extern "C" int mfm_plan_backward_ext(MfmPlan* P, const float* params, const floa
   return backward(P, params, x, nullptr, 0, (float*)workspace, grads, (hipStream_t)stream, &ext);
 }
 
+extern "C" int mfm_plan_grad_step(MfmPlan* P, const float* params, float* grads, const float* x, const void* y,
+                                  uint64_t seed, void* workspace, float* losses, void* stream) {
+  if (!P || !params || !grads || !x || !y || !workspace) {
+    set_error("mfm_plan_grad_step: null argument");
+    return MFM_ERR_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* xo[3] = {nullptr, nullptr, nullptr};
+  int rc = forward(P, params, x, y, 1, seed, (float*)workspace, xo, nullptr, losses, s, grads);
+  if (rc != MFM_OK) return rc;
+  return backward(P, params, x, y, 0, (float*)workspace, grads, s);
+}
+
 extern "C" int mfm_plan_train_step(MfmPlan* P, float* params, float* grads, float* adam_m, float* adam_v,
                                    const float* x, const void* y, uint64_t seed, int32_t step, float lr,
                                    float grad_scale, void* workspace, float* losses, void* stream) {

@@ -274,6 +274,18 @@ class MFMEngine:
                    "mfm_plan_train_step")
         return p.losses
 
+    def grad_step(self, x, y, check=True):
+        """forward(train) + backward(joint loss), one enqueue, no optimizer (data-parallel step:
+        all-reduce self.grads, then adam()).  Returns the device tensor of loss slots (no sync)."""
+        if check:
+            self._check_inputs(x, y)
+        T, B, _ = x.shape
+        p = self.plan(T, B)
+        _lib.check(_lib.lib().mfm_plan_grad_step(p.handle, _ptr(self.params), _ptr(self.grads), _ptr(x), _ptr(y),
+                                                 C.c_uint64(self.seed), _ptr(p.workspace), _ptr(p.losses), _stream()),
+                   "mfm_plan_grad_step")
+        return p.losses
+
     def adam(self, lr=1e-3, grad_scale=1.0):
         self.step_count += 1
         _lib.check(_lib.lib().mfm_adam_flat(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m),

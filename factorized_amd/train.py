@@ -62,11 +62,10 @@ class DataParallelStep:
         if self.world == 1:
             return e.train_step(x, y, lr=self.lr, check=False)
         import torch.distributed as dist
-        out = e.forward(x, y, train=True, want_xhat=False)
-        e.backward(x, y, stage=0)
+        losses = e.grad_step(x, y, check=False)           # fwd + bwd: one enqueue, 11 launches
         dist.all_reduce(e.grads)                          # one flat buffer, one collective
         e.adam(lr=self.lr, grad_scale=1.0 / self.world)
-        return out["losses"]
+        return losses
 
 
 def broadcast_params(engine, world):

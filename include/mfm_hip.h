@@ -176,6 +176,12 @@ int mfm_plan_backward_ext(MfmPlan* plan, const float* params, const float* x, co
                           const float* d_xhat_a, const float* d_xhat_v, const float* d_yhat,
                           const float* d_reg, void* workspace, float* grads, void* stream);
 
+/* forward (train mode) + backward of the joint loss in one enqueue, no optimizer: the data-parallel step
+ * all-reduces `grads` next and then calls mfm_adam_flat (factorized_amd/train.py).  Same launches as
+ * mfm_plan_train_step minus Adam; the gradient buffer is cleared inside the first launch. */
+int mfm_plan_grad_step(MfmPlan* plan, const float* params, float* grads, const float* x, const void* y,
+                       uint64_t seed, void* workspace, float* losses, void* stream);
+
 /* forward + backward + Adam in one enqueue (no host work in between). */
 int mfm_plan_train_step(MfmPlan* plan, float* params, float* grads, float* adam_m, float* adam_v,
                         const float* x, const void* y, uint64_t seed, int32_t step, float lr,

@@ -41,6 +41,11 @@ class OracleEngine:
         loss.backward()
         self.grads.copy_(torch.nn.utils.parameters_to_vector([p.grad for p in self.model.parameters()]))
 
+    def grad_step(self, x, y, check=False):
+        out = self.forward(x, y)
+        self.backward(x, y)
+        return out["losses"]
+
     def adam(self, lr=1e-3, grad_scale=1.0):
         self.t += 1
         g = self.grads * grad_scale

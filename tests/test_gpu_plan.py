@@ -90,6 +90,28 @@ def test_gradients_match_oracle_and_golden(name, seq_path):
     assert np.max(np.abs(got - gold) / scale) < 5 * TOL      # norm / sum / first-8 vs the reference
 
 
+def test_grad_step_equals_forward_plus_backward():
+    """mfm_plan_grad_step (the data-parallel step's one-enqueue fwd+bwd, gradient buffer cleared inside the
+    first launch) must leave exactly what forward + backward leave, also on a dirty gradient buffer."""
+    cs = cases.load_case("klef_b32_t20")
+    e, _ = _engine(cs)
+    xd, yd = torch.from_numpy(cs["x"]).cuda(), torch.from_numpy(cs["y"]).cuda()
+    out = e.forward(xd, yd, train=True, want_xhat=False)
+    e.backward(xd, yd, stage=0)
+    g_ref = e.grads.clone()
+    l_ref = out["losses"].clone()
+    e.grads.fill_(3.0)                      # stale contents must not leak into the result
+    l = e.grad_step(xd, yd)
+    torch.cuda.synchronize()
+    assert rel_err(e.grads.cpu().numpy(), g_ref.cpu().numpy()) < 1e-6   # atomics reorder sums: not bitwise
+    assert rel_err(l.cpu().numpy()[:5], l_ref.cpu().numpy()[:5]) < 1e-6
+    # and a standalone backward afterwards still clears the buffer itself
+    e.grads.fill_(5.0)
+    e.forward(xd, yd, train=True, want_xhat=False)
+    e.backward(xd, yd, stage=0)
+    assert rel_err(e.grads.cpu().numpy(), g_ref.cpu().numpy()) < 1e-6
+
+
 @pytest.mark.parametrize("stage", [1, 2])
 def test_staged_losses(stage):
     """train_beta_vae's stage 1 (gen+reg) and stage 2 (disc+reg) gradients (mfm_mosi.py:278-281)."""
