@@ -38,6 +38,16 @@ class SeqDesc(C.Structure):
                 ("h", C.c_int32), ("is_dec", C.c_int32), ("dc_ext", C.c_void_p)]
 
 
+class MemDesc(C.Structure):
+    _fields_ = [("a1", C.c_void_p), ("a2", C.c_void_p), ("chat", C.c_void_p),
+                ("w1m", C.c_void_p), ("w2m", C.c_void_p), ("w1b", C.c_void_p), ("b1b", C.c_void_p),
+                ("w2b", C.c_void_p), ("b2b", C.c_void_p),
+                ("gam1", C.c_void_p), ("gam2", C.c_void_p), ("mems", C.c_void_p), ("mem_out", C.c_void_p),
+                ("dmem_out", C.c_void_p), ("du1", C.c_void_p), ("du2", C.c_void_p), ("dchat", C.c_void_p),
+                ("T", C.c_int32), ("B", C.c_int32), ("M", C.c_int32), ("H1", C.c_int32), ("H2", C.c_int32),
+                ("train", C.c_int32), ("p1", C.c_float), ("p2", C.c_float), ("seed", C.c_uint64)]
+
+
 class PlanConfig(C.Structure):
     _fields_ = [("d_l", C.c_int32), ("d_a", C.c_int32), ("d_v", C.c_int32),
                 ("zl", C.c_int32), ("za", C.c_int32), ("zv", C.c_int32), ("zy", C.c_int32),
@@ -57,6 +67,8 @@ _SIGS = {
     "mfm_gemm_grouped_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.c_void_p]),
     "mfm_lstm_seq_fwd": (C.c_int, [C.POINTER(SeqDesc), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mfm_lstm_seq_bwd": (C.c_int, [C.POINTER(SeqDesc), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mfm_mfn_mem_fwd": (C.c_int, [C.POINTER(MemDesc), C.c_void_p]),
+    "mfm_mfn_mem_bwd": (C.c_int, [C.POINTER(MemDesc), C.c_void_p]),
     "mfm_mse_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_float,
                                   C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mfm_adam_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,

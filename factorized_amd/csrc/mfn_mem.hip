@@ -1,0 +1,308 @@
+// Memory Fusion Network: the sequential part of MFN.forward (reference mfm_model.py:177-181) as one
+// persistent kernel per direction.
+//
+//   both   = [attended_t , mem]                                   (:177)
+//   gamma1 = sigmoid(gamma1_fc2(drop(relu(gamma1_fc1(both)))))     (:178)
+//   gamma2 = sigmoid(gamma2_fc2(drop(relu(gamma2_fc1(both)))))     (:179)
+//   mem    = gamma1 * mem + gamma2 * cHat_t                         (:180)
+//
+// Everything else in the MFN time loop is independent of `mem` (the three LSTMs, the attention and
+// cHat depend only on the cell states) and is evaluated for all T at once by the sequence kernels and
+// grouped GEMMs; gamma*_fc1 is split by columns, W = [W_att | W_mem], and its attended part (with the
+// bias) also arrives precomputed for all t.  What is left is a chain of T tiny steps
+//   u_n = relu(att_n[t] + W_mem,n mem) ; gamma_n = sigmoid(W_fc2,n drop(u_n) + b_n) ; mem update
+// which the reference runs as ~25 launches per step.  Here ONE workgroup owns one batch row for all T
+// steps (B workgroups: the same latency regime as the small-tile LSTM kernels), all four weight
+// matrices stay in VGPRs (canonical 4 x 8192 floats over 512 threads = 64 registers), mem / u /
+// d-vectors are exchanged through LDS, partial dot products are all-reduced with DPP, two LDS-only
+// barriers per step.  The per-step global operands (att, cHat, saved activations) are prefetched one
+// step ahead with unconditional loads.
+//
+// Backward (BPTT) mirrors it with the transposed weights in registers:
+//   dz_n = dmem * {mem_{t-1}, cHat_t} * gamma_n (1 - gamma_n) ; da_n = W_fc2,n^T dz_n ;
+//   du_n = da_n * relu'/dropout ; dmem = dmem * gamma1 + W_mem,1^T du_1 + W_mem,2^T du_2
+// and leaves dz_n, du_n, dcHat for all t; the weight gradients are sums over (t, b) of outer products of
+// saved tensors and are formed afterwards by the grouped GEMM (host side: mfm_model.py::_MemFn).
+#include <stdlib.h>
+
+#include "internal.h"
+
+namespace mfm {
+
+namespace {
+
+constexpr int MEM_MAXW = 32;      // weights per thread and matrix
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_m(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+// all-reduce over groups of Q adjacent lanes, Q in {1,2,4,8,16}
+__device__ __forceinline__ float group_sum(float v, int Q) {
+  if (Q >= 2) v += dpp_m<0xB1>(v);      // quad_perm [1,0,3,2]
+  if (Q >= 4) v += dpp_m<0x4E>(v);      // quad_perm [2,3,0,1]
+  if (Q >= 8) v += dpp_m<0x141>(v);     // row_half_mirror
+  if (Q >= 16) v += dpp_m<0x140>(v);    // row_mirror
+  return v;
+}
+
+struct MemDev {
+  MfmMemDesc d;
+  int QA, KA, QB, KB1, KB2;       // lanes per output / weights per lane of the two matvec shapes
+};
+
+// ------------------------------------------------------------------------------------- forward
+__global__ __launch_bounds__(1024) void mfn_mem_fwd_kernel(const MemDev P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const MfmMemDesc& d = P.d;
+  const int T = d.T, B = d.B, M = d.M, H1 = d.H1, H2 = d.H2;
+  const int QA = P.QA, KA = P.KA, QB = P.QB;
+  float* memb = lds;                 // [2][M]
+  float* ab = lds + 2 * M;           // [H1 + H2] activations of the step
+  const int row = blockIdx.x;
+  const int tid = threadIdx.x;
+
+  // ---- phase-A role: (net, j, q): u_net[j] = sum_k Wm_net[j][k] mem[k], k = q + QA i
+  const int nA = (H1 + H2) * QA;
+  const bool actA = tid < nA;
+  const int ja = min(tid, nA - 1) / QA, qa = tid % QA;
+  const int netA = ja >= H1;
+  const int jn = netA ? ja - H1 : ja;
+  const float* wm = netA ? d.w2m : d.w1m;
+  float wA[MEM_MAXW];
+#pragma unroll
+  for (int i = 0; i < MEM_MAXW; ++i) {
+    const int k = qa + QA * i;
+    wA[i] = (actA && i < KA && k < M) ? wm[(int64_t)jn * M + min(k, M - 1)] : 0.0f;
+  }
+  float* abuf = netA ? d.a2 : d.a1;
+  const int Hn = netA ? H2 : H1;
+  const float pA = netA ? d.p2 : d.p1;
+  const float keepA = (pA < 1.0f) ? 1.0f / (1.0f - pA) : 0.0f;
+  // ---- phase-B role: (m, q): z_n[m] = sum_k Wb_n[m][k] a_n[k], both nets
+  const int nB = M * QB;
+  const bool actB = tid < nB;
+  const int mb = min(tid, nB - 1) / QB, qb = tid % QB;
+  float wB1[MEM_MAXW], wB2[MEM_MAXW];
+#pragma unroll
+  for (int i = 0; i < MEM_MAXW; ++i) {
+    const int k = qb + QB * i;
+    wB1[i] = (actB && i < P.KB1 && k < H1) ? d.w1b[(int64_t)mb * H1 + min(k, H1 - 1)] : 0.0f;
+    wB2[i] = (actB && i < P.KB2 && k < H2) ? d.w2b[(int64_t)mb * H2 + min(k, H2 - 1)] : 0.0f;
+  }
+  const float bb1 = d.b1b[mb], bb2 = d.b2b[mb];
+
+  if (tid < 2 * M) memb[tid] = 0.0f;
+  float memr = 0.0f;                              // mem[mb], carried by lane q == 0 of the phase-B group
+  const int64_t arow = ((int64_t)row) * Hn + jn;  // + t * B * Hn
+  const int64_t mrow = ((int64_t)row) * M + mb;   // + t * B * M
+  float att_n = abuf[arow];
+  float ch_n = d.chat[mrow];
+  lds_barrier();
+
+  int cur = 0;
+  for (int t = 0; t < T; ++t) {
+    const float att = att_n, ch = ch_n;
+    const int tn = min(t + 1, T - 1);
+    att_n = abuf[(int64_t)tn * B * Hn + arow];     // unconditional prefetch (clamped at the tail)
+    ch_n = d.chat[(int64_t)tn * B * M + mrow];
+    // ---- phase A
+    {
+      const float* mp = memb + cur * M + qa;
+      float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+      for (int i = 0; i < MEM_MAXW; i += 2) {
+        s0 = fmaf(wA[i], mp[min(QA * i, M - 1 - qa)], s0);
+        s1 = fmaf(wA[i + 1], mp[min(QA * (i + 1), M - 1 - qa)], s1);
+      }
+      float u = group_sum(s0 + s1, QA) + att;
+      u = fmaxf(u, 0.0f);
+      if (d.train && pA > 0.0f) {
+        const uint64_t idx = ((uint64_t)(netA + 1) << 56) + ((uint64_t)t << 40) + (uint64_t)row * (uint64_t)Hn + (uint64_t)jn;
+        u = (rng_uniform(d.seed, idx) < pA) ? 0.0f : u * keepA;
+      }
+      if (actA && qa == 0) {
+        ab[ja] = u;
+        abuf[(int64_t)t * B * Hn + arow] = u;       // saved for the backward, in place over the input
+      }
+    }
+    lds_barrier();
+    // ---- phase B + memory update
+    {
+      const float* a1p = ab + qb;
+      const float* a2p = ab + H1 + qb;
+      float z1 = 0.0f, z2 = 0.0f;
+#pragma unroll
+      for (int i = 0; i < MEM_MAXW; ++i) {
+        z1 = fmaf(wB1[i], a1p[min(QB * i, H1 - 1 - qb)], z1);
+        z2 = fmaf(wB2[i], a2p[min(QB * i, H2 - 1 - qb)], z2);
+      }
+      z1 = group_sum(z1, QB) + bb1;
+      z2 = group_sum(z2, QB) + bb2;
+      const float g1 = act_sigmoid(z1), g2 = act_sigmoid(z2);
+      memr = g1 * memr + g2 * ch;
+      if (actB && qb == 0) {
+        memb[(cur ^ 1) * M + mb] = memr;
+        const int64_t o = (int64_t)t * B * M + mrow;
+        d.gam1[o] = g1; d.gam2[o] = g2; d.mems[o] = memr;
+      }
+    }
+    lds_barrier();
+    cur ^= 1;
+  }
+  if (actB && qb == 0 && d.mem_out) d.mem_out[mrow] = memr;
+}
+
+// ------------------------------------------------------------------------------------- backward
+__global__ __launch_bounds__(1024) void mfn_mem_bwd_kernel(const MemDev P) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const MfmMemDesc& d = P.d;
+  const int T = d.T, B = d.B, M = d.M, H1 = d.H1, H2 = d.H2;
+  const int QA = P.QA, KA = P.KA, QB = P.QB;
+  float* dzb = lds;                  // [2][M]  dz of net 1 | net 2
+  float* dub = lds + 2 * M;          // [H1 + H2]
+  const int row = blockIdx.x;
+  const int tid = threadIdx.x;
+
+  // ---- role A (transposed fc2): da_net[j] = sum_m Wb_net[m][j] dz_net[m], m = q + QA i
+  const int nA = (H1 + H2) * QA;
+  const bool actA = tid < nA;
+  const int ja = min(tid, nA - 1) / QA, qa = tid % QA;
+  const int netA = ja >= H1;
+  const int jn = netA ? ja - H1 : ja;
+  const int Hn = netA ? H2 : H1;
+  const float* wb = netA ? d.w2b : d.w1b;
+  float wA[MEM_MAXW];
+#pragma unroll
+  for (int i = 0; i < MEM_MAXW; ++i) {
+    const int m = qa + QA * i;
+    wA[i] = (actA && i < KA && m < M) ? wb[(int64_t)min(m, M - 1) * Hn + jn] : 0.0f;
+  }
+  const float* abuf = netA ? d.a2 : d.a1;
+  float* dubuf = netA ? d.du2 : d.du1;
+  const float pA = netA ? d.p2 : d.p1;
+  const float keepA = (d.train && pA > 0.0f) ? ((pA < 1.0f) ? 1.0f / (1.0f - pA) : 0.0f) : 1.0f;
+  // ---- role B (transposed memory columns): dmem[m] += sum_j Wm_n[j][m] du_n[j], both nets
+  const int nB = M * QB;
+  const bool actB = tid < nB;
+  const int mb = min(tid, nB - 1) / QB, qb = tid % QB;
+  float wB1[MEM_MAXW], wB2[MEM_MAXW];
+#pragma unroll
+  for (int i = 0; i < MEM_MAXW; ++i) {
+    const int j = qb + QB * i;
+    wB1[i] = (actB && i < P.KB1 && j < H1) ? d.w1m[(int64_t)min(j, H1 - 1) * M + mb] : 0.0f;
+    wB2[i] = (actB && i < P.KB2 && j < H2) ? d.w2m[(int64_t)min(j, H2 - 1) * M + mb] : 0.0f;
+  }
+  const int64_t arow = ((int64_t)row) * Hn + jn;
+  const int64_t mrow = ((int64_t)row) * M + mb;
+  float dmem = d.dmem_out ? d.dmem_out[mrow] : 0.0f;     // dL/d mem_T
+  // saved operands of step T-1
+  int64_t o = (int64_t)(T - 1) * B * M + mrow;
+  float g1_n = d.gam1[o], g2_n = d.gam2[o], ch_n = d.chat[o];
+  float mp_n = (T > 1) ? d.mems[o - (int64_t)B * M] : 0.0f;
+  float a_n = abuf[(int64_t)(T - 1) * B * Hn + arow];
+
+  for (int t = T - 1; t >= 0; --t) {
+    const float g1 = g1_n, g2 = g2_n, ch = ch_n, mprev = mp_n, av = a_n;
+    {   // unconditional prefetch of step t-1 (clamped at t = 0; mem_{-1} = 0 by the multiply)
+      const int tp = max(t - 1, 0);
+      const int64_t op = (int64_t)tp * B * M + mrow;
+      g1_n = d.gam1[op]; g2_n = d.gam2[op]; ch_n = d.chat[op];
+      mp_n = d.mems[(int64_t)max(tp - 1, 0) * B * M + mrow] * (tp > 0 ? 1.0f : 0.0f);
+      a_n = abuf[(int64_t)tp * B * Hn + arow];
+    }
+    // ---- phase 1: gate gradients
+    const float dz1 = dmem * mprev * g1 * (1.0f - g1);
+    const float dz2 = dmem * ch * g2 * (1.0f - g2);
+    if (actB && qb == 0) {
+      dzb[mb] = dz1; dzb[M + mb] = dz2;
+      const int64_t oo = (int64_t)t * B * M + mrow;
+      d.gam1[oo] = dz1; d.gam2[oo] = dz2;          // in place: the weight-gradient GEMMs read dz from here
+      d.dchat[oo] = dmem * g2;
+    }
+    const float dmem_direct = dmem * g1;
+    lds_barrier();
+    // ---- phase 2: through gamma*_fc2 and the relu / dropout
+    {
+      const float* zp = dzb + netA * M + qa;
+      float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+      for (int i = 0; i < MEM_MAXW; i += 2) {
+        s0 = fmaf(wA[i], zp[min(QA * i, M - 1 - qa)], s0);
+        s1 = fmaf(wA[i + 1], zp[min(QA * (i + 1), M - 1 - qa)], s1);
+      }
+      const float da = group_sum(s0 + s1, QA);
+      const float du = (av > 0.0f) ? da * keepA : 0.0f;
+      if (actA && qa == 0) {
+        dub[ja] = du;
+        dubuf[(int64_t)t * B * Hn + arow] = du;
+      }
+    }
+    lds_barrier();
+    // ---- phase 3: into the memory
+    {
+      const float* u1p = dub + qb;
+      const float* u2p = dub + H1 + qb;
+      float s = 0.0f, s2 = 0.0f;
+#pragma unroll
+      for (int i = 0; i < MEM_MAXW; ++i) {
+        s = fmaf(wB1[i], u1p[min(QB * i, H1 - 1 - qb)], s);
+        s2 = fmaf(wB2[i], u2p[min(QB * i, H2 - 1 - qb)], s2);
+      }
+      dmem = dmem_direct + group_sum(s + s2, QB);
+    }
+  }
+}
+
+int pow2_ge(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+int mem_setup(const MfmMemDesc* desc, MemDev& P, int& threads, size_t& lds) {
+  const MfmMemDesc& d = *desc;
+  MFM_REQUIRE(d.T >= 1 && d.B >= 1 && d.M >= 1 && d.H1 >= 1 && d.H2 >= 1, "mfn_mem: bad dims T=%d B=%d M=%d H=%d/%d", d.T, d.B, d.M, d.H1, d.H2);
+  MFM_REQUIRE(d.a1 && d.a2 && d.chat && d.w1m && d.w2m && d.w1b && d.b1b && d.w2b && d.b2b && d.gam1 && d.gam2 && d.mems,
+              "mfn_mem: null operand");
+  P.d = d;
+  P.QA = pow2_ge(cdiv(d.M, MEM_MAXW));
+  P.KA = cdiv(d.M, P.QA);
+  const int hmax = d.H1 > d.H2 ? d.H1 : d.H2;
+  P.QB = pow2_ge(cdiv(hmax, MEM_MAXW));
+  P.KB1 = cdiv(d.H1, P.QB);
+  P.KB2 = cdiv(d.H2, P.QB);
+  const int nA = (d.H1 + d.H2) * P.QA, nB = d.M * P.QB;
+  if (P.QA > 16 || P.QB > 16 || nA > 1024 || nB > 1024) {
+    set_error("mfn_mem: memory %d / gate hidden %d,%d do not fit the register-resident recurrence", d.M, d.H1, d.H2);
+    return MFM_ERR_UNSUPPORTED;
+  }
+  threads = round_up(nA > nB ? nA : nB, 64);
+  lds = (size_t)(2 * d.M + d.H1 + d.H2) * sizeof(float);
+  return MFM_OK;
+}
+
+}  // namespace
+
+}  // namespace mfm
+
+using namespace mfm;
+
+extern "C" int mfm_mfn_mem_fwd(const MfmMemDesc* desc, void* stream) {
+  if (!desc) { set_error("mfm_mfn_mem_fwd: null descriptor"); return MFM_ERR_ARG; }
+  MemDev P;
+  int threads = 0; size_t lds = 0;
+  int rc = mem_setup(desc, P, threads, lds);
+  if (rc != MFM_OK) return rc;
+  hipLaunchKernelGGL(mfn_mem_fwd_kernel, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
+  MFM_LAUNCH_CHECK("mfn_mem_fwd_kernel");
+  return MFM_OK;
+}
+
+extern "C" int mfm_mfn_mem_bwd(const MfmMemDesc* desc, void* stream) {
+  if (!desc) { set_error("mfm_mfn_mem_bwd: null descriptor"); return MFM_ERR_ARG; }
+  MemDev P;
+  int threads = 0; size_t lds = 0;
+  int rc = mem_setup(desc, P, threads, lds);
+  if (rc != MFM_OK) return rc;
+  MFM_REQUIRE(desc->du1 && desc->du2 && desc->dchat, "mfm_mfn_mem_bwd: null gradient output");
+  hipLaunchKernelGGL(mfn_mem_bwd_kernel, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
+  MFM_LAUNCH_CHECK("mfn_mem_bwd_kernel");
+  return MFM_OK;
+}

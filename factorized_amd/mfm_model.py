@@ -23,6 +23,8 @@ tensors or a missing library raise.  `.cuda()` calls inside the reference's forw
 The fastest way to train is not this autograd path but `factorized_amd.engine.MFMEngine.train_step`
 (one C call per step); `MFM_KL_EF.engine` exposes it on the same parameter storage.
 """
+import ctypes as C
+import os
 from collections import OrderedDict
 
 import torch
@@ -374,6 +376,91 @@ class _LinearFn(torch.autograd.Function):
         return dx.reshape(ctx.shp), dw, db
 
 
+class _MemFn(torch.autograd.Function):
+    """MFN memory recurrence (reference mfm_model.py:177-181) on mfm_mfn_mem_fwd/bwd: one launch per
+    direction for all T steps; weight gradients as grouped GEMMs over the saved tensors."""
+
+    _calls = 0
+
+    @staticmethod
+    def supported(M, H1, H2):
+        def p2(x):
+            p = 1
+            while p < x:
+                p <<= 1
+            return p
+        qa, qb = p2(-(-M // 32)), p2(-(-max(H1, H2) // 32))
+        return qa <= 16 and qb <= 16 and (H1 + H2) * qa <= 1024 and M * qb <= 1024
+
+    @staticmethod
+    def _desc(T, B, M, H1, H2, a1, a2, chat, w1m, w2m, w1b, b1b, w2b, b2b, gam1, gam2, mems, p1, p2, train, seed,
+              mem_out=None, dmem=None, du1=None, du2=None, dchat=None):
+        d = _lib.MemDesc()
+        d.a1, d.a2, d.chat = a1.data_ptr(), a2.data_ptr(), chat.data_ptr()
+        d.w1m, d.w2m = w1m.data_ptr(), w2m.data_ptr()
+        d.w1b, d.b1b, d.w2b, d.b2b = w1b.data_ptr(), b1b.data_ptr(), w2b.data_ptr(), b2b.data_ptr()
+        d.gam1, d.gam2, d.mems = gam1.data_ptr(), gam2.data_ptr(), mems.data_ptr()
+        d.mem_out = mem_out.data_ptr() if mem_out is not None else None
+        d.dmem_out = dmem.data_ptr() if dmem is not None else None
+        d.du1 = du1.data_ptr() if du1 is not None else None
+        d.du2 = du2.data_ptr() if du2 is not None else None
+        d.dchat = dchat.data_ptr() if dchat is not None else None
+        d.T, d.B, d.M, d.H1, d.H2 = T, B, M, H1, H2
+        d.train, d.p1, d.p2, d.seed = int(train), float(p1), float(p2), int(seed)
+        return d
+
+    @staticmethod
+    def forward(ctx, g1_att, g2_att, chat, w1m, w2m, w1b, b1b, w2b, b2b, p1, p2, train):
+        T, B, H1 = g1_att.shape
+        H2, M = g2_att.shape[2], chat.shape[2]
+        dev = chat.device
+        f = lambda t: t.detach().contiguous().float()
+        a1, a2 = f(g1_att).clone(), f(g2_att).clone()         # overwritten with the activations
+        chat, w1m, w2m, w1b, b1b, w2b, b2b = map(f, (chat, w1m, w2m, w1b, b1b, w2b, b2b))
+        gam1, gam2, mems = (torch.empty(T, B, M, device=dev) for _ in range(3))
+        mem_out = torch.empty(B, M, device=dev)
+        _MemFn._calls += 1
+        seed = (torch.initial_seed() * 0x9E3779B1 + _MemFn._calls) & 0xFFFFFFFFFFFF
+        d = _MemFn._desc(T, B, M, H1, H2, a1, a2, chat, w1m, w2m, w1b, b1b, w2b, b2b, gam1, gam2, mems, p1, p2, train,
+                         seed, mem_out=mem_out)
+        _lib.check(_lib.lib().mfm_mfn_mem_fwd(C.byref(d), E._stream()), "mfm_mfn_mem_fwd")
+        ctx.save_for_backward(a1, a2, chat, w1m, w2m, w1b, b1b, w2b, b2b, gam1, gam2, mems)
+        ctx.cfg = (T, B, M, H1, H2, p1, p2, train, seed)
+        return mem_out
+
+    @staticmethod
+    def backward(ctx, dmem):
+        a1, a2, chat, w1m, w2m, w1b, b1b, w2b, b2b, gam1, gam2, mems = ctx.saved_tensors
+        T, B, M, H1, H2, p1, p2, train, seed = ctx.cfg
+        dev = chat.device
+        dz1, dz2 = gam1.clone(), gam2.clone()                 # turned into pre-sigmoid gradients in place
+        du1 = torch.empty(T, B, H1, device=dev)
+        du2 = torch.empty(T, B, H2, device=dev)
+        dchat = torch.empty(T, B, M, device=dev)
+        dm = dmem.contiguous().float()
+        d = _MemFn._desc(T, B, M, H1, H2, a1, a2, chat, w1m, w2m, w1b, b1b, w2b, b2b, dz1, dz2, mems, p1, p2, train, seed,
+                         dmem=dm, du1=du1, du2=du2, dchat=dchat)
+        _lib.check(_lib.lib().mfm_mfn_mem_bwd(C.byref(d), E._stream()), "mfm_mfn_mem_bwd")
+        TB = T * B
+        dw1b, dw2b = torch.zeros_like(w1b), torch.zeros_like(w2b)
+        db1b, db2b = torch.zeros_like(b1b), torch.zeros_like(b2b)
+        dw1m, dw2m = torch.zeros_like(w1m), torch.zeros_like(w2m)
+        ones = torch.ones(TB, device=dev)
+        g = [
+            # gamma_n_fc2: dW[m, j] = sum_r dz[r, m] a[r, j] ; db[m] = sum_r dz[r, m]
+            E.make_gemm(dz1, a1, dw1b, M, H1, TB, a_sm=1, a_sk=M, b_sk=H1, b_sn=1, ldc=H1, accumulate=1, split_k=0),
+            E.make_gemm(dz2, a2, dw2b, M, H2, TB, a_sm=1, a_sk=M, b_sk=H2, b_sn=1, ldc=H2, accumulate=1, split_k=0),
+            E.make_gemm(dz1, ones, db1b, M, 1, TB, a_sm=1, a_sk=M, b_sk=1, b_sn=1, ldc=1, accumulate=1, split_k=0),
+            E.make_gemm(dz2, ones, db2b, M, 1, TB, a_sm=1, a_sk=M, b_sk=1, b_sn=1, ldc=1, accumulate=1, split_k=0),
+        ]
+        if T > 1:
+            # memory columns of gamma_n_fc1: dW[j, m] = sum_{t>=1,b} du[t,b,j] mem_{t-1}[b,m]
+            g += [E.make_gemm(du1[1:], mems, dw1m, H1, M, TB - B, a_sm=1, a_sk=H1, b_sk=M, b_sn=1, ldc=M, accumulate=1, split_k=0),
+                  E.make_gemm(du2[1:], mems, dw2m, H2, M, TB - B, a_sm=1, a_sk=H2, b_sk=M, b_sn=1, ldc=M, accumulate=1, split_k=0)]
+        E.gemm_grouped(g)
+        return du1, du2, dchat, dw1m, dw2m, dw1b, db1b, dw2b, db2b, None, None, None
+
+
 class HipLinear(nn.Linear):
     """nn.Linear (same parameters / state_dict keys) whose matmuls run on the HIP GEMM."""
 
@@ -437,8 +524,8 @@ class MFN(nn.Module):
     HIP recurrences first (one launch); the attention and the c-hat proposal depend only on the cell
     states, so they are evaluated for ALL timesteps at once as [T*B, .] GEMMs; only the two gamma gates
     and the memory update are sequential in t (20 tiny steps).  Matmuls run on the HIP GEMM
-    (`HipLinear`); the elementwise glue (softmax/relu/tanh/sigmoid/dropout/concat) uses torch device ops
-    -- a fused memory-recurrence kernel is the next step."""
+    (`HipLinear`) and the sequential part is ONE persistent HIP kernel per direction (`_MemFn`,
+    csrc/mfn_mem.hip); the batched elementwise glue (softmax/relu/tanh/concat) uses torch device ops."""
 
     def __init__(self, config, NN1Config, NN2Config, gamma1Config, gamma2Config, outConfig):
         super(MFN, self).__init__()
@@ -495,15 +582,23 @@ class MFN(nn.Module):
         g2_att = _LinearFn.apply(attended, self.gamma2_fc1.weight[:, :na].contiguous(), self.gamma2_fc1.bias)
         w1m = self.gamma1_fc1.weight[:, na:].contiguous()
         w2m = self.gamma2_fc1.weight[:, na:].contiguous()
-        zb1 = torch.zeros(w1m.shape[0], device=x.device)
-        zb2 = torch.zeros(w2m.shape[0], device=x.device)
-        mem = torch.zeros(B, self.mem_dim, device=x.device)
-        for t in range(T):
-            a1 = torch.relu(g1_att[t] + _LinearFn.apply(mem, w1m, zb1))
-            a2 = torch.relu(g2_att[t] + _LinearFn.apply(mem, w2m, zb2))
-            gamma1 = torch.sigmoid(self.gamma1_fc2(self.gamma1_dropout(a1)))
-            gamma2 = torch.sigmoid(self.gamma2_fc2(self.gamma2_dropout(a2)))
-            mem = gamma1 * mem + gamma2 * cHat[t]
+        H1, H2 = w1m.shape[0], w2m.shape[0]
+        if _MemFn.supported(self.mem_dim, H1, H2) and not os.environ.get("MFM_MFN_LOOP"):   # env: A/B timing only
+            # the sequential part (:177-181) as one persistent HIP kernel per direction
+            mem = _MemFn.apply(g1_att, g2_att, cHat, w1m, w2m, self.gamma1_fc2.weight, self.gamma1_fc2.bias,
+                               self.gamma2_fc2.weight, self.gamma2_fc2.bias,
+                               self.gamma1_dropout.p, self.gamma2_dropout.p, self.training)
+        else:
+            # sizes beyond the register-resident kernel: same math step by step on the HIP GEMM
+            zb1 = torch.zeros(H1, device=x.device)
+            zb2 = torch.zeros(H2, device=x.device)
+            mem = torch.zeros(B, self.mem_dim, device=x.device)
+            for t in range(T):
+                a1 = torch.relu(g1_att[t] + _LinearFn.apply(mem, w1m, zb1))
+                a2 = torch.relu(g2_att[t] + _LinearFn.apply(mem, w2m, zb2))
+                gamma1 = torch.sigmoid(self.gamma1_fc2(self.gamma1_dropout(a1)))
+                gamma2 = torch.sigmoid(self.gamma2_fc2(self.gamma2_dropout(a2)))
+                mem = gamma1 * mem + gamma2 * cHat[t]
         return torch.cat([hl, ha, hv, mem], dim=1)
 
 

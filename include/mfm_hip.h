@@ -110,6 +110,36 @@ int mfm_mse_fwd_bwd(const float* xhat, const float* x, int64_t ldx, int64_t rows
                     float inv_count, float grad_scale, float* dxhat, float* loss_slot, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Memory Fusion Network: the memory recurrence of MFN.forward (reference mfm_model.py:177-181),
+ *   gamma_n = sigmoid(gamma_n_fc2(drop(relu(gamma_n_fc1([attended_t, mem])))))  n = 1,2
+ *   mem     = gamma1 * mem + gamma2 * cHat_t
+ * for all T steps in one launch (one workgroup per batch row).  gamma_n_fc1 is split by columns:
+ * a1/a2 hold its attended part INCLUDING the bias for all t (a grouped GEMM over [T*B, .]), w1m/w2m
+ * are its memory columns [H_n, M] (row-major, contiguous).  Forward overwrites a1/a2 with the
+ * post-relu/dropout activations and saves gamma_n and mem_t; backward turns gam1/gam2 into the
+ * pre-sigmoid gradients dz_n in place and writes du_n (gradient wrt a_n's pre-activation, which is also
+ * the gradient wrt the precomputed attended part) and dchat.  Weight gradients are outer-product sums
+ * of these tensors (grouped GEMMs, factorized_amd/mfm_model.py).
+ * Returns MFM_ERR_UNSUPPORTED when M / H_n do not fit the register-resident layout. */
+typedef struct MfmMemDesc {
+  float* a1; float* a2;                 /* [T,B,H1], [T,B,H2] */
+  const float* chat;                    /* [T,B,M] */
+  const float* w1m; const float* w2m;   /* [H1,M], [H2,M] */
+  const float* w1b; const float* b1b;   /* gamma1_fc2: [M,H1], [M] */
+  const float* w2b; const float* b2b;   /* gamma2_fc2: [M,H2], [M] */
+  float* gam1; float* gam2; float* mems;   /* [T,B,M] each */
+  float* mem_out;                       /* [B,M] last memory (forward) */
+  const float* dmem_out;                /* [B,M] dL/d mem_T (backward) */
+  float* du1; float* du2; float* dchat; /* backward outputs [T,B,H1], [T,B,H2], [T,B,M] */
+  int32_t T, B, M, H1, H2, train;
+  float p1, p2;                         /* dropout probabilities of gamma1/gamma2 */
+  uint64_t seed;
+} MfmMemDesc;
+
+int mfm_mfn_mem_fwd(const MfmMemDesc* desc /*host*/, void* stream);
+int mfm_mfn_mem_bwd(const MfmMemDesc* desc /*host*/, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused Adam on one flat parameter buffer (torch.optim.Adam defaults semantics,
  * mfm_mosi.py:403,441): m,v,p updated in place; g is multiplied by grad_scale first (DP
  * averaging).  `step` is the 1-based step count used for bias correction.

@@ -290,3 +290,54 @@ def test_adam_matches_torch(eng):
                                             1e-3, 0.9, 0.999, 1e-8, 1.0,
                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     assert rel_err(p.cpu().numpy(), p_ref.detach().numpy()) < 1e-6
+
+
+# ---------------------------------------------------------------------------------- MFN memory recurrence
+@pytest.mark.parametrize("T,B,M,H1,H2", [(20, 32, 64, 128, 128), (7, 5, 24, 40, 72), (1, 3, 64, 128, 128), (9, 19, 100, 100, 60)])
+def test_mfn_memory_recurrence(eng, T, B, M, H1, H2):
+    """mfm_mfn_mem_fwd/bwd against the step-by-step statement of reference mfm_model.py:177-181 in torch
+    (float64 on the CPU): last memory and every input / weight gradient."""
+    from factorized_amd.mfm_model import _MemFn
+    assert _MemFn.supported(M, H1, H2)
+    rs = np.random.RandomState(5)
+    f = lambda *shape, s=1.0: (rs.normal(size=shape) * s).astype(np.float32)
+    arrs = dict(g1=f(T, B, H1), g2=f(T, B, H2), ch=np.tanh(f(T, B, M)),
+                w1m=f(H1, M, s=0.2), w2m=f(H2, M, s=0.2), w1b=f(M, H1, s=0.15), b1b=f(M, s=0.1),
+                w2b=f(M, H2, s=0.15), b2b=f(M, s=0.1))
+    dmem = f(B, M)
+    # reference
+    r = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in arrs.items()}
+    mem = torch.zeros(B, M, dtype=torch.float64)
+    for t in range(T):
+        a1 = torch.relu(r["g1"][t] + mem @ r["w1m"].T)
+        a2 = torch.relu(r["g2"][t] + mem @ r["w2m"].T)
+        gamma1 = torch.sigmoid(a1 @ r["w1b"].T + r["b1b"])
+        gamma2 = torch.sigmoid(a2 @ r["w2b"].T + r["b2b"])
+        mem = gamma1 * mem + gamma2 * r["ch"][t]
+    (mem * torch.tensor(dmem, dtype=torch.float64)).sum().backward()
+    # HIP
+    d = {k: torch.tensor(v, device="cuda", requires_grad=True) for k, v in arrs.items()}
+    out = _MemFn.apply(d["g1"], d["g2"], d["ch"], d["w1m"], d["w2m"], d["w1b"], d["b1b"], d["w2b"], d["b2b"], 0.0, 0.0, True)
+    (out * torch.tensor(dmem, device="cuda")).sum().backward()
+    torch.cuda.synchronize()
+    assert rel_err(out.detach().cpu().numpy(), mem.detach().numpy()) < TOL
+    for k in arrs:
+        assert rel_err(d[k].grad.cpu().numpy(), r[k].grad.numpy()) < TOL, k
+    # inputs are not modified (the kernel works on private copies)
+    assert np.array_equal(d["g1"].detach().cpu().numpy(), arrs["g1"])
+
+
+def test_mfn_memory_dropout_statistics(eng):
+    """Train-mode dropout inside the gamma nets: kept fraction ~ 1-p, scaled by 1/(1-p), and the backward
+    uses the same mask (a zeroed activation passes no gradient)."""
+    from factorized_amd.mfm_model import _MemFn
+    T, B, M, H = 6, 64, 64, 128
+    g = torch.full((T, B, H), 1.0, device="cuda", requires_grad=True)      # relu input > 0 everywhere
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    ch = torch.ones(T, B, M, device="cuda")
+    out = _MemFn.apply(g, g.detach().clone().requires_grad_(True), ch, z(H, M), z(H, M), torch.full((M, H), 0.01, device="cuda"),
+                       z(M), z(M, H), z(M), 0.5, 0.0, True)
+    out.sum().backward()
+    torch.cuda.synchronize()
+    kept = (g.grad[1:] != 0).float().mean().item()       # t = 0 passes no gradient to gamma1 (mem_{-1} = 0)
+    assert 0.45 < kept < 0.55
