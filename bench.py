@@ -47,11 +47,19 @@ def main():
     rank, local_rank, world = train.dp_env()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    # MFM_BENCH_ONE_DEVICE=1 (testing only): every rank uses cuda:0 and the collectives run on gloo, so the
+    # multi-process path can be exercised on a 1-GPU box; the number it prints is not a scaling result.
+    one_dev = os.environ.get("MFM_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg_fn = {"mosi": C.canonical_configs, "you": C.you_configs, "mosei": C.mosei_configs}[args.shape]
     cfgs = cfg_fn(dropout=True)
