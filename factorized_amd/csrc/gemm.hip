@@ -64,6 +64,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   }
 
   // ---- locate problem / tile (wave-uniform)
+  // Workgroups are dealt to the 8 XCDs round-robin by id, and each XCD has its own L2.  Tiles that share
+  // an operand panel (same m-tile across n, same n-tile across m / gates) are neighbours in the LOGICAL
+  // order, so inside every problem each XCD is given one contiguous run of logical tiles: a panel is then
+  // fetched from HBM once per XCD that needs it instead of once per tile (the LSTM weight-gradient launch
+  // read 37.7 MB for ~6 MB of operands before this, profiles/r01j), while every XCD still gets an equal
+  // share of every problem (a whole-launch remap left the XCDs with the long-K problems as stragglers).
   int pi = 0;
   const int bid = blockIdx.x;
 #pragma unroll 1
@@ -72,6 +78,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   const GemmProblem& P = g.p[pi];
   const MfmGemmDesc& d = P.d;
   int local = bid - P.block_begin;
+  {
+    constexpr int NX = 8;
+    const int nb = ((pi + 1 < g.count) ? g.p[pi + 1].block_begin : (int)gridDim.x) - P.block_begin;
+    const int x = local % NX, j = local / NX;
+    const int per = nb / NX, rem = nb % NX;
+    local = x * per + (x < rem ? x : rem) + j;
+  }
   const int tn = local % P.tiles_n; local /= P.tiles_n;
   const int tm = local % P.tiles_m; local /= P.tiles_m;
   const int z = local % d.batch;

@@ -20,9 +20,9 @@ def classify(name):
         return "enc_seq_fwd" if ("8, 2, 20, 30" in name) else "dec_seq_fwd"
     if "lstm_seq_small_kernel4<true" in name or "lstm_seq_bwd" in name or "lstm_seq_small_kernel<true" in name:
         return "enc_seq_bwd" if ("8, 2, 20, 30" in name) else "dec_seq_bwd"
-    if "latent_fwd_kernel" in name:
+    if "latent_fwd" in name:
         return "latent_fwd"
-    if "latent_bwd_kernel" in name:
+    if "latent_bwd" in name:
         return "latent_bwd"
     if "gemm_f32_kernel" in name:
         return "gemm"
