@@ -349,9 +349,27 @@ static bool use_small_path(int B) {
   return B <= 512;
 }
 
-static int seq_launch(const MfmSeqDesc* descs, int count, int T, int B, bool bwd, hipStream_t stream) {
-  MFM_REQUIRE(descs && count >= 1 && count <= MFM_MAX_SEQ, "lstm_seq: count %d out of range", count);
+static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bool bwd, hipStream_t stream) {
+  MFM_REQUIRE(descs_in && count_in >= 1 && count_in <= MFM_MAX_SEQ, "lstm_seq: count %d out of range", count_in);
   MFM_REQUIRE(T >= 1 && B >= 1, "lstm_seq: T=%d B=%d", T, B);
+  // LSTMs too wide for the weight-resident kernels take the step-by-step path (lstm_step.hip); the rest of
+  // the group still shares one launch
+  MfmSeqDesc descs[MFM_MAX_SEQ], wide[MFM_MAX_SEQ];
+  int count = 0, nwide = 0;
+  for (int i = 0; i < count_in; ++i) {
+    const MfmSeqDesc& s = descs_in[i];
+    MFM_REQUIRE(s.h >= 1, "lstm_seq[%d]: h=%d", i, s.h);
+    MFM_REQUIRE(s.gates && s.hs && s.cs && s.w_hh, "lstm_seq[%d]: null buffer", i);
+    if (s.is_dec) MFM_REQUIRE(s.w_ih && s.b_ih && s.b_hh && s.h_init, "lstm_seq[%d]: decoder needs w_ih/b/h_init", i);
+    if (bwd) MFM_REQUIRE(s.dh_ext, "lstm_seq_bwd[%d]: dh_ext is null", i);
+    const bool force = getenv("MFM_SEQ_STEPWISE") != nullptr;          // testing: every LSTM step by step
+    if (s.h > MFM_SEQ_MAX_RESIDENT_H || force) wide[nwide++] = s; else descs[count++] = s;
+  }
+  if (nwide) {
+    int rc = seq_stepwise(wide, nwide, T, B, bwd, stream);
+    if (rc != MFM_OK) return rc;
+  }
+  if (count == 0) return MFM_OK;
   SeqLaunch L;
   memset(&L, 0, sizeof(L));
   L.count = count; L.T = T; L.B = B;
@@ -360,14 +378,6 @@ static int seq_launch(const MfmSeqDesc* descs, int count, int T, int B, bool bwd
   size_t lds_bytes = 0;
   for (int i = 0; i < count; ++i) {
     const MfmSeqDesc& s = descs[i];
-    MFM_REQUIRE(s.h >= 1, "lstm_seq[%d]: h=%d", i, s.h);
-    if (s.h > 128) {
-      set_error("lstm_seq[%d]: hidden size %d > 128 not supported by the register-resident kernel yet", i, s.h);
-      return MFM_ERR_UNSUPPORTED;
-    }
-    MFM_REQUIRE(s.gates && s.hs && s.cs && s.w_hh, "lstm_seq[%d]: null buffer", i);
-    if (s.is_dec) MFM_REQUIRE(s.w_ih && s.b_ih && s.b_hh && s.h_init, "lstm_seq[%d]: decoder needs w_ih/b/h_init", i);
-    if (bwd) MFM_REQUIRE(s.dh_ext, "lstm_seq_bwd[%d]: dh_ext is null", i);
     SeqDev& d = L.d[i];
     d.gates = s.gates; d.hs = s.hs; d.cs = s.cs;
     d.w_hh = s.w_hh; d.w_ih = s.w_ih; d.b_ih = s.b_ih; d.b_hh = s.b_hh;

@@ -598,12 +598,6 @@ extern "C" int mfm_plan_create(const MfmPlanConfig* cfg, const int64_t* param_of
               "plan: latent sizes must be positive");
   MFM_REQUIRE(c.output_dim >= 1 && c.output_dim <= 64, "plan: output_dim %d", c.output_dim);
   MFM_REQUIRE(c.loss_kind == 0 || c.loss_kind == 1, "plan: loss_kind %d", c.loss_kind);
-  const int hs[7] = {c.zl, c.za, c.zv, c.zl + c.za + c.zv, c.fy + c.fl, c.fy + c.fa, c.fy + c.fv};
-  for (int i = 0; i < 7; ++i)
-    if (hs[i] > 128) {
-      set_error("plan: LSTM hidden size %d > 128 is not supported by the register-resident recurrence yet", hs[i]);
-      return MFM_ERR_UNSUPPORTED;
-    }
   MfmPlan* P = new (std::nothrow) MfmPlan();
   if (!P) { set_error("plan: out of host memory"); return MFM_ERR_ARG; }
   P->cfg = c;

@@ -128,10 +128,15 @@ SEQ_SHAPES = [(8, 5, 1, 3), (8, 5, 32, 20), (24, 7, 33, 4), (32, 300, 32, 20), (
               (104, 9, 16, 5), (120, 325, 32, 20), (20, 6, 5, 1), (128, 4, 3, 2), (36, 10, 40, 3)]
 
 
-@pytest.fixture(params=["mfma", "small", "small:1", "small:2", "small:4"])
+@pytest.fixture(params=["mfma", "small", "small:1", "small:2", "small:4", "stepwise"])
 def seq_path(request, monkeypatch):
     """Both recurrent kernel families: MFMA (16 rows/workgroup) and VALU small-tile (4 rows)."""
     path, _, rows = request.param.partition(":")
+    if path == "stepwise":                            # recurrent GEMM + cell kernel per step (h > 128 path)
+        monkeypatch.setenv("MFM_SEQ_STEPWISE", "1")
+        path = "small"
+    else:
+        monkeypatch.delenv("MFM_SEQ_STEPWISE", raising=False)
     monkeypatch.setenv("MFM_SEQ_PATH", path)
     if rows:
         monkeypatch.setenv("MFM_SEQ_ROWS", rows)      # force the row-tile size of the VALU kernels

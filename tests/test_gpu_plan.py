@@ -51,9 +51,14 @@ def test_forward_matches_reference_golden(name):
     assert np.allclose(cases.summarize(xl)[:2], gold["x_l_hat_sum"][:2], rtol=TOL, atol=1e-4)
 
 
-@pytest.fixture(params=["mfma", "small", "small:1", "small:2", "small:4"])
+@pytest.fixture(params=["mfma", "small", "small:1", "small:2", "small:4", "stepwise"])
 def seq_path(request, monkeypatch):
     path, _, rows = request.param.partition(":")
+    if path == "stepwise":                            # recurrent GEMM + cell kernel per step (h > 128 path)
+        monkeypatch.setenv("MFM_SEQ_STEPWISE", "1")
+        path = "small"
+    else:
+        monkeypatch.delenv("MFM_SEQ_STEPWISE", raising=False)
     monkeypatch.setenv("MFM_SEQ_PATH", path)
     if rows:
         monkeypatch.setenv("MFM_SEQ_ROWS", rows)      # force the row-tile size of the VALU kernels
@@ -88,6 +93,51 @@ def test_gradients_match_oracle_and_golden(name, seq_path):
     got = np.stack(rows)
     scale = np.maximum(np.abs(gold[:, :1]), 1e-6)           # per-tensor L2 norm
     assert np.max(np.abs(got - gold) / scale) < 5 * TOL      # norm / sum / first-8 vs the reference
+
+
+def test_wide_hidden_sizes_match_oracle():
+    """Sizes from the reference's hyper-parameter search (mfm_mosi.py:1305-1320: zl, fl up to 256) make
+    encoder_l 156, ef_encoder 244 and decoder_l 272 wide: beyond the weight-resident LSTM kernels (128) and
+    the latent row kernels; forward losses, every gradient and a 3-step Adam trajectory against the oracle."""
+    from factorized_amd import configs, engine
+    cfgs = configs.canonical_configs(dropout=False, zl_size=156, fl_size=256, za_size=16, fa_size=32)
+    cfg = cfgs[0]
+    B, T = 9, 6
+    xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=21)
+    e = engine.MFMEngine(cfgs)
+    w = synth.make_weights(e.layout.shapes, seed=77)
+    e.load_weights(w)
+    m = O.build("kl_ef", cfgs)
+    O.load_numpy_weights(m, w)
+    m.train()
+    x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+    terms = O.loss_terms(m, x, y, cfg)
+    terms["loss"].backward()
+    xd, yd = x.cuda(), y.cuda()
+    out = e.forward(xd, yd, train=True, want_xhat=False)
+    ld = e.loss_dict(out["losses"])
+    for k in ("disc", "gen", "reg", "loss"):
+        ref = float(terms[k].detach())
+        assert abs(ld[k] - ref) <= TOL * max(abs(ref), 1e-3), (k, ld[k], ref)
+    e.backward(xd, yd, stage=0)
+    gv = e.grad_views()
+    worst = ("", 0.0)
+    for n, p in m.named_parameters():
+        err = rel_err(gv[n].cpu().numpy(), p.grad.numpy())
+        if err > worst[1]:
+            worst = (n, err)
+    assert worst[1] < TOL, "worst gradient mismatch %s: %.3e" % worst
+    opt = torch.optim.Adam(m.parameters())
+    for _ in range(3):
+        opt.zero_grad()
+        O.loss_terms(m, x, y, cfg)["loss"].backward()
+        opt.step()
+        e.train_step(xd, yd)
+    pv = e.param_views()
+    for n, p in m.named_parameters():
+        # Adam normalises by sqrt(v): an element whose gradient is ~0 moves by up to lr per step whatever the
+        # rounding says, so the trajectory bound is a fraction of the 3*lr the parameters can move at all
+        assert np.max(np.abs(pv[n].cpu().numpy() - p.detach().numpy())) < 0.1 * 3e-3, n
 
 
 def test_grad_step_equals_forward_plus_backward():
