@@ -14,7 +14,7 @@
 
 namespace mfm {
 
-#define MFM_GEMM_MAXP 22   // 22 x 168 B of descriptors + the group extras stay inside the 4 KB kernel-argument segment
+#define MFM_GEMM_MAXP 56   // problems per launch (the descriptors travel in the kernel-argument segment, ~9.6 KB)
 constexpr int BK = 32;   // K depth of one LDS stage: 8 MFMA k-steps between barriers
 
 struct GemmProblem {
@@ -23,6 +23,7 @@ struct GemmProblem {
 };
 struct GemmGroup {
   GemmProblem p[MFM_GEMM_MAXP];
+  int begins[MFM_GEMM_MAXP];     // first workgroup of every problem (INT_MAX past `count`): found with one unrolled compare chain
   int count;
   // optional: spans the launch also clears (the fused step's loss slots and gradient buffer ride on its
   // first GEMM instead of two memset launches of ~4.7 us each)
@@ -72,15 +73,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   // share of every problem (a whole-launch remap left the XCDs with the long-K problems as stragglers).
   int pi = 0;
   const int bid = blockIdx.x;
-#pragma unroll 1
-  for (int i = 1; i < g.count; ++i)
-    if (bid >= g.p[i].block_begin) pi = i;
+#pragma unroll
+  for (int i = 1; i < MFM_GEMM_MAXP; ++i) pi += (bid >= g.begins[i]) ? 1 : 0;
   const GemmProblem& P = g.p[pi];
   const MfmGemmDesc& d = P.d;
   int local = bid - P.block_begin;
   {
     constexpr int NX = 8;
-    const int nb = ((pi + 1 < g.count) ? g.p[pi + 1].block_begin : (int)gridDim.x) - P.block_begin;
+    const int nb = ((pi + 1 < g.count) ? g.begins[pi + 1] : (int)gridDim.x) - P.block_begin;
     const int x = local % NX, j = local / NX;
     const int per = nb / NX, rem = nb % NX;
     local = x * per + (x < rem ? x : rem) + j;
@@ -385,8 +385,10 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
     P.d.split_k = split;
     P.k_per_split = kps;
     P.block_begin = total;
+    g.begins[i] = total;
     total += P.tiles_m * P.tiles_n * P.d.batch * split;
   }
+  for (int i = count; i < MFM_GEMM_MAXP; ++i) g.begins[i] = 0x7fffffff;
   bool vec = true;
   for (int i = 0; i < count; ++i) {
     const MfmGemmDesc& d = descs[i];

@@ -481,6 +481,9 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
   if (P->grads_prezeroed != grads) MFM_HIP_CHECK(hipMemsetAsync(grads, 0, (size_t)P->n_params * sizeof(float), s));
   P->grads_prezeroed = nullptr;
   const bool gen_on = (stage != 2), disc_on = (stage != 1);
+  // every weight-gradient product only feeds the optimizer: they are collected here and issued as ONE grouped
+  // launch behind the encoder BPTT (49 problems at the canonical wiring) instead of three launches on the chain
+  std::vector<MfmGemmDesc> tail;
   if (gen_on) {
     // B0: through decoder fc1
     std::vector<MfmGemmDesc> g;
@@ -505,12 +508,12 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       w.b = W + sb.hs; w.b_sk = sb.Hp; w.b_sn = 1;
       w.c = grads + P->off[pb + FC_W]; w.ldc = sb.h;
       w.m = P->dec_d[m]; w.n = sb.h; w.n_valid = sb.h; w.k = (int)TB;
-      g.push_back(w);
+      tail.push_back(w);
       // dbfc = column sums of dx_hat
       MfmGemmDesc bb = w;
       bb.b = W + P->ones; bb.b_sk = 1; bb.b_sn = 1;
       bb.c = grads + P->off[pb + FC_B]; bb.ldc = 1; bb.n = 1; bb.n_valid = 1;
-      g.push_back(bb);
+      tail.push_back(bb);
     }
     RUN(K_FC1_BWD, gemm_group_launch(g.data(), (int)g.size(), s));
     // B1: decoder BPTT
@@ -546,8 +549,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     L.disc_w = disc_on ? 1.0f : 0.0f;
     L.gen_w = gen_on ? 1.0f : 0.0f;
     RUN(K_LAT_BWD, latent_bwd_launch(L, params, grads, s));
-    // weight gradients of the 22 latent Linears: dW[n][k] = sum_r G[r][out+n] X[r][in+k], one grouped GEMM
-    std::vector<MfmGemmDesc> gw;
+    // weight gradients of the 22 latent Linears: dW[n][k] = sum_r G[r][out+n] X[r][in+k]
     const int rs = P->lat.rec_size;
     for (int i = 0; i < P->lat.nops; ++i) {
       const LatOp& op = P->lat_ops[i];
@@ -558,9 +560,8 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       d.b = W + P->lat_rec + op.in_off; d.b_sk = rs; d.b_sn = 1;
       d.c = grads + op.w_off; d.ldc = op.K;
       d.m = op.N; d.n = op.K; d.n_valid = op.K; d.k = P->B;
-      gw.push_back(d);
+      tail.push_back(d);
     }
-    RUN(K_LAT_DW, mfm_gemm_grouped_f32(gw.data(), (int)gw.size(), s));
   }
   // B4: encoder BPTT
   {
@@ -571,15 +572,14 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     }
     RUN(K_ENC_BWD, mfm_lstm_seq_bwd(q, 4, T, B, s));
   }
-  // B5: encoder weight gradients
+  // B5: all weight gradients
   {
-    std::vector<MfmGemmDesc> gw;
     for (int e = 0; e < 4; ++e)
-      dA_gemms(P, P->enc[e], P->enc_p[e], W, grads, gw, x + P->enc_xoff[e], P->D, P->enc_d[e], false);
+      dA_gemms(P, P->enc[e], P->enc_p[e], W, grads, tail, x + P->enc_xoff[e], P->D, P->enc_d[e], false);
     if (gen_on)
       for (int m = 0; m < 3; ++m)
-        dA_gemms(P, P->dec[m], P->dec_p[m], W, grads, gw, W + P->dec_init[m], P->dec_h[m], P->dec_h[m], true);
-    RUN(K_ENC_DW, mfm_gemm_grouped_f32(gw.data(), (int)gw.size(), s));
+        dA_gemms(P, P->dec[m], P->dec_p[m], W, grads, tail, W + P->dec_init[m], P->dec_h[m], P->dec_h[m], true);
+    RUN(K_ENC_DW, mfm_gemm_grouped_f32(tail.data(), (int)tail.size(), s));
   }
   return MFM_OK;
 }
@@ -706,7 +706,7 @@ extern "C" int mfm_plan_num_kernels(void) { return K_COUNT; }
 extern "C" const char* mfm_plan_kernel_name(int kid) {
   static const char* names[K_COUNT] = {"proj_gemm", "enc_seq_fwd", "latent_fwd", "dec_seq_fwd", "fc1_mse_gemm", "mse",
                                        "fc1_bwd_gemm", "dec_seq_bwd", "dec_dw_gemm", "latent_bwd", "enc_seq_bwd",
-                                       "lstm_dw_gemm", "adam", "latent_dw_gemm"};
+                                       "dw_gemm", "adam", "latent_dw_gemm"};
   return (kid >= 0 && kid < K_COUNT) ? names[kid] : "?";
 }
 // Synchronises on the recorded events, adds elapsed ms / launch counts per kernel id, resets the pool.
@@ -759,11 +759,13 @@ extern "C" double mfm_plan_kernel_flops(const MfmPlan* P, int kid) {
     case K_ENC_FWD: case K_ENC_BWD: for (int e = 0; e < 4; ++e) f += TB * 2.0 * 4.0 * P->enc_h[e] * P->enc_h[e]; break;
     case K_DEC_FWD: case K_DEC_BWD: for (int m = 0; m < 3; ++m) f += TB * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m]; break;
     case K_FC1_FWD: for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m]; break;
-    case K_FC1_BWD: for (int m = 0; m < 3; ++m) f += 2.0 * TB * 2.0 * P->dec_h[m] * P->dec_d[m]; break;
+    case K_FC1_BWD: for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m]; break;   // dH only
     case K_DEC_DW: break;   // merged into K_ENC_DW
     case K_ENC_DW:
       for (int e = 0; e < 4; ++e) f += TB * 2.0 * 4.0 * P->enc_h[e] * (P->enc_d[e] + P->enc_h[e]);
       for (int m = 0; m < 3; ++m) f += TB * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m];
+      for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m];            // dWfc
+      for (int i = 0; i < P->lat.nops; ++i) f += 2.0 * P->B * P->lat_ops[i].N * P->lat_ops[i].K;   // latent dW
       break;
     default: break;
   }

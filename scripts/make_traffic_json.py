@@ -12,7 +12,7 @@ import json
 import sqlite3
 import sys
 
-GEMM_ORDER = ["proj_gemm", "fc1_mse_gemm", "fc1_bwd_gemm", "latent_dw_gemm", "lstm_dw_gemm"]
+GEMM_ORDER = ["proj_gemm", "fc1_mse_gemm", "fc1_bwd_gemm", "dw_gemm"]
 
 
 def classify(name):
