@@ -67,6 +67,7 @@ _SIGS = {
     "mfm_gemm_grouped_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.c_void_p]),
     "mfm_lstm_seq_fwd": (C.c_int, [C.POINTER(SeqDesc), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mfm_lstm_seq_bwd": (C.c_int, [C.POINTER(SeqDesc), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mfm_mmd_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mfm_mfn_mem_fwd": (C.c_int, [C.POINTER(MemDesc), C.c_void_p]),
     "mfm_mfn_mem_bwd": (C.c_int, [C.POINTER(MemDesc), C.c_void_p]),
     "mfm_mse_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_float,

@@ -47,11 +47,33 @@ def compute_kernel(x, y):
     return torch.exp(-(diff.pow(2).mean(2) / float(dim)))
 
 
+class _MMDFn(torch.autograd.Function):
+    """loss_MMD value and gradient wrt z in one HIP kernel (mfm_mmd_fwd_bwd, csrc/mmd.hip)."""
+
+    @staticmethod
+    def forward(ctx, z, gauss):
+        zc, gc = z.detach().contiguous().float(), gauss.detach().contiguous().float()
+        B, dim = zc.shape
+        loss = torch.zeros((), device=z.device)
+        dz = torch.empty_like(zc)
+        _lib.check(_lib.lib().mfm_mmd_fwd_bwd(zc.data_ptr(), gc.data_ptr(), B, dim, loss.data_ptr(), dz.data_ptr(),
+                                              E._stream()), "mfm_mmd_fwd_bwd")
+        ctx.save_for_backward(dz)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dl):
+        (dz,) = ctx.saved_tensors
+        return dz * dl, None
+
+
 def loss_MMD(zy, gauss=None):
     """MMD between zy and a N(0,1) sample of the same shape -- mfm_model.py:25-34.  The reference
     draws the sample on the host; pass `gauss` to inject it (parity tests)."""
     if gauss is None:
         gauss = torch.randn(zy.size(), device=zy.device, dtype=zy.dtype)
+    if zy.is_cuda and zy.dim() == 2 and zy.shape[1] <= 256:
+        return _MMDFn.apply(zy, gauss)
     return compute_kernel(gauss, gauss).mean() + compute_kernel(zy, zy).mean() \
         - 2.0 * compute_kernel(gauss, zy).mean()
 

@@ -140,6 +140,14 @@ int mfm_mfn_mem_fwd(const MfmMemDesc* desc /*host*/, void* stream);
 int mfm_mfn_mem_bwd(const MfmMemDesc* desc /*host*/, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * MMD regulariser of the non-KL MFM, replaces loss_MMD / compute_kernel (reference mfm_model.py:14-34):
+ *   *loss += mean K(g,g) + mean K(z,z) - 2 mean K(g,z),  K(a,b) = exp(-mean((a-b)^2)/dim)
+ * z, gauss [B, dim] contiguous (the reference draws gauss ~ N(0,1) on the host; the caller supplies it);
+ * dz (optional) receives d mmd / d z.  dim <= 256. */
+int mfm_mmd_fwd_bwd(const float* z, const float* gauss, int32_t B, int32_t dim, float* loss /*accumulated*/,
+                    float* dz /*[B,dim] or NULL*/, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused Adam on one flat parameter buffer (torch.optim.Adam defaults semantics,
  * mfm_mosi.py:403,441): m,v,p updated in place; g is multiplied by grad_scale first (DP
  * averaging).  `step` is the 1-based step count used for bias correction.

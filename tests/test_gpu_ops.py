@@ -346,3 +346,27 @@ def test_mfn_memory_dropout_statistics(eng):
     torch.cuda.synchronize()
     kept = (g.grad[1:] != 0).float().mean().item()       # t = 0 passes no gradient to gamma1 (mem_{-1} = 0)
     assert 0.45 < kept < 0.55
+
+
+# ---------------------------------------------------------------------------------- MMD
+@pytest.mark.parametrize("B,dim", [(32, 32), (19, 80), (100, 8), (64, 256), (1, 16), (33, 5)])
+def test_mmd_matches_reference_formula(eng, B, dim):
+    """mfm_mmd_fwd_bwd against the reference statement of loss_MMD / compute_kernel (mfm_model.py:14-34) in
+    float64 on the CPU: value and gradient wrt z."""
+    from factorized_amd.mfm_model import loss_MMD
+    rs = np.random.RandomState(B * 1000 + dim)
+    zn = rs.normal(size=(B, dim)).astype(np.float32) * 1.3
+    gn = rs.normal(size=(B, dim)).astype(np.float32)
+
+    def ck(x, y):
+        d = x.shape[1]
+        return torch.exp(-((x.unsqueeze(1) - y.unsqueeze(0)) ** 2).mean(2) / float(d))
+    zr = torch.tensor(zn, dtype=torch.float64, requires_grad=True)
+    gr = torch.tensor(gn, dtype=torch.float64)
+    ref = ck(gr, gr).mean() + ck(zr, zr).mean() - 2.0 * ck(gr, zr).mean()
+    (3.0 * ref).backward()
+    zd = torch.tensor(zn, device="cuda", requires_grad=True)
+    out = loss_MMD(zd, torch.tensor(gn, device="cuda"))
+    (3.0 * out).backward()
+    assert abs(out.item() - ref.item()) <= TOL * max(abs(ref.item()), 1e-3)
+    assert rel_err(zd.grad.cpu().numpy(), zr.grad.numpy()) < TOL
