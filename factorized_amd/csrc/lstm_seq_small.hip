@@ -123,15 +123,41 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
   const int b0 = tile * R;
   const int b = b0 + myrow;
 
-  float* hbuf = lds;                       // [2][HK][R]
-  float* panel = lds + 2 * HK * R;         // [2][h][h] weight staging (two gates at a time)
+  // R == 1: the quad lane q owns the CONTIGUOUS columns k = 16m + 4q + {0..3}, m < NM, so one ds_read_b128
+  // feeds 4 FMAs per gate row (8 LDS reads per step instead of 30) and the weights arrive as 16-byte global
+  // loads straight into registers (no LDS staging round in the prologue).  R > 1: k = 4j + q as before.
+  constexpr int NM = HKB / 16;
+  constexpr int NWR = (R == 1) ? 4 * NM : KQ;     // weights per gate row and thread
+  constexpr int HX = (R == 1) ? HKB : HK;          // extent of one h buffer
+  float* hbuf = lds;                       // [2][HX][R]
+  float* panel = lds + 2 * HKB * R;        // [2][h][h] weight staging (two gates at a time)
   float* obuf = panel;                     // [2][6][HKB][R] step outputs; aliases the panel (barriers below)
   float* xbuf = obuf + 2 * 6 * HKB * R;    // [2][4][HKB][R] x-projections of the next step (encoders)
 
-  float w[2][KQ];
+  float w[2][NWR];
   // round gl stages gates gl (for the p=0 lanes) and 2+gl (p=1 lanes) side by side, so every
   // lane picks its own gate with an address, not a predicate
   auto load_w = [&](int mode) {
+    if constexpr (R == 1) {
+      if ((h & 3) == 0) {
+        const float* wa = (mode == 0) ? d.w_hh : d.w_ih;
+#pragma unroll
+        for (int gl = 0; gl < 2; ++gl) {
+          const int64_t rowo = ((int64_t)(2 * gp + gl) * h + min(u, h - 1)) * h;
+#pragma unroll
+          for (int m = 0; m < NM; ++m) {
+            const int k0 = 16 * m + 4 * q;
+            const bool ok = (u < h) && (k0 < h);
+            const int kc = min(k0, h - 4);
+            f32x4 v = *reinterpret_cast<const f32x4*>(wa + rowo + kc);
+            if (mode == 2) v += *reinterpret_cast<const f32x4*>(d.w_hh + rowo + kc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[gl][4 * m + i] = ok ? v[i] : 0.0f;
+          }
+        }
+        return;
+      }
+    }
     const int n = h * h;
     const int uc = min(u, h - 1);
 #pragma unroll
@@ -141,8 +167,8 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
       __syncthreads();
       const float* src = panel + gp * n + uc * h;
 #pragma unroll
-      for (int j = 0; j < KQ; ++j) {
-        const int k = 4 * j + q;
+      for (int j = 0; j < NWR; ++j) {
+        const int k = (R == 1) ? 16 * (j >> 2) + 4 * q + (j & 3) : 4 * j + q;
         const float v = src[min(k, h - 1)];
         w[gl][j] = (u < h && k < h) ? v : 0.0f;
       }
@@ -158,7 +184,7 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
     for (int gl = 0; gl < 2; ++gl) gxb[gl] = d.b_ih[(2 * gp + gl) * h + u] + d.b_hh[(2 * gp + gl) * h + u];
   }
   if (dec) {
-    for (int idx = tid; idx < HK * R; idx += nt) {
+    for (int idx = tid; idx < HX * R; idx += nt) {
       const int k = idx / R, br = b0 + (idx % R);
       hbuf[idx] = (k < h && br < B) ? d.h_init[(int64_t)br * d.ld_init + k] : 0.0f;
     }
@@ -228,7 +254,21 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
     for (int gl = 0; gl < 2; ++gl)
 #pragma unroll
       for (int r = 0; r < R; ++r) acc[gl][r] = 0.0f;
-    if (dec || t > 0) {
+    if constexpr (R == 1) {
+      if (dec || t > 0) {
+        const float* hb = hbuf + cur * HX + 4 * q;
+        f32x4 hv[NM];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) hv[m] = *reinterpret_cast<const f32x4*>(hb + 16 * m);
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[0][0] = fmaf(w[0][4 * m + i], hv[m][i], acc[0][0]);
+            acc[1][0] = fmaf(w[1][4 * m + i], hv[m][i], acc[1][0]);
+          }
+      }
+    } else if (dec || t > 0) {
       const float* hb = hbuf + cur * (HK * R) + q * R;
       constexpr int RING = (KQ < 4) ? KQ : 4;      // LDS reads kept in flight ahead of their FMAs
       RowVec<R> ring[RING];
@@ -278,7 +318,7 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
       float* ob = obuf + par * (6 * HKB * R) + my_o;
       ob[0] = a0; ob[HKB * R] = a1;
       ob[(4 - gp) * HKB * R] = gp ? hv : c;        // slot 4 (c) from gp 0, slot 5 (h) from gp 1
-      if (gp == 0 && u < HK) hbuf[(cur ^ 1) * (HK * R) + u * R + myrow] = (b < B) ? hv : 0.0f;
+      if (gp == 0 && u < HX) hbuf[(cur ^ 1) * (HX * R) + u * R + myrow] = (b < B) ? hv : 0.0f;
     }
     if (!dec) {
 #pragma unroll
@@ -611,7 +651,7 @@ static size_t small_lds_bytes(const SeqLaunch& L, bool bwd, int R) {
     // forward: h ring + max(weight panel, output record + x-projection record); backward: dA ring +
     // saved-activation record + weight panel (see the bodies)
     const size_t rec = (2 * 6 + 2 * 4) * HKB * R;
-    const size_t need = (bwd ? (2 * 4 + 2 * 7) * HKB * R + hh : 2 * HK * R + (2 * hh > rec ? 2 * hh : rec)) * sizeof(float);
+    const size_t need = (bwd ? (2 * 4 + 2 * 7) * HKB * R + hh : 2 * HKB * R + (2 * hh > rec ? 2 * hh : rec)) * sizeof(float);
     if (need > lds_bytes) lds_bytes = need;
   }
   return (lds_bytes + 15) / 16 * 16;

@@ -228,7 +228,9 @@ def test_lstm_seq_decoder_fwd_bwd(eng, seq_path, h, B, T):
 
 
 def test_lstm_seq_four_in_one_launch(eng, seq_path):
-    """The 4 encoders of the canonical model share one launch; results must equal solo launches."""
+    """The 4 encoders of the canonical model share one launch; results must equal solo launches (to rounding:
+    a solo launch of an uncommon size takes the generic 4-row tile whose k-order of partial sums differs
+    from the 1-row tile of the shared launch)."""
     rs = np.random.RandomState(0)
     T, B = 20, 32
     keep, solo, descs = [], [], []
@@ -252,7 +254,7 @@ def test_lstm_seq_four_in_one_launch(eng, seq_path):
     torch.cuda.synchronize()
     for w, bufs in keep:
         for a, b in zip(bufs[0], bufs[1]):
-            assert torch.equal(a, b)
+            assert torch.allclose(a, b, rtol=0.0, atol=2e-6)
 
 
 # ---------------------------------------------------------------------------------- MSE / Adam
