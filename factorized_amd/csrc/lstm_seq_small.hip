@@ -463,7 +463,7 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
   int cur = 0;
   __syncthreads();
 
-  auto step = [&](const int t) {
+  auto step = [&](const int t, const bool matvec = true) {
     const int par = t & 1;
     const float* sb = sbuf + par * (NV * HKB * R) + my_s;
     const float gi = sb[0], gf = sb[HKB * R], gg = sb[2 * HKB * R], go = sb[3 * HKB * R], cp = sb[4 * HKB * R];
@@ -504,7 +504,7 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
     }
 #pragma unroll
     for (int i = 0; i < NLD; ++i) pf[i] = pn[i];
-    if ((t > 0) || dec) {
+    if (matvec && ((t > 0) || dec)) {
       float aa[R], ab[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) { aa[r] = 0.0f; ab[r] = 0.0f; }
@@ -541,6 +541,35 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
     cur ^= 1;
   };
   for (int t = T - 1; t >= 1; --t) step(t);
+  if (dec && (h & 3) == 0 && R == 1) {
+    // The decoder's step-0 input gradient goes through W_ih alone: d h_init = dA_0 W_ih.  Re-loading the
+    // whole transposed register layout for this one product costs ~7 us (four staging rounds); instead the
+    // 4h rows of W_ih are streamed once with 16-byte loads (thread = 4 consecutive units x one row slice)
+    // and the slices are summed through LDS.
+    const int dcur = cur;
+    step(0, false);
+    const float* db = dabuf + dcur * (4 * HKB * R);
+    const int h4 = h >> 2;
+    const int S = min(min(32, nt / h4), h);         // row slices (S*h partial sums must fit the h*h panel)
+    const int u4 = tid % h4, sl = tid / h4;
+    if (sl < S) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int r = sl; r < 4 * h; r += S) {
+        const int gg = r / h, j = r - gg * h;
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(d.w_ih + (int64_t)r * h + 4 * u4);
+        acc += db[gg * HKB + j] * w4;
+      }
+      float* pr = panel + sl * h + 4 * u4;
+      pr[0] = acc[0]; pr[1] = acc[1]; pr[2] = acc[2]; pr[3] = acc[3];
+    }
+    lds_barrier();
+    if (tid < h && d.d_h_init && b0 < B) {
+      float sum = 0.0f;
+      for (int k = 0; k < S; ++k) sum += panel[k * h + tid];
+      d.d_h_init[(int64_t)b0 * d.ld_dinit + tid] = sum;
+    }
+    return;
+  }
   if (dec) load_wT(1);                 // grad wrt the step-0 input goes through W_ih only (peeled)
   step(0);
   if (dec && bvalid && d.d_h_init && mu < h) d.d_h_init[(int64_t)b * d.ld_dinit + mu] = dh_rec;
