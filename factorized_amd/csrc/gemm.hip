@@ -1,9 +1,9 @@
 // Grouped, batched, strided fp32 GEMM on v_mfma_f32_16x16x4_f32 (gfx950).
 //
 // One launch covers up to MFM_GEMM_MAXP independent problems (input projections of the 4
-// encoders; the 12 weight-gradient products of the encoder backward; ...), because at the
-// MOSI batch size every one of them is far too small to fill 256 CUs on its own and a launch
-// boundary costs ~1.5 us.  Tiles are 32x32 or 64x64 (picked so the group yields >= ~2 blocks
+// encoders; all 49 weight-gradient products of the backward; ...), because at the MOSI batch
+// size every one of them is far too small to fill 256 CUs on its own and a launch boundary costs
+// several us (a grouped launch of this kernel has a ~7 us floor, profiles/r01 GEMM microbenchmark).  Tiles are 32x32 or 64x64 (picked so the group yields >= ~2 blocks
 // per CU), K is staged 32 deep through LDS.  The LDS image follows the operand's memory order so that
 // a thread's 4-element group is ONE ds_write_b128: [k][m+16] for m-/n-contiguous operands (MFMA
 // operand reads conflict-free: row stride == 16 mod 32 banks), [m][k+4] for k-contiguous ones (reads

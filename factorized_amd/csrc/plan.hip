@@ -1,21 +1,21 @@
 // The fused MFM_KL_EF step: one host call enqueues the whole forward / backward / Adam chain
-// (13 launches + 2 memsets) on one HIP stream, with no host work or synchronisation between
+// (11 launches, no memsets) on one HIP stream, with no host work or synchronisation between
 // kernels.  Replaces MFM_KL_EF.forward (reference mfm_model.py:619-660), the joint loss and
 // loss.backward()/optimizer.step() of train_mfm.train (mfm_mosi.py:424-442).
 //
 // Launch chain (F = forward, B = backward):
 //   F0 grouped GEMM   x_t W_ih^T + b_ih + b_hh for all t, 4 encoders        -> gates_e
+//                     (the same launch clears the loss slots and, in the fused step, the gradient buffer)
 //   F1 lstm_seq fwd   4 encoder recurrences (persistent, weights in VGPRs)   -> gates/hs/cs
 //   F2 latent fwd     enc.fc1, mu/logvar heads, z->f MLPs, classifier, KLD, L1|CE
 //   F3 lstm_seq fwd   3 decoder recurrences
-//   F4 grouped GEMM   decoder fc1                                            -> x_hat
-//   F5 mse            3 reconstruction losses + d x_hat
-//   B0 grouped GEMM   dH = dx_hat Wfc ; dWfc ; dbfc                          (9 problems)
+//   F4 grouped GEMM   decoder fc1 -> x_hat, with the squared-error epilogue  -> 3 reconstruction losses, d x_hat
+//   B0 grouped GEMM   dH = dx_hat Wfc                                        (3 problems)
 //   B1 lstm_seq bwd   3 decoder BPTTs                                        -> dA, d h_init
-//   B2 grouped GEMM   decoder dW_ih/dW_hh/db over dA                         (9 problems)
 //   B3 latent bwd
 //   B4 lstm_seq bwd   4 encoder BPTTs
-//   B5 grouped GEMM   encoder dW_ih/dW_hh/db over dA                         (12 problems)
+//   B5 grouped GEMM   EVERY weight gradient: dWfc/dbfc, the 22 latent dW, encoder and decoder
+//                     dW_ih/dW_hh/db over dA                                 (49 problems, one launch)
 //   A  adam           fused, one flat buffer
 #include <math.h>
 #include <stdlib.h>
