@@ -45,6 +45,17 @@ def summarize(a):
     return np.concatenate([[np.sqrt((a * a).sum()), a.sum()], a[:8], np.zeros(max(0, 8 - a.size))])
 
 
+def grad_err(a, b, abs_slack=1e-7):
+    """rel_err for parameter gradients: max|a-b| beyond `abs_slack`, over max|b|.  A gradient that is ~0 by
+    construction (e.g. a bias behind cancelling L1 signs) carries only the rounding noise of the summation
+    order (atomics: ~4e-9), which a purely relative measure cannot bound."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if not b.size:
+        return 0.0
+    return float(max(np.abs(a - b).max() - abs_slack, 0.0) / max(np.abs(b).max(), 1e-12))
+
+
 def rel_err(a, b):
     """max |a-b| / max(|b|) -- the 'relative fp32 tolerance' used throughout
     (BASELINE.json north_star: 1e-4)."""

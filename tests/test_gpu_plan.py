@@ -8,7 +8,7 @@ import torch
 from oracle import mfm_oracle as O
 from factorized_amd import synth
 from tests import cases
-from tests.cases import rel_err
+from tests.cases import grad_err, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -84,7 +84,7 @@ def test_gradients_match_oracle_and_golden(name, seq_path):
     rows = []
     for n, p in m.named_parameters():
         g = gv[n].cpu().numpy()
-        err = rel_err(g, p.grad.numpy())
+        err = grad_err(g, p.grad.numpy())
         rows.append(cases.summarize(g))
         if err > worst[1]:
             worst = (n, err)
@@ -123,7 +123,7 @@ def test_wide_hidden_sizes_match_oracle():
     gv = e.grad_views()
     worst = ("", 0.0)
     for n, p in m.named_parameters():
-        err = rel_err(gv[n].cpu().numpy(), p.grad.numpy())
+        err = grad_err(gv[n].cpu().numpy(), p.grad.numpy())
         if err > worst[1]:
             worst = (n, err)
     assert worst[1] < TOL, "worst gradient mismatch %s: %.3e" % worst
@@ -181,7 +181,7 @@ def test_staged_losses(stage):
         if p.grad is None:
             assert np.all(g == 0.0), n      # torch leaves .grad None; the flat buffer holds zeros
         else:
-            assert rel_err(g, p.grad.numpy()) < TOL, n
+            assert grad_err(g, p.grad.numpy()) < TOL, n
 
 
 @pytest.mark.parametrize("name", ["klef_b32_t20", "klef_b33_t7", "klef_odd_b19_t9", "klef_you_b32_t50"])
