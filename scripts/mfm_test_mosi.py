@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--config", default=os.path.join(os.path.dirname(__file__), "..", "configs", "mosi.json"))
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--n-train", type=int, default=1280)
+    ap.add_argument("--staged", action="store_true",
+                    help="train_beta_vae schedule (mfm_mosi.py:225-361): `epochs` of stage 1 (gen + reg loss), then "
+                         "`epochs` of stage 2 (disc + reg loss), instead of the joint loss of train_mfm")
     args = ap.parse_args()
     _, T = C.load_json_config(args.config)                  # only `seqlength` is read, as in the reference
     cfgs = C.canonical_configs(dropout=True)
@@ -55,12 +58,23 @@ def main():
     Xd = torch.from_numpy(np.ascontiguousarray(Xtr[:, :nb * bs].reshape(T, nb, bs, -1).transpose(1, 0, 2, 3))).to(dev)
     yd = torch.from_numpy(ytr[:nb * bs].reshape(nb, bs)).to(dev)
     xv, yv = torch.from_numpy(Xva).to(dev), torch.from_numpy(yva).to(dev)
-    for epoch in range(args.epochs):
+    schedule = [0] * args.epochs if not args.staged else [1] * args.epochs + [2] * args.epochs
+    c = cfg
+    for epoch, stage in enumerate(schedule):
+        if args.staged and epoch == args.epochs:
+            best = 999999.0                                # the reference restarts the best-valid rule per stage (:348)
         model.train()
         acc = torch.zeros((), device=dev)
         for b in range(nb):
-            losses = eng.train_step(Xd[b], yd[b], lr=lr)
-            acc += losses[0]                               # disc loss, accumulated on device (no per-step sync)
+            if stage == 0:
+                losses = eng.train_step(Xd[b], yd[b], lr=lr)
+                acc += losses[0]                           # disc loss, accumulated on device (no per-step sync)
+            else:
+                losses = eng.forward(Xd[b], yd[b], train=True, want_xhat=False)["losses"]
+                eng.backward(Xd[b], yd[b], stage=stage)    # gradients of gen+reg (1) or disc+reg (2), mfm_mosi.py:278-281
+                eng.adam(lr=lr)
+                gen = c["lda_xl"] * losses[1] + c["lda_xa"] * losses[2] + c["lda_xv"] * losses[3]
+                acc += (gen if stage == 1 else losses[0]) + c["lda_mmd"] * losses[4]
         train_loss = acc.item() / nb
         model.eval()
         out = eng.forward(xv, yv, train=False, want_xhat=False)
