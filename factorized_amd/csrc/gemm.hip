@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   //       MULTIPLY (a select/branch makes hipcc wait vmcnt(0) right behind the load);
   //   (b) the barriers are LDS-only (lds_barrier): __syncthreads() drains the ring with vmcnt(0);
   //   (c) the operand fragments of a tile are read from LDS before the first MFMA.
-  constexpr int DEPTH = 3;
+  constexpr int DEPTH = (FR == 2) ? 2 : 3;
   constexpr int GA = EPT_A / 4, GB = EPT_B / 4;
   float ra[DEPTH][EPT_A], rb[DEPTH][EPT_B];
   const int a_sm = (int)d.a_sm, a_sk = (int)d.a_sk, b_sk = (int)d.b_sk, b_sn = (int)d.b_sn;
@@ -238,20 +238,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
       store_tiles(s);                       // tiles beyond nkt are all-zero: harmless extra MFMAs
       lds_barrier();
       load_tiles(s, kbeg + (kt + DEPTH) * BK);
-      float af[BK / 4][FR], bf[BK / 4][FR];
+      // operand fragments are read from LDS ahead of the MFMAs that use them: the whole tile for the 32x32
+      // variant, half a tile at a time for the 64x64 one (its 4 accumulators already fill the register budget
+      // that decides between 2 and 3 waves per SIMD)
+      constexpr int KSB = (FR == 2) ? BK / 8 : BK / 4;
 #pragma unroll
-      for (int ks = 0; ks < BK / 4; ++ks)
+      for (int kb = 0; kb < BK / 4; kb += KSB) {
+        float af[KSB][FR], bf[KSB][FR];
 #pragma unroll
-        for (int f = 0; f < FR; ++f) {
-          af[ks][f] = As[(ks * 4 + q) * a_lk + (wm * 16 * FR + f * 16 + bi) * a_lm];
-          bf[ks][f] = Bs[(ks * 4 + q) * b_lk + (wn * 16 * FR + f * 16 + bi) * b_ln];
-        }
+        for (int ks = 0; ks < KSB; ++ks)
 #pragma unroll
-      for (int ks = 0; ks < BK / 4; ++ks)
+          for (int f = 0; f < FR; ++f) {
+            af[ks][f] = As[((kb + ks) * 4 + q) * a_lk + (wm * 16 * FR + f * 16 + bi) * a_lm];
+            bf[ks][f] = Bs[((kb + ks) * 4 + q) * b_lk + (wn * 16 * FR + f * 16 + bi) * b_ln];
+          }
 #pragma unroll
-        for (int fm = 0; fm < FR; ++fm)
+        for (int ks = 0; ks < KSB; ++ks)
 #pragma unroll
-          for (int fn = 0; fn < FR; ++fn) acc[fm][fn] = mma16x16x4(af[ks][fm], bf[ks][fn], acc[fm][fn]);
+          for (int fm = 0; fm < FR; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FR; ++fn) acc[fm][fn] = mma16x16x4(af[ks][fm], bf[ks][fn], acc[fm][fn]);
+      }
       lds_barrier();
     }
   }
