@@ -76,6 +76,26 @@ def test_gemm_nn_and_group_of_many(eng):
         assert rel_err(c_d.cpu().numpy(), ref) < 2e-6
 
 
+@pytest.mark.parametrize("count", [56, 57, 130])
+def test_gemm_group_larger_than_one_launch(eng, count):
+    """A group at and beyond the per-launch problem limit (56): the ABI call splits it into launches; every
+    problem, including the last one of a full launch and the first of the next, must come out right."""
+    rs = np.random.RandomState(count)
+    descs, refs, outs = [], [], []
+    for i in range(count):
+        m, n, k = 1 + (i * 7) % 70, 1 + (i * 11) % 45, 1 + (i * 5) % 90
+        A = rs.normal(size=(m, k)).astype(np.float32)
+        B = rs.normal(size=(k, n)).astype(np.float32)
+        a_d, b_d = dev(A), dev(B)
+        c_d = torch.full((m, n), 7.0, device="cuda")
+        descs.append(eng.make_gemm(a_d, b_d, c_d, m, n, k, a_sm=k, a_sk=1, b_sk=n, b_sn=1, ldc=n))
+        refs.append(A.astype(np.float64) @ B.astype(np.float64))
+        outs.append((a_d, b_d, c_d))
+    eng.gemm_grouped(descs)
+    for i, ((_, _, c_d), ref) in enumerate(zip(outs, refs)):
+        assert rel_err(c_d.cpu().numpy(), ref) < 2e-6, i
+
+
 def test_gemm_column_sums_with_ones(eng):
     rs = np.random.RandomState(3)
     R, M = 333, 96
