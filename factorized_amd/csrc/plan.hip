@@ -210,7 +210,8 @@ static int build(MfmPlan* P) {
   // Latency path (latent.hip, row kernels): one row per workgroup while that still fits the chip in one
   // wave of workgroups and every layer meets the vector-load shape requirements.
   {
-    bool ok = c.B <= 256 && (size_t)2 * rs * sizeof(float) <= 24 * 1024 && P->n_params < (1ll << 31);
+    const int row_maxb = getenv("MFM_LATENT_ROW_MAXB") ? atoi(getenv("MFM_LATENT_ROW_MAXB")) : 256;   // tuning override
+    bool ok = c.B <= row_maxb && (size_t)2 * rs * sizeof(float) <= 24 * 1024 && P->n_params < (1ll << 31);
     for (int i = 0; i < L.nops && ok; ++i) {
       const LatOp& op = P->lat_ops[i];
       ok = (op.K % 4 == 0) && op.K >= 4 && op.K <= 128 && op.N <= 128 && (op.w_off % 4 == 0);
