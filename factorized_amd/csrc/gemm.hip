@@ -47,8 +47,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   constexpr int EPT_A = BM * BK / 256, EPT_B = BN * BK / 256;
   constexpr int ASZ = (BK * LDA > BM * LDK) ? BK * LDA : BM * LDK;
   constexpr int BSZ = (BK * LDB > BN * LDK) ? BK * LDB : BN * LDK;
-  __shared__ __attribute__((aligned(16))) float As[ASZ];
-  __shared__ __attribute__((aligned(16))) float Bs[BSZ];
+  // two LDS images per operand: while the MFMAs of K-tile kt read image kt&1, the registers of tile kt+1 are
+  // written to the other one, so a K step costs ONE barrier instead of two
+  __shared__ __attribute__((aligned(16))) float As2[2][ASZ];
+  __shared__ __attribute__((aligned(16))) float Bs2[2][BSZ];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -195,7 +197,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
     const int n = b_ncontig ? idx % BN : idx / BK;
     b_st[g] = n * b_ln + k * b_lk;
   }
-  auto store_tiles = [&](int slot) {
+  auto store_tiles = [&](int slot, int img) {
+    float* As = As2[img];
+    float* Bs = Bs2[img];
 #pragma unroll
     for (int g = 0; g < GA; ++g)
       *reinterpret_cast<f32x4*>(As + a_st[g]) = f32x4{ra[slot][4 * g], ra[slot][4 * g + 1], ra[slot][4 * g + 2], ra[slot][4 * g + 3]};
@@ -231,13 +235,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   // to zero): no branch around a load anywhere
 #pragma unroll
   for (int s = 0; s < DEPTH; ++s) load_tiles(s, kbeg + s * BK);
+  store_tiles(0, 0);
+  load_tiles(0, kbeg + DEPTH * BK);
+  lds_barrier();
+  // ring slot of K-tile kt is kt % DEPTH; slot 0 was just refilled with tile DEPTH
   for (int kt0 = 0; kt0 < nkt; kt0 += DEPTH) {
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s) {
       const int kt = kt0 + s;
-      store_tiles(s);                       // tiles beyond nkt are all-zero: harmless extra MFMAs
-      lds_barrier();
-      load_tiles(s, kbeg + (kt + DEPTH) * BK);
+      const int img = kt & 1;
+      const float* As = As2[img];
+      const float* Bs = Bs2[img];
       // operand fragments are read from LDS ahead of the MFMAs that use them: the whole tile for the 32x32
       // variant, half a tile at a time for the 64x64 one (its 4 accumulators already fill the register budget
       // that decides between 2 and 3 waves per SIMD)
@@ -259,6 +267,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
 #pragma unroll
             for (int fn = 0; fn < FR; ++fn) acc[fm][fn] = mma16x16x4(af[ks][fm], bf[ks][fn], acc[fm][fn]);
       }
+      // next tile (kt+1, ring slot (s+1) % DEPTH) into the other image, then refill that slot with tile
+      // kt+1+DEPTH; tiles beyond nkt are all-zero (clamped, masked loads): harmless
+      const int sn = (s + 1) % DEPTH;
+      store_tiles(sn, img ^ 1);
+      load_tiles(sn, kbeg + (kt + 1 + DEPTH) * BK);
       lds_barrier();
     }
   }
