@@ -57,15 +57,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   const int bi = lane & 15, q = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
 
-#pragma unroll
-  for (int zi = 0; zi < 2; ++zi) {
-    if (g.zero_n[zi] > 0) {          // 16-byte aligned, multiple of 4 floats (checked by the host)
-      f32x4* z4 = reinterpret_cast<f32x4*>(g.zero_ptr[zi]);
-      const int64_t n4 = g.zero_n[zi] >> 2;
-      for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n4; i += (int64_t)gridDim.x * 256) z4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
-
   // ---- locate problem / tile (wave-uniform)
   // Workgroups are dealt to the 8 XCDs round-robin by id, and each XCD has its own L2.  Tiles that share
   // an operand panel (same m-tile across n, same n-tile across m / gates) are neighbours in the LOGICAL
@@ -320,6 +311,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
     if (lane == 0) sqsum[wave] = sq;
     lds_barrier();
     if (tid == 0) atomicAdd(me.loss, (sqsum[0] + sqsum[1] + sqsum[2] + sqsum[3]) * me.inv_count);
+  }
+  // zero-fill spans last: ahead of the K loop these stores would sit in front of the first tile loads in the
+  // in-order vmcnt queue and put a store round trip on every workgroup's critical path
+#pragma unroll
+  for (int zi = 0; zi < 2; ++zi) {
+    if (g.zero_n[zi] > 0) {          // 16-byte aligned, multiple of 4 floats (checked by the host)
+      f32x4* z4 = reinterpret_cast<f32x4*>(g.zero_ptr[zi]);
+      const int64_t n4 = g.zero_n[zi] >> 2;
+      for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n4; i += (int64_t)gridDim.x * 256) z4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
 }
 
