@@ -102,6 +102,8 @@ class FlatLayout:
             n = int(np.prod(self.shapes[name]))
             cur = (cur + n + ALIGN - 1) // ALIGN * ALIGN
         self.offsets = OrderedDict((n, placed[n]) for n in self.shapes)
+        # (offset, numel, shape) in state_dict order: per-tensor views of any buffer with this layout
+        self.slots = [(placed[n], int(np.prod(self.shapes[n])), tuple(self.shapes[n])) for n in self.shapes]
         self.total = cur
         self.numel = sum(int(np.prod(s)) for s in self.shapes.values())
 
