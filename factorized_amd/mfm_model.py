@@ -89,6 +89,30 @@ def _hp(h):
     return (h + 15) // 16 * 16
 
 
+_ONES = {}
+
+
+def _ones(n, dev):
+    """Cached all-ones vector (the bias column sums are GEMMs against it): one fill per size, not per call."""
+    key = (int(n), str(dev))
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones(int(n), device=dev)
+    return t
+
+
+def _zeros_many(dev, *shapes):
+    """Several zero-filled tensors carved from ONE allocation (one fill launch instead of len(shapes)); each
+    starts 64-float aligned."""
+    sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+    offs, cur = [], 0
+    for n in sizes:
+        offs.append(cur)
+        cur += (n + 63) // 64 * 64
+    flat = torch.zeros(max(cur, 1), device=dev)
+    return [flat[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
+
+
 def _rows(x):
     """x [T,B,d] whose last dim is contiguous and whose (t,b) rows have ONE uniform stride
     (a column slice of a contiguous [T,B,D] batch, reference mfm_model.py:620-622) ->
@@ -134,9 +158,10 @@ class _EncoderSeqFn(torch.autograd.Function):
         d_out = d_out.contiguous()
         n_out = fc_w.shape[0]
         h_last = hs[T - 1]
-        g_fcw = torch.zeros_like(fc_w); g_fcb = torch.zeros(n_out, device=dev)
+        g_fcw, g_fcb, g_wih, g_whh, g_bih, g_bhh = _zeros_many(dev, fc_w.shape, (n_out,), w_ih.shape, w_hh.shape,
+                                                               (4 * h,), (4 * h,))
         dh_last = torch.empty(B, h, device=dev)
-        ones = torch.ones(max(T * B, B), device=dev)
+        ones = _ones(max(T * B, B), dev)
         E.gemm_grouped([
             E.make_gemm(d_out, fc_w, dh_last, B, h, n_out, a_sm=n_out, a_sk=1, b_sk=h, b_sn=1, ldc=h),
             E.make_gemm(d_out, h_last, g_fcw, n_out, h, B, a_sm=1, a_sk=n_out, b_sk=Hp, b_sn=1, ldc=h,
@@ -144,8 +169,6 @@ class _EncoderSeqFn(torch.autograd.Function):
             E.make_gemm(d_out, ones, g_fcb, n_out, 1, B, a_sm=1, a_sk=n_out, b_sk=1, b_sn=1, ldc=1,
                         accumulate=1, split_k=0)])
         E.lstm_seq([E.make_seq(gates, hs, cs, w_hh, h, dh_ext=dh_last, ld_dh=h)], T, B, backward=True)
-        g_wih = torch.zeros_like(w_ih); g_whh = torch.zeros_like(w_hh)
-        g_bih = torch.zeros(4 * h, device=dev); g_bhh = torch.zeros(4 * h, device=dev)
         descs = [E.make_gemm(gates, xr, g_wih, h, d, T * B, a_sm=1, a_sk=4 * Hp, b_sk=ldx, b_sn=1, ldc=d,
                              batch=4, a_sz=Hp, c_sz=h * d, accumulate=1, split_k=0),
                  E.make_gemm(gates, ones, g_bih, h, 1, T * B, a_sm=1, a_sk=4 * Hp, b_sk=1, b_sn=1, ldc=1,
@@ -204,8 +227,9 @@ class _DecoderSeqFn(torch.autograd.Function):
         dev = d_out.device
         d_out = d_out.contiguous()
         dhs = torch.empty(T, B, Hp, device=dev)
-        g_fcw = torch.zeros_like(fc_w); g_fcb = torch.zeros(d, device=dev)
-        ones = torch.ones(T * B, device=dev)
+        g_fcw, g_fcb, g_wih, g_whh, g_bih, g_bhh = _zeros_many(dev, fc_w.shape, (d,), w_ih.shape, w_hh.shape,
+                                                               (4 * h,), (4 * h,))
+        ones = _ones(T * B, dev)
         E.gemm_grouped([
             E.make_gemm(d_out, fc_w, dhs, T * B, Hp, d, a_sm=d, a_sk=1, b_sk=h, b_sn=1, ldc=Hp, n_valid=h),
             E.make_gemm(d_out, hs, g_fcw, d, h, T * B, a_sm=1, a_sk=d, b_sk=Hp, b_sn=1, ldc=h,
@@ -215,8 +239,6 @@ class _DecoderSeqFn(torch.autograd.Function):
         d_hT = torch.empty(B, h, device=dev)
         E.lstm_seq([E.make_seq(gates, hs, cs, w_hh, h, w_ih=w_ih, b_ih=b_ih, b_hh=b_hh, h_init=hT, is_dec=True,
                                dh_ext=dhs, ld_dh=Hp, d_h_init=d_hT)], T, B, backward=True)
-        g_wih = torch.zeros_like(w_ih); g_whh = torch.zeros_like(w_hh)
-        g_bih = torch.zeros(4 * h, device=dev); g_bhh = torch.zeros(4 * h, device=dev)
         descs = [E.make_gemm(gates, hT, g_wih, h, h, B, a_sm=1, a_sk=4 * Hp, b_sk=h, b_sn=1, ldc=h,
                              batch=4, a_sz=Hp, c_sz=h * h, accumulate=1, split_k=0),
                  E.make_gemm(gates, ones, g_bih, h, 1, T * B, a_sm=1, a_sk=4 * Hp, b_sk=1, b_sn=1, ldc=1,
@@ -390,9 +412,8 @@ class _LinearFn(torch.autograd.Function):
         dy2 = dy.reshape(M, N).contiguous().float()
         dev = dy.device
         dx = torch.empty(M, K, device=dev)
-        dw = torch.zeros_like(w)
-        db = torch.zeros(N, device=dev)
-        ones = torch.ones(M, device=dev)
+        dw, db = _zeros_many(dev, w.shape, (N,))
+        ones = _ones(M, dev)
         E.gemm_grouped([
             E.make_gemm(dy2, w, dx, M, K, N, a_sm=N, a_sk=1, b_sk=K, b_sn=1, ldc=K),
             E.make_gemm(dy2, x2, dw, N, K, M, a_sm=1, a_sk=N, b_sk=K, b_sn=1, ldc=K, accumulate=1, split_k=0),
@@ -466,10 +487,9 @@ class _MemFn(torch.autograd.Function):
                          dmem=dm, du1=du1, du2=du2, dchat=dchat)
         _lib.check(_lib.lib().mfm_mfn_mem_bwd(C.byref(d), E._stream()), "mfm_mfn_mem_bwd")
         TB = T * B
-        dw1b, dw2b = torch.zeros_like(w1b), torch.zeros_like(w2b)
-        db1b, db2b = torch.zeros_like(b1b), torch.zeros_like(b2b)
-        dw1m, dw2m = torch.zeros_like(w1m), torch.zeros_like(w2m)
-        ones = torch.ones(TB, device=dev)
+        dw1b, dw2b, db1b, db2b, dw1m, dw2m = _zeros_many(dev, w1b.shape, w2b.shape, b1b.shape, b2b.shape, w1m.shape,
+                                                         w2m.shape)
+        ones = _ones(TB, dev)
         g = [
             # gamma_n_fc2: dW[m, j] = sum_r dz[r, m] a[r, j] ; db[m] = sum_r dz[r, m]
             E.make_gemm(dz1, a1, dw1b, M, H1, TB, a_sm=1, a_sk=M, b_sk=H1, b_sn=1, ldc=H1, accumulate=1, split_k=0),
@@ -526,9 +546,8 @@ class _LstmSeqStatesFn(torch.autograd.Function):
         if d_cs is not None:
             dc[:, :, :h] = d_cs
         E.lstm_seq([E.make_seq(gates, hs, cs, w_hh, h, dh_ext=dh, ld_dh=h, dc_ext=dc)], T, B, backward=True)
-        g_wih = torch.zeros_like(w_ih); g_whh = torch.zeros_like(w_hh)
-        g_bih = torch.zeros(4 * h, device=dev); g_bhh = torch.zeros(4 * h, device=dev)
-        ones = torch.ones(T * B, device=dev)
+        g_wih, g_whh, g_bih, g_bhh = _zeros_many(dev, w_ih.shape, w_hh.shape, (4 * h,), (4 * h,))
+        ones = _ones(T * B, dev)
         descs = [E.make_gemm(gates, xr, g_wih, h, d, T * B, a_sm=1, a_sk=4 * Hp, b_sk=ldx, b_sn=1, ldc=d,
                              batch=4, a_sz=Hp, c_sz=h * d, accumulate=1, split_k=0),
                  E.make_gemm(gates, ones, g_bih, h, 1, T * B, a_sm=1, a_sk=4 * Hp, b_sk=1, b_sn=1, ldc=1,
