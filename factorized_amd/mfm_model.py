@@ -505,6 +505,59 @@ class _MemFn(torch.autograd.Function):
         return du1, du2, dchat, dw1m, dw2m, dw1b, db1b, dw2b, db2b, None, None, None
 
 
+class _GroupLinearFn(torch.autograd.Function):
+    """n independent Linears (their own inputs, weights, biases) as ONE grouped GEMM launch forward and one
+    backward: the factorized model has 4-8 of them side by side at three places (mu/logvar heads, z->f fc1,
+    fc2), and at these sizes a launch plus an autograd node cost more than the product."""
+
+    @staticmethod
+    def forward(ctx, n, *args):
+        xs, ws, bs = args[:n], args[n:2 * n], args[2 * n:3 * n]
+        x2s, ys, descs = [], [], []
+        for x, w, b in zip(xs, ws, bs):
+            x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
+            M, K = x2.shape
+            N = w.shape[0]
+            y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+            descs.append(E.make_gemm(x2, w, y, M, N, K, a_sm=K, a_sk=1, b_sk=1, b_sn=K, ldc=N, bias=b))
+            x2s.append(x2); ys.append(y)
+        E.gemm_grouped(descs)
+        ctx.n = n
+        ctx.shapes = [tuple(x.shape) for x in xs]
+        ctx.save_for_backward(*x2s, *ws)
+        return tuple(y.reshape(shp[:-1] + (y.shape[1],)) for y, shp in zip(ys, ctx.shapes))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n = ctx.n
+        x2s, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        dev = x2s[0].device
+        zs = _zeros_many(dev, *([tuple(w.shape) for w in ws] + [(w.shape[0],) for w in ws]))
+        dws, dbs = zs[:n], zs[n:]
+        dxs, descs = [], []
+        for i in range(n):
+            x2, w = x2s[i], ws[i]
+            M, K = x2.shape
+            N = w.shape[0]
+            dy2 = dys[i].reshape(M, N).contiguous().float() if dys[i] is not None else torch.zeros(M, N, device=dev)
+            dx = torch.empty(M, K, device=dev)
+            dxs.append(dx)
+            descs += [E.make_gemm(dy2, w, dx, M, K, N, a_sm=N, a_sk=1, b_sk=K, b_sn=1, ldc=K),
+                      E.make_gemm(dy2, x2, dws[i], N, K, M, a_sm=1, a_sk=N, b_sk=K, b_sn=1, ldc=K, accumulate=1, split_k=0),
+                      E.make_gemm(dy2, _ones(M, dev), dbs[i], N, 1, M, a_sm=1, a_sk=N, b_sk=1, b_sn=1, ldc=1, accumulate=1, split_k=0)]
+        E.gemm_grouped(descs)
+        return (None,) + tuple(dx.reshape(shp) for dx, shp in zip(dxs, ctx.shapes)) + tuple(dws) + tuple(dbs)
+
+
+def linear_group(pairs):
+    """[(x, HipLinear), ...] -> [y, ...] in one launch."""
+    if os.environ.get("MFM_NO_GROUP_LINEAR"):          # A/B timing only
+        return [l(x) for x, l in pairs]
+    n = len(pairs)
+    xs = [x for x, _ in pairs]
+    return list(_GroupLinearFn.apply(n, *xs, *[l.weight for _, l in pairs], *[l.bias for _, l in pairs]))
+
+
 class HipLinear(nn.Linear):
     """nn.Linear (same parameters / state_dict keys) whose matmuls run on the HIP GEMM."""
 
@@ -701,23 +754,26 @@ class _FactorizedMFN(nn.Module):
         za_last = self.encoder_a.forward(x_a)
         zv_last = self.encoder_v.forward(x_v)
         mfn_last = self.mfn_encoder.forward(x)
-        zy = self.last_to_zy_fc1(mfn_last)
         if self._use_kl:
-            zl = self.last_to_zl_fc1(zl_last)
-            za = self.last_to_za_fc1(za_last)
-            zv = self.last_to_zv_fc1(zv_last)
-            reg = loss_KLD(zl, self.last_to_logvarzl_fc1(zl_last)) + loss_KLD(za, self.last_to_logvarza_fc1(za_last)) \
-                + loss_KLD(zv, self.last_to_logvarzv_fc1(zv_last)) + loss_KLD(zy, self.last_to_logvarzy_fc1(mfn_last))
+            zy, zl, za, zv, lvy, lvl, lva, lvv = linear_group([
+                (mfn_last, self.last_to_zy_fc1), (zl_last, self.last_to_zl_fc1), (za_last, self.last_to_za_fc1),
+                (zv_last, self.last_to_zv_fc1), (mfn_last, self.last_to_logvarzy_fc1),
+                (zl_last, self.last_to_logvarzl_fc1), (za_last, self.last_to_logvarza_fc1),
+                (zv_last, self.last_to_logvarzv_fc1)])
+            reg = loss_KLD(zl, lvl) + loss_KLD(za, lva) + loss_KLD(zv, lvv) + loss_KLD(zy, lvy)
         else:
+            zy = self.last_to_zy_fc1(mfn_last)
             zl, za, zv = zl_last, za_last, zv_last
             g = self.mmd_gauss if self.mmd_gauss is not None else [None] * 4
             reg = loss_MMD(zl, g[0]) + loss_MMD(za, g[1]) + loss_MMD(zv, g[2]) + loss_MMD(zy, g[3])
         missing_loss = 0.0
         relu = torch.relu
-        fy = relu(self.zy_to_fy_fc2(self.zy_to_fy_dropout(relu(self.zy_to_fy_fc1(zy)))))
-        fl = relu(self.zl_to_fl_fc2(self.zl_to_fl_dropout(relu(self.zl_to_fl_fc1(zl)))))
-        fa = relu(self.za_to_fa_fc2(self.za_to_fa_dropout(relu(self.za_to_fa_fc1(za)))))
-        fv = relu(self.zv_to_fv_fc2(self.zv_to_fv_dropout(relu(self.zv_to_fv_fc1(zv)))))
+        h1 = linear_group([(zy, self.zy_to_fy_fc1), (zl, self.zl_to_fl_fc1), (za, self.za_to_fa_fc1),
+                           (zv, self.zv_to_fv_fc1)])
+        drops = (self.zy_to_fy_dropout, self.zl_to_fl_dropout, self.za_to_fa_dropout, self.zv_to_fv_dropout)
+        h1 = [dr(relu(v)) for v, dr in zip(h1, drops)]
+        fy, fl, fa, fv = [relu(v) for v in linear_group([(h1[0], self.zy_to_fy_fc2), (h1[1], self.zl_to_fl_fc2),
+                                                          (h1[2], self.za_to_fa_fc2), (h1[3], self.zv_to_fv_fc2)])]
         x_l_hat = self.decoder_l.forward(torch.cat([fy, fl], dim=1), t)
         x_a_hat = self.decoder_a.forward(torch.cat([fy, fa], dim=1), t)
         x_v_hat = self.decoder_v.forward(torch.cat([fy, fv], dim=1), t)
