@@ -74,6 +74,13 @@ _SIGS = {
                                   C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mfm_adam_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "mfm_p2p_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
+    "mfm_p2p_handle_bytes": (C.c_int, []),
+    "mfm_p2p_export": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mfm_p2p_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mfm_p2p_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mfm_p2p_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "mfm_p2p_destroy": (None, [C.c_void_p]),
     "mfm_plan_create": (C.c_int, [C.POINTER(PlanConfig), C.POINTER(C.c_int64), C.c_int64,
                                   C.POINTER(C.c_void_p)]),
     "mfm_plan_destroy": (None, [C.c_void_p]),

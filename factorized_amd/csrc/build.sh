@@ -8,7 +8,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function ${MFM_EXTRA_FLAGS:-}"
 mkdir -p "$HERE/build"
 pids=()
-for f in gemm lstm_seq lstm_seq_small lstm_step latent mfn_mem mmd elementwise plan; do
+for f in gemm lstm_seq lstm_seq_small lstm_step latent mfn_mem mmd p2p elementwise plan; do
   extra=""
   # the SLP vectoriser packs the recurrent FMAs into v_pk_fma_f32, whose even-aligned register
   # pairs push the weight-resident LSTM kernels over their VGPR budget (spills in the time loop)

@@ -1,0 +1,248 @@
+// Gradient all-reduce of the data-parallel step as ONE kernel over peer-mapped staging buffers (xGMI),
+// one process per GPU ("RCCL allReduce(sum) over xGMI (or the direct one-shot P2P
+// variant)").  The flat gradient buffer is 1.9 MB: a ring all-reduce at that size is all latency
+// (2(W-1) hops), while every MI355X has a direct link to each of its 7 peers, so a two-shot exchange
+// moves 1/W of the buffer over each link twice and needs two flag rounds:
+//
+//   push 1   rank r writes slice s of its gradients into rank s's staging row r            (7 links, 1/W each)
+//   reduce   rank s sums its W staging rows in rank order (every slice is summed exactly once, by its
+//            owner, so all ranks end with bit-identical results)
+//   push 2   rank s writes the reduced slice into every peer's result row s and into its own buffer
+//   gather   every rank copies the W-1 foreign result rows into its gradient buffer
+//
+// Synchronisation is workgroup-to-workgroup, not grid-wide: workgroup w of every rank owns chunk w of every
+// slice, signals `flag[r][w] = epoch` at the receiving rank after a system-scope release fence, and waits
+// only for the W flags of its own chunk.  The staging block is device memory allocated uncached
+// (hipDeviceMallocUncached) so that peer writes are never shadowed by a stale L2 line, and exported to the
+// other processes with hipIpcGetMemHandle.  Waits are bounded by the wall clock: a rank that never arrives
+// makes the others give up, set an error word and return, instead of hanging the GPU.
+//
+// Reuse of the rows across calls needs no double buffering: a rank can only start epoch e+1's push of chunk
+// w after it has seen every owner's epoch-e result flag for chunk w, which the owner raises after reading
+// its staging rows; and an owner's epoch-e+1 result push comes after every rank's epoch-e+1 first push,
+// hence after that rank finished copying the epoch-e result rows.
+#include <stdlib.h>
+#include <string.h>
+
+#include "internal.h"
+
+namespace mfm {
+
+constexpr int P2P_MAXR = 8;
+constexpr int P2P_WGS = 64;
+constexpr int P2P_THREADS = 512;
+
+struct P2PDev {
+  float* stage[P2P_MAXR];   // per rank: [W][SL] rows written by the peers (own entry = local pointer)
+  float* res[P2P_MAXR];     // per rank: [W][SL] reduced slices
+  int* f1[P2P_MAXR];        // per rank: [W][P2P_WGS] epoch of the last complete first push
+  int* f2[P2P_MAXR];        // per rank: [W][P2P_WGS] epoch of the last complete result push
+  int* err;                 // local error word
+  int W, rank;
+  int64_t SL, CL;           // slice length, chunk length (floats, multiples of 4)
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 load4_bounded(const float* p, int64_t idx, int64_t n) {
+  if (idx + 4 <= n) return *reinterpret_cast<const f32x4*>(p + idx);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < 4; ++c)
+    if (idx + c < n) v[c] = p[idx + c];
+  return v;
+}
+__device__ __forceinline__ void store4_bounded(float* p, int64_t idx, int64_t n, f32x4 v) {
+  if (idx + 4 <= n) { *reinterpret_cast<f32x4*>(p + idx) = v; return; }
+  for (int c = 0; c < 4; ++c)
+    if (idx + c < n) p[idx + c] = v[c];
+}
+
+// thread t < W waits until flags[t] reaches `epoch`; returns after a block barrier + acquire fence
+__device__ __forceinline__ void wait_flags(const int* flags, int stride, int W, int epoch, int64_t timeout, int* err) {
+  if ((int)threadIdx.x < W) {
+    const int* f = flags + (int64_t)threadIdx.x * stride;
+    const int64_t t0 = wall_clock64();
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+      __builtin_amdgcn_s_sleep(2);
+      // give up after `timeout`, and at once when an earlier wait of this rank already did
+      if (wall_clock64() - t0 > timeout || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        atomicExch(err, 1);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+__global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev d, float* __restrict__ buf, int64_t n, int epoch,
+                                                                   int64_t timeout) {
+  const int w = blockIdx.x, tid = threadIdx.x;
+  const int W = d.W, me = d.rank;
+  const int64_t SL = d.SL, CL = d.CL, cb = (int64_t)w * CL;
+  // ---- push 1: my chunk w of every slice -> the slice owner's staging row `me`
+  for (int i = 0; i < W; ++i) {
+    const int s = (me + 1 + i) % W;                       // start at the next rank: spreads the links
+    float* dst = d.stage[s] + (int64_t)me * SL + cb;
+    for (int64_t k = (int64_t)tid * 4; k < CL && cb + k < SL; k += P2P_THREADS * 4)
+      *reinterpret_cast<f32x4*>(dst + k) = load4_bounded(buf, (int64_t)s * SL + cb + k, n);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  __syncthreads();
+  if (tid < W) __hip_atomic_store(d.f1[tid] + me * P2P_WGS + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // ---- reduce my slice's chunk in rank order, push 2: the result -> every rank's result row `me`
+  wait_flags(d.f1[me] + w, P2P_WGS, W, epoch, timeout, d.err);
+  for (int64_t k = (int64_t)tid * 4; k < CL && cb + k < SL; k += P2P_THREADS * 4) {
+    const float* src = d.stage[me] + cb + k;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(src);
+    for (int r = 1; r < W; ++r) acc += *reinterpret_cast<const f32x4*>(src + (int64_t)r * SL);
+    for (int i = 1; i < W; ++i) {
+      const int p = (me + i) % W;
+      *reinterpret_cast<f32x4*>(d.res[p] + (int64_t)me * SL + cb + k) = acc;
+    }
+    store4_bounded(buf, (int64_t)me * SL + cb + k, n, acc);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  __syncthreads();
+  if (tid < W) __hip_atomic_store(d.f2[tid] + me * P2P_WGS + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // ---- gather: foreign result rows -> my gradient buffer
+  wait_flags(d.f2[me] + w, P2P_WGS, W, epoch, timeout, d.err);
+  for (int i = 1; i < W; ++i) {
+    const int s = (me + i) % W;
+    const float* src = d.res[me] + (int64_t)s * SL + cb;
+    for (int64_t k = (int64_t)tid * 4; k < CL && cb + k < SL; k += P2P_THREADS * 4)
+      store4_bounded(buf, (int64_t)s * SL + cb + k, n, *reinterpret_cast<const f32x4*>(src + k));
+  }
+}
+
+struct P2P {
+  P2PDev d;
+  void* local = nullptr;
+  void* peer[P2P_MAXR] = {};
+  size_t bytes = 0, off_res = 0, off_f1 = 0, off_f2 = 0, off_err = 0;
+  int64_t max_elems = 0;
+  int epoch = 0;
+  int64_t timeout_ticks = 0;
+  bool connected = false;
+};
+
+static void p2p_point(P2P* h, int r, void* base) {
+  char* b = static_cast<char*>(base);
+  h->d.stage[r] = reinterpret_cast<float*>(b);
+  h->d.res[r] = reinterpret_cast<float*>(b + h->off_res);
+  h->d.f1[r] = reinterpret_cast<int*>(b + h->off_f1);
+  h->d.f2[r] = reinterpret_cast<int*>(b + h->off_f2);
+}
+
+}  // namespace mfm
+
+using namespace mfm;
+
+extern "C" {
+
+int mfm_p2p_create(int32_t nranks, int32_t rank, int64_t max_elems, void** handle) {
+  if (!handle || nranks < 1 || nranks > P2P_MAXR || rank < 0 || rank >= nranks || max_elems < 1) {
+    set_error("mfm_p2p_create: need 1 <= nranks <= %d, 0 <= rank < nranks, max_elems >= 1", P2P_MAXR);
+    return MFM_ERR_ARG;
+  }
+  P2P* h = new P2P();
+  h->max_elems = max_elems;
+  h->d.W = nranks;
+  h->d.rank = rank;
+  const int64_t per = (max_elems + nranks - 1) / nranks;
+  h->d.CL = ((per + P2P_WGS - 1) / P2P_WGS + 3) / 4 * 4;
+  h->d.SL = ((per + 3) / 4) * 4;
+  auto up = [](size_t v) { return (v + 4095) / 4096 * 4096; };
+  const size_t rows = up((size_t)nranks * h->d.SL * sizeof(float));
+  const size_t flags = up((size_t)nranks * P2P_WGS * sizeof(int));
+  h->off_res = rows;
+  h->off_f1 = 2 * rows;
+  h->off_f2 = 2 * rows + flags;
+  h->off_err = 2 * rows + 2 * flags;
+  h->bytes = h->off_err + 4096;
+  hipError_t e = hipExtMallocWithFlags(&h->local, h->bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipExtMallocWithFlags(&h->local, h->bytes, hipDeviceMallocFinegrained);
+  }
+  if (e != hipSuccess) { delete h; return hip_fail(e, "mfm_p2p_create: staging allocation"); }
+  e = hipMemset(h->local, 0, h->bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) { (void)hipFree(h->local); delete h; return hip_fail(e, "mfm_p2p_create: memset"); }
+  p2p_point(h, rank, h->local);
+  h->peer[rank] = h->local;
+  h->d.err = reinterpret_cast<int*>(static_cast<char*>(h->local) + h->off_err);
+  const char* t = getenv("MFM_P2P_TIMEOUT_MS");
+  const double ms = t ? atof(t) : 10000.0;
+  h->timeout_ticks = (int64_t)(ms * 1e5);               // wall_clock64 ticks at 100 MHz
+  h->connected = (nranks == 1);
+  *handle = h;
+  return MFM_OK;
+}
+
+int mfm_p2p_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+
+int mfm_p2p_export(void* handle, void* out) {
+  P2P* h = static_cast<P2P*>(handle);
+  if (!h || !out) { set_error("mfm_p2p_export: null argument"); return MFM_ERR_ARG; }
+  hipIpcMemHandle_t ipc;
+  hipError_t e = hipIpcGetMemHandle(&ipc, h->local);
+  if (e != hipSuccess) return hip_fail(e, "hipIpcGetMemHandle");
+  memcpy(out, &ipc, sizeof(ipc));
+  return MFM_OK;
+}
+
+int mfm_p2p_connect(void* handle, const void* all_handles) {
+  P2P* h = static_cast<P2P*>(handle);
+  if (!h || !all_handles) { set_error("mfm_p2p_connect: null argument"); return MFM_ERR_ARG; }
+  // (peer access to a block that lives on another GPU is enabled by the open call itself)
+  for (int r = 0; r < h->d.W; ++r) {
+    if (r == h->d.rank) continue;
+    hipIpcMemHandle_t ipc;
+    memcpy(&ipc, static_cast<const char*>(all_handles) + (size_t)r * sizeof(ipc), sizeof(ipc));
+    void* base = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&base, ipc, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return hip_fail(e, "hipIpcOpenMemHandle");
+    h->peer[r] = base;
+    p2p_point(h, r, base);
+  }
+  h->connected = true;
+  return MFM_OK;
+}
+
+int mfm_p2p_allreduce(void* handle, float* buf, int64_t n, void* stream) {
+  P2P* h = static_cast<P2P*>(handle);
+  if (!h || !buf) { set_error("mfm_p2p_allreduce: null argument"); return MFM_ERR_ARG; }
+  if (!h->connected) { set_error("mfm_p2p_allreduce: mfm_p2p_connect has not been called"); return MFM_ERR_ARG; }
+  if (n < 0 || n > h->max_elems) { set_error("mfm_p2p_allreduce: n=%lld exceeds max_elems=%lld", (long long)n, (long long)h->max_elems); return MFM_ERR_ARG; }
+  if ((reinterpret_cast<uintptr_t>(buf) & 15) != 0) { set_error("mfm_p2p_allreduce: buffer must be 16-byte aligned"); return MFM_ERR_ARG; }
+  if (n == 0 || h->d.W == 1) return MFM_OK;
+  h->epoch += 1;
+  hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(P2P_WGS), dim3(P2P_THREADS), 0, static_cast<hipStream_t>(stream), h->d, buf, n,
+                     h->epoch, h->timeout_ticks);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "p2p_allreduce_kernel launch");
+  return MFM_OK;
+}
+
+int mfm_p2p_status(void* handle, int32_t* timed_out) {
+  P2P* h = static_cast<P2P*>(handle);
+  if (!h || !timed_out) { set_error("mfm_p2p_status: null argument"); return MFM_ERR_ARG; }
+  int v = 0;
+  hipError_t e = hipMemcpy(&v, h->d.err, sizeof(int), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return hip_fail(e, "mfm_p2p_status: read-back");
+  *timed_out = v;
+  return MFM_OK;
+}
+
+void mfm_p2p_destroy(void* handle) {
+  P2P* h = static_cast<P2P*>(handle);
+  if (!h) return;
+  (void)hipDeviceSynchronize();
+  for (int r = 0; r < h->d.W; ++r)
+    if (r != h->d.rank && h->peer[r]) (void)hipIpcCloseMemHandle(h->peer[r]);
+  if (h->local) (void)hipFree(h->local);
+  delete h;
+}
+
+}  // extern "C"

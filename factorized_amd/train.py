@@ -50,20 +50,23 @@ class DeviceDataset:
 class DataParallelStep:
     """step(x, y): fused single-GPU step, or fwd/bwd + all-reduce + Adam when world > 1."""
 
-    def __init__(self, engine, world=1, lr=1e-3):
+    def __init__(self, engine, world=1, lr=1e-3, allreduce=None):
         self.e = engine
         self.world = world
         self.lr = lr
+        self.allreduce = allreduce            # comm.make_allreduce(...); default torch.distributed (RCCL)
         if world > 1:
             engine.reg_scale = float(world)
+            if allreduce is None:
+                from . import comm
+                self.allreduce = comm.TorchAllReduce()
 
     def step(self, x, y):
         e = self.e
         if self.world == 1:
             return e.train_step(x, y, lr=self.lr, check=False)
-        import torch.distributed as dist
-        losses = e.grad_step(x, y, check=False)           # fwd + bwd: one enqueue, 11 launches
-        dist.all_reduce(e.grads)                          # one flat buffer, one collective
+        losses = e.grad_step(x, y, check=False)           # fwd + bwd: one enqueue, 10 launches
+        self.allreduce(e.grads)                           # one flat buffer, one collective
         e.adam(lr=self.lr, grad_scale=1.0 / self.world)
         return losses
 

@@ -156,6 +156,24 @@ int mfm_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, int32
                   float beta1, float beta2, float eps, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Gradient all-reduce of the data-parallel step (the reference has no multi-GPU
+ * path): in-place fp32 sum of one flat buffer over all ranks of one node, ONE kernel launch on the
+ * caller's stream, no host synchronisation.  Ranks are one process per GPU; every rank owns an uncached
+ * staging block that its peers map through HIP IPC and write over xGMI (two-shot: scatter-reduce + gather,
+ * csrc/p2p.hip).  Every slice is summed once, by its owner, in rank order: all ranks receive bit-identical
+ * results.  Set-up: create on every rank -> export 64-byte handle -> exchange the handles out of band
+ * (factorized_amd/comm.py uses torch.distributed.all_gather_object) -> connect -> barrier.
+ * Waits inside the kernel are bounded (MFM_P2P_TIMEOUT_MS, default 10000): a missing peer raises the
+ * flag read by mfm_p2p_status instead of hanging the device. */
+int mfm_p2p_create(int32_t nranks /*<=8*/, int32_t rank, int64_t max_elems, void** handle);
+int mfm_p2p_handle_bytes(void);
+int mfm_p2p_export(void* handle, void* out /*mfm_p2p_handle_bytes()*/);
+int mfm_p2p_connect(void* handle, const void* all_handles /*nranks x mfm_p2p_handle_bytes(), rank order*/);
+int mfm_p2p_allreduce(void* handle, float* buf /*16-byte aligned*/, int64_t n /*<= max_elems*/, void* stream);
+int mfm_p2p_status(void* handle, int32_t* timed_out /*1 if any wait gave up since create (synchronises)*/);
+void mfm_p2p_destroy(void* handle);
+
+/* ------------------------------------------------------------------------------------------
  * The fused MFM_KL_EF training / inference plan (mfm_model.py:557-660 + mfm_mosi.py:424-442).
  * One call enqueues the whole step: input projections -> 4 encoder recurrences -> latent
  * heads/MLPs/classifier + KLD + L1|CE -> 3 decoder recurrences -> fc1 + MSE -> full backward
