@@ -78,6 +78,8 @@ _SIGS = {
     "mfm_p2p_handle_bytes": (C.c_int, []),
     "mfm_p2p_export": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mfm_p2p_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mfm_p2p_local_base": (C.c_void_p, [C.c_void_p]),
+    "mfm_p2p_connect_bases": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "mfm_p2p_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mfm_p2p_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "mfm_p2p_destroy": (None, [C.c_void_p]),

@@ -71,8 +71,25 @@ __device__ __forceinline__ void wait_flags(const int* flags, int stride, int W, 
       }
     }
   }
+  // one acquire per workgroup (the wave that polled): it invalidates this CU's vector L1 and the L2's
+  // non-coherent lines; the staging block itself is uncached, so this is insurance, not the mechanism
+#ifndef P2P_EXPERIMENT_NO_SYSTEM_FENCE
+  if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+#endif
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+// every wave waits for its own stores to be acknowledged, then ONE wave does the system-scope release (an L2
+// write-back on gfx950: once per workgroup, not once per wave) and raises the flags
+__device__ __forceinline__ void publish(int* const* flags, int slot, int W, int epoch) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x < 64) {
+#ifndef P2P_EXPERIMENT_NO_SYSTEM_FENCE
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+#endif
+    if ((int)threadIdx.x < W) __hip_atomic_store(flags[threadIdx.x] + slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev d, float* __restrict__ buf, int64_t n, int epoch,
@@ -80,38 +97,56 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev
   const int w = blockIdx.x, tid = threadIdx.x;
   const int W = d.W, me = d.rank;
   const int64_t SL = d.SL, CL = d.CL, cb = (int64_t)w * CL;
+  // All loops over ranks are unrolled to P2P_MAXR with clamped indices and predicated stores: the loads of
+  // one pass are then issued back to back instead of one dependent round trip per rank.
   // ---- push 1: my chunk w of every slice -> the slice owner's staging row `me`
-  for (int i = 0; i < W; ++i) {
-    const int s = (me + 1 + i) % W;                       // start at the next rank: spreads the links
-    float* dst = d.stage[s] + (int64_t)me * SL + cb;
-    for (int64_t k = (int64_t)tid * 4; k < CL && cb + k < SL; k += P2P_THREADS * 4)
-      *reinterpret_cast<f32x4*>(dst + k) = load4_bounded(buf, (int64_t)s * SL + cb + k, n);
+  for (int64_t k = (int64_t)tid * 4; k < CL && cb + k < SL; k += P2P_THREADS * 4) {
+    f32x4 v[P2P_MAXR];
+#pragma unroll
+    for (int i = 0; i < P2P_MAXR; ++i) {
+      const int s = (me + 1 + min(i, W - 1)) % W;         // start at the next rank: spreads the links
+      v[i] = load4_bounded(buf, (int64_t)s * SL + cb + k, n);
+    }
+#pragma unroll
+    for (int i = 0; i < P2P_MAXR; ++i) {
+      const int s = (me + 1 + min(i, W - 1)) % W;
+      if (i < W) *reinterpret_cast<f32x4*>(d.stage[s] + (int64_t)me * SL + cb + k) = v[i];
+    }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  __syncthreads();
-  if (tid < W) __hip_atomic_store(d.f1[tid] + me * P2P_WGS + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  publish(d.f1, me * P2P_WGS + w, W, epoch);
   // ---- reduce my slice's chunk in rank order, push 2: the result -> every rank's result row `me`
   wait_flags(d.f1[me] + w, P2P_WGS, W, epoch, timeout, d.err);
   for (int64_t k = (int64_t)tid * 4; k < CL && cb + k < SL; k += P2P_THREADS * 4) {
     const float* src = d.stage[me] + cb + k;
-    f32x4 acc = *reinterpret_cast<const f32x4*>(src);
-    for (int r = 1; r < W; ++r) acc += *reinterpret_cast<const f32x4*>(src + (int64_t)r * SL);
-    for (int i = 1; i < W; ++i) {
-      const int p = (me + i) % W;
-      *reinterpret_cast<f32x4*>(d.res[p] + (int64_t)me * SL + cb + k) = acc;
+    f32x4 v[P2P_MAXR];
+#pragma unroll
+    for (int r = 0; r < P2P_MAXR; ++r) v[r] = *reinterpret_cast<const f32x4*>(src + (int64_t)min(r, W - 1) * SL);
+    f32x4 acc = v[0];
+#pragma unroll
+    for (int r = 1; r < P2P_MAXR; ++r)
+      if (r < W) acc += v[r];
+#pragma unroll
+    for (int i = 1; i < P2P_MAXR; ++i) {
+      const int p = (me + min(i, W - 1)) % W;
+      if (i < W) *reinterpret_cast<f32x4*>(d.res[p] + (int64_t)me * SL + cb + k) = acc;
     }
     store4_bounded(buf, (int64_t)me * SL + cb + k, n, acc);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-  __syncthreads();
-  if (tid < W) __hip_atomic_store(d.f2[tid] + me * P2P_WGS + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  publish(d.f2, me * P2P_WGS + w, W, epoch);
   // ---- gather: foreign result rows -> my gradient buffer
   wait_flags(d.f2[me] + w, P2P_WGS, W, epoch, timeout, d.err);
-  for (int i = 1; i < W; ++i) {
-    const int s = (me + i) % W;
-    const float* src = d.res[me] + (int64_t)s * SL + cb;
-    for (int64_t k = (int64_t)tid * 4; k < CL && cb + k < SL; k += P2P_THREADS * 4)
-      store4_bounded(buf, (int64_t)s * SL + cb + k, n, *reinterpret_cast<const f32x4*>(src + k));
+  for (int64_t k = (int64_t)tid * 4; k < CL && cb + k < SL; k += P2P_THREADS * 4) {
+    f32x4 v[P2P_MAXR];
+#pragma unroll
+    for (int i = 1; i < P2P_MAXR; ++i) {
+      const int s = (me + min(i, W - 1)) % W;
+      v[i] = *reinterpret_cast<const f32x4*>(d.res[me] + (int64_t)s * SL + cb + k);
+    }
+#pragma unroll
+    for (int i = 1; i < P2P_MAXR; ++i) {
+      const int s = (me + min(i, W - 1)) % W;
+      if (i < W) store4_bounded(buf, (int64_t)s * SL + cb + k, n, v[i]);
+    }
   }
 }
 
@@ -205,6 +240,23 @@ int mfm_p2p_connect(void* handle, const void* all_handles) {
     if (e != hipSuccess) return hip_fail(e, "hipIpcOpenMemHandle");
     h->peer[r] = base;
     p2p_point(h, r, base);
+  }
+  h->connected = true;
+  return MFM_OK;
+}
+
+void* mfm_p2p_local_base(void* handle) {
+  P2P* h = static_cast<P2P*>(handle);
+  return h ? h->local : nullptr;
+}
+
+int mfm_p2p_connect_bases(void* handle, const void* const* bases) {
+  P2P* h = static_cast<P2P*>(handle);
+  if (!h || !bases) { set_error("mfm_p2p_connect_bases: null argument"); return MFM_ERR_ARG; }
+  for (int r = 0; r < h->d.W; ++r) {
+    if (r == h->d.rank) continue;
+    if (!bases[r]) { set_error("mfm_p2p_connect_bases: base of rank %d is null", r); return MFM_ERR_ARG; }
+    p2p_point(h, r, const_cast<void*>(bases[r]));        // not owned: peer[] stays empty, nothing to close
   }
   h->connected = true;
   return MFM_OK;

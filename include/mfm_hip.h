@@ -169,6 +169,10 @@ int mfm_p2p_create(int32_t nranks /*<=8*/, int32_t rank, int64_t max_elems, void
 int mfm_p2p_handle_bytes(void);
 int mfm_p2p_export(void* handle, void* out /*mfm_p2p_handle_bytes()*/);
 int mfm_p2p_connect(void* handle, const void* all_handles /*nranks x mfm_p2p_handle_bytes(), rank order*/);
+/* ranks that live in ONE process (one host thread / stream per GPU with peer access enabled, or several
+ * streams of one GPU in tests) skip IPC: hand every rank the others' local base pointers */
+void* mfm_p2p_local_base(void* handle);
+int mfm_p2p_connect_bases(void* handle, const void* const* bases /*nranks, rank order; own entry ignored*/);
 int mfm_p2p_allreduce(void* handle, float* buf /*16-byte aligned*/, int64_t n /*<= max_elems*/, void* stream);
 int mfm_p2p_status(void* handle, int32_t* timed_out /*1 if any wait gave up since create (synchronises)*/);
 void mfm_p2p_destroy(void* handle);
