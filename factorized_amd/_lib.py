@@ -81,6 +81,9 @@ _SIGS = {
     "mfm_p2p_local_base": (C.c_void_p, [C.c_void_p]),
     "mfm_p2p_connect_bases": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "mfm_p2p_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mfm_p2p_allreduce_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                         C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                         C.c_void_p]),
     "mfm_p2p_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "mfm_p2p_destroy": (None, [C.c_void_p]),
     "mfm_plan_create": (C.c_int, [C.POINTER(PlanConfig), C.POINTER(C.c_int64), C.c_int64,

@@ -39,33 +39,54 @@ class P2PAllReduce:
     out-of-band channel for the 64-byte handles (torch.distributed.all_gather_object by default)."""
     name = "p2p-two-shot"
 
-    def __init__(self, world, rank, max_elems, exchange=None, barrier=None):
+    def __init__(self, world, rank, max_elems, exchange=None):
         L = _lib.lib()
         self._L = L
+        self._h = None
         self.world, self.rank, self.max_elems = world, rank, int(max_elems)
-        h = C.c_void_p()
-        _lib.check(L.mfm_p2p_create(world, rank, self.max_elems, C.byref(h)), "mfm_p2p_create")
-        self._h = h
-        if world > 1:
-            nb = L.mfm_p2p_handle_bytes()
-            mine = C.create_string_buffer(nb)
-            _lib.check(L.mfm_p2p_export(h, mine), "mfm_p2p_export")
-            if exchange is None:
-                import torch.distributed as dist
+        if exchange is None and world > 1:
+            import torch.distributed as dist
 
-                def exchange(b):
-                    out = [None] * world
-                    dist.all_gather_object(out, b)
-                    return out
-            handles = exchange(bytes(mine.raw))
-            if len(handles) != world or any(len(x) != nb for x in handles):
-                raise _lib.MfmError("P2PAllReduce: handle exchange returned %r entries" % (len(handles),))
-            blob = C.create_string_buffer(b"".join(handles), nb * world)
-            _lib.check(L.mfm_p2p_connect(h, blob), "mfm_p2p_connect")
-            if barrier is None:
-                import torch.distributed as dist
-                barrier = dist.barrier
-            barrier()          # nobody raises a flag before every rank has mapped and cleared its block
+            def exchange(b):
+                out = [None] * world
+                dist.all_gather_object(out, b)
+                return out
+        # Every rank takes part in both exchanges whatever happened locally, so that a failure on one rank
+        # (IPC refused, allocation failed) raises on all of them instead of leaving the others waiting.
+        err, mine = None, b""
+        try:
+            h = C.c_void_p()
+            _lib.check(L.mfm_p2p_create(world, rank, self.max_elems, C.byref(h)), "mfm_p2p_create")
+            self._h = h
+            if world > 1:
+                nb = L.mfm_p2p_handle_bytes()
+                buf = C.create_string_buffer(nb)
+                _lib.check(L.mfm_p2p_export(h, buf), "mfm_p2p_export")
+                mine = bytes(buf.raw)
+        except _lib.MfmError as e:
+            err = e
+        if world == 1:
+            if err is not None:
+                raise err
+            return
+        handles = exchange(mine)
+        status = b"ok"
+        if err is not None:
+            status = ("rank %d: %s" % (rank, err)).encode()
+        elif len(handles) != world or any(len(x) != len(mine) for x in handles):
+            status = ("rank %d: a peer exported no handle" % rank).encode()
+        else:
+            try:
+                blob = C.create_string_buffer(b"".join(handles), len(mine) * world)
+                _lib.check(L.mfm_p2p_connect(self._h, blob), "mfm_p2p_connect")
+            except _lib.MfmError as e:
+                status = ("rank %d: %s" % (rank, e)).encode()
+        # second exchange = agreement + barrier: nobody raises a flag before every rank has mapped and
+        # cleared its block
+        bad = [x for x in exchange(status) if x != b"ok"]
+        if bad:
+            self.close()
+            raise _lib.MfmError("P2PAllReduce set-up failed: " + b"; ".join(bad).decode(errors="replace"))
 
     def __call__(self, t):
         if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
@@ -73,6 +94,15 @@ class P2PAllReduce:
         stream = torch.cuda.current_stream(t.device).cuda_stream
         _lib.check(self._L.mfm_p2p_allreduce(self._h, C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(stream)),
                    "mfm_p2p_allreduce")
+
+    def allreduce_adam(self, e, lr, grad_scale):
+        """All-reduce of e.grads and the flat Adam update of e.params in the same launch."""
+        e.step_count += 1
+        stream = torch.cuda.current_stream(e.grads.device).cuda_stream
+        _lib.check(self._L.mfm_p2p_allreduce_adam(self._h, C.c_void_p(e.grads.data_ptr()), C.c_void_p(e.params.data_ptr()),
+                                                  C.c_void_p(e.adam_m.data_ptr()), C.c_void_p(e.adam_v.data_ptr()),
+                                                  e.grads.numel(), e.step_count, lr, 0.9, 0.999, 1e-8, grad_scale,
+                                                  C.c_void_p(stream)), "mfm_p2p_allreduce_adam")
 
     def timed_out(self):
         v = C.c_int32(0)
@@ -112,8 +142,12 @@ def validate(ar, world, rank, n, device, rounds=6):
         refs.append(v.clone())
     torch.cuda.synchronize(device)
     dist.barrier()
-    for it in range(rounds):                 # no synchronisation between the calls
-        ar(bufs[it])
+    fail = None
+    try:
+        for it in range(rounds):             # no synchronisation between the calls
+            ar(bufs[it])
+    except Exception as e:                   # keep going: the collectives below must stay aligned across ranks
+        fail = e
     torch.cuda.synchronize(device)
     worst = 0.0
     for it in range(rounds):
@@ -124,7 +158,11 @@ def validate(ar, world, rank, n, device, rounds=6):
     chk = bufs[-1].clone()
     dist.all_reduce(chk, op=dist.ReduceOp.MAX)
     same = bool((chk == bufs[-1]).all().item())
-    return (worst < 1e-5 and same and not ar.timed_out()), worst
+    try:
+        timed_out = ar.timed_out()
+    except Exception as e:
+        fail, timed_out = e, True
+    return (worst < 1e-5 and same and not timed_out and fail is None), worst
 
 
 def make_allreduce(world, rank, n, device, verbose=True):

@@ -21,6 +21,7 @@
 // w after it has seen every owner's epoch-e result flag for chunk w, which the owner raises after reading
 // its staging rows; and an owner's epoch-e+1 result push comes after every rank's epoch-e+1 first push,
 // hence after that rank finished copying the epoch-e result rows.
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -92,8 +93,31 @@ __device__ __forceinline__ void publish(int* const* flags, int slot, int W, int 
   }
 }
 
+// Optional fused optimizer: the rank that holds a reduced gradient in registers applies the flat Adam update
+// (same arithmetic as adam_kernel, elementwise.hip) instead of a separate launch reading it back.
+struct AdamArgs {
+  float *p, *m, *v;
+  float beta1, beta2, eps, step_size, bc2_sqrt, grad_scale;
+};
+
+__device__ __forceinline__ void adam4(const AdamArgs& a, int64_t idx, int64_t n, f32x4 g4) {
+  f32x4 pv = load4_bounded(a.p, idx, n), mv = load4_bounded(a.m, idx, n), vv = load4_bounded(a.v, idx, n);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float gg = g4[j] * a.grad_scale;
+    mv[j] = mv[j] + (1.0f - a.beta1) * (gg - mv[j]);
+    vv[j] = vv[j] * a.beta2 + (1.0f - a.beta2) * gg * gg;
+    const float denom = sqrtf(vv[j]) / a.bc2_sqrt + a.eps;
+    pv[j] = pv[j] - a.step_size * mv[j] / denom;
+  }
+  store4_bounded(a.p, idx, n, pv);
+  store4_bounded(a.m, idx, n, mv);
+  store4_bounded(a.v, idx, n, vv);
+}
+
+template <bool ADAM>
 __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev d, float* __restrict__ buf, int64_t n, int epoch,
-                                                                   int64_t timeout) {
+                                                                   int64_t timeout, const AdamArgs ad) {
   const int w = blockIdx.x, tid = threadIdx.x;
   const int W = d.W, me = d.rank;
   const int64_t SL = d.SL, CL = d.CL, cb = (int64_t)w * CL;
@@ -131,6 +155,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev
       if (i < W) *reinterpret_cast<f32x4*>(d.res[p] + (int64_t)me * SL + cb + k) = acc;
     }
     store4_bounded(buf, (int64_t)me * SL + cb + k, n, acc);
+    if (ADAM) adam4(ad, (int64_t)me * SL + cb + k, n, acc);
   }
   publish(d.f2, me * P2P_WGS + w, W, epoch);
   // ---- gather: foreign result rows -> my gradient buffer
@@ -145,9 +170,17 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev
 #pragma unroll
     for (int i = 1; i < P2P_MAXR; ++i) {
       const int s = (me + min(i, W - 1)) % W;
-      if (i < W) store4_bounded(buf, (int64_t)s * SL + cb + k, n, v[i]);
+      if (i < W) {
+        store4_bounded(buf, (int64_t)s * SL + cb + k, n, v[i]);
+        if (ADAM) adam4(ad, (int64_t)s * SL + cb + k, n, v[i]);
+      }
     }
   }
+}
+
+__global__ __launch_bounds__(P2P_THREADS) void adam_only_kernel(const float* __restrict__ g, int64_t n, const AdamArgs ad) {
+  for (int64_t k = ((int64_t)blockIdx.x * P2P_THREADS + threadIdx.x) * 4; k < n; k += (int64_t)P2P_WGS * P2P_THREADS * 4)
+    adam4(ad, k, n, load4_bounded(g, k, n));
 }
 
 struct P2P {
@@ -262,19 +295,45 @@ int mfm_p2p_connect_bases(void* handle, const void* const* bases) {
   return MFM_OK;
 }
 
-int mfm_p2p_allreduce(void* handle, float* buf, int64_t n, void* stream) {
+static int p2p_launch(void* handle, float* buf, int64_t n, void* stream, const AdamArgs* ad, const char* who) {
   P2P* h = static_cast<P2P*>(handle);
-  if (!h || !buf) { set_error("mfm_p2p_allreduce: null argument"); return MFM_ERR_ARG; }
-  if (!h->connected) { set_error("mfm_p2p_allreduce: mfm_p2p_connect has not been called"); return MFM_ERR_ARG; }
-  if (n < 0 || n > h->max_elems) { set_error("mfm_p2p_allreduce: n=%lld exceeds max_elems=%lld", (long long)n, (long long)h->max_elems); return MFM_ERR_ARG; }
-  if ((reinterpret_cast<uintptr_t>(buf) & 15) != 0) { set_error("mfm_p2p_allreduce: buffer must be 16-byte aligned"); return MFM_ERR_ARG; }
-  if (n == 0 || h->d.W == 1) return MFM_OK;
-  h->epoch += 1;
-  hipLaunchKernelGGL(p2p_allreduce_kernel, dim3(P2P_WGS), dim3(P2P_THREADS), 0, static_cast<hipStream_t>(stream), h->d, buf, n,
-                     h->epoch, h->timeout_ticks);
+  if (!h || !buf) { set_error("%s: null argument", who); return MFM_ERR_ARG; }
+  if (!h->connected) { set_error("%s: mfm_p2p_connect has not been called", who); return MFM_ERR_ARG; }
+  if (n < 0 || n > h->max_elems) { set_error("%s: n=%lld exceeds max_elems=%lld", who, (long long)n, (long long)h->max_elems); return MFM_ERR_ARG; }
+  if ((reinterpret_cast<uintptr_t>(buf) & 15) != 0) { set_error("%s: buffer must be 16-byte aligned", who); return MFM_ERR_ARG; }
+  if (n == 0) return MFM_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (h->d.W == 1) {            // one rank: the sum is the buffer itself; only the optimizer is left to do
+    if (!ad) return MFM_OK;
+    hipLaunchKernelGGL(adam_only_kernel, dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, buf, n, *ad);
+  } else {
+    h->epoch += 1;
+    if (ad)
+      hipLaunchKernelGGL(p2p_allreduce_kernel<true>, dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, h->d, buf, n, h->epoch, h->timeout_ticks, *ad);
+    else
+      hipLaunchKernelGGL(p2p_allreduce_kernel<false>, dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, h->d, buf, n, h->epoch, h->timeout_ticks,
+                         AdamArgs{});
+  }
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return hip_fail(e, "p2p_allreduce_kernel launch");
+  if (e != hipSuccess) return hip_fail(e, who);
   return MFM_OK;
+}
+
+int mfm_p2p_allreduce(void* handle, float* buf, int64_t n, void* stream) {
+  return p2p_launch(handle, buf, n, stream, nullptr, "mfm_p2p_allreduce");
+}
+
+int mfm_p2p_allreduce_adam(void* handle, float* grads, float* p, float* m, float* v, int64_t n, int32_t step, float lr, float beta1,
+                           float beta2, float eps, float grad_scale, void* stream) {
+  if (!p || !m || !v || step < 1) { set_error("mfm_p2p_allreduce_adam: bad arguments (step=%d)", step); return MFM_ERR_ARG; }
+  if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) != 0) {
+    set_error("mfm_p2p_allreduce_adam: buffers must be 16-byte aligned");
+    return MFM_ERR_ARG;
+  }
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  AdamArgs ad{p, m, v, beta1, beta2, eps, (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale};
+  return p2p_launch(handle, grads, n, stream, &ad, "mfm_p2p_allreduce_adam");
 }
 
 int mfm_p2p_status(void* handle, int32_t* timed_out) {

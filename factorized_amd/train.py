@@ -8,6 +8,8 @@ so to equal a single-process step at the global batch W*B each rank back-propaga
 `mean-terms + W * KLD` (reg_scale = W inside the plan) and the summed gradients are divided by W
 (grad_scale = 1/W inside the fused Adam).  tests/test_dp_gloo.py checks that algebra on CPU.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -66,8 +68,12 @@ class DataParallelStep:
         if self.world == 1:
             return e.train_step(x, y, lr=self.lr, check=False)
         losses = e.grad_step(x, y, check=False)           # fwd + bwd: one enqueue, 10 launches
-        self.allreduce(e.grads)                           # one flat buffer, one collective
-        e.adam(lr=self.lr, grad_scale=1.0 / self.world)
+        fused = getattr(self.allreduce, "allreduce_adam", None)
+        if fused is not None and os.environ.get("MFM_DP_FUSED_ADAM", "1") == "1":
+            fused(e, self.lr, 1.0 / self.world)           # P2P kernel: collective + Adam in one launch
+        else:
+            self.allreduce(e.grads)                       # one flat buffer, one collective
+            e.adam(lr=self.lr, grad_scale=1.0 / self.world)
         return losses
 
 

@@ -174,6 +174,10 @@ int mfm_p2p_connect(void* handle, const void* all_handles /*nranks x mfm_p2p_han
 void* mfm_p2p_local_base(void* handle);
 int mfm_p2p_connect_bases(void* handle, const void* const* bases /*nranks, rank order; own entry ignored*/);
 int mfm_p2p_allreduce(void* handle, float* buf /*16-byte aligned*/, int64_t n /*<= max_elems*/, void* stream);
+/* the same exchange with the flat Adam update (mfm_adam_flat semantics) applied by the rank-local copy of the
+ * kernel as each reduced slice arrives: all-reduce + optimizer in one launch.  `grads` still receives the sum. */
+int mfm_p2p_allreduce_adam(void* handle, float* grads, float* p, float* m, float* v, int64_t n, int32_t step,
+                           float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 int mfm_p2p_status(void* handle, int32_t* timed_out /*1 if any wait gave up since create (synchronises)*/);
 void mfm_p2p_destroy(void* handle);
 

@@ -44,6 +44,32 @@ def _worker(rank, world, port, sizes, ret):
         torch.cuda.synchronize()
         expect = sum(1.0 + r for r in range(world)) * float(world) ** 5
         out["chain"] = bool((v == expect).all().item())
+        # fused collective + Adam against all-reduce followed by mfm_adam_flat, three steps
+        class E:
+            pass
+        n = 477294
+        g = torch.Generator().manual_seed(5)
+        p0 = torch.randn(n, generator=g)
+        ea, eb = E(), E()
+        for e in (ea, eb):
+            e.params, e.adam_m, e.adam_v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+            e.grads, e.step_count = torch.zeros(n, device=dev), 0
+        from factorized_amd import _lib
+        L = _lib.lib()
+        for step in range(1, 4):
+            gr = torch.Generator().manual_seed(100 * step + rank)
+            grad = (torch.randn(n, generator=gr) * 0.01).to(dev)
+            ea.grads.copy_(grad)
+            eb.grads.copy_(grad)
+            ar.allreduce_adam(ea, 1e-3, 1.0 / world)
+            ar(eb.grads)
+            _lib.check(L.mfm_adam_flat(C.c_void_p(eb.params.data_ptr()), C.c_void_p(eb.grads.data_ptr()),
+                                       C.c_void_p(eb.adam_m.data_ptr()), C.c_void_p(eb.adam_v.data_ptr()), n, step,
+                                       1e-3, 0.9, 0.999, 1e-8, 1.0 / world, None), "adam")
+        torch.cuda.synchronize()
+        out["fused_adam"] = (bool(torch.equal(ea.grads, eb.grads)),
+                             float((ea.params - eb.params).abs().max()), float((ea.adam_v - eb.adam_v).abs().max()),
+                             ea.step_count)
         out["timed_out"] = ar.timed_out()
         # the selection logic picks the kernel when it validates
         chosen = comm.make_allreduce(world, rank, 4099, dev, verbose=False)
@@ -69,6 +95,8 @@ def test_p2p_allreduce_matches_reference_sum(world):
             ok, worst = out[n]
             assert ok, (r, n, worst)
         assert out["chain"] and not out["timed_out"]
+        same_g, dp, dv, steps = out["fused_adam"]
+        assert same_g and dp < 1e-6 and dv < 1e-9 and steps == 3, out["fused_adam"]
         assert out["chosen"] == "p2p-two-shot"
 
 
@@ -112,6 +140,15 @@ def test_p2p_single_rank_and_argument_errors():
     with pytest.raises(_lib.MfmError):
         ar(torch.zeros(10, dtype=torch.float64, device="cuda"))
     assert not ar.timed_out()
+    # one rank: the fused call is just the optimizer
+    class E:
+        pass
+    e = E()
+    e.params, e.adam_m, e.adam_v = torch.ones(1000, device="cuda"), torch.zeros(1000, device="cuda"), torch.zeros(1000, device="cuda")
+    e.grads, e.step_count = torch.full((1000,), 0.5, device="cuda"), 0
+    ar.allreduce_adam(e, 1e-3, 1.0)
+    torch.cuda.synchronize()
+    assert torch.allclose(e.params.cpu(), torch.full((1000,), 1.0 - 1e-3), atol=1e-6) and e.step_count == 1
     ar.close()
     h = C.c_void_p()
     assert L.mfm_p2p_create(9, 0, 10, C.byref(h)) != 0          # more than 8 ranks
