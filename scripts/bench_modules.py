@@ -43,8 +43,28 @@ def run(cls, steps=30):
     return 1e3 * (time.perf_counter() - t0) / steps
 
 
+def run_graphed(cls, steps=100):
+    from factorized_amd import train
+    cfgs = C.canonical_configs(dropout=True)
+    cfg = cfgs[0]
+    m = cls(*cfgs).cuda()
+    m.train()
+    xn, yn = synth.make_batch(cfg["input_dims"], 32, 20, seed=3)
+    x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
+    gs = train.GraphedModuleStep(m, cfg, 32, 20)
+    for _ in range(5):
+        gs.step(x, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gs.step(x, y)
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
 if __name__ == "__main__":
-    print("%-12s %10s %12s" % ("class", "ms/step", "samples/s"))
+    print("%-12s %10s %12s %18s" % ("class", "ms/step", "samples/s", "hipGraph ms/step"))
     for cls in (MFM_KL_EF, MFM_KL, MFM):
         ms = run(cls)
-        print("%-12s %10.3f %12.0f" % (cls.__name__, ms, 32 / ms * 1e3))
+        gms = run_graphed(cls) if cls is not MFM_KL_EF else float("nan")
+        print("%-12s %10.3f %12.0f %18.3f" % (cls.__name__, ms, 32 / ms * 1e3, gms))

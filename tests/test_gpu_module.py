@@ -171,3 +171,51 @@ def test_mfn_based_models_match_reference(name):
         opt.step()
     ref_trace = gold["trace"][:, 0]
     assert np.max(np.abs(np.array(trace) - ref_trace) / np.abs(ref_trace)) < 20 * TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls_name", ["MFM_KL", "MFM"])
+def test_graphed_module_step_matches_eager_steps(cls_name):
+    """train.GraphedModuleStep (hipGraph replay of the reference-style step) follows the same trajectory as
+    the eager loop: same losses and parameters after 4 steps (dropout off; MFM's Gaussian draws come from
+    the same torch generator state)."""
+    import copy
+    from factorized_amd import configs, synth, train
+    from factorized_amd import mfm_model as M
+    cfgs = configs.canonical_configs(dropout=False)
+    cfg = cfgs[0]
+    B, T = 8, 6
+    torch.manual_seed(3)
+    m_e = getattr(M, cls_name)(*cfgs).cuda()
+    m_g = copy.deepcopy(m_e)
+    m_e.train(); m_g.train()
+    batches = []
+    for i in range(4):
+        xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=20 + i)
+        batches.append((torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()))
+    gs = train.GraphedModuleStep(m_g, cfg, B, T, lr=1e-3)
+    for pe, pg in zip(m_e.parameters(), m_g.parameters()):
+        assert torch.equal(pe, pg)                       # the warm-up inside the constructor left no trace
+    opt = torch.optim.Adam(m_e.parameters(), lr=1e-3)
+    l1, mse = torch.nn.L1Loss(), torch.nn.MSELoss()
+    d = cfg["input_dims"]
+    for i, (x, y) in enumerate(batches):
+        torch.manual_seed(100 + i)
+        opt.zero_grad()
+        (xl, xa, xv, yh), reg, miss = m_e.forward(x)
+        loss_e = l1(yh.squeeze(1), y) + cfg["lda_xl"] * mse(xl, x[:, :, :d[0]]) + cfg["lda_xa"] * mse(xa, x[:, :, d[0]:d[0] + d[1]]) \
+            + cfg["lda_xv"] * mse(xv, x[:, :, d[0] + d[1]:]) + cfg["lda_mmd"] * reg + miss
+        loss_e.backward()
+        opt.step()
+        torch.manual_seed(100 + i)
+        loss_g, _ = gs.step(x, y)
+        if cls_name == "MFM_KL":                         # MFM draws its MMD Gaussians from the graph's own generator stream
+            assert abs(float(loss_g) - float(loss_e.detach())) <= 1e-4 * abs(float(loss_e.detach())), (i, float(loss_g))
+    if cls_name == "MFM_KL":
+        for (n, pe), pg in zip(m_e.named_parameters(), m_g.parameters()):
+            assert (pe - pg).abs().max().item() <= 2e-4 * max(pe.abs().max().item(), 1e-3) + 2e-5, n
+    else:
+        assert torch.isfinite(gs.loss).item()
+    gs.set_lr(1e-4)
+    gs.step(*batches[0])
+    assert float(gs.lr) == pytest.approx(1e-4)
