@@ -58,6 +58,26 @@ __device__ __forceinline__ void store4_bounded(float* p, int64_t idx, int64_t n,
     if (idx + c < n) p[idx + c] = v[c];
 }
 
+// Staging rows are written and read with system-scope accesses (sc0 sc1: past this GPU's L2 in both
+// directions) on top of the uncached allocation, as two 8-byte halves -- the widest scoped access there is.
+typedef unsigned long long u64;
+__device__ __forceinline__ void store4_sys(float* p, f32x4 v) {
+  u64 lo, hi;
+  const float a[2] = {v[0], v[1]}, b[2] = {v[2], v[3]};
+  __builtin_memcpy(&lo, a, 8);
+  __builtin_memcpy(&hi, b, 8);
+  __hip_atomic_store(reinterpret_cast<u64*>(p), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(reinterpret_cast<u64*>(p) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ f32x4 load4_sys(const float* p) {
+  const u64 lo = __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const u64 hi = __hip_atomic_load(reinterpret_cast<const u64*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  float a[2], b[2];
+  __builtin_memcpy(a, &lo, 8);
+  __builtin_memcpy(b, &hi, 8);
+  return f32x4{a[0], a[1], b[0], b[1]};
+}
+
 // thread t < W waits until flags[t] reaches `epoch`; returns after a block barrier + acquire fence
 __device__ __forceinline__ void wait_flags(const int* flags, int stride, int W, int epoch, int64_t timeout, int* err) {
   if ((int)threadIdx.x < W) {
@@ -134,7 +154,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev
 #pragma unroll
     for (int i = 0; i < P2P_MAXR; ++i) {
       const int s = (me + 1 + min(i, W - 1)) % W;
-      if (i < W) *reinterpret_cast<f32x4*>(d.stage[s] + (int64_t)me * SL + cb + k) = v[i];
+      if (i < W) store4_sys(d.stage[s] + (int64_t)me * SL + cb + k, v[i]);
     }
   }
   publish(d.f1, me * P2P_WGS + w, W, epoch);
@@ -144,7 +164,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev
     const float* src = d.stage[me] + cb + k;
     f32x4 v[P2P_MAXR];
 #pragma unroll
-    for (int r = 0; r < P2P_MAXR; ++r) v[r] = *reinterpret_cast<const f32x4*>(src + (int64_t)min(r, W - 1) * SL);
+    for (int r = 0; r < P2P_MAXR; ++r) v[r] = load4_sys(src + (int64_t)min(r, W - 1) * SL);
     f32x4 acc = v[0];
 #pragma unroll
     for (int r = 1; r < P2P_MAXR; ++r)
@@ -152,7 +172,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev
 #pragma unroll
     for (int i = 1; i < P2P_MAXR; ++i) {
       const int p = (me + min(i, W - 1)) % W;
-      if (i < W) *reinterpret_cast<f32x4*>(d.res[p] + (int64_t)me * SL + cb + k) = acc;
+      if (i < W) store4_sys(d.res[p] + (int64_t)me * SL + cb + k, acc);
     }
     store4_bounded(buf, (int64_t)me * SL + cb + k, n, acc);
     if (ADAM) adam4(ad, (int64_t)me * SL + cb + k, n, acc);
@@ -165,7 +185,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev
 #pragma unroll
     for (int i = 1; i < P2P_MAXR; ++i) {
       const int s = (me + min(i, W - 1)) % W;
-      v[i] = *reinterpret_cast<const f32x4*>(d.res[me] + (int64_t)s * SL + cb + k);
+      v[i] = load4_sys(d.res[me] + (int64_t)s * SL + cb + k);
     }
 #pragma unroll
     for (int i = 1; i < P2P_MAXR; ++i) {
