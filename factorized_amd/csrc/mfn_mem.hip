@@ -52,7 +52,10 @@ struct MemDev {
 };
 
 // ------------------------------------------------------------------------------------- forward
-__global__ __launch_bounds__(1024) void mfn_mem_fwd_kernel(const MemDev P) {
+// MAXT = 512 gives the compiler 256 registers per thread: the 96 resident weights of the canonical shape
+// (M=64, H=128: 512 threads) then stay in VGPRs; the 1024-thread build (128 registers) spills them.
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void mfn_mem_fwd_kernel(const MemDev P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const MfmMemDesc& d = P.d;
   const int T = d.T, B = d.B, M = d.M, H1 = d.H1, H2 = d.H2;
@@ -154,7 +157,8 @@ __global__ __launch_bounds__(1024) void mfn_mem_fwd_kernel(const MemDev P) {
 }
 
 // ------------------------------------------------------------------------------------- backward
-__global__ __launch_bounds__(1024) void mfn_mem_bwd_kernel(const MemDev P) {
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void mfn_mem_bwd_kernel(const MemDev P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const MfmMemDesc& d = P.d;
   const int T = d.T, B = d.B, M = d.M, H1 = d.H1, H2 = d.H2;
@@ -290,7 +294,8 @@ extern "C" int mfm_mfn_mem_fwd(const MfmMemDesc* desc, void* stream) {
   int threads = 0; size_t lds = 0;
   int rc = mem_setup(desc, P, threads, lds);
   if (rc != MFM_OK) return rc;
-  hipLaunchKernelGGL(mfn_mem_fwd_kernel, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
+  if (threads <= 512) hipLaunchKernelGGL(mfn_mem_fwd_kernel<512>, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
+  else hipLaunchKernelGGL(mfn_mem_fwd_kernel<1024>, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
   MFM_LAUNCH_CHECK("mfn_mem_fwd_kernel");
   return MFM_OK;
 }
@@ -302,7 +307,8 @@ extern "C" int mfm_mfn_mem_bwd(const MfmMemDesc* desc, void* stream) {
   int rc = mem_setup(desc, P, threads, lds);
   if (rc != MFM_OK) return rc;
   MFM_REQUIRE(desc->du1 && desc->du2 && desc->dchat, "mfm_mfn_mem_bwd: null gradient output");
-  hipLaunchKernelGGL(mfn_mem_bwd_kernel, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
+  if (threads <= 512) hipLaunchKernelGGL(mfn_mem_bwd_kernel<512>, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
+  else hipLaunchKernelGGL(mfn_mem_bwd_kernel<1024>, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
   MFM_LAUNCH_CHECK("mfn_mem_bwd_kernel");
   return MFM_OK;
 }

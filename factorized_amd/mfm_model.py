@@ -534,18 +534,20 @@ class _GroupLinearFn(torch.autograd.Function):
         dev = x2s[0].device
         zs = _zeros_many(dev, *([tuple(w.shape) for w in ws] + [(w.shape[0],) for w in ws]))
         dws, dbs = zs[:n], zs[n:]
-        dxs, descs = [], []
+        dxs, descs, keep = [], [], []      # `keep`: the descriptors hold raw pointers of per-iteration temporaries
         for i in range(n):
             x2, w = x2s[i], ws[i]
             M, K = x2.shape
             N = w.shape[0]
             dy2 = dys[i].reshape(M, N).contiguous().float() if dys[i] is not None else torch.zeros(M, N, device=dev)
+            keep.append(dy2)
             dx = torch.empty(M, K, device=dev)
             dxs.append(dx)
             descs += [E.make_gemm(dy2, w, dx, M, K, N, a_sm=N, a_sk=1, b_sk=K, b_sn=1, ldc=K),
                       E.make_gemm(dy2, x2, dws[i], N, K, M, a_sm=1, a_sk=N, b_sk=K, b_sn=1, ldc=K, accumulate=1, split_k=0),
                       E.make_gemm(dy2, _ones(M, dev), dbs[i], N, 1, M, a_sm=1, a_sk=N, b_sk=1, b_sn=1, ldc=1, accumulate=1, split_k=0)]
         E.gemm_grouped(descs)
+        del keep
         return (None,) + tuple(dx.reshape(shp) for dx, shp in zip(dxs, ctx.shapes)) + tuple(dws) + tuple(dbs)
 
 
@@ -567,49 +569,132 @@ class HipLinear(nn.Linear):
 
 
 # ----------------------------------------------------------------------------------- MFN
-class _LstmSeqStatesFn(torch.autograd.Function):
-    """One LSTM over the whole sequence returning (h_T [B,h], c_all [T,B,h]); differentiable in both
-    (the MFN attention reads every c_t, reference mfm_model.py:171-173)."""
+class _SeqGroupFn(torch.autograd.Function):
+    """Several independent sequence encoders in the same launches: `kinds[i]` is "enc" (x -> fc1(h_T), the
+    encoderLSTM contract, 7 tensors) or "states" (x -> (h_T, c_all), the MFN LSTMs, 5 tensors).  One grouped
+    GEMM for all input projections, one mfm_lstm_seq_* call for all recurrences (the library packs up to
+    four per launch), one grouped GEMM for the fc1 heads; backward likewise (MFM / MFM_KL run three
+    encoders and the three MFN LSTMs on the same batch, reference mfm_model.py:745-756, 163-169)."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
-        T, B, d = x.shape
-        h = w_hh.shape[1]
-        Hp = _hp(h)
-        xr, ldx = _rows(x)
-        dev = x.device
-        gates = torch.empty(T, B, 4, Hp, device=dev, dtype=torch.float32)
-        hs = torch.empty(T, B, Hp, device=dev, dtype=torch.float32)
-        cs = torch.empty(T, B, Hp, device=dev, dtype=torch.float32)
-        E.gemm_grouped([E.make_gemm(xr, w_ih, gates, T * B, Hp, d, a_sm=ldx, a_sk=1, b_sk=1, b_sn=d,
-                                    ldc=4 * Hp, bias=b_ih, bias2=b_hh, n_valid=h, batch=4, b_sz=h * d,
-                                    c_sz=Hp, bias_sz=h)])
-        E.lstm_seq([E.make_seq(gates, hs, cs, w_hh, h)], T, B)
-        ctx.save_for_backward(xr, w_ih, w_hh, gates, hs, cs)
-        ctx.dims = (T, B, d, h, Hp, ldx)
-        return hs[T - 1, :, :h].clone(), cs[:, :, :h].clone()
+    def forward(ctx, kinds, *args):
+        specs, pos = [], 0
+        for k in kinds:
+            n = 7 if k == "enc" else 5
+            specs.append((k,) + tuple(args[pos:pos + n]))
+            pos += n
+        T, B = args[0].shape[0], args[0].shape[1]
+        dev = args[0].device
+        proj, seqs, heads, saved, dims, outs = [], [], [], [], [], []
+        for sp in specs:
+            k, x, w_ih, w_hh, b_ih, b_hh = sp[:6]
+            d, h = x.shape[2], w_hh.shape[1]
+            Hp = _hp(h)
+            xr, ldx = _rows(x)
+            gates = torch.empty(T, B, 4, Hp, device=dev, dtype=torch.float32)
+            hs = torch.empty(T, B, Hp, device=dev, dtype=torch.float32)
+            cs = torch.empty(T, B, Hp, device=dev, dtype=torch.float32)
+            proj.append(E.make_gemm(xr, w_ih, gates, T * B, Hp, d, a_sm=ldx, a_sk=1, b_sk=1, b_sn=d, ldc=4 * Hp,
+                                    bias=b_ih, bias2=b_hh, n_valid=h, batch=4, b_sz=h * d, c_sz=Hp, bias_sz=h))
+            seqs.append(E.make_seq(gates, hs, cs, w_hh, h))
+            if k == "enc":
+                fc_w, fc_b = sp[6], sp[7]
+                out = torch.empty(B, fc_w.shape[0], device=dev, dtype=torch.float32)
+                heads.append(E.make_gemm(hs[T - 1], fc_w, out, B, fc_w.shape[0], h, a_sm=Hp, a_sk=1, b_sk=1, b_sn=h,
+                                         ldc=fc_w.shape[0], bias=fc_b))
+                outs.append(out)
+                saved += [xr, w_ih, w_hh, gates, hs, cs, fc_w]
+            else:
+                saved += [xr, w_ih, w_hh, gates, hs, cs]
+            dims.append((k, d, h, Hp, ldx))
+        E.gemm_grouped(proj)
+        for i in range(0, len(seqs), 4):                   # MFM_MAX_SEQ recurrences per launch
+            E.lstm_seq(seqs[i:i + 4], T, B)
+        if heads:
+            E.gemm_grouped(heads)
+        res, it, si = [], iter(outs), 0
+        for (k, d, h, Hp, ldx) in dims:
+            if k == "enc":
+                res.append(next(it))
+                si += 7
+            else:
+                hs, cs = saved[si + 4], saved[si + 5]
+                res += [hs[T - 1, :, :h].clone(), cs[:, :, :h].clone()]
+                si += 6
+        ctx.save_for_backward(*saved)
+        ctx.dims = (T, B, tuple(dims))
+        return tuple(res)
 
     @staticmethod
-    def backward(ctx, d_hT, d_cs):
-        xr, w_ih, w_hh, gates, hs, cs = ctx.saved_tensors
-        T, B, d, h, Hp, ldx = ctx.dims
-        dev = xr.device
-        dh = torch.zeros(B, h, device=dev) if d_hT is None else d_hT.contiguous().float()
-        dc = torch.zeros(T, B, Hp, device=dev)
-        if d_cs is not None:
-            dc[:, :, :h] = d_cs
-        E.lstm_seq([E.make_seq(gates, hs, cs, w_hh, h, dh_ext=dh, ld_dh=h, dc_ext=dc)], T, B, backward=True)
-        g_wih, g_whh, g_bih, g_bhh = _zeros_many(dev, w_ih.shape, w_hh.shape, (4 * h,), (4 * h,))
-        ones = _ones(T * B, dev)
-        descs = [E.make_gemm(gates, xr, g_wih, h, d, T * B, a_sm=1, a_sk=4 * Hp, b_sk=ldx, b_sn=1, ldc=d,
-                             batch=4, a_sz=Hp, c_sz=h * d, accumulate=1, split_k=0),
-                 E.make_gemm(gates, ones, g_bih, h, 1, T * B, a_sm=1, a_sk=4 * Hp, b_sk=1, b_sn=1, ldc=1,
-                             batch=4, a_sz=Hp, c_sz=h, accumulate=1, split_k=0, c2=g_bhh)]
-        if T > 1:
-            descs.append(E.make_gemm(gates[1:], hs, g_whh, h, h, (T - 1) * B, a_sm=1, a_sk=4 * Hp, b_sk=Hp,
-                                     b_sn=1, ldc=h, batch=4, a_sz=Hp, c_sz=h * h, accumulate=1, split_k=0))
-        E.gemm_grouped(descs)
-        return None, g_wih, g_whh, g_bih, g_bhh
+    def backward(ctx, *douts):
+        saved = ctx.saved_tensors
+        T, B, dims = ctx.dims
+        dev = saved[0].device
+        ones = _ones(max(T * B, B), dev)
+        pre, seqs, post, grads = [], [], [], []
+        keep = []          # the descriptors hold raw pointers: temporaries must outlive the launches below
+        si, gi = 0, 0
+        for (k, d, h, Hp, ldx) in dims:
+            if k == "enc":
+                xr, w_ih, w_hh, gates, hs, cs, fc_w = saved[si:si + 7]
+                si += 7
+                d_out = douts[gi]
+                gi += 1
+                n_out = fc_w.shape[0]
+                d_out = torch.zeros(B, n_out, device=dev) if d_out is None else d_out.contiguous().float()
+                g_fcw, g_fcb, g_wih, g_whh, g_bih, g_bhh = _zeros_many(dev, fc_w.shape, (n_out,), w_ih.shape, w_hh.shape,
+                                                                       (4 * h,), (4 * h,))
+                dh = torch.empty(B, h, device=dev)
+                pre += [E.make_gemm(d_out, fc_w, dh, B, h, n_out, a_sm=n_out, a_sk=1, b_sk=h, b_sn=1, ldc=h),
+                        E.make_gemm(d_out, hs[T - 1], g_fcw, n_out, h, B, a_sm=1, a_sk=n_out, b_sk=Hp, b_sn=1, ldc=h,
+                                    accumulate=1, split_k=0),
+                        E.make_gemm(d_out, ones, g_fcb, n_out, 1, B, a_sm=1, a_sk=n_out, b_sk=1, b_sn=1, ldc=1,
+                                    accumulate=1, split_k=0)]
+                seqs.append(E.make_seq(gates, hs, cs, w_hh, h, dh_ext=dh, ld_dh=h))
+                keep += [d_out, dh]
+                tail = [g_fcw, g_fcb]
+            else:
+                xr, w_ih, w_hh, gates, hs, cs = saved[si:si + 6]
+                si += 6
+                d_hT, d_cs = douts[gi], douts[gi + 1]
+                gi += 2
+                g_wih, g_whh, g_bih, g_bhh = _zeros_many(dev, w_ih.shape, w_hh.shape, (4 * h,), (4 * h,))
+                dh = torch.zeros(B, h, device=dev) if d_hT is None else d_hT.contiguous().float()
+                dc = torch.zeros(T, B, Hp, device=dev)
+                if d_cs is not None:
+                    dc[:, :, :h] = d_cs
+                seqs.append(E.make_seq(gates, hs, cs, w_hh, h, dh_ext=dh, ld_dh=h, dc_ext=dc))
+                keep += [dh, dc]
+                tail = []
+            post += [E.make_gemm(gates, xr, g_wih, h, d, T * B, a_sm=1, a_sk=4 * Hp, b_sk=ldx, b_sn=1, ldc=d,
+                                 batch=4, a_sz=Hp, c_sz=h * d, accumulate=1, split_k=0),
+                     E.make_gemm(gates, ones, g_bih, h, 1, T * B, a_sm=1, a_sk=4 * Hp, b_sk=1, b_sn=1, ldc=1,
+                                 batch=4, a_sz=Hp, c_sz=h, accumulate=1, split_k=0, c2=g_bhh)]
+            if T > 1:
+                post.append(E.make_gemm(gates[1:], hs, g_whh, h, h, (T - 1) * B, a_sm=1, a_sk=4 * Hp, b_sk=Hp,
+                                        b_sn=1, ldc=h, batch=4, a_sz=Hp, c_sz=h * h, accumulate=1, split_k=0))
+            grads += [None, g_wih, g_whh, g_bih, g_bhh] + tail
+        if pre:
+            E.gemm_grouped(pre)
+        for i in range(0, len(seqs), 4):
+            E.lstm_seq(seqs[i:i + 4], T, B, backward=True)
+        E.gemm_grouped(post)
+        del keep
+        return (None,) + tuple(grads)
+
+
+def seq_group(encoders, state_lstms):
+    """[(x, encoderLSTM)], [(x, nn.LSTMCell)] -> ([fc1(h_T)], [(h_T, c_all)]) through _SeqGroupFn."""
+    kinds, args = [], []
+    for x, m in encoders:
+        kinds.append("enc")
+        args += [x, m.lstm.weight_ih, m.lstm.weight_hh, m.lstm.bias_ih, m.lstm.bias_hh, m.fc1.weight, m.fc1.bias]
+    for x, c in state_lstms:
+        kinds.append("states")
+        args += [x, c.weight_ih, c.weight_hh, c.bias_ih, c.bias_hh]
+    res = _SeqGroupFn.apply(tuple(kinds), *args)
+    ne = len(encoders)
+    return list(res[:ne]), [(res[ne + 2 * i], res[ne + 2 * i + 1]) for i in range(len(state_lstms))]
 
 
 class MFN(nn.Module):
@@ -653,18 +738,17 @@ class MFN(nn.Module):
         self.out_fc2 = HipLinear(outConfig["shapes"], output_dim)
         self.out_dropout = nn.Dropout(outConfig["drop"])
 
-    def forward(self, x):
+    def forward(self, x, states=None):
+        """`states` = [(h_T, c_all)] * 3 when the caller already ran the three LSTMs (MFM / MFM_KL group them
+        with their own encoders into the same launches)."""
         _require_cuda(x, "MFN.forward")
         T, B = x.shape[0], x.shape[1]
-        x_l = x[:, :, :self.d_l]
-        x_a = x[:, :, self.d_l:self.d_l + self.d_a]
-        x_v = x[:, :, self.d_l + self.d_a:]
-        hl, cl = _LstmSeqStatesFn.apply(x_l, self.lstm_l.weight_ih, self.lstm_l.weight_hh,
-                                        self.lstm_l.bias_ih, self.lstm_l.bias_hh)
-        ha, ca = _LstmSeqStatesFn.apply(x_a, self.lstm_a.weight_ih, self.lstm_a.weight_hh,
-                                        self.lstm_a.bias_ih, self.lstm_a.bias_hh)
-        hv, cv = _LstmSeqStatesFn.apply(x_v, self.lstm_v.weight_ih, self.lstm_v.weight_hh,
-                                        self.lstm_v.bias_ih, self.lstm_v.bias_hh)
+        if states is None:
+            x_l = x[:, :, :self.d_l]
+            x_a = x[:, :, self.d_l:self.d_l + self.d_a]
+            x_v = x[:, :, self.d_l + self.d_a:]
+            _, states = seq_group([], [(x_l, self.lstm_l), (x_a, self.lstm_a), (x_v, self.lstm_v)])
+        (hl, cl), (ha, ca), (hv, cv) = states
         new_cs = torch.cat([cl, ca, cv], dim=2)                                   # [T,B,tot]
         prev_cs = torch.cat([torch.zeros_like(new_cs[:1]), new_cs[:-1]], dim=0)   # c_{t-1}, zeros at t=0
         cStar = torch.cat([prev_cs, new_cs], dim=2)                               # mfm_model.py:171-173
@@ -750,10 +834,17 @@ class _FactorizedMFN(nn.Module):
         x_a = x[:, :, self.d_l:self.d_l + self.d_a]
         x_v = x[:, :, self.d_l + self.d_a:]
         t = x.shape[0]
-        zl_last = self.encoder_l.forward(x_l)
-        za_last = self.encoder_a.forward(x_a)
-        zv_last = self.encoder_v.forward(x_v)
-        mfn_last = self.mfn_encoder.forward(x)
+        if os.environ.get("MFM_NO_SEQ_GROUP"):               # A/B timing only: one launch set per LSTM
+            zl_last = self.encoder_l.forward(x_l)
+            za_last = self.encoder_a.forward(x_a)
+            zv_last = self.encoder_v.forward(x_v)
+            mfn_last = self.mfn_encoder.forward(x)
+        else:
+            mfn = self.mfn_encoder
+            (zl_last, za_last, zv_last), states = seq_group(
+                [(x_l, self.encoder_l), (x_a, self.encoder_a), (x_v, self.encoder_v)],
+                [(x_l, mfn.lstm_l), (x_a, mfn.lstm_a), (x_v, mfn.lstm_v)])
+            mfn_last = mfn.forward(x, states)
         if self._use_kl:
             zy, zl, za, zv, lvy, lvl, lva, lvv = linear_group([
                 (mfn_last, self.last_to_zy_fc1), (zl_last, self.last_to_zl_fc1), (za_last, self.last_to_za_fc1),
