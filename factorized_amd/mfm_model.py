@@ -266,6 +266,88 @@ class decoderLSTM(nn.Module):
                                    self.lstm.bias_hh, self.fc1.weight, self.fc1.bias)
 
 
+class _DecoderGroupFn(torch.autograd.Function):
+    """n independent decoderLSTMs (7 tensors each: hT, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b) on the same T in
+    shared launches: one mfm_lstm_seq_* call and one grouped fc1 GEMM per direction (the three modality
+    decoders of MFM / MFM_KL, reference mfm_model.py:547-549)."""
+
+    @staticmethod
+    def forward(ctx, n, t, *args):
+        T = int(t)
+        dev = args[0].device
+        seqs, heads, saved, dims, outs = [], [], [], [], []
+        for i in range(n):
+            hT, w_ih, w_hh, b_ih, b_hh, fc_w, fc_b = args[7 * i:7 * i + 7]
+            B, h = hT.shape
+            Hp, d = _hp(h), fc_w.shape[0]
+            hT = hT.contiguous().float()
+            gates = torch.empty(T, B, 4, Hp, device=dev, dtype=torch.float32)
+            hs = torch.empty(T, B, Hp, device=dev, dtype=torch.float32)
+            cs = torch.empty(T, B, Hp, device=dev, dtype=torch.float32)
+            out = torch.empty(T, B, d, device=dev, dtype=torch.float32)
+            seqs.append(E.make_seq(gates, hs, cs, w_hh, h, w_ih=w_ih, b_ih=b_ih, b_hh=b_hh, h_init=hT, is_dec=True))
+            heads.append(E.make_gemm(hs, fc_w, out, T * B, d, h, a_sm=Hp, a_sk=1, b_sk=1, b_sn=h, ldc=d, bias=fc_b))
+            saved += [hT, w_ih, w_hh, b_ih, b_hh, fc_w, gates, hs, cs]
+            dims.append((B, d, h, Hp))
+            outs.append(out)
+        for i in range(0, n, 4):
+            E.lstm_seq(seqs[i:i + 4], T, dims[0][0])
+        E.gemm_grouped(heads)
+        ctx.save_for_backward(*saved)
+        ctx.dims = (T, tuple(dims))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        saved = ctx.saved_tensors
+        T, dims = ctx.dims
+        dev = saved[0].device
+        pre, seqs, post, grads, keep = [], [], [], [], []
+        for i, (B, d, h, Hp) in enumerate(dims):
+            hT, w_ih, w_hh, b_ih, b_hh, fc_w, gates, hs, cs = saved[9 * i:9 * i + 9]
+            d_out = douts[i]
+            d_out = torch.zeros(T, B, d, device=dev) if d_out is None else d_out.contiguous().float()
+            dhs = torch.empty(T, B, Hp, device=dev)
+            d_hT = torch.empty(B, h, device=dev)
+            g_fcw, g_fcb, g_wih, g_whh, g_bih, g_bhh = _zeros_many(dev, fc_w.shape, (d,), w_ih.shape, w_hh.shape,
+                                                                   (4 * h,), (4 * h,))
+            ones = _ones(T * B, dev)
+            keep += [d_out, dhs]
+            pre += [E.make_gemm(d_out, fc_w, dhs, T * B, Hp, d, a_sm=d, a_sk=1, b_sk=h, b_sn=1, ldc=Hp, n_valid=h),
+                    E.make_gemm(d_out, hs, g_fcw, d, h, T * B, a_sm=1, a_sk=d, b_sk=Hp, b_sn=1, ldc=h,
+                                accumulate=1, split_k=0),
+                    E.make_gemm(d_out, ones, g_fcb, d, 1, T * B, a_sm=1, a_sk=d, b_sk=1, b_sn=1, ldc=1,
+                                accumulate=1, split_k=0)]
+            seqs.append(E.make_seq(gates, hs, cs, w_hh, h, w_ih=w_ih, b_ih=b_ih, b_hh=b_hh, h_init=hT, is_dec=True,
+                                   dh_ext=dhs, ld_dh=Hp, d_h_init=d_hT))
+            post += [E.make_gemm(gates, hT, g_wih, h, h, B, a_sm=1, a_sk=4 * Hp, b_sk=h, b_sn=1, ldc=h,
+                                 batch=4, a_sz=Hp, c_sz=h * h, accumulate=1, split_k=0),
+                     E.make_gemm(gates, ones, g_bih, h, 1, T * B, a_sm=1, a_sk=4 * Hp, b_sk=1, b_sn=1, ldc=1,
+                                 batch=4, a_sz=Hp, c_sz=h, accumulate=1, split_k=0, c2=g_bhh)]
+            if T > 1:
+                # steps >= 1 feed h back as the input (mfm_model.py:85): the same product goes to both
+                post.append(E.make_gemm(gates[1:], hs, g_whh, h, h, (T - 1) * B, a_sm=1, a_sk=4 * Hp, b_sk=Hp,
+                                        b_sn=1, ldc=h, batch=4, a_sz=Hp, c_sz=h * h, accumulate=1, split_k=0,
+                                        c2=g_wih))
+            grads += [d_hT, g_wih, g_whh, g_bih, g_bhh, g_fcw, g_fcb]
+        E.gemm_grouped(pre)
+        for i in range(0, len(seqs), 4):
+            E.lstm_seq(seqs[i:i + 4], T, dims[0][0], backward=True)
+        E.gemm_grouped(post)
+        del keep
+        return (None, None) + tuple(grads)
+
+
+def decoder_group(pairs, t):
+    """[(hT, decoderLSTM), ...] -> [x_hat, ...] in shared launches (all on the same batch size)."""
+    if os.environ.get("MFM_NO_SEQ_GROUP") or len({p[0].shape[0] for p in pairs}) != 1:
+        return [m.forward(hT, t) for hT, m in pairs]
+    args = []
+    for hT, m in pairs:
+        args += [hT, m.lstm.weight_ih, m.lstm.weight_hh, m.lstm.bias_ih, m.lstm.bias_hh, m.fc1.weight, m.fc1.bias]
+    return list(_DecoderGroupFn.apply(len(pairs), t, *args))
+
+
 # ----------------------------------------------------------------------------------- MFM_KL_EF
 class _KLEFFn(torch.autograd.Function):
     """The whole MFM_KL_EF forward as ONE plan call; backward = mfm_plan_backward_ext with the
@@ -865,9 +947,9 @@ class _FactorizedMFN(nn.Module):
         h1 = [dr(relu(v)) for v, dr in zip(h1, drops)]
         fy, fl, fa, fv = [relu(v) for v in linear_group([(h1[0], self.zy_to_fy_fc2), (h1[1], self.zl_to_fl_fc2),
                                                           (h1[2], self.za_to_fa_fc2), (h1[3], self.zv_to_fv_fc2)])]
-        x_l_hat = self.decoder_l.forward(torch.cat([fy, fl], dim=1), t)
-        x_a_hat = self.decoder_a.forward(torch.cat([fy, fa], dim=1), t)
-        x_v_hat = self.decoder_v.forward(torch.cat([fy, fv], dim=1), t)
+        x_l_hat, x_a_hat, x_v_hat = decoder_group([(torch.cat([fy, fl], dim=1), self.decoder_l),
+                                                   (torch.cat([fy, fa], dim=1), self.decoder_a),
+                                                   (torch.cat([fy, fv], dim=1), self.decoder_v)], t)
         y_hat = self.fy_to_y_fc2(self.fy_to_y_dropout(relu(self.fy_to_y_fc1(fy))))
         return [x_l_hat, x_a_hat, x_v_hat, y_hat], reg, missing_loss
 
