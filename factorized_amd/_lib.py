@@ -45,7 +45,8 @@ class MemDesc(C.Structure):
                 ("gam1", C.c_void_p), ("gam2", C.c_void_p), ("mems", C.c_void_p), ("mem_out", C.c_void_p),
                 ("dmem_out", C.c_void_p), ("du1", C.c_void_p), ("du2", C.c_void_p), ("dchat", C.c_void_p),
                 ("T", C.c_int32), ("B", C.c_int32), ("M", C.c_int32), ("H1", C.c_int32), ("H2", C.c_int32),
-                ("train", C.c_int32), ("p1", C.c_float), ("p2", C.c_float), ("seed", C.c_uint64)]
+                ("train", C.c_int32), ("p1", C.c_float), ("p2", C.c_float), ("seed", C.c_uint64),
+                ("seed_dev", C.c_void_p)]
 
 
 class PlanConfig(C.Structure):

@@ -95,6 +95,7 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_fwd_kernel(const MemDev P) {
   }
   const float bb1 = d.b1b[mb], bb2 = d.b2b[mb];
 
+  const uint64_t seed = d.seed + (d.seed_dev ? *d.seed_dev : 0ull);
   if (tid < 2 * M) memb[tid] = 0.0f;
   float memr = 0.0f;                              // mem[mb], carried by lane q == 0 of the phase-B group
   const int64_t arow = ((int64_t)row) * Hn + jn;  // + t * B * Hn
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_fwd_kernel(const MemDev P) {
       u = fmaxf(u, 0.0f);
       if (d.train && pA > 0.0f) {
         const uint64_t idx = ((uint64_t)(netA + 1) << 56) + ((uint64_t)t << 40) + (uint64_t)row * (uint64_t)Hn + (uint64_t)jn;
-        u = (rng_uniform(d.seed, idx) < pA) ? 0.0f : u * keepA;
+        u = (rng_uniform(seed, idx) < pA) ? 0.0f : u * keepA;
       }
       if (actA && qa == 0) {
         ab[ja] = u;

@@ -508,6 +508,7 @@ class _MemFn(torch.autograd.Function):
     direction for all T steps; weight gradients as grouped GEMMs over the saved tensors."""
 
     _calls = 0
+    _replay_counter = {}       # device -> int64[1]: advanced inside a captured graph, added to the seed by the kernel
 
     @staticmethod
     def supported(M, H1, H2):
@@ -550,6 +551,19 @@ class _MemFn(torch.autograd.Function):
         seed = (torch.initial_seed() * 0x9E3779B1 + _MemFn._calls) & 0xFFFFFFFFFFFF
         d = _MemFn._desc(T, B, M, H1, H2, a1, a2, chat, w1m, w2m, w1b, b1b, w2b, b2b, gam1, gam2, mems, p1, p2, train,
                          seed, mem_out=mem_out)
+        if train and (p1 > 0 or p2 > 0):
+            # a replayed hipGraph re-runs this launch with the same host seed: under capture, add a device word
+            # that the graph itself advances, so every replay draws new masks
+            ctr = _MemFn._replay_counter.get(dev)
+            capturing = torch.cuda.is_current_stream_capturing()
+            if ctr is None:
+                if capturing:
+                    raise RuntimeError("MFN memory kernel: run one eager training step before capturing a graph "
+                                       "(its replay counter cannot be allocated inside the capture)")
+                ctr = _MemFn._replay_counter[dev] = torch.zeros(1, dtype=torch.int64, device=dev)
+            if capturing:
+                ctr.add_(0x1E3779B97F4A7C15)
+                d.seed_dev = ctr.data_ptr()
         _lib.check(_lib.lib().mfm_mfn_mem_fwd(C.byref(d), E._stream()), "mfm_mfn_mem_fwd")
         ctx.save_for_backward(a1, a2, chat, w1m, w2m, w1b, b1b, w2b, b2b, gam1, gam2, mems)
         ctx.cfg = (T, B, M, H1, H2, p1, p2, train, seed)

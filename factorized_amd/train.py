@@ -94,14 +94,11 @@ class GraphedModuleStep:
     choice), the learning rate is a device scalar (`set_lr`) so ReduceLROnPlateau keeps working.
     `MFM_KL_EF` has the one-call fused engine (`model.engine.train_step`), which is 10x faster still.
 
-    Restriction: the MFN memory kernel keys its dropout masks on a host-side call counter, which a graph
-    would freeze, so a model whose MFN gamma networks use dropout in train mode is refused.
+    Dropout stays random under replay: torch's generators advance a device offset, and the MFN memory kernel
+    adds a device word that the graph itself advances to its host seed (MfmMemDesc.seed_dev).
     """
 
     def __init__(self, model, cfg, B, T, lr=1e-3, warmup=3):
-        mfn = getattr(model, "mfn_encoder", None)
-        if mfn is not None and model.training and (mfn.gamma1_dropout.p > 0 or mfn.gamma2_dropout.p > 0):
-            raise ValueError("GraphedModuleStep: MFN gamma dropout > 0 would repeat its masks on every replay")
         dev = next(model.parameters()).device
         self.model, self.cfg = model, cfg
         d = cfg["input_dims"]

@@ -134,6 +134,8 @@ typedef struct MfmMemDesc {
   int32_t T, B, M, H1, H2, train;
   float p1, p2;                         /* dropout probabilities of gamma1/gamma2 */
   uint64_t seed;
+  const uint64_t* seed_dev;             /* optional device word added to `seed` when the kernel runs: lets a captured
+                                           hipGraph draw new masks on every replay (the caller advances it in-graph) */
 } MfmMemDesc;
 
 int mfm_mfn_mem_fwd(const MfmMemDesc* desc /*host*/, void* stream);

@@ -49,8 +49,6 @@ def run_graphed(cls, steps=100):
     cfg = cfgs[0]
     m = cls(*cfgs).cuda()
     m.train()
-    # the graph cannot advance the MFN kernel's host-side dropout counter: time it with the gamma dropouts off
-    m.mfn_encoder.gamma1_dropout.p = m.mfn_encoder.gamma2_dropout.p = 0.0
     xn, yn = synth.make_batch(cfg["input_dims"], 32, 20, seed=3)
     x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
     gs = train.GraphedModuleStep(m, cfg, 32, 20)

@@ -219,3 +219,30 @@ def test_graphed_module_step_matches_eager_steps(cls_name):
     gs.set_lr(1e-4)
     gs.step(*batches[0])
     assert float(gs.lr) == pytest.approx(1e-4)
+
+
+@pytest.mark.gpu
+def test_mfn_memory_dropout_changes_under_graph_replay():
+    """The MFN memory kernel's dropout is keyed by a host seed, which a captured graph would freeze; under
+    capture it adds a device word advanced by the graph (MfmMemDesc.seed_dev): replays draw new masks."""
+    from factorized_amd import mfm_model as M
+    torch.manual_seed(0)
+    T, B, Mm, H = 5, 4, 64, 128
+    g = torch.Generator().manual_seed(1)
+    r = lambda *s: (torch.randn(*s, generator=g) * 0.3).cuda()
+    args = [r(T, B, H), r(T, B, H), r(T, B, Mm), r(H, Mm), r(H, Mm), r(Mm, H), r(Mm), r(Mm, H), r(Mm)]
+    eager = M._MemFn.apply(*args, 0.5, 0.5, True)            # also allocates the replay counter
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        M._MemFn.apply(*args, 0.5, 0.5, True)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = M._MemFn.apply(*args, 0.5, 0.5, True)
+    graph.replay(); torch.cuda.synchronize(); a = out.clone()
+    graph.replay(); torch.cuda.synchronize(); b = out.clone()
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert not torch.equal(a, b)                              # different masks on the two replays
+    assert eager.shape == a.shape
