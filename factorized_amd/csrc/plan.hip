@@ -142,26 +142,27 @@ static int build(MfmPlan* P) {
   // stage 0: encoder fc1 (mfm_model.py:60-61)
   for (int e = 0; e < 4; ++e)
     add_op(P->lat_ops, L, 0, L.in_off[e], last_off[e], eh[e], eh[e], o[ep[e] + FC_W], o[ep[e] + FC_B], 0, -1, 0.f);
-  // stages 1, 2: mu / logvar heads (mfm_model.py:630-639)
+  // stage 1: mu heads (mfm_model.py:630-639).  The logvar heads only feed the KLD, nothing downstream waits
+  // for them, so they ride along with the classifier's first layer in stage 4 (the row kernels give every
+  // thread one work item per stage: 4*(16+152) output quads and 4*(16+240)/4 input groups still fit 1024).
   const int pmu[4] = {P_TO_ZL, P_TO_ZA, P_TO_ZV, P_TO_ZY};
   const int plv[4] = {P_TO_LVL, P_TO_LVA, P_TO_LVV, P_TO_LVY};
-  // (two stages although independent: the row kernels give every thread one work item per stage)
   for (int e = 0; e < 4; ++e)
     add_op(P->lat_ops, L, 1, last_off[e], L.mu_off[e], eh[e], zn[e], o[pmu[e]], o[pmu[e] + 1], 0, -1, 0.f);
-  for (int e = 0; e < 4; ++e)
-    add_op(P->lat_ops, L, 2, last_off[e], L.lv_off[e], eh[e], zn[e], o[plv[e]], o[plv[e] + 1], 0, -1, 0.f);
-  // stages 3, 4: z -> f MLPs (mfm_model.py:644-647)
+  // stages 2, 3: z -> f MLPs (mfm_model.py:644-647)
   const int pf1[4] = {P_ZL_F1, P_ZA_F1, P_ZV_F1, P_ZY_F1};
   const int pf2[4] = {P_ZL_F2, P_ZA_F2, P_ZV_F2, P_ZY_F2};
   const float pd[4] = {c.drop_zl, c.drop_za, c.drop_zv, c.drop_zy};
   for (int e = 0; e < 4; ++e)
-    add_op(P->lat_ops, L, 3, L.mu_off[e], f1_off[e], zn[e], fn[e], o[pf1[e]], o[pf1[e] + 1], 1, m1_off[e], pd[e]);
+    add_op(P->lat_ops, L, 2, L.mu_off[e], f1_off[e], zn[e], fn[e], o[pf1[e]], o[pf1[e] + 1], 1, m1_off[e], pd[e]);
   for (int e = 0; e < 4; ++e)
-    add_op(P->lat_ops, L, 4, f1_off[e], L.f_off[e], fn[e], fn[e], o[pf2[e]], o[pf2[e] + 1], 1, -1, 0.f);
-  // stages 5, 6: classifier (mfm_model.py:657)
-  add_op(P->lat_ops, L, 5, L.f_off[3], c1_off, c.fy, c.fy, o[P_Y_F1], o[P_Y_F1 + 1], 1, mc_off, c.drop_y);
-  add_op(P->lat_ops, L, 6, c1_off, L.yhat_off, c.fy, c.output_dim, o[P_Y_F2], o[P_Y_F2 + 1], 0, -1, 0.f);
-  L.nstages = 7;
+    add_op(P->lat_ops, L, 3, f1_off[e], L.f_off[e], fn[e], fn[e], o[pf2[e]], o[pf2[e] + 1], 1, -1, 0.f);
+  // stages 4, 5: classifier (mfm_model.py:657); stage 4 also carries the logvar heads
+  add_op(P->lat_ops, L, 4, L.f_off[3], c1_off, c.fy, c.fy, o[P_Y_F1], o[P_Y_F1 + 1], 1, mc_off, c.drop_y);
+  for (int e = 0; e < 4; ++e)
+    add_op(P->lat_ops, L, 4, last_off[e], L.lv_off[e], eh[e], zn[e], o[plv[e]], o[plv[e] + 1], 0, -1, 0.f);
+  add_op(P->lat_ops, L, 5, c1_off, L.yhat_off, c.fy, c.output_dim, o[P_Y_F2], o[P_Y_F2 + 1], 0, -1, 0.f);
+  L.nstages = 6;
   {
     int s = 0;
     L.stage_begin[0] = 0;

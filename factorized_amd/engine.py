@@ -72,10 +72,9 @@ def klef_param_shapes(cfg):
 _LATENT_STAGE_KEYS = [
     ("encoder_l.fc1", "encoder_a.fc1", "encoder_v.fc1", "ef_encoder.fc1"),
     ("last_to_zl_fc1", "last_to_za_fc1", "last_to_zv_fc1", "last_to_zy_fc1"),
-    ("last_to_logvarzl_fc1", "last_to_logvarza_fc1", "last_to_logvarzv_fc1", "last_to_logvarzy_fc1"),
     ("zl_to_fl_fc1", "za_to_fa_fc1", "zv_to_fv_fc1", "zy_to_fy_fc1"),
     ("zl_to_fl_fc2", "za_to_fa_fc2", "zv_to_fv_fc2", "zy_to_fy_fc2"),
-    ("fy_to_y_fc1",),
+    ("fy_to_y_fc1", "last_to_logvarzl_fc1", "last_to_logvarza_fc1", "last_to_logvarzv_fc1", "last_to_logvarzy_fc1"),
     ("fy_to_y_fc2",),
 ]
 
