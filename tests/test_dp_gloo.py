@@ -146,3 +146,34 @@ def test_device_dataset_layout_cpu():
     assert ds.nb == 2 and tuple(ds.X.shape) == (2, 20, 32, 325) and ds.X.is_contiguous()
     X, _ = synth.make_dataset(cfg["input_dims"], 70, 20, seed=11)
     assert np.array_equal(ds.batch(1)[0].numpy(), X[:, 32:64])     # contiguous column slice (mfm_mosi.py:425-429)
+
+
+def _comm_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from factorized_amd import comm
+    dev = torch.device("cpu")
+    # no GPU here: the P2P set-up fails on every rank, all ranks must learn it together (no rank is left
+    # waiting in a collective) and the RCCL/torch.distributed path must be chosen
+    ar = comm.make_allreduce(world, rank, 1000, dev, verbose=False)
+    v = torch.full((1000,), float(rank + 1))
+    ar(v)
+    os.environ["MFM_ALLREDUCE"] = "rccl"
+    forced = comm.make_allreduce(world, rank, 1000, dev, verbose=False)
+    ret[rank] = (ar.name, forced.name, float(v[0]), float(v[-1]), ar.timed_out())
+    dist.destroy_process_group()
+
+
+def test_allreduce_selection_falls_back_together():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_comm_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret[r] == ("rccl", "rccl", 3.0, 3.0, False), ret[r]
+
+
+def test_allreduce_single_rank_is_torch_path():
+    from factorized_amd import comm
+    assert comm.make_allreduce(1, 0, 10, torch.device("cpu")).name == "rccl"
