@@ -146,6 +146,25 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         in_sync = bool((lo == hi).all().item())
+        # cost of the exchange alone (outside the timed region): the collective in use next to
+        # torch.distributed's, 50 back-to-back calls on the gradient buffer each
+        coll_us = {}
+        entries = [(allreduce.name, allreduce)]
+        if allreduce.name != "rccl":
+            entries.append(("rccl", comm.TorchAllReduce()))
+        for name, fn in entries:
+            for _ in range(5):
+                fn(e.grads)
+            barrier()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(50):
+                fn(e.grads)
+            ev1.record()
+            torch.cuda.synchronize()
+            tt = torch.tensor([1e3 * ev0.elapsed_time(ev1) / 50], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            coll_us[name] = round(float(tt.item()), 1)
     timed = e.collect_timing(T, B)[dom]
     e.set_timing(T, B, 0)
 
@@ -176,7 +195,8 @@ def main():
                        "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world,
                        "params": e.layout.numel,
                        "collective": allreduce.name if allreduce is not None else None,
-                       "replicas_in_sync": in_sync},
+                       "replicas_in_sync": in_sync,
+                       "collective_us_per_call": coll_us if world > 1 else None},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 4),
                          "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 6), "traffic": traffic,
