@@ -110,6 +110,7 @@ _SIGS = {
     "mfm_plan_num_kernels": (C.c_int, []),
     "mfm_plan_kernel_name": (C.c_char_p, [C.c_int]),
     "mfm_plan_collect_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "mfm_timing_bracket_overhead_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "mfm_plan_kernel_flops": (C.c_double, [C.c_void_p, C.c_int]),
 }
 

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
   // an operand panel (same m-tile across n, same n-tile across m / gates) are neighbours in the LOGICAL
   // order, so inside every problem each XCD is given one contiguous run of logical tiles: a panel is then
   // fetched from HBM once per XCD that needs it instead of once per tile (the LSTM weight-gradient launch
-  // read 37.7 MB for ~6 MB of operands before this, profiles/r01j), while every XCD still gets an equal
+  // read 37.7 MB for ~6 MB of operands before this), while every XCD still gets an equal
   // share of every problem (a whole-launch remap left the XCDs with the long-K problems as stragglers).
   int pi = 0;
   const int bid = blockIdx.x;

@@ -726,6 +726,25 @@ extern "C" int mfm_plan_collect_timing(MfmPlan* P, double* sum_ms /*[K_COUNT]*/,
   return MFM_OK;
 }
 
+// Cost of one event bracket with nothing inside it (two hipEventRecord on `stream`): the median of 33 empty
+// brackets.  A bracket around a kernel reads kernel duration + about this much (the records are packets of
+// their own); bench.py subtracts it so that its per-kernel time can be compared with rocprofv3's.
+extern "C" int mfm_timing_bracket_overhead_ms(void* stream, double* ms_out) {
+  if (!ms_out) return MFM_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int N = 33;
+  hipEvent_t a[N], b[N];
+  for (int i = 0; i < N; ++i) { MFM_HIP_CHECK(hipEventCreate(&a[i])); MFM_HIP_CHECK(hipEventCreate(&b[i])); }
+  for (int i = 0; i < N; ++i) { MFM_HIP_CHECK(hipEventRecord(a[i], s)); MFM_HIP_CHECK(hipEventRecord(b[i], s)); }
+  MFM_HIP_CHECK(hipEventSynchronize(b[N - 1]));
+  float v[N];
+  for (int i = 0; i < N; ++i) MFM_HIP_CHECK(hipEventElapsedTime(&v[i], a[i], b[i]));
+  std::sort(v, v + N);
+  *ms_out = v[N / 2];
+  for (int i = 0; i < N; ++i) { (void)hipEventDestroy(a[i]); (void)hipEventDestroy(b[i]); }
+  return MFM_OK;
+}
+
 // ---- algorithmic work: 2*4h*(d+h) per cell step, 2*in*out per Linear
 static double fwd_flops_per_sample(const MfmPlan* P) {
   const MfmPlanConfig& c = P->cfg;

@@ -316,6 +316,13 @@ class MFMEngine:
                                                          flops=L.mfm_plan_kernel_flops(p.handle, i))
                 for i in range(n)}
 
+    def bracket_overhead_ms(self):
+        """Median cost of an empty HIP-event bracket on the current stream (what the per-kernel brackets of
+        set_timing add to each kernel they surround)."""
+        v = C.c_double(0.0)
+        _lib.check(_lib.lib().mfm_timing_bracket_overhead_ms(_stream(), C.byref(v)), "mfm_timing_bracket_overhead_ms")
+        return v.value
+
     def work_per_step(self, T, B):
         p = self.plan(T, B)
         return dict(flops=_lib.lib().mfm_plan_flops_per_step(p.handle),

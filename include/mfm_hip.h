@@ -266,6 +266,8 @@ int mfm_plan_set_timing(MfmPlan* plan, int mask);
 int mfm_plan_num_kernels(void);
 const char* mfm_plan_kernel_name(int kid);
 int mfm_plan_collect_timing(MfmPlan* plan, double* sum_ms, int64_t* count);
+/* median cost (ms) of an EMPTY event bracket on `stream`: what a bracket adds to the kernel it surrounds */
+int mfm_timing_bracket_overhead_ms(void* stream, double* ms_out);
 /* algorithmic FLOPs of ONE launch of kernel `kid` (matrix work only). */
 double mfm_plan_kernel_flops(const MfmPlan* plan, int kid);
 
