@@ -18,7 +18,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from factorized_amd import configs as C, synth  # noqa: E402
-from factorized_amd.mfm_model import MFM_KL_EF  # noqa: E402
+from factorized_amd.mfm_model import MFM, MFM_KL, MFM_KL_EF  # noqa: E402
+from factorized_amd.train import GraphedModuleStep  # noqa: E402
 
 
 def score(pred, y):
@@ -35,6 +36,10 @@ def main():
     ap.add_argument("--config", default=os.path.join(os.path.dirname(__file__), "..", "configs", "mosi.json"))
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--n-train", type=int, default=1280)
+    ap.add_argument("--model", choices=["kl_ef", "kl", "mmd"], default="kl_ef",
+                    help="kl_ef: MFM_KL_EF on the fused one-call engine; kl / mmd: MFM_KL / MFM, the classes "
+                         "train_mfm picks by config['type'] (mfm_mosi.py:398-401), on the module path with the "
+                         "reference-style step replayed as a hipGraph")
     ap.add_argument("--staged", action="store_true",
                     help="train_beta_vae schedule (mfm_mosi.py:225-361): `epochs` of stage 1 (gen + reg loss), then "
                          "`epochs` of stage 2 (disc + reg loss), instead of the joint loss of train_mfm")
@@ -49,6 +54,10 @@ def main():
     p = np.random.permutation(Xtr.shape[1])
     Xtr, ytr = Xtr[:, p], ytr[p]
     dev = torch.device("cuda")
+    if args.model != "kl_ef":
+        if args.staged:
+            raise SystemExit("--staged is implemented on the fused MFM_KL_EF engine only")
+        return train_module_path(args, cfgs, T, (Xtr, ytr), (Xva, yva), (Xte, yte), dev)
     model = MFM_KL_EF(*cfgs).to(dev)
     eng = model.engine                                     # fused step on the module's own storage
     lr = 1e-3
@@ -85,6 +94,54 @@ def main():
             bad += 1
             if bad > patience:
                 lr, bad = lr * factor, 0
+        if valid_loss <= best:
+            best = valid_loss
+            print(epoch, train_loss, valid_loss, "saving model")
+            best_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        else:
+            print(epoch, train_loss, valid_loss)
+        sys.stdout.flush()
+    model.load_state_dict(best_state)
+    model.eval()
+    with torch.no_grad():
+        decoded, _, _ = model.forward(torch.from_numpy(Xte).to(dev))
+    print("scoring y_hat")
+    score(decoded[3].squeeze(1).cpu().numpy(), yte)
+
+
+def train_module_path(args, cfgs, T, train_set, valid_set, test_set, dev):
+    """train_mfm (mfm_mosi.py:386-503) for MFM_KL / MFM: same loop, the step body replayed as a hipGraph."""
+    cfg = cfgs[0]
+    (Xtr, ytr), (Xva, yva), (Xte, yte) = train_set, valid_set, test_set
+    model = (MFM_KL if args.model == "kl" else MFM)(*cfgs).to(dev)
+    model.train()
+    bs = cfg["batchsize"]
+    nb = Xtr.shape[1] // bs                                  # floor division, tail dropped (:423)
+    Xd = torch.from_numpy(np.ascontiguousarray(Xtr[:, :nb * bs].reshape(T, nb, bs, -1).transpose(1, 0, 2, 3))).to(dev)
+    yd = torch.from_numpy(ytr[:nb * bs].reshape(nb, bs)).to(dev)
+    xv, yv = torch.from_numpy(Xva).to(dev), torch.from_numpy(yva).to(dev)
+    stepper = GraphedModuleStep(model, cfg, bs, T, lr=1e-3)
+    l1 = torch.nn.L1Loss()
+    lr, best, bad, factor, patience = 1e-3, 999999.0, 0, 0.1, 10     # ReduceLROnPlateau('min') defaults (:417)
+    best_state = None
+    for epoch in range(args.epochs):
+        model.train()
+        acc = torch.zeros((), device=dev)
+        for b in range(nb):
+            _, disc = stepper.step(Xd[b], yd[b])
+            acc += disc                                      # accumulated on the device: no per-step .item()
+        train_loss = acc.item() / nb
+        model.eval()
+        with torch.no_grad():
+            decoded, _, _ = model.forward(xv)
+            valid_loss = l1(decoded[3].squeeze(1), yv).item()
+        if valid_loss < best * (1 - 1e-4):
+            bad = 0
+        else:
+            bad += 1
+            if bad > patience:
+                lr, bad = lr * factor, 0
+                stepper.set_lr(lr)
         if valid_loss <= best:
             best = valid_loss
             print(epoch, train_loss, valid_loss, "saving model")

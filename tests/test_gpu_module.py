@@ -246,3 +246,22 @@ def test_mfn_memory_dropout_changes_under_graph_replay():
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
     assert not torch.equal(a, b)                              # different masks on the two replays
     assert eager.shape == a.shape
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["kl_ef", "kl", "mmd"])
+def test_driver_script_trains_and_scores(model):
+    """scripts/mfm_test_mosi.py (the reference's train_mfm loop restated, mfm_mosi.py:386-503) end to end on
+    synthetic MOSI-shape data: the `epoch train valid` log lines, the best-checkpoint reload and score()."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "mfm_test_mosi.py"), "--model", model,
+                          "--epochs", "2", "--n-train", "128"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().splitlines()
+    assert any(l.startswith("0 ") and "saving model" in l for l in lines), out.stdout
+    assert "scoring y_hat" in out.stdout and "mae: " in out.stdout and "Accuracy " in out.stdout
+    ep = [l.split() for l in lines if l[:2] in ("0 ", "1 ")]
+    assert len(ep) == 2 and all(np.isfinite(float(e[1])) and np.isfinite(float(e[2])) for e in ep)
