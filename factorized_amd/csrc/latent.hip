@@ -566,6 +566,22 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_row_kernel(const Laten
     if (tid < nw) reinterpret_cast<int*>(ops)[tid] = opv;
     if (tid < e3) rec[io + kk] = hv;
   }
+  // Descriptor fields the epilogue needs are fetched NOW (scalar loads, first touch of those kernarg lines)
+  // and pinned in SGPRs: read where they are used they cost the tail of the kernel a chain of cold misses.
+#define PIN_S(x) asm volatile("" : "+s"(x))
+  int e_mu[4], e_lv[4], e_zn[4], e_fo[4], e_fn[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    e_mu[m] = L.mu_off[m]; e_lv[m] = L.lv_off[m]; e_zn[m] = L.z_n[m]; e_fo[m] = L.f_off[m]; e_fn[m] = L.f_n[m];
+    PIN_S(e_mu[m]); PIN_S(e_lv[m]); PIN_S(e_zn[m]); PIN_S(e_fo[m]); PIN_S(e_fn[m]);
+  }
+  float* e_dec[3]; int64_t e_ld[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) { e_dec[m] = L.dec_init[m]; e_ld[m] = L.dec_ld[m]; PIN_S(e_dec[m]); PIN_S(e_ld[m]); }
+  int e_yoff = L.yhat_off, e_od = L.od, e_rs = L.rec_size, e_B = L.B, e_kind = L.loss_kind, e_haslv = L.has_logvar;
+  float* e_yout = L.yhat_out; float* e_rec = L.rec; float* e_losses = L.losses;
+  PIN_S(e_yoff); PIN_S(e_od); PIN_S(e_rs); PIN_S(e_B); PIN_S(e_kind); PIN_S(e_haslv); PIN_S(e_yout); PIN_S(e_rec); PIN_S(e_losses);
+#undef PIN_S
   const int q = tid & 3;
   const int wave0 = tid & ~63;
   struct Slot { f32x4 w[8]; float bias; i32x4 e; };
@@ -640,23 +656,24 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_row_kernel(const Laten
 
   // ---- losses (one partial per workgroup, one atomic each)
   float kld = 0.0f;
-  if (L.has_logvar) {
+  if (e_haslv) {
+#pragma unroll
     for (int m = 0; m < 4; ++m)
-      for (int j = tid; j < L.z_n[m]; j += nt) {
-        const float mu = rec[L.mu_off[m] + j], lv = rec[L.lv_off[m] + j];
+      for (int j = tid; j < e_zn[m]; j += nt) {
+        const float mu = rec[e_mu[m] + j], lv = rec[e_lv[m] + j];
         kld += 1.0f + lv - mu * mu - expf(lv);
       }
   }
   float disc = 0.0f;
   if (L.y) {
-    if (L.loss_kind == 0) {
-      if (tid < L.od) disc += fabsf(rec[L.yhat_off + tid] - yv);
+    if (e_kind == 0) {
+      if (tid < e_od) disc += fabsf(rec[e_yoff + tid] - yv);
     } else if (tid == 0) {
-      const float* z = rec + L.yhat_off;
+      const float* z = rec + e_yoff;
       float mx = z[0];
-      for (int o = 1; o < L.od; ++o) mx = fmaxf(mx, z[o]);
+      for (int o = 1; o < e_od; ++o) mx = fmaxf(mx, z[o]);
       float se = 0.0f;
-      for (int o = 0; o < L.od; ++o) se += expf(z[o] - mx);
+      for (int o = 0; o < e_od; ++o) se += expf(z[o] - mx);
       disc += (logf(se) + mx) - z[ylab];
     }
   }
@@ -667,26 +684,27 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_row_kernel(const Laten
     if ((tid & 63) == 0) { red[0][tid >> 6] = kld; red[1][tid >> 6] = disc; }
   }
   lds_barrier();
-  if (tid == 0 && L.losses) {
-    if (L.has_logvar) atomicAdd(L.losses + 4, -0.5f * (red[0][0] + red[0][1]));
+  if (tid == 0 && e_losses) {
+    if (e_haslv) atomicAdd(e_losses + 4, -0.5f * (red[0][0] + red[0][1]));
     if (L.y) {
-      const float inv = (L.loss_kind == 0) ? 1.0f / ((float)L.B * (float)L.od) : 1.0f / (float)L.B;
-      atomicAdd(L.losses + 0, (red[1][0] + red[1][1]) * inv);
+      const float inv = (e_kind == 0) ? 1.0f / ((float)e_B * (float)e_od) : 1.0f / (float)e_B;
+      atomicAdd(e_losses + 0, (red[1][0] + red[1][1]) * inv);
     }
   }
   // ---- outputs: plain stores, nothing in this kernel waits for them
-  const int fy = L.f_n[3];
+  const int fy = e_fn[3];
+#pragma unroll
   for (int m = 0; m < 3; ++m) {
-    if (!L.dec_init[m]) continue;
-    const int hd = fy + L.f_n[m];
+    if (!e_dec[m]) continue;
+    const int hd = fy + e_fn[m];
     for (int j = tid; j < hd; j += nt)
-      L.dec_init[m][(int64_t)row * L.dec_ld[m] + j] = (j < fy) ? rec[L.f_off[3] + j] : rec[L.f_off[m] + (j - fy)];
+      e_dec[m][(int64_t)row * e_ld[m] + j] = (j < fy) ? rec[e_fo[3] + j] : rec[e_fo[m] + (j - fy)];
   }
-  if (L.yhat_out)
-    for (int o = tid; o < L.od; o += nt) L.yhat_out[(int64_t)row * L.od + o] = rec[L.yhat_off + o];
-  if (L.rec) {
-    const int n4 = L.rec_size >> 2;
-    f32x4* d4 = reinterpret_cast<f32x4*>(L.rec + (int64_t)row * L.rec_size);
+  if (e_yout)
+    for (int o = tid; o < e_od; o += nt) e_yout[(int64_t)row * e_od + o] = rec[e_yoff + o];
+  if (e_rec) {
+    const int n4 = e_rs >> 2;
+    f32x4* d4 = reinterpret_cast<f32x4*>(e_rec + (int64_t)row * e_rs);
     const f32x4* s4 = reinterpret_cast<const f32x4*>(rec);
     for (int idx = tid; idx < n4; idx += nt) d4[idx] = s4[idx];
   }
