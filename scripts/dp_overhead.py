@@ -1,5 +1,7 @@
-import sys, time, torch
-sys.path.insert(0, "/root/repo")
+"""Fused single-GPU step against the data-parallel split (mfm_plan_grad_step + mfm_adam_flat as separate
+calls) on one GPU: the split itself must cost nothing, so that the exchange is the only data-parallel overhead."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from factorized_amd import configs as C, engine, synth, train
 cfgs = C.canonical_configs(dropout=True); cfg = cfgs[0]
 e = engine.MFMEngine(cfgs, device="cuda:0")
