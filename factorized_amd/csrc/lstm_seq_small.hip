@@ -690,13 +690,14 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
   int max_threads = 64;
   for (int i = 0; i < L.count; ++i)
     if (8 * L.d[i].Hp > max_threads) max_threads = 8 * L.d[i].Hp;
-  // Row-tile size: the finest tile that still gives at most ~1 workgroup per CU.  Fewer rows per
-  // workgroup = shorter serial chain per time step (the step time is VALU-issue bound: ~60 FMAs per
-  // thread and row); only the pre-instantiated size tuples have R < 4 variants.
+  // Row-tile size.  Fewer rows per workgroup = shorter serial chain per time step (the step time is
+  // VALU-issue bound: ~60 FMAs per thread and row), and that outweighs running several rounds of
+  // workgroups per CU for as long as measured: 1-row tiles win up to 6 workgroups per CU (B=32..384 with four
+  // LSTMs per launch: +12 % per step at B=128/256 over 2- and 4-row tiles), 4-row tiles from there on
+  // (B=512: 0.856 vs 0.948 ms); 2-row tiles never did (profiles/r01l_rows_per_workgroup.txt).  Only the
+  // pre-instantiated size tuples have R < 4 variants.
   const int cus = device_cus();
-  int R = 4;
-  if ((long)L.count * cdiv(L.B, 1) <= (long)cus + cus / 8) R = 1;
-  else if ((long)L.count * cdiv(L.B, 2) <= (long)cus + cus / 8) R = 2;
+  int R = ((long)L.count * L.B < 6L * cus) ? 1 : 4;
   if (const char* e = getenv("MFM_SEQ_ROWS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) R = v; }
   for (int attempt = 0; attempt < 2; ++attempt) {
     const int tiles = cdiv(L.B, R);
