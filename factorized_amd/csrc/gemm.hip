@@ -379,6 +379,8 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
   long base_blocks = 0;
   for (int i = 0; i < count; ++i)
     base_blocks += (long)cdiv(descs[i].m, BT) * cdiv(descs[i].n, BT) * descs[i].batch;
+  long kdepth = 2048;      // K elements one workgroup walks at most (accumulating problems; measured 256..4096 at B=512/2048)
+  if (const char* e = getenv("MFM_GEMM_KDEPTH")) { const long v = atol(e); if (v >= 64) kdepth = v; }   // tuning override
   int total = 0;
   for (int i = 0; i < count; ++i) {
     GemmProblem& P = g.p[i];
@@ -394,7 +396,7 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
       split = 1;
       if (P.d.accumulate && P.d.k >= 128) {
         const long want_fill = (3L * cus + base_blocks - 1) / base_blocks;
-        const long want_depth = (P.d.k + 1023) / 1024;
+        const long want_depth = (P.d.k + kdepth - 1) / kdepth;
         long want = want_fill > want_depth ? want_fill : want_depth;
         const long maxs = P.d.k / 64;
         split = (int)(want < 1 ? 1 : (want > maxs ? maxs : want));
