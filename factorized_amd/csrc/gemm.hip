@@ -39,8 +39,13 @@ struct GemmGroup {
 // VEC: every operand of every problem in the group is unit-stride along its 4-element load groups
 // (true for all products of the MFM step); the 16-byte path is then unconditional.  A launch with
 // an oddly strided operand uses the VEC=false instantiation (dword buffer loads) for the whole group.
+// Occupancy target (second launch-bounds argument = waves per SIMD): a K step is a chain of latencies (LDS
+// write -> barrier -> fragment reads -> 8 MFMAs), so resident waves are what keeps the MFMA pipe fed.  88
+// registers / 5 workgroups per CU for the 32x32 tiles, 158 / 3 for the 64x64 tiles, no spills; measured
+// against the compiler's default (108 / 4 and 188 / 2): +4 % on the whole step at B=2048, +1 % at B=32;
+// 6 waves (80 registers, 4 spilled) gains nothing more.
 template <int FR, bool VEC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmGroup g) {
+__global__ __launch_bounds__(256, (FR == 1) ? (VEC ? 5 : 4) : 3) void gemm_f32_kernel(const GemmGroup g) {
   constexpr int BM = 32 * FR, BN = 32 * FR;
   constexpr int LDA = BM + 16, LDB = BN + 16;     // [k][m] layout (m-/n-contiguous operands)
   constexpr int LDK = BK + 4;                     // [m][k] layout (k-contiguous operands)
