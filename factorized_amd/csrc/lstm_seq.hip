@@ -32,7 +32,7 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // --------------------------------------------------------------------------------- forward
-template <int HK4>
+template <int HK4, int KIND>
 __device__ __forceinline__ void seq_fwd_body(const SeqDev& d, const int T, const int B, const int tile,
                                              float* lds) {
   constexpr int HK = HK4 * 4;
@@ -44,7 +44,10 @@ __device__ __forceinline__ void seq_fwd_body(const SeqDev& d, const int T, const
   const int u0 = wave * 16;
   const int b = tile * 16 + bi;
   const bool bvalid = active && (b < B);
-  const bool dec = d.is_dec != 0;
+  // KIND 0: encoder-only kernel (no weight-swap code at all); KIND 1: decoder kernel -- the flag is still read
+  // from the descriptor there: with `dec` a compile-time constant hipcc hoists so much of the weight-swap code
+  // that the one-off prologue spills ~300 registers, which a 20-step kernel does notice
+  const bool dec = (KIND != 0) && (d.is_dec != 0);
 
   float w[4][HK4];
   // Branch-free weight fetch (pad elements read element 0 and are multiplied by 0).
@@ -104,7 +107,11 @@ __device__ __forceinline__ void seq_fwd_body(const SeqDev& d, const int T, const
 
   float c[4] = {0.f, 0.f, 0.f, 0.f};
   int cur = 0;
-  for (int t = 0; t < T; ++t) {
+  // One time step.  The decoder swaps its weights once (W_ih for step 0, W_ih + W_hh afterwards,
+  // mfm_model.py:83-85); that reload sits BETWEEN two calls of the step, not inside the time loop: a
+  // reload in the loop makes every weight register loop-variant and the h >= 104 instantiations then
+  // spill their weights and re-read them from scratch on every step (51-168 spilled registers).
+  auto step = [&](const int t) {
     f32x4 acc[4];
     const int64_t rowt = (int64_t)t * B + b;
     if (dec) {
@@ -126,13 +133,6 @@ __device__ __forceinline__ void seq_fwd_body(const SeqDev& d, const int T, const
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = mma16x16x4(w[g][kk], hv, acc[g]);
       }
-    }
-    if (dec && t == 0 && T > 1) {
-      // opaque zero: keeps LICM from hoisting 4*HK4 loop-invariant addresses (and their spills)
-      // out of the time loop
-      int z = 0;
-      asm volatile("" : "+v"(z));
-      load_w(std::integral_constant<int, 2>{}, z);
     }
     if (active) {
       f32x4 gi, gf, gg, go, cv, hv;
@@ -161,11 +161,18 @@ __device__ __forceinline__ void seq_fwd_body(const SeqDev& d, const int T, const
     }
     lds_barrier();
     cur ^= 1;
+  };
+  int t0 = 0;
+  if (KIND != 0 && dec) {
+    step(0);
+    if (T > 1) load_w(std::integral_constant<int, 2>{}, 0);
+    t0 = 1;
   }
+  for (int t = t0; t < T; ++t) step(t);
 }
 
 // --------------------------------------------------------------------------------- backward
-template <int HK4>
+template <int HK4, int KIND>
 __device__ __forceinline__ void seq_bwd_body(const SeqDev& d, const int T, const int B, const int tile,
                                              float* lds) {
   constexpr int HK = HK4 * 4;   // padded hidden extent; reduction runs over 4*HK gate columns
@@ -177,7 +184,10 @@ __device__ __forceinline__ void seq_bwd_body(const SeqDev& d, const int T, const
   const int u0 = wave * 16;
   const int b = tile * 16 + bi;
   const bool bvalid = active && (b < B);
-  const bool dec = d.is_dec != 0;
+  // KIND 0: encoder-only kernel (no weight-swap code at all); KIND 1: decoder kernel -- the flag is still read
+  // from the descriptor there: with `dec` a compile-time constant hipcc hoists so much of the weight-swap code
+  // that the one-off prologue spills ~300 registers, which a 20-step kernel does notice
+  const bool dec = (KIND != 0) && (d.is_dec != 0);
 
   float wT[HK];
   auto load_wT = [&](auto mode, int zofs) {
@@ -208,7 +218,9 @@ __device__ __forceinline__ void seq_bwd_body(const SeqDev& d, const int T, const
   int cur = 0;
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int t = T - 1; t >= 0; --t) {
+  // One BPTT step; `first` marks t == 0, where the decoder's input gradient goes through W_ih only: that
+  // weight swap lives in the peeled last call, outside the time loop (see the forward body).
+  auto step = [&](const int t, auto first) {
     const int64_t rowt = (int64_t)t * B + b;
     f32x4 dh = dh_rec;
     if (bvalid) {
@@ -262,10 +274,8 @@ __device__ __forceinline__ void seq_bwd_body(const SeqDev& d, const int T, const
         }
       }
       lds_barrier();
-      if (dec && t == 0) {   // grad wrt the step-0 input goes through W_ih only
-        int z = 0;
-        asm volatile("" : "+v"(z));   // opaque zero: no LICM of the reload's addresses
-        load_wT(std::integral_constant<int, 1>{}, z);
+      if constexpr (decltype(first)::value) {
+        if (dec) load_wT(std::integral_constant<int, 1>{}, 0);   // grad wrt the step-0 input goes through W_ih only
       }
       f32x4 a0 = zero4, a1 = zero4, a2 = zero4, a3 = zero4;
       if (active) {
@@ -291,6 +301,12 @@ __device__ __forceinline__ void seq_bwd_body(const SeqDev& d, const int T, const
       dh_rec = (a0 + a1) + (a2 + a3);
       cur ^= 1;
     }
+  };
+  if constexpr (KIND != 0) {
+    for (int t = T - 1; t >= 1; --t) step(t, std::false_type{});
+    step(0, std::true_type{});
+  } else {
+    for (int t = T - 1; t >= 0; --t) step(t, std::false_type{});
   }
   if (dec && bvalid && d.d_h_init) {
 #pragma unroll
@@ -301,28 +317,30 @@ __device__ __forceinline__ void seq_bwd_body(const SeqDev& d, const int T, const
   }
 }
 
-#define MFM_SEQ_CASES(BODY)                                                                  \
+#define MFM_SEQ_CASES(BODY, KIND)                                                            \
   switch (d.hk4) {                                                                           \
-    case 2: BODY<2>(d, L.T, L.B, tile, lds); break;                                          \
-    case 4: BODY<4>(d, L.T, L.B, tile, lds); break;                                          \
-    case 6: BODY<6>(d, L.T, L.B, tile, lds); break;                                          \
-    case 8: BODY<8>(d, L.T, L.B, tile, lds); break;                                          \
-    case 10: BODY<10>(d, L.T, L.B, tile, lds); break;                                        \
-    case 12: BODY<12>(d, L.T, L.B, tile, lds); break;                                        \
-    case 14: BODY<14>(d, L.T, L.B, tile, lds); break;                                        \
-    case 16: BODY<16>(d, L.T, L.B, tile, lds); break;                                        \
-    case 18: BODY<18>(d, L.T, L.B, tile, lds); break;                                        \
-    case 20: BODY<20>(d, L.T, L.B, tile, lds); break;                                        \
-    case 22: BODY<22>(d, L.T, L.B, tile, lds); break;                                        \
-    case 24: BODY<24>(d, L.T, L.B, tile, lds); break;                                        \
-    case 26: BODY<26>(d, L.T, L.B, tile, lds); break;                                        \
-    case 28: BODY<28>(d, L.T, L.B, tile, lds); break;                                        \
-    case 30: BODY<30>(d, L.T, L.B, tile, lds); break;                                        \
-    case 32: BODY<32>(d, L.T, L.B, tile, lds); break;                                        \
+    case 2: BODY<2, KIND>(d, L.T, L.B, tile, lds); break;                                                        \
+    case 4: BODY<4, KIND>(d, L.T, L.B, tile, lds); break;                                                        \
+    case 6: BODY<6, KIND>(d, L.T, L.B, tile, lds); break;                                                        \
+    case 8: BODY<8, KIND>(d, L.T, L.B, tile, lds); break;                                                        \
+    case 10: BODY<10, KIND>(d, L.T, L.B, tile, lds); break;                                                      \
+    case 12: BODY<12, KIND>(d, L.T, L.B, tile, lds); break;                                                      \
+    case 14: BODY<14, KIND>(d, L.T, L.B, tile, lds); break;                                                      \
+    case 16: BODY<16, KIND>(d, L.T, L.B, tile, lds); break;                                                      \
+    case 18: BODY<18, KIND>(d, L.T, L.B, tile, lds); break;                                                      \
+    case 20: BODY<20, KIND>(d, L.T, L.B, tile, lds); break;                                                      \
+    case 22: BODY<22, KIND>(d, L.T, L.B, tile, lds); break;                                                      \
+    case 24: BODY<24, KIND>(d, L.T, L.B, tile, lds); break;                                                      \
+    case 26: BODY<26, KIND>(d, L.T, L.B, tile, lds); break;                                                      \
+    case 28: BODY<28, KIND>(d, L.T, L.B, tile, lds); break;                                                      \
+    case 30: BODY<30, KIND>(d, L.T, L.B, tile, lds); break;                                                      \
+    case 32: BODY<32, KIND>(d, L.T, L.B, tile, lds); break;                                                      \
     default: break;                                                                          \
   }
 
-template <bool BWD>
+// One kernel per direction AND per kind (encoders / decoders): the encoder kernels then carry no weight-swap
+// code and keep all weights of the h = 120 instantiation in registers (0 spills; 165-750 before).
+template <bool BWD, int KIND>
 __global__ __launch_bounds__(512) void lstm_seq_kernel(const SeqLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int di = 0;
@@ -332,11 +350,7 @@ __global__ __launch_bounds__(512) void lstm_seq_kernel(const SeqLaunch L) {
     if (bid >= L.d[i].block_begin) di = i;
   const SeqDev& d = L.d[di];
   const int tile = bid - d.block_begin;
-  if (BWD) {
-    MFM_SEQ_CASES(seq_bwd_body)
-  } else {
-    MFM_SEQ_CASES(seq_fwd_body)
-  }
+  if (BWD) { MFM_SEQ_CASES(seq_bwd_body, KIND) } else { MFM_SEQ_CASES(seq_fwd_body, KIND) }
 }
 
 // Path choice.  The VALU kernels (lstm_seq_small.hip, 4 rows per workgroup) win while the chip
@@ -396,11 +410,29 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     if (need > lds_bytes) lds_bytes = need;
   }
   if (use_small_path(B)) return seq_small_launch(L, bwd, stream);
-  if (bwd)
-    hipLaunchKernelGGL(lstm_seq_kernel<true>, dim3(total), dim3(64 * max_waves), lds_bytes, stream, L);
-  else
-    hipLaunchKernelGGL(lstm_seq_kernel<false>, dim3(total), dim3(64 * max_waves), lds_bytes, stream, L);
-  MFM_LAUNCH_CHECK(bwd ? "lstm_seq_bwd_kernel" : "lstm_seq_fwd_kernel");
+  // encoders and decoders run different kernels: a mixed call becomes two launches
+  for (int kind = 0; kind < 2; ++kind) {
+    SeqLaunch K = L;
+    K.count = 0;
+    int ktotal = 0;
+    for (int i = 0; i < L.count; ++i) {
+      if ((L.d[i].is_dec != 0) != (kind == 1)) continue;
+      K.d[K.count] = L.d[i];
+      K.d[K.count].block_begin = ktotal;
+      ktotal += tiles;
+      ++K.count;
+    }
+    if (K.count == 0) continue;
+    const dim3 grid(ktotal), block(64 * max_waves);
+    if (bwd) {
+      if (kind) hipLaunchKernelGGL((lstm_seq_kernel<true, 1>), grid, block, lds_bytes, stream, K);
+      else hipLaunchKernelGGL((lstm_seq_kernel<true, 0>), grid, block, lds_bytes, stream, K);
+    } else {
+      if (kind) hipLaunchKernelGGL((lstm_seq_kernel<false, 1>), grid, block, lds_bytes, stream, K);
+      else hipLaunchKernelGGL((lstm_seq_kernel<false, 0>), grid, block, lds_bytes, stream, K);
+    }
+    MFM_LAUNCH_CHECK(bwd ? "lstm_seq_bwd_kernel" : "lstm_seq_fwd_kernel");
+  }
   return MFM_OK;
 }
 
