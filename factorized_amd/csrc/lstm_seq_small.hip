@@ -667,7 +667,10 @@ static bool try_all(const SeqLaunch& L, bool bwd, int total, int threads, size_t
          try_launch4<R, 26, 6, 6, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||      // decoders
          try_launch4<R, 30, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||      // single-LSTM launches
          try_launch4<R, 26, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||
-         try_launch4<R, 8, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err);
+         try_launch4<R, 8, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||
+         // MFM / MFM_KL on the module path (mfm_model.py::seq_group): encoders 32/8/80 + MFN LSTM 88, MFN 64/48
+         try_launch4<R, 8, 2, 20, 22>(L, bwd, total, threads, lds_bytes, stream, err) ||
+         try_launch4<R, 16, 12, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err);
 }
 
 static size_t small_lds_bytes(const SeqLaunch& L, bool bwd, int R) {
