@@ -19,11 +19,12 @@
 //     LDS as [gate*HK+unit][16 rows], and dh_{t-1}^T = W^T * dA_t^T runs on the same MFMA with
 //     four independent accumulator chains.  dA overwrites the saved gates in place; the weight
 //     gradients are batched GEMMs over dA afterwards (plan.hip).
+#include <algorithm>
 #include <type_traits>
 
 #include <stdlib.h>
 
-#include "common.h"
+#include "internal.h"
 #include "lstm_seq_dev.h"
 
 namespace mfm {
@@ -384,6 +385,12 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     if (rc != MFM_OK) return rc;
   }
   if (count == 0) return MFM_OK;
+  // Longest job first: workgroups are dispatched in block order, and once a launch needs more than one
+  // round of workgroups (B >= 128 with four LSTMs) the widest LSTM must not start in the last round
+  // (B=2048: encoder recurrences 154 -> 132 us forward, 163 -> 151 us backward).  While everything is
+  // resident at once the caller's order is kept: widest-first measured 0.8 % slower per step at B=32.
+  if ((long)count * B > (long)device_cus() && !getenv("MFM_SEQ_KEEP_ORDER"))
+    std::stable_sort(descs, descs + count, [](const MfmSeqDesc& a, const MfmSeqDesc& b) { return a.h > b.h; });
   SeqLaunch L;
   memset(&L, 0, sizeof(L));
   L.count = count; L.T = T; L.B = B;

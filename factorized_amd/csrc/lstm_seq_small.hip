@@ -663,7 +663,9 @@ static bool try_launch4(const SeqLaunch& L, bool bwd, int total, int threads, si
 template <int R>
 static bool try_all(const SeqLaunch& L, bool bwd, int total, int threads, size_t lds_bytes, hipStream_t stream,
                     hipError_t* err) {
+  // (from 2 rounds of workgroups on, the launcher orders the LSTMs of a call widest first: lstm_seq.hip)
   return try_launch4<R, 8, 2, 20, 30>(L, bwd, total, threads, lds_bytes, stream, err) ||     // MFM_KL_EF encoders
+         try_launch4<R, 30, 20, 8, 2>(L, bwd, total, threads, lds_bytes, stream, err) ||
          try_launch4<R, 26, 6, 6, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||      // decoders
          try_launch4<R, 30, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||      // single-LSTM launches
          try_launch4<R, 26, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||

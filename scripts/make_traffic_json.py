@@ -17,9 +17,9 @@ GEMM_ORDER = ["proj_gemm", "fc1_mse_gemm", "fc1_bwd_gemm", "dw_gemm"]
 
 def classify(name):
     if "lstm_seq_small_kernel4<false" in name or "lstm_seq_fwd" in name or "lstm_seq_small_kernel<false" in name:
-        return "enc_seq_fwd" if ("8, 2, 20, 30" in name) else "dec_seq_fwd"
+        return "enc_seq_fwd" if ("8, 2, 20, 30" in name or "30, 20, 8, 2" in name) else "dec_seq_fwd"
     if "lstm_seq_small_kernel4<true" in name or "lstm_seq_bwd" in name or "lstm_seq_small_kernel<true" in name:
-        return "enc_seq_bwd" if ("8, 2, 20, 30" in name) else "dec_seq_bwd"
+        return "enc_seq_bwd" if ("8, 2, 20, 30" in name or "30, 20, 8, 2" in name) else "dec_seq_bwd"
     if "latent_fwd" in name:
         return "latent_fwd"
     if "latent_bwd" in name:
