@@ -65,11 +65,10 @@ __device__ __forceinline__ void seq_fwd_body(const SeqDev& d, const int T, const
         const int k = 4 * kk + q;
         const int off = (g * h + uc) * h + min(k, h - 1) + zofs;   // always a valid address
         const float m = (float)(uok & (int)(k < h));            // 0 for pad elements
-        float v;
-        if constexpr (MODE == 0) v = d.w_hh[off];
-        else if constexpr (MODE == 1) v = d.w_ih[off];
-        else v = d.w_ih[off] + d.w_hh[off];
-        w[g][kk] = v * m;
+        if constexpr (MODE == 0) w[g][kk] = d.w_hh[off] * m;
+        else if constexpr (MODE == 1) w[g][kk] = d.w_ih[off] * m;
+        else if constexpr (MODE == 2) w[g][kk] = (d.w_ih[off] + d.w_hh[off]) * m;
+        else w[g][kk] += d.w_hh[off] * m;     // MODE 3: W_ih is resident, add W_hh (same single rounding as MODE 2)
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -166,7 +165,7 @@ __device__ __forceinline__ void seq_fwd_body(const SeqDev& d, const int T, const
   int t0 = 0;
   if (KIND != 0 && dec) {
     step(0);
-    if (T > 1) load_w(std::integral_constant<int, 2>{}, 0);
+    if (T > 1) load_w(std::integral_constant<int, 3>{}, 0);   // W_ih (step 0) -> W_ih + W_hh (steps >= 1)
     t0 = 1;
   }
   for (int t = t0; t < T; ++t) step(t);
