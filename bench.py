@@ -221,9 +221,17 @@ def main():
             if cores > 1:
                 runs.append(O.time_cpu_steps(cfgs, B, T, budget_s=8.0, threads=min(cores, 8)))
             r = max(runs, key=lambda q: q["samples_per_s"])
+            cpu_model = "?"
+            try:
+                for line in open("/proc/cpuinfo"):
+                    if line.startswith("model name"):
+                        cpu_model = line.split(":", 1)[1].strip()
+                        break
+            except OSError:
+                pass
             out["cpu_baseline"] = {"value": round(r["samples_per_s"], 1), "unit": "samples/s", "cores": r["threads"],
                                    "kind": "port", "ms_per_step": round(r["ms_per_step"], 2),
-                                   "host_cores": cores,
+                                   "host_cores": cores, "host_cpu": cpu_model,
                                    "all_runs": [{"threads": q["threads"], "samples_per_s": round(q["samples_per_s"], 1),
                                                  "steps": q["steps"]} for q in runs],
                                    "sample": "%d training steps (~8 s) of the torch-CPU oracle (restated reference "
