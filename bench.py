@@ -241,6 +241,10 @@ def main():
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
+        # ordered teardown: no rank unmaps or frees its staging block while a peer could still touch it
+        barrier()
+        if allreduce is not None:
+            allreduce.close()
         dist.destroy_process_group()
 
 
