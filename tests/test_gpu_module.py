@@ -265,3 +265,29 @@ def test_driver_script_trains_and_scores(model):
     assert "scoring y_hat" in out.stdout and "mae: " in out.stdout and "Accuracy " in out.stdout
     ep = [l.split() for l in lines if l[:2] in ("0 ", "1 ")]
     assert len(ep) == 2 and all(np.isfinite(float(e[1])) and np.isfinite(float(e[2])) for e in ep)
+
+
+@pytest.mark.gpu
+def test_graphed_module_step_cross_entropy_and_multi_output():
+    """GraphedModuleStep on the YouTube-shape classification head (CrossEntropy on int64 labels,
+    mfm_you.py:451,484) and on a 7-output regression (MOSEI shape): losses are finite and training moves them."""
+    from factorized_amd import configs, synth, train
+    from factorized_amd import mfm_model as M
+    for cfg_fn, B, T in ((configs.you_configs, 8, 5), (configs.mosei_configs, 8, 5)):
+        cfgs = cfg_fn(dropout=False)
+        cfg = cfgs[0]
+        torch.manual_seed(1)
+        model = M.MFM_KL(*cfgs).cuda()
+        model.train()
+        classes = cfg["output_dim"] if cfg.get("loss", "l1") == "ce" else 0
+        xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=5, output_dim=cfg["output_dim"], classes=classes)
+        x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
+        gs = train.GraphedModuleStep(model, cfg, B, T, lr=1e-3)
+        first = None
+        for i in range(30):
+            loss, disc = gs.step(x, y)
+            if i == 0:
+                first = float(loss)
+        last = float(loss)
+        assert np.isfinite(first) and np.isfinite(last) and np.isfinite(float(disc))
+        assert last < first, (first, last)
