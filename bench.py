@@ -79,7 +79,7 @@ def main():
     my_batches = train.shard_batches(data.nb, rank, world)
     # the gradient collective: the P2P kernel if it sets up and validates on this job's devices, else RCCL
     allreduce = comm.make_allreduce(world, rank, e.grads.numel(), e.device) if world > 1 else None
-    stepper = train.DataParallelStep(e, world, lr=1e-3, allreduce=allreduce)
+    stepper = train.DataParallelStep(e, world, lr=1e-3, allreduce=allreduce, rank=rank)
 
     def run(n, first=0):
         for i in range(n):

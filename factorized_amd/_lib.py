@@ -49,6 +49,13 @@ class MemDesc(C.Structure):
                 ("seed_dev", C.c_void_p)]
 
 
+class AdamSpan(C.Structure):
+    _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("step", C.c_int32), ("reserved", C.c_int32)]
+
+
+MFM_ADAM_MAX_SPANS = 8
+
+
 class PlanConfig(C.Structure):
     _fields_ = [("d_l", C.c_int32), ("d_a", C.c_int32), ("d_v", C.c_int32),
                 ("zl", C.c_int32), ("za", C.c_int32), ("zv", C.c_int32), ("zy", C.c_int32),
@@ -75,6 +82,8 @@ _SIGS = {
                                   C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mfm_adam_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "mfm_adam_flat_spans": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AdamSpan), C.c_int32,
+                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mfm_p2p_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
     "mfm_p2p_handle_bytes": (C.c_int, []),
     "mfm_p2p_export": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -104,6 +113,10 @@ _SIGS = {
     "mfm_plan_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_float,
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mfm_plan_train_step_staged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(AdamSpan),
+                                             C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mfm_plan_latent_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mfm_plan_flops_per_step": (C.c_double, [C.c_void_p]),
     "mfm_plan_bytes_per_step": (C.c_double, [C.c_void_p]),
     "mfm_plan_set_timing": (C.c_int, [C.c_void_p, C.c_int]),

@@ -98,6 +98,10 @@ class P2PAllReduce:
     def allreduce_adam(self, e, lr, grad_scale):
         """All-reduce of e.grads and the flat Adam update of e.params in the same launch."""
         e.step_count += 1
+        gs = getattr(e, "group_steps", None)
+        if gs:
+            for g in gs:
+                gs[g] = e.step_count
         stream = torch.cuda.current_stream(e.grads.device).cuda_stream
         _lib.check(self._L.mfm_p2p_allreduce_adam(self._h, C.c_void_p(e.grads.data_ptr()), C.c_void_p(e.params.data_ptr()),
                                                   C.c_void_p(e.adam_m.data_ptr()), C.c_void_p(e.adam_v.data_ptr()),

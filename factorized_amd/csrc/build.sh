@@ -1,21 +1,5 @@
 #!/bin/bash
-# Build libmfm_hip.so for gfx950 in-tree (cross-compiles without a GPU).
+# Build libmfm_hip.so for gfx950 in-tree (cross-compiles without a GPU); incremental through the Makefile.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-ROOT="$(cd "$HERE/../.." && pwd)"
-OUT="$HERE/../libmfm_hip.so"
-HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function ${MFM_EXTRA_FLAGS:-}"
-mkdir -p "$HERE/build"
-pids=()
-for f in gemm lstm_seq lstm_seq_small lstm_step latent mfn_mem mmd p2p elementwise plan; do
-  extra=""
-  # the SLP vectoriser packs the recurrent FMAs into v_pk_fma_f32, whose even-aligned register
-  # pairs push the weight-resident LSTM kernels over their VGPR budget (spills in the time loop)
-  case "$f" in lstm_seq*) extra="-fno-slp-vectorize" ;; esac
-  ( $HIPCC $FLAGS $extra -c "$HERE/$f.hip" -o "$HERE/build/$f.o" ) &
-  pids+=($!)
-done
-for p in "${pids[@]}"; do wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$HERE"/build/*.o -o "$OUT"
-echo "built $OUT"
+make -C "$HERE" -f "$HERE/Makefile" -j"$(nproc)" "$@"

@@ -133,6 +133,79 @@ int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, int ste
   return MFM_OK;
 }
 
+// ---------------------------------------------------------------- Adam over spans of the flat buffer
+// Staged training (train_beta_vae, reference mfm_mosi.py:278-281) leaves whole groups of tensors without a
+// gradient; torch.optim.Adam skips a parameter whose .grad is None and keeps a step counter PER PARAMETER, so a
+// group that joins later starts its bias correction at step 1.  One launch updates up to MFM_ADAM_MAX_SPANS
+// disjoint element ranges, each with its own step count; elements outside every span are left untouched.
+struct AdamSpansDev {
+  int64_t b4[MFM_ADAM_MAX_SPANS], e4[MFM_ADAM_MAX_SPANS];       // [begin, end) in float4 units
+  float step_size[MFM_ADAM_MAX_SPANS], bc2_sqrt[MFM_ADAM_MAX_SPANS];
+  int count;
+};
+__global__ __launch_bounds__(256) void adam_spans_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, int64_t n4,
+                                                         const AdamSpansDev S, float beta1, float beta2, float eps,
+                                                         float grad_scale) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float step_size = 0.0f, bc2_sqrt = 1.0f;
+    bool live = false;
+#pragma unroll
+    for (int k = 0; k < MFM_ADAM_MAX_SPANS; ++k) {
+      const bool in = (k < S.count) && (i >= S.b4[k]) && (i < S.e4[k]);
+      step_size = in ? S.step_size[k] : step_size;
+      bc2_sqrt = in ? S.bc2_sqrt[k] : bc2_sqrt;
+      live = live || in;
+    }
+    if (!live) continue;
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gg = gv[j] * grad_scale;
+      mv[j] = mv[j] + (1.0f - beta1) * (gg - mv[j]);
+      vv[j] = vv[j] * beta2 + (1.0f - beta2) * gg * gg;
+      const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+      pv[j] = pv[j] - step_size * mv[j] / denom;
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+}
+
+int adam_spans_launch(float* p, const float* g, float* m, float* v, const MfmAdamSpan* spans, int nspans, float lr,
+                      float beta1, float beta2, float eps, float grad_scale, hipStream_t stream) {
+  MFM_REQUIRE(p && g && m && v && spans && nspans >= 1 && nspans <= MFM_ADAM_MAX_SPANS, "adam spans: bad arguments (nspans=%d)", nspans);
+  MFM_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam spans: buffers must be 16-byte aligned");
+  AdamSpansDev S;
+  memset(&S, 0, sizeof(S));
+  S.count = nspans;
+  int64_t hi = 0;
+  for (int k = 0; k < nspans; ++k) {
+    const MfmAdamSpan& sp = spans[k];
+    MFM_REQUIRE(sp.begin >= 0 && sp.end > sp.begin && (sp.begin & 3) == 0 && (sp.end & 3) == 0 && sp.step >= 1,
+                "adam spans[%d]: [%lld,%lld) step %d (bounds must be multiples of 4 elements, step >= 1)", k,
+                (long long)sp.begin, (long long)sp.end, sp.step);
+    const double bc1 = 1.0 - pow((double)beta1, (double)sp.step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)sp.step);
+    S.b4[k] = sp.begin >> 2; S.e4[k] = sp.end >> 2;
+    S.step_size[k] = (float)((double)lr / bc1);
+    S.bc2_sqrt[k] = (float)sqrt(bc2);
+    if (sp.end > hi) hi = sp.end;
+  }
+  const int64_t n4 = hi >> 2;
+  int64_t nb = (n4 + 255) / 256;
+  if (nb < 1) nb = 1;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(adam_spans_kernel, dim3((int)nb), dim3(256), 0, stream, p, g, m, v, n4, S, beta1, beta2, eps, grad_scale);
+  MFM_LAUNCH_CHECK("adam_spans_kernel");
+  return MFM_OK;
+}
+
 // ---------------------------------------------------------------- fill
 __global__ void fill_kernel(float* p, int64_t n, float val) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = val;
@@ -167,4 +240,9 @@ extern "C" int mfm_mse_fwd_bwd(const float* xhat, const float* x, int64_t ldx, i
 extern "C" int mfm_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr,
                              float beta1, float beta2, float eps, float grad_scale, void* stream) {
   return mfm::adam_launch(p, g, m, v, n, step, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream);
+}
+
+extern "C" int mfm_adam_flat_spans(float* p, const float* g, float* m, float* v, const MfmAdamSpan* spans, int32_t nspans,
+                                   float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  return mfm::adam_spans_launch(p, g, m, v, spans, nspans, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream);
 }

@@ -21,6 +21,8 @@ struct MseItem {
 int mse_group_launch(const MseItem* items, int count, hipStream_t stream);
 int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1,
                 float beta2, float eps, float grad_scale, hipStream_t stream);
+int adam_spans_launch(float* p, const float* g, float* m, float* v, const MfmAdamSpan* spans, int nspans, float lr,
+                      float beta1, float beta2, float eps, float grad_scale, hipStream_t stream);
 int fill_launch(float* p, int64_t n, float val, hipStream_t stream);
 
 // latent.hip -- the fused "latent stack": encoder fc1 heads, mu/logvar heads, z->f MLPs,

@@ -61,6 +61,7 @@ struct MfmPlan {
   mfm::LatentDev lat;
   mfm::LatOp lat_ops[MFM_LAT_MAXOPS];
   int64_t lat_ops_off, dbg_off, lat_grd, lat_items_off;
+  int lay_f1[4], lay_m1[4], lay_c1, lay_mc;   // record offsets kept for mfm_plan_latent_layout
   std::vector<int> lat_items;       // row-path item tables: forward then backward, [MAXSTAGES][1024][4] each
   // timing
   int timing_mask;
@@ -138,6 +139,8 @@ static int build(MfmPlan* P) {
   const int c1_off = seg(c.fy), mc_off = seg(c.fy);
   L.yhat_off = seg(c.output_dim); L.od = c.output_dim;
   L.rec_size = rs;
+  for (int e = 0; e < 4; ++e) { P->lay_f1[e] = f1_off[e]; P->lay_m1[e] = m1_off[e]; }
+  P->lay_c1 = c1_off; P->lay_mc = mc_off;
   const int64_t* o = P->off;
   // stage 0: encoder fc1 (mfm_model.py:60-61)
   for (int e = 0; e < 4; ++e)
@@ -695,6 +698,48 @@ extern "C" int mfm_plan_train_step(MfmPlan* P, float* params, float* grads, floa
   rc = backward(P, params, x, y, 0, (float*)workspace, grads, s);
   if (rc != MFM_OK) return rc;
   RUN(K_ADAM, adam_launch(params, grads, adam_m, adam_v, P->n_params, step, lr, 0.9f, 0.999f, 1e-8f, grad_scale, s));
+  return MFM_OK;
+}
+
+extern "C" int mfm_plan_train_step_staged(MfmPlan* P, float* params, float* grads, float* adam_m, float* adam_v,
+                                          const float* x, const void* y, uint64_t seed, int32_t stage,
+                                          const MfmAdamSpan* spans, int32_t nspans, float lr, float grad_scale,
+                                          void* workspace, float* losses, void* stream) {
+  if (!P || !params || !grads || !adam_m || !adam_v || !x || !y || !workspace || !spans) {
+    set_error("mfm_plan_train_step_staged: null argument");
+    return MFM_ERR_ARG;
+  }
+  MFM_REQUIRE(stage >= 0 && stage <= 2, "mfm_plan_train_step_staged: stage %d", stage);
+  hipStream_t s = (hipStream_t)stream;
+  float* xo[3] = {nullptr, nullptr, nullptr};
+  int rc = forward(P, params, x, y, 1, seed, (float*)workspace, xo, nullptr, losses, s, grads);
+  if (rc != MFM_OK) return rc;
+  rc = backward(P, params, x, y, stage, (float*)workspace, grads, s);
+  if (rc != MFM_OK) return rc;
+  RUN(K_ADAM, adam_spans_launch(params, grads, adam_m, adam_v, spans, nspans, lr, 0.9f, 0.999f, 1e-8f, grad_scale, s));
+  return MFM_OK;
+}
+
+extern "C" int mfm_plan_latent_layout(const MfmPlan* P, int64_t* out) {
+  if (!P || !out) { set_error("mfm_plan_latent_layout: null argument"); return MFM_ERR_ARG; }
+  for (int i = 0; i < 32; ++i) out[i] = 0;
+  out[0] = P->lat_rec * (int64_t)sizeof(float);
+  out[1] = P->lat_grd * (int64_t)sizeof(float);
+  out[2] = P->lat.rec_size;
+  const int order[4] = {0, 1, 2, 3};      // l, a, v, y
+  for (int i = 0; i < 4; ++i) {
+    const int e = order[i];
+    out[3 + i] = P->lay_m1[e];
+    out[8 + i] = P->lay_f1[e];
+    out[13 + i] = P->lat.f_n[e];
+    out[17 + i] = P->lat.f_off[e];
+    out[23 + i] = P->lat.mu_off[e];
+    out[27 + i] = P->lat.z_n[e];
+  }
+  out[7] = P->lay_mc;
+  out[12] = P->lay_c1;
+  out[21] = P->lat.yhat_off;
+  out[22] = P->lat.row_path;
   return MFM_OK;
 }
 

@@ -79,6 +79,17 @@ _LATENT_STAGE_KEYS = [
 ]
 
 
+def _staged_group(name):
+    """Which stage losses of train_beta_vae (reference mfm_mosi.py:278-281) reach a tensor: 'disc' = only the
+    discriminative term (the classifier), 'gen' = only the reconstruction terms (the three decoders and the
+    modality z->f MLPs), 'shared' = every stage (everything on the way to the KLD and to f_y)."""
+    if name.startswith("fy_to_y_"):
+        return "disc"
+    if name.startswith("decoder_") or name.startswith(("zl_to_fl_", "za_to_fa_", "zv_to_fv_")):
+        return "gen"
+    return "shared"
+
+
 class FlatLayout:
     """Placement of the named tensors in one flat fp32 buffer.  `shapes`/`offsets` iterate in the
     reference's state_dict order (what the C plan expects); the PHYSICAL order is chosen here."""
@@ -105,6 +116,16 @@ class FlatLayout:
         self.slots = [(placed[n], int(np.prod(self.shapes[n])), tuple(self.shapes[n])) for n in self.shapes]
         self.total = cur
         self.numel = sum(int(np.prod(s)) for s in self.shapes.values())
+        # contiguous runs of tensors that belong to the same staged-training group, in physical order:
+        # [(group, begin, end)] with 64-float aligned bounds (Adam over spans, mfm_adam_flat_spans)
+        self.group_spans = []
+        ends = [placed[n] for n in order[1:]] + [cur]
+        for name, end in zip(order, ends):
+            g = _staged_group(name)
+            if self.group_spans and self.group_spans[-1][0] == g:
+                self.group_spans[-1] = (g, self.group_spans[-1][1], end)
+            else:
+                self.group_spans.append((g, placed[name], end))
 
     def views(self, flat):
         out = OrderedDict()
@@ -149,6 +170,8 @@ class _Plan:
         _lib.check(_lib.lib().mfm_plan_init_workspace(handle, _ptr(self.workspace), _stream()),
                    "mfm_plan_init_workspace")
         self.losses = torch.zeros(_lib.MFM_LOSS_SLOTS, dtype=torch.float32, device=engine.device)
+        self.fwd_serial = 0        # forwards run on this workspace so far (autograd path: whose activations it holds)
+        self.consumed = False      # the last forward's activations were overwritten by a backward
 
     def __del__(self):
         try:
@@ -180,6 +203,12 @@ class MFMEngine:
         self.reg_scale = float(reg_scale)
         self.seed = 1234
         self._plans = {}
+        # Staged training (train_beta_vae): Adam step counters per tensor group.  "frozen" = torch >= 2 semantics
+        # (zero_grad sets .grad to None, Adam skips such parameters: a group without a gradient in the current
+        # stage keeps its values and moments); "legacy" = torch 0.4 semantics (zero_grad leaves zero tensors
+        # behind once a gradient has existed: such a group keeps moving on its decaying momentum).  See DESIGN.md.
+        self.staged_adam = "frozen"
+        self.group_steps = {"shared": 0, "gen": 0, "disc": 0}
 
     # ------------------------------------------------------------------ parameters
     def param_views(self):
@@ -199,6 +228,7 @@ class MFMEngine:
             host[o:o + a.size] = a.ravel()
         self.params.copy_(torch.from_numpy(host))
         self.adam_m.zero_(); self.adam_v.zero_(); self.step_count = 0
+        self.group_steps = {"shared": 0, "gen": 0, "disc": 0}
 
     def state_dict(self):
         return OrderedDict((k, v.detach().clone()) for k, v in self.param_views().items())
@@ -232,6 +262,8 @@ class MFMEngine:
         if want_xhat:
             xh = [torch.empty(T, B, d, dtype=torch.float32, device=self.device) for d in (d_l, d_a, d_v)]
         y_hat = torch.empty(B, self.cfg["output_dim"], dtype=torch.float32, device=self.device)
+        p.fwd_serial += 1
+        p.consumed = False
         _lib.check(_lib.lib().mfm_plan_forward(p.handle, _ptr(self.params), _ptr(x), _ptr(y), int(bool(train)),
                                                C.c_uint64(self.seed), _ptr(p.workspace), _ptr(xh[0]), _ptr(xh[1]),
                                                _ptr(xh[2]), _ptr(y_hat), _ptr(p.losses), _stream()),
@@ -260,14 +292,54 @@ class MFMEngine:
                                                     _ptr(self.grads), _stream()), "mfm_plan_backward_ext")
         return self.grads
 
-    def train_step(self, x, y, lr=1e-3, grad_scale=1.0, check=True):
-        """forward(train) + backward(joint loss) + Adam, one enqueue.  Returns the device
-        tensor of loss slots (no sync)."""
+    def _staged_spans(self, stage):
+        """Advance the per-group Adam step counters for one step of `stage` and return the spans to update."""
+        has_grad = {"shared": True, "gen": stage != 2, "disc": stage != 1}
+        gs = self.group_steps
+        active = {}
+        for g in gs:
+            if has_grad[g] or (self.staged_adam == "legacy" and gs[g] > 0):
+                gs[g] += 1
+                active[g] = gs[g]
+        spans = [(b, e, active[g]) for g, b, e in self.layout.group_spans if g in active]
+        merged = []
+        for b, e, st in spans:                       # neighbours with the same step count become one span
+            if merged and merged[-1][1] == b and merged[-1][2] == st:
+                merged[-1] = (merged[-1][0], e, st)
+            else:
+                merged.append((b, e, st))
+        return merged
+
+    def train_step(self, x, y, lr=1e-3, grad_scale=1.0, check=True, stage=0):
+        """forward(train) + backward + Adam, one enqueue.  stage 0 = the joint loss of train_mfm
+        (mfm_mosi.py:439); 1 = gen + reg, 2 = disc + reg (train_beta_vae, mfm_mosi.py:278-281), with Adam
+        skipping the tensors the stage loss does not reach (`staged_adam`).  Returns the device tensor of loss
+        slots (no sync)."""
         if check:
             self._check_inputs(x, y)
         T, B, _ = x.shape
         p = self.plan(T, B)
+        gs = self.group_steps
+        if stage != 0 or not (gs["shared"] == gs["gen"] == gs["disc"]):
+            spans = self._staged_spans(stage)
+            self.step_count = gs["shared"]
+            if len(spans) > _lib.MFM_ADAM_MAX_SPANS:
+                raise _lib.MfmError("staged Adam: %d spans (max %d)" % (len(spans), _lib.MFM_ADAM_MAX_SPANS))
+            arr = (_lib.AdamSpan * len(spans))()
+            for i, (b, e_, st) in enumerate(spans):
+                arr[i].begin, arr[i].end, arr[i].step = b, e_, st
+            p.fwd_serial += 1
+            p.consumed = True
+            _lib.check(_lib.lib().mfm_plan_train_step_staged(
+                p.handle, _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v), _ptr(x), _ptr(y),
+                C.c_uint64(self.seed), int(stage), arr, len(spans), lr, grad_scale, _ptr(p.workspace), _ptr(p.losses),
+                _stream()), "mfm_plan_train_step_staged")
+            return p.losses
         self.step_count += 1
+        for g in gs:
+            gs[g] = self.step_count
+        p.fwd_serial += 1
+        p.consumed = True
         _lib.check(_lib.lib().mfm_plan_train_step(p.handle, _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m),
                                                   _ptr(self.adam_v), _ptr(x), _ptr(y), C.c_uint64(self.seed),
                                                   self.step_count, lr, grad_scale, _ptr(p.workspace),
@@ -282,6 +354,8 @@ class MFMEngine:
             self._check_inputs(x, y)
         T, B, _ = x.shape
         p = self.plan(T, B)
+        p.fwd_serial += 1
+        p.consumed = True
         _lib.check(_lib.lib().mfm_plan_grad_step(p.handle, _ptr(self.params), _ptr(self.grads), _ptr(x), _ptr(y),
                                                  C.c_uint64(self.seed), _ptr(p.workspace), _ptr(p.losses), _stream()),
                    "mfm_plan_grad_step")
@@ -289,9 +363,33 @@ class MFMEngine:
 
     def adam(self, lr=1e-3, grad_scale=1.0):
         self.step_count += 1
+        for g in self.group_steps:
+            self.group_steps[g] = self.step_count
         _lib.check(_lib.lib().mfm_adam_flat(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m),
                                             _ptr(self.adam_v), self.layout.total, self.step_count, lr,
                                             0.9, 0.999, 1e-8, grad_scale, _stream()), "mfm_adam_flat")
+
+    def latent_record(self, T, B):
+        """(activation record, gradient record, layout dict) of the latent stack for the plan at (T,B): views into
+        the plan workspace [B, rec] plus record offsets (mfm_plan_latent_layout).  Tests / tuning aids."""
+        p = self.plan(T, B)
+        out = (C.c_int64 * 32)()
+        _lib.check(_lib.lib().mfm_plan_latent_layout(p.handle, out), "mfm_plan_latent_layout")
+        rs = int(out[2])
+        ws = p.workspace.view(torch.float32)
+        rec = ws[out[0] // 4: out[0] // 4 + B * rs].view(B, rs)
+        grd = ws[out[1] // 4: out[1] // 4 + B * rs].view(B, rs)
+        sites = ("zl_to_fl", "za_to_fa", "zv_to_fv", "zy_to_fy", "fy_to_y")
+        lay = dict(rec_size=rs, row_path=bool(out[22]),
+                   mask={s: int(out[3 + i]) for i, s in enumerate(sites)},
+                   act={s: int(out[8 + i]) for i, s in enumerate(sites)},
+                   width={s: int(out[13 + min(i, 3)]) for i, s in enumerate(sites)},
+                   f={s: int(out[17 + i]) for i, s in enumerate(("l", "a", "v", "y"))},
+                   mu={s: int(out[23 + i]) for i, s in enumerate(("l", "a", "v", "y"))},
+                   z_n={s: int(out[27 + i]) for i, s in enumerate(("l", "a", "v", "y"))},
+                   y_hat=int(out[21]))
+        lay["width"]["fy_to_y"] = int(out[16])
+        return rec, grd, lay
 
     def loss_dict(self, losses):
         """Host view of the loss slots (synchronises)."""

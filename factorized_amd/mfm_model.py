@@ -355,10 +355,17 @@ class _KLEFFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, module, *params):
+        if x.requires_grad:
+            raise _lib.MfmError("MFM_KL_EF.forward: the input requires grad; the fused plan does not produce d loss / d x "
+                                "(the reference never asks for it) -- detach the batch")
         eng = module.engine
         out = eng.forward(x, None, train=module.training, want_xhat=True)
         kld = out["losses"][4].clone()
         ctx.module = module
+        # the plan's workspace for (T,B) holds the activations of the LAST forward only: remember which one
+        # this graph belongs to, so that backward can refuse to differentiate somebody else's activations
+        plan = eng.plan(x.shape[0], x.shape[1])
+        ctx.plan, ctx.serial = plan, plan.fwd_serial
         ctx.save_for_backward(x)
         return out["x_l_hat"], out["x_a_hat"], out["x_v_hat"], out["y_hat"], kld
 
@@ -368,6 +375,16 @@ class _KLEFFn(torch.autograd.Function):
         module = ctx.module
         eng = module.engine
         T, B, _ = x.shape
+        plan = ctx.plan
+        if eng.plan(T, B) is not plan or plan.fwd_serial != ctx.serial:
+            raise RuntimeError("MFM_KL_EF backward: another forward with the same (T=%d, B=%d) ran on this model since "
+                               "the graph was built; its activations replaced this one's in the plan workspace.  Call "
+                               "backward() before the next forward (gradient accumulation over several forwards: "
+                               "backward each one first)" % (T, B))
+        if plan.consumed:
+            raise RuntimeError("MFM_KL_EF backward: this graph was already back-propagated (BPTT overwrites the saved "
+                               "gates in place; retain_graph is not supported on the fused plan)")
+        plan.consumed = True
         d_l, d_a, d_v = eng.cfg["input_dims"]
         dev = x.device
 
@@ -426,6 +443,22 @@ class MFM_KL_EF(nn.Module):
         self._param_names = [n for n, _ in self.named_parameters()]
         self._plist = [p for _, p in self.named_parameters()]      # Parameter objects survive .to()/.cuda()
         self._engine = None
+
+    # ---- whole-module checkpoints (torch.save(model, path) / torch.load, reference mfm_mosi.py:342-346,473-481)
+    # and copy.deepcopy: the engine holds native plan handles and device workspaces, none of which can or should
+    # be serialised.  The state keeps the parameters (views are written as ordinary tensors sharing one storage)
+    # and drops the engine; the first CUDA use of the restored module adopts a fresh one (`engine` property).
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_engine"] = None
+        return state
+
+    def __setstate__(self, state):
+        super(MFM_KL_EF, self).__setstate__(state)
+        self._engine = None
+        # `_plist` must hold the SAME Parameter objects as the sub-modules (pickle keeps identity through its memo;
+        # rebuild defensively in case a custom unpickler did not)
+        self._plist = [p for _, p in self.named_parameters()]
 
     # ---- flat storage: every parameter becomes a view into the engine's flat buffer
     def _flat_ok(self):
@@ -702,14 +735,14 @@ class _SeqGroupFn(torch.autograd.Function):
                 saved += [xr, w_ih, w_hh, gates, hs, cs, fc_w]
             else:
                 saved += [xr, w_ih, w_hh, gates, hs, cs]
-            dims.append((k, d, h, Hp, ldx))
+            dims.append((k, d, h, Hp, ldx, bool(x.requires_grad)))
         E.gemm_grouped(proj)
         for i in range(0, len(seqs), 4):                   # MFM_MAX_SEQ recurrences per launch
             E.lstm_seq(seqs[i:i + 4], T, B)
         if heads:
             E.gemm_grouped(heads)
         res, it, si = [], iter(outs), 0
-        for (k, d, h, Hp, ldx) in dims:
+        for (k, d, h, Hp, ldx, _) in dims:
             if k == "enc":
                 res.append(next(it))
                 si += 7
@@ -730,7 +763,7 @@ class _SeqGroupFn(torch.autograd.Function):
         pre, seqs, post, grads = [], [], [], []
         keep = []          # the descriptors hold raw pointers: temporaries must outlive the launches below
         si, gi = 0, 0
-        for (k, d, h, Hp, ldx) in dims:
+        for (k, d, h, Hp, ldx, need_dx) in dims:
             if k == "enc":
                 xr, w_ih, w_hh, gates, hs, cs, fc_w = saved[si:si + 7]
                 si += 7
@@ -769,7 +802,13 @@ class _SeqGroupFn(torch.autograd.Function):
             if T > 1:
                 post.append(E.make_gemm(gates[1:], hs, g_whh, h, h, (T - 1) * B, a_sm=1, a_sk=4 * Hp, b_sk=Hp,
                                         b_sn=1, ldc=h, batch=4, a_sz=Hp, c_sz=h * h, accumulate=1, split_k=0))
-            grads += [None, g_wih, g_whh, g_bih, g_bhh] + tail
+            dx = None
+            if need_dx:
+                # dx_t = dA_t W_ih, summed over the four gates (same product as _EncoderSeqFn.backward)
+                dx = torch.zeros(T, B, d, device=dev)
+                post.append(E.make_gemm(gates, w_ih, dx, T * B, d, h, a_sm=4 * Hp, a_sk=1, b_sk=d, b_sn=1, ldc=d,
+                                        batch=4, a_sz=Hp, b_sz=h * d, c_sz=0, accumulate=1, split_k=1))
+            grads += [dx, g_wih, g_whh, g_bih, g_bhh] + tail
         if pre:
             E.gemm_grouped(pre)
         for i in range(0, len(seqs), 4):

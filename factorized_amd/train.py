@@ -52,10 +52,17 @@ class DeviceDataset:
 class DataParallelStep:
     """step(x, y): fused single-GPU step, or fwd/bwd + all-reduce + Adam when world > 1."""
 
-    def __init__(self, engine, world=1, lr=1e-3, allreduce=None):
+    def __init__(self, engine, world=1, lr=1e-3, allreduce=None, rank=None):
         self.e = engine
         self.world = world
         self.lr = lr
+        if world > 1:
+            # per-rank dropout streams (SURVEY.md section 8e): the latent kernels key their masks by
+            # (seed, call counter, op, row, column), and every rank numbers its rows 0..B-1 -- with one
+            # shared seed the W shards of a global batch would all draw the same masks
+            r = dp_env()[0] if rank is None else int(rank)
+            if hasattr(engine, "seed"):
+                engine.seed = int(engine.seed) + 7919 * r
         self.allreduce = allreduce            # comm.make_allreduce(...); default torch.distributed (RCCL)
         if world > 1:
             engine.reg_scale = float(world)
@@ -99,6 +106,12 @@ class GraphedModuleStep:
     """
 
     def __init__(self, model, cfg, B, T, lr=1e-3, warmup=3):
+        from .mfm_model import MFM_KL_EF
+        if isinstance(model, MFM_KL_EF):
+            # the fused plan bakes its dropout seed (host value x call counter) into the captured kernel
+            # arguments: every replay would reuse one set of masks
+            raise ValueError("GraphedModuleStep is for the module-path classes (MFM, MFM_KL); MFM_KL_EF trains through "
+                             "its one-call fused engine: model.engine.train_step(x, y)")
         dev = next(model.parameters()).device
         self.model, self.cfg = model, cfg
         d = cfg["input_dims"]

@@ -157,6 +157,16 @@ int mfm_mmd_fwd_bwd(const float* z, const float* gauss, int32_t B, int32_t dim, 
 int mfm_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr,
                   float beta1, float beta2, float eps, float grad_scale, void* stream);
 
+/* The same update restricted to up to MFM_ADAM_MAX_SPANS disjoint element ranges of the flat buffer, each with its
+ * own 1-based step count; elements outside every span keep p, m and v untouched.  This is torch.optim.Adam's
+ * treatment of parameters whose .grad is None (skipped; per-parameter step counters), which staged training
+ * relies on: train_beta_vae (reference mfm_mosi.py:278-281, 346-358) trains gen+reg first -- the classifier gets no
+ * gradient -- then disc+reg -- the decoders and the modality z->f MLPs get none.  begin/end are multiples of 4. */
+#define MFM_ADAM_MAX_SPANS 8
+typedef struct MfmAdamSpan { int64_t begin, end; int32_t step; int32_t reserved; } MfmAdamSpan;
+int mfm_adam_flat_spans(float* p, const float* g, float* m, float* v, const MfmAdamSpan* spans /*host*/, int32_t nspans,
+                        float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Gradient all-reduce of the data-parallel step (the reference has no multi-GPU
  * path): in-place fp32 sum of one flat buffer over all ranks of one node, ONE kernel launch on the
@@ -252,6 +262,22 @@ int mfm_plan_grad_step(MfmPlan* plan, const float* params, float* grads, const f
 int mfm_plan_train_step(MfmPlan* plan, float* params, float* grads, float* adam_m, float* adam_v,
                         const float* x, const void* y, uint64_t seed, int32_t step, float lr,
                         float grad_scale, void* workspace, float* losses, void* stream);
+
+/* forward (train mode) + backward of the STAGE loss (0 joint, 1 gen+reg, 2 disc+reg) + Adam over `spans`
+ * (mfm_adam_flat_spans semantics) in one enqueue: one step of train_beta_vae's loop (reference mfm_mosi.py:255-285). */
+int mfm_plan_train_step_staged(MfmPlan* plan, float* params, float* grads, float* adam_m, float* adam_v,
+                               const float* x, const void* y, uint64_t seed, int32_t stage,
+                               const MfmAdamSpan* spans /*host*/, int32_t nspans, float lr, float grad_scale,
+                               void* workspace, float* losses, void* stream);
+
+/* Where the latent stack keeps its per-row record inside the workspace (tests and tuning aids: dropout masks and
+ * pre-activation gradients can be read back from the workspace tensor).  out[0] byte offset of the activation
+ * record [B, rec], out[1] byte offset of the gradient record, out[2] rec (floats per row); then record offsets
+ * (floats): out[3..6] dropout scale (0 or 1/(1-p)) of z{l,a,v,y}_to_f*_fc1, out[7] of fy_to_y_fc1,
+ * out[8..11] post-dropout activation of the same four layers, out[12] of fy_to_y_fc1, out[13..16] their widths
+ * f{l,a,v,y}, out[17..20] f segments (outputs of *_fc2), out[21] y_hat, out[22] 1 if the row-per-workgroup kernels
+ * run at this (T,B), out[23..26] mu segments z{l,a,v,y} (inputs of *_fc1), out[27..30] their widths, out[31] reserved. */
+int mfm_plan_latent_layout(const MfmPlan* plan, int64_t* out /*[32]*/);
 
 /* Algorithmic work of one training step at this plan's (T,B):
  * 3 x forward FLOPs; activation+input bytes per sample plus 10 P 4 parameter/optimizer bytes. */

@@ -63,3 +63,17 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     den = max(np.abs(b).max(), 1e-12) if b.size else 1.0
     return float(np.abs(a - b).max() / den) if b.size else 0.0
+
+
+def report(key, value):
+    """Record a measured worst-case error (DESIGN.md quotes these): appended to gpurun_out/parity_worst.jsonl when
+    that directory exists (the GPU runs create it), otherwise dropped."""
+    import json
+    d = os.path.join(os.path.dirname(GOLDEN.rstrip("/")), "..", "gpurun_out")
+    d = os.path.normpath(d)
+    if os.path.isdir(d):
+        try:
+            with open(os.path.join(d, "parity_worst.jsonl"), "a") as f:
+                f.write(json.dumps({"key": key, "value": float(value)}) + "\n")
+        except OSError:
+            pass

@@ -142,9 +142,55 @@ def run_case(name, variant, cfg_fn, overrides, B, T, steps):
           "bytes=%d" % os.path.getsize(os.path.join(HERE, name + ".npz")))
 
 
+def run_staged(name, B, T, n1, n2):
+    """train_beta_vae's schedule (mfm_mosi.py:238-239, 278-284, 346-358): ONE Adam optimizer, `n1` steps on
+    gen + reg (stage 1), then `n2` steps on disc + reg (stage 2), on the reference MFM_KL_EF.  Two traces:
+    'frozen' with this torch's zero_grad (sets .grad to None -> Adam skips parameters the stage loss does not
+    reach) and 'legacy' with zero_grad(set_to_none=False), which is what the reference's PyTorch 0.4 did (a
+    zero gradient keeps the parameter moving on its decaying first moment)."""
+    cfgs = C.canonical_configs(dropout=False)
+    cfg = cfgs[0]
+    xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7)
+    x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+    out = {}
+    for mode in ("frozen", "legacy"):
+        model = REF.MFM_KL_EF(*cfgs)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        w = synth.make_weights(shapes, seed=1234)
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()})
+        model.train()
+        opt = torch.optim.Adam(model.parameters())
+        trace = []
+        for s in range(n1 + n2):
+            stage = 1 if s < n1 else 2
+            opt.zero_grad(set_to_none=(mode == "frozen"))
+            terms, _ = ref_losses(model, x, y, cfg, "l1")
+            reg = cfg["lda_mmd"] * terms["reg"]
+            loss = terms["gen"] + reg if stage == 1 else terms["disc"] + reg      # mfm_mosi.py:278-281
+            loss.backward()
+            opt.step()
+            trace.append([loss.item(), terms["disc"].item(), terms["gen"].item(), terms["reg"].item()])
+            if s == n1 - 1:
+                out[mode + "_param_after_stage1"] = np.stack([summarize(p) for p in model.parameters()])
+        out[mode + "_param_after_stage2"] = np.stack([summarize(p) for p in model.parameters()])
+        out[mode + "_trace"] = np.array(trace, dtype=np.float64)
+    out["param_names"] = np.array([n for n, _ in model.named_parameters()])
+    out["meta"] = np.array([B, T, n1, n2])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "frozen lossN=%.6f legacy lossN=%.6f" % (out["frozen_trace"][-1][0], out["legacy_trace"][-1][0]),
+          "bytes=%d" % os.path.getsize(os.path.join(HERE, name + ".npz")))
+
+
+STAGED = [("klef_staged_b32_t20", 32, 20, 4, 4)]
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for case in CASES:
         if only and case[0] not in only:
             continue
         run_case(*case)
+    for case in STAGED:
+        if only and case[0] not in only:
+            continue
+        run_staged(*case)

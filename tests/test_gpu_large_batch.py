@@ -1,0 +1,154 @@
+"""Numeric parity of the LARGE-BATCH kernels against the CPU oracle (round-1 review: every figure quoted for
+B > 512 ran on kernels no oracle comparison reached).  Kernels named here, by the path that selects them:
+
+  latent_fwd_kernel<true> / latent_bwd_kernel<true>   staged-LDS latent kernels: B > 256, or MFM_LATENT_PATH=staged
+  gemm_f32_kernel<2, true>                             64x64 tiles: blocks64 >= 2 CUs, or MFM_GEMM_FR=2
+  lstm_seq_kernel<false|true, 0|1>                     MFMA recurrences (16 rows per workgroup): B > 512
+  lstm_seq_small_kernel4<.., R=4, ..>                  4-row VALU tiles: 384 < B <= 512
+
+Tolerance: 1e-4 relative fp32 (BASELINE.json north_star), forward losses + all 78 gradients + 3 Adam steps."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mfm_oracle as O
+from factorized_amd import configs, synth
+from tests import cases
+from tests.cases import grad_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _compare(cfgs, B, T, loss_kind="l1", adam_steps=3, tag=""):
+    from factorized_amd import engine
+    cfg = cfgs[0]
+    classes = cfg["output_dim"] if loss_kind == "ce" else 0
+    xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=13, output_dim=cfg["output_dim"], classes=classes)
+    e = engine.MFMEngine(cfgs)
+    w = synth.make_weights(e.layout.shapes, seed=1234)
+    e.load_weights(w)
+    torch.set_num_threads(8)
+    m = O.build("kl_ef", cfgs)
+    O.load_numpy_weights(m, w)
+    m.train()
+    x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+    terms = O.loss_terms(m, x, y, cfg, loss_kind)
+    terms["loss"].backward()
+    xd, yd = x.cuda(), y.cuda()
+    out = e.forward(xd, yd, train=True, want_xhat=True)
+    ld = e.loss_dict(out["losses"])
+    for k in ("disc", "gen_l", "gen_a", "gen_v", "gen", "reg", "loss"):
+        ref = float(terms[k].detach())
+        assert abs(ld[k] - ref) <= TOL * max(abs(ref), 1e-3), (k, ld[k], ref)
+    dec = terms["decoded"]
+    for got, ref in ((out["x_l_hat"], dec[0]), (out["x_a_hat"], dec[1]), (out["x_v_hat"], dec[2]), (out["y_hat"], dec[3])):
+        assert cases.rel_err(got.cpu().numpy(), ref.detach().numpy()) < TOL
+    e.backward(xd, yd, stage=0)
+    gv = e.grad_views()
+    worst = ("", 0.0)
+    for n, p in m.named_parameters():
+        err = grad_err(gv[n].cpu().numpy(), p.grad.numpy())
+        if err > worst[1]:
+            worst = (n, err)
+    cases.report("large_batch_grad_%s_B%d_T%d" % (tag, B, T), worst[1])
+    assert worst[1] < TOL, "worst gradient mismatch %s: %.3e" % worst
+    if adam_steps:
+        opt = torch.optim.Adam(m.parameters())
+        for _ in range(adam_steps):
+            opt.zero_grad()
+            O.loss_terms(m, x, y, cfg, loss_kind)["loss"].backward()
+            opt.step()
+            e.train_step(xd, yd)
+        pv = e.param_views()
+        wp = 0.0
+        for n, p in m.named_parameters():
+            # Adam normalises by sqrt(v): an element whose gradient is ~0 moves by up to lr per step whatever the
+            # rounding says, so the trajectory bound is a fraction of the adam_steps*lr a parameter can move at all
+            wp = max(wp, float(np.max(np.abs(pv[n].cpu().numpy() - p.detach().numpy()))))
+        cases.report("large_batch_adam%d_absdiff_%s_B%d_T%d" % (adam_steps, tag, B, T), wp)
+        assert wp < 0.1 * adam_steps * 1e-3, wp
+
+
+@pytest.mark.parametrize("B", [512, 1024])
+def test_mosi_shape_large_batch_matches_oracle(B, monkeypatch):
+    """Default path selection at B=512 (4-row VALU recurrences, staged latent, 32x32 or 64x64 GEMM tiles by block
+    count) and B=1024 (MFMA recurrences lstm_seq_kernel<*,0|1>, latent_*_kernel<true>, gemm_f32_kernel<2,true>)."""
+    _need_gpu()
+    for k in ("MFM_SEQ_PATH", "MFM_SEQ_ROWS", "MFM_LATENT_PATH", "MFM_GEMM_FR", "MFM_SEQ_STEPWISE"):
+        monkeypatch.delenv(k, raising=False)
+    _compare(configs.canonical_configs(dropout=False), B, 20, tag="mosi")
+
+
+def test_mosei_shape_large_batch_matches_oracle(monkeypatch):
+    """BASELINE config 4's shape (300/74/35 features, 7 regression outputs) at B=1024, T=20 on the default
+    large-batch path."""
+    _need_gpu()
+    for k in ("MFM_SEQ_PATH", "MFM_SEQ_ROWS", "MFM_LATENT_PATH", "MFM_GEMM_FR", "MFM_SEQ_STEPWISE"):
+        monkeypatch.delenv(k, raising=False)
+    _compare(configs.mosei_configs(dropout=False), 1024, 20, tag="mosei")
+
+
+def test_you_shape_large_batch_matches_oracle(monkeypatch):
+    """BASELINE config 3's shape (300/74/36 features, T=50, 3-way cross-entropy) at B=640."""
+    _need_gpu()
+    for k in ("MFM_SEQ_PATH", "MFM_SEQ_ROWS", "MFM_LATENT_PATH", "MFM_GEMM_FR", "MFM_SEQ_STEPWISE"):
+        monkeypatch.delenv(k, raising=False)
+    _compare(configs.you_configs(dropout=False), 640, 50, loss_kind="ce", adam_steps=2, tag="you")
+
+
+@pytest.mark.parametrize("variant", ["staged", "fr2", "staged+fr2+mfma"])
+@pytest.mark.parametrize("name", cases.KLEF_CASES)
+def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
+    """The same kernels forced onto every golden case (B = 1 .. 229, ragged sizes, T = 1, CE and 7-output heads):
+    MFM_LATENT_PATH=staged -> latent_fwd/bwd_kernel<true|false>, MFM_GEMM_FR=2 -> gemm_f32_kernel<2,*>,
+    MFM_SEQ_PATH=mfma -> lstm_seq_kernel; gradients against the oracle and the reference's golden summaries."""
+    _need_gpu()
+    from factorized_amd import engine
+    monkeypatch.delenv("MFM_SEQ_STEPWISE", raising=False)
+    monkeypatch.delenv("MFM_SEQ_ROWS", raising=False)
+    if "staged" in variant:
+        monkeypatch.setenv("MFM_LATENT_PATH", "staged")
+    if "fr2" in variant:
+        monkeypatch.setenv("MFM_GEMM_FR", "2")
+    if "mfma" in variant:
+        monkeypatch.setenv("MFM_SEQ_PATH", "mfma")
+    cs = cases.load_case(name)
+    e = engine.MFMEngine(cs["cfgs"])
+    w = synth.make_weights(e.layout.shapes, seed=1234)
+    e.load_weights(w)
+    if "staged" in variant:
+        assert not e.latent_record(cs["T"], cs["B"])[2]["row_path"]
+    cfg = cs["cfg"]
+    x, y = torch.from_numpy(cs["x"]), torch.from_numpy(cs["y"])
+    torch.set_num_threads(4)
+    m = O.build("kl_ef", cs["cfgs"])
+    O.load_numpy_weights(m, w)
+    m.train()
+    terms = O.loss_terms(m, x, y, cfg, cs["loss_kind"])
+    terms["loss"].backward()
+    xd, yd = x.cuda(), y.cuda()
+    out = e.forward(xd, yd, train=True, want_xhat=False)
+    ld = e.loss_dict(out["losses"])
+    gold = cs["gold"]
+    for k in ("disc", "gen", "reg", "loss"):
+        ref = float(gold["fwd_" + k])
+        assert abs(ld[k] - ref) <= TOL * max(abs(ref), 1e-3), (k, ld[k], ref)
+    e.backward(xd, yd, stage=0)
+    gv = e.grad_views()
+    rows, worst = [], ("", 0.0)
+    for n, p in m.named_parameters():
+        g = gv[n].cpu().numpy()
+        rows.append(cases.summarize(g))
+        err = grad_err(g, p.grad.numpy())
+        if err > worst[1]:
+            worst = (n, err)
+    assert worst[1] < TOL, "worst gradient mismatch %s: %.3e" % worst
+    gs = gold["grad_summary"]
+    scale = np.maximum(np.abs(gs[:, :1]), 1e-6)
+    assert np.max(np.abs(np.stack(rows) - gs) / scale) < 5 * TOL

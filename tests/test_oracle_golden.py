@@ -80,3 +80,36 @@ def test_numpy_cell_gate_order():
                                cell.bias_ih.detach().numpy(), cell.bias_hh.detach().numpy())
     assert np.allclose(h1.detach().numpy(), h2, atol=1e-6)
     assert np.allclose(c1.detach().numpy(), c2, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["frozen", "legacy"])
+def test_oracle_staged_training_matches_reference(mode):
+    """train_beta_vae's two-stage schedule on the oracle vs the reference's own trajectory (run_staged in
+    tests/golden/make_golden.py): pins oracle.stage_loss and both zero_grad semantics."""
+    torch.set_num_threads(1)
+    gold = np.load(cases.GOLDEN + "/klef_staged_b32_t20.npz")
+    B, T, n1, n2 = (int(v) for v in gold["meta"])
+    from factorized_amd import configs
+    cfgs = configs.canonical_configs(dropout=False)
+    cfg = cfgs[0]
+    model = O.build("kl_ef", cfgs)
+    O.load_numpy_weights(model, synth.make_weights(O.state_shapes(model), seed=1234))
+    model.train()
+    xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7)
+    x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+    opt = torch.optim.Adam(model.parameters())
+    trace = []
+    for s in range(n1 + n2):
+        stage = 1 if s < n1 else 2
+        opt.zero_grad(set_to_none=(mode == "frozen"))
+        terms = O.loss_terms(model, x, y, cfg)
+        loss = O.stage_loss(terms, cfg, stage)
+        loss.backward()
+        opt.step()
+        trace.append([loss.item(), terms["disc"].item(), terms["gen"].item(), terms["reg"].item()])
+        if s == n1 - 1:
+            p1 = np.stack([cases.summarize(p.detach().numpy()) for p in model.parameters()])
+            assert np.allclose(p1, gold[mode + "_param_after_stage1"], rtol=1e-5, atol=1e-6)
+    p2 = np.stack([cases.summarize(p.detach().numpy()) for p in model.parameters()])
+    assert np.allclose(p2, gold[mode + "_param_after_stage2"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(np.array(trace), gold[mode + "_trace"], rtol=1e-5, atol=1e-6)
