@@ -59,6 +59,7 @@ def _compare(cfgs, B, T, loss_kind="l1", adam_steps=3, tag=""):
     cases.report("large_batch_grad_%s_B%d_T%d" % (tag, B, T), worst[1])
     assert worst[1] < TOL, "worst gradient mismatch %s: %.3e" % worst
     if adam_steps:
+        g0 = {n: p.grad.detach().clone().numpy() for n, p in m.named_parameters()}
         opt = torch.optim.Adam(m.parameters())
         for _ in range(adam_steps):
             opt.zero_grad()
@@ -66,13 +67,20 @@ def _compare(cfgs, B, T, loss_kind="l1", adam_steps=3, tag=""):
             opt.step()
             e.train_step(xd, yd)
         pv = e.param_views()
-        wp = 0.0
+        w_sig, w_any = 0.0, 0.0
         for n, p in m.named_parameters():
-            # Adam normalises by sqrt(v): an element whose gradient is ~0 moves by up to lr per step whatever the
-            # rounding says, so the trajectory bound is a fraction of the adam_steps*lr a parameter can move at all
-            wp = max(wp, float(np.max(np.abs(pv[n].cpu().numpy() - p.detach().numpy()))))
-        cases.report("large_batch_adam%d_absdiff_%s_B%d_T%d" % (adam_steps, tag, B, T), wp)
-        assert wp < 0.1 * adam_steps * 1e-3, wp
+            d = np.abs(pv[n].cpu().numpy() - p.detach().numpy())
+            # Adam normalises by sqrt(v): an element whose gradient is rounding noise (|g| below 1e-3 of the tensor's
+            # largest) moves by up to lr per step in a direction the noise decides, so only the elements with a
+            # significant gradient are held to a tight bound; the rest to "cannot have moved further than Adam moves"
+            sig = np.abs(g0[n]) > 1e-3 * np.abs(g0[n]).max()
+            if sig.any():
+                w_sig = max(w_sig, float(d[sig].max()))
+            w_any = max(w_any, float(d.max()))
+        cases.report("large_batch_adam%d_absdiff_significant_%s_B%d_T%d" % (adam_steps, tag, B, T), w_sig)
+        cases.report("large_batch_adam%d_absdiff_any_%s_B%d_T%d" % (adam_steps, tag, B, T), w_any)
+        assert w_sig < 2e-5, w_sig
+        assert w_any < 1.01 * adam_steps * 1e-3, w_any
 
 
 @pytest.mark.parametrize("B", [512, 1024])

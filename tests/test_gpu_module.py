@@ -56,12 +56,16 @@ def test_module_driver_step_matches_oracle(name):
         ropt.zero_grad()
         rloss = _ref_style_loss(ref, x, y, cfg)
         rloss.backward()
+        cases.report("module_klef_loss_rel_step%d_%s" % (step, name), abs(loss.item() - rloss.item()) / abs(rloss.item()))
         assert abs(loss.item() - rloss.item()) < 10 * TOL * abs(rloss.item())
         if step == 0:
             for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
                 assert rel_err(p.grad.cpu().numpy(), q.grad.numpy()) < TOL, n
         opt.step()
         ropt.step()
+    wp = max(rel_err(p.detach().cpu().numpy(), q.detach().numpy())
+             for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()))
+    cases.report("module_klef_params_rel_after3_%s" % name, wp)
     for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
         assert rel_err(p.detach().cpu().numpy(), q.detach().numpy()) < 20 * TOL, n
     # evaluate()/predict() style call (mfm_mosi.py:445-465)
@@ -170,6 +174,7 @@ def test_mfn_based_models_match_reference(name):
                     assert rel_err(p.grad.cpu().numpy(), q.grad.numpy()) < 2 * TOL, n
         opt.step()
     ref_trace = gold["trace"][:, 0]
+    cases.report("module_mfn_trace_rel_%s" % variant, np.max(np.abs(np.array(trace) - ref_trace) / np.abs(ref_trace)))
     assert np.max(np.abs(np.array(trace) - ref_trace) / np.abs(ref_trace)) < 20 * TOL
 
 
