@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
+BF16_MATRIX_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (2:1-sparsity figures are never used)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -36,6 +37,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (reference batchsize=32)")
     ap.add_argument("--seq", type=int, default=0, help="sequence length; 0 = read configs/mosi.json")
     ap.add_argument("--shape", default="mosi", choices=["mosi", "you", "mosei"])
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="fp32 = the reference's arithmetic (BASELINE config 1, the headline); bf16 = bf16 MFMA operands, "
+                         "fp32 accumulate / master weights / cell state / loss (BASELINE configs 2-4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-kernel time table to stderr")
     args = ap.parse_args()
@@ -71,7 +75,7 @@ def main():
                                                                  "mosei": "mosi.json"}[args.shape]))
     B = args.batch
 
-    e = engine.MFMEngine(cfgs, device="cuda:%d" % local_rank)
+    e = engine.MFMEngine(cfgs, device="cuda:%d" % local_rank, precision=args.dtype)
     e.load_weights(synth.make_weights(e.layout.shapes, seed=1234))
     train.broadcast_params(e, world)
     n_samples = max(1280, B * world * 8)          # MOSI-scale split (1,284 train utterances)
@@ -179,11 +183,14 @@ def main():
         k_flops = timed["flops"]
         achieved = (k_flops / (k_ms * 1e-3)) / 1e12 if k_ms > 0 and k_flops > 0 else 0.0
         work = e.work_per_step(T, B)
+        peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "fp32" else BF16_MATRIX_PEAK_TFLOPS
         # HBM bytes per launch of the dominant kernel: measured in a SEPARATE rocprofv3 --pmc pass of this
         # command (scripts/profile_round.sh -> profiles/r01_traffic.json); only valid for the workload it
         # was measured on, otherwise null.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json" if args.dtype == "fp32" else "r02_traffic_bf16.json")
+        if not os.path.exists(tpath) and args.dtype == "fp32":
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath) and args.shape == "mosi" and B == 32 and T == 20:
             try:
                 traffic = json.load(open(tpath)).get(dom, {}).get("total_bytes")
@@ -193,19 +200,23 @@ def main():
             "metric": "training samples/sec (MOSI-shape, T=%d, 3 modalities)" % T,
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "MFM_KL_EF %s canonical sizes, per-GPU B=%d, T=%d, D=%d, train mode "
-                                   "(fwd + joint loss + bwd + Adam), fp32 HIP" % (args.shape, B, T, sum(cfg["input_dims"])),
+                                   "(fwd + joint loss + bwd + Adam), %s HIP" % (args.shape, B, T, sum(cfg["input_dims"]),
+                                                                            "fp32" if args.dtype == "fp32" else
+                                                                            "bf16-operand / fp32-accumulate"),
                        "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world,
                        "params": e.layout.numel,
                        "collective": allreduce.name if allreduce is not None else None,
                        "replicas_in_sync": in_sync,
                        "collective_us_per_call": coll_us if world > 1 else None},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 4),
-                         "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 6), "traffic": traffic,
-                         "note": "fp32 matrix peak == fp32 vector peak on gfx950 (157.3 TF); at B<=512 the "
-                                 "recurrent products run on the VALU small-tile kernels, above on the MFMA",
+                         "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 6), "traffic": traffic,
+                         "note": ("fp32 matrix peak == fp32 vector peak on gfx950 (157.3 TF); at B<=512 the "
+                                  "recurrent products run on the VALU small-tile kernels, above on the MFMA")
+                         if args.dtype == "fp32" else
+                         "dense bf16 MFMA peak; every GEMM and recurrence feeds v_mfma_f32_16x16x32_bf16",
                          "kernel_us": round(1e3 * k_ms, 2), "kernel_us_event_bracket": round(1e3 * k_raw_ms, 2),
                          "empty_bracket_us": round(1e3 * ev_ms, 2), "kernel_flops": k_flops,
                          "step_flops": work["flops"], "step_bytes": work["bytes"],

@@ -65,7 +65,7 @@ class PlanConfig(C.Structure):
                 ("lda_xl", C.c_float), ("lda_xa", C.c_float), ("lda_xv", C.c_float), ("lda_reg", C.c_float),
                 ("drop_zy", C.c_float), ("drop_zl", C.c_float), ("drop_za", C.c_float),
                 ("drop_zv", C.c_float), ("drop_y", C.c_float),
-                ("reg_scale", C.c_float)]
+                ("reg_scale", C.c_float), ("precision", C.c_int32)]
 
 
 _SIGS = {
@@ -73,6 +73,9 @@ _SIGS = {
     "mfm_last_error": (C.c_char_p, []),
     "mfm_device_cus": (C.c_int, []),
     "mfm_gemm_grouped_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.c_void_p]),
+    "mfm_gemm_grouped_bf16": (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.c_void_p]),
+    "mfm_lstm_seq_fwd_bf16": (C.c_int, [C.POINTER(SeqDesc), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mfm_lstm_seq_bwd_bf16": (C.c_int, [C.POINTER(SeqDesc), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mfm_lstm_seq_fwd": (C.c_int, [C.POINTER(SeqDesc), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mfm_lstm_seq_bwd": (C.c_int, [C.POINTER(SeqDesc), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mfm_mmd_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -11,30 +11,11 @@
 #include <stdlib.h>
 
 #include "internal.h"
+#include "gemm_common.h"
 
 namespace mfm {
 
-#define MFM_GEMM_MAXP 56   // problems per launch (the descriptors travel in the kernel-argument segment, ~9.6 KB)
 constexpr int BK = 32;   // K depth of one LDS stage: 8 MFMA k-steps between barriers
-
-struct GemmProblem {
-  MfmGemmDesc d;
-  int tiles_m, tiles_n, block_begin, k_per_split;
-};
-struct GemmGroup {
-  GemmProblem p[MFM_GEMM_MAXP];
-  int begins[MFM_GEMM_MAXP];     // first workgroup of every problem (INT_MAX past `count`): found with one unrolled compare chain
-  int count;
-  // optional: spans the launch also clears (the fused step's loss slots and gradient buffer ride on its
-  // first GEMM instead of two memset launches of ~4.7 us each)
-  float* zero_ptr[2];
-  int64_t zero_n[2];
-  // optional: squared-error epilogue for the first mse_count problems (decoder fc1 -> x_hat): the tile that
-  // produced x_hat also forms d x_hat and its share of the reconstruction loss (mfm_mosi.py:441-446), so the
-  // separate elementwise launch and its re-read of x_hat disappear
-  MseEpi mse[3];
-  int mse_count;
-};
 
 // VEC: every operand of every problem in the group is unit-stride along its 4-element load groups
 // (true for all products of the MFM step); the 16-byte path is then unconditional.  A launch with
@@ -272,61 +253,7 @@ __global__ __launch_bounds__(256, (FR == 1) ? (VEC ? 5 : 4) : 3) void gemm_f32_k
     }
   }
 
-  // ---- epilogue
-  float* __restrict__ C = d.c + (int64_t)z * d.c_sz;
-  float* __restrict__ C2 = d.c2 ? d.c2 + (int64_t)z * d.c_sz : nullptr;
-  float sq = 0.0f;
-#pragma unroll
-  for (int fm = 0; fm < FR; ++fm)
-#pragma unroll
-    for (int fn = 0; fn < FR; ++fn) {
-      const int col = n0 + wn * 16 * FR + fn * 16 + bi;
-      if (col >= d.n) continue;
-      float bsum = 0.0f;
-      if (split == 0 && col < d.n_valid) {
-        if (d.bias) bsum += d.bias[(int64_t)z * d.bias_sz + col];
-        if (d.bias2) bsum += d.bias2[(int64_t)z * d.bias_sz + col];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 16 * FR + fm * 16 + q * 4 + r;
-        if (row >= d.m) continue;
-        float v = (col < d.n_valid) ? d.alpha * acc[fm][fn][r] + bsum : 0.0f;
-        const int64_t off = (int64_t)row * d.ldc + col;
-        if (d.accumulate) {
-          if (col < d.n_valid) {
-            atomicAdd(C + off, v);
-            if (C2) atomicAdd(C2 + off, v);
-          }
-        } else {
-          C[off] = v;
-          if (C2) C2[off] = v;
-          if (do_mse && col < d.n_valid) {
-            const float diff = v - tgt[fm][fn][r];
-            sq += diff * diff;
-            if (me.dxhat) me.dxhat[off] = me.grad_scale * diff;
-          }
-        }
-      }
-    }
-  if (do_mse && me.loss) {
-    __shared__ float sqsum[4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-    if (lane == 0) sqsum[wave] = sq;
-    lds_barrier();
-    if (tid == 0) atomicAdd(me.loss, (sqsum[0] + sqsum[1] + sqsum[2] + sqsum[3]) * me.inv_count);
-  }
-  // zero-fill spans last: ahead of the K loop these stores would sit in front of the first tile loads in the
-  // in-order vmcnt queue and put a store round trip on every workgroup's critical path
-#pragma unroll
-  for (int zi = 0; zi < 2; ++zi) {
-    if (g.zero_n[zi] > 0) {          // 16-byte aligned, multiple of 4 floats (checked by the host)
-      f32x4* z4 = reinterpret_cast<f32x4*>(g.zero_ptr[zi]);
-      const int64_t n4 = g.zero_n[zi] >> 2;
-      for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n4; i += (int64_t)gridDim.x * 256) z4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  }
+  gemm_epilogue<FR>(g, d, pi, z, split, m0, n0, wm, wn, bi, q, tid, lane, wave, acc, tgt, do_mse);
 }
 
 static int g_cus = 0;
@@ -343,7 +270,7 @@ int device_cus() {
 
 // Host-side launch of one group (count <= MFM_GEMM_MAXP).
 int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, const ZeroSpans* zs, const MseEpi* mse,
-                      int mse_count) {
+                      int mse_count, int precision) {
   MFM_REQUIRE(count >= 1 && count <= MFM_GEMM_MAXP, "gemm group: count %d out of range", count);
   const int cus = device_cus();
   GemmGroup g;
@@ -386,6 +313,16 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
     base_blocks += (long)cdiv(descs[i].m, BT) * cdiv(descs[i].n, BT) * descs[i].batch;
   long kdepth = 2048;      // K elements one workgroup walks at most (accumulating problems; measured 256..4096 at B=512/2048)
   if (const char* e = getenv("MFM_GEMM_KDEPTH")) { const long v = atol(e); if (v >= 64) kdepth = v; }   // tuning override
+  bool vec = true;
+  for (int i = 0; i < count; ++i) {
+    const MfmGemmDesc& d = descs[i];
+    const bool a_mcontig = (d.a_sm == 1 && d.a_sk != 1), b_ncontig = (d.b_sn == 1 && d.b_sk != 1);
+    if (!(a_mcontig || d.a_sk == 1) || !(b_ncontig || d.b_sk == 1)) vec = false;
+  }
+  // bf16 MFMA operands (precision 1) need every operand unit-stride along its 16-byte load groups; a group with an
+  // oddly strided operand runs on the fp32 kernel's dword path instead
+  const bool bf16 = (precision == 1) && vec;
+  const int bk = bf16 ? BKB : BK;
   int total = 0;
   for (int i = 0; i < count; ++i) {
     GemmProblem& P = g.p[i];
@@ -408,7 +345,7 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
         if (split < 1) split = 1;
       }
     }
-    int kps = round_up(cdiv(P.d.k > 0 ? P.d.k : 1, split), BK);
+    int kps = round_up(cdiv(P.d.k > 0 ? P.d.k : 1, split), bk);
     split = cdiv(P.d.k > 0 ? P.d.k : 1, kps);
     P.d.split_k = split;
     P.k_per_split = kps;
@@ -417,12 +354,7 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
     total += P.tiles_m * P.tiles_n * P.d.batch * split;
   }
   for (int i = count; i < MFM_GEMM_MAXP; ++i) g.begins[i] = 0x7fffffff;
-  bool vec = true;
-  for (int i = 0; i < count; ++i) {
-    const MfmGemmDesc& d = descs[i];
-    const bool a_mcontig = (d.a_sm == 1 && d.a_sk != 1), b_ncontig = (d.b_sn == 1 && d.b_sk != 1);
-    if (!(a_mcontig || d.a_sk == 1) || !(b_ncontig || d.b_sk == 1)) vec = false;
-  }
+  if (bf16) return gemm_bf16_launch_kernel(g, FR, total, stream);
   if (FR == 2) {
     if (vec) hipLaunchKernelGGL((gemm_f32_kernel<2, true>), dim3(total), dim3(256), 0, stream, g);
     else hipLaunchKernelGGL((gemm_f32_kernel<2, false>), dim3(total), dim3(256), 0, stream, g);
@@ -453,3 +385,19 @@ extern "C" int mfm_gemm_grouped_f32(const MfmGemmDesc* descs, int count, void* s
 }
 
 extern "C" int mfm_device_cus(void) { return mfm::device_cus(); }
+
+extern "C" int mfm_gemm_grouped_bf16(const MfmGemmDesc* descs, int count, void* stream) {
+  if (!descs || count <= 0) {
+    mfm::set_error("mfm_gemm_grouped_bf16: no problems");
+    return MFM_ERR_ARG;
+  }
+  int done = 0;
+  while (done < count) {
+    int n = count - done;
+    if (n > MFM_GEMM_MAXP) n = MFM_GEMM_MAXP;
+    int rc = mfm::gemm_group_launch(descs + done, n, (hipStream_t)stream, nullptr, nullptr, 0, 1);
+    if (rc != MFM_OK) return rc;
+    done += n;
+  }
+  return MFM_OK;
+}

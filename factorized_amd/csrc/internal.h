@@ -9,8 +9,10 @@ struct ZeroSpans { float* ptr[2]; int64_t n[2]; };   // spans (multiples of 4 fl
 struct MseEpi {          // squared-error epilogue of one product: target, d(output), loss slot, scales
   const float* x; int64_t ldx; float* dxhat; float* loss; float inv_count, grad_scale;
 };
+// precision: 0 = fp32 operands on v_mfma_f32_16x16x4_f32, 1 = operands rounded to bf16 on the way into LDS,
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation (gemm_bf16.hip)
 int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, const ZeroSpans* zs = nullptr,
-                      const MseEpi* mse = nullptr, int mse_count = 0);
+                      const MseEpi* mse = nullptr, int mse_count = 0, int precision = 0);
 int device_cus();
 
 // elementwise.hip

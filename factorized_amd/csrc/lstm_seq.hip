@@ -363,7 +363,7 @@ static bool use_small_path(int B) {
   return B <= 512;
 }
 
-static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bool bwd, hipStream_t stream) {
+static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bool bwd, hipStream_t stream, bool bf16 = false) {
   MFM_REQUIRE(descs_in && count_in >= 1 && count_in <= MFM_MAX_SEQ, "lstm_seq: count %d out of range", count_in);
   MFM_REQUIRE(T >= 1 && B >= 1, "lstm_seq: T=%d B=%d", T, B);
   // LSTMs too wide for the weight-resident kernels take the step-by-step path (lstm_step.hip); the rest of
@@ -415,6 +415,7 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     const size_t need = (bwd ? 2 * 4 * HK * 16 : 2 * HK * 16) * sizeof(float);
     if (need > lds_bytes) lds_bytes = need;
   }
+  if (bf16) return seq_bf16_launch(L, bwd, stream);      // bf16 MFMA operands: one kernel family for every batch size
   if (use_small_path(B)) return seq_small_launch(L, bwd, stream);
   // encoders and decoders run different kernels: a mixed call becomes two launches
   for (int kind = 0; kind < 2; ++kind) {
@@ -449,4 +450,10 @@ extern "C" int mfm_lstm_seq_fwd(const MfmSeqDesc* descs, int count, int T, int B
 }
 extern "C" int mfm_lstm_seq_bwd(const MfmSeqDesc* descs, int count, int T, int B, void* stream) {
   return mfm::seq_launch(descs, count, T, B, true, (hipStream_t)stream);
+}
+extern "C" int mfm_lstm_seq_fwd_bf16(const MfmSeqDesc* descs, int count, int T, int B, void* stream) {
+  return mfm::seq_launch(descs, count, T, B, false, (hipStream_t)stream, true);
+}
+extern "C" int mfm_lstm_seq_bwd_bf16(const MfmSeqDesc* descs, int count, int T, int B, void* stream) {
+  return mfm::seq_launch(descs, count, T, B, true, (hipStream_t)stream, true);
 }

@@ -1,0 +1,381 @@
+// Whole-sequence LSTM recurrence with bf16 MFMA operands (BASELINE.json configs 2-4: "bf16 compute, fp32
+// master weights / cell state / loss"), forward and BPTT, for gfx950.
+//
+// Same decomposition as lstm_seq.hip -- one persistent workgroup per (LSTM, 16-row batch tile), wave w owns
+// hidden units [16w, 16w+16) of all four gates, weights resident in VGPRs for all T steps, the accumulator
+// lane holds gates i,f,g,o of 4 units for one batch row so the pointwise math is lane-local and c stays in
+// fp32 registers -- but the recurrent product runs on v_mfma_f32_16x16x32_bf16:
+//   * operands: the weights are rounded to bf16 ONCE per launch (from the fp32 master copy; the decoder's
+//     W_ih + W_hh is summed in fp32 and rounded once), h_{t-1} / dA_t are rounded when they are written to
+//     the LDS exchange panel; products are exact, accumulation is fp32, everything saved for the backward
+//     (activated gates, h, c) stays fp32 in HBM;
+//   * 8 bf16 per lane and k-block instead of one fp32: h = 120 needs 16 MFMAs of 16 (bf16) cycles per step
+//     where the fp32 kernel issues 120 of 32 cycles -- the matrix work drops from ~1.6 us to ~0.1 us per
+//     step and the resident weights from 120 to 64 VGPRs;
+//   * the exchange panel is [16 rows][K] bf16 with K contiguous, so a lane's MFMA B fragment (8 consecutive
+//     k of one batch row) is ONE ds_read_b128 and its four new h values are ONE ds_write_b64; rows are
+//     padded by 16 bytes, which spreads the 16 rows of a fragment read over all 64 banks.
+// The k index of a fragment element is (k-block, lane >> 4, j); A and B fragments are built with the same
+// convention, and the MFMA sums over all of k, so the result does not depend on the hardware's internal
+// k order.
+#include <algorithm>
+#include <type_traits>
+
+#include <stdlib.h>
+
+#include "internal.h"
+#include "lstm_seq_dev.h"
+
+namespace mfm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 ld4b(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4b(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
+  const f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+  const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ f32x4 mma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// --------------------------------------------------------------------------------- forward
+// KB = number of 32-wide k-blocks covering the hidden size (h <= 32 KB).
+template <int KB, int KIND>
+__device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, const int B, const int tile, __bf16* lds) {
+  constexpr int HKP = KB * 32;
+  constexpr int LROW = HKP + 8;      // bf16 elements per LDS row (16-byte pad)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int bi = lane & 15, q = lane >> 4;
+  const int h = d.h, Hp = d.Hp;
+  const bool active = wave < (Hp >> 4);
+  const int u0 = wave * 16;
+  const int b = tile * 16 + bi;
+  const bool bvalid = active && (b < B);
+  const bool dec = (KIND != 0) && (d.is_dec != 0);
+
+  bf16x8 w[4][KB];
+  // MODE 0: W_hh (encoder)   1: W_ih (decoder step 0)   2: W_ih + W_hh (decoder steps >= 1; one rounding)
+  auto load_w = [&](auto mode) {
+    constexpr int MODE = decltype(mode)::value;
+    const int unit = u0 + bi;
+    const int uc = min(unit, h - 1);
+    const int uok = (int)active & (int)(unit < h);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = kb * 32 + 8 * q + j;
+          const int off = (g * h + uc) * h + min(k, h - 1);       // always a valid address
+          const float m = (float)(uok & (int)(k < h));            // 0 for pad elements
+          float x;
+          if constexpr (MODE == 0) x = d.w_hh[off];
+          else if constexpr (MODE == 1) x = d.w_ih[off];
+          else x = d.w_ih[off] + d.w_hh[off];
+          v[j] = x * m;
+        }
+        w[g][kb] = pack8(v);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (dec) load_w(std::integral_constant<int, 1>{}); else load_w(std::integral_constant<int, 0>{});
+
+  f32x4 bias[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bias[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (dec && active) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int unit = u0 + 4 * q + r;
+        if (unit < h) bias[g][r] = d.b_ih[g * h + unit] + d.b_hh[g * h + unit];
+      }
+    }
+  }
+
+  // exchange panel [2][16][LROW]: zero everywhere first (k beyond h meets zero weights, but 0 * garbage may be NaN)
+  for (int idx = tid; idx < 2 * 16 * LROW; idx += blockDim.x) lds[idx] = (__bf16)0.0f;
+  __syncthreads();
+  if (dec) {
+    for (int idx = tid; idx < 16 * h; idx += blockDim.x) {
+      const int r = idx / h, unit = idx - r * h, br = tile * 16 + r;
+      if (br < B) lds[r * LROW + unit] = (__bf16)d.h_init[(int64_t)br * d.ld_init + unit];
+    }
+    __syncthreads();
+  }
+
+  const int64_t row4 = 4 * (int64_t)Hp;
+  f32x4 gx[4];
+  if (!dec) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      gx[g] = bvalid ? ld4b(d.gates + ((int64_t)b) * row4 + g * Hp + u0 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  float c[4] = {0.f, 0.f, 0.f, 0.f};
+  int cur = 0;
+  auto step = [&](const int t) {
+    f32x4 acc[4];
+    const int64_t rowt = (int64_t)t * B + b;
+    if (dec) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = bias[g];
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = gx[g];
+      if (t + 1 < T && bvalid) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gx[g] = ld4b(d.gates + (rowt + B) * row4 + g * Hp + u0 + 4 * q);
+      }
+    }
+    if (active && (dec || t > 0)) {
+      const __bf16* hb = lds + cur * (16 * LROW) + bi * LROW + 8 * q;
+      bf16x8 hv[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) hv[kb] = *reinterpret_cast<const bf16x8*>(hb + kb * 32);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = mma_bf16(w[g][kb], hv[kb], acc[g]);
+    }
+    if (active) {
+      f32x4 gi, gf, gg, go, cv, hv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        gi[r] = act_sigmoid(acc[0][r]);
+        gf[r] = act_sigmoid(acc[1][r]);
+        gg[r] = act_tanh(acc[2][r]);
+        go[r] = act_sigmoid(acc[3][r]);
+        c[r] = gf[r] * c[r] + gi[r] * gg[r];
+        cv[r] = c[r];
+        hv[r] = go[r] * act_tanh(c[r]);
+      }
+      if (bvalid) {
+        float* gp = d.gates + rowt * row4 + u0 + 4 * q;
+        st4b(gp, gi); st4b(gp + Hp, gf); st4b(gp + 2 * Hp, gg); st4b(gp + 3 * Hp, go);
+        st4b(d.cs + rowt * Hp + u0 + 4 * q, cv);
+        st4b(d.hs + rowt * Hp + u0 + 4 * q, hv);
+      }
+      if (u0 + 4 * q < HKP) {
+        const f32x4 hz = (b < B) ? hv : f32x4{0.f, 0.f, 0.f, 0.f};
+        __bf16* hn = lds + (cur ^ 1) * (16 * LROW) + bi * LROW + u0 + 4 * q;
+        *reinterpret_cast<bf16x4*>(hn) = __builtin_convertvector(hz, bf16x4);
+      }
+    }
+    lds_barrier();
+    cur ^= 1;
+  };
+  int t0 = 0;
+  if (KIND != 0 && dec) {
+    step(0);
+    if (T > 1) load_w(std::integral_constant<int, 2>{});   // W_ih (step 0) -> W_ih + W_hh (steps >= 1)
+    t0 = 1;
+  }
+  for (int t = t0; t < T; ++t) step(t);
+}
+
+// --------------------------------------------------------------------------------- backward
+// The reduction runs over the gate columns in the padded numbering [4][HKP] (HKP = 32 KB): 4 KB k-blocks.
+template <int KB, int KIND>
+__device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, const int B, const int tile, __bf16* lds) {
+  constexpr int HKP = KB * 32;
+  constexpr int NKB = 4 * KB;
+  constexpr int LROW = 4 * HKP + 8;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int bi = lane & 15, q = lane >> 4;
+  const int h = d.h, Hp = d.Hp;
+  const bool active = wave < (Hp >> 4);
+  const int u0 = wave * 16;
+  const int b = tile * 16 + bi;
+  const bool bvalid = active && (b < B);
+  const bool dec = (KIND != 0) && (d.is_dec != 0);
+
+  bf16x8 wT[NKB];
+  auto load_wT = [&](auto mode) {
+    constexpr int MODE = decltype(mode)::value;
+    const int unit = u0 + bi;   // A row = output unit of dh
+    const int uc = min(unit, h - 1);
+    const int uok = (int)active & (int)(unit < h);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = kb * 32 + 8 * q + j;       // gate column in the [4][HKP] numbering
+        const int g = k / HKP, up = k % HKP;
+        const int off = (g * h + min(up, h - 1)) * h + uc;   // always a valid address
+        const float m = (float)(uok & (int)(up < h));
+        float x;
+        if constexpr (MODE == 0) x = d.w_hh[off];
+        else if constexpr (MODE == 1) x = d.w_ih[off];
+        else x = d.w_ih[off] + d.w_hh[off];
+        v[j] = x * m;
+      }
+      wT[kb] = pack8(v);
+      if ((kb & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (dec) load_wT(std::integral_constant<int, 2>{}); else load_wT(std::integral_constant<int, 0>{});
+
+  for (int idx = tid; idx < 2 * 16 * LROW; idx += blockDim.x) lds[idx] = (__bf16)0.0f;
+  __syncthreads();
+
+  const int64_t row4 = 4 * (int64_t)Hp;
+  f32x4 dh_rec = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dc[4] = {0.f, 0.f, 0.f, 0.f};
+  int cur = 0;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto step = [&](const int t, auto first) {
+    const int64_t rowt = (int64_t)t * B + b;
+    f32x4 dh = dh_rec;
+    if (bvalid) {
+      if (dec) {
+        const f32x4 e = ld4b(d.dh_ext + rowt * Hp + u0 + 4 * q);
+        dh += e;
+      } else if (t == T - 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int unit = u0 + 4 * q + r;
+          if (unit < h) dh[r] += d.dh_ext[(int64_t)b * d.ld_dh + unit];
+        }
+      }
+    }
+    f32x4 gi = zero4, gf = zero4, gg = zero4, go = zero4, ct = zero4, cp = zero4;
+    float* gp = d.gates + rowt * row4 + u0 + 4 * q;
+    if (bvalid) {
+      gi = ld4b(gp); gf = ld4b(gp + Hp); gg = ld4b(gp + 2 * Hp); go = ld4b(gp + 3 * Hp);
+      ct = ld4b(d.cs + rowt * Hp + u0 + 4 * q);
+      if (t > 0) cp = ld4b(d.cs + (rowt - B) * Hp + u0 + 4 * q);
+    }
+    f32x4 dce = zero4;
+    if (bvalid && d.dc_ext) dce = ld4b(d.dc_ext + rowt * Hp + u0 + 4 * q);
+    f32x4 dai, daf, dag, dao;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float tc = act_tanh(ct[r]);
+      const float dot = dh[r] * tc;
+      const float dct = dh[r] * go[r] * (1.0f - tc * tc) + dc[r] + dce[r];
+      dai[r] = dct * gg[r] * gi[r] * (1.0f - gi[r]);
+      daf[r] = dct * cp[r] * gf[r] * (1.0f - gf[r]);
+      dag[r] = dct * gi[r] * (1.0f - gg[r] * gg[r]);
+      dao[r] = dot * go[r] * (1.0f - go[r]);
+      dc[r] = dct * gf[r];
+    }
+    if (bvalid) { st4b(gp, dai); st4b(gp + Hp, daf); st4b(gp + 2 * Hp, dag); st4b(gp + 3 * Hp, dao); }
+
+    const bool need_rec = (t > 0) || dec;
+    if (need_rec) {
+      __bf16* db = lds + cur * (16 * LROW);
+      if (active && u0 + 4 * q < HKP) {
+        __bf16* dp = db + bi * LROW + u0 + 4 * q;
+        *reinterpret_cast<bf16x4*>(dp) = __builtin_convertvector(dai, bf16x4);
+        *reinterpret_cast<bf16x4*>(dp + HKP) = __builtin_convertvector(daf, bf16x4);
+        *reinterpret_cast<bf16x4*>(dp + 2 * HKP) = __builtin_convertvector(dag, bf16x4);
+        *reinterpret_cast<bf16x4*>(dp + 3 * HKP) = __builtin_convertvector(dao, bf16x4);
+      }
+      lds_barrier();
+      if constexpr (decltype(first)::value) {
+        if (dec) load_wT(std::integral_constant<int, 1>{});   // grad wrt the step-0 input goes through W_ih only
+      }
+      f32x4 a0 = zero4, a1 = zero4, a2 = zero4, a3 = zero4;
+      if (active) {
+        const __bf16* dp = db + bi * LROW + 8 * q;
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb += 4) {
+          bf16x8 v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const bf16x8*>(dp + (kb + j) * 32);
+          a0 = mma_bf16(wT[kb + 0], v[0], a0);
+          a1 = mma_bf16(wT[kb + 1], v[1], a1);
+          a2 = mma_bf16(wT[kb + 2], v[2], a2);
+          a3 = mma_bf16(wT[kb + 3], v[3], a3);
+        }
+      }
+      dh_rec = (a0 + a1) + (a2 + a3);
+      cur ^= 1;
+    }
+  };
+  if constexpr (KIND != 0) {
+    for (int t = T - 1; t >= 1; --t) step(t, std::false_type{});
+    step(0, std::true_type{});
+  } else {
+    for (int t = T - 1; t >= 0; --t) step(t, std::false_type{});
+  }
+  if (dec && bvalid && d.d_h_init) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int unit = u0 + 4 * q + r;
+      if (unit < h) d.d_h_init[(int64_t)b * d.ld_dinit + unit] = dh_rec[r];
+    }
+  }
+}
+
+#define MFM_SEQB_CASES(BODY, KIND)                                        \
+  switch (kb) {                                                           \
+    case 1: BODY<1, KIND>(d, L.T, L.B, tile, lds); break;                 \
+    case 2: BODY<2, KIND>(d, L.T, L.B, tile, lds); break;                 \
+    case 3: BODY<3, KIND>(d, L.T, L.B, tile, lds); break;                 \
+    case 4: BODY<4, KIND>(d, L.T, L.B, tile, lds); break;                 \
+    default: break;                                                       \
+  }
+
+template <bool BWD, int KIND>
+__global__ __launch_bounds__(512) void lstm_seq_bf16_kernel(const SeqLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+  int di = 0;
+  const int bid = blockIdx.x;
+#pragma unroll 1
+  for (int i = 1; i < L.count; ++i)
+    if (bid >= L.d[i].block_begin) di = i;
+  const SeqDev& d = L.d[di];
+  const int tile = bid - d.block_begin;
+  const int kb = (d.h + 31) >> 5;
+  if (BWD) { MFM_SEQB_CASES(seqb_bwd_body, KIND) } else { MFM_SEQB_CASES(seqb_fwd_body, KIND) }
+}
+
+// L: descriptors filled by seq_launch (lstm_seq.hip); every LSTM has h <= MFM_SEQ_MAX_RESIDENT_H.
+int seq_bf16_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
+  const int tiles = cdiv(L.B, 16);
+  for (int kind = 0; kind < 2; ++kind) {
+    SeqLaunch K = L;
+    K.count = 0;
+    int ktotal = 0, max_waves = 1;
+    size_t lds_bytes = 0;
+    for (int i = 0; i < L.count; ++i) {
+      if ((L.d[i].is_dec != 0) != (kind == 1)) continue;
+      K.d[K.count] = L.d[i];
+      K.d[K.count].block_begin = ktotal;
+      ktotal += tiles;
+      ++K.count;
+      const SeqDev& d = L.d[i];
+      if (d.Hp / 16 > max_waves) max_waves = d.Hp / 16;
+      const size_t hkp = (size_t)((d.h + 31) / 32) * 32;
+      const size_t need = 2 * 16 * ((bwd ? 4 * hkp : hkp) + 8) * sizeof(__bf16);
+      if (need > lds_bytes) lds_bytes = need;
+    }
+    if (K.count == 0) continue;
+    const dim3 grid(ktotal), block(64 * max_waves);
+    if (bwd) {
+      if (kind) hipLaunchKernelGGL((lstm_seq_bf16_kernel<true, 1>), grid, block, lds_bytes, stream, K);
+      else hipLaunchKernelGGL((lstm_seq_bf16_kernel<true, 0>), grid, block, lds_bytes, stream, K);
+    } else {
+      if (kind) hipLaunchKernelGGL((lstm_seq_bf16_kernel<false, 1>), grid, block, lds_bytes, stream, K);
+      else hipLaunchKernelGGL((lstm_seq_bf16_kernel<false, 0>), grid, block, lds_bytes, stream, K);
+    }
+    MFM_LAUNCH_CHECK(bwd ? "lstm_seq_bf16_bwd_kernel" : "lstm_seq_bf16_fwd_kernel");
+  }
+  return MFM_OK;
+}
+
+}  // namespace mfm

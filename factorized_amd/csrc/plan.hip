@@ -365,13 +365,13 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       d.m = (int)TB; d.n = sb.Hp; d.n_valid = sb.h; d.k = P->enc_d[e]; d.batch = 4; d.split_k = 1;
       d.alpha = 1.0f;
     }
-    RUN(K_PROJ, gemm_group_launch(g, 4, s, &zs));
+    RUN(K_PROJ, gemm_group_launch(g, 4, s, &zs, nullptr, 0, c.precision));
   }
   // F1: encoder recurrences
   {
     MfmSeqDesc q[4];
     for (int e = 0; e < 4; ++e) q[e] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
-    RUN(K_ENC_FWD, mfm_lstm_seq_fwd(q, 4, T, B, s));
+    RUN(K_ENC_FWD, c.precision ? mfm_lstm_seq_fwd_bf16(q, 4, T, B, s) : mfm_lstm_seq_fwd(q, 4, T, B, s));
   }
   // F2: latent stack
   {
@@ -398,7 +398,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       q[m] = seq_desc(P, P->dec[m], P->dec_p[m], params, W, true);
       q[m].h_init = W + P->dec_init[m]; q[m].ld_init = P->dec_h[m];
     }
-    RUN(K_DEC_FWD, mfm_lstm_seq_fwd(q, 3, T, B, s));
+    RUN(K_DEC_FWD, c.precision ? mfm_lstm_seq_fwd_bf16(q, 3, T, B, s) : mfm_lstm_seq_fwd(q, 3, T, B, s));
   }
   // F4: decoder fc1 -> x_hat
   float* xh[3];
@@ -428,7 +428,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       me[m].inv_count = (float)(1.0 / cnt);
       me[m].grad_scale = (float)(2.0 * lda[m] / cnt);
     }
-    RUN(K_FC1_FWD, gemm_group_launch(g, 3, s, nullptr, me, 3));
+    RUN(K_FC1_FWD, gemm_group_launch(g, 3, s, nullptr, me, 3, c.precision));
   }
   return MFM_OK;
 }
@@ -520,7 +520,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       bb.c = grads + P->off[pb + FC_B]; bb.ldc = 1; bb.n = 1; bb.n_valid = 1;
       tail.push_back(bb);
     }
-    RUN(K_FC1_BWD, gemm_group_launch(g.data(), (int)g.size(), s));
+    RUN(K_FC1_BWD, gemm_group_launch(g.data(), (int)g.size(), s, nullptr, nullptr, 0, c.precision));
     // B1: decoder BPTT
     {
       MfmSeqDesc q[3];
@@ -530,7 +530,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
         q[m].dh_ext = W + P->dec_dhs[m]; q[m].ld_dh = P->dec[m].Hp;
         q[m].d_h_init = W + P->dec_dinit[m]; q[m].ld_dinit = P->dec_h[m];
       }
-      RUN(K_DEC_BWD, mfm_lstm_seq_bwd(q, 3, T, B, s));
+      RUN(K_DEC_BWD, c.precision ? mfm_lstm_seq_bwd_bf16(q, 3, T, B, s) : mfm_lstm_seq_bwd(q, 3, T, B, s));
     }
     // (B2: the decoder weight gradients only feed Adam; they share the encoders' launch at the end)
   }
@@ -575,7 +575,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       q[e] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
       q[e].dh_ext = W + P->dh_last[e]; q[e].ld_dh = P->enc_h[e];
     }
-    RUN(K_ENC_BWD, mfm_lstm_seq_bwd(q, 4, T, B, s));
+    RUN(K_ENC_BWD, c.precision ? mfm_lstm_seq_bwd_bf16(q, 4, T, B, s) : mfm_lstm_seq_bwd(q, 4, T, B, s));
   }
   // B5: all weight gradients
   {
@@ -584,7 +584,8 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     if (gen_on)
       for (int m = 0; m < 3; ++m)
         dA_gemms(P, P->dec[m], P->dec_p[m], W, grads, tail, W + P->dec_init[m], P->dec_h[m], P->dec_h[m], true);
-    RUN(K_ENC_DW, mfm_gemm_grouped_f32(tail.data(), (int)tail.size(), s));
+    RUN(K_ENC_DW, c.precision ? mfm_gemm_grouped_bf16(tail.data(), (int)tail.size(), s)
+                                : mfm_gemm_grouped_f32(tail.data(), (int)tail.size(), s));
   }
   return MFM_OK;
 }
@@ -603,6 +604,7 @@ extern "C" int mfm_plan_create(const MfmPlanConfig* cfg, const int64_t* param_of
               "plan: latent sizes must be positive");
   MFM_REQUIRE(c.output_dim >= 1 && c.output_dim <= 64, "plan: output_dim %d", c.output_dim);
   MFM_REQUIRE(c.loss_kind == 0 || c.loss_kind == 1, "plan: loss_kind %d", c.loss_kind);
+  MFM_REQUIRE(c.precision == 0 || c.precision == 1, "plan: precision %d (0 = fp32, 1 = bf16 operands)", c.precision);
   MfmPlan* P = new (std::nothrow) MfmPlan();
   if (!P) { set_error("plan: out of host memory"); return MFM_ERR_ARG; }
   P->cfg = c;

@@ -159,6 +159,7 @@ class _Plan:
         pc.drop_za, pc.drop_zv = cfg["za_to_fa_dropout"], cfg["zv_to_fv_dropout"]
         pc.drop_y = cfg["fy_to_y_dropout"]
         pc.reg_scale = reg_scale
+        pc.precision = 1 if engine.precision == "bf16" else 0
         offs = (C.c_int64 * _lib.MFM_KLEF_NPARAM)(*engine.layout.offsets.values())
         handle = C.c_void_p(0)
         _lib.check(_lib.lib().mfm_plan_create(C.byref(pc), offs, engine.layout.total, C.byref(handle)),
@@ -185,7 +186,7 @@ class _Plan:
 class MFMEngine:
     """Fused MFM_KL_EF on one MI355X.  `configs` is the reference's six-dict list."""
 
-    def __init__(self, configs, device="cuda", reg_scale=1.0):
+    def __init__(self, configs, device="cuda", reg_scale=1.0, precision="fp32"):
         if not torch.cuda.is_available():
             raise _lib.MfmError("MFMEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
                                 "there is no CPU fallback")
@@ -201,6 +202,11 @@ class MFMEngine:
         self.adam_v = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.step_count = 0
         self.reg_scale = float(reg_scale)
+        # "fp32": the reference's arithmetic (1e-4 parity).  "bf16": bf16 MFMA operands in every GEMM and recurrence,
+        # fp32 accumulation / master weights / Adam / cell state / latent stack / losses (BASELINE configs 2-4)
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
         self.seed = 1234
         self._plans = {}
         # Staged training (train_beta_vae): Adam step counters per tensor group.  "frozen" = torch >= 2 semantics
@@ -235,7 +241,7 @@ class MFMEngine:
 
     # ------------------------------------------------------------------ plans
     def plan(self, T, B):
-        key = (int(T), int(B), self.reg_scale)
+        key = (int(T), int(B), self.reg_scale, self.precision)
         p = self._plans.get(key)
         if p is None:
             p = _Plan(self, int(T), int(B), self.reg_scale)

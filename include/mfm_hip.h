@@ -66,6 +66,11 @@ typedef struct MfmGemmDesc {
 } MfmGemmDesc;
 
 int mfm_gemm_grouped_f32(const MfmGemmDesc* descs /*host*/, int count, void* stream);
+/* The same products with bf16 MFMA operands (v_mfma_f32_16x16x32_bf16) and fp32 accumulation: a and b are still
+ * fp32 buffers, rounded to bf16 (nearest even) on the way from the global tile to LDS; c, bias, alpha, the
+ * epilogue and the atomics are fp32 exactly as above.  "bf16 compute, fp32 master weights" of BASELINE.json
+ * configs 2-4.  A group holding an operand that is not unit-stride along m/n or k runs on the fp32 kernel. */
+int mfm_gemm_grouped_bf16(const MfmGemmDesc* descs /*host*/, int count, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Whole-sequence LSTM recurrence (one persistent workgroup per 16 batch rows per LSTM; weights
@@ -95,6 +100,12 @@ typedef struct MfmSeqDesc {
 } MfmSeqDesc;
 
 int mfm_lstm_seq_fwd(const MfmSeqDesc* descs /*host*/, int count, int T, int B, void* stream);
+
+/* bf16 variants: W (rounded once per launch; the decoder's W_ih + W_hh summed in fp32 first), h_{t-1} and dA_t
+ * enter v_mfma_f32_16x16x32_bf16 as bf16, accumulation / gate math / cell state / every saved tensor stay fp32.
+ * One kernel family for all batch sizes (csrc/lstm_seq_bf16.hip); h > 128 falls back to the fp32 step-by-step path. */
+int mfm_lstm_seq_fwd_bf16(const MfmSeqDesc* descs /*host*/, int count, int T, int B, void* stream);
+int mfm_lstm_seq_bwd_bf16(const MfmSeqDesc* descs /*host*/, int count, int T, int B, void* stream);
 
 /* BPTT over the saved gates/cs (autograd of the loops above).  On return `gates` holds the
  * pre-activation gate gradients dA[T,B,4,Hp] (in place); weight/bias gradients are then plain
@@ -214,6 +225,10 @@ typedef struct MfmPlanConfig {
   float lda_xl, lda_xa, lda_xv, lda_reg;   /* mfm_mosi.py:433,437 */
   float drop_zy, drop_zl, drop_za, drop_zv, drop_y;
   float reg_scale;        /* extra factor on the KLD term (DP: world size) */
+  int32_t precision;      /* 0 = fp32 everywhere (BASELINE config 1; 1e-4 parity with the reference);
+                             1 = bf16 MFMA operands in every GEMM and LSTM recurrence, fp32 accumulation, master
+                                 weights, Adam moments, cell state, saved activations, latent stack and losses
+                                 (BASELINE configs 2-4; gate: matched loss curve) */
 } MfmPlanConfig;
 
 typedef struct MfmPlan MfmPlan;

@@ -16,12 +16,17 @@ from factorized_amd import configs as C, engine, synth  # noqa: E402
 PEAK = 157.3
 
 
-def run(B, path, steps):
-    os.environ["MFM_SEQ_PATH"] = path
-    cfgs = C.canonical_configs(dropout=True)
-    e = engine.MFMEngine(cfgs)
+def run(B, path, steps, shape="mosi", T=20):
+    if path == "bf16":
+        os.environ.pop("MFM_SEQ_PATH", None)
+    else:
+        os.environ["MFM_SEQ_PATH"] = path
+    cfgs = {"mosi": C.canonical_configs, "you": C.you_configs, "mosei": C.mosei_configs}[shape](dropout=True)
+    e = engine.MFMEngine(cfgs, precision="bf16" if path == "bf16" else "fp32")
     e.load_weights(synth.make_weights(e.layout.shapes, seed=1234))
-    xn, yn = synth.make_batch(cfgs[0]["input_dims"], B, 20, seed=3)
+    ce = cfgs[0].get("loss", "l1") == "ce"
+    xn, yn = synth.make_batch(cfgs[0]["input_dims"], B, T, seed=3, output_dim=cfgs[0]["output_dim"],
+                              classes=cfgs[0]["output_dim"] if ce else 0)
     x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
     for _ in range(5):
         e.train_step(x, y, check=False)
@@ -31,17 +36,20 @@ def run(B, path, steps):
         e.train_step(x, y, check=False)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    w = e.work_per_step(20, B)
+    w = e.work_per_step(T, B)
     return dict(B=B, path=path, ms=1e3 * dt, samples_per_s=B / dt, tflops=w["flops"] / dt / 1e12,
                 frac=w["flops"] / dt / 1e12 / PEAK, hbm_gbs=w["bytes"] / dt / 1e9)
 
 
 if __name__ == "__main__":
     Bs = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [32, 128, 512, 2048, 8192]
+    shape = sys.argv[2] if len(sys.argv) > 2 else "mosi"
+    T = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+    print("# shape %s, T=%d; frac = fraction of the fp32 matrix peak (157.3 TF) for every row, bf16 rows included" % (shape, T))
     print("%6s %6s %9s %12s %8s %8s %9s" % ("B", "path", "ms/step", "samples/s", "TFLOP/s", "frac", "alg GB/s"))
     for B in Bs:
-        for path in ("small", "mfma"):
-            r = run(B, path, steps=50 if B <= 2048 else 10)
+        for path in ("small", "mfma", "bf16"):
+            r = run(B, path, steps=50 if B <= 2048 else 10, shape=shape, T=T)
             print("%6d %6s %9.3f %12.0f %8.2f %8.4f %9.1f" % (r["B"], r["path"], r["ms"], r["samples_per_s"],
                                                               r["tflops"], r["frac"], r["hbm_gbs"]))
             sys.stdout.flush()

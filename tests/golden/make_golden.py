@@ -77,7 +77,7 @@ def ref_losses(model, x, y, cfg, loss_kind):
     return dict(disc=disc, gen=gen, gen_l=gl, gen_a=ga, gen_v=gv, reg=reg, loss=loss), decoded
 
 
-def run_case(name, variant, cfg_fn, overrides, B, T, steps):
+def run_case(name, variant, cfg_fn, overrides, B, T, steps, light=False):
     cfgs = cfg_fn(dropout=False, **overrides)
     cfg = cfgs[0]
     loss_kind = cfg.get("loss", "l1")
@@ -119,11 +119,16 @@ def run_case(name, variant, cfg_fn, overrides, B, T, steps):
             for k in ("disc", "gen", "gen_l", "gen_a", "gen_v", "reg", "loss"):
                 out["fwd_" + k] = np.float64(terms[k].item())
             x_l_hat, x_a_hat, x_v_hat, y_hat = decoded
-            out["y_hat"] = y_hat.detach().numpy().copy()
-            out["x_a_hat"] = x_a_hat.detach().numpy().copy()
+            if not light:          # light cases (large batches) keep summaries only
+                out["y_hat"] = y_hat.detach().numpy().copy()
+                out["x_a_hat"] = x_a_hat.detach().numpy().copy()
+            else:
+                out["y_hat_sum"] = summarize(y_hat)
+                out["x_a_hat_sum"] = summarize(x_a_hat)
             for tag, xh in (("x_l_hat", x_l_hat), ("x_v_hat", x_v_hat)):
-                out[tag + "_first"] = xh[0].detach().numpy().copy()
-                out[tag + "_last"] = xh[-1].detach().numpy().copy()
+                if not light:
+                    out[tag + "_first"] = xh[0].detach().numpy().copy()
+                    out[tag + "_last"] = xh[-1].detach().numpy().copy()
                 out[tag + "_sum"] = summarize(xh)
             names = [n for n, _ in model.named_parameters()]
             out["grad_summary"] = np.stack([
@@ -182,6 +187,8 @@ def run_staged(name, B, T, n1, n2):
 
 
 STAGED = [("klef_staged_b32_t20", 32, 20, 4, 4)]
+# BASELINE config 4 (MOSEI shape, large batch): summaries + loss trace only
+LIGHT = [("klef_mosei_b1024_t20", "kl_ef", C.mosei_configs, {}, 1024, 20, 8)]
 
 
 if __name__ == "__main__":
@@ -194,3 +201,8 @@ if __name__ == "__main__":
         if only and case[0] not in only:
             continue
         run_staged(*case)
+    for case in LIGHT:
+        if only and case[0] not in only:
+            continue
+        torch.set_num_threads(8)
+        run_case(*case, light=True)
