@@ -35,7 +35,7 @@ class SeqDesc(C.Structure):
                 ("h_init", C.c_void_p), ("ld_init", C.c_int64),
                 ("dh_ext", C.c_void_p), ("ld_dh", C.c_int64),
                 ("d_h_init", C.c_void_p), ("ld_dinit", C.c_int64),
-                ("h", C.c_int32), ("is_dec", C.c_int32), ("dc_ext", C.c_void_p)]
+                ("h", C.c_int32), ("is_dec", C.c_int32), ("dc_ext", C.c_void_p), ("w_pack", C.c_void_p)]
 
 
 class MemDesc(C.Structure):
@@ -74,6 +74,8 @@ _SIGS = {
     "mfm_device_cus": (C.c_int, []),
     "mfm_gemm_grouped_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.c_void_p]),
     "mfm_gemm_grouped_bf16": (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.c_void_p]),
+    "mfm_lstm_pack_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "mfm_lstm_pack_bf16": (C.c_int, [C.POINTER(SeqDesc), C.c_int, C.c_void_p]),
     "mfm_lstm_seq_fwd_bf16": (C.c_int, [C.POINTER(SeqDesc), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mfm_lstm_seq_bwd_bf16": (C.c_int, [C.POINTER(SeqDesc), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mfm_lstm_seq_fwd": (C.c_int, [C.POINTER(SeqDesc), C.c_int, C.c_int, C.c_int, C.c_void_p]),

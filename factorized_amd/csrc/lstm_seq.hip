@@ -405,6 +405,7 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     d.dh_ext = s.dh_ext; d.ld_dh = s.ld_dh;
     d.d_h_init = s.d_h_init; d.ld_dinit = s.ld_dinit;
     d.dc_ext = s.dc_ext;
+    d.w_pack = bf16 ? s.w_pack : nullptr;
     d.h = s.h; d.Hp = round_up(s.h, 16);
     d.hk4 = round_up(cdiv(s.h, 4), 2);
     d.is_dec = s.is_dec;

@@ -87,7 +87,18 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  if (dec) load_w(std::integral_constant<int, 1>{}); else load_w(std::integral_constant<int, 0>{});
+  // packed fragments (mfm_lstm_pack_bf16): lane-linear, one coalesced 16-byte load per fragment
+  const bf16x8* pk = reinterpret_cast<const bf16x8*>(d.w_pack);
+  const int64_t pack_frags = (int64_t)(Hp >> 4) * 4 * KB * 64;
+  auto load_packed = [&](int which) {
+    const bf16x8* base = pk + which * pack_frags + (int64_t)min(wave, (Hp >> 4) - 1) * 4 * KB * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) w[g][kb] = base[(g * KB + kb) * 64];
+  };
+  if (pk) load_packed(dec ? 1 : 0);
+  else if (dec) load_w(std::integral_constant<int, 1>{}); else load_w(std::integral_constant<int, 0>{});
 
   f32x4 bias[4];
 #pragma unroll
@@ -177,7 +188,9 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
   int t0 = 0;
   if (KIND != 0 && dec) {
     step(0);
-    if (T > 1) load_w(std::integral_constant<int, 2>{});   // W_ih (step 0) -> W_ih + W_hh (steps >= 1)
+    if (T > 1) {                                            // W_ih (step 0) -> W_ih + W_hh (steps >= 1)
+      if (pk) load_packed(0); else load_w(std::integral_constant<int, 2>{});
+    }
     t0 = 1;
   }
   for (int t = t0; t < T; ++t) step(t);
@@ -225,7 +238,16 @@ __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, cons
       if ((kb & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
   };
-  if (dec) load_wT(std::integral_constant<int, 2>{}); else load_wT(std::integral_constant<int, 0>{});
+  const bf16x8* pk = reinterpret_cast<const bf16x8*>(d.w_pack);
+  const int64_t pack_frags = (int64_t)(Hp >> 4) * NKB * 64;          // == the forward packs' size
+  const int bwd_first_pack = dec ? 2 : 1;                            // enc: [fwd, bwd]   dec: [fwd main, fwd first, bwd main, bwd first]
+  auto load_packedT = [&](int which) {
+    const bf16x8* base = pk + which * pack_frags + (int64_t)min(wave, (Hp >> 4) - 1) * NKB * 64 + lane;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) wT[kb] = base[kb * 64];
+  };
+  if (pk) load_packedT(bwd_first_pack);
+  else if (dec) load_wT(std::integral_constant<int, 2>{}); else load_wT(std::integral_constant<int, 0>{});
 
   for (int idx = tid; idx < 2 * 16 * LROW; idx += blockDim.x) lds[idx] = (__bf16)0.0f;
   __syncthreads();
@@ -286,7 +308,9 @@ __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, cons
       }
       lds_barrier();
       if constexpr (decltype(first)::value) {
-        if (dec) load_wT(std::integral_constant<int, 1>{});   // grad wrt the step-0 input goes through W_ih only
+        if (dec) {                                             // grad wrt the step-0 input goes through W_ih only
+          if (pk) load_packedT(3); else load_wT(std::integral_constant<int, 1>{});
+        }
       }
       f32x4 a0 = zero4, a1 = zero4, a2 = zero4, a3 = zero4;
       if (active) {
@@ -343,6 +367,104 @@ __global__ __launch_bounds__(512) void lstm_seq_bf16_kernel(const SeqLaunch L) {
   const int kb = (d.h + 31) >> 5;
   if (BWD) { MFM_SEQB_CASES(seqb_bwd_body, KIND) } else { MFM_SEQB_CASES(seqb_fwd_body, KIND) }
 }
+
+// --------------------------------------------------------------------------------- weight packing
+// The fragments above are gathers over the fp32 weight matrices (8 consecutive k of one gate row forward, 8 gate
+// rows of one column backward): fetched inside the recurrence kernels they cost 128-256 uncoalesced load
+// instructions per lane and dominate a 20-step launch (measured: 73-110 us per launch at B=32, ~5 us of it steps).
+// So the bf16 fragments are built ONCE per step by a fully parallel kernel into a lane-linear image -- fragment f of
+// wave w is one 16-byte element at [(w * nfrag + f) * 64 + lane] -- and the recurrences start with 16-32 coalesced
+// loads.  Pack order per LSTM: encoder [fwd W_hh | bwd W_hh]; decoder [fwd W_ih+W_hh | fwd W_ih | bwd W_ih+W_hh |
+// bwd W_ih].  Every pack has (Hp/16) * 4 * KB * 64 fragments.
+struct PackItem { const float* w_hh; const float* w_ih; bf16x8* out; int h, Hp, KB, is_dec, frag_begin; };
+struct PackLaunch { PackItem it[MFM_MAX_SEQ * 2]; int count; };
+
+__global__ __launch_bounds__(256) void lstm_pack_bf16_kernel(const PackLaunch L) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int ii = 0;
+#pragma unroll 1
+  for (int i = 1; i < L.count; ++i)
+    if (gid >= L.it[i].frag_begin) ii = i;
+  const PackItem& it = L.it[ii];
+  const int h = it.h, KB = it.KB, HKP = KB * 32;
+  const int per_pack = (it.Hp >> 4) * 4 * KB * 64;
+  const int npack = it.is_dec ? 4 : 2;
+  int f = (int)(gid - it.frag_begin);
+  if (f >= per_pack * npack) return;
+  const int which = f / per_pack;
+  f -= which * per_pack;
+  const int lane = f & 63;
+  int r = f >> 6;
+  const int bi = lane & 15, q = lane >> 4;
+  const bool bwd = it.is_dec ? (which >= 2) : (which == 1);
+  // MODE: 0 W_hh, 1 W_ih, 2 W_ih + W_hh
+  const int mode = it.is_dec ? ((which & 1) ? 1 : 2) : 0;
+  float v[8];
+  if (!bwd) {
+    const int kb = r % KB; r /= KB;
+    const int g = r & 3, wave = r >> 2;
+    const int unit = wave * 16 + bi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kb * 32 + 8 * q + j;
+      const bool ok = unit < h && k < h;
+      const int off = ok ? (g * h + unit) * h + k : 0;
+      const float x = mode == 0 ? it.w_hh[off] : (mode == 1 ? it.w_ih[off] : it.w_ih[off] + it.w_hh[off]);
+      v[j] = ok ? x : 0.0f;
+    }
+  } else {
+    const int nkb = 4 * KB;
+    const int kb = r % nkb, wave = r / nkb;
+    const int unit = wave * 16 + bi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kb * 32 + 8 * q + j;
+      const int g = k / HKP, up = k % HKP;
+      const bool ok = unit < h && up < h;
+      const int off = ok ? (g * h + up) * h + unit : 0;
+      const float x = mode == 0 ? it.w_hh[off] : (mode == 1 ? it.w_ih[off] : it.w_ih[off] + it.w_hh[off]);
+      v[j] = ok ? x : 0.0f;
+    }
+  }
+  it.out[(int64_t)which * per_pack + (f & ~63) + lane] = pack8(v);
+}
+
+}  // namespace mfm
+
+extern "C" int64_t mfm_lstm_pack_bytes(int32_t h, int32_t is_dec) {
+  if (h < 1 || h > mfm::MFM_SEQ_MAX_RESIDENT_H) return 0;
+  const int64_t Hp = (h + 15) / 16 * 16, KB = (h + 31) / 32;
+  return (is_dec ? 4 : 2) * (Hp / 16) * 4 * KB * 64 * 16;
+}
+
+extern "C" int mfm_lstm_pack_bf16(const MfmSeqDesc* descs, int count, void* stream) {
+  using namespace mfm;
+  MFM_REQUIRE(descs && count >= 1, "mfm_lstm_pack_bf16: no descriptors");
+  int done = 0;
+  while (done < count) {
+    PackLaunch L;
+    memset(&L, 0, sizeof(L));
+    int64_t total = 0;
+    while (done < count && L.count < MFM_MAX_SEQ * 2) {
+      const MfmSeqDesc& s = descs[done++];
+      if (s.h > MFM_SEQ_MAX_RESIDENT_H) continue;      // step-by-step fp32 path: nothing to pack
+      MFM_REQUIRE(s.h >= 1 && s.w_hh && s.w_pack, "mfm_lstm_pack_bf16: h=%d, w_hh / w_pack must be set", s.h);
+      if (s.is_dec) MFM_REQUIRE(s.w_ih, "mfm_lstm_pack_bf16: decoder needs w_ih");
+      PackItem& it = L.it[L.count++];
+      it.w_hh = s.w_hh; it.w_ih = s.w_ih; it.out = reinterpret_cast<bf16x8*>(s.w_pack);
+      it.h = s.h; it.Hp = round_up(s.h, 16); it.KB = cdiv(s.h, 32); it.is_dec = s.is_dec;
+      MFM_REQUIRE(total < (int64_t)1 << 30, "mfm_lstm_pack_bf16: too many fragments");
+      it.frag_begin = (int)total;
+      total += (int64_t)(s.is_dec ? 4 : 2) * (it.Hp >> 4) * 4 * it.KB * 64;
+    }
+    if (L.count == 0) continue;
+    hipLaunchKernelGGL(lstm_pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, L);
+    MFM_LAUNCH_CHECK("lstm_pack_bf16_kernel");
+  }
+  return MFM_OK;
+}
+
+namespace mfm {
 
 // L: descriptors filled by seq_launch (lstm_seq.hip); every LSTM has h <= MFM_SEQ_MAX_RESIDENT_H.
 int seq_bf16_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {

@@ -11,6 +11,7 @@ struct SeqDev {
   const float* dh_ext; int64_t ld_dh;
   float* d_h_init; int64_t ld_dinit;
   const float* dc_ext;
+  const void* w_pack;      // bf16 path: packed weight fragments (mfm_lstm_pack_bf16), or null
   int h, Hp, hk4, is_dec, block_begin;
 };
 struct SeqLaunch {

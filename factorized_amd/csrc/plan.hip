@@ -25,12 +25,13 @@
 #include <vector>
 
 #include "internal.h"
+#include "lstm_seq_dev.h"
 
 namespace mfm {
 
 enum KernelId {
   K_PROJ = 0, K_ENC_FWD, K_LAT_FWD, K_DEC_FWD, K_FC1_FWD, K_MSE, K_FC1_BWD, K_DEC_BWD, K_DEC_DW,
-  K_LAT_BWD, K_ENC_BWD, K_ENC_DW, K_ADAM, K_LAT_DW, K_COUNT
+  K_LAT_BWD, K_ENC_BWD, K_ENC_DW, K_ADAM, K_LAT_DW, K_PACK, K_COUNT
 };
 
 // state_dict order of MFM_KL_EF (78 tensors), see include/mfm_hip.h
@@ -40,7 +41,7 @@ enum { P_ENC_L = 0, P_ENC_A = 6, P_ENC_V = 12, P_DEC_L = 18, P_DEC_A = 24, P_DEC
        P_ZV_F1 = 70, P_ZV_F2 = 72, P_Y_F1 = 74, P_Y_F2 = 76 };
 enum { W_IH = 0, W_HH = 1, B_IH = 2, B_HH = 3, FC_W = 4, FC_B = 5 };
 
-struct SeqBuf { int64_t gates, hs, cs; int h, Hp; };
+struct SeqBuf { int64_t gates, hs, cs, wpack; int h, Hp; };
 
 struct TimingPair { hipEvent_t a, b; int kid; };
 
@@ -107,6 +108,7 @@ static int build(MfmPlan* P) {
     s.gates = carve(cur, TB * 4 * s.Hp);
     s.hs = carve(cur, TB * s.Hp);
     s.cs = carve(cur, TB * s.Hp);
+    s.wpack = c.precision ? carve(cur, mfm_lstm_pack_bytes(s.h, 0) / 4) : -1;
     P->dh_last[e] = carve(cur, (int64_t)c.B * eh[e]);
   }
   for (int m = 0; m < 3; ++m) {
@@ -116,6 +118,7 @@ static int build(MfmPlan* P) {
     s.gates = carve(cur, TB * 4 * s.Hp);
     s.hs = carve(cur, TB * s.Hp);
     s.cs = carve(cur, TB * s.Hp);
+    s.wpack = c.precision ? carve(cur, mfm_lstm_pack_bytes(s.h, 1) / 4) : -1;
     P->dec_dhs[m] = carve(cur, TB * s.Hp);
     P->dec_init[m] = carve(cur, (int64_t)c.B * s.h);
     P->dec_dinit[m] = carve(cur, (int64_t)c.B * s.h);
@@ -328,6 +331,7 @@ static MfmSeqDesc seq_desc(const MfmPlan* P, const SeqBuf& sb, int pbase, const 
   d.b_ih = params + P->off[pbase + B_IH];
   d.b_hh = params + P->off[pbase + B_HH];
   d.h = sb.h; d.is_dec = dec ? 1 : 0;
+  if (sb.wpack >= 0 && sb.h <= MFM_SEQ_MAX_RESIDENT_H) d.w_pack = W + sb.wpack;   // bf16 plans: fragments packed by K_PACK
   return d;
 }
 
@@ -349,6 +353,14 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     P->grads_prezeroed = grads_to_zero;
   }
   P->calls++;
+
+  // bf16 plans: the recurrences' weight fragments, rounded and packed once per step (lstm_seq_bf16.hip)
+  if (c.precision) {
+    MfmSeqDesc q[7];
+    for (int e = 0; e < 4; ++e) q[e] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
+    for (int m = 0; m < 3; ++m) q[4 + m] = seq_desc(P, P->dec[m], P->dec_p[m], params, W, true);
+    RUN(K_PACK, mfm_lstm_pack_bf16(q, 7, s));
+  }
 
   // F0: input projections
   {
@@ -755,7 +767,7 @@ extern "C" int mfm_plan_num_kernels(void) { return K_COUNT; }
 extern "C" const char* mfm_plan_kernel_name(int kid) {
   static const char* names[K_COUNT] = {"proj_gemm", "enc_seq_fwd", "latent_fwd", "dec_seq_fwd", "fc1_mse_gemm", "mse",
                                        "fc1_bwd_gemm", "dec_seq_bwd", "dec_dw_gemm", "latent_bwd", "enc_seq_bwd",
-                                       "dw_gemm", "adam", "latent_dw_gemm"};
+                                       "dw_gemm", "adam", "latent_dw_gemm", "bf16_weight_pack"};
   return (kid >= 0 && kid < K_COUNT) ? names[kid] : "?";
 }
 // Synchronises on the recorded events, adds elapsed ms / launch counts per kernel id, resets the pool.

@@ -456,7 +456,7 @@ def make_gemm(a, b, c, m, n, k, a_sm, a_sk, b_sk, b_sn, ldc, bias=None, bias2=No
 
 
 def make_seq(gates, hs, cs, w_hh, h, w_ih=None, b_ih=None, b_hh=None, h_init=None, is_dec=False,
-             dh_ext=None, ld_dh=0, d_h_init=None, dc_ext=None):
+             dh_ext=None, ld_dh=0, d_h_init=None, dc_ext=None, w_pack=None):
     d = _lib.SeqDesc()
     d.gates, d.hs, d.cs = gates.data_ptr(), hs.data_ptr(), cs.data_ptr()
     d.w_hh = w_hh.data_ptr()
@@ -471,6 +471,7 @@ def make_seq(gates, hs, cs, w_hh, h, w_ih=None, b_ih=None, b_hh=None, h_init=Non
         d.d_h_init, d.ld_dinit = d_h_init.data_ptr(), d_h_init.stride(0)
     d.h, d.is_dec = h, int(is_dec)
     d.dc_ext = dc_ext.data_ptr() if dc_ext is not None else None
+    d.w_pack = w_pack.data_ptr() if w_pack is not None else None
     return d
 
 

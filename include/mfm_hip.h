@@ -97,6 +97,9 @@ typedef struct MfmSeqDesc {
   int32_t h, is_dec;
   const float* dc_ext;   /* optional [T,B,Hp]: external grad wrt every CELL state c_t (the MFN encoder
                             reads c_t, mfm_model.py:171-173); NULL for the plain encoders/decoders */
+  void* w_pack;          /* bf16 entry points only, optional: mfm_lstm_pack_bytes(h, is_dec) bytes filled by
+                            mfm_lstm_pack_bf16 from the CURRENT weights (bf16 MFMA fragments in lane order); NULL =
+                            the recurrence kernels gather their fragments from the fp32 matrices themselves (slow) */
 } MfmSeqDesc;
 
 int mfm_lstm_seq_fwd(const MfmSeqDesc* descs /*host*/, int count, int T, int B, void* stream);
@@ -104,6 +107,8 @@ int mfm_lstm_seq_fwd(const MfmSeqDesc* descs /*host*/, int count, int T, int B, 
 /* bf16 variants: W (rounded once per launch; the decoder's W_ih + W_hh summed in fp32 first), h_{t-1} and dA_t
  * enter v_mfma_f32_16x16x32_bf16 as bf16, accumulation / gate math / cell state / every saved tensor stay fp32.
  * One kernel family for all batch sizes (csrc/lstm_seq_bf16.hip); h > 128 falls back to the fp32 step-by-step path. */
+int64_t mfm_lstm_pack_bytes(int32_t h, int32_t is_dec);
+int mfm_lstm_pack_bf16(const MfmSeqDesc* descs /*host*/, int count, void* stream);
 int mfm_lstm_seq_fwd_bf16(const MfmSeqDesc* descs /*host*/, int count, int T, int B, void* stream);
 int mfm_lstm_seq_bwd_bf16(const MfmSeqDesc* descs /*host*/, int count, int T, int B, void* stream);
 

@@ -265,6 +265,50 @@ def test_bf16_lstm_seq_four_in_one_launch_matches_single_launches(eng):
         assert torch.equal(h0, h1) and torch.equal(c0, c1) and torch.equal(g0, g1)
 
 
+@pytest.mark.parametrize("h,is_dec", [(120, False), (104, True), (24, True), (36, False), (8, False)])
+def test_bf16_packed_weight_fragments_equal_in_kernel_gather(eng, h, is_dec):
+    """mfm_lstm_pack_bf16 (what the plan runs once per step) must hand the recurrences exactly the fragments they
+    would gather themselves: forward and backward results bit-identical with and without the pack."""
+    from factorized_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(h)
+    T, B = 5, 21
+    Hp = (h + 15) // 16 * 16
+    k = 1.0 / np.sqrt(h)
+    w_ih, w_hh = dev(rs.uniform(-k, k, size=(4 * h, h))), dev(rs.uniform(-k, k, size=(4 * h, h)))
+    b_ih, b_hh = dev(rs.uniform(-k, k, size=4 * h)), dev(rs.uniform(-k, k, size=4 * h))
+    init = dev(rs.normal(size=(B, h)))
+    gp = np.zeros((T, B, 4, Hp), dtype=np.float32)
+    gp[:, :, :, :h] = rs.normal(size=(T, B, 4, h))
+    dh_all = np.zeros((T, B, Hp), dtype=np.float32)
+    dh_all[:, :, :h] = rs.normal(size=(T, B, h))
+    nbytes = L.mfm_lstm_pack_bytes(h, int(is_dec))
+    assert nbytes > 0 and L.mfm_lstm_pack_bytes(129, 0) == 0
+    pack = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    res = []
+    for use_pack in (False, True):
+        gates = dev(gp)
+        hs, cs = torch.zeros(T, B, Hp, device="cuda"), torch.zeros(T, B, Hp, device="cuda")
+        kw = dict(w_pack=pack if use_pack else None)
+        if is_dec:
+            kw.update(w_ih=w_ih, b_ih=b_ih, b_hh=b_hh, h_init=init, is_dec=True)
+        d = eng.make_seq(gates, hs, cs, w_hh, h, **kw)
+        if use_pack:
+            arr = (_lib.SeqDesc * 1)(d)
+            _lib.check(L.mfm_lstm_pack_bf16(arr, 1, None), "mfm_lstm_pack_bf16")
+        seq_bf16([d], T, B)
+        fwd = (gates.clone(), hs.clone(), cs.clone())
+        dinit = torch.zeros(B, h, device="cuda")
+        if is_dec:
+            d = eng.make_seq(gates, hs, cs, w_hh, h, dh_ext=dev(dh_all), ld_dh=Hp, d_h_init=dinit, **kw)
+        else:
+            d = eng.make_seq(gates, hs, cs, w_hh, h, dh_ext=dev(dh_all[-1, :, :h]), ld_dh=h, **kw)
+        seq_bf16([d], T, B, backward=True)
+        res.append(fwd + (gates.clone(), dinit.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 # ---------------------------------------------------------------------------------- the whole step
 def _bf16_engine(cfgs):
     from factorized_amd import engine
