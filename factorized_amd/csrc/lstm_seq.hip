@@ -363,6 +363,16 @@ static bool use_small_path(int B) {
   return B <= 512;
 }
 
+// bf16 MFMA recurrences (lstm_seq_bf16.hip) work on 16-row batch tiles: 128 x 16 cells of gate math per workgroup and
+// step (~2 us per step at h = 120, VALU-bound), whatever B is.  Below ~190 rows the chip is better used by the
+// fp32 VALU kernels' one-row workgroups (0.8 us per step, and exact fp32 products), so a bf16 plan keeps its
+// recurrences on those until B reaches MFM_BF16_SEQ_MINB (default 192; measured crossover between B = 128 and 256,
+// profiles/r02_batch_sweep_mosi.txt).  The bf16 entry points of the ABI always run the bf16 kernels.
+bool bf16_seq_pays(int B) {
+  const char* e = getenv("MFM_BF16_SEQ_MINB");
+  return B >= (e ? atoi(e) : 192);
+}
+
 static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bool bwd, hipStream_t stream, bool bf16 = false) {
   MFM_REQUIRE(descs_in && count_in >= 1 && count_in <= MFM_MAX_SEQ, "lstm_seq: count %d out of range", count_in);
   MFM_REQUIRE(T >= 1 && B >= 1, "lstm_seq: T=%d B=%d", T, B);

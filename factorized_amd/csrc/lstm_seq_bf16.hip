@@ -43,6 +43,23 @@ __device__ __forceinline__ f32x4 mma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// Global traffic of the time loops goes through BUFFER instructions on one-time-step slabs: a lane that has nothing
+// to load or store (batch row >= B, idle wave) is given an offset at the end of the slab, which the hardware
+// range check turns into "load 0" / "drop the store".  So no memory instruction of a step sits under a branch, and
+// the compiler can count: the wait for the NEXT step's prefetched activations becomes vmcnt(#younger stores) instead
+// of vmcnt(0) -- with branches around them every step waited for its own stores to be acknowledged (~1 us each:
+// the first version of this file ran 1.95 us per step at h = 120, this one ~0.7).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slab(const float* base, int64_t elem_off, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(base + elem_off), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, int off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, int off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+}
+
 // --------------------------------------------------------------------------------- forward
 // KB = number of 32-wide k-blocks covering the hidden size (h <= 32 KB).
 template <int KB, int KIND>
@@ -124,29 +141,33 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
     __syncthreads();
   }
 
+  // pointers and slab geometry are formed once (a descriptor field read inside the loop is re-fetched from the
+  // kernel-argument segment after every store: the compiler cannot prove the stores do not alias it)
+  float* const gates_p = d.gates;
+  float* const cs_p = d.cs;
+  float* const hs_p = d.hs;
   const int64_t row4 = 4 * (int64_t)Hp;
+  const int slab_g = B * 4 * Hp * 4, slab_h = B * Hp * 4;                    // bytes of one time step
+  const int voff_g = bvalid ? (b * 4 * Hp + u0 + 4 * q) * 4 : slab_g;          // idle lanes: out of range
+  const int voff_h = bvalid ? (b * Hp + u0 + 4 * q) * 4 : slab_h;
+  const int gx_bytes = dec ? 0 : slab_g;                                      // decoders have no x-projection to fetch
   f32x4 gx[4];
-  if (!dec) {
+  {
+    const __amdgpu_buffer_rsrc_t r0 = slab(gates_p, 0, gx_bytes);
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      gx[g] = bvalid ? ld4b(d.gates + ((int64_t)b) * row4 + g * Hp + u0 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < 4; ++g) gx[g] = bld4(r0, voff_g + g * Hp * 4);
   }
 
   float c[4] = {0.f, 0.f, 0.f, 0.f};
   int cur = 0;
   auto step = [&](const int t) {
     f32x4 acc[4];
-    const int64_t rowt = (int64_t)t * B + b;
-    if (dec) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = bias[g];
-    } else {
+    for (int g = 0; g < 4; ++g) acc[g] = dec ? bias[g] : gx[g];
+    {   // x-projection of step t+1 (the last step re-reads its own slab: unused)
+      const __amdgpu_buffer_rsrc_t rn = slab(gates_p, (int64_t)min(t + 1, T - 1) * B * row4, gx_bytes);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = gx[g];
-      if (t + 1 < T && bvalid) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) gx[g] = ld4b(d.gates + (rowt + B) * row4 + g * Hp + u0 + 4 * q);
-      }
+      for (int g = 0; g < 4; ++g) gx[g] = bld4(rn, voff_g + g * Hp * 4);
     }
     if (active && (dec || t > 0)) {
       const __bf16* hb = lds + cur * (16 * LROW) + bi * LROW + 8 * q;
@@ -158,7 +179,7 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = mma_bf16(w[g][kb], hv[kb], acc[g]);
     }
-    if (active) {
+    {   // every wave runs this block (idle waves compute on zeros and their stores fall outside the slabs)
       f32x4 gi, gf, gg, go, cv, hv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -170,11 +191,13 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
         cv[r] = c[r];
         hv[r] = go[r] * act_tanh(c[r]);
       }
-      if (bvalid) {
-        float* gp = d.gates + rowt * row4 + u0 + 4 * q;
-        st4b(gp, gi); st4b(gp + Hp, gf); st4b(gp + 2 * Hp, gg); st4b(gp + 3 * Hp, go);
-        st4b(d.cs + rowt * Hp + u0 + 4 * q, cv);
-        st4b(d.hs + rowt * Hp + u0 + 4 * q, hv);
+      {
+        const __amdgpu_buffer_rsrc_t rg = slab(gates_p, (int64_t)t * B * row4, slab_g);
+        const __amdgpu_buffer_rsrc_t rc = slab(cs_p, (int64_t)t * B * Hp, slab_h);
+        const __amdgpu_buffer_rsrc_t rh = slab(hs_p, (int64_t)t * B * Hp, slab_h);
+        bst4(rg, voff_g, gi); bst4(rg, voff_g + Hp * 4, gf); bst4(rg, voff_g + 2 * Hp * 4, gg); bst4(rg, voff_g + 3 * Hp * 4, go);
+        bst4(rc, voff_h, cv);
+        bst4(rh, voff_h, hv);
       }
       if (u0 + 4 * q < HKP) {
         const f32x4 hz = (b < B) ? hv : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -252,36 +275,46 @@ __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, cons
   for (int idx = tid; idx < 2 * 16 * LROW; idx += blockDim.x) lds[idx] = (__bf16)0.0f;
   __syncthreads();
 
+  float* const gates_p = d.gates;
+  const float* const cs_p = d.cs;
+  const float* const dh_p = d.dh_ext;
+  const float* const dc_p = d.dc_ext;
   const int64_t row4 = 4 * (int64_t)Hp;
-  f32x4 dh_rec = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int slab_g = B * 4 * Hp * 4, slab_h = B * Hp * 4;                    // bytes of one time step
+  const int voff_g = bvalid ? (b * 4 * Hp + u0 + 4 * q) * 4 : slab_g;          // idle lanes: out of range
+  const int voff_h = bvalid ? (b * Hp + u0 + 4 * q) * 4 : slab_h;
+  const int dhe_bytes = dec ? slab_h : 0;           // per-step external dh exists for decoders only
+  const int dce_bytes = dc_p ? slab_h : 0;          // optional external dc (MFN encoder LSTMs)
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  // encoders receive an external gradient on h_{T-1} only: it seeds the recurrent term
+  f32x4 dh_rec = zero4;
+  if (!dec && bvalid) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int unit = u0 + 4 * q + r;
+      if (unit < h) dh_rec[r] = dh_p[(int64_t)b * d.ld_dh + unit];
+    }
+  }
   float dc[4] = {0.f, 0.f, 0.f, 0.f};
   int cur = 0;
-  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // saved activations of the step ABOUT to be processed: requested one step ahead, unconditionally (see slab())
+  f32x4 n_gi, n_gf, n_gg, n_go, n_ct, n_cp, n_dhe, n_dce;
+  auto fetch = [&](const int t) {
+    const __amdgpu_buffer_rsrc_t rg = slab(gates_p, (int64_t)t * B * row4, slab_g);
+    n_gi = bld4(rg, voff_g); n_gf = bld4(rg, voff_g + Hp * 4); n_gg = bld4(rg, voff_g + 2 * Hp * 4); n_go = bld4(rg, voff_g + 3 * Hp * 4);
+    n_ct = bld4(slab(cs_p, (int64_t)t * B * Hp, slab_h), voff_h);
+    n_cp = bld4(slab(cs_p, (int64_t)max(t - 1, 0) * B * Hp, t > 0 ? slab_h : 0), voff_h);     // c_{-1} = 0
+    n_dhe = bld4(slab(dh_p, (int64_t)t * B * Hp, dhe_bytes), voff_h);
+    n_dce = bld4(slab(dc_p ? dc_p : cs_p, (int64_t)t * B * Hp, dce_bytes), voff_h);
+  };
+  fetch(T - 1);
 
   auto step = [&](const int t, auto first) {
-    const int64_t rowt = (int64_t)t * B + b;
-    f32x4 dh = dh_rec;
-    if (bvalid) {
-      if (dec) {
-        const f32x4 e = ld4b(d.dh_ext + rowt * Hp + u0 + 4 * q);
-        dh += e;
-      } else if (t == T - 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int unit = u0 + 4 * q + r;
-          if (unit < h) dh[r] += d.dh_ext[(int64_t)b * d.ld_dh + unit];
-        }
-      }
-    }
-    f32x4 gi = zero4, gf = zero4, gg = zero4, go = zero4, ct = zero4, cp = zero4;
-    float* gp = d.gates + rowt * row4 + u0 + 4 * q;
-    if (bvalid) {
-      gi = ld4b(gp); gf = ld4b(gp + Hp); gg = ld4b(gp + 2 * Hp); go = ld4b(gp + 3 * Hp);
-      ct = ld4b(d.cs + rowt * Hp + u0 + 4 * q);
-      if (t > 0) cp = ld4b(d.cs + (rowt - B) * Hp + u0 + 4 * q);
-    }
-    f32x4 dce = zero4;
-    if (bvalid && d.dc_ext) dce = ld4b(d.dc_ext + rowt * Hp + u0 + 4 * q);
+    const f32x4 gi = n_gi, gf = n_gf, gg = n_gg, go = n_go, ct = n_ct, cp = n_cp;
+    const f32x4 dh = dh_rec + n_dhe;
+    const f32x4 dce = n_dce;
+    fetch(max(t - 1, 0));                      // step 0 re-reads its own slabs: unused
     f32x4 dai, daf, dag, dao;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -294,7 +327,10 @@ __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, cons
       dao[r] = dot * go[r] * (1.0f - go[r]);
       dc[r] = dct * gf[r];
     }
-    if (bvalid) { st4b(gp, dai); st4b(gp + Hp, daf); st4b(gp + 2 * Hp, dag); st4b(gp + 3 * Hp, dao); }
+    {
+      const __amdgpu_buffer_rsrc_t rg = slab(gates_p, (int64_t)t * B * row4, slab_g);
+      bst4(rg, voff_g, dai); bst4(rg, voff_g + Hp * 4, daf); bst4(rg, voff_g + 2 * Hp * 4, dag); bst4(rg, voff_g + 3 * Hp * 4, dao);
+    }
 
     const bool need_rec = (t > 0) || dec;
     if (need_rec) {

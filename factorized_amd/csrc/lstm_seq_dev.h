@@ -22,6 +22,7 @@ struct SeqLaunch {
 int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream);
 // lstm_seq_bf16.hip: bf16 MFMA operands, fp32 accumulate / cell state / saved activations
 int seq_bf16_launch(SeqLaunch& L, bool bwd, hipStream_t stream);
+bool bf16_seq_pays(int B);     // lstm_seq.hip: batch size from which a bf16 plan runs its recurrences on the bf16 kernels
 // lstm_step.hip: step-by-step path (recurrent GEMM + cell kernel per time step) for h > MFM_SEQ_MAX_RESIDENT_H
 int seq_stepwise(const MfmSeqDesc* descs, int count, int T, int B, bool bwd, hipStream_t stream);
 constexpr int MFM_SEQ_MAX_RESIDENT_H = 128;

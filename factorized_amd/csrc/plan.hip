@@ -355,7 +355,8 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
   P->calls++;
 
   // bf16 plans: the recurrences' weight fragments, rounded and packed once per step (lstm_seq_bf16.hip)
-  if (c.precision) {
+  const bool seq_bf16 = c.precision && bf16_seq_pays(B);
+  if (seq_bf16) {
     MfmSeqDesc q[7];
     for (int e = 0; e < 4; ++e) q[e] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
     for (int m = 0; m < 3; ++m) q[4 + m] = seq_desc(P, P->dec[m], P->dec_p[m], params, W, true);
@@ -383,7 +384,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
   {
     MfmSeqDesc q[4];
     for (int e = 0; e < 4; ++e) q[e] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
-    RUN(K_ENC_FWD, c.precision ? mfm_lstm_seq_fwd_bf16(q, 4, T, B, s) : mfm_lstm_seq_fwd(q, 4, T, B, s));
+    RUN(K_ENC_FWD, seq_bf16 ? mfm_lstm_seq_fwd_bf16(q, 4, T, B, s) : mfm_lstm_seq_fwd(q, 4, T, B, s));
   }
   // F2: latent stack
   {
@@ -410,7 +411,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       q[m] = seq_desc(P, P->dec[m], P->dec_p[m], params, W, true);
       q[m].h_init = W + P->dec_init[m]; q[m].ld_init = P->dec_h[m];
     }
-    RUN(K_DEC_FWD, c.precision ? mfm_lstm_seq_fwd_bf16(q, 3, T, B, s) : mfm_lstm_seq_fwd(q, 3, T, B, s));
+    RUN(K_DEC_FWD, seq_bf16 ? mfm_lstm_seq_fwd_bf16(q, 3, T, B, s) : mfm_lstm_seq_fwd(q, 3, T, B, s));
   }
   // F4: decoder fc1 -> x_hat
   float* xh[3];
@@ -498,6 +499,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
   if (P->grads_prezeroed != grads) MFM_HIP_CHECK(hipMemsetAsync(grads, 0, (size_t)P->n_params * sizeof(float), s));
   P->grads_prezeroed = nullptr;
   const bool gen_on = (stage != 2), disc_on = (stage != 1);
+  const bool seq_bf16 = c.precision && bf16_seq_pays(B);
   // every weight-gradient product only feeds the optimizer: they are collected here and issued as ONE grouped
   // launch behind the encoder BPTT (49 problems at the canonical wiring) instead of three launches on the chain
   std::vector<MfmGemmDesc> tail;
@@ -542,7 +544,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
         q[m].dh_ext = W + P->dec_dhs[m]; q[m].ld_dh = P->dec[m].Hp;
         q[m].d_h_init = W + P->dec_dinit[m]; q[m].ld_dinit = P->dec_h[m];
       }
-      RUN(K_DEC_BWD, c.precision ? mfm_lstm_seq_bwd_bf16(q, 3, T, B, s) : mfm_lstm_seq_bwd(q, 3, T, B, s));
+      RUN(K_DEC_BWD, seq_bf16 ? mfm_lstm_seq_bwd_bf16(q, 3, T, B, s) : mfm_lstm_seq_bwd(q, 3, T, B, s));
     }
     // (B2: the decoder weight gradients only feed Adam; they share the encoders' launch at the end)
   }
@@ -587,7 +589,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       q[e] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
       q[e].dh_ext = W + P->dh_last[e]; q[e].ld_dh = P->enc_h[e];
     }
-    RUN(K_ENC_BWD, c.precision ? mfm_lstm_seq_bwd_bf16(q, 4, T, B, s) : mfm_lstm_seq_bwd(q, 4, T, B, s));
+    RUN(K_ENC_BWD, seq_bf16 ? mfm_lstm_seq_bwd_bf16(q, 4, T, B, s) : mfm_lstm_seq_bwd(q, 4, T, B, s));
   }
   // B5: all weight gradients
   {

@@ -12,7 +12,9 @@ from factorized_amd import engine as E  # noqa: E402
 
 
 def run(h, B, T, path, bwd, dec=False, iters=50):
-    os.environ["MFM_SEQ_PATH"] = path
+    bf16 = path.startswith("bf16")
+    if not bf16:
+        os.environ["MFM_SEQ_PATH"] = path
     Hp = (h + 15) // 16 * 16
     g = torch.randn(T, B, 4, Hp, device="cuda") * 0.5
     hs = torch.zeros(T, B, Hp, device="cuda"); cs = torch.zeros(T, B, Hp, device="cuda")
@@ -28,13 +30,25 @@ def run(h, B, T, path, bwd, dec=False, iters=50):
                        dh_ext=dh, ld_dh=Hp, d_h_init=dinit)
     else:
         d = E.make_seq(g, hs, cs, w, h, dh_ext=dh, ld_dh=h)
+    call = lambda: E.lstm_seq([d], T, B, backward=bwd)
+    if bf16:
+        from factorized_amd import _lib
+        L = _lib.lib()
+        if path == "bf16":           # "bf16-nopack": the kernels gather their weight fragments themselves
+            pack = torch.zeros(L.mfm_lstm_pack_bytes(h, int(dec)), dtype=torch.uint8, device="cuda")
+            d.w_pack = pack.data_ptr()
+        arr = (_lib.SeqDesc * 1)(d)
+        if path == "bf16":
+            _lib.check(L.mfm_lstm_pack_bf16(arr, 1, None), "pack")
+        fn = L.mfm_lstm_seq_bwd_bf16 if bwd else L.mfm_lstm_seq_fwd_bf16
+        call = lambda: _lib.check(fn(arr, 1, T, B, None), "seq bf16")
     for _ in range(5):
-        E.lstm_seq([d], T, B, backward=bwd)
+        call()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):
-        E.lstm_seq([d], T, B, backward=bwd)
+        call()
     b.record(); torch.cuda.synchronize()
     return 1e3 * a.elapsed_time(b) / iters
 

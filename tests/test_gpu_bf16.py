@@ -318,11 +318,23 @@ def _bf16_engine(cfgs):
     return e, w
 
 
+@pytest.fixture(params=["all-bf16", "default"])
+def seq_policy(request, monkeypatch):
+    """a bf16 plan runs its recurrences on the bf16 MFMA kernels from B = 192 on and on the fp32 VALU kernels below
+    (lstm_seq.hip::bf16_seq_pays); 'all-bf16' forces the bf16 kernels at every batch size."""
+    if request.param == "all-bf16":
+        monkeypatch.setenv("MFM_BF16_SEQ_MINB", "1")
+    else:
+        monkeypatch.delenv("MFM_BF16_SEQ_MINB", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("name", ["klef_b32_t20", "klef_b33_t7", "klef_b1_t20", "klef_b5_t1", "klef_b229_t20",
                                   "klef_you_b32_t50", "klef_mosei_b64_t20", "klef_odd_b19_t9"])
-def test_bf16_forward_and_gradients_near_fp32_reference(name):
-    """bounds (stated, measured worst in DESIGN.md): loss terms within 2e-2 relative of the reference's fp32 golden;
-    every parameter gradient within 5e-2 of the oracle's in relative L2 norm and cosine > 0.998."""
+def test_bf16_forward_and_gradients_near_fp32_reference(name, seq_policy):
+    """bounds (measured worst case in brackets): loss terms within 1e-3 relative of the
+    reference's fp32 golden [7e-5]; every parameter gradient within 8e-2 of the oracle's in relative L2 norm
+    [4.0e-2, one tensor at B=229] and cosine > 0.995 [1 - 7.4e-4]."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     cs = cases.load_case(name)
@@ -336,8 +348,8 @@ def test_bf16_forward_and_gradients_near_fp32_reference(name):
     for k in ("disc", "gen_l", "gen_a", "gen_v", "reg", "loss"):
         ref = float(gold["fwd_" + k])
         worst_l = max(worst_l, abs(ld[k] - ref) / max(abs(ref), 1e-3))
-    cases.report("bf16_loss_terms_rel_%s" % name, worst_l)
-    assert worst_l < 2e-2, (ld, worst_l)
+    cases.report("bf16_loss_terms_rel_%s_%s" % (name, seq_policy), worst_l)
+    assert worst_l < 1e-3, (ld, worst_l)
     assert rel_err(out["y_hat"].cpu().numpy(), gold["y_hat"]) < 5e-2
     assert rel_err(out["x_a_hat"].cpu().numpy(), gold["x_a_hat"]) < 5e-2
     m = O.build("kl_ef", cs["cfgs"])
@@ -359,18 +371,18 @@ def test_bf16_forward_and_gradients_near_fp32_reference(name):
             worst_g = (n, rel)
         if cos < worst_c[1]:
             worst_c = (n, cos)
-    cases.report("bf16_grad_relL2_%s" % name, worst_g[1])
-    cases.report("bf16_grad_one_minus_cos_%s" % name, 1.0 - worst_c[1])
-    assert worst_g[1] < 5e-2, worst_g
-    assert worst_c[1] > 0.998, worst_c
+    cases.report("bf16_grad_relL2_%s_%s" % (name, seq_policy), worst_g[1])
+    cases.report("bf16_grad_one_minus_cos_%s_%s" % (name, seq_policy), 1.0 - worst_c[1])
+    assert worst_g[1] < 8e-2, worst_g
+    assert worst_c[1] > 0.995, worst_c
     # not accidentally the fp32 path
     assert worst_g[1] > 1e-5
 
 
 @pytest.mark.parametrize("name", ["klef_b32_t20", "klef_you_b32_t50", "klef_b33_t7"])
-def test_bf16_loss_curve_tracks_fp32_reference(name):
+def test_bf16_loss_curve_tracks_fp32_reference(name, seq_policy):
     """'matched loss curve' gate: N fused bf16 steps against the reference's own fp32
-    loss trace (golden); every term within 2e-2 relative at every step."""
+    loss trace (golden); every term within 2e-3 relative at every step [measured 1.5e-4 over 20 steps]."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     cs = cases.load_case(name)
@@ -382,8 +394,8 @@ def test_bf16_loss_curve_tracks_fp32_reference(name):
         trace.append([ld["loss"], ld["disc"], ld["gen"], ld["reg"]])
     trace, ref = np.array(trace), cs["gold"]["trace"]
     dev_ = float(np.max(np.abs(trace - ref) / np.maximum(np.abs(ref), 1e-2)))
-    cases.report("bf16_trace_rel_%s" % name, dev_)
-    assert dev_ < 2e-2, (trace[-1], ref[-1])
+    cases.report("bf16_trace_rel_%s_%s" % (name, seq_policy), dev_)
+    assert dev_ < 2e-3, (trace[-1], ref[-1])
     assert trace[-1, 0] < trace[0, 0]                  # and it trains
 
 
@@ -398,7 +410,7 @@ def test_bf16_large_batch_mosei_loss_curve():
     cfg = cfgs[0]
     xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7, output_dim=cfg["output_dim"])
     x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
-    for prec, bound in (("fp32", 2e-4), ("bf16", 2e-2)):
+    for prec, bound in (("fp32", 2e-4), ("bf16", 1e-3)):          # measured: bf16 3.2e-5
         from factorized_amd import engine
         e = engine.MFMEngine(cfgs, precision=prec)
         e.load_weights(synth.make_weights(e.layout.shapes, seed=1234))
