@@ -46,7 +46,7 @@ class MemDesc(C.Structure):
                 ("dmem_out", C.c_void_p), ("du1", C.c_void_p), ("du2", C.c_void_p), ("dchat", C.c_void_p),
                 ("T", C.c_int32), ("B", C.c_int32), ("M", C.c_int32), ("H1", C.c_int32), ("H2", C.c_int32),
                 ("train", C.c_int32), ("p1", C.c_float), ("p2", C.c_float), ("seed", C.c_uint64),
-                ("seed_dev", C.c_void_p)]
+                ("seed_dev", C.c_void_p), ("ld_wm", C.c_int64), ("dchat_pre_tanh", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class AdamSpan(C.Structure):
@@ -65,7 +65,10 @@ class PlanConfig(C.Structure):
                 ("lda_xl", C.c_float), ("lda_xa", C.c_float), ("lda_xv", C.c_float), ("lda_reg", C.c_float),
                 ("drop_zy", C.c_float), ("drop_zl", C.c_float), ("drop_za", C.c_float),
                 ("drop_zv", C.c_float), ("drop_y", C.c_float),
-                ("reg_scale", C.c_float), ("precision", C.c_int32)]
+                ("reg_scale", C.c_float), ("precision", C.c_int32),
+                ("variant", C.c_int32), ("hl", C.c_int32), ("ha", C.c_int32), ("hv", C.c_int32), ("mem_dim", C.c_int32),
+                ("nn1", C.c_int32), ("nn2", C.c_int32), ("g1", C.c_int32), ("g2", C.c_int32),
+                ("drop_nn1", C.c_float), ("drop_nn2", C.c_float), ("drop_g1", C.c_float), ("drop_g2", C.c_float)]
 
 
 _SIGS = {
@@ -101,6 +104,8 @@ _SIGS = {
                                          C.c_void_p]),
     "mfm_p2p_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "mfm_p2p_destroy": (None, [C.c_void_p]),
+    "mfm_plan_num_params": (C.c_int, [C.c_int32]),
+    "mfm_plan_set_gauss": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mfm_plan_create": (C.c_int, [C.POINTER(PlanConfig), C.POINTER(C.c_int64), C.c_int64,
                                   C.POINTER(C.c_void_p)]),
     "mfm_plan_destroy": (None, [C.c_void_p]),
@@ -122,6 +127,7 @@ _SIGS = {
                                              C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(AdamSpan),
                                              C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mfm_plan_latent_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "mfm_plan_mfn_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mfm_plan_flops_per_step": (C.c_double, [C.c_void_p]),
     "mfm_plan_bytes_per_step": (C.c_double, [C.c_void_p]),
     "mfm_plan_set_timing": (C.c_int, [C.c_void_p, C.c_int]),

@@ -270,7 +270,7 @@ int device_cus() {
 
 // Host-side launch of one group (count <= MFM_GEMM_MAXP).
 int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, const ZeroSpans* zs, const MseEpi* mse,
-                      int mse_count, int precision) {
+                      int mse_count, int precision, const GemmEpiSet* epis) {
   MFM_REQUIRE(count >= 1 && count <= MFM_GEMM_MAXP, "gemm group: count %d out of range", count);
   const int cus = device_cus();
   GemmGroup g;
@@ -282,8 +282,19 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
     MFM_REQUIRE(mse[i].x && !descs[i].accumulate && descs[i].batch == 1, "gemm group: mse epilogue %d needs a plain (non-accumulating, unbatched) product", i);
     g.mse[i] = mse[i];
   }
+  if (epis && epis->count > 0) {
+    MFM_REQUIRE(epis->count <= MFM_GEMM_NEPI && epis->count <= count && epis->epi, "gemm group: %d output transforms (max %d)", epis->count, MFM_GEMM_NEPI);
+    for (int i = 0; i < epis->count; ++i) {
+      const GemmEpi& e = epis->epi[i];
+      MFM_REQUIRE(e.kind >= 0 && e.kind <= 3 && (e.kind == 0 || e.kind == 2 || e.aux), "gemm group: bad output transform %d", i);
+      MFM_REQUIRE(e.kind == 0 || (!descs[i].accumulate && descs[i].split_k <= 1 && descs[i].batch == 1),
+                  "gemm group: output transform %d needs a plain (non-accumulating, unbatched) product", i);
+      g.epi[i] = e;
+    }
+    g.epi_count = epis->count; g.epi_train = epis->train; g.epi_seed = epis->seed;
+  }
   if (zs) {
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MFM_GEMM_ZSPANS; ++i) {
       if (zs->n[i] <= 0) continue;
       MFM_REQUIRE((zs->n[i] & 3) == 0 && (((uintptr_t)zs->ptr[i]) & 15) == 0, "gemm group: zero span %d not 16-byte shaped", i);
       g.zero_ptr[i] = zs->ptr[i]; g.zero_n[i] = zs->n[i];

@@ -6,6 +6,7 @@
 
 namespace mfm {
 
+#define MFM_GEMM_NEPI 4     // problems per launch that may carry an output transform (always the first ones)
 #define MFM_GEMM_MAXP 56   // problems per launch (the descriptors travel in the kernel-argument segment, ~9.6 KB)
 
 struct GemmProblem {
@@ -18,13 +19,17 @@ struct GemmGroup {
   int count;
   // optional: spans the launch also clears (the fused step's loss slots and gradient buffer ride on its
   // first GEMM instead of two memset launches of ~4.7 us each)
-  float* zero_ptr[2];
-  int64_t zero_n[2];
+  float* zero_ptr[MFM_GEMM_ZSPANS];
+  int64_t zero_n[MFM_GEMM_ZSPANS];
   // optional: squared-error epilogue for the first mse_count problems (decoder fc1 -> x_hat): the tile that
   // produced x_hat also forms d x_hat and its share of the reconstruction loss (mfm_mosi.py:441-446), so the
   // separate elementwise launch and its re-read of x_hat disappear
   MseEpi mse[3];
   int mse_count;
+  // optional: per-problem output transforms (internal.h::GemmEpi), first epi_count problems
+  GemmEpi epi[MFM_GEMM_NEPI];
+  int epi_count, epi_train;
+  unsigned long long epi_seed;
 };
 
 
@@ -56,6 +61,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmGroup& g, const MfmGemmD
         if (row >= d.m) continue;
         float v = (col < d.n_valid) ? d.alpha * acc[fm][fn][r] + bsum : 0.0f;
         const int64_t off = (int64_t)row * d.ldc + col;
+        if (pi < g.epi_count && col < d.n_valid) {          // wave-uniform condition on pi
+          const GemmEpi& ep = g.epi[pi];
+          if (ep.kind == 1) {
+            float mk = 1.0f;
+            if (g.epi_train && ep.p > 0.0f) {
+              const uint64_t idx = ((uint64_t)ep.op_id << 40) + (uint64_t)row * (uint64_t)d.n_valid + (uint64_t)col;
+              mk = (rng_uniform(g.epi_seed, idx) < ep.p) ? 0.0f : 1.0f / (1.0f - ep.p);
+            }
+            ep.aux[off] = (v > 0.0f) ? mk : 0.0f;
+            v = fmaxf(v, 0.0f) * mk;
+          } else if (ep.kind == 2) {
+            v = act_tanh(v);
+          } else if (ep.kind == 3) {
+            v *= ep.aux[off];
+          }
+        }
         if (d.accumulate) {
           if (col < d.n_valid) {
             atomicAdd(C + off, v);
@@ -83,7 +104,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmGroup& g, const MfmGemmD
   // zero-fill spans last: ahead of the K loop these stores would sit in front of the first tile loads in the
   // in-order vmcnt queue and put a store round trip on every workgroup's critical path
 #pragma unroll
-  for (int zi = 0; zi < 2; ++zi) {
+  for (int zi = 0; zi < MFM_GEMM_ZSPANS; ++zi) {
     if (g.zero_n[zi] > 0) {          // 16-byte aligned, multiple of 4 floats (checked by the host)
       f32x4* z4 = reinterpret_cast<f32x4*>(g.zero_ptr[zi]);
       const int64_t n4 = g.zero_n[zi] >> 2;

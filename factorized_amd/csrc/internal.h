@@ -5,14 +5,22 @@
 namespace mfm {
 
 // gemm.hip
-struct ZeroSpans { float* ptr[2]; int64_t n[2]; };   // spans (multiples of 4 floats, 16-byte aligned) a GEMM launch also clears
+#define MFM_GEMM_ZSPANS 3
+struct ZeroSpans { float* ptr[MFM_GEMM_ZSPANS]; int64_t n[MFM_GEMM_ZSPANS]; };   // spans (multiples of 4 floats, 16-byte aligned) a GEMM launch also clears
+// optional per-problem output transform, applied to the finished element v of C (non-accumulating problems):
+//   1  relu + dropout:  aux <- (v > 0) * scale,  v <- max(v, 0) * scale      scale = 0 | 1/(1-p) in train mode, else 1
+//   2  tanh
+//   3  v <- v * aux                                                            (backward of kind 1)
+// aux is addressed like C (row * ldc + col).  The dropout stream is keyed by (seed, op_id, row, col).
+struct GemmEpi { float* aux; float p; int kind; unsigned op_id; int pad_; };
+struct GemmEpiSet { const GemmEpi* epi; int count; unsigned long long seed; int train; };
 struct MseEpi {          // squared-error epilogue of one product: target, d(output), loss slot, scales
   const float* x; int64_t ldx; float* dxhat; float* loss; float inv_count, grad_scale;
 };
 // precision: 0 = fp32 operands on v_mfma_f32_16x16x4_f32, 1 = operands rounded to bf16 on the way into LDS,
 // v_mfma_f32_16x16x32_bf16 with fp32 accumulation (gemm_bf16.hip)
 int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, const ZeroSpans* zs = nullptr,
-                      const MseEpi* mse = nullptr, int mse_count = 0, int precision = 0);
+                      const MseEpi* mse = nullptr, int mse_count = 0, int precision = 0, const GemmEpiSet* epis = nullptr);
 int device_cus();
 
 // elementwise.hip
@@ -26,6 +34,17 @@ int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, int ste
 int adam_spans_launch(float* p, const float* g, float* m, float* v, const MfmAdamSpan* spans, int nspans, float lr,
                       float beta1, float beta2, float eps, float grad_scale, hipStream_t stream);
 int fill_launch(float* p, int64_t n, float val, hipStream_t stream);
+
+// mfn_att.hip -- row-wise glue of the MFN attention block (everything between its GEMMs)
+struct MfnCs { const float* cs[3]; float* dcx[3]; int h[3]; int T, B; };     // the three MFN LSTMs' cell states [T,B,Hp]
+int mfn_cstar_launch(const MfnCs& c, float* cstar, hipStream_t stream);
+int mfn_dcs_scatter_launch(const MfnCs& c, const float* dcs, hipStream_t stream);
+int mfn_softmax_fwd_launch(float* att, const float* cstar, float* attended, int64_t rows, int n, hipStream_t stream);
+int mfn_softmax_bwd_launch(const float* datt, const float* att, const float* cstar, float* dlog, float* dcs, int64_t rows,
+                           int n, hipStream_t stream);
+// mmd.hip -- strided form of mfm_mmd_fwd_bwd: z / dz are column blocks of wider row-major buffers
+int mmd_launch(const float* z, int64_t ldz, const float* g, int64_t ldg, int B, int dim, float* loss, float* dz, int64_t lddz,
+               float dz_scale, hipStream_t stream);
 
 // latent.hip -- the fused "latent stack": encoder fc1 heads, mu/logvar heads, z->f MLPs,
 // classifier, KLD and discriminative loss, interpreted from a small op table.
@@ -70,6 +89,8 @@ struct LatentDev {
   const float* reg_w_ptr;              // optional device scalar: upstream gradient wrt the KLD sum
   float* losses;
   float* grd_out;                      // [B, rec_size] gradient record written by the backward
+  const float* grd_seed;               // optional [B, rec_size]: gradients injected into the record before the backward
+                                       // walks the stages (the MMD regulariser's d reg / d z of the non-KL MFM)
   unsigned long long* dbg;             // optional: block 0 / thread 0 writes s_memtime at phase marks
   int B, rows_per_wg, train, has_logvar;
   int row_path;                        // 1: one batch row per workgroup, weights read straight from L2 (latent.hip)

@@ -310,7 +310,8 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_kernel(const LatentDev
     const f32x4* s4 = reinterpret_cast<const f32x4*>(L.rec + (int64_t)row0 * RS);
     f32x4* r4 = reinterpret_cast<f32x4*>(rec);
     f32x4* g4 = reinterpret_cast<f32x4*>(grd);
-    for (int idx = tid; idx < n4; idx += nt) { r4[idx] = s4[idx]; g4[idx] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const f32x4* sd4 = L.grd_seed ? reinterpret_cast<const f32x4*>(L.grd_seed + (int64_t)row0 * RS) : nullptr;
+    for (int idx = tid; idx < n4; idx += nt) { r4[idx] = s4[idx]; g4[idx] = sd4 ? sd4[idx] : f32x4{0.f, 0.f, 0.f, 0.f}; }
   }
   lds_barrier();
 
@@ -730,11 +731,14 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_row_kernel(const Laten
     f32x4* r4 = reinterpret_cast<f32x4*>(rec);
     f32x4* g4 = reinterpret_cast<f32x4*>(grd);
     const f32x4 rv = s4[min(tid, n4 - 1)];
+    const f32x4* sd4 = L.grd_seed ? reinterpret_cast<const f32x4*>(L.grd_seed + (int64_t)row * RS) : nullptr;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 sv = sd4 ? sd4[min(tid, n4 - 1)] : zero;
     load_items(L.items_bwd, L.nstages, tab, tid);
     if (tid < nw) reinterpret_cast<int*>(ops)[tid] = opv;
     if (tid < L.nops) pfxN[tid] = L.ops[tid].pfx_n;
-    if (tid < n4) { r4[tid] = rv; g4[tid] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    for (int idx = tid + nt; idx < n4; idx += nt) { r4[idx] = s4[idx]; g4[idx] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (tid < n4) { r4[tid] = rv; g4[tid] = sv; }
+    for (int idx = tid + nt; idx < n4; idx += nt) { r4[idx] = s4[idx]; g4[idx] = sd4 ? sd4[idx] : zero; }
   }
   lds_barrier();
   const int l = tid & 15;

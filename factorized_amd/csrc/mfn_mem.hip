@@ -49,6 +49,7 @@ __device__ __forceinline__ float group_sum(float v, int Q) {
 struct MemDev {
   MfmMemDesc d;
   int QA, KA, QB, KB1, KB2;       // lanes per output / weights per lane of the two matvec shapes
+  int64_t ldw;                    // row stride of the memory-column weight blocks
 };
 
 // ------------------------------------------------------------------------------------- forward
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_fwd_kernel(const MemDev P) {
 #pragma unroll
   for (int i = 0; i < MEM_MAXW; ++i) {
     const int k = qa + QA * i;
-    wA[i] = (actA && i < KA && k < M) ? wm[(int64_t)jn * M + min(k, M - 1)] : 0.0f;
+    wA[i] = (actA && i < KA && k < M) ? wm[(int64_t)jn * P.ldw + min(k, M - 1)] : 0.0f;
   }
   float* abuf = netA ? d.a2 : d.a1;
   const int Hn = netA ? H2 : H1;
@@ -195,8 +196,8 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_bwd_kernel(const MemDev P) {
 #pragma unroll
   for (int i = 0; i < MEM_MAXW; ++i) {
     const int j = qb + QB * i;
-    wB1[i] = (actB && i < P.KB1 && j < H1) ? d.w1m[(int64_t)min(j, H1 - 1) * M + mb] : 0.0f;
-    wB2[i] = (actB && i < P.KB2 && j < H2) ? d.w2m[(int64_t)min(j, H2 - 1) * M + mb] : 0.0f;
+    wB1[i] = (actB && i < P.KB1 && j < H1) ? d.w1m[(int64_t)min(j, H1 - 1) * P.ldw + mb] : 0.0f;
+    wB2[i] = (actB && i < P.KB2 && j < H2) ? d.w2m[(int64_t)min(j, H2 - 1) * P.ldw + mb] : 0.0f;
   }
   const int64_t arow = ((int64_t)row) * Hn + jn;
   const int64_t mrow = ((int64_t)row) * M + mb;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_bwd_kernel(const MemDev P) {
       dzb[mb] = dz1; dzb[M + mb] = dz2;
       const int64_t oo = (int64_t)t * B * M + mrow;
       d.gam1[oo] = dz1; d.gam2[oo] = dz2;          // in place: the weight-gradient GEMMs read dz from here
-      d.dchat[oo] = dmem * g2;
+      d.dchat[oo] = d.dchat_pre_tanh ? dmem * g2 * (1.0f - ch * ch) : dmem * g2;
     }
     const float dmem_direct = dmem * g1;
     lds_barrier();
@@ -267,6 +268,7 @@ int mem_setup(const MfmMemDesc* desc, MemDev& P, int& threads, size_t& lds) {
   MFM_REQUIRE(d.a1 && d.a2 && d.chat && d.w1m && d.w2m && d.w1b && d.b1b && d.w2b && d.b2b && d.gam1 && d.gam2 && d.mems,
               "mfn_mem: null operand");
   P.d = d;
+  P.ldw = d.ld_wm > 0 ? d.ld_wm : d.M;
   P.QA = pow2_ge(cdiv(d.M, MEM_MAXW));
   P.KA = cdiv(d.M, P.QA);
   const int hmax = d.H1 > d.H2 ? d.H1 : d.H2;

@@ -16,7 +16,8 @@ constexpr int MT = 32;          // rows per tile
 constexpr int MMD_KMAX = 256;   // feature dimension limit (registers: dim/8 accumulators per thread)
 
 __global__ __launch_bounds__(256) void mmd_kernel(const float* __restrict__ z, const float* __restrict__ g, int B, int dim,
-                                                  float* __restrict__ loss, float* __restrict__ dz, float loss_scale) {
+                                                  float* __restrict__ loss, float* __restrict__ dz, float loss_scale,
+                                                  int64_t ldz, int64_t ldg, int64_t lddz, float dz_scale) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int ld = dim | 1;                         // odd row stride: conflict-free when lanes walk rows
   float* zi = lds;                                // [MT][ld]
@@ -34,8 +35,8 @@ __global__ __launch_bounds__(256) void mmd_kernel(const float* __restrict__ z, c
   for (int e = tid; e < MT * dim; e += 256) {
     const int r = e / dim, c = e - r * dim;
     const int row = min(i0 + r, B - 1);
-    zi[r * ld + c] = z[(int64_t)row * dim + c];
-    gi[r * ld + c] = g[(int64_t)row * dim + c];
+    zi[r * ld + c] = z[(int64_t)row * ldz + c];
+    gi[r * ld + c] = g[(int64_t)row * ldg + c];
   }
   float acc[MMD_KMAX / 8];
 #pragma unroll
@@ -48,8 +49,8 @@ __global__ __launch_bounds__(256) void mmd_kernel(const float* __restrict__ z, c
     for (int e = tid; e < MT * dim; e += 256) {
       const int r = e / dim, c = e - r * dim;
       const int row = min(j0 + r, B - 1);
-      zj[r * ld + c] = z[(int64_t)row * dim + c];
-      gj[r * ld + c] = g[(int64_t)row * dim + c];
+      zj[r * ld + c] = z[(int64_t)row * ldz + c];
+      gj[r * ld + c] = g[(int64_t)row * ldg + c];
     }
     __syncthreads();
     // phase 1: the three kernel values of (i, j) for this thread's 4 columns
@@ -92,11 +93,11 @@ __global__ __launch_bounds__(256) void mmd_kernel(const float* __restrict__ z, c
     }
   }
   if (dz && ilive) {
-    const float coef = 4.0f * loss_scale * inv_k2;     // loss_scale = 1 / B^2
+    const float coef = 4.0f * loss_scale * inv_k2 * dz_scale;     // loss_scale = 1 / B^2
 #pragma unroll
     for (int t = 0; t < MMD_KMAX / 8; ++t) {
       const int c = js + 8 * t;
-      if (c < dim) dz[(int64_t)(i0 + il) * dim + c] = coef * acc[t];
+      if (c < dim) dz[(int64_t)(i0 + il) * lddz + c] = coef * acc[t];
     }
   }
 #pragma unroll
@@ -108,6 +109,20 @@ __global__ __launch_bounds__(256) void mmd_kernel(const float* __restrict__ z, c
 
 }  // namespace
 
+int mmd_launch(const float* z, int64_t ldz, const float* g, int64_t ldg, int B, int dim, float* loss, float* dz, int64_t lddz,
+               float dz_scale, hipStream_t stream) {
+  MFM_REQUIRE(B >= 1 && dim >= 1, "mmd: B=%d dim=%d", B, dim);
+  if (dim > MMD_KMAX) { set_error("mmd: feature dimension %d > %d", dim, MMD_KMAX); return MFM_ERR_UNSUPPORTED; }
+  const int ld = dim | 1;
+  const size_t lds = ((size_t)4 * MT * ld + 2 * MT * (MT + 1)) * sizeof(float);
+  if (lds > 64 * 1024)
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)mmd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(mmd_kernel, dim3(cdiv(B, MT)), dim3(256), lds, stream, z, g, B, dim, loss, dz,
+                     1.0f / ((float)B * (float)B), ldz, ldg, lddz, dz_scale);
+  MFM_LAUNCH_CHECK("mmd_kernel");
+  return MFM_OK;
+}
+
 }  // namespace mfm
 
 using namespace mfm;
@@ -115,14 +130,5 @@ using namespace mfm;
 extern "C" int mfm_mmd_fwd_bwd(const float* z, const float* gauss, int32_t B, int32_t dim, float* loss, float* dz,
                                void* stream) {
   if (!z || !gauss || !loss) { set_error("mfm_mmd_fwd_bwd: null argument"); return MFM_ERR_ARG; }
-  MFM_REQUIRE(B >= 1 && dim >= 1, "mmd: B=%d dim=%d", B, dim);
-  if (dim > MMD_KMAX) { set_error("mmd: feature dimension %d > %d", dim, MMD_KMAX); return MFM_ERR_UNSUPPORTED; }
-  const int ld = dim | 1;
-  const size_t lds = ((size_t)4 * MT * ld + 2 * MT * (MT + 1)) * sizeof(float);
-  if (lds > 64 * 1024)
-    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)mmd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(mmd_kernel, dim3(cdiv(B, MT)), dim3(256), lds, (hipStream_t)stream, z, gauss, (int)B, (int)dim, loss, dz,
-                     1.0f / ((float)B * (float)B));
-  MFM_LAUNCH_CHECK("mmd_kernel");
-  return MFM_OK;
+  return mmd_launch(z, dim, gauss, dim, (int)B, (int)dim, loss, dz, dim, 1.0f, (hipStream_t)stream);
 }

@@ -31,15 +31,53 @@ namespace mfm {
 
 enum KernelId {
   K_PROJ = 0, K_ENC_FWD, K_LAT_FWD, K_DEC_FWD, K_FC1_FWD, K_MSE, K_FC1_BWD, K_DEC_BWD, K_DEC_DW,
-  K_LAT_BWD, K_ENC_BWD, K_ENC_DW, K_ADAM, K_LAT_DW, K_PACK, K_COUNT
+  K_LAT_BWD, K_ENC_BWD, K_ENC_DW, K_ADAM, K_LAT_DW, K_PACK,
+  // Memory Fusion Network (variants 1, 2)
+  K_MFN_GLUE, K_MFN_ATT_FWD, K_MFN_MEM_FWD, K_MFN_HEADS, K_MFN_MEM_BWD, K_MFN_ATT_BWD, K_MMD, K_COUNT
 };
 
-// state_dict order of MFM_KL_EF (78 tensors), see include/mfm_hip.h
-enum { P_ENC_L = 0, P_ENC_A = 6, P_ENC_V = 12, P_DEC_L = 18, P_DEC_A = 24, P_DEC_V = 30, P_ENC_Y = 36,
-       P_TO_ZY = 42, P_TO_LVY = 44, P_TO_ZL = 46, P_TO_ZA = 48, P_TO_ZV = 50, P_TO_LVL = 52, P_TO_LVA = 54,
-       P_TO_LVV = 56, P_ZY_F1 = 58, P_ZY_F2 = 60, P_ZL_F1 = 62, P_ZL_F2 = 64, P_ZA_F1 = 66, P_ZA_F2 = 68,
-       P_ZV_F1 = 70, P_ZV_F2 = 72, P_Y_F1 = 74, P_Y_F2 = 76 };
+// Index of every tensor group in the reference model's state_dict order (see include/mfm_hip.h):
+//   MFM_KL_EF  78 tensors: enc l,a,v | dec l,a,v | ef_encoder | heads | z->f | classifier
+//   MFM_KL    104 tensors: enc l,a,v | dec l,a,v | mfn_encoder (32) | heads | z->f | classifier
+//   MFM        90 tensors: the same without the logvar heads and the modality mu heads
+struct PIdx {
+  int enc[4], dec[3];            // encoderLSTM / decoderLSTM blocks: 6 tensors each; enc[3] = ef_encoder (variant 0)
+  int mfl[3];                    // MFN LSTMCells: 4 tensors each (weight_ih, weight_hh, bias_ih, bias_hh)
+  int att1_1, att1_2, att2_1, att2_2, g1_1, g1_2, g2_1, g2_2;     // MFN Linears (weight; bias = +1)
+  int to_z[4], to_lv[4];         // mu / logvar heads in the order l, a, v, y; -1 = absent
+  int zf1[4], zf2[4];            // z -> f MLPs, order l, a, v, y
+  int y_f1, y_f2;
+  int count;
+};
+static PIdx pidx_for(int variant) {
+  PIdx p;
+  memset(&p, 0xff, sizeof(p));      // -1 everywhere
+  p.enc[0] = 0; p.enc[1] = 6; p.enc[2] = 12;
+  p.dec[0] = 18; p.dec[1] = 24; p.dec[2] = 30;
+  if (variant == 0) {
+    p.enc[3] = 36;
+    p.to_z[3] = 42; p.to_lv[3] = 44; p.to_z[0] = 46; p.to_z[1] = 48; p.to_z[2] = 50;
+    p.to_lv[0] = 52; p.to_lv[1] = 54; p.to_lv[2] = 56;
+    p.zf1[3] = 58; p.zf2[3] = 60; p.zf1[0] = 62; p.zf2[0] = 64; p.zf1[1] = 66; p.zf2[1] = 68; p.zf1[2] = 70; p.zf2[2] = 72;
+    p.y_f1 = 74; p.y_f2 = 76; p.count = 78;
+    return p;
+  }
+  p.mfl[0] = 36; p.mfl[1] = 40; p.mfl[2] = 44;
+  p.att1_1 = 48; p.att1_2 = 50; p.att2_1 = 52; p.att2_2 = 54; p.g1_1 = 56; p.g1_2 = 58; p.g2_1 = 60; p.g2_2 = 62;
+  // 64..67: mfn_encoder.out_fc1 / out_fc2 -- in the state_dict, unused by forward (reference mfm_model.py:133-137,199)
+  p.to_z[3] = 68;
+  int next = 70;
+  if (variant == 1) {
+    p.to_lv[3] = 70; p.to_z[0] = 72; p.to_z[1] = 74; p.to_z[2] = 76; p.to_lv[0] = 78; p.to_lv[1] = 80; p.to_lv[2] = 82;
+    next = 84;
+  }
+  p.zf1[3] = next; p.zf2[3] = next + 2;
+  for (int e = 0; e < 3; ++e) { p.zf1[e] = next + 4 + 4 * e; p.zf2[e] = next + 6 + 4 * e; }
+  p.y_f1 = next + 16; p.y_f2 = next + 18; p.count = next + 20;
+  return p;
+}
 enum { W_IH = 0, W_HH = 1, B_IH = 2, B_HH = 3, FC_W = 4, FC_B = 5 };
+#define MFM_MAX_NPARAM 104
 
 struct SeqBuf { int64_t gates, hs, cs, wpack; int h, Hp; };
 
@@ -49,15 +87,28 @@ struct TimingPair { hipEvent_t a, b; int kid; };
 
 struct MfmPlan {
   MfmPlanConfig cfg;
-  int64_t off[MFM_KLEF_NPARAM];
+  mfm::PIdx pi;
+  int64_t off[MFM_MAX_NPARAM];
   int64_t n_params;
   int D, T, B;
-  // encoders l,a,v,y ; decoders l,a,v
-  int enc_d[4], enc_xoff[4], enc_h[4], enc_p[4];
+  // sequence encoders: variant 0: l, a, v, early-fusion (n_enc = 4); variants 1, 2: l, a, v + the three MFN LSTMs
+  // (n_enc = 6; entries 3..5 have no fc1 head, their cell states feed the attention block); decoders l, a, v
+  int n_enc;
+  int enc_d[6], enc_xoff[6], enc_h[6], enc_p[6];
   int dec_d[3], dec_h[3], dec_p[3], dec_xoff[3];
-  mfm::SeqBuf enc[4], dec[3];
+  mfm::SeqBuf enc[6], dec[3];
   int64_t dec_dhs[3], dec_init[3], dec_dinit[3], xhat[3], dxhat[3];
   int64_t lat_rec, dh_last[4], yhat, ones, losses;
+  // ---- Memory Fusion Network buffers (element offsets into the workspace; variants 1, 2)
+  int tot, A2, nzy;                  // sum of MFN hidden sizes, width of cStar, width of the latent's y input
+  int64_t dcx[3];                    // d loss / d c_t of the MFN LSTMs [T,B,Hp] (dc_ext of the BPTT)
+  int64_t cstar, h1, m1, att, attended, h2, m2, chat, a1, a2, gam1, gam2, mems, mem_out;
+  int64_t zero_blk, zero_len;        // cleared by the step's first launch: zyin | d_hT | dmem | datt
+  int64_t zyin, d_hT, dmem, datt;
+  int64_t du1, du2, dchat, dh2, dlog, dh1, dcs;
+  int64_t lat_seed;                  // variant 2: gradient seed record of the latent backward (d MMD / d z)
+  int z_seg[4];                      // variant 2: record offsets of z_l, z_a, z_v, z_y
+  const float* gauss;                // variant 2: caller's N(0,1) sample [B, zl+za+zv+zy]
   int64_t ws_floats;
   mfm::LatentDev lat;
   mfm::LatOp lat_ops[MFM_LAT_MAXOPS];
@@ -89,30 +140,34 @@ static void add_op(LatOp* ops, LatentDev& L, int stage, int in_off, int out_off,
 
 static int build(MfmPlan* P) {
   const MfmPlanConfig& c = P->cfg;
+  const PIdx& pi = P->pi;
+  const int V = c.variant;
   P->T = c.T; P->B = c.B;
   P->D = c.d_l + c.d_a + c.d_v;
   const int ze = c.zl + c.za + c.zv;
-  const int ed[4] = {c.d_l, c.d_a, c.d_v, P->D};
-  const int ex[4] = {0, c.d_l, c.d_l + c.d_a, 0};
-  const int eh[4] = {c.zl, c.za, c.zv, ze};
-  const int ep[4] = {P_ENC_L, P_ENC_A, P_ENC_V, P_ENC_Y};
   const int dd[3] = {c.d_l, c.d_a, c.d_v};
+  const int dx[3] = {0, c.d_l, c.d_l + c.d_a};
   const int fm[3] = {c.fl, c.fa, c.fv};
-  const int dp[3] = {P_DEC_L, P_DEC_A, P_DEC_V};
+  const int mh[3] = {c.hl, c.ha, c.hv};
   int64_t cur = 0;
   const int64_t TB = (int64_t)c.T * c.B;
-  for (int e = 0; e < 4; ++e) {
-    P->enc_d[e] = ed[e]; P->enc_xoff[e] = ex[e]; P->enc_h[e] = eh[e]; P->enc_p[e] = ep[e];
+  P->n_enc = (V == 0) ? 4 : 6;
+  for (int e = 0; e < P->n_enc; ++e) {
+    if (e < 3) { P->enc_d[e] = dd[e]; P->enc_xoff[e] = dx[e]; P->enc_h[e] = (e == 0 ? c.zl : (e == 1 ? c.za : c.zv)); P->enc_p[e] = pi.enc[e]; }
+    else if (V == 0) { P->enc_d[e] = P->D; P->enc_xoff[e] = 0; P->enc_h[e] = ze; P->enc_p[e] = pi.enc[3]; }
+    else { P->enc_d[e] = dd[e - 3]; P->enc_xoff[e] = dx[e - 3]; P->enc_h[e] = mh[e - 3]; P->enc_p[e] = pi.mfl[e - 3]; }
     SeqBuf& s = P->enc[e];
-    s.h = eh[e]; s.Hp = round_up(eh[e], 16);
+    s.h = P->enc_h[e]; s.Hp = round_up(s.h, 16);
     s.gates = carve(cur, TB * 4 * s.Hp);
     s.hs = carve(cur, TB * s.Hp);
     s.cs = carve(cur, TB * s.Hp);
     s.wpack = c.precision ? carve(cur, mfm_lstm_pack_bytes(s.h, 0) / 4) : -1;
-    P->dh_last[e] = carve(cur, (int64_t)c.B * eh[e]);
+    if (e < 4) P->dh_last[e] = -1;
+    if (e < 3 || V == 0) P->dh_last[e] = carve(cur, (int64_t)c.B * P->enc_h[e]);
+    if (V != 0 && e >= 3) P->dcx[e - 3] = carve(cur, TB * s.Hp);
   }
   for (int m = 0; m < 3; ++m) {
-    P->dec_d[m] = dd[m]; P->dec_h[m] = c.fy + fm[m]; P->dec_p[m] = dp[m]; P->dec_xoff[m] = ex[m];
+    P->dec_d[m] = dd[m]; P->dec_h[m] = c.fy + fm[m]; P->dec_p[m] = pi.dec[m]; P->dec_xoff[m] = dx[m];
     SeqBuf& s = P->dec[m];
     s.h = P->dec_h[m]; s.Hp = round_up(s.h, 16);
     s.gates = carve(cur, TB * 4 * s.Hp);
@@ -125,6 +180,29 @@ static int build(MfmPlan* P) {
     P->xhat[m] = carve(cur, TB * dd[m]);
     P->dxhat[m] = carve(cur, TB * dd[m]);
   }
+  // ---- Memory Fusion Network (variants 1, 2): every [T*B, .] tensor of the attention block and the memory recurrence
+  P->tot = P->A2 = P->nzy = 0;
+  if (V != 0) {
+    P->tot = c.hl + c.ha + c.hv; P->A2 = 2 * P->tot;
+    P->nzy = (V == 1) ? 2 * c.zy : c.zy;          // [mu_y | logvar_y] or z_y: the latent stack's fourth input
+    const int M = c.mem_dim;
+    P->cstar = carve(cur, TB * P->A2); P->att = carve(cur, TB * P->A2); P->attended = carve(cur, TB * P->A2);
+    P->h1 = carve(cur, TB * c.nn1); P->m1 = carve(cur, TB * c.nn1);
+    P->h2 = carve(cur, TB * c.nn2); P->m2 = carve(cur, TB * c.nn2);
+    P->chat = carve(cur, TB * M);
+    P->a1 = carve(cur, TB * c.g1); P->a2 = carve(cur, TB * c.g2);
+    P->gam1 = carve(cur, TB * M); P->gam2 = carve(cur, TB * M); P->mems = carve(cur, TB * M);
+    P->mem_out = carve(cur, (int64_t)c.B * M);
+    P->zero_blk = cur;
+    P->zyin = carve(cur, (int64_t)c.B * P->nzy);
+    P->d_hT = carve(cur, (int64_t)c.B * P->tot);
+    P->dmem = carve(cur, (int64_t)c.B * M);
+    P->datt = carve(cur, TB * P->A2);
+    P->zero_len = cur - P->zero_blk;               // carve() keeps 64-float granules: a multiple of 4
+    P->du1 = carve(cur, TB * c.g1); P->du2 = carve(cur, TB * c.g2); P->dchat = carve(cur, TB * M);
+    P->dh2 = carve(cur, TB * c.nn2); P->dlog = carve(cur, TB * P->A2); P->dh1 = carve(cur, TB * c.nn1);
+    P->dcs = carve(cur, TB * P->A2);
+  }
   // ---- latent record layout (every segment starts on a multiple of 4 floats)
   LatentDev& L = P->lat;
   memset(&L, 0, sizeof(L));
@@ -132,43 +210,62 @@ static int build(MfmPlan* P) {
   auto seg = [&](int n) { const int at = rs; rs += round_up(n, 4); return at; };
   const int zn[4] = {c.zl, c.za, c.zv, c.zy};
   const int fn[4] = {c.fl, c.fa, c.fv, c.fy};
+  // inputs of the stack: last hidden state of the modality encoders, and for y the early-fusion encoder's
+  // (variant 0) or the precomputed heads on the MFN output (variants 1, 2: [mu_y | logvar_y] / z_y)
+  const int in_n[4] = {c.zl, c.za, c.zv, V == 0 ? ze : P->nzy};
   int last_off[4], f1_off[4], m1_off[4];
-  for (int e = 0; e < 4; ++e) { L.in_off[e] = seg(eh[e]); L.enc_n[e] = eh[e]; }
-  for (int e = 0; e < 4; ++e) last_off[e] = seg(eh[e]);
-  for (int e = 0; e < 4; ++e) { L.mu_off[e] = seg(zn[e]); L.z_n[e] = zn[e]; }
-  for (int e = 0; e < 4; ++e) L.lv_off[e] = seg(zn[e]);
+  for (int e = 0; e < 4; ++e) { L.in_off[e] = seg(in_n[e]); L.enc_n[e] = in_n[e]; }
+  const int nfc = (V == 0) ? 4 : 3;                 // encoder fc1 heads inside the stack
+  for (int e = 0; e < 4; ++e) last_off[e] = (e < nfc) ? seg(in_n[e]) : -1;
+  for (int e = 0; e < 4; ++e) {
+    L.z_n[e] = zn[e];
+    if (V == 2) L.mu_off[e] = (e < 3) ? last_off[e] : L.in_off[3];          // z = the encoder output itself
+    else if (V == 1 && e == 3) L.mu_off[e] = L.in_off[3];
+    else L.mu_off[e] = seg(zn[e]);
+  }
+  for (int e = 0; e < 4; ++e) {
+    if (V == 2) L.lv_off[e] = 0;
+    else if (V == 1 && e == 3) L.lv_off[e] = L.in_off[3] + c.zy;
+    else L.lv_off[e] = seg(zn[e]);
+  }
   for (int e = 0; e < 4; ++e) { f1_off[e] = seg(fn[e]); m1_off[e] = seg(fn[e]); }
   for (int e = 0; e < 4; ++e) { L.f_off[e] = seg(fn[e]); L.f_n[e] = fn[e]; }
   const int c1_off = seg(c.fy), mc_off = seg(c.fy);
   L.yhat_off = seg(c.output_dim); L.od = c.output_dim;
   L.rec_size = rs;
-  for (int e = 0; e < 4; ++e) { P->lay_f1[e] = f1_off[e]; P->lay_m1[e] = m1_off[e]; }
+  for (int e = 0; e < 4; ++e) { P->lay_f1[e] = f1_off[e]; P->lay_m1[e] = m1_off[e]; P->z_seg[e] = L.mu_off[e]; }
   P->lay_c1 = c1_off; P->lay_mc = mc_off;
   const int64_t* o = P->off;
-  // stage 0: encoder fc1 (mfm_model.py:60-61)
-  for (int e = 0; e < 4; ++e)
-    add_op(P->lat_ops, L, 0, L.in_off[e], last_off[e], eh[e], eh[e], o[ep[e] + FC_W], o[ep[e] + FC_B], 0, -1, 0.f);
-  // stage 1: mu heads (mfm_model.py:630-639).  The logvar heads only feed the KLD, nothing downstream waits
-  // for them, so they ride along with the classifier's first layer in stage 4 (the row kernels give every
+  int st = 0;
+  // encoder fc1 (mfm_model.py:60-61)
+  for (int e = 0; e < nfc; ++e)
+    add_op(P->lat_ops, L, st, L.in_off[e], last_off[e], in_n[e], in_n[e], o[pi.enc[e] + FC_W], o[pi.enc[e] + FC_B], 0, -1, 0.f);
+  ++st;
+  // mu heads (mfm_model.py:630-639 / 737-744).  The logvar heads only feed the KLD, nothing downstream waits
+  // for them, so they ride along with the classifier's first layer (the row kernels give every
   // thread one work item per stage: 4*(16+152) output quads and 4*(16+240)/4 input groups still fit 1024).
-  const int pmu[4] = {P_TO_ZL, P_TO_ZA, P_TO_ZV, P_TO_ZY};
-  const int plv[4] = {P_TO_LVL, P_TO_LVA, P_TO_LVV, P_TO_LVY};
-  for (int e = 0; e < 4; ++e)
-    add_op(P->lat_ops, L, 1, last_off[e], L.mu_off[e], eh[e], zn[e], o[pmu[e]], o[pmu[e] + 1], 0, -1, 0.f);
-  // stages 2, 3: z -> f MLPs (mfm_model.py:644-647)
-  const int pf1[4] = {P_ZL_F1, P_ZA_F1, P_ZV_F1, P_ZY_F1};
-  const int pf2[4] = {P_ZL_F2, P_ZA_F2, P_ZV_F2, P_ZY_F2};
+  if (V != 2) {
+    for (int e = 0; e < nfc; ++e)
+      add_op(P->lat_ops, L, st, last_off[e], L.mu_off[e], in_n[e], zn[e], o[pi.to_z[e]], o[pi.to_z[e] + 1], 0, -1, 0.f);
+    ++st;
+  }
+  // z -> f MLPs (mfm_model.py:644-647)
   const float pd[4] = {c.drop_zl, c.drop_za, c.drop_zv, c.drop_zy};
   for (int e = 0; e < 4; ++e)
-    add_op(P->lat_ops, L, 2, L.mu_off[e], f1_off[e], zn[e], fn[e], o[pf1[e]], o[pf1[e] + 1], 1, m1_off[e], pd[e]);
+    add_op(P->lat_ops, L, st, L.mu_off[e], f1_off[e], zn[e], fn[e], o[pi.zf1[e]], o[pi.zf1[e] + 1], 1, m1_off[e], pd[e]);
+  ++st;
   for (int e = 0; e < 4; ++e)
-    add_op(P->lat_ops, L, 3, f1_off[e], L.f_off[e], fn[e], fn[e], o[pf2[e]], o[pf2[e] + 1], 1, -1, 0.f);
-  // stages 4, 5: classifier (mfm_model.py:657); stage 4 also carries the logvar heads
-  add_op(P->lat_ops, L, 4, L.f_off[3], c1_off, c.fy, c.fy, o[P_Y_F1], o[P_Y_F1 + 1], 1, mc_off, c.drop_y);
-  for (int e = 0; e < 4; ++e)
-    add_op(P->lat_ops, L, 4, last_off[e], L.lv_off[e], eh[e], zn[e], o[plv[e]], o[plv[e] + 1], 0, -1, 0.f);
-  add_op(P->lat_ops, L, 5, c1_off, L.yhat_off, c.fy, c.output_dim, o[P_Y_F2], o[P_Y_F2 + 1], 0, -1, 0.f);
-  L.nstages = 6;
+    add_op(P->lat_ops, L, st, f1_off[e], L.f_off[e], fn[e], fn[e], o[pi.zf2[e]], o[pi.zf2[e] + 1], 1, -1, 0.f);
+  ++st;
+  // classifier (mfm_model.py:657); its first stage also carries the logvar heads
+  add_op(P->lat_ops, L, st, L.f_off[3], c1_off, c.fy, c.fy, o[pi.y_f1], o[pi.y_f1 + 1], 1, mc_off, c.drop_y);
+  if (V != 2)
+    for (int e = 0; e < nfc; ++e)
+      add_op(P->lat_ops, L, st, last_off[e], L.lv_off[e], in_n[e], zn[e], o[pi.to_lv[e]], o[pi.to_lv[e] + 1], 0, -1, 0.f);
+  ++st;
+  add_op(P->lat_ops, L, st, c1_off, L.yhat_off, c.fy, c.output_dim, o[pi.y_f2], o[pi.y_f2 + 1], 0, -1, 0.f);
+  ++st;
+  L.nstages = st;
   {
     int s = 0;
     L.stage_begin[0] = 0;
@@ -183,7 +280,7 @@ static int build(MfmPlan* P) {
       }
     }
   }
-  L.has_logvar = 1;
+  L.has_logvar = (V != 2) ? 1 : 0;
   L.B = c.B;
   L.loss_kind = c.loss_kind;
   // LDS weight panel: the tensors of one stage are expected to be contiguous in the flat buffer
@@ -219,6 +316,7 @@ static int build(MfmPlan* P) {
   {
     const int row_maxb = getenv("MFM_LATENT_ROW_MAXB") ? atoi(getenv("MFM_LATENT_ROW_MAXB")) : 256;   // tuning override
     bool ok = c.B <= row_maxb && (size_t)2 * rs * sizeof(float) <= 24 * 1024 && P->n_params < (1ll << 31);
+    ok = ok && (in_n[0] + in_n[1] + in_n[2] + in_n[3] <= MFM_LAT_ROW_THREADS);     // prologue: one input element per thread
     for (int i = 0; i < L.nops && ok; ++i) {
       const LatOp& op = P->lat_ops[i];
       ok = (op.K % 4 == 0) && op.K >= 4 && op.K <= 128 && op.N <= 128 && (op.w_off % 4 == 0);
@@ -291,6 +389,8 @@ static int build(MfmPlan* P) {
   P->lat_items_off = carve(cur, (int64_t)P->lat_items.size());
   P->lat_grd = carve(cur, (int64_t)c.B * rs);
   P->lat_rec = carve(cur, (int64_t)c.B * rs);
+  P->lat_seed = (V == 2) ? carve(cur, (int64_t)c.B * rs) : -1;
+  if (V != 0) P->dh_last[3] = carve(cur, (int64_t)c.B * P->nzy);     // d loss / d [mu_y | logvar_y] (or z_y)
   P->yhat = carve(cur, (int64_t)c.B * c.output_dim);
   P->ones = carve(cur, TB);
   P->losses = carve(cur, MFM_LOSS_SLOTS);
@@ -335,14 +435,113 @@ static MfmSeqDesc seq_desc(const MfmPlan* P, const SeqBuf& sb, int pbase, const 
   return d;
 }
 
+// element offset helpers
+static inline const float* PW(const MfmPlan* P, const float* params, int idx) { return params + P->off[idx]; }
+
+// ---- Memory Fusion Network, forward (reference mfm_model.py:140-199 restructured, see mfn_att.hip / mfn_mem.hip):
+// cStar gather -> att1_fc1 (+relu/dropout) -> att1_fc2 -> softmax * cStar -> {att2_fc1 (+relu/dropout), attended part
+// of gamma1_fc1 / gamma2_fc1} -> att2_fc2 (+tanh) -> memory recurrence -> heads on [h_l, h_a, h_v, mem]
+static int mfn_forward(MfmPlan* P, const float* params, int train, uint64_t seed, float* W, hipStream_t s) {
+  const MfmPlanConfig& c = P->cfg;
+  const PIdx& pi = P->pi;
+  const int T = P->T, B = P->B, M = c.mem_dim, A2 = P->A2;
+  const int64_t TB = (int64_t)T * B;
+  const int prec = c.precision;
+  MfnCs cs;
+  memset(&cs, 0, sizeof(cs));
+  for (int m = 0; m < 3; ++m) { cs.cs[m] = W + P->enc[3 + m].cs; cs.h[m] = P->enc[3 + m].h; }
+  cs.T = T; cs.B = B;
+  RUN(K_MFN_GLUE, mfn_cstar_launch(cs, W + P->cstar, s));
+  auto lin = [&](const float* a, int lda, int k, int widx, int n, float* cout, int ldc, int ldw) {
+    MfmGemmDesc d;
+    memset(&d, 0, sizeof(d));
+    d.a = a; d.a_sm = lda; d.a_sk = 1;
+    d.b = PW(P, params, widx); d.b_sn = ldw; d.b_sk = 1;
+    d.c = cout; d.ldc = ldc; d.bias = PW(P, params, widx + 1);
+    d.m = (int)TB; d.n = n; d.n_valid = n; d.k = k; d.batch = 1; d.split_k = 1; d.alpha = 1.0f;
+    return d;
+  };
+  GemmEpiSet es;
+  memset(&es, 0, sizeof(es));
+  es.seed = seed * 0x9E3779B97F4A7C15ull + P->calls; es.train = train;
+  {   // h1 = drop(relu(att1_fc1(cStar)))
+    MfmGemmDesc g = lin(W + P->cstar, A2, A2, pi.att1_1, c.nn1, W + P->h1, c.nn1, A2);
+    GemmEpi e = {W + P->m1, c.drop_nn1, 1, 101u, 0};
+    es.epi = &e; es.count = 1;
+    RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
+  }
+  {   // logits = att1_fc2(h1)
+    MfmGemmDesc g = lin(W + P->h1, c.nn1, c.nn1, pi.att1_2, A2, W + P->att, A2, c.nn1);
+    RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec));
+  }
+  RUN(K_MFN_GLUE, mfn_softmax_fwd_launch(W + P->att, W + P->cstar, W + P->attended, TB, A2, s));
+  {   // h2 = drop(relu(att2_fc1(attended))) ; a_n = gamma_n_fc1[:, :A2] attended + b   (the memory columns: mfn_mem)
+    MfmGemmDesc g[3];
+    g[0] = lin(W + P->attended, A2, A2, pi.att2_1, c.nn2, W + P->h2, c.nn2, A2);
+    g[1] = lin(W + P->attended, A2, A2, pi.g1_1, c.g1, W + P->a1, c.g1, A2 + M);
+    g[2] = lin(W + P->attended, A2, A2, pi.g2_1, c.g2, W + P->a2, c.g2, A2 + M);
+    GemmEpi e = {W + P->m2, c.drop_nn2, 1, 102u, 0};
+    es.epi = &e; es.count = 1;
+    RUN(K_MFN_ATT_FWD, gemm_group_launch(g, 3, s, nullptr, nullptr, 0, prec, &es));
+  }
+  {   // cHat = tanh(att2_fc2(h2))
+    MfmGemmDesc g = lin(W + P->h2, c.nn2, c.nn2, pi.att2_2, M, W + P->chat, M, c.nn2);
+    GemmEpi e = {nullptr, 0.0f, 2, 0u, 0};
+    es.epi = &e; es.count = 1;
+    RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
+  }
+  {   // gamma gates + memory update for all T (mfm_model.py:177-181)
+    MfmMemDesc md;
+    memset(&md, 0, sizeof(md));
+    md.a1 = W + P->a1; md.a2 = W + P->a2; md.chat = W + P->chat;
+    md.w1m = PW(P, params, pi.g1_1) + A2; md.w2m = PW(P, params, pi.g2_1) + A2; md.ld_wm = A2 + M;
+    md.w1b = PW(P, params, pi.g1_2); md.b1b = PW(P, params, pi.g1_2 + 1);
+    md.w2b = PW(P, params, pi.g2_2); md.b2b = PW(P, params, pi.g2_2 + 1);
+    md.gam1 = W + P->gam1; md.gam2 = W + P->gam2; md.mems = W + P->mems; md.mem_out = W + P->mem_out;
+    md.T = T; md.B = B; md.M = M; md.H1 = c.g1; md.H2 = c.g2; md.train = train;
+    md.p1 = c.drop_g1; md.p2 = c.drop_g2; md.seed = es.seed ^ 0x5DEECE66Dull;
+    RUN(K_MFN_MEM_FWD, mfm_mfn_mem_fwd(&md, s));
+  }
+  {   // heads on mfn_last = [h_l(T-1), h_a(T-1), h_v(T-1), mem]: mu_y (and logvar_y), summed over the four segments
+    // into the zero-filled latent input (accumulating problems; the bias rides on the first segment)
+    MfmGemmDesc g[8];
+    int n = 0;
+    const int nheads = (c.variant == 1) ? 2 : 1;
+    for (int hd = 0; hd < nheads; ++hd) {
+      const int widx = hd == 0 ? pi.to_z[3] : pi.to_lv[3];
+      int koff = 0;
+      for (int sg = 0; sg < 4; ++sg) {
+        const SeqBuf* sb = sg < 3 ? &P->enc[3 + sg] : nullptr;
+        MfmGemmDesc d;
+        memset(&d, 0, sizeof(d));
+        d.a = sb ? W + sb->hs + (int64_t)(T - 1) * B * sb->Hp : W + P->mem_out;
+        d.a_sm = sb ? sb->Hp : M; d.a_sk = 1;
+        const int k = sb ? sb->h : M;
+        d.b = PW(P, params, widx) + koff; d.b_sn = P->tot + M; d.b_sk = 1;
+        d.c = W + P->zyin + hd * c.zy; d.ldc = P->nzy;
+        if (sg == 0) d.bias = PW(P, params, widx + 1);
+        d.m = B; d.n = c.zy; d.n_valid = c.zy; d.k = k; d.batch = 1; d.split_k = 1; d.accumulate = 1; d.alpha = 1.0f;
+        g[n++] = d;
+        koff += k;
+      }
+    }
+    RUN(K_MFN_HEADS, gemm_group_launch(g, n, s, nullptr, nullptr, 0, prec));
+  }
+  return MFM_OK;
+}
+
 static int forward(MfmPlan* P, const float* params, const float* x, const void* y, int train, uint64_t seed,
                    float* W, float* xhat_out[3], float* yhat_out, float* losses_out, hipStream_t s,
                    float* grads_to_zero = nullptr) {
   const MfmPlanConfig& c = P->cfg;
+  const PIdx& pi = P->pi;
+  const int V = c.variant;
   const int T = P->T, B = P->B;
   const int64_t TB = (int64_t)T * B;
   float* losses = losses_out ? losses_out : W + P->losses;
-  // the loss slots (and, in the fused step, the gradient buffer) are cleared by the first GEMM launch
+  if (V == 2) MFM_REQUIRE(P->gauss, "plan (MFM / MMD variant): call mfm_plan_set_gauss before the forward");
+  // the loss slots (and, in the fused step, the gradient buffer; variants 1, 2: the MFN's accumulation targets)
+  // are cleared by the first GEMM launch
   ZeroSpans zs;
   memset(&zs, 0, sizeof(zs));
   if ((((uintptr_t)losses) & 15) == 0) { zs.ptr[0] = losses; zs.n[0] = MFM_LOSS_SLOTS; }
@@ -352,22 +551,24 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     zs.ptr[1] = grads_to_zero; zs.n[1] = P->n_params;
     P->grads_prezeroed = grads_to_zero;
   }
+  if (V != 0) { zs.ptr[2] = W + P->zero_blk; zs.n[2] = P->zero_len; }
   P->calls++;
 
   // bf16 plans: the recurrences' weight fragments, rounded and packed once per step (lstm_seq_bf16.hip)
   const bool seq_bf16 = c.precision && bf16_seq_pays(B);
   if (seq_bf16) {
-    MfmSeqDesc q[7];
-    for (int e = 0; e < 4; ++e) q[e] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
-    for (int m = 0; m < 3; ++m) q[4 + m] = seq_desc(P, P->dec[m], P->dec_p[m], params, W, true);
-    RUN(K_PACK, mfm_lstm_pack_bf16(q, 7, s));
+    MfmSeqDesc q[9];
+    int n = 0;
+    for (int e = 0; e < P->n_enc; ++e) q[n++] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
+    for (int m = 0; m < 3; ++m) q[n++] = seq_desc(P, P->dec[m], P->dec_p[m], params, W, true);
+    RUN(K_PACK, mfm_lstm_pack_bf16(q, n, s));
   }
 
   // F0: input projections
   {
-    MfmGemmDesc g[4];
+    MfmGemmDesc g[6];
     memset(g, 0, sizeof(g));
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < P->n_enc; ++e) {
       const SeqBuf& sb = P->enc[e];
       const int pb = P->enc_p[e];
       MfmGemmDesc& d = g[e];
@@ -378,13 +579,18 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       d.m = (int)TB; d.n = sb.Hp; d.n_valid = sb.h; d.k = P->enc_d[e]; d.batch = 4; d.split_k = 1;
       d.alpha = 1.0f;
     }
-    RUN(K_PROJ, gemm_group_launch(g, 4, s, &zs, nullptr, 0, c.precision));
+    RUN(K_PROJ, gemm_group_launch(g, P->n_enc, s, &zs, nullptr, 0, c.precision));
   }
-  // F1: encoder recurrences
-  {
-    MfmSeqDesc q[4];
-    for (int e = 0; e < 4; ++e) q[e] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
-    RUN(K_ENC_FWD, seq_bf16 ? mfm_lstm_seq_fwd_bf16(q, 4, T, B, s) : mfm_lstm_seq_fwd(q, 4, T, B, s));
+  // F1: encoder recurrences (up to MFM_MAX_SEQ per launch)
+  for (int e0 = 0; e0 < P->n_enc; e0 += MFM_MAX_SEQ) {
+    MfmSeqDesc q[MFM_MAX_SEQ];
+    const int n = std::min(MFM_MAX_SEQ, P->n_enc - e0);
+    for (int e = 0; e < n; ++e) q[e] = seq_desc(P, P->enc[e0 + e], P->enc_p[e0 + e], params, W, false);
+    RUN(K_ENC_FWD, seq_bf16 ? mfm_lstm_seq_fwd_bf16(q, n, T, B, s) : mfm_lstm_seq_fwd(q, n, T, B, s));
+  }
+  if (V != 0) {
+    int rc = mfn_forward(P, params, train, seed, W, s);
+    if (rc != MFM_OK) return rc;
   }
   // F2: latent stack
   {
@@ -394,6 +600,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     L.items_bwd = L.items_fwd + (size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
     if (getenv("MFM_LATENT_DBG")) L.dbg = reinterpret_cast<unsigned long long*>(W + P->dbg_off);
     for (int e = 0; e < 4; ++e) {
+      if (e == 3 && V != 0) { L.enc_h[e] = W + P->zyin; L.enc_ld[e] = P->nzy; continue; }
       L.enc_h[e] = W + P->enc[e].hs + (int64_t)(T - 1) * B * P->enc[e].Hp;
       L.enc_ld[e] = P->enc[e].Hp;
     }
@@ -403,6 +610,19 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     L.y = y; L.losses = losses; L.train = train;
     L.seed = seed * 0x9E3779B97F4A7C15ull + P->calls;
     RUN(K_LAT_FWD, latent_fwd_launch(L, params, s));
+  }
+  // MMD regulariser of the non-KL MFM on z_l, z_a, z_v, z_y (mfm_model.py:540-541): value into the reg slot, its
+  // gradient (times lda_mmd) into the latent backward's seed record
+  if (V == 2) {
+    const int rs = P->lat.rec_size;
+    const int zn[4] = {c.zl, c.za, c.zv, c.zy};
+    const int gl = c.zl + c.za + c.zv + c.zy;
+    int goff = 0;
+    for (int e = 0; e < 4; ++e) {
+      RUN(K_MMD, mmd_launch(W + P->lat_rec + P->z_seg[e], rs, P->gauss + goff, gl, B, zn[e], losses + 4,
+                            W + P->lat_seed + P->z_seg[e], rs, c.lda_reg, s));
+      goff += zn[e];
+    }
   }
   // F3: decoder recurrences
   {
@@ -443,6 +663,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     }
     RUN(K_FC1_FWD, gemm_group_launch(g, 3, s, nullptr, me, 3, c.precision));
   }
+  (void)pi;
   return MFM_OK;
 }
 
@@ -491,11 +712,131 @@ struct ExtGrads {           // upstream gradients supplied by the caller (autogr
   const float* d_reg;       // device scalar
 };
 
+// ---- Memory Fusion Network, backward.  Appends the MFN's weight-gradient products to `tail`.
+static int mfn_backward(MfmPlan* P, const float* params, float* W, float* grads, hipStream_t s,
+                        std::vector<MfmGemmDesc>& tail) {
+  const MfmPlanConfig& c = P->cfg;
+  const PIdx& pi = P->pi;
+  const int T = P->T, B = P->B, M = c.mem_dim, A2 = P->A2, tot = P->tot;
+  const int64_t TB = (int64_t)T * B;
+  const int prec = c.precision;
+  // TN product for a weight gradient: C[m][n] (+)= sum_r A[r][m] B[r][n] over `rows` rows
+  auto tn = [&](const float* a, int lda, int m, const float* b, int ldb, int n, float* cc, int ldc, int64_t rows) {
+    MfmGemmDesc d;
+    memset(&d, 0, sizeof(d));
+    d.alpha = 1.0f; d.batch = 1; d.accumulate = 1; d.split_k = 0;
+    d.a = a; d.a_sm = 1; d.a_sk = lda;
+    d.b = b; d.b_sk = ldb; d.b_sn = 1;
+    d.c = cc; d.ldc = ldc; d.m = m; d.n = n; d.n_valid = n; d.k = (int)rows;
+    tail.push_back(d);
+  };
+  auto colsum = [&](const float* a, int lda, int m, float* cc, int64_t rows) { tn(a, lda, m, W + P->ones, 1, 1, cc, 1, rows); };
+  // NN product: C[r][n] = sum_k A[r][k] Wt[k][n], Wt = a [K, N] row-major block with row stride ldw
+  auto nn = [&](const float* a, int lda, int k, const float* wt, int ldw, int n, float* cc, int ldc, int64_t rows, int acc) {
+    MfmGemmDesc d;
+    memset(&d, 0, sizeof(d));
+    d.alpha = 1.0f; d.batch = 1; d.split_k = 1; d.accumulate = acc;
+    d.a = a; d.a_sm = lda; d.a_sk = 1;
+    d.b = wt; d.b_sk = ldw; d.b_sn = 1;
+    d.c = cc; d.ldc = ldc; d.m = (int)rows; d.n = n; d.n_valid = n; d.k = k;
+    return d;
+  };
+  GemmEpiSet es;
+  memset(&es, 0, sizeof(es));
+  const int nheads = (c.variant == 1) ? 2 : 1;
+  {   // through the heads on mfn_last: d h_T of the three MFN LSTMs and d mem_T (accumulated over the heads)
+    MfmGemmDesc g[4];
+    int n = 0;
+    for (int hd = 0; hd < nheads; ++hd) {
+      const int widx = hd == 0 ? pi.to_z[3] : pi.to_lv[3];
+      const float* dz = W + P->dh_last[3] + hd * c.zy;
+      g[n++] = nn(dz, P->nzy, c.zy, PW(P, params, widx), tot + M, tot, W + P->d_hT, tot, B, 1);
+      g[n++] = nn(dz, P->nzy, c.zy, PW(P, params, widx) + tot, tot + M, M, W + P->dmem, M, B, 1);
+      // dW_head[:, segment] = dz^T segment ; db = column sums of dz
+      int koff = 0;
+      for (int sg = 0; sg < 4; ++sg) {
+        const SeqBuf* sb = sg < 3 ? &P->enc[3 + sg] : nullptr;
+        const float* seg = sb ? W + sb->hs + (int64_t)(T - 1) * B * sb->Hp : W + P->mem_out;
+        const int k = sb ? sb->h : M;
+        tn(dz, P->nzy, c.zy, seg, sb ? sb->Hp : M, k, grads + P->off[widx] + koff, tot + M, B);
+        koff += k;
+      }
+      colsum(dz, P->nzy, c.zy, grads + P->off[widx + 1], B);
+    }
+    RUN(K_MFN_HEADS, gemm_group_launch(g, n, s, nullptr, nullptr, 0, prec));
+  }
+  {   // memory recurrence BPTT: dz_n (in gam_n), du_n, d(pre-tanh cHat)
+    MfmMemDesc md;
+    memset(&md, 0, sizeof(md));
+    md.a1 = W + P->a1; md.a2 = W + P->a2; md.chat = W + P->chat;
+    md.w1m = PW(P, params, pi.g1_1) + A2; md.w2m = PW(P, params, pi.g2_1) + A2; md.ld_wm = A2 + M;
+    md.w1b = PW(P, params, pi.g1_2); md.b1b = PW(P, params, pi.g1_2 + 1);
+    md.w2b = PW(P, params, pi.g2_2); md.b2b = PW(P, params, pi.g2_2 + 1);
+    md.gam1 = W + P->gam1; md.gam2 = W + P->gam2; md.mems = W + P->mems;
+    md.dmem_out = W + P->dmem; md.du1 = W + P->du1; md.du2 = W + P->du2; md.dchat = W + P->dchat;
+    md.dchat_pre_tanh = 1;
+    md.T = T; md.B = B; md.M = M; md.H1 = c.g1; md.H2 = c.g2; md.train = 1;
+    md.p1 = c.drop_g1; md.p2 = c.drop_g2;
+    RUN(K_MFN_MEM_BWD, mfm_mfn_mem_bwd(&md, s));
+  }
+  {   // dh2 = d(pre cHat) W_att2_fc2, times the relu / dropout mask of att2_fc1's output
+    MfmGemmDesc g = nn(W + P->dchat, M, M, PW(P, params, pi.att2_2), c.nn2, c.nn2, W + P->dh2, c.nn2, TB, 0);
+    GemmEpi e = {W + P->m2, 0.0f, 3, 0u, 0};
+    es.epi = &e; es.count = 1;
+    RUN(K_MFN_ATT_BWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
+  }
+  {   // d attended = dh2 W_att2_fc1 + du1 W_gamma1_fc1[:, :A2] + du2 W_gamma2_fc1[:, :A2]   (into the zero-filled buffer)
+    MfmGemmDesc g[3];
+    g[0] = nn(W + P->dh2, c.nn2, c.nn2, PW(P, params, pi.att2_1), A2, A2, W + P->datt, A2, TB, 1);
+    g[1] = nn(W + P->du1, c.g1, c.g1, PW(P, params, pi.g1_1), A2 + M, A2, W + P->datt, A2, TB, 1);
+    g[2] = nn(W + P->du2, c.g2, c.g2, PW(P, params, pi.g2_1), A2 + M, A2, W + P->datt, A2, TB, 1);
+    RUN(K_MFN_ATT_BWD, gemm_group_launch(g, 3, s, nullptr, nullptr, 0, prec));
+  }
+  RUN(K_MFN_GLUE, mfn_softmax_bwd_launch(W + P->datt, W + P->att, W + P->cstar, W + P->dlog, W + P->dcs, TB, A2, s));
+  {   // dh1 = d logits W_att1_fc2, times the mask of att1_fc1's output
+    MfmGemmDesc g = nn(W + P->dlog, A2, A2, PW(P, params, pi.att1_2), c.nn1, c.nn1, W + P->dh1, c.nn1, TB, 0);
+    GemmEpi e = {W + P->m1, 0.0f, 3, 0u, 0};
+    es.epi = &e; es.count = 1;
+    RUN(K_MFN_ATT_BWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
+  }
+  {   // d cStar += dh1 W_att1_fc1   (on top of the softmax kernel's d attended * attention)
+    MfmGemmDesc g = nn(W + P->dh1, c.nn1, c.nn1, PW(P, params, pi.att1_1), A2, A2, W + P->dcs, A2, TB, 1);
+    RUN(K_MFN_ATT_BWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec));
+  }
+  {   // d cStar -> d c_t of the three LSTMs
+    MfnCs cs;
+    memset(&cs, 0, sizeof(cs));
+    for (int m = 0; m < 3; ++m) { cs.dcx[m] = W + P->dcx[m]; cs.h[m] = P->enc[3 + m].h; }
+    cs.T = T; cs.B = B;
+    RUN(K_MFN_GLUE, mfn_dcs_scatter_launch(cs, W + P->dcs, s));
+  }
+  // ---- weight gradients of the MFN Linears (sums over all T*B rows; biases = column sums)
+  float* G = grads;
+  const int64_t* o = P->off;
+  tn(W + P->dh1, c.nn1, c.nn1, W + P->cstar, A2, A2, G + o[pi.att1_1], A2, TB);       colsum(W + P->dh1, c.nn1, c.nn1, G + o[pi.att1_1 + 1], TB);
+  tn(W + P->dlog, A2, A2, W + P->h1, c.nn1, c.nn1, G + o[pi.att1_2], c.nn1, TB);      colsum(W + P->dlog, A2, A2, G + o[pi.att1_2 + 1], TB);
+  tn(W + P->dh2, c.nn2, c.nn2, W + P->attended, A2, A2, G + o[pi.att2_1], A2, TB);    colsum(W + P->dh2, c.nn2, c.nn2, G + o[pi.att2_1 + 1], TB);
+  tn(W + P->dchat, M, M, W + P->h2, c.nn2, c.nn2, G + o[pi.att2_2], c.nn2, TB);       colsum(W + P->dchat, M, M, G + o[pi.att2_2 + 1], TB);
+  const int64_t du[2] = {P->du1, P->du2}, dzb[2] = {P->gam1, P->gam2}, ab[2] = {P->a1, P->a2};
+  const int gw[2] = {c.g1, c.g2}, gi1[2] = {pi.g1_1, pi.g2_1}, gi2[2] = {pi.g1_2, pi.g2_2};
+  for (int n = 0; n < 2; ++n) {
+    // gamma_n_fc1 = [attended columns | memory columns]: the memory part multiplies mem_{t-1} (zero at t = 0)
+    tn(W + du[n], gw[n], gw[n], W + P->attended, A2, A2, G + o[gi1[n]], A2 + M, TB);
+    if (T > 1) tn(W + du[n] + (int64_t)B * gw[n], gw[n], gw[n], W + P->mems, M, M, G + o[gi1[n]] + A2, A2 + M, TB - B);
+    colsum(W + du[n], gw[n], gw[n], G + o[gi1[n] + 1], TB);
+    tn(W + dzb[n], M, M, W + ab[n], gw[n], gw[n], G + o[gi2[n]], gw[n], TB);           colsum(W + dzb[n], M, M, G + o[gi2[n] + 1], TB);
+  }
+  return MFM_OK;
+}
+
 static int backward(MfmPlan* P, const float* params, const float* x, const void* y, int stage, float* W,
                     float* grads, hipStream_t s, const ExtGrads* ext = nullptr) {
   const MfmPlanConfig& c = P->cfg;
+  const int V = c.variant;
   const int T = P->T, B = P->B;
   const int64_t TB = (int64_t)T * B;
+  MFM_REQUIRE(!(ext && V == 2), "plan (MFM / MMD variant): backward for external upstream gradients is not available "
+                                "(the regulariser's gradient is formed inside the plan)");
   if (P->grads_prezeroed != grads) MFM_HIP_CHECK(hipMemsetAsync(grads, 0, (size_t)P->n_params * sizeof(float), s));
   P->grads_prezeroed = nullptr;
   const bool gen_on = (stage != 2), disc_on = (stage != 1);
@@ -559,10 +900,14 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       L.d_dec_init[m] = gen_on ? W + P->dec_dinit[m] : nullptr;
       L.dec_ld[m] = P->dec_h[m];
     }
-    for (int e = 0; e < 4; ++e) { L.dh_last[e] = W + P->dh_last[e]; L.dh_ld[e] = P->enc_h[e]; }
+    for (int e = 0; e < 4; ++e) {
+      L.dh_last[e] = W + P->dh_last[e];
+      L.dh_ld[e] = (e == 3 && V != 0) ? P->nzy : P->enc_h[e];
+    }
     L.rec = W + P->lat_rec;
     L.y = y;
     L.grd_out = W + P->lat_grd;
+    if (V == 2) L.grd_seed = W + P->lat_seed;        // d (lda_mmd * MMD) / d z, written by the forward
     if (ext) { L.d_yhat_ext = ext->d_yhat; L.reg_w_ptr = ext->d_reg; }
     L.reg_w = c.lda_reg * c.reg_scale;
     L.disc_w = disc_on ? 1.0f : 0.0f;
@@ -582,18 +927,32 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       tail.push_back(d);
     }
   }
-  // B4: encoder BPTT
-  {
-    MfmSeqDesc q[4];
-    for (int e = 0; e < 4; ++e) {
-      q[e] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
-      q[e].dh_ext = W + P->dh_last[e]; q[e].ld_dh = P->enc_h[e];
+  // Memory Fusion Network (variants 1, 2): from d [mu_y | logvar_y] back to d h_T / d c_t of its three LSTMs
+  if (V != 0) {
+    int rc = mfn_backward(P, params, W, grads, s, tail);
+    if (rc != MFM_OK) return rc;
+  }
+  // B4: encoder BPTT (up to MFM_MAX_SEQ per launch)
+  for (int e0 = 0; e0 < P->n_enc; e0 += MFM_MAX_SEQ) {
+    MfmSeqDesc q[MFM_MAX_SEQ];
+    const int n = std::min(MFM_MAX_SEQ, P->n_enc - e0);
+    for (int i = 0; i < n; ++i) {
+      const int e = e0 + i;
+      q[i] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
+      if (V != 0 && e >= 3) {     // MFN LSTM: gradient on h_{T-1} from the heads, on every c_t from the attention block
+        int hoff = 0;
+        for (int m = 0; m < e - 3; ++m) hoff += P->enc[3 + m].h;
+        q[i].dh_ext = W + P->d_hT + hoff; q[i].ld_dh = P->tot;
+        q[i].dc_ext = W + P->dcx[e - 3];
+      } else {
+        q[i].dh_ext = W + P->dh_last[e]; q[i].ld_dh = P->enc_h[e];
+      }
     }
-    RUN(K_ENC_BWD, seq_bf16 ? mfm_lstm_seq_bwd_bf16(q, 4, T, B, s) : mfm_lstm_seq_bwd(q, 4, T, B, s));
+    RUN(K_ENC_BWD, seq_bf16 ? mfm_lstm_seq_bwd_bf16(q, n, T, B, s) : mfm_lstm_seq_bwd(q, n, T, B, s));
   }
   // B5: all weight gradients
   {
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < P->n_enc; ++e)
       dA_gemms(P, P->enc[e], P->enc_p[e], W, grads, tail, x + P->enc_xoff[e], P->D, P->enc_d[e], false);
     if (gen_on)
       for (int m = 0; m < 3; ++m)
@@ -619,11 +978,22 @@ extern "C" int mfm_plan_create(const MfmPlanConfig* cfg, const int64_t* param_of
   MFM_REQUIRE(c.output_dim >= 1 && c.output_dim <= 64, "plan: output_dim %d", c.output_dim);
   MFM_REQUIRE(c.loss_kind == 0 || c.loss_kind == 1, "plan: loss_kind %d", c.loss_kind);
   MFM_REQUIRE(c.precision == 0 || c.precision == 1, "plan: precision %d (0 = fp32, 1 = bf16 operands)", c.precision);
+  MFM_REQUIRE(c.variant >= 0 && c.variant <= 2, "plan: variant %d (0 MFM_KL_EF, 1 MFM_KL, 2 MFM)", c.variant);
+  if (c.variant != 0) {
+    MFM_REQUIRE(c.hl > 0 && c.ha > 0 && c.hv > 0 && c.mem_dim > 0 && c.nn1 > 0 && c.nn2 > 0 && c.g1 > 0 && c.g2 > 0,
+                "plan: MFN sizes must be positive (h_dims %d/%d/%d, memsize %d, NN1/NN2/gamma1/gamma2 %d/%d/%d/%d)",
+                c.hl, c.ha, c.hv, c.mem_dim, c.nn1, c.nn2, c.g1, c.g2);
+    MFM_REQUIRE(c.hl <= MFM_SEQ_MAX_RESIDENT_H && c.ha <= MFM_SEQ_MAX_RESIDENT_H && c.hv <= MFM_SEQ_MAX_RESIDENT_H,
+                "plan: MFN LSTM sizes above %d are not supported on the fused plan (use the module path)", MFM_SEQ_MAX_RESIDENT_H);
+    MFM_REQUIRE(2 * (c.hl + c.ha + c.hv) <= 1024, "plan: cStar width %d > 1024", 2 * (c.hl + c.ha + c.hv));
+  }
   MfmPlan* P = new (std::nothrow) MfmPlan();
   if (!P) { set_error("plan: out of host memory"); return MFM_ERR_ARG; }
   P->cfg = c;
+  P->pi = pidx_for(c.variant);
+  P->gauss = nullptr;
   if (P->cfg.reg_scale == 0.0f) P->cfg.reg_scale = 1.0f;
-  for (int i = 0; i < MFM_KLEF_NPARAM; ++i) {
+  for (int i = 0; i < P->pi.count; ++i) {
     P->off[i] = param_offsets[i];
     if (param_offsets[i] < 0 || param_offsets[i] >= n_params_total) {
       delete P; set_error("plan: param offset %d out of range", i); return MFM_ERR_ARG;
@@ -634,6 +1004,16 @@ extern "C" int mfm_plan_create(const MfmPlanConfig* cfg, const int64_t* param_of
   int rc = build(P);
   if (rc != MFM_OK) { delete P; return rc; }
   *out = P;
+  return MFM_OK;
+}
+
+extern "C" int mfm_plan_num_params(int32_t variant) {
+  return (variant >= 0 && variant <= 2) ? pidx_for(variant).count : 0;
+}
+
+extern "C" int mfm_plan_set_gauss(MfmPlan* P, const float* gauss) {
+  if (!P) { set_error("mfm_plan_set_gauss: null plan"); return MFM_ERR_ARG; }
+  P->gauss = gauss;
   return MFM_OK;
 }
 
@@ -759,6 +1139,18 @@ extern "C" int mfm_plan_latent_layout(const MfmPlan* P, int64_t* out) {
   return MFM_OK;
 }
 
+extern "C" int mfm_plan_mfn_layout(const MfmPlan* P, int64_t* out) {
+  if (!P || !out) { set_error("mfm_plan_mfn_layout: null argument"); return MFM_ERR_ARG; }
+  for (int i = 0; i < 16; ++i) out[i] = 0;
+  if (P->cfg.variant == 0) { set_error("mfm_plan_mfn_layout: the plan has no Memory Fusion Network (variant 0)"); return MFM_ERR_ARG; }
+  const int64_t f = (int64_t)sizeof(float);
+  out[0] = P->cstar * f; out[1] = P->h1 * f; out[2] = P->m1 * f; out[3] = P->att * f; out[4] = P->attended * f;
+  out[5] = P->h2 * f; out[6] = P->m2 * f; out[7] = P->chat * f; out[8] = P->mem_out * f; out[9] = P->zyin * f;
+  out[10] = P->A2; out[11] = P->cfg.nn1; out[12] = P->cfg.nn2; out[13] = P->cfg.mem_dim; out[14] = P->nzy;
+  out[15] = (int64_t)P->T * P->B;
+  return MFM_OK;
+}
+
 // ---- timing: HIP events on the launch stream around the kernels selected by `mask`
 extern "C" int mfm_plan_set_timing(MfmPlan* P, int mask) {
   if (!P) return MFM_ERR_ARG;
@@ -769,7 +1161,8 @@ extern "C" int mfm_plan_num_kernels(void) { return K_COUNT; }
 extern "C" const char* mfm_plan_kernel_name(int kid) {
   static const char* names[K_COUNT] = {"proj_gemm", "enc_seq_fwd", "latent_fwd", "dec_seq_fwd", "fc1_mse_gemm", "mse",
                                        "fc1_bwd_gemm", "dec_seq_bwd", "dec_dw_gemm", "latent_bwd", "enc_seq_bwd",
-                                       "dw_gemm", "adam", "latent_dw_gemm", "bf16_weight_pack"};
+                                       "dw_gemm", "adam", "latent_dw_gemm", "bf16_weight_pack", "mfn_glue", "mfn_att_fwd_gemm",
+                                       "mfn_mem_fwd", "mfn_heads_gemm", "mfn_mem_bwd", "mfn_att_bwd_gemm", "mmd"};
   return (kid >= 0 && kid < K_COUNT) ? names[kid] : "?";
 }
 // Synchronises on the recorded events, adds elapsed ms / launch counts per kernel id, resets the pool.
@@ -810,23 +1203,27 @@ extern "C" int mfm_timing_bracket_overhead_ms(void* stream, double* ms_out) {
 static double fwd_flops_per_sample(const MfmPlan* P) {
   const MfmPlanConfig& c = P->cfg;
   double f = 0.0;
-  for (int e = 0; e < 4; ++e) {
+  for (int e = 0; e < P->n_enc; ++e) {
     const double h = P->enc_h[e], d = P->enc_d[e];
-    f += P->T * 2.0 * 4.0 * h * (d + h) + 2.0 * h * h;
+    f += P->T * 2.0 * 4.0 * h * (d + h);
   }
   for (int m = 0; m < 3; ++m) {
     const double h = P->dec_h[m], d = P->dec_d[m];
     f += P->T * (2.0 * 4.0 * h * (h + h) + 2.0 * h * d);
   }
-  for (int i = 4; i < P->lat.nops; ++i) f += 2.0 * P->lat_ops[i].K * P->lat_ops[i].N;
-  (void)c;
+  for (int i = 0; i < P->lat.nops; ++i) f += 2.0 * P->lat_ops[i].K * P->lat_ops[i].N;
+  if (c.variant != 0) {      // MFN per time step: attention (4 Linears), the two gamma nets; once: heads on mfn_last
+    const double A2 = P->A2, M = c.mem_dim;
+    f += P->T * 2.0 * (A2 * c.nn1 + c.nn1 * A2 + A2 * c.nn2 + c.nn2 * M + (A2 + M) * (c.g1 + c.g2) + (c.g1 + c.g2) * M);
+    f += 2.0 * (P->tot + M) * P->nzy;
+  }
   return f;
 }
 extern "C" double mfm_plan_flops_per_step(const MfmPlan* P) { return P ? 3.0 * fwd_flops_per_sample(P) * P->B : 0.0; }
 extern "C" double mfm_plan_bytes_per_step(const MfmPlan* P) {
   if (!P) return 0.0;
   double sh = 0.0;
-  for (int e = 0; e < 4; ++e) sh += P->enc_h[e];
+  for (int e = 0; e < P->n_enc; ++e) sh += P->enc_h[e];
   for (int m = 0; m < 3; ++m) sh += P->dec_h[m];
   const double per_sample = 2.0 * P->T * P->D * 4.0 + 4.0 + 2.0 * P->T * 6.0 * sh * 4.0;
   return per_sample * P->B + 10.0 * (double)P->n_params * 4.0;
@@ -837,14 +1234,15 @@ extern "C" double mfm_plan_kernel_flops(const MfmPlan* P, int kid) {
   const double TB = (double)P->T * P->B;
   double f = 0.0;
   switch (kid) {
-    case K_PROJ: for (int e = 0; e < 4; ++e) f += TB * 2.0 * 4.0 * P->enc_h[e] * P->enc_d[e]; break;
-    case K_ENC_FWD: case K_ENC_BWD: for (int e = 0; e < 4; ++e) f += TB * 2.0 * 4.0 * P->enc_h[e] * P->enc_h[e]; break;
+    case K_PROJ: for (int e = 0; e < P->n_enc; ++e) f += TB * 2.0 * 4.0 * P->enc_h[e] * P->enc_d[e]; break;
+    // (variants 1, 2 run the six encoder recurrences as two launches: this is the sum of both)
+    case K_ENC_FWD: case K_ENC_BWD: for (int e = 0; e < P->n_enc; ++e) f += TB * 2.0 * 4.0 * P->enc_h[e] * P->enc_h[e]; break;
     case K_DEC_FWD: case K_DEC_BWD: for (int m = 0; m < 3; ++m) f += TB * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m]; break;
     case K_FC1_FWD: for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m]; break;
     case K_FC1_BWD: for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m]; break;   // dH only
     case K_DEC_DW: break;   // merged into K_ENC_DW
     case K_ENC_DW:
-      for (int e = 0; e < 4; ++e) f += TB * 2.0 * 4.0 * P->enc_h[e] * (P->enc_d[e] + P->enc_h[e]);
+      for (int e = 0; e < P->n_enc; ++e) f += TB * 2.0 * 4.0 * P->enc_h[e] * (P->enc_d[e] + P->enc_h[e]);
       for (int m = 0; m < 3; ++m) f += TB * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m];
       for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m];            // dWfc
       for (int i = 0; i < P->lat.nops; ++i) f += 2.0 * P->B * P->lat_ops[i].N * P->lat_ops[i].K;   // latent dW

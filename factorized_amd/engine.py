@@ -66,9 +66,100 @@ def klef_param_shapes(cfg):
     return s
 
 
+VARIANTS = {"kl_ef": 0, "kl": 1, "mmd": 2}
+
+
+def mfn_param_shapes(configs, variant):
+    """Ordered name -> shape of MFM_KL ('kl', 104 tensors, reference mfm_model.py:662-721) or MFM ('mmd', 90 tensors,
+    :469-520), both with the Memory Fusion Network encoder (:93-138; out_fc1 / out_fc2 exist, forward never uses
+    them)."""
+    cfg, nn1, nn2, g1, g2, outc = configs
+    d_l, d_a, d_v = cfg["input_dims"]
+    hl, ha, hv = cfg["h_dims"]
+    zl, za, zv, zy = cfg["zl_size"], cfg["za_size"], cfg["zv_size"], cfg["zy_size"]
+    fl, fa, fv, fy = cfg["fl_size"], cfg["fa_size"], cfg["fv_size"], cfg["fy_size"]
+    od, M = cfg["output_dim"], cfg["memsize"]
+    assert cfg.get("windowsize", 2) == 2, "the fused MFN plan is built for windowsize 2 (cStar = [c_{t-1}, c_t])"
+    tot = hl + ha + hv
+    A2 = 2 * tot
+    s = OrderedDict()
+
+    def cell(prefix, d, h):
+        s[prefix + ".weight_ih"] = (4 * h, d)
+        s[prefix + ".weight_hh"] = (4 * h, h)
+        s[prefix + ".bias_ih"] = (4 * h,)
+        s[prefix + ".bias_hh"] = (4 * h,)
+
+    def lstm(prefix, d, h, out):
+        cell(prefix + ".lstm", d, h)
+        s[prefix + ".fc1.weight"] = (out, h)
+        s[prefix + ".fc1.bias"] = (out,)
+
+    def lin(name, i, o):
+        s[name + ".weight"] = (o, i)
+        s[name + ".bias"] = (o,)
+
+    lstm("encoder_l", d_l, zl, zl)
+    lstm("encoder_a", d_a, za, za)
+    lstm("encoder_v", d_v, zv, zv)
+    lstm("decoder_l", fy + fl, fy + fl, d_l)
+    lstm("decoder_a", fy + fa, fy + fa, d_a)
+    lstm("decoder_v", fy + fv, fy + fv, d_v)
+    cell("mfn_encoder.lstm_l", d_l, hl)
+    cell("mfn_encoder.lstm_a", d_a, ha)
+    cell("mfn_encoder.lstm_v", d_v, hv)
+    lin("mfn_encoder.att1_fc1", A2, nn1["shapes"])
+    lin("mfn_encoder.att1_fc2", nn1["shapes"], A2)
+    lin("mfn_encoder.att2_fc1", A2, nn2["shapes"])
+    lin("mfn_encoder.att2_fc2", nn2["shapes"], M)
+    lin("mfn_encoder.gamma1_fc1", A2 + M, g1["shapes"])
+    lin("mfn_encoder.gamma1_fc2", g1["shapes"], M)
+    lin("mfn_encoder.gamma2_fc1", A2 + M, g2["shapes"])
+    lin("mfn_encoder.gamma2_fc2", g2["shapes"], M)
+    lin("mfn_encoder.out_fc1", tot + M, outc["shapes"])
+    lin("mfn_encoder.out_fc2", outc["shapes"], od)
+    lin("last_to_zy_fc1", tot + M, zy)
+    if variant == "kl":
+        lin("last_to_logvarzy_fc1", tot + M, zy)
+        lin("last_to_zl_fc1", zl, zl)
+        lin("last_to_za_fc1", za, za)
+        lin("last_to_zv_fc1", zv, zv)
+        lin("last_to_logvarzl_fc1", zl, zl)
+        lin("last_to_logvarza_fc1", za, za)
+        lin("last_to_logvarzv_fc1", zv, zv)
+    for tag, zi, fo in (("zy_to_fy", zy, fy), ("zl_to_fl", zl, fl), ("za_to_fa", za, fa), ("zv_to_fv", zv, fv)):
+        lin(tag + "_fc1", zi, fo)
+        lin(tag + "_fc2", fo, fo)
+    lin("fy_to_y_fc1", fy, fy)
+    lin("fy_to_y_fc2", fy, od)
+    return s
+
+
+def param_shapes(configs, variant="kl_ef"):
+    return klef_param_shapes(configs[0]) if variant == "kl_ef" else mfn_param_shapes(configs, variant)
+
+
 # Latent-stack tensors grouped by the stage of the fused latent kernel that consumes them
 # (csrc/latent.hip): each group is laid out contiguously so a stage's weights are ONE linear
 # global->LDS copy.  Everything else (the LSTM tensors) keeps state_dict order in front.
+_LATENT_STAGE_KEYS_MFN = {
+    "kl": [
+        ("encoder_l.fc1", "encoder_a.fc1", "encoder_v.fc1"),
+        ("last_to_zl_fc1", "last_to_za_fc1", "last_to_zv_fc1"),
+        ("zl_to_fl_fc1", "za_to_fa_fc1", "zv_to_fv_fc1", "zy_to_fy_fc1"),
+        ("zl_to_fl_fc2", "za_to_fa_fc2", "zv_to_fv_fc2", "zy_to_fy_fc2"),
+        ("fy_to_y_fc1", "last_to_logvarzl_fc1", "last_to_logvarza_fc1", "last_to_logvarzv_fc1"),
+        ("fy_to_y_fc2",),
+    ],
+    "mmd": [
+        ("encoder_l.fc1", "encoder_a.fc1", "encoder_v.fc1"),
+        ("zl_to_fl_fc1", "za_to_fa_fc1", "zv_to_fv_fc1", "zy_to_fy_fc1"),
+        ("zl_to_fl_fc2", "za_to_fa_fc2", "zv_to_fv_fc2", "zy_to_fy_fc2"),
+        ("fy_to_y_fc1",),
+        ("fy_to_y_fc2",),
+    ],
+}
+
 _LATENT_STAGE_KEYS = [
     ("encoder_l.fc1", "encoder_a.fc1", "encoder_v.fc1", "ef_encoder.fc1"),
     ("last_to_zl_fc1", "last_to_za_fc1", "last_to_zv_fc1", "last_to_zy_fc1"),
@@ -94,15 +185,16 @@ class FlatLayout:
     """Placement of the named tensors in one flat fp32 buffer.  `shapes`/`offsets` iterate in the
     reference's state_dict order (what the C plan expects); the PHYSICAL order is chosen here."""
 
-    def __init__(self, shapes):
+    def __init__(self, shapes, variant="kl_ef"):
         self.shapes = OrderedDict(shapes)
         stage_of = {}
-        for st, prefixes in enumerate(_LATENT_STAGE_KEYS):
+        stage_keys = _LATENT_STAGE_KEYS if variant == "kl_ef" else _LATENT_STAGE_KEYS_MFN[variant]
+        for st, prefixes in enumerate(stage_keys):
             for pre in prefixes:
                 stage_of[pre + ".weight"] = st
                 stage_of[pre + ".bias"] = st
         order = [n for n in self.shapes if n not in stage_of]
-        for st in range(len(_LATENT_STAGE_KEYS)):
+        for st in range(len(stage_keys)):
             order += [n for n in self.shapes if stage_of.get(n) == st]
         assert sorted(order) == sorted(self.shapes)
         placed = {}
@@ -160,7 +252,16 @@ class _Plan:
         pc.drop_y = cfg["fy_to_y_dropout"]
         pc.reg_scale = reg_scale
         pc.precision = 1 if engine.precision == "bf16" else 0
-        offs = (C.c_int64 * _lib.MFM_KLEF_NPARAM)(*engine.layout.offsets.values())
+        pc.variant = VARIANTS[engine.variant]
+        if engine.variant != "kl_ef":
+            nn1, nn2, g1, g2 = engine.configs[1:5]
+            pc.hl, pc.ha, pc.hv = cfg["h_dims"]
+            pc.mem_dim = cfg["memsize"]
+            pc.nn1, pc.nn2, pc.g1, pc.g2 = nn1["shapes"], nn2["shapes"], g1["shapes"], g2["shapes"]
+            pc.drop_nn1, pc.drop_nn2, pc.drop_g1, pc.drop_g2 = nn1["drop"], nn2["drop"], g1["drop"], g2["drop"]
+        nparam = _lib.lib().mfm_plan_num_params(pc.variant)
+        assert nparam == len(engine.layout.offsets), (nparam, len(engine.layout.offsets))
+        offs = (C.c_int64 * nparam)(*engine.layout.offsets.values())
         handle = C.c_void_p(0)
         _lib.check(_lib.lib().mfm_plan_create(C.byref(pc), offs, engine.layout.total, C.byref(handle)),
                    "mfm_plan_create")
@@ -184,9 +285,10 @@ class _Plan:
 
 
 class MFMEngine:
-    """Fused MFM_KL_EF on one MI355X.  `configs` is the reference's six-dict list."""
+    """The fused training / inference step of MFM_KL_EF (variant "kl_ef"), MFM_KL ("kl") or MFM ("mmd") on one MI355X.
+    `configs` is the reference's six-dict list."""
 
-    def __init__(self, configs, device="cuda", reg_scale=1.0, precision="fp32"):
+    def __init__(self, configs, device="cuda", reg_scale=1.0, precision="fp32", variant="kl_ef"):
         if not torch.cuda.is_available():
             raise _lib.MfmError("MFMEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
                                 "there is no CPU fallback")
@@ -194,7 +296,11 @@ class MFMEngine:
         self.configs = configs
         self.cfg = configs[0]
         self.device = torch.device(device)
-        self.layout = FlatLayout(klef_param_shapes(self.cfg))
+        if variant not in VARIANTS:
+            raise ValueError("variant must be one of %s" % sorted(VARIANTS))
+        self.variant = variant
+        self.layout = FlatLayout(param_shapes(configs, variant), variant)
+        self.gauss = None            # variant "mmd": fixed N(0,1) sample [B, zl+za+zv+zy] (parity runs); None = draw per call
         n = self.layout.total
         self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.grads = torch.zeros(n, dtype=torch.float32, device=self.device)
@@ -241,12 +347,25 @@ class MFMEngine:
 
     # ------------------------------------------------------------------ plans
     def plan(self, T, B):
-        key = (int(T), int(B), self.reg_scale, self.precision)
+        key = (int(T), int(B), self.reg_scale, self.precision, self.variant)
         p = self._plans.get(key)
         if p is None:
             p = _Plan(self, int(T), int(B), self.reg_scale)
             self._plans[key] = p
         return p
+
+    def _gauss_for(self, p, B):
+        """variant "mmd": hand the plan the N(0,1) sample loss_MMD draws per forward (reference mfm_model.py:26)."""
+        if self.variant != "mmd":
+            return
+        c = self.cfg
+        gl = c["zl_size"] + c["za_size"] + c["zv_size"] + c["zy_size"]
+        g = self.gauss
+        if g is None:
+            g = torch.randn(B, gl, device=self.device)
+        assert g.shape == (B, gl) and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()
+        p.gauss_ref = g              # keep it alive until the next call
+        _lib.check(_lib.lib().mfm_plan_set_gauss(p.handle, _ptr(g)), "mfm_plan_set_gauss")
 
     def _check_inputs(self, x, y):
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
@@ -270,6 +389,7 @@ class MFMEngine:
         y_hat = torch.empty(B, self.cfg["output_dim"], dtype=torch.float32, device=self.device)
         p.fwd_serial += 1
         p.consumed = False
+        self._gauss_for(p, B)
         _lib.check(_lib.lib().mfm_plan_forward(p.handle, _ptr(self.params), _ptr(x), _ptr(y), int(bool(train)),
                                                C.c_uint64(self.seed), _ptr(p.workspace), _ptr(xh[0]), _ptr(xh[1]),
                                                _ptr(xh[2]), _ptr(y_hat), _ptr(p.losses), _stream()),
@@ -325,6 +445,7 @@ class MFMEngine:
             self._check_inputs(x, y)
         T, B, _ = x.shape
         p = self.plan(T, B)
+        self._gauss_for(p, B)
         gs = self.group_steps
         if stage != 0 or not (gs["shared"] == gs["gen"] == gs["disc"]):
             spans = self._staged_spans(stage)
@@ -360,6 +481,7 @@ class MFMEngine:
             self._check_inputs(x, y)
         T, B, _ = x.shape
         p = self.plan(T, B)
+        self._gauss_for(p, B)
         p.fwd_serial += 1
         p.consumed = True
         _lib.check(_lib.lib().mfm_plan_grad_step(p.handle, _ptr(self.params), _ptr(self.grads), _ptr(x), _ptr(y),
@@ -396,6 +518,19 @@ class MFMEngine:
                    y_hat=int(out[21]))
         lay["width"]["fy_to_y"] = int(out[16])
         return rec, grd, lay
+
+    def mfn_buffers(self, T, B):
+        """variants "kl" / "mmd": views of the MFN's [T*B, .] workspace tensors (mfm_plan_mfn_layout).  Tests / tuning."""
+        p = self.plan(T, B)
+        out = (C.c_int64 * 16)()
+        _lib.check(_lib.lib().mfm_plan_mfn_layout(p.handle, out), "mfm_plan_mfn_layout")
+        ws = p.workspace.view(torch.float32)
+        TB, A2, n1, n2, M, nzy = int(out[15]), int(out[10]), int(out[11]), int(out[12]), int(out[13]), int(out[14])
+
+        def v(i, rows, cols):
+            return ws[out[i] // 4: out[i] // 4 + rows * cols].view(rows, cols)
+        return dict(cstar=v(0, TB, A2), h1=v(1, TB, n1), m1=v(2, TB, n1), att=v(3, TB, A2), attended=v(4, TB, A2),
+                    h2=v(5, TB, n2), m2=v(6, TB, n2), chat=v(7, TB, M), mem_out=v(8, B, M), zyin=v(9, B, nzy))
 
     def loss_dict(self, losses):
         """Host view of the loss slots (synchronises)."""

@@ -152,6 +152,11 @@ typedef struct MfmMemDesc {
   uint64_t seed;
   const uint64_t* seed_dev;             /* optional device word added to `seed` when the kernel runs: lets a captured
                                            hipGraph draw new masks on every replay (the caller advances it in-graph) */
+  int64_t ld_wm;                        /* row stride of w1m / w2m (0 = M): lets them be the memory COLUMNS of the
+                                           reference's gamma_n_fc1.weight [H_n, att+M] in place, without a copy */
+  int32_t dchat_pre_tanh;               /* backward: write dchat * (1 - chat^2), the gradient wrt the PRE-activation of
+                                           cHat = tanh(.) (chat then holds the tanh output), instead of dL/dchat */
+  int32_t reserved_;
 } MfmMemDesc;
 
 int mfm_mfn_mem_fwd(const MfmMemDesc* desc /*host*/, void* stream);
@@ -234,13 +239,29 @@ typedef struct MfmPlanConfig {
                              1 = bf16 MFMA operands in every GEMM and LSTM recurrence, fp32 accumulation, master
                                  weights, Adam moments, cell state, saved activations, latent stack and losses
                                  (BASELINE configs 2-4; gate: matched loss curve) */
+  /* ---- model variant (the classes train_mfm picks by config['type'], reference mfm_mosi.py:398-401) */
+  int32_t variant;        /* 0 = MFM_KL_EF (early-fusion LSTM for z_y; mfm_model.py:557-660)
+                             1 = MFM_KL    (Memory Fusion Network for z_y + KLD;  mfm_model.py:662-764, 93-199)
+                             2 = MFM       (MFN for z_y, no logvar heads, MMD regulariser; mfm_model.py:469-555, 14-34) */
+  int32_t hl, ha, hv;     /* variants 1, 2: MFN LSTMCell sizes (config["h_dims"]) */
+  int32_t mem_dim;        /* memsize; windowsize is 2 (cStar = [c_{t-1}, c_t]) */
+  int32_t nn1, nn2, g1, g2;                       /* hidden widths of att1 / att2 / gamma1 / gamma2 (*Config["shapes"]) */
+  float drop_nn1, drop_nn2, drop_g1, drop_g2;     /* their dropouts (*Config["drop"]) */
 } MfmPlanConfig;
 
 typedef struct MfmPlan MfmPlan;
 
-/* host-side: builds the op tables; no device allocation. */
-int mfm_plan_create(const MfmPlanConfig* cfg, const int64_t* param_offsets /*[MFM_KLEF_NPARAM]*/,
+/* number of parameter tensors of a variant in reference state_dict order: 78 / 104 / 90 */
+int mfm_plan_num_params(int32_t variant);
+/* host-side: builds the op tables; no device allocation.  param_offsets has mfm_plan_num_params(cfg->variant)
+ * entries: the element offset of every tensor of the reference model's state_dict(), in its order, inside the
+ * flat buffer (the MFN's out_fc1 / out_fc2 exist in the state_dict but are unused by forward, as in the reference). */
+int mfm_plan_create(const MfmPlanConfig* cfg, const int64_t* param_offsets /*[mfm_plan_num_params(variant)]*/,
                     int64_t n_params_total, MfmPlan** out);
+/* variant 2 only: the N(0,1) sample loss_MMD draws for every forward (reference mfm_model.py:26: torch.randn on the
+ * host).  [B, zl+za+zv+zy] row-major device buffer read by the next forward / step calls; the caller refreshes it
+ * (or keeps it fixed for parity runs). */
+int mfm_plan_set_gauss(MfmPlan* plan, const float* gauss);
 void mfm_plan_destroy(MfmPlan* plan);
 int64_t mfm_plan_workspace_bytes(const MfmPlan* plan);
 /* byte offset inside the workspace of 64 uint64 shader-clock stamps the latent kernels write when
@@ -298,6 +319,13 @@ int mfm_plan_train_step_staged(MfmPlan* plan, float* params, float* grads, float
  * f{l,a,v,y}, out[17..20] f segments (outputs of *_fc2), out[21] y_hat, out[22] 1 if the row-per-workgroup kernels
  * run at this (T,B), out[23..26] mu segments z{l,a,v,y} (inputs of *_fc1), out[27..30] their widths, out[31] reserved. */
 int mfm_plan_latent_layout(const MfmPlan* plan, int64_t* out /*[32]*/);
+
+/* variants 1, 2: where the Memory Fusion Network keeps its [T*B, .] tensors inside the workspace (tests / tuning aids).
+ * Byte offsets: out[0] cStar, out[1] h1 = drop(relu(att1_fc1)), out[2] its relu/dropout mask (0 | 1/(1-p)), out[3] attention,
+ * out[4] attended, out[5] h2, out[6] its mask, out[7] cHat, out[8] final memory [B, memsize], out[9] the latent stack's y
+ * input [B, nzy]; then sizes: out[10] width of cStar, out[11] NN1, out[12] NN2 hidden widths, out[13] memsize, out[14] nzy,
+ * out[15] T*B. */
+int mfm_plan_mfn_layout(const MfmPlan* plan, int64_t* out /*[16]*/);
 
 /* Algorithmic work of one training step at this plan's (T,B):
  * 3 x forward FLOPs; activation+input bytes per sample plus 10 P 4 parameter/optimizer bytes. */
