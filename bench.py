@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 FP32_MATRIX_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
 BF16_MATRIX_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (2:1-sparsity figures are never used)
 HBM_PEAK_GBS = 8000.0
+MODEL_NAME = {"kl_ef": "MFM_KL_EF", "kl": "MFM_KL (MFN encoder, KLD)", "mmd": "MFM (MFN encoder, MMD)"}
 
 
 def main():
@@ -40,6 +41,9 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="fp32 = the reference's arithmetic (BASELINE config 1, the headline); bf16 = bf16 MFMA operands, "
                          "fp32 accumulate / master weights / cell state / loss (BASELINE configs 2-4)")
+    ap.add_argument("--model", default="kl_ef", choices=["kl_ef", "kl", "mmd"],
+                    help="kl_ef = MFM_KL_EF (the headline workload); kl / mmd = MFM_KL / MFM with the Memory Fusion Network "
+                         "encoder, the classes train_mfm picks by config['type'] (reference mfm_mosi.py:398-401)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-kernel time table to stderr")
     args = ap.parse_args()
@@ -75,7 +79,7 @@ def main():
                                                                  "mosei": "mosi.json"}[args.shape]))
     B = args.batch
 
-    e = engine.MFMEngine(cfgs, device="cuda:%d" % local_rank, precision=args.dtype)
+    e = engine.MFMEngine(cfgs, device="cuda:%d" % local_rank, precision=args.dtype, variant=args.model)
     e.load_weights(synth.make_weights(e.layout.shapes, seed=1234))
     train.broadcast_params(e, world)
     n_samples = max(1280, B * world * 8)          # MOSI-scale split (1,284 train utterances)
@@ -191,7 +195,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r02_traffic.json" if args.dtype == "fp32" else "r02_traffic_bf16.json")
         if not os.path.exists(tpath) and args.dtype == "fp32":
             tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and args.shape == "mosi" and B == 32 and T == 20:
+        if os.path.exists(tpath) and args.shape == "mosi" and B == 32 and T == 20 and args.model == "kl_ef":
             try:
                 traffic = json.load(open(tpath)).get(dom, {}).get("total_bytes")
             except Exception:
@@ -201,7 +205,7 @@ def main():
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "MFM_KL_EF %s canonical sizes, per-GPU B=%d, T=%d, D=%d, train mode "
+            "config": {"workload": MODEL_NAME[args.model] + " %s canonical sizes, per-GPU B=%d, T=%d, D=%d, train mode "
                                    "(fwd + joint loss + bwd + Adam), %s HIP" % (args.shape, B, T, sum(cfg["input_dims"]),
                                                                             "fp32" if args.dtype == "fp32" else
                                                                             "bf16-operand / fp32-accumulate"),
@@ -228,9 +232,13 @@ def main():
             cores = os.cpu_count() or 1
             # the reference step is ~165 tiny ops: it stops scaling at a handful of threads, so time
             # it at 1 thread and at min(cores, 8) threads (bounded ~8 s each) and report the faster.
-            runs = [O.time_cpu_steps(cfgs, B, T, budget_s=8.0, threads=1)]
+            runs = [O.time_cpu_steps(cfgs, B, T, budget_s=8.0, threads=1, variant=args.model)]
             if cores > 1:
-                runs.append(O.time_cpu_steps(cfgs, B, T, budget_s=8.0, threads=min(cores, 8)))
+                runs.append(O.time_cpu_steps(cfgs, B, T, budget_s=8.0, threads=min(cores, 8), variant=args.model))
+            if cores > 8 and os.environ.get("MFM_BENCH_ALL_CORES") == "1":
+                # SURVEY.md section 8d asks for the all-physical-cores figure once: it is slower than 1 thread for this
+                # ~165-tiny-op step (recorded in profiles/), so the default run does not spend 8 s on it
+                runs.append(O.time_cpu_steps(cfgs, B, T, budget_s=8.0, threads=cores // 2, variant=args.model))
             r = max(runs, key=lambda q: q["samples_per_s"])
             cpu_model = "?"
             try:

@@ -348,6 +348,66 @@ def decoder_group(pairs, t):
     return list(_DecoderGroupFn.apply(len(pairs), t, *args))
 
 
+
+# ----------------------------------------------------------------------------------- fused engine on module storage
+class _FusedEngineMixin:
+    """Gives a model class the `engine` property: an MFMEngine (the one-call fused plan) whose flat parameter buffer
+    IS the module's parameter storage -- every nn.Parameter becomes a view into it on first CUDA use, so
+    `model.engine.train_step(x, y)` and a reference-style `loss.backward(); optimizer.step()` update the same numbers.
+    Also whole-module checkpoints (torch.save(model, path) / torch.load, reference mfm_mosi.py:342-346, 473-481) and
+    copy.deepcopy: the engine holds native plan handles and device workspaces, which are dropped from the pickled
+    state and re-adopted lazily."""
+    _engine_variant = "kl_ef"
+
+    def _init_engine_slots(self):
+        self._param_names = [n for n, _ in self.named_parameters()]
+        self._plist = [p for _, p in self.named_parameters()]      # Parameter objects survive .to()/.cuda()
+        self._engine = None
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_engine"] = None
+        return state
+
+    def __setstate__(self, state):
+        nn.Module.__setstate__(self, state)
+        self._engine = None
+        # `_plist` must hold the SAME Parameter objects as the sub-modules (pickle keeps identity through its memo;
+        # rebuild defensively in case a custom unpickler did not)
+        self._plist = [p for _, p in self.named_parameters()]
+
+    def _flat_ok(self):
+        if self._engine is None:
+            return False
+        eng = self._engine
+        base = eng.params.data_ptr()
+        o0, ol = eng.layout.slots[0][0], eng.layout.slots[-1][0]
+        return (self._plist[0].data_ptr() == base + 4 * o0 and self._plist[-1].data_ptr() == base + 4 * ol)
+
+    def _adopt(self, device):
+        cfg = dict(self._configs[0])
+        for k, dflt in (("lda_xl", 1.0), ("lda_xa", 1.0), ("lda_xv", 1.0), ("lda_mmd", 1.0)):
+            cfg.setdefault(k, dflt)
+        eng = E.MFMEngine([cfg] + list(self._configs[1:]), device=device, variant=self._engine_variant)
+        assert list(eng.layout.shapes.keys()) == self._param_names, "parameter naming drifted from the reference"
+        pd = OrderedDict(self.named_parameters())
+        eng.load_weights(OrderedDict((n, p.detach()) for n, p in pd.items()))
+        views = eng.param_views()
+        for n, p in pd.items():
+            p.data = views[n]
+        self._engine = eng
+
+    @property
+    def engine(self):
+        """The fused engine sharing this module's parameter storage (built on first CUDA use)."""
+        if not self._flat_ok():
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise _lib.MfmError("%s: parameters are on %s; move the model to the GPU first" % (type(self).__name__, dev))
+            self._adopt(dev)
+        return self._engine
+
+
 # ----------------------------------------------------------------------------------- MFM_KL_EF
 class _KLEFFn(torch.autograd.Function):
     """The whole MFM_KL_EF forward as ONE plan call; backward = mfm_plan_backward_ext with the
@@ -401,7 +461,7 @@ class _KLEFFn(torch.autograd.Function):
         return (None, None) + tuple(flat[o:o + n].view(shp) for o, n, shp in lay.slots)
 
 
-class MFM_KL_EF(nn.Module):
+class MFM_KL_EF(_FusedEngineMixin, nn.Module):
     def __init__(self, config, NN1Config, NN2Config, gamma1Config, gamma2Config, outConfig):
         super(MFM_KL_EF, self).__init__()
         self._configs = [config, NN1Config, NN2Config, gamma1Config, gamma2Config, outConfig]
@@ -440,57 +500,7 @@ class MFM_KL_EF(nn.Module):
         self.fy_to_y_fc1 = nn.Linear(fy, fy)
         self.fy_to_y_fc2 = nn.Linear(fy, output_dim)
         self.fy_to_y_dropout = nn.Dropout(config['fy_to_y_dropout'])
-        self._param_names = [n for n, _ in self.named_parameters()]
-        self._plist = [p for _, p in self.named_parameters()]      # Parameter objects survive .to()/.cuda()
-        self._engine = None
-
-    # ---- whole-module checkpoints (torch.save(model, path) / torch.load, reference mfm_mosi.py:342-346,473-481)
-    # and copy.deepcopy: the engine holds native plan handles and device workspaces, none of which can or should
-    # be serialised.  The state keeps the parameters (views are written as ordinary tensors sharing one storage)
-    # and drops the engine; the first CUDA use of the restored module adopts a fresh one (`engine` property).
-    def __getstate__(self):
-        state = dict(self.__dict__)
-        state["_engine"] = None
-        return state
-
-    def __setstate__(self, state):
-        super(MFM_KL_EF, self).__setstate__(state)
-        self._engine = None
-        # `_plist` must hold the SAME Parameter objects as the sub-modules (pickle keeps identity through its memo;
-        # rebuild defensively in case a custom unpickler did not)
-        self._plist = [p for _, p in self.named_parameters()]
-
-    # ---- flat storage: every parameter becomes a view into the engine's flat buffer
-    def _flat_ok(self):
-        if self._engine is None:
-            return False
-        eng = self._engine
-        base = eng.params.data_ptr()
-        o0, ol = eng.layout.slots[0][0], eng.layout.slots[-1][0]
-        return (self._plist[0].data_ptr() == base + 4 * o0 and self._plist[-1].data_ptr() == base + 4 * ol)
-
-    def _adopt(self, device):
-        cfg = dict(self._configs[0])
-        for k, dflt in (("lda_xl", 1.0), ("lda_xa", 1.0), ("lda_xv", 1.0), ("lda_mmd", 1.0)):
-            cfg.setdefault(k, dflt)
-        eng = E.MFMEngine([cfg] + list(self._configs[1:]), device=device)
-        assert list(eng.layout.shapes.keys()) == self._param_names, "parameter naming drifted from the reference"
-        pd = OrderedDict(self.named_parameters())
-        eng.load_weights(OrderedDict((n, p.detach()) for n, p in pd.items()))
-        views = eng.param_views()
-        for n, p in pd.items():
-            p.data = views[n]
-        self._engine = eng
-
-    @property
-    def engine(self):
-        """The fused engine sharing this module's parameter storage (build on first CUDA use)."""
-        if not self._flat_ok():
-            dev = next(self.parameters()).device
-            if dev.type != "cuda":
-                raise _lib.MfmError("MFM_KL_EF: parameters are on %s; move the model to the GPU first" % dev)
-            self._adopt(dev)
-        return self._engine
+        self._init_engine_slots()
 
     def forward(self, x):
         _require_cuda(x, "MFM_KL_EF.forward")
@@ -917,13 +927,15 @@ class MFN(nn.Module):
         return torch.cat([hl, ha, hv, mem], dim=1)
 
 
-class _FactorizedMFN(nn.Module):
+class _FactorizedMFN(_FusedEngineMixin, nn.Module):
     """Shared body of MFM (MMD regulariser, mfm_model.py:469-555) and MFM_KL (KLD, :662-764): the
     three HIP sequence encoders/decoders around the MFN fusion encoder."""
 
     def __init__(self, use_kl, config, NN1Config, NN2Config, gamma1Config, gamma2Config, outConfig):
         super(_FactorizedMFN, self).__init__()
         self._use_kl = use_kl
+        self._engine_variant = "kl" if use_kl else "mmd"
+        self._configs = [config, NN1Config, NN2Config, gamma1Config, gamma2Config, outConfig]
         [self.d_l, self.d_a, self.d_v] = config["input_dims"]
         [self.dh_l, self.dh_a, self.dh_v] = config["h_dims"]
         zy, zl, za, zv = config['zy_size'], config['zl_size'], config['za_size'], config['zv_size']
@@ -962,6 +974,7 @@ class _FactorizedMFN(nn.Module):
         self.fy_to_y_fc2 = HipLinear(fy, output_dim)
         self.fy_to_y_dropout = nn.Dropout(config['fy_to_y_dropout'])
         self.mmd_gauss = None      # optional injected N(0,1) samples [zl, za, zv, zy] (parity tests)
+        self._init_engine_slots()
 
     def forward(self, x):
         _require_cuda(x, "%s.forward" % type(self).__name__)

@@ -270,6 +270,33 @@ def test_driver_script_trains_and_scores(model):
     assert "scoring y_hat" in out.stdout and "mae: " in out.stdout and "Accuracy " in out.stdout
     ep = [l.split() for l in lines if l[:2] in ("0 ", "1 ")]
     assert len(ep) == 2 and all(np.isfinite(float(e[1])) and np.isfinite(float(e[2])) for e in ep)
+    # score() prints every line of the reference's (mfm_mosi.py:483-499)
+    for key in ("mae: ", "corr: ", "mult_acc: ", "mult f_score: ", "Confusion Matrix :", "Classification Report :"):
+        assert key in out.stdout, key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [["--model", "kl_ef", "--staged"], ["--model", "kl", "--staged", "--legacy-adam"],
+                                  ["--model", "mmd", "--staged"], ["--model", "kl_ef", "--task", "ce"],
+                                  ["--model", "kl", "--task", "ce"]])
+def test_driver_script_staged_and_classification_modes(args):
+    """train_beta_vae's two-stage schedule (mfm_mosi.py:225-361) for all three model classes, and the
+    classification drivers' cross-entropy mode (mfm_you.py:451-489, 556-564), end to end incl. the whole-module
+    checkpoint reload."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "mfm_test_mosi.py"), "--epochs", "2",
+                          "--n-train", "96"] + args, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l and l[0].isdigit() and l.split()[0].isdigit()]
+    n_ep = 4 if "--staged" in args else 2
+    ep = [l.split() for l in lines if len(l.split()) >= 3]
+    assert len(ep) >= n_ep and all(np.isfinite(float(e[1])) and np.isfinite(float(e[2])) for e in ep[:n_ep]), out.stdout
+    assert "scoring y_hat" in out.stdout and "Confusion Matrix :" in out.stdout and "Accuracy " in out.stdout
+    if "ce" not in args:
+        assert "mult f_score: " in out.stdout
 
 
 @pytest.mark.gpu
