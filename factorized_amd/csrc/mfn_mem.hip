@@ -25,6 +25,8 @@
 // saved tensors and are formed afterwards by the grouped GEMM (host side: mfm_model.py::_MemFn).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "internal.h"
 
 namespace mfm {
@@ -44,6 +46,18 @@ __device__ __forceinline__ float group_sum(float v, int Q) {
   if (Q >= 8) v += dpp_m<0x141>(v);     // row_half_mirror
   if (Q >= 16) v += dpp_m<0x140>(v);    // row_mirror
   return v;
+}
+
+// Stores of the time loops go through buffer instructions whose per-lane offset is pushed out of range for lanes
+// that have nothing to store: no store sits under a branch, so the compiler can count the memory operations between
+// a prefetch and its use (vmcnt(n) instead of vmcnt(0): with branches every step waited for its own stores to be
+// acknowledged, ~1 us each -- forward 52.8 -> ~25 us per launch at T = 20).
+constexpr int OOB = 0x7FFFFFF0;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mem_rsrc(const float* p, int64_t elems) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(elems * 4), 0x00020000);
+}
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int off_bytes, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off_bytes, 0, 0);
 }
 
 struct MemDev {
@@ -104,6 +118,10 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_fwd_kernel(const MemDev P) {
   float att_n = abuf[arow];
   float ch_n = d.chat[mrow];
   lds_barrier();
+  const int64_t TBl = (int64_t)T * B;
+  const __amdgpu_buffer_rsrc_t ra1 = mem_rsrc(d.a1, TBl * H1), ra2 = mem_rsrc(d.a2, TBl * H2);
+  const __amdgpu_buffer_rsrc_t rg1 = mem_rsrc(d.gam1, TBl * M), rg2 = mem_rsrc(d.gam2, TBl * M), rmm = mem_rsrc(d.mems, TBl * M);
+  const bool stA = actA && qa == 0, stB = actB && qb == 0;
 
   int cur = 0;
   for (int t = 0; t < T; ++t) {
@@ -126,9 +144,11 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_fwd_kernel(const MemDev P) {
         const uint64_t idx = ((uint64_t)(netA + 1) << 56) + ((uint64_t)t << 40) + (uint64_t)row * (uint64_t)Hn + (uint64_t)jn;
         u = (rng_uniform(seed, idx) < pA) ? 0.0f : u * keepA;
       }
-      if (actA && qa == 0) {
-        ab[ja] = u;
-        abuf[(int64_t)t * B * Hn + arow] = u;       // saved for the backward, in place over the input
+      if (stA) ab[ja] = u;
+      {   // saved for the backward, in place over the input
+        const int off = (int)(((int64_t)t * B * Hn + arow) * 4);
+        bstore(ra1, (stA && !netA) ? off : OOB, u);
+        bstore(ra2, (stA && netA) ? off : OOB, u);
       }
     }
     lds_barrier();
@@ -146,10 +166,10 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_fwd_kernel(const MemDev P) {
       z2 = group_sum(z2, QB) + bb2;
       const float g1 = act_sigmoid(z1), g2 = act_sigmoid(z2);
       memr = g1 * memr + g2 * ch;
-      if (actB && qb == 0) {
-        memb[(cur ^ 1) * M + mb] = memr;
-        const int64_t o = (int64_t)t * B * M + mrow;
-        d.gam1[o] = g1; d.gam2[o] = g2; d.mems[o] = memr;
+      if (stB) memb[(cur ^ 1) * M + mb] = memr;
+      {
+        const int off = stB ? (int)(((int64_t)t * B * M + mrow) * 4) : OOB;
+        bstore(rg1, off, g1); bstore(rg2, off, g2); bstore(rmm, off, memr);
       }
     }
     lds_barrier();
@@ -185,7 +205,6 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_bwd_kernel(const MemDev P) {
     wA[i] = (actA && i < KA && m < M) ? wb[(int64_t)min(m, M - 1) * Hn + jn] : 0.0f;
   }
   const float* abuf = netA ? d.a2 : d.a1;
-  float* dubuf = netA ? d.du2 : d.du1;
   const float pA = netA ? d.p2 : d.p1;
   const float keepA = (d.train && pA > 0.0f) ? ((pA < 1.0f) ? 1.0f / (1.0f - pA) : 0.0f) : 1.0f;
   // ---- role B (transposed memory columns): dmem[m] += sum_j Wm_n[j][m] du_n[j], both nets
@@ -207,6 +226,11 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_bwd_kernel(const MemDev P) {
   float g1_n = d.gam1[o], g2_n = d.gam2[o], ch_n = d.chat[o];
   float mp_n = (T > 1) ? d.mems[o - (int64_t)B * M] : 0.0f;
   float a_n = abuf[(int64_t)(T - 1) * B * Hn + arow];
+  const int64_t TBl = (int64_t)T * B;
+  const __amdgpu_buffer_rsrc_t rg1 = mem_rsrc(d.gam1, TBl * M), rg2 = mem_rsrc(d.gam2, TBl * M), rdc = mem_rsrc(d.dchat, TBl * M);
+  const __amdgpu_buffer_rsrc_t ru1 = mem_rsrc(d.du1, TBl * H1), ru2 = mem_rsrc(d.du2, TBl * H2);
+  const bool stA = actA && qa == 0, stB = actB && qb == 0;
+  const bool pre_tanh = d.dchat_pre_tanh != 0;
 
   for (int t = T - 1; t >= 0; --t) {
     const float g1 = g1_n, g2 = g2_n, ch = ch_n, mprev = mp_n, av = a_n;
@@ -220,11 +244,11 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_bwd_kernel(const MemDev P) {
     // ---- phase 1: gate gradients
     const float dz1 = dmem * mprev * g1 * (1.0f - g1);
     const float dz2 = dmem * ch * g2 * (1.0f - g2);
-    if (actB && qb == 0) {
-      dzb[mb] = dz1; dzb[M + mb] = dz2;
-      const int64_t oo = (int64_t)t * B * M + mrow;
-      d.gam1[oo] = dz1; d.gam2[oo] = dz2;          // in place: the weight-gradient GEMMs read dz from here
-      d.dchat[oo] = d.dchat_pre_tanh ? dmem * g2 * (1.0f - ch * ch) : dmem * g2;
+    if (stB) { dzb[mb] = dz1; dzb[M + mb] = dz2; }
+    {   // in place: the weight-gradient GEMMs read dz from gam1 / gam2
+      const int off = stB ? (int)(((int64_t)t * B * M + mrow) * 4) : OOB;
+      bstore(rg1, off, dz1); bstore(rg2, off, dz2);
+      bstore(rdc, off, pre_tanh ? dmem * g2 * (1.0f - ch * ch) : dmem * g2);
     }
     const float dmem_direct = dmem * g1;
     lds_barrier();
@@ -239,9 +263,11 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_bwd_kernel(const MemDev P) {
       }
       const float da = group_sum(s0 + s1, QA);
       const float du = (av > 0.0f) ? da * keepA : 0.0f;
-      if (actA && qa == 0) {
-        dub[ja] = du;
-        dubuf[(int64_t)t * B * Hn + arow] = du;
+      if (stA) dub[ja] = du;
+      {
+        const int off = (int)(((int64_t)t * B * Hn + arow) * 4);
+        bstore(ru1, (stA && !netA) ? off : OOB, du);
+        bstore(ru2, (stA && netA) ? off : OOB, du);
       }
     }
     lds_barrier();
@@ -267,6 +293,11 @@ int mem_setup(const MfmMemDesc* desc, MemDev& P, int& threads, size_t& lds) {
   MFM_REQUIRE(d.T >= 1 && d.B >= 1 && d.M >= 1 && d.H1 >= 1 && d.H2 >= 1, "mfn_mem: bad dims T=%d B=%d M=%d H=%d/%d", d.T, d.B, d.M, d.H1, d.H2);
   MFM_REQUIRE(d.a1 && d.a2 && d.chat && d.w1m && d.w2m && d.w1b && d.b1b && d.w2b && d.b2b && d.gam1 && d.gam2 && d.mems,
               "mfn_mem: null operand");
+  {
+    const int64_t widest = std::max<int64_t>(d.M, std::max(d.H1, d.H2));
+    MFM_REQUIRE((int64_t)d.T * d.B * widest * 4 < ((int64_t)1 << 31), "mfn_mem: T*B*width %lld exceeds the 2 GB buffer-addressing range",
+                (long long)((int64_t)d.T * d.B * widest));
+  }
   P.d = d;
   P.ldw = d.ld_wm > 0 ? d.ld_wm : d.M;
   P.QA = pow2_ge(cdiv(d.M, MEM_MAXW));
