@@ -1032,3 +1032,11 @@ class MFM_KL(_FactorizedMFN):
 
     def __init__(self, config, NN1Config, NN2Config, gamma1Config, gamma2Config, outConfig):
         super(MFM_KL, self).__init__(True, config, NN1Config, NN2Config, gamma1Config, gamma2Config, outConfig)
+
+
+# the reference keeps every model class in mfm_model.py: `from mfm_model import M_A, MFM_missing, ...` keeps working
+def __getattr__(name):
+    if name in ("M_A", "M_B", "M_C", "M_D", "MFM_missing", "seq2seq", "basic_missing"):
+        from . import mfm_extra
+        return getattr(mfm_extra, name)
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))

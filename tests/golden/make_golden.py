@@ -186,6 +186,53 @@ def run_staged(name, B, T, n1, n2):
           "bytes=%d" % os.path.getsize(os.path.join(HERE, name + ".npz")))
 
 
+EXTRA_SIZES = dict(input_dims=[37, 3, 11], h_dims=[40, 12, 20], memsize=24, zl_size=20, za_size=12, zv_size=36, zy_size=24,
+                   fy_size=12, fl_size=28, fa_size=4, fv_size=20)
+EXTRA = ["M_A", "M_B", "M_C", "M_D", "MFM_missing", "seq2seq", "basic_missing"]
+
+
+def run_extra(name, B=12, T=6):
+    """ablations M_A..M_D (mfm_model.py:201-467) and the missing-modality family (:766-1017): the REFERENCE classes'
+    forward outputs (summaries of every returned tensor, in order) and the gradient summaries of a scalar objective
+    that touches every output (oracle/mfm_oracle_extra.py::test_objective).  loss_MMD's torch.randn samples are
+    replaced by a seeded sequence that is stored next to the results."""
+    from oracle import mfm_oracle_extra as X
+    cfgs = C.canonical_configs(dropout=False, **EXTRA_SIZES)
+    cfgs[1]["shapes"], cfgs[2]["shapes"], cfgs[3]["shapes"], cfgs[4]["shapes"] = 36, 20, 28, 44
+    cfg = cfgs[0]
+    model = getattr(REF, name)(*cfgs)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    w = synth.make_weights(shapes, seed=1234)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()})
+    model.train()
+    xn, _ = synth.make_batch(cfg["input_dims"], B, T, seed=7)
+    x = torch.from_numpy(xn)
+    rs = np.random.RandomState(99)
+    zs = {"zl": cfg["zl_size"], "za": cfg["za_size"], "zv": cfg["zv_size"], "zy": cfg["zy_size"]}
+    gauss = [torch.from_numpy(rs.normal(size=(B, zs[k])).astype(np.float32)) for k in X.N_GAUSS[name]]
+    it = iter(gauss)
+    orig = torch.randn
+    torch.randn = lambda *a, **k: next(it)
+    try:
+        out = model.forward(x)
+    finally:
+        torch.randn = orig
+    flat = X.flatten_outputs(out)
+    X.test_objective(out).backward()
+    res = {"out_summary": np.stack([summarize(o) for o in flat]),
+           "out_shapes": np.array([list(o.shape) + [0] * (3 - o.dim()) for o in flat]),
+           "objective": np.float64(X.test_objective(out).item()),
+           "param_names": np.array([n for n, _ in model.named_parameters()]),
+           "grad_summary": np.stack([summarize(p.grad) if p.grad is not None else np.full(10, np.nan)
+                                     for _, p in model.named_parameters()]),
+           "meta": np.array([B, T])}
+    if gauss:
+        res["gauss"] = np.concatenate([g.numpy() for g in gauss], axis=1)
+    np.savez_compressed(os.path.join(HERE, "extra_%s.npz" % name), **res)
+    print("extra_" + name, "objective=%.6f" % res["objective"], "outputs=%d" % len(flat),
+          "bytes=%d" % os.path.getsize(os.path.join(HERE, "extra_%s.npz" % name)))
+
+
 STAGED = [("klef_staged_b32_t20", 32, 20, 4, 4)]
 # BASELINE config 4 (MOSEI shape, large batch): summaries + loss trace only
 LIGHT = [("klef_mosei_b1024_t20", "kl_ef", C.mosei_configs, {}, 1024, 20, 8)]
@@ -201,6 +248,10 @@ if __name__ == "__main__":
         if only and case[0] not in only:
             continue
         run_staged(*case)
+    for name in EXTRA:
+        if only and ("extra_" + name) not in only:
+            continue
+        run_extra(name)
     for case in LIGHT:
         if only and case[0] not in only:
             continue

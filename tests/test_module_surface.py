@@ -49,3 +49,19 @@ def test_loss_helpers_match_oracle():
     assert torch.allclose(M.loss_KLD(mu, lv), O.kld_sum(mu, lv))
     z, gs = torch.randn(6, 4, generator=g), torch.randn(6, 4, generator=g)
     assert torch.allclose(M.loss_MMD(z, gs), O.mmd(z, gs))
+
+
+def test_ablation_and_missing_modality_classes_keep_reference_state_dict():
+    """M_A..M_D, MFM_missing, seq2seq, basic_missing (reference mfm_model.py:201-467, 766-1017): same keys, order and
+    shapes as the oracle restatements, which tests/test_oracle_extra_golden.py pins to the reference itself; and they
+    are importable from mfm_model like in the reference."""
+    from oracle import mfm_oracle_extra as X
+    from tests.extra_cases import EXTRA, extra_configs
+    cfgs = extra_configs()
+    for name in EXTRA:
+        m = getattr(M, name)(*cfgs)
+        ref = X.CLASSES[name](*cfgs)
+        sd, rd = m.state_dict(), ref.state_dict()
+        assert list(sd.keys()) == list(rd.keys()), name
+        assert all(tuple(sd[k].shape) == tuple(rd[k].shape) for k in sd), name
+        m.load_state_dict(rd)
