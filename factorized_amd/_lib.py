@@ -131,6 +131,7 @@ _SIGS = {
     "mfm_plan_flops_per_step": (C.c_double, [C.c_void_p]),
     "mfm_plan_bytes_per_step": (C.c_double, [C.c_void_p]),
     "mfm_plan_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "mfm_plan_set_timing_every": (C.c_int, [C.c_void_p, C.c_int]),
     "mfm_plan_num_kernels": (C.c_int, []),
     "mfm_plan_kernel_name": (C.c_char_p, [C.c_int]),
     "mfm_plan_collect_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

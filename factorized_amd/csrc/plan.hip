@@ -116,7 +116,7 @@ struct MfmPlan {
   int lay_f1[4], lay_m1[4], lay_c1, lay_mc;   // record offsets kept for mfm_plan_latent_layout
   std::vector<int> lat_items;       // row-path item tables: forward then backward, [MAXSTAGES][1024][4] each
   // timing
-  int timing_mask;
+  int timing_mask, timing_every;
   std::vector<mfm::TimingPair> pool;
   size_t pool_used;
   uint64_t calls;
@@ -402,6 +402,9 @@ struct Timer {
   MfmPlan* P; hipStream_t s; int kid; TimingPair* tp;
   Timer(MfmPlan* P_, hipStream_t s_, int kid_) : P(P_), s(s_), kid(kid_), tp(nullptr) {
     if (!(P->timing_mask & (1 << kid))) return;
+    // sampled: a bracket is two extra packets on the stream (~4.6 us per bracket); timing every step would put that
+    // into every step of bench.py's timed region, so only every `timing_every`-th call of the plan is bracketed
+    if (P->timing_every > 1 && (P->calls % (uint64_t)P->timing_every) != 0) return;
     if (P->pool_used == P->pool.size()) {
       if (P->pool.size() >= 65536) return;
       TimingPair t; t.kid = -1;
@@ -1000,7 +1003,7 @@ extern "C" int mfm_plan_create(const MfmPlanConfig* cfg, const int64_t* param_of
     }
   }
   P->n_params = n_params_total;
-  P->timing_mask = 0; P->pool_used = 0; P->calls = 0; P->grads_prezeroed = nullptr;
+  P->timing_mask = 0; P->timing_every = 1; P->pool_used = 0; P->calls = 0; P->grads_prezeroed = nullptr;
   int rc = build(P);
   if (rc != MFM_OK) { delete P; return rc; }
   *out = P;
@@ -1155,6 +1158,11 @@ extern "C" int mfm_plan_mfn_layout(const MfmPlan* P, int64_t* out) {
 extern "C" int mfm_plan_set_timing(MfmPlan* P, int mask) {
   if (!P) return MFM_ERR_ARG;
   P->timing_mask = mask;
+  return MFM_OK;
+}
+extern "C" int mfm_plan_set_timing_every(MfmPlan* P, int every) {
+  if (!P || every < 1) return MFM_ERR_ARG;
+  P->timing_every = every;
   return MFM_OK;
 }
 extern "C" int mfm_plan_num_kernels(void) { return K_COUNT; }

@@ -337,6 +337,9 @@ double mfm_plan_bytes_per_step(const MfmPlan* plan);
  * mfm_plan_kernel_name); mfm_plan_collect_timing synchronises on the recorded events, returns
  * summed milliseconds and launch counts per kernel id and resets the recorder. */
 int mfm_plan_set_timing(MfmPlan* plan, int mask);
+/* bracket only every `every`-th step (default 1 = every step): an event bracket is two extra packets on the stream
+ * (mfm_timing_bracket_overhead_ms), which a timed region should not pay on every step */
+int mfm_plan_set_timing_every(MfmPlan* plan, int every);
 int mfm_plan_num_kernels(void);
 const char* mfm_plan_kernel_name(int kid);
 int mfm_plan_collect_timing(MfmPlan* plan, double* sum_ms, int64_t* count);

@@ -40,7 +40,7 @@ def test_extra_model_matches_oracle_and_reference(name):
     worst = 0.0
     for i, (a, b) in enumerate(zip(flat, rflat)):
         assert tuple(a.shape) == tuple(b.shape), i
-        if b.numel() and float(b.abs().max()) > 0:
+        if b.numel() and float(b.detach().abs().max()) > 0:
             worst = max(worst, rel_err(a.detach().cpu().numpy(), b.detach().numpy()))
     cases.report("extra_outputs_rel_%s" % name, worst)
     assert worst < TOL
