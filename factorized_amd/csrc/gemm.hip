@@ -25,8 +25,11 @@ constexpr int BK = 32;   // K depth of one LDS stage: 8 MFMA k-steps between bar
 // registers / 5 workgroups per CU for the 32x32 tiles, 158 / 3 for the 64x64 tiles, no spills; measured
 // against the compiler's default (108 / 4 and 188 / 2): +4 % on the whole step at B=2048, +1 % at B=32;
 // 6 waves (80 registers, 4 spilled) gains nothing more.
+// FR = 4: 128x128 tiles (each wave 64x64 = 16 accumulators) for launches with thousands of 64x64 tiles: twice the MFMA
+// work per staged byte and per barrier of the FR = 2 variant; 2 workgroups per CU (73 KB of LDS, <= 256 registers).
+// It carries no squared-error epilogue (64 more live registers): launches that need one stay on FR <= 2.
 template <int FR, bool VEC>
-__global__ __launch_bounds__(256, (FR == 1) ? (VEC ? 5 : 4) : 3) void gemm_f32_kernel(const GemmGroup g) {
+__global__ __launch_bounds__(256, (FR == 1) ? (VEC ? 5 : 4) : (FR == 2 ? 3 : 2)) void gemm_f32_kernel(const GemmGroup g) {
   constexpr int BM = 32 * FR, BN = 32 * FR;
   constexpr int LDA = BM + 16, LDB = BN + 16;     // [k][m] layout (m-/n-contiguous operands)
   constexpr int LDK = BK + 4;                     // [m][k] layout (k-contiguous operands)
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256, (FR == 1) ? (VEC ? 5 : 4) : 3) void gemm_f32_k
   //       MULTIPLY (a select/branch makes hipcc wait vmcnt(0) right behind the load);
   //   (b) the barriers are LDS-only (lds_barrier): __syncthreads() drains the ring with vmcnt(0);
   //   (c) the operand fragments of a tile are read from LDS before the first MFMA.
-  constexpr int DEPTH = (FR == 2) ? 2 : 3;
+  constexpr int DEPTH = (FR == 1) ? 3 : (FR == 2 ? 2 : 1);
   constexpr int GA = EPT_A / 4, GB = EPT_B / 4;
   float ra[DEPTH][EPT_A], rb[DEPTH][EPT_B];
   const int a_sm = (int)d.a_sm, a_sk = (int)d.a_sk, b_sk = (int)d.b_sk, b_sn = (int)d.b_sn;
@@ -186,10 +189,11 @@ __global__ __launch_bounds__(256, (FR == 1) ? (VEC ? 5 : 4) : 3) void gemm_f32_k
   };
 
   // squared-error epilogue: the targets of this thread's outputs are requested before the K loop
-  const bool do_mse = pi < g.mse_count;          // wave-uniform
+  const bool do_mse = (FR <= 2) && pi < g.mse_count;          // wave-uniform
   const MseEpi& me = g.mse[do_mse ? pi : 0];
-  float tgt[FR][FR][4];
-  if (do_mse) {
+  constexpr int TF = (FR <= 2) ? FR : 1;            // FR = 4 has no squared-error epilogue: no target registers
+  float tgt[TF][TF][4];
+  if constexpr (FR <= 2) if (do_mse) {
 #pragma unroll
     for (int fm = 0; fm < FR; ++fm)
 #pragma unroll
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256, (FR == 1) ? (VEC ? 5 : 4) : 3) void gemm_f32_k
       // operand fragments are read from LDS ahead of the MFMAs that use them: the whole tile for the 32x32
       // variant, half a tile at a time for the 64x64 one (its 4 accumulators already fill the register budget
       // that decides between 2 and 3 waves per SIMD)
-      constexpr int KSB = (FR == 2) ? BK / 8 : BK / 4;
+      constexpr int KSB = (FR == 1) ? BK / 4 : (FR == 2 ? BK / 8 : BK / 16);
 #pragma unroll
       for (int kb = 0; kb < BK / 4; kb += KSB) {
         float af[KSB][FR], bf[KSB][FR];
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256, (FR == 1) ? (VEC ? 5 : 4) : 3) void gemm_f32_k
     }
   }
 
-  gemm_epilogue<FR>(g, d, pi, z, split, m0, n0, wm, wn, bi, q, tid, lane, wave, acc, tgt, do_mse);
+  gemm_epilogue<FR, TF>(g, d, pi, z, split, m0, n0, wm, wn, bi, q, tid, lane, wave, acc, tgt, do_mse);
 }
 
 static int g_cus = 0;
@@ -317,7 +321,14 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
     blocks64 += (long)cdiv(d.m, 64) * cdiv(d.n, 64) * d.batch;
   }
   int FR = (blocks64 >= 2L * cus) ? 2 : 1;
-  if (const char* e = getenv("MFM_GEMM_FR")) FR = (e[0] == '2') ? 2 : 1;   // tuning override
+  // 128x128 tiles (FR = 4) are opt-in: on single large forward-layout products they add ~10 % over 64x64 (fp32:
+  // 61 -> 69 TF/s on the projection shape, 86 -> 99 TF/s at 4096^3), but the step's grouped launches mix in small-K
+  // and weight-gradient problems that lose more than that (proj launch at B=2048: 457 -> 514 us), and the bf16-operand
+  // kernel is faster at 64x64 throughout (profiles/r02_gemm_tiles.txt)
+  if (const char* e = getenv("MFM_GEMM_FR")) {      // tuning override
+    FR = (e[0] == '4') ? 4 : ((e[0] == '2') ? 2 : 1);
+    if (FR == 4 && mse_count > 0) FR = 2;
+  }
   const int BT = 32 * FR;
   long base_blocks = 0;
   for (int i = 0; i < count; ++i)
@@ -366,7 +377,10 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
   }
   for (int i = count; i < MFM_GEMM_MAXP; ++i) g.begins[i] = 0x7fffffff;
   if (bf16) return gemm_bf16_launch_kernel(g, FR, total, stream);
-  if (FR == 2) {
+  if (FR == 4) {
+    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<4, true>), dim3(total), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<4, false>), dim3(total), dim3(256), 0, stream, g);
+  } else if (FR == 2) {
     if (vec) hipLaunchKernelGGL((gemm_f32_kernel<2, true>), dim3(total), dim3(256), 0, stream, g);
     else hipLaunchKernelGGL((gemm_f32_kernel<2, false>), dim3(total), dim3(256), 0, stream, g);
   } else {

@@ -26,6 +26,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int FR>
 __global__ __launch_bounds__(256, (FR == 1) ? 4 : 2) void gemm_bf16_kernel(const GemmGroup g) {
+  static_assert(FR == 1 || FR == 2 || FR == 4, "tile sizes 32, 64, 128");
   constexpr int BM = 32 * FR, BN = 32 * FR;
   constexpr int LDK = BKB + 8;                       // bf16 elements per LDS row
   constexpr int EPT = BM * BKB / 256;                // fp32 elements per thread and operand tile: 8 / 16
@@ -113,9 +114,13 @@ __global__ __launch_bounds__(256, (FR == 1) ? 4 : 2) void gemm_bf16_kernel(const
         if constexpr (G == 2) {
           const f32x2 t = {r[0][e], r[1][e]};
           *reinterpret_cast<bf16x2*>(p) = __builtin_convertvector(t, bf16x2);
-        } else {
+        } else if constexpr (G == 4) {
           const f32x4 t = {r[0][e], r[1][e], r[2][e], r[3][e]};
           *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(t, bf16x4);
+        } else {
+          const f32x4 t0 = {r[0][e], r[1][e], r[2][e], r[3][e]}, t1 = {r[4][e], r[5][e], r[6][e], r[7][e]};
+          const bf16x4 b0 = __builtin_convertvector(t0, bf16x4), b1 = __builtin_convertvector(t1, bf16x4);
+          *reinterpret_cast<bf16x8*>(p) = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
         }
       }
     } else {
@@ -137,10 +142,11 @@ __global__ __launch_bounds__(256, (FR == 1) ? 4 : 2) void gemm_bf16_kernel(const
   };
 
   // squared-error epilogue: the targets of this thread's outputs are requested before the K loop
-  const bool do_mse = pi < g.mse_count;          // wave-uniform
+  const bool do_mse = (FR <= 2) && pi < g.mse_count;          // wave-uniform
   const MseEpi& me = g.mse[do_mse ? pi : 0];
-  float tgt[FR][FR][4];
-  if (do_mse) {
+  constexpr int TF = (FR <= 2) ? FR : 1;
+  float tgt[TF][TF][4];
+  if constexpr (FR <= 2) if (do_mse) {
 #pragma unroll
     for (int fm = 0; fm < FR; ++fm)
 #pragma unroll
@@ -187,11 +193,12 @@ __global__ __launch_bounds__(256, (FR == 1) ? 4 : 2) void gemm_bf16_kernel(const
     lds_barrier();
   }
 
-  gemm_epilogue<FR>(g, d, pi, z, split, m0, n0, wm, wn, bi, q, tid, lane, wave, acc, tgt, do_mse);
+  gemm_epilogue<FR, TF>(g, d, pi, z, split, m0, n0, wm, wn, bi, q, tid, lane, wave, acc, tgt, do_mse);
 }
 
 int gemm_bf16_launch_kernel(const GemmGroup& g, int FR, int total, hipStream_t stream) {
-  if (FR == 2) hipLaunchKernelGGL((gemm_bf16_kernel<2>), dim3(total), dim3(256), 0, stream, g);
+  if (FR == 4) hipLaunchKernelGGL((gemm_bf16_kernel<4>), dim3(total), dim3(256), 0, stream, g);
+  else if (FR == 2) hipLaunchKernelGGL((gemm_bf16_kernel<2>), dim3(total), dim3(256), 0, stream, g);
   else hipLaunchKernelGGL((gemm_bf16_kernel<1>), dim3(total), dim3(256), 0, stream, g);
   MFM_LAUNCH_CHECK("gemm_bf16_kernel");
   return MFM_OK;

@@ -35,11 +35,11 @@ struct GemmGroup {
 
 // Epilogue of one workgroup tile.  acc[fm][fn] follows the 16x16 MFMA accumulator map (row = 4*(lane>>4) + r,
 // col = lane & 15), identical for the f32 and bf16 instructions.
-template <int FR>
+template <int FR, int TF>
 __device__ __forceinline__ void gemm_epilogue(const GemmGroup& g, const MfmGemmDesc& d, const int pi, const int z,
                                               const int split, const int m0, const int n0, const int wm, const int wn,
                                               const int bi, const int q, const int tid, const int lane, const int wave,
-                                              f32x4 (&acc)[FR][FR], float (&tgt)[FR][FR][4], const bool do_mse) {
+                                              f32x4 (&acc)[FR][FR], float (&tgt)[TF][TF][4], const bool do_mse) {
   const MseEpi& me = g.mse[do_mse ? pi : 0];
   float* __restrict__ C = d.c + (int64_t)z * d.c_sz;
   float* __restrict__ C2 = d.c2 ? d.c2 + (int64_t)z * d.c_sz : nullptr;
@@ -86,7 +86,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmGroup& g, const MfmGemmD
           C[off] = v;
           if (C2) C2[off] = v;
           if (do_mse && col < d.n_valid) {
-            const float diff = v - tgt[fm][fn][r];
+            const float diff = v - tgt[fm % TF][fn % TF][r];
             sq += diff * diff;
             if (me.dxhat) me.dxhat[off] = me.grad_scale * diff;
           }

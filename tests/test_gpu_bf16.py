@@ -53,7 +53,7 @@ def seq_bf16(descs, T, B, backward=False):
 
 
 # ---------------------------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("fr", ["1", "2"])
+@pytest.mark.parametrize("fr", ["1", "2", "4"])
 @pytest.mark.parametrize("m,n,k", [(640, 128, 300), (37, 5, 11), (64, 64, 64), (1, 1, 1), (130, 70, 325), (2048, 96, 410)])
 def test_bf16_gemm_nt_bias(eng, m, n, k, fr, monkeypatch):
     """forward product layout (x W^T + b: both operands k-contiguous), strided A rows, pad columns"""
@@ -77,7 +77,7 @@ def test_bf16_gemm_nt_bias(eng, m, n, k, fr, monkeypatch):
         assert 1e-4 < rel_err(out[:, :n], full) < 3e-2
 
 
-@pytest.mark.parametrize("fr", ["1", "2"])
+@pytest.mark.parametrize("fr", ["1", "2", "4"])
 def test_bf16_gemm_tn_splitk_accumulate_dual_output(eng, fr, monkeypatch):
     """weight-gradient layout dW = dA^T X: BOTH operands contiguous along m / n (transposed in registers), batched
     over the four gates, split-K with atomics, second output"""

@@ -110,7 +110,7 @@ def test_you_shape_large_batch_matches_oracle(monkeypatch):
     _compare(configs.you_configs(dropout=False), 640, 50, loss_kind="ce", adam_steps=2, tag="you")
 
 
-@pytest.mark.parametrize("variant", ["staged", "fr2", "staged+fr2+mfma"])
+@pytest.mark.parametrize("variant", ["staged", "fr2", "fr4", "staged+fr2+mfma"])
 @pytest.mark.parametrize("name", cases.KLEF_CASES)
 def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
     """The same kernels forced onto every golden case (B = 1 .. 229, ragged sizes, T = 1, CE and 7-output heads):
@@ -124,6 +124,9 @@ def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
         monkeypatch.setenv("MFM_LATENT_PATH", "staged")
     if "fr2" in variant:
         monkeypatch.setenv("MFM_GEMM_FR", "2")
+    if "fr4" in variant:
+        monkeypatch.setenv("MFM_GEMM_FR", "4")     # gemm_f32_kernel<4,*>: 128x128 tiles (launches with a squared-error
+                                                   # epilogue stay on 64x64)
     if "mfma" in variant:
         monkeypatch.setenv("MFM_SEQ_PATH", "mfma")
     cs = cases.load_case(name)

@@ -24,8 +24,18 @@ def dev(a):
 
 
 # ---------------------------------------------------------------------------------- GEMM
+@pytest.fixture(params=["auto", "1", "2", "4"])
+def gemm_fr(request, monkeypatch):
+    """tile size of the grouped GEMM: 32x32, 64x64, 128x128 (gemm_f32_kernel<1|2|4, *>) or the launcher's own choice"""
+    if request.param == "auto":
+        monkeypatch.delenv("MFM_GEMM_FR", raising=False)
+    else:
+        monkeypatch.setenv("MFM_GEMM_FR", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("m,n,k", [(640, 128, 300), (37, 5, 11), (64, 64, 16), (1, 1, 1), (130, 70, 325)])
-def test_gemm_nt_bias(eng, m, n, k):
+def test_gemm_nt_bias(eng, m, n, k, gemm_fr):
     rs = np.random.RandomState(m + n + k)
     A = rs.normal(size=(m, k + 3)).astype(np.float32)     # row stride k+3: a strided slice
     W = rs.normal(size=(n, k)).astype(np.float32)
@@ -43,7 +53,7 @@ def test_gemm_nt_bias(eng, m, n, k):
     assert np.all(out[:, n:] == 0.0)            # pad columns are exact zeros
 
 
-def test_gemm_tn_splitk_accumulate_dual_output(eng):
+def test_gemm_tn_splitk_accumulate_dual_output(eng, gemm_fr):
     rs = np.random.RandomState(5)
     R, M, N = 640, 120, 325
     dA = rs.normal(size=(R, 4, 128)).astype(np.float32)      # [rows, gate, Hp]
@@ -59,7 +69,7 @@ def test_gemm_tn_splitk_accumulate_dual_output(eng):
     assert rel_err(c2.cpu().numpy(), ref) < 5e-6
 
 
-def test_gemm_nn_and_group_of_many(eng):
+def test_gemm_nn_and_group_of_many(eng, gemm_fr):
     rs = np.random.RandomState(9)
     descs, refs, outs = [], [], []
     for i in range(7):
