@@ -45,6 +45,21 @@ class DeviceDataset:
         self.y = torch.from_numpy(np.ascontiguousarray(y)).to(device)
         self.nb = nb
 
+    @classmethod
+    def from_arrays(cls, X, y, batchsize, device):
+        """X [T, N, D] time-major float32 (what `data.assemble` / the reference's `swapaxes(0,1)` produce), y [N] or
+        [N, k] -> the same HBM-resident `[nb, T, B, D]` batch layout; the tail that does not fill a batch is dropped
+        (mfm_mosi.py:423)."""
+        self = cls.__new__(cls)
+        T, N = X.shape[0], X.shape[1]
+        nb = N // batchsize
+        Xb = np.ascontiguousarray(X[:, :nb * batchsize].reshape(T, nb, batchsize, -1).transpose(1, 0, 2, 3))
+        yb = np.ascontiguousarray(np.asarray(y)[:nb * batchsize].reshape((nb, batchsize) + tuple(np.asarray(y).shape[1:])))
+        self.X = torch.from_numpy(Xb).to(device)
+        self.y = torch.from_numpy(yb).to(device)
+        self.nb = nb
+        return self
+
     def batch(self, i):
         return self.X[i], self.y[i]
 
