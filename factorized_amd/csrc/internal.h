@@ -23,6 +23,22 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
                       const MseEpi* mse = nullptr, int mse_count = 0, int precision = 0, const GemmEpiSet* epis = nullptr);
 int device_cus();
 
+// gemm_panel.hip -- row-panel GEMM for the large-batch input projections: the A rows stay in LDS, every column group
+// (weight block [n_valid, k_len] with row stride ldw, consuming panel columns [k_off, k_off + k_len)) is walked by the
+// same workgroup.  C columns [n_valid, n) are written as zeros (pad units).
+#define MFM_PANEL_MAXG 28
+struct PanelGroup {
+  const float* w; const float* bias; const float* bias2; float* c;
+  int64_t ldw, ldc;
+  int n, n_valid, k_off, k_len;
+};
+struct PanelLaunch {
+  const float* a; int64_t lda; int M, K;
+  PanelGroup g[MFM_PANEL_MAXG]; int ngroups;
+  float* zero_ptr[MFM_GEMM_ZSPANS]; int64_t zero_n[MFM_GEMM_ZSPANS];
+};
+int gemm_panel_launch(PanelLaunch& L, const ZeroSpans* zs, int precision, hipStream_t stream);
+
 // elementwise.hip
 struct MseItem {
   const float* xhat; const float* x; float* dxhat; float* loss_slot;

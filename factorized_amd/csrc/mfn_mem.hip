@@ -60,9 +60,14 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int off_bytes, 
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off_bytes, 0, 0);
 }
 
+// Matvec operand layout (round 2): lane q of a QA- / QB-lane group owns the CONTIGUOUS slice k in [32 q, 32 q + 32) of the
+// reduction dimension, so its 32 vector elements arrive as 8 ds_read_b128 (the first version interleaved k = q + Q i:
+// 96 ds_read_b32 per thread and step made the kernels LDS-instruction bound, ~2 us per step).  LDS vectors are padded to
+// 32 Q floats and zero-filled once; weights beyond the true extent are zero.
 struct MemDev {
   MfmMemDesc d;
   int QA, KA, QB, KB1, KB2;       // lanes per output / weights per lane of the two matvec shapes
+  int MP, H1P, H2P;               // LDS extents: 32 QA, 32 QB, 32 QB
   int64_t ldw;                    // row stride of the memory-column weight blocks
 };
 
@@ -74,9 +79,10 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_fwd_kernel(const MemDev P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const MfmMemDesc& d = P.d;
   const int T = d.T, B = d.B, M = d.M, H1 = d.H1, H2 = d.H2;
-  const int QA = P.QA, KA = P.KA, QB = P.QB;
-  float* memb = lds;                 // [2][M]
-  float* ab = lds + 2 * M;           // [H1 + H2] activations of the step
+  const int QA = P.QA, QB = P.QB;
+  const int MP = P.MP, H1P = P.H1P;
+  float* memb = lds;                 // [2][MP]
+  float* ab = lds + 2 * MP;          // [H1P + H2P] activations of the step
   const int row = blockIdx.x;
   const int tid = threadIdx.x;
 
@@ -90,8 +96,8 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_fwd_kernel(const MemDev P) {
   float wA[MEM_MAXW];
 #pragma unroll
   for (int i = 0; i < MEM_MAXW; ++i) {
-    const int k = qa + QA * i;
-    wA[i] = (actA && i < KA && k < M) ? wm[(int64_t)jn * P.ldw + min(k, M - 1)] : 0.0f;
+    const int k = MEM_MAXW * qa + i;
+    wA[i] = (actA && k < M) ? wm[(int64_t)jn * P.ldw + min(k, M - 1)] : 0.0f;
   }
   float* abuf = netA ? d.a2 : d.a1;
   const int Hn = netA ? H2 : H1;
@@ -104,14 +110,14 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_fwd_kernel(const MemDev P) {
   float wB1[MEM_MAXW], wB2[MEM_MAXW];
 #pragma unroll
   for (int i = 0; i < MEM_MAXW; ++i) {
-    const int k = qb + QB * i;
-    wB1[i] = (actB && i < P.KB1 && k < H1) ? d.w1b[(int64_t)mb * H1 + min(k, H1 - 1)] : 0.0f;
-    wB2[i] = (actB && i < P.KB2 && k < H2) ? d.w2b[(int64_t)mb * H2 + min(k, H2 - 1)] : 0.0f;
+    const int k = MEM_MAXW * qb + i;
+    wB1[i] = (actB && k < H1) ? d.w1b[(int64_t)mb * H1 + min(k, H1 - 1)] : 0.0f;
+    wB2[i] = (actB && k < H2) ? d.w2b[(int64_t)mb * H2 + min(k, H2 - 1)] : 0.0f;
   }
   const float bb1 = d.b1b[mb], bb2 = d.b2b[mb];
 
   const uint64_t seed = d.seed + (d.seed_dev ? *d.seed_dev : 0ull);
-  if (tid < 2 * M) memb[tid] = 0.0f;
+  for (int i = tid; i < 2 * MP + H1P + P.H2P; i += blockDim.x) lds[i] = 0.0f;
   float memr = 0.0f;                              // mem[mb], carried by lane q == 0 of the phase-B group
   const int64_t arow = ((int64_t)row) * Hn + jn;  // + t * B * Hn
   const int64_t mrow = ((int64_t)row) * M + mb;   // + t * B * M
@@ -131,12 +137,13 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_fwd_kernel(const MemDev P) {
     ch_n = d.chat[(int64_t)tn * B * M + mrow];
     // ---- phase A
     {
-      const float* mp = memb + cur * M + qa;
+      const f32x4* mp = reinterpret_cast<const f32x4*>(memb + cur * MP + MEM_MAXW * qa);
       float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
-      for (int i = 0; i < MEM_MAXW; i += 2) {
-        s0 = fmaf(wA[i], mp[min(QA * i, M - 1 - qa)], s0);
-        s1 = fmaf(wA[i + 1], mp[min(QA * (i + 1), M - 1 - qa)], s1);
+      for (int i = 0; i < MEM_MAXW / 4; ++i) {
+        const f32x4 v = mp[i];
+        s0 = fmaf(wA[4 * i], v[0], s0); s1 = fmaf(wA[4 * i + 1], v[1], s1);
+        s0 = fmaf(wA[4 * i + 2], v[2], s0); s1 = fmaf(wA[4 * i + 3], v[3], s1);
       }
       float u = group_sum(s0 + s1, QA) + att;
       u = fmaxf(u, 0.0f);
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_fwd_kernel(const MemDev P) {
         const uint64_t idx = ((uint64_t)(netA + 1) << 56) + ((uint64_t)t << 40) + (uint64_t)row * (uint64_t)Hn + (uint64_t)jn;
         u = (rng_uniform(seed, idx) < pA) ? 0.0f : u * keepA;
       }
-      if (stA) ab[ja] = u;
+      if (stA) ab[netA ? H1P + jn : jn] = u;
       {   // saved for the backward, in place over the input
         const int off = (int)(((int64_t)t * B * Hn + arow) * 4);
         bstore(ra1, (stA && !netA) ? off : OOB, u);
@@ -154,19 +161,20 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_fwd_kernel(const MemDev P) {
     lds_barrier();
     // ---- phase B + memory update
     {
-      const float* a1p = ab + qb;
-      const float* a2p = ab + H1 + qb;
+      const f32x4* a1p = reinterpret_cast<const f32x4*>(ab + MEM_MAXW * qb);
+      const f32x4* a2p = reinterpret_cast<const f32x4*>(ab + H1P + MEM_MAXW * qb);
       float z1 = 0.0f, z2 = 0.0f;
 #pragma unroll
-      for (int i = 0; i < MEM_MAXW; ++i) {
-        z1 = fmaf(wB1[i], a1p[min(QB * i, H1 - 1 - qb)], z1);
-        z2 = fmaf(wB2[i], a2p[min(QB * i, H2 - 1 - qb)], z2);
+      for (int i = 0; i < MEM_MAXW / 4; ++i) {
+        const f32x4 v1 = a1p[i], v2 = a2p[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { z1 = fmaf(wB1[4 * i + e], v1[e], z1); z2 = fmaf(wB2[4 * i + e], v2[e], z2); }
       }
       z1 = group_sum(z1, QB) + bb1;
       z2 = group_sum(z2, QB) + bb2;
       const float g1 = act_sigmoid(z1), g2 = act_sigmoid(z2);
       memr = g1 * memr + g2 * ch;
-      if (stB) memb[(cur ^ 1) * M + mb] = memr;
+      if (stB) memb[(cur ^ 1) * MP + mb] = memr;
       {
         const int off = stB ? (int)(((int64_t)t * B * M + mrow) * 4) : OOB;
         bstore(rg1, off, g1); bstore(rg2, off, g2); bstore(rmm, off, memr);
@@ -184,9 +192,12 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_bwd_kernel(const MemDev P) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const MfmMemDesc& d = P.d;
   const int T = d.T, B = d.B, M = d.M, H1 = d.H1, H2 = d.H2;
-  const int QA = P.QA, KA = P.KA, QB = P.QB;
-  float* dzb = lds;                  // [2][M]  dz of net 1 | net 2
-  float* dub = lds + 2 * M;          // [H1 + H2]
+  const int QA = P.QA, QB = P.QB;
+  const int MP = P.MP, H1P = P.H1P;
+  float* dzb = lds;                  // [2][MP]  dz of net 1 | net 2
+  float* dub = lds + 2 * MP;         // [H1P + H2P]
+  for (int i = threadIdx.x; i < 2 * MP + H1P + P.H2P; i += blockDim.x) lds[i] = 0.0f;
+  lds_barrier();
   const int row = blockIdx.x;
   const int tid = threadIdx.x;
 
@@ -201,8 +212,8 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_bwd_kernel(const MemDev P) {
   float wA[MEM_MAXW];
 #pragma unroll
   for (int i = 0; i < MEM_MAXW; ++i) {
-    const int m = qa + QA * i;
-    wA[i] = (actA && i < KA && m < M) ? wb[(int64_t)min(m, M - 1) * Hn + jn] : 0.0f;
+    const int m = MEM_MAXW * qa + i;
+    wA[i] = (actA && m < M) ? wb[(int64_t)min(m, M - 1) * Hn + jn] : 0.0f;
   }
   const float* abuf = netA ? d.a2 : d.a1;
   const float pA = netA ? d.p2 : d.p1;
@@ -214,9 +225,9 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_bwd_kernel(const MemDev P) {
   float wB1[MEM_MAXW], wB2[MEM_MAXW];
 #pragma unroll
   for (int i = 0; i < MEM_MAXW; ++i) {
-    const int j = qb + QB * i;
-    wB1[i] = (actB && i < P.KB1 && j < H1) ? d.w1m[(int64_t)min(j, H1 - 1) * P.ldw + mb] : 0.0f;
-    wB2[i] = (actB && i < P.KB2 && j < H2) ? d.w2m[(int64_t)min(j, H2 - 1) * P.ldw + mb] : 0.0f;
+    const int j = MEM_MAXW * qb + i;
+    wB1[i] = (actB && j < H1) ? d.w1m[(int64_t)min(j, H1 - 1) * P.ldw + mb] : 0.0f;
+    wB2[i] = (actB && j < H2) ? d.w2m[(int64_t)min(j, H2 - 1) * P.ldw + mb] : 0.0f;
   }
   const int64_t arow = ((int64_t)row) * Hn + jn;
   const int64_t mrow = ((int64_t)row) * M + mb;
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_bwd_kernel(const MemDev P) {
     // ---- phase 1: gate gradients
     const float dz1 = dmem * mprev * g1 * (1.0f - g1);
     const float dz2 = dmem * ch * g2 * (1.0f - g2);
-    if (stB) { dzb[mb] = dz1; dzb[M + mb] = dz2; }
+    if (stB) { dzb[mb] = dz1; dzb[MP + mb] = dz2; }
     {   // in place: the weight-gradient GEMMs read dz from gam1 / gam2
       const int off = stB ? (int)(((int64_t)t * B * M + mrow) * 4) : OOB;
       bstore(rg1, off, dz1); bstore(rg2, off, dz2);
@@ -254,16 +265,17 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_bwd_kernel(const MemDev P) {
     lds_barrier();
     // ---- phase 2: through gamma*_fc2 and the relu / dropout
     {
-      const float* zp = dzb + netA * M + qa;
+      const f32x4* zp = reinterpret_cast<const f32x4*>(dzb + netA * MP + MEM_MAXW * qa);
       float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
-      for (int i = 0; i < MEM_MAXW; i += 2) {
-        s0 = fmaf(wA[i], zp[min(QA * i, M - 1 - qa)], s0);
-        s1 = fmaf(wA[i + 1], zp[min(QA * (i + 1), M - 1 - qa)], s1);
+      for (int i = 0; i < MEM_MAXW / 4; ++i) {
+        const f32x4 v = zp[i];
+        s0 = fmaf(wA[4 * i], v[0], s0); s1 = fmaf(wA[4 * i + 1], v[1], s1);
+        s0 = fmaf(wA[4 * i + 2], v[2], s0); s1 = fmaf(wA[4 * i + 3], v[3], s1);
       }
       const float da = group_sum(s0 + s1, QA);
       const float du = (av > 0.0f) ? da * keepA : 0.0f;
-      if (stA) dub[ja] = du;
+      if (stA) dub[netA ? H1P + jn : jn] = du;
       {
         const int off = (int)(((int64_t)t * B * Hn + arow) * 4);
         bstore(ru1, (stA && !netA) ? off : OOB, du);
@@ -273,13 +285,14 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_bwd_kernel(const MemDev P) {
     lds_barrier();
     // ---- phase 3: into the memory
     {
-      const float* u1p = dub + qb;
-      const float* u2p = dub + H1 + qb;
+      const f32x4* u1p = reinterpret_cast<const f32x4*>(dub + MEM_MAXW * qb);
+      const f32x4* u2p = reinterpret_cast<const f32x4*>(dub + H1P + MEM_MAXW * qb);
       float s = 0.0f, s2 = 0.0f;
 #pragma unroll
-      for (int i = 0; i < MEM_MAXW; ++i) {
-        s = fmaf(wB1[i], u1p[min(QB * i, H1 - 1 - qb)], s);
-        s2 = fmaf(wB2[i], u2p[min(QB * i, H2 - 1 - qb)], s2);
+      for (int i = 0; i < MEM_MAXW / 4; ++i) {
+        const f32x4 v1 = u1p[i], v2 = u2p[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s = fmaf(wB1[4 * i + e], v1[e], s); s2 = fmaf(wB2[4 * i + e], v2[e], s2); }
       }
       dmem = dmem_direct + group_sum(s + s2, QB);
     }
@@ -311,8 +324,9 @@ int mem_setup(const MfmMemDesc* desc, MemDev& P, int& threads, size_t& lds) {
     set_error("mfn_mem: memory %d / gate hidden %d,%d do not fit the register-resident recurrence", d.M, d.H1, d.H2);
     return MFM_ERR_UNSUPPORTED;
   }
+  P.MP = MEM_MAXW * P.QA; P.H1P = MEM_MAXW * P.QB; P.H2P = MEM_MAXW * P.QB;
   threads = round_up(nA > nB ? nA : nB, 64);
-  lds = (size_t)(2 * d.M + d.H1 + d.H2) * sizeof(float);
+  lds = (size_t)(2 * P.MP + P.H1P + P.H2P) * sizeof(float);
   return MFM_OK;
 }
 

@@ -582,7 +582,33 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       d.m = (int)TB; d.n = sb.Hp; d.n_valid = sb.h; d.k = P->enc_d[e]; d.batch = 4; d.split_k = 1;
       d.alpha = 1.0f;
     }
-    RUN(K_PROJ, gemm_group_launch(g, P->n_enc, s, &zs, nullptr, 0, c.precision));
+    // large batches: the row-panel kernel reads x once for all encoders (gemm_panel.hip); below ~2 workgroup rounds of
+    // panels the tiled kernel's finer decomposition wins (MFM_PANEL_MINROWS overrides the threshold)
+    long min_rows = (c.precision ? 128L : 64L) * 2 * device_cus();
+    if (const char* e = getenv("MFM_PANEL_MINROWS")) min_rows = atol(e);
+    const bool panel = TB >= min_rows && 4 * P->n_enc <= MFM_PANEL_MAXG && (int64_t)TB * P->D < ((int64_t)1 << 29);
+    if (panel) {
+      PanelLaunch PL;
+      memset(&PL, 0, sizeof(PL));
+      PL.a = x; PL.lda = P->D; PL.M = (int)TB; PL.K = P->D;
+      for (int e = 0; e < P->n_enc; ++e) {
+        const SeqBuf& sb = P->enc[e];
+        const int pb = P->enc_p[e];
+        for (int gt = 0; gt < 4; ++gt) {
+          PanelGroup& G = PL.g[PL.ngroups++];
+          G.w = params + P->off[pb + W_IH] + (int64_t)gt * sb.h * P->enc_d[e]; G.ldw = P->enc_d[e];
+          G.bias = params + P->off[pb + B_IH] + gt * sb.h; G.bias2 = params + P->off[pb + B_HH] + gt * sb.h;
+          G.c = W + sb.gates + gt * sb.Hp; G.ldc = 4 * (int64_t)sb.Hp;
+          G.n = sb.Hp; G.n_valid = sb.h; G.k_off = P->enc_xoff[e]; G.k_len = P->enc_d[e];
+        }
+      }
+      int rc = MFM_ERR_UNSUPPORTED;
+      { Timer _t(P, s, K_PROJ); rc = gemm_panel_launch(PL, &zs, c.precision, s); }
+      if (rc == MFM_ERR_UNSUPPORTED) RUN(K_PROJ, gemm_group_launch(g, P->n_enc, s, &zs, nullptr, 0, c.precision));
+      else if (rc != MFM_OK) return rc;
+    } else {
+      RUN(K_PROJ, gemm_group_launch(g, P->n_enc, s, &zs, nullptr, 0, c.precision));
+    }
   }
   // F1: encoder recurrences (up to MFM_MAX_SEQ per launch)
   for (int e0 = 0; e0 < P->n_enc; e0 += MFM_MAX_SEQ) {

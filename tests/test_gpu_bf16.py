@@ -318,14 +318,18 @@ def _bf16_engine(cfgs):
     return e, w
 
 
-@pytest.fixture(params=["all-bf16", "default"])
+@pytest.fixture(params=["all-bf16", "default", "all-bf16+panel"])
 def seq_policy(request, monkeypatch):
     """a bf16 plan runs its recurrences on the bf16 MFMA kernels from B = 192 on and on the fp32 VALU kernels below
     (lstm_seq.hip::bf16_seq_pays); 'all-bf16' forces the bf16 kernels at every batch size."""
-    if request.param == "all-bf16":
+    if request.param.startswith("all-bf16"):
         monkeypatch.setenv("MFM_BF16_SEQ_MINB", "1")
     else:
         monkeypatch.delenv("MFM_BF16_SEQ_MINB", raising=False)
+    if "panel" in request.param:
+        monkeypatch.setenv("MFM_PANEL_MINROWS", "1")    # gemm_panel_kernel<true> for the input projections
+    else:
+        monkeypatch.delenv("MFM_PANEL_MINROWS", raising=False)
     return request.param
 
 

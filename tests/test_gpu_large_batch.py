@@ -5,6 +5,8 @@ B > 512 ran on kernels no oracle comparison reached).  Kernels named here, by th
   gemm_f32_kernel<2, true>                             64x64 tiles: blocks64 >= 2 CUs, or MFM_GEMM_FR=2
   lstm_seq_kernel<false|true, 0|1>                     MFMA recurrences (16 rows per workgroup): B > 512
   lstm_seq_small_kernel4<.., R=4, ..>                  4-row VALU tiles: 384 < B <= 512
+  gemm_panel_kernel<false|true>                        row-panel projection GEMM: T*B >= 2 rounds of panels (B >= 1639 fp32
+                                                       at T=20), or MFM_PANEL_MINROWS=1
 
 Tolerance: 1e-4 relative fp32 (BASELINE.json north_star), forward losses + all 78 gradients + 3 Adam steps."""
 import numpy as np
@@ -83,7 +85,7 @@ def _compare(cfgs, B, T, loss_kind="l1", adam_steps=3, tag=""):
         assert w_any < 1.01 * adam_steps * 1e-3, w_any
 
 
-@pytest.mark.parametrize("B", [512, 1024])
+@pytest.mark.parametrize("B", [512, 1024, 1700])
 def test_mosi_shape_large_batch_matches_oracle(B, monkeypatch):
     """Default path selection at B=512 (4-row VALU recurrences, staged latent, 32x32 or 64x64 GEMM tiles by block
     count) and B=1024 (MFMA recurrences lstm_seq_kernel<*,0|1>, latent_*_kernel<true>, gemm_f32_kernel<2,true>)."""
@@ -110,7 +112,7 @@ def test_you_shape_large_batch_matches_oracle(monkeypatch):
     _compare(configs.you_configs(dropout=False), 640, 50, loss_kind="ce", adam_steps=2, tag="you")
 
 
-@pytest.mark.parametrize("variant", ["staged", "fr2", "fr4", "staged+fr2+mfma"])
+@pytest.mark.parametrize("variant", ["staged", "fr2", "fr4", "panel", "staged+fr2+mfma"])
 @pytest.mark.parametrize("name", cases.KLEF_CASES)
 def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
     """The same kernels forced onto every golden case (B = 1 .. 229, ragged sizes, T = 1, CE and 7-output heads):
@@ -129,6 +131,10 @@ def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
                                                    # epilogue stay on 64x64)
     if "mfma" in variant:
         monkeypatch.setenv("MFM_SEQ_PATH", "mfma")
+    if "panel" in variant:
+        monkeypatch.setenv("MFM_PANEL_MINROWS", "1")    # gemm_panel_kernel<false>: the large-batch projection kernel
+    else:
+        monkeypatch.delenv("MFM_PANEL_MINROWS", raising=False)
     cs = cases.load_case(name)
     e = engine.MFMEngine(cs["cfgs"])
     w = synth.make_weights(e.layout.shapes, seed=1234)

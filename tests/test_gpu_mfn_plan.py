@@ -128,11 +128,16 @@ ODD_MFN = dict(input_dims=[37, 3, 11], h_dims=[40, 12, 20], memsize=24, zl_size=
                fy_size=12, fl_size=28, fa_size=4, fv_size=20)
 
 
+@pytest.mark.parametrize("panel", [False, True])
 @pytest.mark.parametrize("variant,B,T,od", [("kl", 19, 9, 1), ("mmd", 19, 9, 1), ("kl", 300, 6, 7), ("mmd", 5, 1, 1)])
-def test_fused_mfn_plan_odd_sizes_and_large_batch_vs_oracle(variant, B, T, od):
+def test_fused_mfn_plan_odd_sizes_and_large_batch_vs_oracle(variant, B, T, od, panel, monkeypatch):
     """ragged sizes (nothing a multiple of 16), 7-output head, T = 1, and a batch that takes the staged latent kernels
     and multi-row recurrence tiles; forward losses, every gradient, 3 Adam steps"""
     _need_gpu()
+    if panel:
+        monkeypatch.setenv("MFM_PANEL_MINROWS", "1")      # six LSTMs' projections (24 column groups) on the row-panel GEMM
+    else:
+        monkeypatch.delenv("MFM_PANEL_MINROWS", raising=False)
     cfgs = configs.canonical_configs(dropout=False, output_dim=od, **ODD_MFN)
     cfgs[1]["shapes"], cfgs[2]["shapes"], cfgs[3]["shapes"], cfgs[4]["shapes"] = 36, 20, 28, 44
     cfg = cfgs[0]
