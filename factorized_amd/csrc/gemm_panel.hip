@@ -11,8 +11,8 @@
 // shared panel: the l / a / v slices are column ranges of the same rows), and the only repeated traffic is the
 // weight set (0.8 MB, L2-resident) once per panel: 28 (fp32) / 56 (bf16) FLOP per loaded byte.
 //
-// Column groups: group = (weight block [n, k_len] row-major with row stride ldw, column offset k_off into the panel,
-// biases, C block).  K-tiles are taken on the PANEL's tile grid (multiples of BK from column 0), so the A fragments
+// Column groups: group = one LSTM: (weight block [4h, k_len] row-major with row stride ldw, column offset k_off into the
+// panel, biases, C block [., 4 Hp] with per-gate padding -- internal.h::PanelGroup).  K-tiles are taken on the PANEL's tile grid (multiples of BK from column 0), so the A fragments
 // are always aligned; a weight tile is addressed at (k - k_off) with 4-byte-aligned 16-byte buffer loads and masked
 // to [0, k_len): only the tiles that overlap a group's column range are visited.
 #include <stdlib.h>
@@ -57,18 +57,32 @@ __global__ __launch_bounds__(PANEL_THREADS) void gemm_panel_kernel(const PanelLa
     const int a_bytes = (int)(((int64_t)(L.M - 1) * L.lda + L.K) * 4);
     const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)L.a, 0, a_bytes, 0x00020000);
     const int groups_per_row = KT * BK / 4;
-    for (int idx = tid; idx < BM * groups_per_row; idx += PANEL_THREADS) {
-      const int r = idx / groups_per_row, k = (idx - r * groups_per_row) * 4;
-      const int row = m0 + r;
-      const int off = (int)(((int64_t)min(row, L.M - 1) * L.lda + min(k, L.K - 1)) * 4);
-      f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ares, off, 0, 0));
+    const int total = BM * groups_per_row;
+    constexpr int U = 8;                          // loads in flight per thread (a serial loop pays one HBM round trip per group)
+    for (int base = tid; base < total; base += PANEL_THREADS * U) {
+      f32x4 v[U];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (row < L.M && k + e < L.K) ? v[e] : 0.0f;
-      if constexpr (BF16) {
-        *reinterpret_cast<bf16x4*>(Ap + (size_t)r * LDA + k) = __builtin_convertvector(v, bf16x4);
-      } else {
+      for (int u = 0; u < U; ++u) {
+        const int idx = min(base + u * PANEL_THREADS, total - 1);
+        const int r = idx / groups_per_row, k = (idx - r * groups_per_row) * 4;
+        const int off = (int)(((int64_t)min(m0 + r, L.M - 1) * L.lda + min(k, L.K - 1)) * 4);
+        v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ares, off, 0, 0));
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Ap[(size_t)r * LDA + k + e] = v[e];
+      for (int u = 0; u < U; ++u) {
+        const int idx = base + u * PANEL_THREADS;
+        if (idx < total) {
+          const int r = idx / groups_per_row, k = (idx - r * groups_per_row) * 4;
+          f32x4 w = v[u];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w[e] = (m0 + r < L.M && k + e < L.K) ? w[e] : 0.0f;
+          if constexpr (BF16) {
+            *reinterpret_cast<bf16x4*>(Ap + (size_t)r * LDA + k) = __builtin_convertvector(w, bf16x4);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Ap[(size_t)r * LDA + k + e] = w[e];
+          }
+        }
       }
     }
   }
@@ -76,16 +90,30 @@ __global__ __launch_bounds__(PANEL_THREADS) void gemm_panel_kernel(const PanelLa
   // one "job" = (group, 128-column chunk); every job walks the K-tiles that overlap the group's column range
   f32x4 breg[GB];
   auto load_b = [&](const PanelGroup& G, const __amdgpu_buffer_rsrc_t wres, int n0, int kt) {
+    // a group whose column range does not start on a multiple of 4 needs elements BEFORE its first 16-byte group: a
+    // 16-byte load there would start in front of the weight block (a negative offset: the whole load reads 0, and the
+    // compiler merges four consecutive dword loads back into exactly that), so such groups (the 5- and 20-column
+    // modality slices) take dword loads at offsets clamped to the block and masked afterwards
+    const bool dwords = (G.k_off & 3) != 0;        // wave-uniform
 #pragma unroll
     for (int j = 0; j < GB; ++j) {
       const int idx = tid + j * PANEL_THREADS;
       const int nn = idx / (BK / 4), kk = (idx % (BK / 4)) * 4;
       const int n = n0 + nn;
+      const int sg = n / G.seg, u = n - sg * G.seg;
+      const bool nok = n < G.n && u < G.seg_valid;
+      const int wrow = nok ? sg * G.seg_valid + u : 0;
       const int ko = kt * BK + kk - G.k_off;                         // column inside the weight block
-      const int off = (int)(((int64_t)min(n, G.n_valid - 1) * G.ldw + ko) * 4);    // negative -> out of range -> 0
-      f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, off, 0, 0));
+      f32x4 v;
+      if (dwords) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= (float)((int)(n < G.n_valid) & (int)(ko + e >= 0) & (int)(ko + e < G.k_len));
+        for (int e = 0; e < 4; ++e)
+          v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wres, (int)(((int64_t)wrow * G.ldw + max(ko + e, 0)) * 4), 0, 0));
+      } else {
+        v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, (int)(((int64_t)wrow * G.ldw + max(ko, 0)) * 4), 0, 0));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= (float)((int)nok & (int)(ko + e >= 0) & (int)(ko + e < G.k_len));
       breg[j] = v;
     }
   };
@@ -102,7 +130,8 @@ __global__ __launch_bounds__(PANEL_THREADS) void gemm_panel_kernel(const PanelLa
 
   for (int gi = 0; gi < L.ngroups; ++gi) {
     const PanelGroup& G = L.g[gi];
-    const int w_bytes = (int)(((int64_t)(G.n_valid - 1) * G.ldw + G.k_len) * 4);
+    const int w_rows = (G.n / G.seg) * G.seg_valid;
+    const int w_bytes = (int)(((int64_t)(w_rows - 1) * G.ldw + G.k_len) * 4);
     const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)G.w, 0, w_bytes, 0x00020000);
     const int kt0 = G.k_off / BK, kt1 = (G.k_off + G.k_len + BK - 1) / BK;
     for (int n0 = 0; n0 < G.n; n0 += BN) {
@@ -163,11 +192,12 @@ __global__ __launch_bounds__(PANEL_THREADS) void gemm_panel_kernel(const PanelLa
         for (int fn = 0; fn < FN; ++fn) {
           const int col = n0 + wn * 16 * FN + fn * 16 + bi;
           if (col >= G.n) continue;
-          const bool cv = col < G.n_valid;
+          const int sg = col / G.seg, u = col - sg * G.seg;
+          const bool cv = u < G.seg_valid;
           float bsum = 0.0f;
           if (cv) {
-            if (G.bias) bsum += G.bias[col];
-            if (G.bias2) bsum += G.bias2[col];
+            if (G.bias) bsum += G.bias[sg * G.seg_valid + u];
+            if (G.bias2) bsum += G.bias2[sg * G.seg_valid + u];
           }
 #pragma unroll
           for (int fm = 0; fm < FM; ++fm)
@@ -197,8 +227,9 @@ int gemm_panel_launch(PanelLaunch& L, const ZeroSpans* zs, int precision, hipStr
   MFM_REQUIRE((int64_t)(L.M - 1) * L.lda + L.K < ((int64_t)1 << 29), "gemm panel: A spans >= 2^31 bytes");
   for (int i = 0; i < L.ngroups; ++i) {
     const PanelGroup& G = L.g[i];
-    MFM_REQUIRE(G.w && G.c && G.n >= 1 && G.n_valid >= 1 && G.n_valid <= G.n && G.k_len >= 1 && G.k_off >= 0 && G.k_off + G.k_len <= L.K,
-                "gemm panel: group %d: n=%d n_valid=%d k=[%d,+%d) of %d", i, G.n, G.n_valid, G.k_off, G.k_len, L.K);
+    MFM_REQUIRE(G.w && G.c && G.n >= 1 && G.seg >= 1 && G.n % G.seg == 0 && G.seg_valid >= 1 && G.seg_valid <= G.seg && G.k_len >= 1 &&
+                    G.k_off >= 0 && G.k_off + G.k_len <= L.K,
+                "gemm panel: group %d: n=%d seg=%d/%d k=[%d,+%d) of %d", i, G.n, G.seg_valid, G.seg, G.k_off, G.k_len, L.K);
   }
   memset(L.zero_ptr, 0, sizeof(L.zero_ptr));
   memset(L.zero_n, 0, sizeof(L.zero_n));

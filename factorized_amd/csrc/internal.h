@@ -30,7 +30,10 @@ int device_cus();
 struct PanelGroup {
   const float* w; const float* bias; const float* bias2; float* c;
   int64_t ldw, ldc;
-  int n, n_valid, k_off, k_len;
+  // n = nseg * seg output columns: column j belongs to segment j / seg (an LSTM gate) at position u = j % seg; it is a
+  // real unit when u < seg_valid, and then weight row / bias element (j / seg) * seg_valid + u produces it; pad
+  // columns are written as zeros.  (One LSTM = one group: nseg 4, seg Hp, seg_valid h.)
+  int n, seg, seg_valid, k_off, k_len;
 };
 struct PanelLaunch {
   const float* a; int64_t lda; int M, K;

@@ -582,11 +582,12 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       d.m = (int)TB; d.n = sb.Hp; d.n_valid = sb.h; d.k = P->enc_d[e]; d.batch = 4; d.split_k = 1;
       d.alpha = 1.0f;
     }
-    // large batches: the row-panel kernel reads x once for all encoders (gemm_panel.hip); below ~2 workgroup rounds of
-    // panels the tiled kernel's finer decomposition wins (MFM_PANEL_MINROWS overrides the threshold)
-    long min_rows = (c.precision ? 128L : 64L) * 2 * device_cus();
+    // large batches: the row-panel kernel reads x once for all encoders (gemm_panel.hip).  Measured crossover against
+    // the tiled kernel (profiles/r02_gemm_panel.txt): fp32 (64-row panels) from ~2 workgroup rounds, bf16 (128-row
+    // panels) from ~5/8 of one round; MFM_PANEL_MINROWS overrides the threshold
+    long min_rows = c.precision ? 128L * device_cus() * 5 / 8 : 64L * 2 * device_cus();
     if (const char* e = getenv("MFM_PANEL_MINROWS")) min_rows = atol(e);
-    const bool panel = TB >= min_rows && 4 * P->n_enc <= MFM_PANEL_MAXG && (int64_t)TB * P->D < ((int64_t)1 << 29);
+    const bool panel = TB >= min_rows && P->n_enc <= MFM_PANEL_MAXG && (int64_t)TB * P->D < ((int64_t)1 << 29);
     if (panel) {
       PanelLaunch PL;
       memset(&PL, 0, sizeof(PL));
@@ -594,13 +595,11 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       for (int e = 0; e < P->n_enc; ++e) {
         const SeqBuf& sb = P->enc[e];
         const int pb = P->enc_p[e];
-        for (int gt = 0; gt < 4; ++gt) {
-          PanelGroup& G = PL.g[PL.ngroups++];
-          G.w = params + P->off[pb + W_IH] + (int64_t)gt * sb.h * P->enc_d[e]; G.ldw = P->enc_d[e];
-          G.bias = params + P->off[pb + B_IH] + gt * sb.h; G.bias2 = params + P->off[pb + B_HH] + gt * sb.h;
-          G.c = W + sb.gates + gt * sb.Hp; G.ldc = 4 * (int64_t)sb.Hp;
-          G.n = sb.Hp; G.n_valid = sb.h; G.k_off = P->enc_xoff[e]; G.k_len = P->enc_d[e];
-        }
+        PanelGroup& G = PL.g[PL.ngroups++];
+        G.w = params + P->off[pb + W_IH]; G.ldw = P->enc_d[e];
+        G.bias = params + P->off[pb + B_IH]; G.bias2 = params + P->off[pb + B_HH];
+        G.c = W + sb.gates; G.ldc = 4 * (int64_t)sb.Hp;
+        G.n = 4 * sb.Hp; G.seg = sb.Hp; G.seg_valid = sb.h; G.k_off = P->enc_xoff[e]; G.k_len = P->enc_d[e];
       }
       int rc = MFM_ERR_UNSUPPORTED;
       { Timer _t(P, s, K_PROJ); rc = gemm_panel_launch(PL, &zs, c.precision, s); }
