@@ -5,7 +5,7 @@
 namespace mfm {
 
 // gemm.hip
-#define MFM_GEMM_ZSPANS 3
+#define MFM_GEMM_ZSPANS 4
 struct ZeroSpans { float* ptr[MFM_GEMM_ZSPANS]; int64_t n[MFM_GEMM_ZSPANS]; };   // spans (multiples of 4 floats, 16-byte aligned) a GEMM launch also clears
 // optional per-problem output transform, applied to the finished element v of C (non-accumulating problems):
 //   1  relu + dropout:  aux <- (v > 0) * scale,  v <- max(v, 0) * scale      scale = 0 | 1/(1-p) in train mode, else 1
@@ -41,6 +41,16 @@ struct PanelLaunch {
   float* zero_ptr[MFM_GEMM_ZSPANS]; int64_t zero_n[MFM_GEMM_ZSPANS];
 };
 int gemm_panel_launch(PanelLaunch& L, const ZeroSpans* zs, int precision, hipStream_t stream);
+
+// dec_fc1.hip -- decoder fc1 forward + squared-error loss + backward to the hidden states, one launch (fp32)
+struct DecFc1Item {
+  const float* hs; const float* w; const float* bias; const float* x;   // H [rows, Hp], Wfc [d, h], b [d], target columns (row stride ldx)
+  float* xhat; float* dxhat; float* dhs; float* loss;                   // [rows, d] (optional), [rows, d] (optional), [rows, Hp], slot
+  int64_t ldx; int d, h, Hp; float inv_count, grad_scale;
+  int tile_begin, col_groups, frags_per_group;                          // filled by dec_fc1_launch
+};
+struct DecFc1Launch { DecFc1Item it[3]; int n_items, rows, with_bwd; };
+int dec_fc1_launch(DecFc1Launch& L, bool dhs_zeroed, hipStream_t stream);
 
 // elementwise.hip
 struct MseItem {

@@ -104,6 +104,7 @@ struct MfmPlan {
   int64_t dcx[3];                    // d loss / d c_t of the MFN LSTMs [T,B,Hp] (dc_ext of the BPTT)
   int64_t cstar, h1, m1, att, attended, h2, m2, chat, a1, a2, gam1, gam2, mems, mem_out;
   int64_t zero_blk, zero_len;        // cleared by the step's first launch: zyin | d_hT | dmem | datt
+  int64_t dhs_blk, dhs_len;          // the decoders' dH buffers (cleared by the first launch when the fused fc1 kernel runs)
   int64_t zyin, d_hT, dmem, datt;
   int64_t du1, du2, dchat, dh2, dlog, dh1, dcs;
   int64_t lat_seed;                  // variant 2: gradient seed record of the latent backward (d MMD / d z)
@@ -121,6 +122,7 @@ struct MfmPlan {
   size_t pool_used;
   uint64_t calls;
   const float* grads_prezeroed;     // gradient buffer cleared by the forward pass of the running fused step
+  unsigned long long fc1_bwd_call = ~0ull;   // value of `calls` for which the forward already produced dH of the decoders (dec_fc1.hip)
 };
 
 namespace mfm {
@@ -174,12 +176,14 @@ static int build(MfmPlan* P) {
     s.hs = carve(cur, TB * s.Hp);
     s.cs = carve(cur, TB * s.Hp);
     s.wpack = c.precision ? carve(cur, mfm_lstm_pack_bytes(s.h, 1) / 4) : -1;
-    P->dec_dhs[m] = carve(cur, TB * s.Hp);
     P->dec_init[m] = carve(cur, (int64_t)c.B * s.h);
     P->dec_dinit[m] = carve(cur, (int64_t)c.B * s.h);
     P->xhat[m] = carve(cur, TB * dd[m]);
     P->dxhat[m] = carve(cur, TB * dd[m]);
   }
+  P->dhs_blk = cur;                                // one block: the fused fc1 kernel adds into it (dec_fc1.hip), zero span 3
+  for (int m = 0; m < 3; ++m) P->dec_dhs[m] = carve(cur, TB * P->dec[m].Hp);
+  P->dhs_len = cur - P->dhs_blk;
   // ---- Memory Fusion Network (variants 1, 2): every [T*B, .] tensor of the attention block and the memory recurrence
   P->tot = P->A2 = P->nzy = 0;
   if (V != 0) {
@@ -555,6 +559,13 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     P->grads_prezeroed = grads_to_zero;
   }
   if (V != 0) { zs.ptr[2] = W + P->zero_blk; zs.n[2] = P->zero_len; }
+  // fp32 plans: decoder fc1, the squared error AND (training) dH = dx_hat Wfc run as one launch (dec_fc1.hip) whose column
+  // groups add into dH; bf16 plans, shapes it does not take and MFM_FC1_FUSED=0 use the grouped GEMMs (F4, B0)
+  const bool fc1_env_on = !(getenv("MFM_FC1_FUSED") && atoi(getenv("MFM_FC1_FUSED")) == 0);
+  long fc1_max_rows = 5120;                        // measured crossover (profiles/r02_dec_fc1.txt)
+  if (const char* e = getenv("MFM_FC1_FUSED_MAXROWS")) fc1_max_rows = atol(e);
+  const bool fc1_fused = c.precision == 0 && fc1_env_on && TB <= fc1_max_rows;
+  if (fc1_fused && train) { zs.ptr[3] = W + P->dhs_blk; zs.n[3] = P->dhs_len; }
   P->calls++;
 
   // bf16 plans: the recurrences' weight fragments, rounded and packed once per step (lstm_seq_bf16.hip)
@@ -689,7 +700,23 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       me[m].inv_count = (float)(1.0 / cnt);
       me[m].grad_scale = (float)(2.0 * lda[m] / cnt);
     }
-    RUN(K_FC1_FWD, gemm_group_launch(g, 3, s, nullptr, me, 3, c.precision));
+    int rc = MFM_ERR_UNSUPPORTED;
+    if (fc1_fused) {
+      DecFc1Launch FL;
+      memset(&FL, 0, sizeof(FL));
+      FL.n_items = 3; FL.rows = (int)TB; FL.with_bwd = train ? 1 : 0;
+      for (int m = 0; m < 3; ++m) {
+        DecFc1Item& I = FL.it[m];
+        I.hs = g[m].a; I.w = g[m].b; I.bias = g[m].bias; I.x = me[m].x; I.ldx = me[m].ldx;
+        I.xhat = xh[m]; I.dxhat = me[m].dxhat; I.dhs = W + P->dec_dhs[m]; I.loss = me[m].loss;
+        I.d = P->dec_d[m]; I.h = P->dec[m].h; I.Hp = P->dec[m].Hp;
+        I.inv_count = me[m].inv_count; I.grad_scale = me[m].grad_scale;
+      }
+      { Timer _t(P, s, K_FC1_FWD); rc = dec_fc1_launch(FL, train != 0, s); }
+      if (rc == MFM_OK && train) P->fc1_bwd_call = P->calls;
+      else if (rc != MFM_OK && rc != MFM_ERR_UNSUPPORTED) return rc;
+    }
+    if (rc == MFM_ERR_UNSUPPORTED) RUN(K_FC1_FWD, gemm_group_launch(g, 3, s, nullptr, me, 3, c.precision));
   }
   (void)pi;
   return MFM_OK;
@@ -903,7 +930,9 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       bb.c = grads + P->off[pb + FC_B]; bb.ldc = 1; bb.n = 1; bb.n_valid = 1;
       tail.push_back(bb);
     }
-    RUN(K_FC1_BWD, gemm_group_launch(g.data(), (int)g.size(), s, nullptr, nullptr, 0, c.precision));
+    // dH is already there when this step's forward ran the fused fc1 kernel and the gradient is the plan's own d x_hat
+    const bool dh_done = !ext && P->fc1_bwd_call == P->calls;
+    if (!dh_done) RUN(K_FC1_BWD, gemm_group_launch(g.data(), (int)g.size(), s, nullptr, nullptr, 0, c.precision));
     // B1: decoder BPTT
     {
       MfmSeqDesc q[3];

@@ -5,6 +5,8 @@ B > 512 ran on kernels no oracle comparison reached).  Kernels named here, by th
   gemm_f32_kernel<2, true>                             64x64 tiles: blocks64 >= 2 CUs, or MFM_GEMM_FR=2
   lstm_seq_kernel<false|true, 0|1>                     MFMA recurrences (16 rows per workgroup): B > 512
   lstm_seq_small_kernel4<.., R=4, ..>                  4-row VALU tiles: 384 < B <= 512
+  dec_fc1_kernel                                       decoder fc1 + squared error + dH in one launch: fp32, T*B <= 5120 (default at
+                                                       the golden sizes; MFM_FC1_FUSED=0 -> the two GEMM launches)
   gemm_panel_kernel<false|true>                        row-panel projection GEMM: T*B >= 2 rounds of panels (B >= 1639 fp32
                                                        at T=20), or MFM_PANEL_MINROWS=1
 
@@ -95,6 +97,15 @@ def test_mosi_shape_large_batch_matches_oracle(B, monkeypatch):
     _compare(configs.canonical_configs(dropout=False), B, 20, tag="mosi")
 
 
+def test_fused_decoder_fc1_kernel_at_large_batch(monkeypatch):
+    """dec_fc1_kernel forced beyond its default row limit (2560 row tiles per decoder, ragged last tile: B=1023)."""
+    _need_gpu()
+    for k in ("MFM_SEQ_PATH", "MFM_SEQ_ROWS", "MFM_LATENT_PATH", "MFM_GEMM_FR", "MFM_SEQ_STEPWISE", "MFM_FC1_FUSED"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("MFM_FC1_FUSED_MAXROWS", "100000000")
+    _compare(configs.canonical_configs(dropout=False), 1023, 5, adam_steps=0, tag="fc1fused")
+
+
 def test_mosei_shape_large_batch_matches_oracle(monkeypatch):
     """BASELINE config 4's shape (300/74/35 features, 7 regression outputs) at B=1024, T=20 on the default
     large-batch path."""
@@ -112,7 +123,7 @@ def test_you_shape_large_batch_matches_oracle(monkeypatch):
     _compare(configs.you_configs(dropout=False), 640, 50, loss_kind="ce", adam_steps=2, tag="you")
 
 
-@pytest.mark.parametrize("variant", ["staged", "fr2", "fr4", "panel", "staged+fr2+mfma"])
+@pytest.mark.parametrize("variant", ["staged", "fr2", "fr4", "panel", "staged+fr2+mfma", "fc1gemm"])
 @pytest.mark.parametrize("name", cases.KLEF_CASES)
 def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
     """The same kernels forced onto every golden case (B = 1 .. 229, ragged sizes, T = 1, CE and 7-output heads):
@@ -131,6 +142,10 @@ def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
                                                    # epilogue stay on 64x64)
     if "mfma" in variant:
         monkeypatch.setenv("MFM_SEQ_PATH", "mfma")
+    if "fc1gemm" in variant:
+        monkeypatch.setenv("MFM_FC1_FUSED", "0")        # decoder fc1 as grouped GEMM + squared-error epilogue, dH as its own
+    else:                                               # launch (what T*B > 5120 and bf16 plans run) instead of dec_fc1_kernel
+        monkeypatch.delenv("MFM_FC1_FUSED", raising=False)
     if "panel" in variant:
         monkeypatch.setenv("MFM_PANEL_MINROWS", "1")    # gemm_panel_kernel<false>: the large-batch projection kernel
     else:
