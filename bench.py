@@ -108,7 +108,7 @@ def main():
     barrier()
     if dbg:
         sys.stderr.write("warmup done\n"); sys.stderr.flush()
-    e.set_timing(T, B, (1 << 20) - 1)
+    e.set_timing(T, B, (1 << 30) - 1)
     run(10, args.warmup)
     barrier()
     table = e.collect_timing(T, B)

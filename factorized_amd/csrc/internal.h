@@ -71,6 +71,20 @@ int mfn_dcs_scatter_launch(const MfnCs& c, const float* dcs, hipStream_t stream)
 int mfn_softmax_fwd_launch(float* att, const float* cstar, float* attended, int64_t rows, int n, hipStream_t stream);
 int mfn_softmax_bwd_launch(const float* datt, const float* att, const float* cstar, float* dlog, float* dcs, int64_t rows,
                            int n, hipStream_t stream);
+// mfn_att_fused.hip -- the whole attention block of the MFN per 16-row tile, one launch per direction (fp32, small T*B)
+struct MfnAttFused {
+  const float* cs[3]; float* dcx[3]; int h[3], Hp[3], off[3];         // the three MFN LSTMs' cell states / their gradients
+  int tot, A2, T, B, nn1, nn2, g1, g2, M;
+  const float *w_att1_1, *b_att1_1, *w_att1_2, *b_att1_2, *w_att2_1, *b_att2_1, *w_att2_2, *b_att2_2;
+  const float *w_gam1, *b_gam1, *w_gam2, *b_gam2;                      // gamma_n_fc1 [g_n, A2 + M]: the first A2 columns
+  float *cstar, *h1, *m1, *att, *attended, *h2, *m2, *a1, *a2, *chat;  // saved by the forward
+  const float *dchat, *du1, *du2;                                      // backward inputs (memory recurrence BPTT)
+  float *dh2, *dlog, *dh1;                                             // backward outputs for the weight-gradient GEMMs
+  float p1, p2; int train; unsigned long long seed;
+};
+bool mfn_att_fused_supported(const MfnAttFused& L);
+int mfn_att_fused_fwd_launch(const MfnAttFused& L, hipStream_t stream);
+int mfn_att_fused_bwd_launch(const MfnAttFused& L, hipStream_t stream);   // dcx must have been cleared (it is added to)
 // mmd.hip -- strided form of mfm_mmd_fwd_bwd: z / dz are column blocks of wider row-major buffers
 int mmd_launch(const float* z, int64_t ldz, const float* g, int64_t ldg, int B, int dim, float* loss, float* dz, int64_t lddz,
                float dz_scale, hipStream_t stream);

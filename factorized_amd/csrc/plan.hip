@@ -103,7 +103,7 @@ struct MfmPlan {
   int tot, A2, nzy;                  // sum of MFN hidden sizes, width of cStar, width of the latent's y input
   int64_t dcx[3];                    // d loss / d c_t of the MFN LSTMs [T,B,Hp] (dc_ext of the BPTT)
   int64_t cstar, h1, m1, att, attended, h2, m2, chat, a1, a2, gam1, gam2, mems, mem_out;
-  int64_t zero_blk, zero_len;        // cleared by the step's first launch: zyin | d_hT | dmem | datt
+  int64_t zero_blk, zero_len;        // cleared by the step's first launch: dcx | zyin | d_hT | dmem | datt
   int64_t dhs_blk, dhs_len;          // the decoders' dH buffers (cleared by the first launch when the fused fc1 kernel runs)
   int64_t zyin, d_hT, dmem, datt;
   int64_t du1, du2, dchat, dh2, dlog, dh1, dcs;
@@ -166,7 +166,6 @@ static int build(MfmPlan* P) {
     s.wpack = c.precision ? carve(cur, mfm_lstm_pack_bytes(s.h, 0) / 4) : -1;
     if (e < 4) P->dh_last[e] = -1;
     if (e < 3 || V == 0) P->dh_last[e] = carve(cur, (int64_t)c.B * P->enc_h[e]);
-    if (V != 0 && e >= 3) P->dcx[e - 3] = carve(cur, TB * s.Hp);
   }
   for (int m = 0; m < 3; ++m) {
     P->dec_d[m] = dd[m]; P->dec_h[m] = c.fy + fm[m]; P->dec_p[m] = pi.dec[m]; P->dec_xoff[m] = dx[m];
@@ -198,6 +197,7 @@ static int build(MfmPlan* P) {
     P->gam1 = carve(cur, TB * M); P->gam2 = carve(cur, TB * M); P->mems = carve(cur, TB * M);
     P->mem_out = carve(cur, (int64_t)c.B * M);
     P->zero_blk = cur;
+    for (int m = 0; m < 3; ++m) P->dcx[m] = carve(cur, TB * P->enc[3 + m].Hp);   // the fused attention backward adds into these
     P->zyin = carve(cur, (int64_t)c.B * P->nzy);
     P->d_hT = carve(cur, (int64_t)c.B * P->tot);
     P->dmem = carve(cur, (int64_t)c.B * M);
@@ -448,54 +448,94 @@ static inline const float* PW(const MfmPlan* P, const float* params, int idx) { 
 // ---- Memory Fusion Network, forward (reference mfm_model.py:140-199 restructured, see mfn_att.hip / mfn_mem.hip):
 // cStar gather -> att1_fc1 (+relu/dropout) -> att1_fc2 -> softmax * cStar -> {att2_fc1 (+relu/dropout), attended part
 // of gamma1_fc1 / gamma2_fc1} -> att2_fc2 (+tanh) -> memory recurrence -> heads on [h_l, h_a, h_v, mem]
+// The MFN attention block as one launch per direction (mfn_att_fused.hip): OPT-IN with MFM_MFN_FUSED=1 (fp32 plans, T*B up
+// to MFM_MFN_FUSED_MAXROWS, sizes that fit its LDS tiles).  Parity-tested on every MFN case, but measured slower than the
+// GEMM launches it replaces (60 vs ~46 us forward at T*B = 640: profiles/r02_mfn_att_fused.txt), so the default stays off.
+static bool mfn_fused_desc(const MfmPlan* P, const float* params, float* W, MfnAttFused& F) {
+  const MfmPlanConfig& c = P->cfg;
+  const PIdx& pi = P->pi;
+  memset(&F, 0, sizeof(F));
+  int off = 0;
+  for (int m = 0; m < 3; ++m) {
+    F.cs[m] = W + P->enc[3 + m].cs; F.dcx[m] = W + P->dcx[m];
+    F.h[m] = P->enc[3 + m].h; F.Hp[m] = P->enc[3 + m].Hp; F.off[m] = off; off += F.h[m];
+  }
+  F.tot = P->tot; F.A2 = P->A2; F.T = P->T; F.B = P->B;
+  F.nn1 = c.nn1; F.nn2 = c.nn2; F.g1 = c.g1; F.g2 = c.g2; F.M = c.mem_dim;
+  F.w_att1_1 = PW(P, params, pi.att1_1); F.b_att1_1 = PW(P, params, pi.att1_1 + 1);
+  F.w_att1_2 = PW(P, params, pi.att1_2); F.b_att1_2 = PW(P, params, pi.att1_2 + 1);
+  F.w_att2_1 = PW(P, params, pi.att2_1); F.b_att2_1 = PW(P, params, pi.att2_1 + 1);
+  F.w_att2_2 = PW(P, params, pi.att2_2); F.b_att2_2 = PW(P, params, pi.att2_2 + 1);
+  F.w_gam1 = PW(P, params, pi.g1_1); F.b_gam1 = PW(P, params, pi.g1_1 + 1);
+  F.w_gam2 = PW(P, params, pi.g2_1); F.b_gam2 = PW(P, params, pi.g2_1 + 1);
+  F.cstar = W + P->cstar; F.h1 = W + P->h1; F.m1 = W + P->m1; F.att = W + P->att; F.attended = W + P->attended;
+  F.h2 = W + P->h2; F.m2 = W + P->m2; F.a1 = W + P->a1; F.a2 = W + P->a2; F.chat = W + P->chat;
+  F.dchat = W + P->dchat; F.du1 = W + P->du1; F.du2 = W + P->du2;
+  F.dh2 = W + P->dh2; F.dlog = W + P->dlog; F.dh1 = W + P->dh1;
+  F.p1 = c.drop_nn1; F.p2 = c.drop_nn2;
+  if (c.precision != 0) return false;
+  const char* on = getenv("MFM_MFN_FUSED");
+  if (!on || atoi(on) == 0) return false;
+  long max_rows = 5120;
+  if (const char* e = getenv("MFM_MFN_FUSED_MAXROWS")) max_rows = atol(e);
+  if ((int64_t)P->T * P->B > max_rows) return false;
+  return mfn_att_fused_supported(F);
+}
+
 static int mfn_forward(MfmPlan* P, const float* params, int train, uint64_t seed, float* W, hipStream_t s) {
   const MfmPlanConfig& c = P->cfg;
   const PIdx& pi = P->pi;
   const int T = P->T, B = P->B, M = c.mem_dim, A2 = P->A2;
   const int64_t TB = (int64_t)T * B;
   const int prec = c.precision;
-  MfnCs cs;
-  memset(&cs, 0, sizeof(cs));
-  for (int m = 0; m < 3; ++m) { cs.cs[m] = W + P->enc[3 + m].cs; cs.h[m] = P->enc[3 + m].h; }
-  cs.T = T; cs.B = B;
-  RUN(K_MFN_GLUE, mfn_cstar_launch(cs, W + P->cstar, s));
-  auto lin = [&](const float* a, int lda, int k, int widx, int n, float* cout, int ldc, int ldw) {
-    MfmGemmDesc d;
-    memset(&d, 0, sizeof(d));
-    d.a = a; d.a_sm = lda; d.a_sk = 1;
-    d.b = PW(P, params, widx); d.b_sn = ldw; d.b_sk = 1;
-    d.c = cout; d.ldc = ldc; d.bias = PW(P, params, widx + 1);
-    d.m = (int)TB; d.n = n; d.n_valid = n; d.k = k; d.batch = 1; d.split_k = 1; d.alpha = 1.0f;
-    return d;
-  };
   GemmEpiSet es;
   memset(&es, 0, sizeof(es));
   es.seed = seed * 0x9E3779B97F4A7C15ull + P->calls; es.train = train;
-  {   // h1 = drop(relu(att1_fc1(cStar)))
-    MfmGemmDesc g = lin(W + P->cstar, A2, A2, pi.att1_1, c.nn1, W + P->h1, c.nn1, A2);
-    GemmEpi e = {W + P->m1, c.drop_nn1, 1, 101u, 0};
-    es.epi = &e; es.count = 1;
-    RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
-  }
-  {   // logits = att1_fc2(h1)
-    MfmGemmDesc g = lin(W + P->h1, c.nn1, c.nn1, pi.att1_2, A2, W + P->att, A2, c.nn1);
-    RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec));
-  }
-  RUN(K_MFN_GLUE, mfn_softmax_fwd_launch(W + P->att, W + P->cstar, W + P->attended, TB, A2, s));
-  {   // h2 = drop(relu(att2_fc1(attended))) ; a_n = gamma_n_fc1[:, :A2] attended + b   (the memory columns: mfn_mem)
-    MfmGemmDesc g[3];
-    g[0] = lin(W + P->attended, A2, A2, pi.att2_1, c.nn2, W + P->h2, c.nn2, A2);
-    g[1] = lin(W + P->attended, A2, A2, pi.g1_1, c.g1, W + P->a1, c.g1, A2 + M);
-    g[2] = lin(W + P->attended, A2, A2, pi.g2_1, c.g2, W + P->a2, c.g2, A2 + M);
-    GemmEpi e = {W + P->m2, c.drop_nn2, 1, 102u, 0};
-    es.epi = &e; es.count = 1;
-    RUN(K_MFN_ATT_FWD, gemm_group_launch(g, 3, s, nullptr, nullptr, 0, prec, &es));
-  }
-  {   // cHat = tanh(att2_fc2(h2))
-    MfmGemmDesc g = lin(W + P->h2, c.nn2, c.nn2, pi.att2_2, M, W + P->chat, M, c.nn2);
-    GemmEpi e = {nullptr, 0.0f, 2, 0u, 0};
-    es.epi = &e; es.count = 1;
-    RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
+  MfnAttFused F;
+  if (mfn_fused_desc(P, params, W, F)) {
+    F.train = train; F.seed = es.seed;
+    RUN(K_MFN_ATT_FWD, mfn_att_fused_fwd_launch(F, s));
+  } else {
+    MfnCs cs;
+    memset(&cs, 0, sizeof(cs));
+    for (int m = 0; m < 3; ++m) { cs.cs[m] = W + P->enc[3 + m].cs; cs.h[m] = P->enc[3 + m].h; }
+    cs.T = T; cs.B = B;
+    RUN(K_MFN_GLUE, mfn_cstar_launch(cs, W + P->cstar, s));
+    auto lin = [&](const float* a, int lda, int k, int widx, int n, float* cout, int ldc, int ldw) {
+      MfmGemmDesc d;
+      memset(&d, 0, sizeof(d));
+      d.a = a; d.a_sm = lda; d.a_sk = 1;
+      d.b = PW(P, params, widx); d.b_sn = ldw; d.b_sk = 1;
+      d.c = cout; d.ldc = ldc; d.bias = PW(P, params, widx + 1);
+      d.m = (int)TB; d.n = n; d.n_valid = n; d.k = k; d.batch = 1; d.split_k = 1; d.alpha = 1.0f;
+      return d;
+    };
+    {   // h1 = drop(relu(att1_fc1(cStar)))
+      MfmGemmDesc g = lin(W + P->cstar, A2, A2, pi.att1_1, c.nn1, W + P->h1, c.nn1, A2);
+      GemmEpi e = {W + P->m1, c.drop_nn1, 1, 101u, 0};
+      es.epi = &e; es.count = 1;
+      RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
+    }
+    {   // logits = att1_fc2(h1)
+      MfmGemmDesc g = lin(W + P->h1, c.nn1, c.nn1, pi.att1_2, A2, W + P->att, A2, c.nn1);
+      RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec));
+    }
+    RUN(K_MFN_GLUE, mfn_softmax_fwd_launch(W + P->att, W + P->cstar, W + P->attended, TB, A2, s));
+    {   // h2 = drop(relu(att2_fc1(attended))) ; a_n = gamma_n_fc1[:, :A2] attended + b   (the memory columns: mfn_mem)
+      MfmGemmDesc g[3];
+      g[0] = lin(W + P->attended, A2, A2, pi.att2_1, c.nn2, W + P->h2, c.nn2, A2);
+      g[1] = lin(W + P->attended, A2, A2, pi.g1_1, c.g1, W + P->a1, c.g1, A2 + M);
+      g[2] = lin(W + P->attended, A2, A2, pi.g2_1, c.g2, W + P->a2, c.g2, A2 + M);
+      GemmEpi e = {W + P->m2, c.drop_nn2, 1, 102u, 0};
+      es.epi = &e; es.count = 1;
+      RUN(K_MFN_ATT_FWD, gemm_group_launch(g, 3, s, nullptr, nullptr, 0, prec, &es));
+    }
+    {   // cHat = tanh(att2_fc2(h2))
+      MfmGemmDesc g = lin(W + P->h2, c.nn2, c.nn2, pi.att2_2, M, W + P->chat, M, c.nn2);
+      GemmEpi e = {nullptr, 0.0f, 2, 0u, 0};
+      es.epi = &e; es.count = 1;
+      RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
+    }
   }
   {   // gamma gates + memory update for all T (mfm_model.py:177-181)
     MfmMemDesc md;
@@ -834,36 +874,42 @@ static int mfn_backward(MfmPlan* P, const float* params, float* W, float* grads,
     md.p1 = c.drop_g1; md.p2 = c.drop_g2;
     RUN(K_MFN_MEM_BWD, mfm_mfn_mem_bwd(&md, s));
   }
-  {   // dh2 = d(pre cHat) W_att2_fc2, times the relu / dropout mask of att2_fc1's output
-    MfmGemmDesc g = nn(W + P->dchat, M, M, PW(P, params, pi.att2_2), c.nn2, c.nn2, W + P->dh2, c.nn2, TB, 0);
-    GemmEpi e = {W + P->m2, 0.0f, 3, 0u, 0};
-    es.epi = &e; es.count = 1;
-    RUN(K_MFN_ATT_BWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
-  }
-  {   // d attended = dh2 W_att2_fc1 + du1 W_gamma1_fc1[:, :A2] + du2 W_gamma2_fc1[:, :A2]   (into the zero-filled buffer)
-    MfmGemmDesc g[3];
-    g[0] = nn(W + P->dh2, c.nn2, c.nn2, PW(P, params, pi.att2_1), A2, A2, W + P->datt, A2, TB, 1);
-    g[1] = nn(W + P->du1, c.g1, c.g1, PW(P, params, pi.g1_1), A2 + M, A2, W + P->datt, A2, TB, 1);
-    g[2] = nn(W + P->du2, c.g2, c.g2, PW(P, params, pi.g2_1), A2 + M, A2, W + P->datt, A2, TB, 1);
-    RUN(K_MFN_ATT_BWD, gemm_group_launch(g, 3, s, nullptr, nullptr, 0, prec));
-  }
-  RUN(K_MFN_GLUE, mfn_softmax_bwd_launch(W + P->datt, W + P->att, W + P->cstar, W + P->dlog, W + P->dcs, TB, A2, s));
-  {   // dh1 = d logits W_att1_fc2, times the mask of att1_fc1's output
-    MfmGemmDesc g = nn(W + P->dlog, A2, A2, PW(P, params, pi.att1_2), c.nn1, c.nn1, W + P->dh1, c.nn1, TB, 0);
-    GemmEpi e = {W + P->m1, 0.0f, 3, 0u, 0};
-    es.epi = &e; es.count = 1;
-    RUN(K_MFN_ATT_BWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
-  }
-  {   // d cStar += dh1 W_att1_fc1   (on top of the softmax kernel's d attended * attention)
-    MfmGemmDesc g = nn(W + P->dh1, c.nn1, c.nn1, PW(P, params, pi.att1_1), A2, A2, W + P->dcs, A2, TB, 1);
-    RUN(K_MFN_ATT_BWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec));
-  }
-  {   // d cStar -> d c_t of the three LSTMs
-    MfnCs cs;
-    memset(&cs, 0, sizeof(cs));
-    for (int m = 0; m < 3; ++m) { cs.dcx[m] = W + P->dcx[m]; cs.h[m] = P->enc[3 + m].h; }
-    cs.T = T; cs.B = B;
-    RUN(K_MFN_GLUE, mfn_dcs_scatter_launch(cs, W + P->dcs, s));
+  MfnAttFused F;
+  if (mfn_fused_desc(P, params, W, F)) {
+    // one launch: dh2, d attended, softmax backward, dh1, d cStar and its scatter onto the LSTMs' dc (added into the zero block)
+    RUN(K_MFN_ATT_BWD, mfn_att_fused_bwd_launch(F, s));
+  } else {
+    {   // dh2 = d(pre cHat) W_att2_fc2, times the relu / dropout mask of att2_fc1's output
+      MfmGemmDesc g = nn(W + P->dchat, M, M, PW(P, params, pi.att2_2), c.nn2, c.nn2, W + P->dh2, c.nn2, TB, 0);
+      GemmEpi e = {W + P->m2, 0.0f, 3, 0u, 0};
+      es.epi = &e; es.count = 1;
+      RUN(K_MFN_ATT_BWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
+    }
+    {   // d attended = dh2 W_att2_fc1 + du1 W_gamma1_fc1[:, :A2] + du2 W_gamma2_fc1[:, :A2]   (into the zero-filled buffer)
+      MfmGemmDesc g[3];
+      g[0] = nn(W + P->dh2, c.nn2, c.nn2, PW(P, params, pi.att2_1), A2, A2, W + P->datt, A2, TB, 1);
+      g[1] = nn(W + P->du1, c.g1, c.g1, PW(P, params, pi.g1_1), A2 + M, A2, W + P->datt, A2, TB, 1);
+      g[2] = nn(W + P->du2, c.g2, c.g2, PW(P, params, pi.g2_1), A2 + M, A2, W + P->datt, A2, TB, 1);
+      RUN(K_MFN_ATT_BWD, gemm_group_launch(g, 3, s, nullptr, nullptr, 0, prec));
+    }
+    RUN(K_MFN_GLUE, mfn_softmax_bwd_launch(W + P->datt, W + P->att, W + P->cstar, W + P->dlog, W + P->dcs, TB, A2, s));
+    {   // dh1 = d logits W_att1_fc2, times the mask of att1_fc1's output
+      MfmGemmDesc g = nn(W + P->dlog, A2, A2, PW(P, params, pi.att1_2), c.nn1, c.nn1, W + P->dh1, c.nn1, TB, 0);
+      GemmEpi e = {W + P->m1, 0.0f, 3, 0u, 0};
+      es.epi = &e; es.count = 1;
+      RUN(K_MFN_ATT_BWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
+    }
+    {   // d cStar += dh1 W_att1_fc1   (on top of the softmax kernel's d attended * attention)
+      MfmGemmDesc g = nn(W + P->dh1, c.nn1, c.nn1, PW(P, params, pi.att1_1), A2, A2, W + P->dcs, A2, TB, 1);
+      RUN(K_MFN_ATT_BWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec));
+    }
+    {   // d cStar -> d c_t of the three LSTMs
+      MfnCs cs;
+      memset(&cs, 0, sizeof(cs));
+      for (int m = 0; m < 3; ++m) { cs.dcx[m] = W + P->dcx[m]; cs.h[m] = P->enc[3 + m].h; }
+      cs.T = T; cs.B = B;
+      RUN(K_MFN_GLUE, mfn_dcs_scatter_launch(cs, W + P->dcs, s));
+    }
   }
   // ---- weight gradients of the MFN Linears (sums over all T*B rows; biases = column sums)
   float* G = grads;

@@ -67,7 +67,8 @@ def test_klef_whole_module_checkpoint_roundtrip():
         d1, k1, _ = loaded.forward(x)
     for a, b in zip(d0, d1):
         assert torch.equal(a, b)
-    assert torch.equal(k0, k1)
+    # the KLD sum is accumulated with float atomics over the batch rows: equal up to the order of the additions
+    assert abs(float(k0) - float(k1)) <= 1e-6 * abs(float(k0))
     # the restored module trains, and its fused engine still shares the module's storage
     loaded.train()
     before = loaded.fy_to_y_fc2.weight.detach().clone()

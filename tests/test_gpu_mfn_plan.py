@@ -43,6 +43,19 @@ def _oracle(variant, cfgs, w, gauss=None):
     return m
 
 
+@pytest.fixture(params=["att-fused", "att-gemm"], autouse=True)
+def att_path(request, monkeypatch):
+    """Every test of this file runs on both forms of the MFN attention block: the grouped GEMMs + row kernels (the default)
+    and mfn_att_fwd_kernel / mfn_att_bwd_kernel (one launch per direction with every intermediate in LDS; opt-in with
+    MFM_MFN_FUSED=1 because it measured slower, forced here for any row count)."""
+    if request.param == "att-fused":
+        monkeypatch.setenv("MFM_MFN_FUSED", "1")
+        monkeypatch.setenv("MFM_MFN_FUSED_MAXROWS", "100000000")
+    else:
+        monkeypatch.setenv("MFM_MFN_FUSED", "0")
+    return request.param
+
+
 @pytest.mark.parametrize("name", ["kl_b32_t20", "mmd_b32_t20"])
 def test_fused_mfn_plan_matches_reference_golden_and_oracle(name):
     _need_gpu()
