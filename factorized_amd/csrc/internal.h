@@ -52,6 +52,21 @@ struct DecFc1Item {
 struct DecFc1Launch { DecFc1Item it[3]; int n_items, rows, with_bwd; };
 int dec_fc1_launch(DecFc1Launch& L, bool dhs_zeroed, hipStream_t stream);
 
+// dw_onepass.hip -- all weight gradients of one LSTM as ONE product over the rows (large T*B)
+#define MFM_DW_MAXI 12
+struct DwItem {
+  const float* dA; int ldA, M, Hp, h;          // gate-gradient buffer [rows, ldA]; M = 4 Hp columns walked; column m = gate * Hp + unit
+  const float* x; int64_t ldx; int dx;          // input rows (encoders; null / 0 for decoders)
+  const float* hs; int ldh, hN, shift;          // saved hidden states [rows, ldh]; row r pairs with hs[r - shift] (zero for r < shift)
+  float* c_x; int ldc_x;                        // dW_ih [4h, dx]
+  float* c_h; float* c_h2; int ldc_h;           // dW_hh [4h, hN] (and the decoders' dW_ih)
+  float* c_b; float* c_b2;                      // db_ih, db_hh [4h]
+  int tile_begin, m_tiles, splits, rows_per_split;     // filled by dw_onepass_launch
+};
+struct DwLaunch { DwItem it[MFM_DW_MAXI]; int n_items, rows; };
+int dw_onepass_supported(const DwItem& I, int precision);
+int dw_onepass_launch(DwLaunch& L, int precision, hipStream_t stream);
+
 // elementwise.hip
 struct MseItem {
   const float* xhat; const float* x; float* dxhat; float* loss_slot;
@@ -88,6 +103,10 @@ int mfn_att_fused_bwd_launch(const MfnAttFused& L, hipStream_t stream);   // dcx
 // mmd.hip -- strided form of mfm_mmd_fwd_bwd: z / dz are column blocks of wider row-major buffers
 int mmd_launch(const float* z, int64_t ldz, const float* g, int64_t ldg, int B, int dim, float* loss, float* dz, int64_t lddz,
                float dz_scale, hipStream_t stream);
+// up to 4 terms that share B, the row strides and the loss slot in one launch
+struct MmdItem { const float* z; const float* g; float* dz; int dim; };
+int mmd_group_launch(const MmdItem* items, int count, int64_t ldz, int64_t ldg, int64_t lddz, int B, float* loss,
+                     float dz_scale, hipStream_t stream);
 
 // latent.hip -- the fused "latent stack": encoder fc1 heads, mu/logvar heads, z->f MLPs,
 // classifier, KLD and discriminative loss, interpreted from a small op table.

@@ -15,10 +15,18 @@ namespace {
 constexpr int MT = 32;          // rows per tile
 constexpr int MMD_KMAX = 256;   // feature dimension limit (registers: dim/8 accumulators per thread)
 
-__global__ __launch_bounds__(256) void mmd_kernel(const float* __restrict__ z, const float* __restrict__ g, int B, int dim,
-                                                  float* __restrict__ loss, float* __restrict__ dz, float loss_scale,
+// up to 4 independent terms per launch (blockIdx.y): the non-KL MFM regularises z_l, z_a, z_v, z_y in one go
+struct MmdTerm { const float* z; const float* g; float* dz; int dim, pad_; };
+struct MmdGroup { MmdTerm t[4]; };
+
+__global__ __launch_bounds__(256) void mmd_kernel(const MmdGroup G, int B, float* __restrict__ loss, float loss_scale,
                                                   int64_t ldz, int64_t ldg, int64_t lddz, float dz_scale) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  const MmdTerm& M = G.t[blockIdx.y];
+  const float* __restrict__ z = M.z;
+  const float* __restrict__ g = M.g;
+  float* __restrict__ dz = M.dz;
+  const int dim = M.dim;
   const int ld = dim | 1;                         // odd row stride: conflict-free when lanes walk rows
   float* zi = lds;                                // [MT][ld]
   float* gi = zi + MT * ld;
@@ -109,18 +117,32 @@ __global__ __launch_bounds__(256) void mmd_kernel(const float* __restrict__ z, c
 
 }  // namespace
 
-int mmd_launch(const float* z, int64_t ldz, const float* g, int64_t ldg, int B, int dim, float* loss, float* dz, int64_t lddz,
-               float dz_scale, hipStream_t stream) {
-  MFM_REQUIRE(B >= 1 && dim >= 1, "mmd: B=%d dim=%d", B, dim);
-  if (dim > MMD_KMAX) { set_error("mmd: feature dimension %d > %d", dim, MMD_KMAX); return MFM_ERR_UNSUPPORTED; }
-  const int ld = dim | 1;
+int mmd_group_launch(const MmdItem* items, int count, int64_t ldz, int64_t ldg, int64_t lddz, int B, float* loss,
+                     float dz_scale, hipStream_t stream) {
+  MFM_REQUIRE(B >= 1 && count >= 1 && count <= 4, "mmd: B=%d terms=%d", B, count);
+  MmdGroup G;
+  memset(&G, 0, sizeof(G));
+  int dmax = 0;
+  for (int i = 0; i < count; ++i) {
+    MFM_REQUIRE(items[i].dim >= 1 && items[i].z && items[i].g, "mmd: term %d", i);
+    if (items[i].dim > MMD_KMAX) { set_error("mmd: feature dimension %d > %d", items[i].dim, MMD_KMAX); return MFM_ERR_UNSUPPORTED; }
+    G.t[i].z = items[i].z; G.t[i].g = items[i].g; G.t[i].dz = items[i].dz; G.t[i].dim = items[i].dim;
+    dmax = std::max(dmax, items[i].dim);
+  }
+  const int ld = dmax | 1;
   const size_t lds = ((size_t)4 * MT * ld + 2 * MT * (MT + 1)) * sizeof(float);
   if (lds > 64 * 1024)
     MFM_HIP_CHECK(hipFuncSetAttribute((const void*)mmd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(mmd_kernel, dim3(cdiv(B, MT)), dim3(256), lds, stream, z, g, B, dim, loss, dz,
-                     1.0f / ((float)B * (float)B), ldz, ldg, lddz, dz_scale);
+  hipLaunchKernelGGL(mmd_kernel, dim3(cdiv(B, MT), count), dim3(256), lds, stream, G, B, loss, 1.0f / ((float)B * (float)B),
+                     ldz, ldg, lddz, dz_scale);
   MFM_LAUNCH_CHECK("mmd_kernel");
   return MFM_OK;
+}
+
+int mmd_launch(const float* z, int64_t ldz, const float* g, int64_t ldg, int B, int dim, float* loss, float* dz, int64_t lddz,
+               float dz_scale, hipStream_t stream) {
+  MmdItem it = {z, g, dz, dim};
+  return mmd_group_launch(&it, 1, ldz, ldg, lddz, B, loss, dz_scale, stream);
 }
 
 }  // namespace mfm

@@ -697,11 +697,12 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     const int zn[4] = {c.zl, c.za, c.zv, c.zy};
     const int gl = c.zl + c.za + c.zv + c.zy;
     int goff = 0;
+    MmdItem it[4];
     for (int e = 0; e < 4; ++e) {
-      RUN(K_MMD, mmd_launch(W + P->lat_rec + P->z_seg[e], rs, P->gauss + goff, gl, B, zn[e], losses + 4,
-                            W + P->lat_seed + P->z_seg[e], rs, c.lda_reg, s));
+      it[e].z = W + P->lat_rec + P->z_seg[e]; it[e].g = P->gauss + goff; it[e].dz = W + P->lat_seed + P->z_seg[e]; it[e].dim = zn[e];
       goff += zn[e];
     }
+    RUN(K_MMD, mmd_group_launch(it, 4, rs, gl, rs, B, losses + 4, c.lda_reg, s));     // the four terms in one launch
   }
   // F3: decoder recurrences
   {
@@ -762,8 +763,9 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
   return MFM_OK;
 }
 
+// `only_init`: just the decoders' t = 0 input product (the rest went to the one-pass kernel, dw_onepass.hip)
 static void dA_gemms(const MfmPlan* P, const SeqBuf& sb, int pb, float* W, float* grads, std::vector<MfmGemmDesc>& out,
-                     const float* xin, int64_t ldx, int kin, bool dec) {
+                     const float* xin, int64_t ldx, int kin, bool dec, bool only_init = false) {
   const int T = P->T, B = P->B;
   const int64_t TB = (int64_t)T * B;
   MfmGemmDesc base;
@@ -771,7 +773,7 @@ static void dA_gemms(const MfmPlan* P, const SeqBuf& sb, int pb, float* W, float
   base.a_sz = sb.Hp; base.a_sm = 1; base.a_sk = 4 * (int64_t)sb.Hp;
   base.m = sb.h; base.batch = 4; base.accumulate = 1; base.split_k = 0; base.alpha = 1.0f;
   // recurrent product sum_{t>=1} dA_t^T h_{t-1}
-  if (T > 1) {
+  if (T > 1 && !only_init) {
     MfmGemmDesc d = base;
     d.a = W + sb.gates + (int64_t)B * 4 * sb.Hp;
     d.b = W + sb.hs; d.b_sk = sb.Hp; d.b_sn = 1;
@@ -790,7 +792,7 @@ static void dA_gemms(const MfmPlan* P, const SeqBuf& sb, int pb, float* W, float
     out.push_back(d);
   }
   // biases: column sums of dA (both b_ih and b_hh)
-  {
+  if (!only_init) {
     MfmGemmDesc d = base;
     d.a = W + sb.gates;
     d.b = W + P->ones; d.b_sk = 1; d.b_sn = 1;
@@ -1053,13 +1055,39 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     }
     RUN(K_ENC_BWD, seq_bf16 ? mfm_lstm_seq_bwd_bf16(q, n, T, B, s) : mfm_lstm_seq_bwd(q, n, T, B, s));
   }
-  // B5: all weight gradients
+  // B5: all weight gradients on the grouped TN GEMM.  Opt-in (MFM_DW_ONEPASS_MINROWS=<T*B from which to use it>): the
+  // LSTMs' sums over the rows on the one-pass kernel (dw_onepass.hip) -- parity-tested, measured slower at B=2048
   {
-    for (int e = 0; e < P->n_enc; ++e)
-      dA_gemms(P, P->enc[e], P->enc_p[e], W, grads, tail, x + P->enc_xoff[e], P->D, P->enc_d[e], false);
+    long dw_min_rows = 1L << 60;
+    if (const char* e = getenv("MFM_DW_ONEPASS_MINROWS")) dw_min_rows = atol(e);
+    const bool onepass = TB >= dw_min_rows && (int64_t)TB * P->D < ((int64_t)1 << 29);
+    DwLaunch DL;
+    memset(&DL, 0, sizeof(DL));
+    DL.rows = (int)TB;
+    auto item = [&](const SeqBuf& sb, int pb, const float* xin, int64_t ldx, int kin, bool dec) {
+      DwItem I;
+      memset(&I, 0, sizeof(I));
+      I.dA = W + sb.gates; I.ldA = 4 * sb.Hp; I.M = 4 * sb.Hp; I.Hp = sb.Hp; I.h = sb.h;
+      if (!dec) { I.x = xin; I.ldx = ldx; I.dx = kin; I.c_x = grads + P->off[pb + W_IH]; I.ldc_x = kin; }
+      I.hs = W + sb.hs; I.ldh = sb.Hp; I.hN = sb.h; I.shift = B;
+      I.c_h = grads + P->off[pb + W_HH]; I.ldc_h = sb.h;
+      if (dec) I.c_h2 = grads + P->off[pb + W_IH];          // steps >= 1 feed h back as the input (mfm_model.py:85)
+      I.c_b = grads + P->off[pb + B_IH]; I.c_b2 = grads + P->off[pb + B_HH];
+      return I;
+    };
+    for (int e = 0; e < P->n_enc; ++e) {
+      DwItem I = item(P->enc[e], P->enc_p[e], x + P->enc_xoff[e], P->D, P->enc_d[e], false);
+      if (onepass && DL.n_items < MFM_DW_MAXI && dw_onepass_supported(I, c.precision)) DL.it[DL.n_items++] = I;
+      else dA_gemms(P, P->enc[e], P->enc_p[e], W, grads, tail, x + P->enc_xoff[e], P->D, P->enc_d[e], false);
+    }
     if (gen_on)
-      for (int m = 0; m < 3; ++m)
-        dA_gemms(P, P->dec[m], P->dec_p[m], W, grads, tail, W + P->dec_init[m], P->dec_h[m], P->dec_h[m], true);
+      for (int m = 0; m < 3; ++m) {
+        DwItem I = item(P->dec[m], P->dec_p[m], nullptr, 0, 0, true);
+        const bool op = onepass && DL.n_items < MFM_DW_MAXI && dw_onepass_supported(I, c.precision);
+        if (op) DL.it[DL.n_items++] = I;
+        dA_gemms(P, P->dec[m], P->dec_p[m], W, grads, tail, W + P->dec_init[m], P->dec_h[m], P->dec_h[m], true, op);
+      }
+    if (DL.n_items > 0) RUN(K_DEC_DW, dw_onepass_launch(DL, c.precision, s));
     RUN(K_ENC_DW, c.precision ? mfm_gemm_grouped_bf16(tail.data(), (int)tail.size(), s)
                                 : mfm_gemm_grouped_f32(tail.data(), (int)tail.size(), s));
   }
@@ -1268,7 +1296,7 @@ extern "C" int mfm_plan_set_timing_every(MfmPlan* P, int every) {
 extern "C" int mfm_plan_num_kernels(void) { return K_COUNT; }
 extern "C" const char* mfm_plan_kernel_name(int kid) {
   static const char* names[K_COUNT] = {"proj_gemm", "enc_seq_fwd", "latent_fwd", "dec_seq_fwd", "fc1_mse_gemm", "mse",
-                                       "fc1_bwd_gemm", "dec_seq_bwd", "dec_dw_gemm", "latent_bwd", "enc_seq_bwd",
+                                       "fc1_bwd_gemm", "dec_seq_bwd", "lstm_dw_onepass", "latent_bwd", "enc_seq_bwd",
                                        "dw_gemm", "adam", "latent_dw_gemm", "bf16_weight_pack", "mfn_glue", "mfn_att_fwd_gemm",
                                        "mfn_mem_fwd", "mfn_heads_gemm", "mfn_mem_bwd", "mfn_att_bwd_gemm", "mmd"};
   return (kid >= 0 && kid < K_COUNT) ? names[kid] : "?";

@@ -6,13 +6,14 @@ Usage: scripts/make_traffic_json.py pmc_fetch_results.db pmc_write_results.db > 
 
 read  = 2 x FETCH_SIZE KiB (on gfx950 FETCH_SIZE counts 128-B requests as 64 B: MI355X_MICROARCH.md, HBM)
 write = WRITE_SIZE KiB (uncalibrated)
-The six grouped-GEMM launches of a step share one kernel symbol; they are told apart by their position
-between two Adam launches (plan.hip issues them in a fixed order)."""
+The grouped-GEMM launches of a step share one kernel symbol; they are told apart by their position between two Adam
+launches (plan.hip issues them in a fixed order): four per step when decoder fc1 runs as GEMMs, two (projection, weight
+gradients) when the fused dec_fc1_kernel takes fc1 + squared error + dH (the default up to 5120 rows)."""
 import json
 import sqlite3
 import sys
 
-GEMM_ORDER = ["proj_gemm", "fc1_mse_gemm", "fc1_bwd_gemm", "dw_gemm"]
+GEMM_ORDER = {4: ["proj_gemm", "fc1_mse_gemm", "fc1_bwd_gemm", "dw_gemm"], 2: ["proj_gemm", "dw_gemm"]}
 
 
 def classify(name):
@@ -26,6 +27,8 @@ def classify(name):
         return "latent_bwd"
     if "gemm_f32_kernel" in name:
         return "gemm"
+    if "dec_fc1_kernel" in name:
+        return "fc1_mse_gemm"          # the plan's timer id of that launch (K_FC1_FWD)
     if "mse_kernel" in name:
         return "mse"
     if "adam_kernel" in name:
@@ -37,17 +40,28 @@ def per_kernel(path, counter):
     c = sqlite3.connect(path)
     rows = c.execute("select dispatch_id, kernel_name, value from counters_collection where counter_name=? "
                      "order by dispatch_id", (counter,)).fetchall()
-    acc, gemm_pos = {}, 0
+    acc, step = {}, []
+
+    def flush():
+        gemms = [v for k, v in step if k == "gemm"]
+        names = GEMM_ORDER.get(len(gemms))
+        gi = 0
+        for k, v in step:
+            if k == "gemm":
+                if names is None:
+                    continue                      # a partial step at the start / end of the trace
+                k = names[gi]
+                gi += 1
+            acc.setdefault(k, []).append(v)
+        del step[:]
+
     for _, name, value in rows:
         k = classify(name)
         if k is None:
             continue
-        if k == "gemm":
-            k = GEMM_ORDER[gemm_pos % len(GEMM_ORDER)]
-            gemm_pos += 1
-        elif k == "adam":
-            gemm_pos = 0
-        acc.setdefault(k, []).append(value)
+        step.append((k, value))
+        if k == "adam":
+            flush()
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 

@@ -328,8 +328,10 @@ def seq_policy(request, monkeypatch):
         monkeypatch.delenv("MFM_BF16_SEQ_MINB", raising=False)
     if "panel" in request.param:
         monkeypatch.setenv("MFM_PANEL_MINROWS", "1")    # gemm_panel_kernel<true> for the input projections
+        monkeypatch.setenv("MFM_DW_ONEPASS_MINROWS", "1")   # and dw_onepass_kernel<true> for the LSTM weight gradients
     else:
         monkeypatch.delenv("MFM_PANEL_MINROWS", raising=False)
+        monkeypatch.delenv("MFM_DW_ONEPASS_MINROWS", raising=False)
     return request.param
 
 

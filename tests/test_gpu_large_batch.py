@@ -7,6 +7,7 @@ B > 512 ran on kernels no oracle comparison reached).  Kernels named here, by th
   lstm_seq_small_kernel4<.., R=4, ..>                  4-row VALU tiles: 384 < B <= 512
   dec_fc1_kernel                                       decoder fc1 + squared error + dH in one launch: fp32, T*B <= 5120 (default at
                                                        the golden sizes; MFM_FC1_FUSED=0 -> the two GEMM launches)
+  dw_onepass_kernel<false|true>                        LSTM weight gradients, one pass over dA: opt-in, MFM_DW_ONEPASS_MINROWS=1
   gemm_panel_kernel<false|true>                        row-panel projection GEMM: T*B >= 2 rounds of panels (B >= 1639 fp32
                                                        at T=20), or MFM_PANEL_MINROWS=1
 
@@ -123,7 +124,7 @@ def test_you_shape_large_batch_matches_oracle(monkeypatch):
     _compare(configs.you_configs(dropout=False), 640, 50, loss_kind="ce", adam_steps=2, tag="you")
 
 
-@pytest.mark.parametrize("variant", ["staged", "fr2", "fr4", "panel", "staged+fr2+mfma", "fc1gemm"])
+@pytest.mark.parametrize("variant", ["staged", "fr2", "fr4", "panel", "staged+fr2+mfma", "fc1gemm", "dwonepass"])
 @pytest.mark.parametrize("name", cases.KLEF_CASES)
 def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
     """The same kernels forced onto every golden case (B = 1 .. 229, ragged sizes, T = 1, CE and 7-output heads):
@@ -146,6 +147,10 @@ def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
         monkeypatch.setenv("MFM_FC1_FUSED", "0")        # decoder fc1 as grouped GEMM + squared-error epilogue, dH as its own
     else:                                               # launch (what T*B > 5120 and bf16 plans run) instead of dec_fc1_kernel
         monkeypatch.delenv("MFM_FC1_FUSED", raising=False)
+    if "dwonepass" in variant:
+        monkeypatch.setenv("MFM_DW_ONEPASS_MINROWS", "1")   # dw_onepass_kernel<false>: the LSTM weight gradients in one pass
+    else:                                                   # over dA (opt-in: measured slower than the GEMMs)
+        monkeypatch.delenv("MFM_DW_ONEPASS_MINROWS", raising=False)
     if "panel" in variant:
         monkeypatch.setenv("MFM_PANEL_MINROWS", "1")    # gemm_panel_kernel<false>: the large-batch projection kernel
     else:

@@ -149,8 +149,10 @@ def test_fused_mfn_plan_odd_sizes_and_large_batch_vs_oracle(variant, B, T, od, p
     _need_gpu()
     if panel:
         monkeypatch.setenv("MFM_PANEL_MINROWS", "1")      # six LSTMs' projections (24 column groups) on the row-panel GEMM
+        monkeypatch.setenv("MFM_DW_ONEPASS_MINROWS", "1")     # and their weight gradients on the one-pass kernel
     else:
         monkeypatch.delenv("MFM_PANEL_MINROWS", raising=False)
+        monkeypatch.delenv("MFM_DW_ONEPASS_MINROWS", raising=False)
     cfgs = configs.canonical_configs(dropout=False, output_dim=od, **ODD_MFN)
     cfgs[1]["shapes"], cfgs[2]["shapes"], cfgs[3]["shapes"], cfgs[4]["shapes"] = 36, 20, 28, 44
     cfg = cfgs[0]
