@@ -352,18 +352,25 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
 // --------------------------------------------------------------------------------- backward
 // Same LDS hand-over as the forward: the saved activations of step t-2 are fetched by 7*Hp*R/64 full waves
 // during step t and published one step later; dA_t leaves through the dA panel the matvec reads anyway.
-template <int KQ, int R>
+// KS = k-slices per unit pair (lanes that share a pair of output units and all-reduce their partial sums).  16: the layout
+// described at the top (8 * Hp threads).  8 (one-row tiles only): half the threads with twice the FMAs each and contiguous
+// gate columns per lane (c = 32 m + 4 q + e, one ds_read_b128 per 4 columns).  Built on the hypothesis that the step is
+// VALU-issue bound (~165 instructions per wave and step, 56 of them the recurrent FMAs); measured no faster (see
+// seq_small_launch), so it is opt-in (MFM_SEQ_KS=8) and parity-tested only.
+template <int KQ, int R, int KS = 16>
 __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds) {
   constexpr int HK = 4 * KQ;                       // padded hidden extent
   constexpr int HKB = (HK + 15) / 16 * 16;         // per-gate extent of the dA panel (multiple of 16) == Hp
-  constexpr int NG = HKB / 16;                     // gate columns per thread and gate
-  constexpr int NW = 4 * NG;                       // gate columns per thread: k = g*HKB + 16 i + q
-  constexpr int NTH = 8 * HKB;
+  static_assert(KS == 16 || (KS == 8 && R == 1), "8 k-slices: one-row tiles only");
+  constexpr int NG = HKB / 16;                     // gate columns per thread and gate (KS == 16)
+  constexpr int NW = 4 * HKB / KS;                 // gate columns per thread: KS 16: k = g*HKB + 16 i + q;  KS 8: c = 32 m + 4 q + e
+  constexpr int NB = NW / 4;                       // 16-byte column blocks per thread (KS == 8)
+  constexpr int NTH = (KS / 2) * HKB;
   constexpr int NV = 7;                            // staged values per (unit,row): gi gf gg go c_{t-1} dh_ext dc_ext
-  constexpr int NLD = (NV * R + 7) / 8;            // fetch elements per thread and step
-  constexpr int NST = (4 * R + 7) / 8;             // dA elements written per thread and step
+  constexpr int NLD = (NV * R + KS / 2 - 1) / (KS / 2);     // fetch elements per thread and step
+  constexpr int NST = (4 * R + KS / 2 - 1) / (KS / 2);      // dA elements written per thread and step
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int q = tid & 15, up = tid >> 4;
+  const int q = tid & (KS - 1), up = tid / KS;
   const int h = d.h, Hp = d.Hp;
   const bool dec = d.is_dec != 0;
   const bool has_dc = d.dc_ext != nullptr;
@@ -385,13 +392,32 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
     for (int g = 0; g < 4; ++g) {
       stage_gate(d, mode, g, panel, tid, nt);
       __syncthreads();
+      if constexpr (KS == 16) {
 #pragma unroll
-      for (int i = 0; i < NG; ++i) {
-        const int j = 16 * i + q;                    // unit index of this gate column
-        const int jc = min(j, h - 1);
-        const float va = panel[jc * h + uac], vb = panel[jc * h + ubc];
-        wa[g * NG + i] = (j < h && ua < h) ? va : 0.0f;
-        wb[g * NG + i] = (j < h && ub < h) ? vb : 0.0f;
+        for (int i = 0; i < NG; ++i) {
+          const int j = 16 * i + q;                    // unit index of this gate column
+          const int jc = min(j, h - 1);
+          const float va = panel[jc * h + uac], vb = panel[jc * h + ubc];
+          wa[g * NG + i] = (j < h && ua < h) ? va : 0.0f;
+          wb[g * NG + i] = (j < h && ub < h) ? vb : 0.0f;
+        }
+      } else {
+        // block m of this lane = flat gate columns 32 m + 4 q + {0..3}; a block never straddles two gates (HKB % 4 == 0)
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+          const int c0 = 32 * m + 4 * q;
+          const int cg = c0 / HKB, j0 = c0 - cg * HKB;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int j = j0 + e;
+            const int jc = min(j, h - 1);
+            const float va = panel[jc * h + uac], vb = panel[jc * h + ubc];
+            const float na = (j < h && ua < h) ? va : 0.0f, nb = (j < h && ub < h) ? vb : 0.0f;
+            if (g == 0) { wa[4 * m + e] = 0.0f; wb[4 * m + e] = 0.0f; }
+            wa[4 * m + e] = (cg == g) ? na : wa[4 * m + e];
+            wb[4 * m + e] = (cg == g) ? nb : wb[4 * m + e];
+          }
+        }
       }
       __syncthreads();
     }
@@ -508,31 +534,52 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
       float aa[R], ab[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) { aa[r] = 0.0f; ab[r] = 0.0f; }
-      const float* dp = db + q * R;
-      constexpr int RING = (NW < 4) ? NW : 4;
-      RowVec<R> ring[RING];
+      if constexpr (KS == 16) {
+        const float* dp = db + q * R;
+        constexpr int RING = (NW < 4) ? NW : 4;
+        RowVec<R> ring[RING];
 #pragma unroll
-      for (int i = 0; i < RING; ++i) ring[i] = ld_rows<R>(dp + 16 * R * i);
+        for (int i = 0; i < RING; ++i) ring[i] = ld_rows<R>(dp + 16 * R * i);
 #pragma unroll
-      for (int i = 0; i < NW; ++i) {
-        const RowVec<R> dv = ring[i % RING];                               // the R rows of column 16i+q
-        if (i + RING < NW) ring[i % RING] = ld_rows<R>(dp + 16 * R * (i + RING));
+        for (int i = 0; i < NW; ++i) {
+          const RowVec<R> dv = ring[i % RING];                               // the R rows of column 16i+q
+          if (i + RING < NW) ring[i % RING] = ld_rows<R>(dp + 16 * R * (i + RING));
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          aa[r] = fmaf(wa[i], dv.v[r], aa[r]);
-          ab[r] = fmaf(wb[i], dv.v[r], ab[r]);
+          for (int r = 0; r < R; ++r) {
+            aa[r] = fmaf(wa[i], dv.v[r], aa[r]);
+            ab[r] = fmaf(wb[i], dv.v[r], ab[r]);
+          }
+        }
+      } else {
+        const float* dp = db + 4 * q;
+        constexpr int RING = (NB < 4) ? NB : 4;
+        f32x4 ring[RING];
+#pragma unroll
+        for (int i = 0; i < RING; ++i) ring[i] = *reinterpret_cast<const f32x4*>(dp + 32 * i);
+#pragma unroll
+        for (int m = 0; m < NB; ++m) {
+          const f32x4 dv = ring[m % RING];                                   // gate columns 32 m + 4 q + {0..3}
+          if (m + RING < NB) ring[m % RING] = *reinterpret_cast<const f32x4*>(dp + 32 * (m + RING));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            aa[0] = fmaf(wa[4 * m + e], dv[e], aa[0]);
+            ab[0] = fmaf(wb[4 * m + e], dv[e], ab[0]);
+          }
         }
       }
-      // all-reduce over the 16 k-slices
+      // all-reduce over the k-slices (after the two quad steps every lane of a quad holds the quad's sum, so the mirror
+      // steps only have to bring in the other quads)
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         float v = aa[r];
         v += dpp_f<DPP_QUAD_XOR1>(v); v += dpp_f<DPP_QUAD_XOR2>(v);
-        v += dpp_f<DPP_ROW_HALF_MIRROR>(v); v += dpp_f<DPP_ROW_MIRROR>(v);
+        v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
+        if constexpr (KS == 16) v += dpp_f<DPP_ROW_MIRROR>(v);
         aa[r] = v;
         v = ab[r];
         v += dpp_f<DPP_QUAD_XOR1>(v); v += dpp_f<DPP_QUAD_XOR2>(v);
-        v += dpp_f<DPP_ROW_HALF_MIRROR>(v); v += dpp_f<DPP_ROW_MIRROR>(v);
+        v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
+        if constexpr (KS == 16) v += dpp_f<DPP_ROW_MIRROR>(v);
         ab[r] = v;
       }
       const float sa = sel_row<R>(aa, mrc), sb2 = sel_row<R>(ab, mrc);
@@ -617,8 +664,10 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_kernel(const SeqLaunch L)
 // 16 the register allocator reaches single-variant quality (the 16-way switch spills ~80 VGPRs in the
 // forward time loop, 4x slower).  The canonical MFM sizes (encoders 32/8/80/120, decoders 104/24/24)
 // are pre-instantiated; any other size combination takes the generic kernel above.
-template <bool BWD, int R, int K0, int K1, int K2, int K3>
-__global__ __launch_bounds__(1024) void lstm_seq_small_kernel4(const SeqLaunch L) {
+// KS = 8 (backward, one-row tiles): 4 * Hp threads per workgroup, launched with at most 512 -> 256 VGPRs per thread for
+// the doubled resident weights.
+template <bool BWD, int R, int K0, int K1, int K2, int K3, int KS = 16>
+__global__ __launch_bounds__(KS == 16 ? 1024 : 512) void lstm_seq_small_kernel4(const SeqLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int di = 0;
   const int bid = blockIdx.x;
@@ -629,7 +678,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_kernel4(const SeqLaunch L
   const int tile = bid - d.block_begin;
 #define MFM_ONE(IDX, KK)                                                         \
   if (KK > 0 && di == IDX) {                                                     \
-    if (BWD) small_bwd_body<(KK > 0 ? KK : 2), R>(d, L.T, L.B, tile, lds);       \
+    if (BWD) small_bwd_body<(KK > 0 ? KK : 2), R, KS>(d, L.T, L.B, tile, lds);   \
     else small_fwd_body<(KK > 0 ? KK : 2), R>(d, L.T, L.B, tile, lds);           \
     return;                                                                      \
   }
@@ -637,7 +686,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_kernel4(const SeqLaunch L
 #undef MFM_ONE
 }
 
-template <int R, int K0, int K1, int K2, int K3>
+template <int R, int K0, int K1, int K2, int K3, int KS = 16>
 static bool try_launch4(const SeqLaunch& L, bool bwd, int total, int threads, size_t lds_bytes, hipStream_t stream,
                         hipError_t* err) {
   const int want[4] = {K0, K1, K2, K3};
@@ -647,14 +696,14 @@ static bool try_launch4(const SeqLaunch& L, bool bwd, int total, int threads, si
   for (int i = 0; i < n; ++i) if (L.d[i].hk4 != want[i]) return false;
   *err = hipSuccess;
   if (lds_bytes > 64 * 1024) {
-    *err = bwd ? hipFuncSetAttribute((const void*)lstm_seq_small_kernel4<true, R, K0, K1, K2, K3>,
+    *err = bwd ? hipFuncSetAttribute((const void*)lstm_seq_small_kernel4<true, R, K0, K1, K2, K3, KS>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
                : hipFuncSetAttribute((const void*)lstm_seq_small_kernel4<false, R, K0, K1, K2, K3>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (*err != hipSuccess) return true;
   }
   if (bwd)
-    hipLaunchKernelGGL((lstm_seq_small_kernel4<true, R, K0, K1, K2, K3>), dim3(total), dim3(threads), lds_bytes, stream, L);
+    hipLaunchKernelGGL((lstm_seq_small_kernel4<true, R, K0, K1, K2, K3, KS>), dim3(total), dim3(threads), lds_bytes, stream, L);
   else
     hipLaunchKernelGGL((lstm_seq_small_kernel4<false, R, K0, K1, K2, K3>), dim3(total), dim3(threads), lds_bytes, stream, L);
   return true;
@@ -673,6 +722,17 @@ static bool try_all(const SeqLaunch& L, bool bwd, int total, int threads, size_t
          // MFM / MFM_KL on the module path (mfm_model.py::seq_group): encoders 32/8/80 + MFN LSTM 88, MFN 64/48
          try_launch4<R, 8, 2, 20, 22>(L, bwd, total, threads, lds_bytes, stream, err) ||
          try_launch4<R, 16, 12, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err);
+}
+
+// backward, one-row tiles, 8 k-slices (4 * Hp threads): the pre-instantiated size tuples
+static bool try_all_fat(const SeqLaunch& L, int total, int threads, size_t lds_bytes, hipStream_t stream, hipError_t* err) {
+  return try_launch4<1, 8, 2, 20, 30, 8>(L, true, total, threads, lds_bytes, stream, err) ||
+         try_launch4<1, 26, 6, 6, 0, 8>(L, true, total, threads, lds_bytes, stream, err) ||
+         try_launch4<1, 30, 0, 0, 0, 8>(L, true, total, threads, lds_bytes, stream, err) ||
+         try_launch4<1, 26, 0, 0, 0, 8>(L, true, total, threads, lds_bytes, stream, err) ||
+         try_launch4<1, 8, 0, 0, 0, 8>(L, true, total, threads, lds_bytes, stream, err) ||
+         try_launch4<1, 8, 2, 20, 22, 8>(L, true, total, threads, lds_bytes, stream, err) ||
+         try_launch4<1, 16, 12, 0, 0, 8>(L, true, total, threads, lds_bytes, stream, err);
 }
 
 static size_t small_lds_bytes(const SeqLaunch& L, bool bwd, int R) {
@@ -711,7 +771,15 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
     const size_t lds_bytes = small_lds_bytes(L, bwd, R);
     hipError_t err = hipSuccess;
     bool done = false;
-    if (R == 1) done = try_all<1>(L, bwd, total, max_threads, lds_bytes, stream, &err);
+    // backward, one-row tiles: MFM_SEQ_KS=8 selects 8 k-slices per unit pair (half the threads, twice the FMAs each).
+    // Opt-in: measured equal (encoders 30.5 vs 29.8 us) or slower (decoders 37.9 vs 32.6 us, 24 spilled registers) at B=32
+    // (profiles/r02_seq_ks8.txt) -- the step is a latency chain (LDS hand-over, barrier, reduction), not issue-bound enough
+    // for fewer, fatter waves to pay
+    bool fat = false;
+    if (const char* e = getenv("MFM_SEQ_KS")) fat = bwd && R == 1 && max_threads / 2 <= 512 && atoi(e) == 8;
+    if (fat) done = try_all_fat(L, total, max_threads / 2, lds_bytes, stream, &err);
+    if (done) {}
+    else if (R == 1) done = try_all<1>(L, bwd, total, max_threads, lds_bytes, stream, &err);
     else if (R == 2) done = try_all<2>(L, bwd, total, max_threads, lds_bytes, stream, &err);
     else done = try_all<4>(L, bwd, total, max_threads, lds_bytes, stream, &err);
     if (done) {

@@ -158,10 +158,14 @@ SEQ_SHAPES = [(8, 5, 1, 3), (8, 5, 32, 20), (24, 7, 33, 4), (32, 300, 32, 20), (
               (104, 9, 16, 5), (120, 325, 32, 20), (20, 6, 5, 1), (128, 4, 3, 2), (36, 10, 40, 3)]
 
 
-@pytest.fixture(params=["mfma", "small", "small:1", "small:2", "small:4", "stepwise"])
+@pytest.fixture(params=["mfma", "small", "small:1", "small:2", "small:4", "stepwise", "small:1:ks8"])
 def seq_path(request, monkeypatch):
-    """Both recurrent kernel families: MFMA (16 rows/workgroup) and VALU small-tile (4 rows)."""
-    path, _, rows = request.param.partition(":")
+    """Both recurrent kernel families: MFMA (16 rows/workgroup) and VALU small-tile (4 rows); "ks8": the one-row BPTT
+    with 8 k-slices per unit pair (small_bwd_body<.., 1, 8>, opt-in)."""
+    monkeypatch.delenv("MFM_SEQ_KS", raising=False)
+    if request.param.endswith(":ks8"):
+        monkeypatch.setenv("MFM_SEQ_KS", "8")
+    path, _, rows = request.param.replace(":ks8", "").partition(":")
     if path == "stepwise":                            # recurrent GEMM + cell kernel per step (h > 128 path)
         monkeypatch.setenv("MFM_SEQ_STEPWISE", "1")
         path = "small"
