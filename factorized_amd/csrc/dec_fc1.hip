@@ -41,6 +41,10 @@ constexpr int FC1_KS2W = 4;                  // reduction steps of product 2 per
 constexpr int FC1_LD = 16 * FC1_MAXF + 4;    // LDS row stride: (LD / 4) odd and LD == 4 (mod 64): conflict-free reads
 constexpr int FC1_OOB = 0x7FFFFFF0;          // buffer offset beyond any resource: the load returns 0
 
+// bf16 plans: the same products with every operand (H, Wfc, dx_hat) rounded to bf16 first and fp32 accumulation -- what
+// the bf16-operand GEMM computes; at these sizes the launch is latency, not matrix time, so the fp32 MFMA stays
+__device__ __forceinline__ float rnd_bf16(float x, bool on) { return on ? (float)(__bf16)x : x; }
+
 __global__ __launch_bounds__(FC1_THREADS) void dec_fc1_kernel(const DecFc1Launch L) {
   __shared__ __attribute__((aligned(16))) float Ht[FC1_ROWS * FC1_LD];              // hidden rows
   __shared__ __attribute__((aligned(16))) float Dx[FC1_ROWS * FC1_LD];              // d x_hat of this column group
@@ -97,6 +101,11 @@ __global__ __launch_bounds__(FC1_THREADS) void dec_fc1_kernel(const DecFc1Launch
     xv[r] = (cok && row < L.rows) ? I.x[(int64_t)row * I.ldx + n] : 0.0f;
   }
   const float bv = cok ? I.bias[n] : 0.0f;
+  const bool rb = L.bf16 != 0;
+  if (rb) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hreg[e] = rnd_bf16(hreg[e], true);
+  }
   if (hr < FC1_ROWS) *reinterpret_cast<f32x4*>(Ht + hr * FC1_LD + hk) = hreg;
   lds_barrier();
 
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(FC1_THREADS) void dec_fc1_kernel(const DecFc1Launch
     for (int j = 0; j < FC1_MAXF; ++j) {
       const f32x4 hv = *reinterpret_cast<const f32x4*>(Ht + bi * FC1_LD + 16 * min(j, J - 1) + 4 * q);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc1 = mma16x16x4(hv[e], w1[j][e], acc1);
+      for (int e = 0; e < 4; ++e) acc1 = mma16x16x4(hv[e], rnd_bf16(w1[j][e], rb), acc1);
     }
   }
   // ---- squared-error epilogue
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(FC1_THREADS) void dec_fc1_kernel(const DecFc1Launch
         if (I.xhat) I.xhat[o] = xh;
         if (I.dxhat) I.dxhat[o] = dx;
       }
-      Dx[row * FC1_LD + wave * 16 + bi] = dx;
+      Dx[row * FC1_LD + wave * 16 + bi] = rnd_bf16(dx, rb);
     }
   }
 #pragma unroll
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(FC1_THREADS) void dec_fc1_kernel(const DecFc1Launch
     for (int i = 0; i < FC1_KS2W; ++i) {
       const float a = Dx[bi * FC1_LD + 4 * min(ks0 + i, KS - 1) + q];
 #pragma unroll
-      for (int f = 0; f < FC1_MAXF; ++f) acc2[f] = mma16x16x4(a, w2[i][f], acc2[f]);
+      for (int f = 0; f < FC1_MAXF; ++f) acc2[f] = mma16x16x4(a, rnd_bf16(w2[i][f], rb), acc2[f]);
     }
     // waves 4..7 park their tiles, waves 0..3 add theirs on top (same lane -> same element), then the 4 tiles are summed
     float* P = Pt + (wave & 3) * FC1_ROWS * FC1_LD;

@@ -49,7 +49,7 @@ struct DecFc1Item {
   int64_t ldx; int d, h, Hp; float inv_count, grad_scale;
   int tile_begin, col_groups, frags_per_group;                          // filled by dec_fc1_launch
 };
-struct DecFc1Launch { DecFc1Item it[3]; int n_items, rows, with_bwd; };
+struct DecFc1Launch { DecFc1Item it[3]; int n_items, rows, with_bwd, bf16; };   // bf16: operands rounded to bf16 (RNE) first
 int dec_fc1_launch(DecFc1Launch& L, bool dhs_zeroed, hipStream_t stream);
 
 // dw_onepass.hip -- all weight gradients of one LSTM as ONE product over the rows (large T*B)

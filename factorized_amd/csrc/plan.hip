@@ -599,12 +599,13 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     P->grads_prezeroed = grads_to_zero;
   }
   if (V != 0) { zs.ptr[2] = W + P->zero_blk; zs.n[2] = P->zero_len; }
-  // fp32 plans: decoder fc1, the squared error AND (training) dH = dx_hat Wfc run as one launch (dec_fc1.hip) whose column
-  // groups add into dH; bf16 plans, shapes it does not take and MFM_FC1_FUSED=0 use the grouped GEMMs (F4, B0)
+  // up to 5120 rows: decoder fc1, the squared error AND (training) dH = dx_hat Wfc run as one launch (dec_fc1.hip) whose
+  // column groups add into dH (bf16 plans: operands rounded to bf16 in the kernel); larger T*B, shapes it does not take and
+  // MFM_FC1_FUSED=0 use the grouped GEMMs (F4, B0)
   const bool fc1_env_on = !(getenv("MFM_FC1_FUSED") && atoi(getenv("MFM_FC1_FUSED")) == 0);
   long fc1_max_rows = 5120;                        // measured crossover (profiles/r02_dec_fc1.txt)
   if (const char* e = getenv("MFM_FC1_FUSED_MAXROWS")) fc1_max_rows = atol(e);
-  const bool fc1_fused = c.precision == 0 && fc1_env_on && TB <= fc1_max_rows;
+  const bool fc1_fused = fc1_env_on && TB <= fc1_max_rows;
   if (fc1_fused && train) { zs.ptr[3] = W + P->dhs_blk; zs.n[3] = P->dhs_len; }
   P->calls++;
 
@@ -745,7 +746,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     if (fc1_fused) {
       DecFc1Launch FL;
       memset(&FL, 0, sizeof(FL));
-      FL.n_items = 3; FL.rows = (int)TB; FL.with_bwd = train ? 1 : 0;
+      FL.n_items = 3; FL.rows = (int)TB; FL.with_bwd = train ? 1 : 0; FL.bf16 = c.precision;
       for (int m = 0; m < 3; ++m) {
         DecFc1Item& I = FL.it[m];
         I.hs = g[m].a; I.w = g[m].b; I.bias = g[m].bias; I.x = me[m].x; I.ldx = me[m].ldx;
