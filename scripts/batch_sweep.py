@@ -17,7 +17,7 @@ PEAK = 157.3
 
 
 def run(B, path, steps, shape="mosi", T=20):
-    if path == "bf16":
+    if path in ("bf16", "auto"):          # the plan's own kernel selection (fp32 "auto", bf16 plan)
         os.environ.pop("MFM_SEQ_PATH", None)
     else:
         os.environ["MFM_SEQ_PATH"] = path
@@ -48,7 +48,7 @@ if __name__ == "__main__":
     print("# shape %s, T=%d; frac = fraction of the fp32 matrix peak (157.3 TF) for every row, bf16 rows included" % (shape, T))
     print("%6s %6s %9s %12s %8s %8s %9s" % ("B", "path", "ms/step", "samples/s", "TFLOP/s", "frac", "alg GB/s"))
     for B in Bs:
-        for path in ("small", "mfma", "bf16"):
+        for path in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("auto", "bf16")):
             r = run(B, path, steps=50 if B <= 2048 else 10, shape=shape, T=T)
             print("%6d %6s %9.3f %12.0f %8.2f %8.4f %9.1f" % (r["B"], r["path"], r["ms"], r["samples_per_s"],
                                                               r["tflops"], r["frac"], r["hbm_gbs"]))
