@@ -121,7 +121,7 @@ struct LatOp {
   float drop_p;
   int stage;
   int pfx_n, pfx_k;             // exclusive prefix sums of N / K over the ops of the same stage (host-filled)
-  int pad_;
+  int chain;                    // modality chain of the layer: 0 l, 1 a, 2 v, 3 y (incl. the classifier)
 };
 struct LatentDev {
   // Op table in DEVICE memory (uploaded once by mfm_plan_init_workspace).  It must not live in the
@@ -160,6 +160,12 @@ struct LatentDev {
   // encoding in latent.hip) and the number of threads that have an item in each stage
   const int* items_fwd; const int* items_bwd;
   int nitems_fwd[MFM_LAT_MAXSTAGES], nitems_bwd[MFM_LAT_MAXSTAGES];
+  // row path, small batches: the four modality chains of a row (l, a, v, y: independent inside the stack) run as
+  // nch = 4 workgroups on 4 CUs (grid = B * nch, item tables [chain][stage][thread]); the record is laid out chain by
+  // chain, chain c owns floats [ch_lo[c], ch_hi[c]) of it.  nch == 1: one workgroup per row, tables at index 0.
+  int nch, ch_lo[4], ch_hi[4];
+  int pre;                             // chain workgroups of 512 threads that request every stage's weights up front (latent.hip)
+  int nitems_fwd_c[4][MFM_LAT_MAXSTAGES], nitems_bwd_c[4][MFM_LAT_MAXSTAGES];
   uint64_t seed;
   float reg_w, disc_w, gen_w;
 };

@@ -26,6 +26,9 @@
 namespace mfm {
 
 constexpr int LAT_THREADS = 1024;
+constexpr int LAT_PRE_THREADS = 512;         // chain workgroups with every stage's weights requested up front (256 VGPRs)
+constexpr int LAT_PRE_STAGES = 6;
+constexpr int LAT_PRE_SLOTS = 4;             // weights requested 4 stages ahead (6 resident slots spill: 222 + 60 registers)
 
 __device__ __forceinline__ float wave_sum_l(float v) {
 #pragma unroll
@@ -537,14 +540,25 @@ __device__ __forceinline__ void load_items(const int* __restrict__ items, int ns
   for (int s = 0; s < MFM_LAT_MAXSTAGES; ++s) tab[s * MFM_LAT_ROW_THREADS + tid] = v[s];
 }
 
-__global__ __launch_bounds__(LAT_THREADS) void latent_fwd_row_kernel(const LatentDev L, const float* __restrict__ params) {
+// PRE (chain workgroups, <= 6 stages, <= 512 work items per stage): 512 threads, and the weights of ALL stages are requested
+// before the first one runs -- a chain is 4-6 dependent stages of almost no arithmetic, and with one-stage-ahead
+// prefetch every stage still costs the ~2 us its cold weights take to arrive (the optimizer rewrote them a step ago).
+template <bool PRE>
+__global__ __launch_bounds__(PRE ? LAT_PRE_THREADS : LAT_THREADS) void latent_fwd_row_kernel(const LatentDev L, const float* __restrict__ params) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ LatOp ops[MFM_LAT_MAXOPS];
   __shared__ float red[2][16];
   i32x4* tab = reinterpret_cast<i32x4*>(lds);                        // [MAXSTAGES][1024] items
   float* rec = lds + MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
-  const int row = blockIdx.x;
+  // nch == 4: this workgroup runs ONE modality chain (l, a, v or y) of its row -- the chains are independent inside the
+  // stack, and four CUs stream a row's weights instead of one (LatentDev::nch)
+  const int nch = L.nch;
+  const int row = (int)blockIdx.x / nch, ch = (int)blockIdx.x - row * nch;
+  const bool all = nch == 1;
   const int tid = threadIdx.x, nt = blockDim.x;
+  int nif[MFM_LAT_MAXSTAGES];
+#pragma unroll
+  for (int i = 0; i < MFM_LAT_MAXSTAGES; ++i) nif[i] = L.nitems_fwd_c[ch][i];
   // prologue: op table, item table and the four encoder states are requested together (one round trip)
   float yv = 0.0f;
   int ylab = 0;
@@ -563,7 +577,7 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_row_kernel(const Laten
       if (L.loss_kind == 0) yv = reinterpret_cast<const float*>(L.y)[(int64_t)row * L.od + min(tid, L.od - 1)];
       else ylab = (int)reinterpret_cast<const int64_t*>(L.y)[row];
     }
-    load_items(L.items_fwd, L.nstages, tab, tid);
+    load_items(L.items_fwd + (size_t)ch * (MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4), L.nstages, tab, tid);
     if (tid < nw) reinterpret_cast<int*>(ops)[tid] = opv;
     if (tid < e3) rec[io + kk] = hv;
   }
@@ -602,16 +616,16 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_row_kernel(const Laten
     // unconditional (the last stage requests its own weights again): a load under a branch would make the
     // compiler's in-order vmcnt accounting conservative and the wait for `cur` would also cover `nxt`.
     const int sn = min(s + 1, L.nstages - 1);
-    if (wave0 < max(L.nitems_fwd[s], L.nitems_fwd[sn])) {
+    if (wave0 < (PRE ? nif[s] : max(nif[s], nif[sn]))) {
       const int in_off = cur.e[2] & 0xFFFF, K = (cur.e[2] >> 16) & 0xFF;
       f32x4 xv[8];
-      if (wave0 < L.nitems_fwd[s]) {          // `cur` was fetched one stage ago exactly when this holds
+      if (wave0 < nif[s]) {          // `cur` was fetched one stage ago exactly when this holds
 #pragma unroll
         for (int j = 0; j < 8; ++j) xv[j] = *reinterpret_cast<const f32x4*>(rec + in_off + min(4 * q + 16 * j, K - 4));
       }
-      fetch(sn, nxt);
+      if constexpr (!PRE) fetch(sn, nxt);
       mark(L, 2 + 2 * s);
-      if (wave0 < L.nitems_fwd[s]) {
+      if (wave0 < nif[s]) {
         float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -648,25 +662,39 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_row_kernel(const Laten
     lds_barrier();
     mark(L, 3 + 2 * s);
   };
-  Slot sa, sb;
-  fetch(0, sa);
-  for (int s = 0; s < L.nstages; s += 2) {
-    stage(s, sa, sb);
-    if (s + 1 < L.nstages) stage(s + 1, sb, sa);
+  if constexpr (PRE) {
+    Slot sl[LAT_PRE_SLOTS];
+#pragma unroll
+    for (int i = 0; i < LAT_PRE_SLOTS; ++i) fetch(min(i, L.nstages - 1), sl[i]);
+#pragma unroll
+    for (int i = 0; i < LAT_PRE_STAGES; ++i) {
+      if (i < L.nstages) stage(i, sl[i % LAT_PRE_SLOTS], sl[i % LAT_PRE_SLOTS]);
+      if (i + LAT_PRE_SLOTS < LAT_PRE_STAGES) fetch(min(i + LAT_PRE_SLOTS, L.nstages - 1), sl[i % LAT_PRE_SLOTS]);   // unconditional
+    }
+  } else {
+    Slot sa, sb;
+    fetch(0, sa);
+    for (int s = 0; s < L.nstages; s += 2) {
+      stage(s, sa, sb);
+      if (s + 1 < L.nstages) stage(s + 1, sb, sa);
+    }
   }
 
   // ---- losses (one partial per workgroup, one atomic each)
   float kld = 0.0f;
   if (e_haslv) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 4; ++m) {
+      if (!all && m != ch) continue;
       for (int j = tid; j < e_zn[m]; j += nt) {
         const float mu = rec[e_mu[m] + j], lv = rec[e_lv[m] + j];
         kld += 1.0f + lv - mu * mu - expf(lv);
       }
+    }
   }
   float disc = 0.0f;
-  if (L.y) {
+  const bool ych = all || ch == 3;                // the workgroup that holds the classifier's outputs
+  if (L.y && ych) {
     if (e_kind == 0) {
       if (tid < e_od) disc += fabsf(rec[e_yoff + tid] - yv);
     } else if (tid == 0) {
@@ -687,7 +715,7 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_row_kernel(const Laten
   lds_barrier();
   if (tid == 0 && e_losses) {
     if (e_haslv) atomicAdd(e_losses + 4, -0.5f * (red[0][0] + red[0][1]));
-    if (L.y) {
+    if (L.y && ych) {
       const float inv = (e_kind == 0) ? 1.0f / ((float)e_B * (float)e_od) : 1.0f / (float)e_B;
       atomicAdd(e_losses + 0, (red[1][0] + red[1][1]) * inv);
     }
@@ -698,21 +726,25 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_row_kernel(const Laten
   for (int m = 0; m < 3; ++m) {
     if (!e_dec[m]) continue;
     const int hd = fy + e_fn[m];
-    for (int j = tid; j < hd; j += nt)
+    // decoder input [f_y | f_m]: the y chain owns the first part (for all three decoders), chain m the second
+    const int j0 = (all || ch == 3) ? 0 : fy, j1 = (all || ch == m) ? hd : fy;
+    for (int j = j0 + tid; j < j1; j += nt)
       e_dec[m][(int64_t)row * e_ld[m] + j] = (j < fy) ? rec[e_fo[3] + j] : rec[e_fo[m] + (j - fy)];
   }
-  if (e_yout)
+  if (e_yout && ych)
     for (int o = tid; o < e_od; o += nt) e_yout[(int64_t)row * e_od + o] = rec[e_yoff + o];
   if (e_rec) {
-    const int n4 = e_rs >> 2;
+    // the saved record: this workgroup's range of it (the whole row, or its chain's contiguous segments)
+    const int lo4 = all ? 0 : (L.ch_lo[ch] >> 2), hi4 = all ? (e_rs >> 2) : (L.ch_hi[ch] >> 2);
     f32x4* d4 = reinterpret_cast<f32x4*>(e_rec + (int64_t)row * e_rs);
     const f32x4* s4 = reinterpret_cast<const f32x4*>(rec);
-    for (int idx = tid; idx < n4; idx += nt) d4[idx] = s4[idx];
+    for (int idx = lo4 + tid; idx < hi4; idx += nt) d4[idx] = s4[idx];
   }
   mark(L, 20);
 }
 
-__global__ __launch_bounds__(LAT_THREADS) void latent_bwd_row_kernel(const LatentDev L, const float* __restrict__ params,
+template <bool PRE>
+__global__ __launch_bounds__(PRE ? LAT_PRE_THREADS : LAT_THREADS) void latent_bwd_row_kernel(const LatentDev L, const float* __restrict__ params,
                                                                      float* __restrict__ grads) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ LatOp ops[MFM_LAT_MAXOPS];
@@ -721,8 +753,13 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_row_kernel(const Laten
   i32x4* tab = reinterpret_cast<i32x4*>(lds);                        // [MAXSTAGES][1024] items
   float* rec = lds + MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
   float* grd = rec + RS;
-  const int row = blockIdx.x;
+  const int nch = L.nch;                           // 4: one modality chain of the row per workgroup (see the forward)
+  const int row = (int)blockIdx.x / nch, ch = (int)blockIdx.x - row * nch;
+  const bool all = nch == 1;
   const int tid = threadIdx.x, nt = blockDim.x;
+  int nib[MFM_LAT_MAXSTAGES];
+#pragma unroll
+  for (int i = 0; i < MFM_LAT_MAXSTAGES; ++i) nib[i] = L.nitems_bwd_c[ch][i];
   {   // op table, item table and the saved record are requested together (one round trip)
     const int nw = L.nops * (int)(sizeof(LatOp) / 4);
     const int opv = reinterpret_cast<const int*>(L.ops)[min(tid, nw - 1)];
@@ -734,7 +771,7 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_row_kernel(const Laten
     const f32x4* sd4 = L.grd_seed ? reinterpret_cast<const f32x4*>(L.grd_seed + (int64_t)row * RS) : nullptr;
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 sv = sd4 ? sd4[min(tid, n4 - 1)] : zero;
-    load_items(L.items_bwd, L.nstages, tab, tid);
+    load_items(L.items_bwd + (size_t)ch * (MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4), L.nstages, tab, tid);
     if (tid < nw) reinterpret_cast<int*>(ops)[tid] = opv;
     if (tid < L.nops) pfxN[tid] = L.ops[tid].pfx_n;
     if (tid < n4) { r4[tid] = rv; g4[tid] = sv; }
@@ -751,8 +788,14 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_row_kernel(const Laten
 #pragma unroll
     for (int j = 0; j < 8; ++j) t.w[j] = *reinterpret_cast<const f32x4*>(wr + min(l + 16 * j, N - 1) * K);
   };
-  Slot sa, sb;
-  fetch(L.nstages - 1, sa);
+  Slot sa, sb, sl[PRE ? LAT_PRE_SLOTS : 1];
+  // PRE: walk position p = 0 .. 5 is stage nstages-1-p; slot p % 4; the first four positions are requested here
+  if constexpr (PRE) {
+#pragma unroll
+    for (int p = 0; p < LAT_PRE_SLOTS; ++p) fetch(max(L.nstages - 1 - p, 0), sl[p]);
+  } else {
+    fetch(L.nstages - 1, sa);
+  }
   // ---- seeds
   if (L.d_yhat_ext) {
     for (int o = tid; o < L.od; o += nt) grd[L.yhat_off + o] = L.d_yhat_ext[(int64_t)row * L.od + o];
@@ -811,16 +854,16 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_row_kernel(const Laten
     const int sn = max(s - 1, 0);
     mark(L, 25 + 3 * s);
     // ---- pass 2a: dX[k] += sum_n g[n] W[n][k]   (per-wave skip and unconditional loads as in the forward)
-    if (wave0 < max(L.nitems_bwd[s], L.nitems_bwd[sn])) {
+    if (wave0 < (PRE ? nib[s] : max(nib[s], nib[sn]))) {
       const int N = (cur.e[1] >> 8) & 0xFF;
       const int out_off = cur.e[2] & 0xFFFF, in_idx = (cur.e[2] >> 16) & 0xFFFF;
       float gv[8];
-      if (wave0 < L.nitems_bwd[s]) {
+      if (wave0 < nib[s]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) gv[j] = grd[out_off + min(l + 16 * j, N - 1)];
       }
-      fetch(sn, nxt);                // stage 0 requests its own weights again
-      if (wave0 < L.nitems_bwd[s]) {
+      if constexpr (!PRE) fetch(sn, nxt);                // stage 0 requests its own weights again
+      if (wave0 < nib[s]) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -850,9 +893,18 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_row_kernel(const Laten
     lds_barrier();
     mark(L, 27 + 3 * s);
   };
-  for (int s = L.nstages - 1; s >= 0; s -= 2) {
-    stage(s, sa, sb);
-    if (s >= 1) stage(s - 1, sb, sa);
+  if constexpr (PRE) {
+#pragma unroll
+    for (int p = 0; p < LAT_PRE_STAGES; ++p) {
+      const int st = L.nstages - 1 - p;
+      if (st >= 0) stage(st, sl[p % LAT_PRE_SLOTS], sl[p % LAT_PRE_SLOTS]);
+      if (p + LAT_PRE_SLOTS < LAT_PRE_STAGES) fetch(max(L.nstages - 1 - (p + LAT_PRE_SLOTS), 0), sl[p % LAT_PRE_SLOTS]);
+    }
+  } else {
+    for (int s = L.nstages - 1; s >= 0; s -= 2) {
+      stage(s, sa, sb);
+      if (s >= 1) stage(s - 1, sb, sa);
+    }
   }
 
   // ---- bias gradients of all layers in one go (the record keeps every pre-activation gradient).  Inside
@@ -864,19 +916,20 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_row_kernel(const Laten
     for (int item = tid; item < totn; item += nt) {
       const int o = find_op(pfxN, ob, oe, item, 1);
       const LatOp& op = ops[o];
+      if (!all && op.chain != ch) continue;         // another workgroup of this row holds that layer's gradients
       const int n = item - pfxN[o];
       atomicAdd(grads + op.b_off + n, grd[op.out_off + n]);
     }
   }
   for (int m = 0; m < 4; ++m) {
-    if (!L.dh_last[m]) continue;
+    if (!L.dh_last[m] || (!all && m != ch)) continue;
     for (int k = tid; k < L.enc_n[m]; k += nt) L.dh_last[m][(int64_t)row * L.dh_ld[m] + k] = grd[L.in_off[m] + k];
   }
   if (L.grd_out) {
-    const int n4 = RS >> 2;
+    const int lo4 = all ? 0 : (L.ch_lo[ch] >> 2), hi4 = all ? (RS >> 2) : (L.ch_hi[ch] >> 2);
     f32x4* d4 = reinterpret_cast<f32x4*>(L.grd_out + (int64_t)row * RS);
     const f32x4* s4 = reinterpret_cast<const f32x4*>(grd);
-    for (int idx = tid; idx < n4; idx += nt) d4[idx] = s4[idx];
+    for (int idx = lo4 + tid; idx < hi4; idx += nt) d4[idx] = s4[idx];
   }
 }
 
@@ -890,8 +943,13 @@ static int set_lds_limit(const void* fn, size_t bytes) {
 int latent_fwd_launch(const LatentDev& L, const float* params, hipStream_t stream) {
   if (L.row_path) {
     const size_t lds1 = ((size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + L.rec_size) * sizeof(float);
-    if (int rc1 = set_lds_limit((const void*)latent_fwd_row_kernel, lds1)) return rc1;
-    hipLaunchKernelGGL(latent_fwd_row_kernel, dim3(L.B), dim3(LAT_THREADS), lds1, stream, L, params);
+    if (L.pre) {
+      if (int rc1 = set_lds_limit((const void*)latent_fwd_row_kernel<true>, lds1)) return rc1;
+      hipLaunchKernelGGL(latent_fwd_row_kernel<true>, dim3(L.B * L.nch), dim3(LAT_PRE_THREADS), lds1, stream, L, params);
+    } else {
+      if (int rc1 = set_lds_limit((const void*)latent_fwd_row_kernel<false>, lds1)) return rc1;
+      hipLaunchKernelGGL(latent_fwd_row_kernel<false>, dim3(L.B * L.nch), dim3(LAT_THREADS), lds1, stream, L, params);
+    }
     MFM_LAUNCH_CHECK("latent_fwd_row_kernel");
     return MFM_OK;
   }
@@ -910,8 +968,13 @@ int latent_fwd_launch(const LatentDev& L, const float* params, hipStream_t strea
 int latent_bwd_launch(const LatentDev& L, const float* params, float* grads, hipStream_t stream) {
   if (L.row_path) {
     const size_t lds1 = ((size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + 2 * (size_t)L.rec_size) * sizeof(float);
-    if (int rc1 = set_lds_limit((const void*)latent_bwd_row_kernel, lds1)) return rc1;
-    hipLaunchKernelGGL(latent_bwd_row_kernel, dim3(L.B), dim3(LAT_THREADS), lds1, stream, L, params, grads);
+    if (L.pre) {
+      if (int rc1 = set_lds_limit((const void*)latent_bwd_row_kernel<true>, lds1)) return rc1;
+      hipLaunchKernelGGL(latent_bwd_row_kernel<true>, dim3(L.B * L.nch), dim3(LAT_PRE_THREADS), lds1, stream, L, params, grads);
+    } else {
+      if (int rc1 = set_lds_limit((const void*)latent_bwd_row_kernel<false>, lds1)) return rc1;
+      hipLaunchKernelGGL(latent_bwd_row_kernel<false>, dim3(L.B * L.nch), dim3(LAT_THREADS), lds1, stream, L, params, grads);
+    }
     MFM_LAUNCH_CHECK("latent_bwd_row_kernel");
     return MFM_OK;
   }

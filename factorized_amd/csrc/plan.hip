@@ -133,11 +133,11 @@ static int64_t carve(int64_t& cursor, int64_t n) {
   return at;
 }
 
-static void add_op(LatOp* ops, LatentDev& L, int stage, int in_off, int out_off, int K, int N, int64_t w_off, int64_t b_off,
-                   int relu, int mask_off, float p) {
+static void add_op(LatOp* ops, LatentDev& L, int stage, int chain, int in_off, int out_off, int K, int N, int64_t w_off,
+                   int64_t b_off, int relu, int mask_off, float p) {
   LatOp& o = ops[L.nops++];
   o.in_off = in_off; o.out_off = out_off; o.K = K; o.N = N; o.w_off = w_off; o.b_off = b_off;
-  o.relu = relu; o.mask_off = mask_off; o.drop_p = p; o.stage = stage;
+  o.relu = relu; o.mask_off = mask_off; o.drop_p = p; o.stage = stage; o.chain = chain;
 }
 
 static int build(MfmPlan* P) {
@@ -218,24 +218,29 @@ static int build(MfmPlan* P) {
   // (variant 0) or the precomputed heads on the MFN output (variants 1, 2: [mu_y | logvar_y] / z_y)
   const int in_n[4] = {c.zl, c.za, c.zv, V == 0 ? ze : P->nzy};
   int last_off[4], f1_off[4], m1_off[4];
-  for (int e = 0; e < 4; ++e) { L.in_off[e] = seg(in_n[e]); L.enc_n[e] = in_n[e]; }
   const int nfc = (V == 0) ? 4 : 3;                 // encoder fc1 heads inside the stack
-  for (int e = 0; e < 4; ++e) last_off[e] = (e < nfc) ? seg(in_n[e]) : -1;
+  int c1_off = 0, mc_off = 0;
+  // chain by chain (l, a, v, y): every segment a modality's layers read or write is contiguous, so that a workgroup that
+  // runs one chain of a row (LatentDev::nch) saves / restores one range of the record
   for (int e = 0; e < 4; ++e) {
+    L.ch_lo[e] = rs;
+    L.in_off[e] = seg(in_n[e]); L.enc_n[e] = in_n[e];
+    last_off[e] = (e < nfc) ? seg(in_n[e]) : -1;
     L.z_n[e] = zn[e];
     if (V == 2) L.mu_off[e] = (e < 3) ? last_off[e] : L.in_off[3];          // z = the encoder output itself
     else if (V == 1 && e == 3) L.mu_off[e] = L.in_off[3];
     else L.mu_off[e] = seg(zn[e]);
-  }
-  for (int e = 0; e < 4; ++e) {
     if (V == 2) L.lv_off[e] = 0;
     else if (V == 1 && e == 3) L.lv_off[e] = L.in_off[3] + c.zy;
     else L.lv_off[e] = seg(zn[e]);
+    f1_off[e] = seg(fn[e]); m1_off[e] = seg(fn[e]);
+    L.f_off[e] = seg(fn[e]); L.f_n[e] = fn[e];
+    if (e == 3) {
+      c1_off = seg(c.fy); mc_off = seg(c.fy);
+      L.yhat_off = seg(c.output_dim); L.od = c.output_dim;
+    }
+    L.ch_hi[e] = rs;
   }
-  for (int e = 0; e < 4; ++e) { f1_off[e] = seg(fn[e]); m1_off[e] = seg(fn[e]); }
-  for (int e = 0; e < 4; ++e) { L.f_off[e] = seg(fn[e]); L.f_n[e] = fn[e]; }
-  const int c1_off = seg(c.fy), mc_off = seg(c.fy);
-  L.yhat_off = seg(c.output_dim); L.od = c.output_dim;
   L.rec_size = rs;
   for (int e = 0; e < 4; ++e) { P->lay_f1[e] = f1_off[e]; P->lay_m1[e] = m1_off[e]; P->z_seg[e] = L.mu_off[e]; }
   P->lay_c1 = c1_off; P->lay_mc = mc_off;
@@ -243,31 +248,31 @@ static int build(MfmPlan* P) {
   int st = 0;
   // encoder fc1 (mfm_model.py:60-61)
   for (int e = 0; e < nfc; ++e)
-    add_op(P->lat_ops, L, st, L.in_off[e], last_off[e], in_n[e], in_n[e], o[pi.enc[e] + FC_W], o[pi.enc[e] + FC_B], 0, -1, 0.f);
+    add_op(P->lat_ops, L, st, e, L.in_off[e], last_off[e], in_n[e], in_n[e], o[pi.enc[e] + FC_W], o[pi.enc[e] + FC_B], 0, -1, 0.f);
   ++st;
   // mu heads (mfm_model.py:630-639 / 737-744).  The logvar heads only feed the KLD, nothing downstream waits
   // for them, so they ride along with the classifier's first layer (the row kernels give every
   // thread one work item per stage: 4*(16+152) output quads and 4*(16+240)/4 input groups still fit 1024).
   if (V != 2) {
     for (int e = 0; e < nfc; ++e)
-      add_op(P->lat_ops, L, st, last_off[e], L.mu_off[e], in_n[e], zn[e], o[pi.to_z[e]], o[pi.to_z[e] + 1], 0, -1, 0.f);
+      add_op(P->lat_ops, L, st, e, last_off[e], L.mu_off[e], in_n[e], zn[e], o[pi.to_z[e]], o[pi.to_z[e] + 1], 0, -1, 0.f);
     ++st;
   }
   // z -> f MLPs (mfm_model.py:644-647)
   const float pd[4] = {c.drop_zl, c.drop_za, c.drop_zv, c.drop_zy};
   for (int e = 0; e < 4; ++e)
-    add_op(P->lat_ops, L, st, L.mu_off[e], f1_off[e], zn[e], fn[e], o[pi.zf1[e]], o[pi.zf1[e] + 1], 1, m1_off[e], pd[e]);
+    add_op(P->lat_ops, L, st, e, L.mu_off[e], f1_off[e], zn[e], fn[e], o[pi.zf1[e]], o[pi.zf1[e] + 1], 1, m1_off[e], pd[e]);
   ++st;
   for (int e = 0; e < 4; ++e)
-    add_op(P->lat_ops, L, st, f1_off[e], L.f_off[e], fn[e], fn[e], o[pi.zf2[e]], o[pi.zf2[e] + 1], 1, -1, 0.f);
+    add_op(P->lat_ops, L, st, e, f1_off[e], L.f_off[e], fn[e], fn[e], o[pi.zf2[e]], o[pi.zf2[e] + 1], 1, -1, 0.f);
   ++st;
   // classifier (mfm_model.py:657); its first stage also carries the logvar heads
-  add_op(P->lat_ops, L, st, L.f_off[3], c1_off, c.fy, c.fy, o[pi.y_f1], o[pi.y_f1 + 1], 1, mc_off, c.drop_y);
+  add_op(P->lat_ops, L, st, 3, L.f_off[3], c1_off, c.fy, c.fy, o[pi.y_f1], o[pi.y_f1 + 1], 1, mc_off, c.drop_y);
   if (V != 2)
     for (int e = 0; e < nfc; ++e)
-      add_op(P->lat_ops, L, st, last_off[e], L.lv_off[e], in_n[e], zn[e], o[pi.to_lv[e]], o[pi.to_lv[e] + 1], 0, -1, 0.f);
+      add_op(P->lat_ops, L, st, e, last_off[e], L.lv_off[e], in_n[e], zn[e], o[pi.to_lv[e]], o[pi.to_lv[e] + 1], 0, -1, 0.f);
   ++st;
-  add_op(P->lat_ops, L, st, c1_off, L.yhat_off, c.fy, c.output_dim, o[pi.y_f2], o[pi.y_f2 + 1], 0, -1, 0.f);
+  add_op(P->lat_ops, L, st, 3, c1_off, L.yhat_off, c.fy, c.output_dim, o[pi.y_f2], o[pi.y_f2 + 1], 0, -1, 0.f);
   ++st;
   L.nstages = st;
   {
@@ -333,59 +338,91 @@ static int build(MfmPlan* P) {
     if (const char* e = getenv("MFM_LATENT_PATH")) { if (!strcmp(e, "staged")) ok = false; }
     L.row_path = ok ? 1 : 0;
   }
-  // row path: the work item of thread t in stage s is static, so it is tabulated here once (encoding: latent.hip)
+  // row path: the work item of thread t in stage s is static, so it is tabulated here once (encoding: latent.hip).
+  // Chains: at small batches (B * 4 <= CUs) every row's four modality chains get a workgroup each (the forward launch is
+  // bound by what ONE CU can stream from L2, ~14 B/clk: 228 KB of weights per row-workgroup = 6.8 us of its 14 us); the
+  // tables then exist per chain [chain][stage][thread], chain c seeing only its own layers.  MFM_LATENT_CHAINS=0 disables.
   const int NT = MFM_LAT_ROW_THREADS;
-  P->lat_items.assign((size_t)2 * MFM_LAT_MAXSTAGES * NT * 4, 0);
+  const size_t TABN = (size_t)4 * MFM_LAT_MAXSTAGES * NT * 4;        // ints per direction
+  P->lat_items.assign(2 * TABN, 0);
+  L.nch = 1;
   if (L.row_path) {
+    bool chains = 4 * c.B <= device_cus();
+    if (const char* e = getenv("MFM_LATENT_CHAINS")) chains = chains && atoi(e) != 0;
+    L.nch = chains ? 4 : 1;
     int* fw = P->lat_items.data();
-    int* bw = fw + (size_t)MFM_LAT_MAXSTAGES * NT * 4;
-    for (int st = 0; st < L.nstages; ++st) {
-      const int ob = L.stage_begin[st], oe = L.stage_begin[st + 1];
-      int sn = 0, sk = 0;
-      for (int i = ob; i < oe; ++i) { sn += P->lat_ops[i].N; sk += P->lat_ops[i].K; }
-      L.nitems_fwd[st] = 4 * sn;
-      L.nitems_bwd[st] = 4 * sk;
-      for (int t = 0; t < NT; ++t) {
-        {   // forward: quad (n, q) -> output column n of op o
-          const bool live = t < 4 * sn;
-          const int item = std::min(t, 4 * sn - 1) >> 2;
-          int o = ob;
-          while (o + 1 < oe && item >= P->lat_ops[o + 1].pfx_n) ++o;
-          const LatOp& op = P->lat_ops[o];
-          const int n = item - op.pfx_n;
-          int* e = fw + ((size_t)st * NT + t) * 4;
-          e[0] = (int)(op.w_off + (int64_t)n * op.K);
-          e[1] = (int)(op.b_off + n);
-          e[2] = op.in_off | (op.K << 16);
-          e[3] = (op.out_off + n) | (o << 16) | ((op.relu ? 1 : 0) << 24) | ((op.mask_off >= 0 ? 1 : 0) << 25) |
-                 ((live ? 1 : 0) << 26);
+    int* bw = fw + TABN;
+    for (int ch = 0; ch < L.nch; ++ch)
+      for (int st = 0; st < L.nstages; ++st) {
+        const int ob = L.stage_begin[st], oe = L.stage_begin[st + 1];
+        // the layers of this stage this workgroup kind runs, with their own prefix sums
+        std::vector<int> sel, pn, pk;
+        int sn = 0, sk = 0;
+        for (int i = ob; i < oe; ++i) {
+          if (L.nch > 1 && P->lat_ops[i].chain != ch) continue;
+          sel.push_back(i); pn.push_back(sn); pk.push_back(sk);
+          sn += P->lat_ops[i].N; sk += P->lat_ops[i].K;
         }
-        {   // backward: 16 lanes (kc, l) -> input columns kc..kc+3 of op o
-          const bool live = t < 4 * sk;
-          const int col = (std::min(t, 4 * sk - 1) >> 4) * 4;
-          int o = ob;
-          while (o + 1 < oe && col >= P->lat_ops[o + 1].pfx_k) ++o;
-          const LatOp& op = P->lat_ops[o];
-          const int kc = col - op.pfx_k;
-          int* e = bw + ((size_t)st * NT + t) * 4;
-          e[0] = (int)(op.w_off + kc);
-          e[1] = op.K | (op.N << 8);
-          e[2] = op.out_off | ((op.in_off + kc) << 16);
-          // the layer that PRODUCED these input columns: its relu / dropout mask is applied to the gradient
-          // as it is accumulated (they are linear, so masking each contribution == masking the sum)
-          int prelu = 0, pmask = 0;
-          for (int pi = 0; pi < ob; ++pi) {
-            const LatOp& pr = P->lat_ops[pi];
-            const int idx = op.in_off + kc;
-            if (idx >= pr.out_off && idx < pr.out_off + pr.N) {
-              prelu = pr.relu ? 1 : 0;
-              pmask = pr.mask_off >= 0 ? pr.mask_off + (idx - pr.out_off) + 1 : 0;
-            }
+        L.nitems_fwd_c[ch][st] = 4 * sn;
+        L.nitems_bwd_c[ch][st] = 4 * sk;
+        if (L.nch == 1) { L.nitems_fwd[st] = 4 * sn; L.nitems_bwd[st] = 4 * sk; }
+        for (int t = 0; t < NT; ++t) {
+          int* ef = fw + (((size_t)ch * MFM_LAT_MAXSTAGES + st) * NT + t) * 4;
+          int* eb = bw + (((size_t)ch * MFM_LAT_MAXSTAGES + st) * NT + t) * 4;
+          if (sel.empty()) { ef[0] = ef[1] = ef[2] = ef[3] = 0; eb[0] = eb[1] = eb[2] = eb[3] = 0; ef[2] = 4 << 16; eb[1] = 4 | (1 << 8); continue; }
+          {   // forward: quad (n, q) -> output column n of op o
+            const bool live = t < 4 * sn;
+            const int item = std::min(t, 4 * sn - 1) >> 2;
+            size_t si = 0;
+            while (si + 1 < sel.size() && item >= pn[si + 1]) ++si;
+            const int o = sel[si];
+            const LatOp& op = P->lat_ops[o];
+            const int n = item - pn[si];
+            ef[0] = (int)(op.w_off + (int64_t)n * op.K);
+            ef[1] = (int)(op.b_off + n);
+            ef[2] = op.in_off | (op.K << 16);
+            ef[3] = (op.out_off + n) | (o << 16) | ((op.relu ? 1 : 0) << 24) | ((op.mask_off >= 0 ? 1 : 0) << 25) |
+                    ((live ? 1 : 0) << 26);
           }
-          e[3] = (live ? 1 : 0) | (prelu << 1) | (pmask << 2);
+          {   // backward: 16 lanes (kc, l) -> input columns kc..kc+3 of op o
+            const bool live = t < 4 * sk;
+            const int col = (std::min(t, 4 * sk - 1) >> 4) * 4;
+            size_t si = 0;
+            while (si + 1 < sel.size() && col >= pk[si + 1]) ++si;
+            const int o = sel[si];
+            const LatOp& op = P->lat_ops[o];
+            const int kc = col - pk[si];
+            eb[0] = (int)(op.w_off + kc);
+            eb[1] = op.K | (op.N << 8);
+            eb[2] = op.out_off | ((op.in_off + kc) << 16);
+            // the layer that PRODUCED these input columns: its relu / dropout mask is applied to the gradient
+            // as it is accumulated (they are linear, so masking each contribution == masking the sum)
+            int prelu = 0, pmask = 0;
+            for (int pi = 0; pi < ob; ++pi) {
+              const LatOp& pr = P->lat_ops[pi];
+              const int idx = op.in_off + kc;
+              if (idx >= pr.out_off && idx < pr.out_off + pr.N) {
+                prelu = pr.relu ? 1 : 0;
+                pmask = pr.mask_off >= 0 ? pr.mask_off + (idx - pr.out_off) + 1 : 0;
+              }
+            }
+            eb[3] = (live ? 1 : 0) | (prelu << 1) | (pmask << 2);
+          }
         }
       }
-    }
+    // MFM_LATENT_PRE=1 (opt-in): chain workgroups of 512 threads that request the weights four stages ahead instead of one
+    // -- measured no faster (13.5 vs 13.8 us forward: the stages are not waiting for weights), profiles/r02_latent_chains.txt
+    L.pre = 0;
+    if (const char* e = getenv("MFM_LATENT_PRE")) L.pre = (atoi(e) != 0 && L.nch > 1 && L.nstages <= 6) ? 1 : 0;
+    for (int ch = 0; ch < L.nch && L.pre; ++ch)
+      for (int st = 0; st < L.nstages; ++st)
+        if (L.nitems_fwd_c[ch][st] > 512 || L.nitems_bwd_c[ch][st] > 512) L.pre = 0;
+    if (L.nch > 1)       // whole-stage counts (bias-gradient loops of the backward walk all layers of a stage)
+      for (int st = 0; st < L.nstages; ++st) {
+        int sn = 0, sk = 0;
+        for (int i = L.stage_begin[st]; i < L.stage_begin[st + 1]; ++i) { sn += P->lat_ops[i].N; sk += P->lat_ops[i].K; }
+        L.nitems_fwd[st] = 4 * sn; L.nitems_bwd[st] = 4 * sk;
+      }
   }
 
   P->lat_ops_off = carve(cur, (int64_t)(sizeof(P->lat_ops) / (sizeof(float))));
@@ -677,7 +714,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     LatentDev L = P->lat;
     L.ops = reinterpret_cast<const LatOp*>(W + P->lat_ops_off);
     L.items_fwd = reinterpret_cast<const int*>(W + P->lat_items_off);
-    L.items_bwd = L.items_fwd + (size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
+    L.items_bwd = L.items_fwd + (size_t)4 * MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
     if (getenv("MFM_LATENT_DBG")) L.dbg = reinterpret_cast<unsigned long long*>(W + P->dbg_off);
     for (int e = 0; e < 4; ++e) {
       if (e == 3 && V != 0) { L.enc_h[e] = W + P->zyin; L.enc_ld[e] = P->nzy; continue; }
@@ -1000,7 +1037,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     LatentDev L = P->lat;
     L.ops = reinterpret_cast<const LatOp*>(W + P->lat_ops_off);
     L.items_fwd = reinterpret_cast<const int*>(W + P->lat_items_off);
-    L.items_bwd = L.items_fwd + (size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
+    L.items_bwd = L.items_fwd + (size_t)4 * MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
     if (getenv("MFM_LATENT_DBG")) L.dbg = reinterpret_cast<unsigned long long*>(W + P->dbg_off);
     for (int m = 0; m < 3; ++m) {
       L.d_dec_init[m] = gen_on ? W + P->dec_dinit[m] : nullptr;
