@@ -165,6 +165,7 @@ struct LatentDev {
   // chain, chain c owns floats [ch_lo[c], ch_hi[c]) of it.  nch == 1: one workgroup per row, tables at index 0.
   int nch, ch_lo[4], ch_hi[4];
   int pre;                             // chain workgroups of 512 threads that request every stage's weights up front (latent.hip)
+  int row_threads;                     // threads per row-path workgroup: 512 when no chain stage has more items, else 1024
   int nitems_fwd_c[4][MFM_LAT_MAXSTAGES], nitems_bwd_c[4][MFM_LAT_MAXSTAGES];
   uint64_t seed;
   float reg_w, disc_w, gen_w;

@@ -948,7 +948,7 @@ int latent_fwd_launch(const LatentDev& L, const float* params, hipStream_t strea
       hipLaunchKernelGGL(latent_fwd_row_kernel<true>, dim3(L.B * L.nch), dim3(LAT_PRE_THREADS), lds1, stream, L, params);
     } else {
       if (int rc1 = set_lds_limit((const void*)latent_fwd_row_kernel<false>, lds1)) return rc1;
-      hipLaunchKernelGGL(latent_fwd_row_kernel<false>, dim3(L.B * L.nch), dim3(LAT_THREADS), lds1, stream, L, params);
+      hipLaunchKernelGGL(latent_fwd_row_kernel<false>, dim3(L.B * L.nch), dim3(L.row_threads), lds1, stream, L, params);
     }
     MFM_LAUNCH_CHECK("latent_fwd_row_kernel");
     return MFM_OK;
@@ -973,7 +973,7 @@ int latent_bwd_launch(const LatentDev& L, const float* params, float* grads, hip
       hipLaunchKernelGGL(latent_bwd_row_kernel<true>, dim3(L.B * L.nch), dim3(LAT_PRE_THREADS), lds1, stream, L, params, grads);
     } else {
       if (int rc1 = set_lds_limit((const void*)latent_bwd_row_kernel<false>, lds1)) return rc1;
-      hipLaunchKernelGGL(latent_bwd_row_kernel<false>, dim3(L.B * L.nch), dim3(LAT_THREADS), lds1, stream, L, params, grads);
+      hipLaunchKernelGGL(latent_bwd_row_kernel<false>, dim3(L.B * L.nch), dim3(L.row_threads), lds1, stream, L, params, grads);
     }
     MFM_LAUNCH_CHECK("latent_bwd_row_kernel");
     return MFM_OK;

@@ -417,6 +417,17 @@ static int build(MfmPlan* P) {
     for (int ch = 0; ch < L.nch && L.pre; ++ch)
       for (int st = 0; st < L.nstages; ++st)
         if (L.nitems_fwd_c[ch][st] > 512 || L.nitems_bwd_c[ch][st] > 512) L.pre = 0;
+    // chain workgroups whose widest stage fits 512 threads are launched with 512: half the item table to copy in the prologue
+    // (16 bytes per thread and stage), half the waves to walk through every barrier
+    L.row_threads = MFM_LAT_ROW_THREADS;
+    if (L.nch > 1) {
+      int mx = 0;
+      for (int ch = 0; ch < L.nch; ++ch)
+        for (int st = 0; st < L.nstages; ++st) mx = std::max(mx, std::max(L.nitems_fwd_c[ch][st], L.nitems_bwd_c[ch][st]));
+      int in_sum = 0;
+      for (int e = 0; e < 4; ++e) in_sum += L.enc_n[e];
+      if (mx <= 512 && in_sum <= 512 && !(getenv("MFM_LATENT_512") && atoi(getenv("MFM_LATENT_512")) == 0)) L.row_threads = 512;
+    }
     if (L.nch > 1)       // whole-stage counts (bias-gradient loops of the backward walk all layers of a stage)
       for (int st = 0; st < L.nstages; ++st) {
         int sn = 0, sk = 0;
