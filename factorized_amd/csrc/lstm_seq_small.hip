@@ -99,6 +99,35 @@ __device__ __forceinline__ void stage_gate(const SeqDev& d, int mode, int g, flo
   }
 }
 
+// Two gates per round for the one-row BPTT prologue: both gates' [h x h] blocks are requested before either is parked in
+// LDS, so the prologue pays two L2 round trips instead of four (a workgroup is alone on its CU and its bandwidth is what
+// it keeps in flight: 4 loads per thread and round trip were ~14 B/clk, ~2 us per gate; decoders stage W_ih + W_hh).
+__device__ __forceinline__ void stage_gates2(const SeqDev& d, int mode, int g, float* __restrict__ panel, int tid, int nt) {
+  const int n = d.h * d.h;
+  if ((n & 3) != 0) {          // scalar fallback
+    stage_gate(d, mode, g, panel, tid, nt);
+    stage_gate(d, mode, g + 1, panel + n, tid, nt);
+    return;
+  }
+  const int n4 = n >> 2;
+  const f32x4* a4 = reinterpret_cast<const f32x4*>((mode == 0 ? d.w_hh : d.w_ih) + (int64_t)g * n);
+  const f32x4* b4 = reinterpret_cast<const f32x4*>(d.w_hh + (int64_t)g * n);
+  f32x4* p4 = reinterpret_cast<f32x4*>(panel);
+  // gates g and g + 1 are adjacent in memory: one range of 2 n4 vectors
+  for (int base = tid; base < 2 * n4; base += 8 * nt) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = a4[min(base + u * nt, 2 * n4 - 1)];
+    if (mode == 2) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] += b4[min(base + u * nt, 2 * n4 - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (base + u * nt < 2 * n4) p4[base + u * nt] = v[u];
+  }
+}
+
 // --------------------------------------------------------------------------------- forward
 // Global traffic goes through LDS so that it is issued by full, coalesced waves: a vector-memory
 // instruction occupies the CU's address unit for ~16 clocks per wave whether 2 or 64 lanes carry data,
@@ -383,39 +412,46 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
 
   float* dabuf = lds;                       // [2][4][HKB][R]
   float* sbuf = lds + 2 * 4 * HKB * R;      // [2][NV][HKB][R] saved activations of the coming step
-  float* panel = sbuf + 2 * NV * HKB * R;   // [h][h] weight staging
+  float* panel = sbuf + 2 * NV * HKB * R;   // [1 or 2][h][h] weight staging (one-row tiles: two gates per round)
 
   float wa[NW], wb[NW];
   auto load_wT = [&](int mode) {
     const int uac = min(ua, h - 1), ubc = min(ub, h - 1);
+    constexpr int PG = (R == 1) ? 2 : 1;          // gates staged per round (the panel holds PG blocks: small_lds_bytes)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      stage_gate(d, mode, g, panel, tid, nt);
+    for (int g0 = 0; g0 < 4; g0 += PG) {
+      if constexpr (PG == 2) stage_gates2(d, mode, g0, panel, tid, nt);
+      else stage_gate(d, mode, g0, panel, tid, nt);
       __syncthreads();
-      if constexpr (KS == 16) {
 #pragma unroll
-        for (int i = 0; i < NG; ++i) {
-          const int j = 16 * i + q;                    // unit index of this gate column
-          const int jc = min(j, h - 1);
-          const float va = panel[jc * h + uac], vb = panel[jc * h + ubc];
-          wa[g * NG + i] = (j < h && ua < h) ? va : 0.0f;
-          wb[g * NG + i] = (j < h && ub < h) ? vb : 0.0f;
-        }
-      } else {
-        // block m of this lane = flat gate columns 32 m + 4 q + {0..3}; a block never straddles two gates (HKB % 4 == 0)
+      for (int gg = 0; gg < PG; ++gg) {
+        const int g = g0 + gg;
+        const float* pan = panel + gg * h * h;
+        if constexpr (KS == 16) {
 #pragma unroll
-        for (int m = 0; m < NB; ++m) {
-          const int c0 = 32 * m + 4 * q;
-          const int cg = c0 / HKB, j0 = c0 - cg * HKB;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int j = j0 + e;
+          for (int i = 0; i < NG; ++i) {
+            const int j = 16 * i + q;                    // unit index of this gate column
             const int jc = min(j, h - 1);
-            const float va = panel[jc * h + uac], vb = panel[jc * h + ubc];
-            const float na = (j < h && ua < h) ? va : 0.0f, nb = (j < h && ub < h) ? vb : 0.0f;
-            if (g == 0) { wa[4 * m + e] = 0.0f; wb[4 * m + e] = 0.0f; }
-            wa[4 * m + e] = (cg == g) ? na : wa[4 * m + e];
-            wb[4 * m + e] = (cg == g) ? nb : wb[4 * m + e];
+            const float va = pan[jc * h + uac], vb = pan[jc * h + ubc];
+            wa[g * NG + i] = (j < h && ua < h) ? va : 0.0f;
+            wb[g * NG + i] = (j < h && ub < h) ? vb : 0.0f;
+          }
+        } else {
+          // block m of this lane = flat gate columns 32 m + 4 q + {0..3}; a block never straddles two gates (HKB % 4 == 0)
+#pragma unroll
+          for (int m = 0; m < NB; ++m) {
+            const int c0 = 32 * m + 4 * q;
+            const int cg = c0 / HKB, j0 = c0 - cg * HKB;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int j = j0 + e;
+              const int jc = min(j, h - 1);
+              const float va = pan[jc * h + uac], vb = pan[jc * h + ubc];
+              const float na = (j < h && ua < h) ? va : 0.0f, nb = (j < h && ub < h) ? vb : 0.0f;
+              if (g == 0) { wa[4 * m + e] = 0.0f; wb[4 * m + e] = 0.0f; }
+              wa[4 * m + e] = (cg == g) ? na : wa[4 * m + e];
+              wb[4 * m + e] = (cg == g) ? nb : wb[4 * m + e];
+            }
           }
         }
       }
@@ -745,7 +781,8 @@ static size_t small_lds_bytes(const SeqLaunch& L, bool bwd, int R) {
     // forward: h ring + max(weight panel, output record + x-projection record); backward: dA ring +
     // saved-activation record + weight panel (see the bodies)
     const size_t rec = (2 * 6 + 2 * 4) * HKB * R;
-    const size_t need = (bwd ? (2 * 4 + 2 * 7) * HKB * R + hh : 2 * HKB * R + (2 * hh > rec ? 2 * hh : rec)) * sizeof(float);
+    // backward, one-row tiles: the weight panel holds two gates (stage_gates2)
+    const size_t need = (bwd ? (2 * 4 + 2 * 7) * HKB * R + (R == 1 ? 2 : 1) * hh : 2 * HKB * R + (2 * hh > rec ? 2 * hh : rec)) * sizeof(float);
     if (need > lds_bytes) lds_bytes = need;
   }
   return (lds_bytes + 15) / 16 * 16;
