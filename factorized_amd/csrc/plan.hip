@@ -1423,7 +1423,15 @@ extern "C" double mfm_plan_kernel_flops(const MfmPlan* P, int kid) {
     // (variants 1, 2 run the six encoder recurrences as two launches: this is the sum of both)
     case K_ENC_FWD: case K_ENC_BWD: for (int e = 0; e < P->n_enc; ++e) f += TB * 2.0 * 4.0 * P->enc_h[e] * P->enc_h[e]; break;
     case K_DEC_FWD: case K_DEC_BWD: for (int m = 0; m < 3; ++m) f += TB * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m]; break;
-    case K_FC1_FWD: for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m]; break;
+    case K_FC1_FWD: {
+      for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m];
+      // the fused kernel (dec_fc1.hip; the plan's default up to 5120 rows) also forms dH = dx_hat Wfc in the same launch
+      long fc1_max_rows = 5120;
+      if (const char* e = getenv("MFM_FC1_FUSED_MAXROWS")) fc1_max_rows = atol(e);
+      const bool on = !(getenv("MFM_FC1_FUSED") && atoi(getenv("MFM_FC1_FUSED")) == 0);
+      if (on && TB <= (double)fc1_max_rows) f *= 2.0;
+      break;
+    }
     case K_FC1_BWD: for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m]; break;   // dH only
     case K_DEC_DW: break;   // merged into K_ENC_DW
     case K_ENC_DW:
@@ -1432,6 +1440,25 @@ extern "C" double mfm_plan_kernel_flops(const MfmPlan* P, int kid) {
       for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m];            // dWfc
       for (int i = 0; i < P->lat.nops; ++i) f += 2.0 * P->B * P->lat_ops[i].N * P->lat_ops[i].K;   // latent dW
       break;
+    // Memory Fusion Network (variants 1, 2), GEMM form: per-launch AVERAGE over the launches that share the timer id
+    case K_MFN_ATT_FWD: {
+      const MfmPlanConfig& c = P->cfg;
+      const double A2 = P->A2, M = c.mem_dim;
+      f = TB * 2.0 * (A2 * c.nn1 + c.nn1 * A2 + A2 * (c.nn2 + c.g1 + c.g2) + c.nn2 * M) / 4.0;
+      break;
+    }
+    case K_MFN_ATT_BWD: {
+      const MfmPlanConfig& c = P->cfg;
+      const double A2 = P->A2, M = c.mem_dim;
+      f = TB * 2.0 * (M * c.nn2 + (c.nn2 + c.g1 + c.g2) * A2 + A2 * c.nn1 + c.nn1 * A2) / 4.0;
+      break;
+    }
+    case K_MFN_MEM_FWD: case K_MFN_MEM_BWD: {
+      const MfmPlanConfig& c = P->cfg;
+      f = TB * 2.0 * 2.0 * c.mem_dim * (c.g1 + c.g2);        // W_mem,n mem and W_fc2,n u_n for both gates
+      break;
+    }
+    case K_MFN_HEADS: f = 2.0 * P->B * (P->tot + P->cfg.mem_dim) * P->cfg.zy * (P->cfg.variant == 1 ? 2 : 1); break;
     default: break;
   }
   return f;
