@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libmfm_hip.so")
 
 MFM_KLEF_NPARAM = 78
 MFM_LOSS_SLOTS = 8
-MFM_MAX_SEQ = 4
+MFM_MAX_SEQ = 6
 
 
 class MfmError(RuntimeError):

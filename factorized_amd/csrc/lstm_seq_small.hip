@@ -702,7 +702,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_kernel(const SeqLaunch L)
 // are pre-instantiated; any other size combination takes the generic kernel above.
 // KS = 8 (backward, one-row tiles): 4 * Hp threads per workgroup, launched with at most 512 -> 256 VGPRs per thread for
 // the doubled resident weights.
-template <bool BWD, int R, int K0, int K1, int K2, int K3, int KS = 16>
+template <bool BWD, int R, int KS, int K0, int K1, int K2, int K3, int K4 = 0, int K5 = 0>
 __global__ __launch_bounds__(KS == 16 ? 1024 : 512) void lstm_seq_small_kernel4(const SeqLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int di = 0;
@@ -718,30 +718,30 @@ __global__ __launch_bounds__(KS == 16 ? 1024 : 512) void lstm_seq_small_kernel4(
     else small_fwd_body<(KK > 0 ? KK : 2), R>(d, L.T, L.B, tile, lds);           \
     return;                                                                      \
   }
-  MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3)
+  MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3) MFM_ONE(4, K4) MFM_ONE(5, K5)
 #undef MFM_ONE
 }
 
-template <int R, int K0, int K1, int K2, int K3, int KS = 16>
+template <int R, int KS, int K0, int K1, int K2, int K3, int K4 = 0, int K5 = 0>
 static bool try_launch4(const SeqLaunch& L, bool bwd, int total, int threads, size_t lds_bytes, hipStream_t stream,
                         hipError_t* err) {
-  const int want[4] = {K0, K1, K2, K3};
+  const int want[6] = {K0, K1, K2, K3, K4, K5};
   int n = 0;
-  for (int i = 0; i < 4; ++i) if (want[i] > 0) n = i + 1;
+  for (int i = 0; i < 6; ++i) if (want[i] > 0) n = i + 1;
   if (L.count != n) return false;
   for (int i = 0; i < n; ++i) if (L.d[i].hk4 != want[i]) return false;
   *err = hipSuccess;
   if (lds_bytes > 64 * 1024) {
-    *err = bwd ? hipFuncSetAttribute((const void*)lstm_seq_small_kernel4<true, R, K0, K1, K2, K3, KS>,
+    *err = bwd ? hipFuncSetAttribute((const void*)lstm_seq_small_kernel4<true, R, KS, K0, K1, K2, K3, K4, K5>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)
-               : hipFuncSetAttribute((const void*)lstm_seq_small_kernel4<false, R, K0, K1, K2, K3>,
+               : hipFuncSetAttribute((const void*)lstm_seq_small_kernel4<false, R, KS, K0, K1, K2, K3, K4, K5>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (*err != hipSuccess) return true;
   }
   if (bwd)
-    hipLaunchKernelGGL((lstm_seq_small_kernel4<true, R, K0, K1, K2, K3, KS>), dim3(total), dim3(threads), lds_bytes, stream, L);
+    hipLaunchKernelGGL((lstm_seq_small_kernel4<true, R, KS, K0, K1, K2, K3, K4, K5>), dim3(total), dim3(threads), lds_bytes, stream, L);
   else
-    hipLaunchKernelGGL((lstm_seq_small_kernel4<false, R, K0, K1, K2, K3>), dim3(total), dim3(threads), lds_bytes, stream, L);
+    hipLaunchKernelGGL((lstm_seq_small_kernel4<false, R, KS, K0, K1, K2, K3, K4, K5>), dim3(total), dim3(threads), lds_bytes, stream, L);
   return true;
 }
 
@@ -749,26 +749,29 @@ template <int R>
 static bool try_all(const SeqLaunch& L, bool bwd, int total, int threads, size_t lds_bytes, hipStream_t stream,
                     hipError_t* err) {
   // (from 2 rounds of workgroups on, the launcher orders the LSTMs of a call widest first: lstm_seq.hip)
-  return try_launch4<R, 8, 2, 20, 30>(L, bwd, total, threads, lds_bytes, stream, err) ||     // MFM_KL_EF encoders
-         try_launch4<R, 30, 20, 8, 2>(L, bwd, total, threads, lds_bytes, stream, err) ||
-         try_launch4<R, 26, 6, 6, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||      // decoders
-         try_launch4<R, 30, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||      // single-LSTM launches
-         try_launch4<R, 26, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||
-         try_launch4<R, 8, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||
+  return try_launch4<R, 16, 8, 2, 20, 30>(L, bwd, total, threads, lds_bytes, stream, err) ||     // MFM_KL_EF encoders
+         try_launch4<R, 16, 30, 20, 8, 2>(L, bwd, total, threads, lds_bytes, stream, err) ||
+         try_launch4<R, 16, 26, 6, 6, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||      // decoders
+         try_launch4<R, 16, 30, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||      // single-LSTM launches
+         try_launch4<R, 16, 26, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||
+         try_launch4<R, 16, 8, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||
          // MFM / MFM_KL on the module path (mfm_model.py::seq_group): encoders 32/8/80 + MFN LSTM 88, MFN 64/48
-         try_launch4<R, 8, 2, 20, 22>(L, bwd, total, threads, lds_bytes, stream, err) ||
-         try_launch4<R, 16, 12, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err);
+         try_launch4<R, 16, 8, 2, 20, 22>(L, bwd, total, threads, lds_bytes, stream, err) ||
+         try_launch4<R, 16, 16, 12, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||
+         // MFM / MFM_KL on the fused plan: all six LSTMs of the step (encoders 32/8/80, MFN 88/64/48) in one launch
+         try_launch4<R, 16, 8, 2, 20, 22, 16, 12>(L, bwd, total, threads, lds_bytes, stream, err);
 }
 
 // backward, one-row tiles, 8 k-slices (4 * Hp threads): the pre-instantiated size tuples
 static bool try_all_fat(const SeqLaunch& L, int total, int threads, size_t lds_bytes, hipStream_t stream, hipError_t* err) {
-  return try_launch4<1, 8, 2, 20, 30, 8>(L, true, total, threads, lds_bytes, stream, err) ||
-         try_launch4<1, 26, 6, 6, 0, 8>(L, true, total, threads, lds_bytes, stream, err) ||
-         try_launch4<1, 30, 0, 0, 0, 8>(L, true, total, threads, lds_bytes, stream, err) ||
-         try_launch4<1, 26, 0, 0, 0, 8>(L, true, total, threads, lds_bytes, stream, err) ||
-         try_launch4<1, 8, 0, 0, 0, 8>(L, true, total, threads, lds_bytes, stream, err) ||
-         try_launch4<1, 8, 2, 20, 22, 8>(L, true, total, threads, lds_bytes, stream, err) ||
-         try_launch4<1, 16, 12, 0, 0, 8>(L, true, total, threads, lds_bytes, stream, err);
+  return try_launch4<1, 8, 8, 2, 20, 30>(L, true, total, threads, lds_bytes, stream, err) ||
+         try_launch4<1, 8, 26, 6, 6, 0>(L, true, total, threads, lds_bytes, stream, err) ||
+         try_launch4<1, 8, 30, 0, 0, 0>(L, true, total, threads, lds_bytes, stream, err) ||
+         try_launch4<1, 8, 26, 0, 0, 0>(L, true, total, threads, lds_bytes, stream, err) ||
+         try_launch4<1, 8, 8, 0, 0, 0>(L, true, total, threads, lds_bytes, stream, err) ||
+         try_launch4<1, 8, 8, 2, 20, 22>(L, true, total, threads, lds_bytes, stream, err) ||
+         try_launch4<1, 8, 16, 12, 0, 0>(L, true, total, threads, lds_bytes, stream, err) ||
+         try_launch4<1, 8, 8, 2, 20, 22, 16, 12>(L, true, total, threads, lds_bytes, stream, err);
 }
 
 static size_t small_lds_bytes(const SeqLaunch& L, bool bwd, int R) {

@@ -84,7 +84,7 @@ int mfm_gemm_grouped_bf16(const MfmGemmDesc* descs /*host*/, int count, void* st
  *   step 0 consumes h_init [B, ld_init] through w_ih from zero state; steps >=1 feed the
  *   hidden state back as the input, i.e. gates = h (W_ih+W_hh)^T + b_ih + b_hh.
  */
-#define MFM_MAX_SEQ 4
+#define MFM_MAX_SEQ 6
 typedef struct MfmSeqDesc {
   float* gates; float* hs; float* cs;
   const float* w_hh; const float* w_ih; const float* b_ih; const float* b_hh;
