@@ -100,6 +100,19 @@ struct MfnAttFused {
 bool mfn_att_fused_supported(const MfnAttFused& L);
 int mfn_att_fused_fwd_launch(const MfnAttFused& L, hipStream_t stream);
 int mfn_att_fused_bwd_launch(const MfnAttFused& L, hipStream_t stream);   // dcx must have been cleared (it is added to)
+// mfn_mem.hip -- the heads on mfn_last = [h_l, h_a, h_v](T-1) | mem_T (mu_y and, variant 1, logvar_y) folded into the
+// memory recurrence launches: forward as the kernel's tail (mem_T is in its LDS), backward as its head (d mem_T and d h_T
+// from d [mu_y | logvar_y]); two ~6 us GEMM launches less per step.  The heads' weight gradients stay in the tail GEMM.
+struct MfnHeadsDev {
+  int on, tot, nheads, zy, nzy;
+  const float* seg[3]; int seg_ld[3], seg_n[3];     // last hidden state rows [B, ld] of the three MFN LSTMs
+  const float* w[2]; const float* b[2];             // head weights [zy, tot + M], biases [zy]
+  float* zyin;                                      // forward out [B, nzy]: head hd at columns hd * zy
+  const float* dz;                                  // backward in [B, nzy]
+  float* d_hT;                                      // backward out [B, tot]
+};
+int mfn_mem_fwd_launch(const MfmMemDesc* desc, const MfnHeadsDev* heads, hipStream_t stream);
+int mfn_mem_bwd_launch(const MfmMemDesc* desc, const MfnHeadsDev* heads, hipStream_t stream);
 // mmd.hip -- strided form of mfm_mmd_fwd_bwd: z / dz are column blocks of wider row-major buffers
 int mmd_launch(const float* z, int64_t ldz, const float* g, int64_t ldg, int B, int dim, float* loss, float* dz, int64_t lddz,
                float dz_scale, hipStream_t stream);

@@ -69,6 +69,7 @@ struct MemDev {
   int QA, KA, QB, KB1, KB2;       // lanes per output / weights per lane of the two matvec shapes
   int MP, H1P, H2P;               // LDS extents: 32 QA, 32 QB, 32 QB
   int64_t ldw;                    // row stride of the memory-column weight blocks
+  MfnHeadsDev hd;                 // heads on [h_T | mem_T] folded into the launch (internal.h); hd.on == 0: not used
 };
 
 // ------------------------------------------------------------------------------------- forward
@@ -184,6 +185,29 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_fwd_kernel(const MemDev P) {
     cur ^= 1;
   }
   if (actB && qb == 0 && d.mem_out) d.mem_out[mrow] = memr;
+  // ---- heads on mfn_last = [h_l, h_a, h_v](T-1) | mem_T (mem_T sits in memb[cur]): 8 lanes per output, K = tot + M
+  if (P.hd.on) {
+    const MfnHeadsDev& H = P.hd;
+    const int KT = H.tot + M, nout = H.nheads * H.zy;
+    const int q8 = tid & 7;
+    const int n0 = H.seg_n[0], n1 = n0 + H.seg_n[1];
+    for (int o = tid >> 3; o < nout; o += (int)blockDim.x >> 3) {
+      const int hd = o / H.zy, n = o - hd * H.zy;
+      const float* wr = H.w[hd] + (int64_t)n * KT;
+      float s = 0.0f;
+#pragma unroll 8
+      for (int k = q8; k < KT; k += 8) {
+        float v;
+        if (k < n0) v = H.seg[0][(int64_t)row * H.seg_ld[0] + k];
+        else if (k < n1) v = H.seg[1][(int64_t)row * H.seg_ld[1] + (k - n0)];
+        else if (k < H.tot) v = H.seg[2][(int64_t)row * H.seg_ld[2] + (k - n1)];
+        else v = memb[cur * MP + (k - H.tot)];
+        s = fmaf(wr[k], v, s);
+      }
+      s = group_sum(s, 8);
+      if (q8 == 0) H.zyin[(int64_t)row * H.nzy + hd * H.zy + n] = s + H.b[hd][n];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------- backward
@@ -232,6 +256,26 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_bwd_kernel(const MemDev P) {
   const int64_t arow = ((int64_t)row) * Hn + jn;
   const int64_t mrow = ((int64_t)row) * M + mb;
   float dmem = d.dmem_out ? d.dmem_out[mrow] : 0.0f;     // dL/d mem_T
+  if (P.hd.on) {
+    // through the heads: d mem_T[m] = sum_{head, n} dz[n] W[n][tot + m] (every lane of the group of m), and
+    // d h_T[j] = sum dz[n] W[n][j] for the three LSTMs' last hidden states (one output per thread)
+    const MfnHeadsDev& H = P.hd;
+    const int KT = H.tot + M;
+    float acc = 0.0f;
+    for (int hd = 0; hd < H.nheads; ++hd) {
+#pragma unroll 16
+      for (int n = 0; n < H.zy; ++n) acc = fmaf(H.dz[(int64_t)row * H.nzy + hd * H.zy + n], H.w[hd][(int64_t)n * KT + H.tot + mb], acc);
+    }
+    dmem = acc;
+    for (int j = tid; j < H.tot; j += blockDim.x) {
+      float a = 0.0f;
+      for (int hd = 0; hd < H.nheads; ++hd) {
+#pragma unroll 16
+        for (int n = 0; n < H.zy; ++n) a = fmaf(H.dz[(int64_t)row * H.nzy + hd * H.zy + n], H.w[hd][(int64_t)n * KT + j], a);
+      }
+      H.d_hT[(int64_t)row * H.tot + j] = a;
+    }
+  }
   // saved operands of step T-1
   int64_t o = (int64_t)(T - 1) * B * M + mrow;
   float g1_n = d.gam1[o], g2_n = d.gam2[o], ch_n = d.chat[o];
@@ -336,27 +380,46 @@ int mem_setup(const MfmMemDesc* desc, MemDev& P, int& threads, size_t& lds) {
 
 using namespace mfm;
 
-extern "C" int mfm_mfn_mem_fwd(const MfmMemDesc* desc, void* stream) {
+int mfm::mfn_mem_fwd_launch(const MfmMemDesc* desc, const MfnHeadsDev* heads, hipStream_t stream) {
   if (!desc) { set_error("mfm_mfn_mem_fwd: null descriptor"); return MFM_ERR_ARG; }
   MemDev P;
   int threads = 0; size_t lds = 0;
   int rc = mem_setup(desc, P, threads, lds);
   if (rc != MFM_OK) return rc;
+  memset(&P.hd, 0, sizeof(P.hd));
+  if (heads && heads->on) {
+    MFM_REQUIRE(heads->nheads >= 1 && heads->nheads <= 2 && heads->zyin && heads->w[0] && heads->b[0] && threads >= 64,
+                "mfn_mem: heads descriptor");
+    P.hd = *heads;
+  }
   if (threads <= 512) hipLaunchKernelGGL(mfn_mem_fwd_kernel<512>, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
   else hipLaunchKernelGGL(mfn_mem_fwd_kernel<1024>, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
   MFM_LAUNCH_CHECK("mfn_mem_fwd_kernel");
   return MFM_OK;
 }
 
-extern "C" int mfm_mfn_mem_bwd(const MfmMemDesc* desc, void* stream) {
+extern "C" int mfm_mfn_mem_fwd(const MfmMemDesc* desc, void* stream) {
+  return mfm::mfn_mem_fwd_launch(desc, nullptr, (hipStream_t)stream);
+}
+
+int mfm::mfn_mem_bwd_launch(const MfmMemDesc* desc, const MfnHeadsDev* heads, hipStream_t stream) {
   if (!desc) { set_error("mfm_mfn_mem_bwd: null descriptor"); return MFM_ERR_ARG; }
   MemDev P;
   int threads = 0; size_t lds = 0;
   int rc = mem_setup(desc, P, threads, lds);
   if (rc != MFM_OK) return rc;
   MFM_REQUIRE(desc->du1 && desc->du2 && desc->dchat, "mfm_mfn_mem_bwd: null gradient output");
+  memset(&P.hd, 0, sizeof(P.hd));
+  if (heads && heads->on) {
+    MFM_REQUIRE(heads->nheads >= 1 && heads->nheads <= 2 && heads->dz && heads->d_hT && heads->w[0], "mfn_mem: heads descriptor (backward)");
+    P.hd = *heads;
+  }
   if (threads <= 512) hipLaunchKernelGGL(mfn_mem_bwd_kernel<512>, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
   else hipLaunchKernelGGL(mfn_mem_bwd_kernel<1024>, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
   MFM_LAUNCH_CHECK("mfn_mem_bwd_kernel");
   return MFM_OK;
+}
+
+extern "C" int mfm_mfn_mem_bwd(const MfmMemDesc* desc, void* stream) {
+  return mfm::mfn_mem_bwd_launch(desc, nullptr, (hipStream_t)stream);
 }

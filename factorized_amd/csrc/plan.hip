@@ -530,6 +530,26 @@ static bool mfn_fused_desc(const MfmPlan* P, const float* params, float* W, MfnA
   return mfn_att_fused_supported(F);
 }
 
+// The heads on [h_l, h_a, h_v](T-1) | mem_T folded into the memory-recurrence launches (fp32 plans; MFM_MFN_HEADS_FOLD=0:
+// the grouped-GEMM form, which bf16 plans keep for their bf16-rounded operands)
+static bool mfn_heads_desc(const MfmPlan* P, const float* params, float* W, MfnHeadsDev& H) {
+  const MfmPlanConfig& c = P->cfg;
+  const PIdx& pi = P->pi;
+  memset(&H, 0, sizeof(H));
+  H.tot = P->tot; H.nheads = (c.variant == 1) ? 2 : 1; H.zy = c.zy; H.nzy = P->nzy;
+  for (int m = 0; m < 3; ++m) {
+    const SeqBuf& sb = P->enc[3 + m];
+    H.seg[m] = W + sb.hs + (int64_t)(P->T - 1) * P->B * sb.Hp; H.seg_ld[m] = sb.Hp; H.seg_n[m] = sb.h;
+  }
+  H.w[0] = PW(P, params, pi.to_z[3]); H.b[0] = PW(P, params, pi.to_z[3] + 1);
+  if (H.nheads == 2) { H.w[1] = PW(P, params, pi.to_lv[3]); H.b[1] = PW(P, params, pi.to_lv[3] + 1); }
+  H.zyin = W + P->zyin; H.dz = W + P->dh_last[3]; H.d_hT = W + P->d_hT;
+  bool on = c.precision == 0;
+  if (const char* e = getenv("MFM_MFN_HEADS_FOLD")) on = on && atoi(e) != 0;
+  H.on = on ? 1 : 0;
+  return on;
+}
+
 static int mfn_forward(MfmPlan* P, const float* params, int train, uint64_t seed, float* W, hipStream_t s) {
   const MfmPlanConfig& c = P->cfg;
   const PIdx& pi = P->pi;
@@ -595,7 +615,10 @@ static int mfn_forward(MfmPlan* P, const float* params, int train, uint64_t seed
     md.gam1 = W + P->gam1; md.gam2 = W + P->gam2; md.mems = W + P->mems; md.mem_out = W + P->mem_out;
     md.T = T; md.B = B; md.M = M; md.H1 = c.g1; md.H2 = c.g2; md.train = train;
     md.p1 = c.drop_g1; md.p2 = c.drop_g2; md.seed = es.seed ^ 0x5DEECE66Dull;
-    RUN(K_MFN_MEM_FWD, mfm_mfn_mem_fwd(&md, s));
+    MfnHeadsDev H;
+    mfn_heads_desc(P, params, W, H);
+    RUN(K_MFN_MEM_FWD, mfn_mem_fwd_launch(&md, &H, s));
+    if (H.on) return MFM_OK;          // mu_y (and logvar_y) came out of the same launch
   }
   {   // heads on mfn_last = [h_l(T-1), h_a(T-1), h_v(T-1), mem]: mu_y (and logvar_y), summed over the four segments
     // into the zero-filled latent input (accumulating problems; the bias rides on the first segment)
@@ -909,7 +932,8 @@ static int mfn_backward(MfmPlan* P, const float* params, float* W, float* grads,
       }
       colsum(dz, P->nzy, c.zy, grads + P->off[widx + 1], B);
     }
-    RUN(K_MFN_HEADS, gemm_group_launch(g, n, s, nullptr, nullptr, 0, prec));
+    MfnHeadsDev Hc;
+    if (!mfn_heads_desc(P, params, W, Hc)) RUN(K_MFN_HEADS, gemm_group_launch(g, n, s, nullptr, nullptr, 0, prec));
   }
   {   // memory recurrence BPTT: dz_n (in gam_n), du_n, d(pre-tanh cHat)
     MfmMemDesc md;
@@ -923,7 +947,9 @@ static int mfn_backward(MfmPlan* P, const float* params, float* W, float* grads,
     md.dchat_pre_tanh = 1;
     md.T = T; md.B = B; md.M = M; md.H1 = c.g1; md.H2 = c.g2; md.train = 1;
     md.p1 = c.drop_g1; md.p2 = c.drop_g2;
-    RUN(K_MFN_MEM_BWD, mfm_mfn_mem_bwd(&md, s));
+    MfnHeadsDev H;
+    mfn_heads_desc(P, params, W, H);          // folded: d mem_T and d h_T are formed at the head of this launch
+    RUN(K_MFN_MEM_BWD, mfn_mem_bwd_launch(&md, &H, s));
   }
   MfnAttFused F;
   if (mfn_fused_desc(P, params, W, F)) {

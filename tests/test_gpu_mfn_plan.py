@@ -43,16 +43,21 @@ def _oracle(variant, cfgs, w, gauss=None):
     return m
 
 
-@pytest.fixture(params=["att-fused", "att-gemm"], autouse=True)
+@pytest.fixture(params=["att-fused", "att-gemm", "heads-gemm"], autouse=True)
 def att_path(request, monkeypatch):
     """Every test of this file runs on both forms of the MFN attention block: the grouped GEMMs + row kernels (the default)
     and mfn_att_fwd_kernel / mfn_att_bwd_kernel (one launch per direction with every intermediate in LDS; opt-in with
     MFM_MFN_FUSED=1 because it measured slower, forced here for any row count)."""
+    # "heads-gemm": the heads on [h_T | mem_T] as grouped GEMMs (MFM_MFN_HEADS_FOLD=0) instead of inside the memory
+    # recurrence launches (the fp32 default)
+    monkeypatch.delenv("MFM_MFN_HEADS_FOLD", raising=False)
     if request.param == "att-fused":
         monkeypatch.setenv("MFM_MFN_FUSED", "1")
         monkeypatch.setenv("MFM_MFN_FUSED_MAXROWS", "100000000")
     else:
         monkeypatch.setenv("MFM_MFN_FUSED", "0")
+    if request.param == "heads-gemm":
+        monkeypatch.setenv("MFM_MFN_HEADS_FOLD", "0")
     return request.param
 
 
