@@ -184,6 +184,9 @@ struct LatentDev {
   float reg_w, disc_w, gen_w;
 };
 int latent_fwd_launch(const LatentDev& L, const float* params, hipStream_t stream);
+// lstm_seq.hip / lstm_seq_small.hip -- the encoder recurrences of MFM_KL_EF with their rows' latent chains folded in
+int seq_fold_launch(const MfmSeqDesc* descs, int count, int T, int B, bool bwd, const LatentDev& lat, const float* params,
+                    float* grads, hipStream_t stream);
 int latent_bwd_launch(const LatentDev& L, const float* params, float* grads, hipStream_t stream);
 
 }  // namespace mfm

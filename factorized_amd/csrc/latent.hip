@@ -23,22 +23,15 @@
 // compiler copy the whole table to scratch in every thread.
 #include "internal.h"
 
+#include "latent_row_dev.h"
+
 namespace mfm {
 
-constexpr int LAT_THREADS = 1024;
-constexpr int LAT_PRE_THREADS = 512;         // chain workgroups with every stage's weights requested up front (256 VGPRs)
-constexpr int LAT_PRE_STAGES = 6;
-constexpr int LAT_PRE_SLOTS = 4;             // weights requested 4 stages ahead (6 resident slots spill: 222 + 60 registers)
 
 __device__ __forceinline__ float wave_sum_l(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
-}
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_quad(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
 }
 
 // linear global -> LDS copy of `n4` 16-byte chunks, 8 loads in flight per thread
@@ -75,10 +68,6 @@ __device__ __forceinline__ void span_store(const float* __restrict__ src, float*
   if (n4 > PRE_U * nt) copy_span(src + 4 * PRE_U * nt, dst + 4 * PRE_U * nt, n4 - PRE_U * nt, tid, nt);
 }
 
-// debug: phase timestamps of workgroup 0 (shader clock), enabled with MFM_LATENT_DBG=1
-__device__ __forceinline__ void mark(const LatentDev& L, int slot) {
-  if (L.dbg && blockIdx.x == 0 && threadIdx.x == 0) L.dbg[slot] = __builtin_readcyclecounter();
-}
 
 __device__ __forceinline__ void load_ops(const LatentDev& L, LatOp* ops) {
   for (int i = threadIdx.x; i < L.nops * (int)(sizeof(LatOp) / 4); i += blockDim.x)
@@ -91,16 +80,6 @@ __device__ __forceinline__ void load_ops(const LatentDev& L, LatOp* ops) {
 // trip per step, ~2000 cycles per item in the 8-op stages.
 __device__ __forceinline__ void build_prefix(const LatentDev& L, int* pfxN, int* pfxK) {
   for (int i = threadIdx.x; i < L.nops; i += blockDim.x) { pfxN[i] = L.ops[i].pfx_n; pfxK[i] = L.ops[i].pfx_k; }
-}
-__device__ __forceinline__ int find_op(const int* pfx, int ob, int oe, int x, int mult) {
-  int o = ob;
-#pragma unroll
-  for (int i = 1; i < 8; ++i) {
-    const int idx = min(ob + i, oe - 1);
-    const int p = pfx[idx] * mult;
-    o += (int)((ob + i < oe) & (x >= p));
-  }
-  return o;
 }
 
 // STAGED is a template parameter (not a runtime flag) so that the weight pointer has a static address
@@ -489,448 +468,20 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_kernel(const LatentDev
   }
 }
 
-// =====================================================================================================
-// Latency path: ONE batch row per workgroup, weights straight from L2 into registers.
-//
-// At the reference's minibatch (B=32) the stack is a chain of dependent stages of tiny matvecs; what costs
-// time is the chain, not the arithmetic.  The staged kernels above put 4 rows in a workgroup (8 workgroups
-// at B=32), copy each stage's weights into LDS and walk k in a dependent loop: ~4.5 us per stage
-// (profiles/r01 latent phase timeline).  Here every row gets its own workgroup (B workgroups), each weight
-// element is used exactly once per workgroup, so it goes global -> register with all loads of a stage in
-// flight at once, and the only LDS traffic is the activation / gradient record:
-//   forward : lane (n, q) of a quad holds W[n][4q+16j .. +3], j < 8, dots it with the input segment,
-//             quad all-reduce with two DPP adds.
-//   backward: lane (kc, l) of a 16-lane group holds W[l+16j][4kc .. +3], j < 8, accumulates g[n]*W[n][k],
-//             16-lane all-reduce with four DPP adds per value, lanes 0..3 add dX[4kc+l] into the record.
-// Which (layer, column) a thread owns in a stage is static; the host tabulates it (plan.hip) as one int4 per
-// thread and stage, the prologue copies the table into LDS, so a stage starts with one LDS read instead of
-// a search through the op table:
-//   forward  x = element offset of weight row n          y = element offset of bias[n]
-//            z = in_off | K << 16                         w = (out_off + n) | op << 16 | relu << 24 | mask << 25 | live << 26
-//   backward x = element offset of W[0][kc]               y = K | N << 8
-//            z = out_off | (in_off + kc) << 16            w = live | producer relu << 1 | (producer mask index + 1) << 2
-// Weights of stage s+1 are requested while stage s computes (two register slots whose roles swap by
-// unrolling the stage loop twice: copying a slot would need the data, i.e. wait for the prefetch).
-// Requirements (checked on the host, otherwise the staged kernels run): K % 4 == 0, K, N <= 128, weights
-// 16-byte aligned, one work item per thread and stage (4*sum N, 4*sum K <= 1024), B <= 256.
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_row(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
-}
-// sum over the 64 lanes of a wave, result valid in every lane's return value only for lane groups' leaders:
-// 16-lane all-reduce with DPP, then the four row leaders are combined through scalar registers
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  v += dpp_row<0xB1>(v); v += dpp_row<0x4E>(v);
-  v += dpp_row<0x141>(v); v += dpp_row<0x140>(v);
-  const int iv = __builtin_bit_cast(int, v);
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16)) +
-         __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
-}
-
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-// copy this thread's items of all stages (one coalesced 16-byte load each) into the LDS table
-__device__ __forceinline__ void load_items(const int* __restrict__ items, int nstages, i32x4* tab, int tid) {
-  const i32x4* src = reinterpret_cast<const i32x4*>(items);
-  i32x4 v[MFM_LAT_MAXSTAGES];
-#pragma unroll
-  for (int s = 0; s < MFM_LAT_MAXSTAGES; ++s) v[s] = src[min(s, nstages - 1) * MFM_LAT_ROW_THREADS + tid];
-#pragma unroll
-  for (int s = 0; s < MFM_LAT_MAXSTAGES; ++s) tab[s * MFM_LAT_ROW_THREADS + tid] = v[s];
-}
-
-// PRE (chain workgroups, <= 6 stages, <= 512 work items per stage): 512 threads, and the weights of ALL stages are requested
-// before the first one runs -- a chain is 4-6 dependent stages of almost no arithmetic, and with one-stage-ahead
-// prefetch every stage still costs the ~2 us its cold weights take to arrive (the optimizer rewrote them a step ago).
+// The row kernels' bodies live in latent_row_dev.h (shared with the fold launches of lstm_seq_small.hip)
 template <bool PRE>
 __global__ __launch_bounds__(PRE ? LAT_PRE_THREADS : LAT_THREADS) void latent_fwd_row_kernel(const LatentDev L, const float* __restrict__ params) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ LatOp ops[MFM_LAT_MAXOPS];
-  __shared__ float red[2][16];
-  i32x4* tab = reinterpret_cast<i32x4*>(lds);                        // [MAXSTAGES][1024] items
-  float* rec = lds + MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
-  // nch == 4: this workgroup runs ONE modality chain (l, a, v or y) of its row -- the chains are independent inside the
-  // stack, and four CUs stream a row's weights instead of one (LatentDev::nch)
-  const int nch = L.nch;
-  const int row = (int)blockIdx.x / nch, ch = (int)blockIdx.x - row * nch;
-  const bool all = nch == 1;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  int nif[MFM_LAT_MAXSTAGES];
-#pragma unroll
-  for (int i = 0; i < MFM_LAT_MAXSTAGES; ++i) nif[i] = L.nitems_fwd_c[ch][i];
-  // prologue: op table, item table and the four encoder states are requested together (one round trip)
-  float yv = 0.0f;
-  int ylab = 0;
-  {
-    const int nw = L.nops * (int)(sizeof(LatOp) / 4);
-    const int opv = reinterpret_cast<const int*>(L.ops)[min(tid, nw - 1)];
-    const int e0 = L.enc_n[0], e1 = e0 + L.enc_n[1], e2 = e1 + L.enc_n[2], e3 = e2 + L.enc_n[3];
-    const int tt = min(tid, e3 - 1);
-    const int m = (tt >= e0) + (tt >= e1) + (tt >= e2);
-    const int kk = tt - (m == 0 ? 0 : (m == 1 ? e0 : (m == 2 ? e1 : e2)));
-    const float* src = m == 0 ? L.enc_h[0] : (m == 1 ? L.enc_h[1] : (m == 2 ? L.enc_h[2] : L.enc_h[3]));
-    const int64_t ld = m == 0 ? L.enc_ld[0] : (m == 1 ? L.enc_ld[1] : (m == 2 ? L.enc_ld[2] : L.enc_ld[3]));
-    const int io = m == 0 ? L.in_off[0] : (m == 1 ? L.in_off[1] : (m == 2 ? L.in_off[2] : L.in_off[3]));
-    const float hv = src[(int64_t)row * ld + kk];
-    if (L.y) {      // the target is needed only by the loss at the very end: fetch it now, not there
-      if (L.loss_kind == 0) yv = reinterpret_cast<const float*>(L.y)[(int64_t)row * L.od + min(tid, L.od - 1)];
-      else ylab = (int)reinterpret_cast<const int64_t*>(L.y)[row];
-    }
-    load_items(L.items_fwd + (size_t)ch * (MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4), L.nstages, tab, tid);
-    if (tid < nw) reinterpret_cast<int*>(ops)[tid] = opv;
-    if (tid < e3) rec[io + kk] = hv;
-  }
-  // Descriptor fields the epilogue needs are fetched NOW (scalar loads, first touch of those kernarg lines)
-  // and pinned in SGPRs: read where they are used they cost the tail of the kernel a chain of cold misses.
-#define PIN_S(x) asm volatile("" : "+s"(x))
-  int e_mu[4], e_lv[4], e_zn[4], e_fo[4], e_fn[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    e_mu[m] = L.mu_off[m]; e_lv[m] = L.lv_off[m]; e_zn[m] = L.z_n[m]; e_fo[m] = L.f_off[m]; e_fn[m] = L.f_n[m];
-    PIN_S(e_mu[m]); PIN_S(e_lv[m]); PIN_S(e_zn[m]); PIN_S(e_fo[m]); PIN_S(e_fn[m]);
-  }
-  float* e_dec[3]; int64_t e_ld[3];
-#pragma unroll
-  for (int m = 0; m < 3; ++m) { e_dec[m] = L.dec_init[m]; e_ld[m] = L.dec_ld[m]; PIN_S(e_dec[m]); PIN_S(e_ld[m]); }
-  int e_yoff = L.yhat_off, e_od = L.od, e_rs = L.rec_size, e_B = L.B, e_kind = L.loss_kind, e_haslv = L.has_logvar;
-  float* e_yout = L.yhat_out; float* e_rec = L.rec; float* e_losses = L.losses;
-  PIN_S(e_yoff); PIN_S(e_od); PIN_S(e_rs); PIN_S(e_B); PIN_S(e_kind); PIN_S(e_haslv); PIN_S(e_yout); PIN_S(e_rec); PIN_S(e_losses);
-#undef PIN_S
-  const int q = tid & 3;
-  const int wave0 = tid & ~63;
-  struct Slot { f32x4 w[8]; float bias; i32x4 e; };
-  auto fetch = [&](int s, Slot& t) {          // weights + bias of this thread's item in stage s
-    t.e = tab[s * MFM_LAT_ROW_THREADS + tid];
-    const int K = (t.e[2] >> 16) & 0xFF;
-    const float* wr = params + (unsigned)t.e[0];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) t.w[j] = *reinterpret_cast<const f32x4*>(wr + min(4 * q + 16 * j, K - 4));
-    t.bias = params[(unsigned)t.e[1]];
-  };
-  mark(L, 0);
-  lds_barrier();
-  mark(L, 1);
-  auto stage = [&](int s, Slot& cur, Slot& nxt) {
-    // A wave with no item in this stage nor in the next skips the body.  Inside the body every load is
-    // unconditional (the last stage requests its own weights again): a load under a branch would make the
-    // compiler's in-order vmcnt accounting conservative and the wait for `cur` would also cover `nxt`.
-    const int sn = min(s + 1, L.nstages - 1);
-    if (wave0 < (PRE ? nif[s] : max(nif[s], nif[sn]))) {
-      const int in_off = cur.e[2] & 0xFFFF, K = (cur.e[2] >> 16) & 0xFF;
-      f32x4 xv[8];
-      if (wave0 < nif[s]) {          // `cur` was fetched one stage ago exactly when this holds
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xv[j] = *reinterpret_cast<const f32x4*>(rec + in_off + min(4 * q + 16 * j, K - 4));
-      }
-      if constexpr (!PRE) fetch(sn, nxt);
-      mark(L, 2 + 2 * s);
-      if (wave0 < nif[s]) {
-        float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const f32x4 w4 = cur.w[j], x4 = xv[j];
-          float p = w4[0] * x4[0];
-          p = fmaf(w4[1], x4[1], p); p = fmaf(w4[2], x4[2], p); p = fmaf(w4[3], x4[3], p);
-          p = (4 * q + 16 * j < K) ? p : 0.0f;
-          if (j & 1) a1 += p; else a0 += p;
-        }
-        float v = a0 + a1;
-        v += dpp_quad<0xB1>(v);
-        v += dpp_quad<0x4E>(v);
-        v += cur.bias;
-        const int ew = cur.e[3];
-        if (((ew >> 26) & 1) && q == 0) {
-          const int out_idx = ew & 0xFFFF;
-          if ((ew >> 24) & 1) v = fmaxf(v, 0.0f);
-          if ((ew >> 25) & 1) {
-            const int o = (ew >> 16) & 0xFF;
-            const LatOp& op = ops[o];
-            const int n = out_idx - op.out_off;
-            float mk = 1.0f;
-            if (L.train && op.drop_p > 0.0f) {
-              const uint64_t idx = ((uint64_t)o << 40) + (uint64_t)row * (uint64_t)op.N + (uint64_t)n;
-              mk = (rng_uniform(L.seed, idx) < op.drop_p) ? 0.0f : 1.0f / (1.0f - op.drop_p);
-            }
-            v *= mk;
-            rec[op.mask_off + n] = mk;
-          }
-          rec[out_idx] = v;
-        }
-      }
-    }
-    lds_barrier();
-    mark(L, 3 + 2 * s);
-  };
-  if constexpr (PRE) {
-    Slot sl[LAT_PRE_SLOTS];
-#pragma unroll
-    for (int i = 0; i < LAT_PRE_SLOTS; ++i) fetch(min(i, L.nstages - 1), sl[i]);
-#pragma unroll
-    for (int i = 0; i < LAT_PRE_STAGES; ++i) {
-      if (i < L.nstages) stage(i, sl[i % LAT_PRE_SLOTS], sl[i % LAT_PRE_SLOTS]);
-      if (i + LAT_PRE_SLOTS < LAT_PRE_STAGES) fetch(min(i + LAT_PRE_SLOTS, L.nstages - 1), sl[i % LAT_PRE_SLOTS]);   // unconditional
-    }
-  } else {
-    Slot sa, sb;
-    fetch(0, sa);
-    for (int s = 0; s < L.nstages; s += 2) {
-      stage(s, sa, sb);
-      if (s + 1 < L.nstages) stage(s + 1, sb, sa);
-    }
-  }
-
-  // ---- losses (one partial per workgroup, one atomic each)
-  float kld = 0.0f;
-  if (e_haslv) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      if (!all && m != ch) continue;
-      for (int j = tid; j < e_zn[m]; j += nt) {
-        const float mu = rec[e_mu[m] + j], lv = rec[e_lv[m] + j];
-        kld += 1.0f + lv - mu * mu - expf(lv);
-      }
-    }
-  }
-  float disc = 0.0f;
-  const bool ych = all || ch == 3;                // the workgroup that holds the classifier's outputs
-  if (L.y && ych) {
-    if (e_kind == 0) {
-      if (tid < e_od) disc += fabsf(rec[e_yoff + tid] - yv);
-    } else if (tid == 0) {
-      const float* z = rec + e_yoff;
-      float mx = z[0];
-      for (int o = 1; o < e_od; ++o) mx = fmaxf(mx, z[o]);
-      float se = 0.0f;
-      for (int o = 0; o < e_od; ++o) se += expf(z[o] - mx);
-      disc += (logf(se) + mx) - z[ylab];
-    }
-  }
-  // only the first two waves can hold non-zero partials (z_n, od <= 128)
-  if (tid < 128) {
-    kld = wave_sum_dpp(kld);
-    disc = wave_sum_dpp(disc);
-    if ((tid & 63) == 0) { red[0][tid >> 6] = kld; red[1][tid >> 6] = disc; }
-  }
-  lds_barrier();
-  if (tid == 0 && e_losses) {
-    if (e_haslv) atomicAdd(e_losses + 4, -0.5f * (red[0][0] + red[0][1]));
-    if (L.y && ych) {
-      const float inv = (e_kind == 0) ? 1.0f / ((float)e_B * (float)e_od) : 1.0f / (float)e_B;
-      atomicAdd(e_losses + 0, (red[1][0] + red[1][1]) * inv);
-    }
-  }
-  // ---- outputs: plain stores, nothing in this kernel waits for them
-  const int fy = e_fn[3];
-#pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    if (!e_dec[m]) continue;
-    const int hd = fy + e_fn[m];
-    // decoder input [f_y | f_m]: the y chain owns the first part (for all three decoders), chain m the second
-    const int j0 = (all || ch == 3) ? 0 : fy, j1 = (all || ch == m) ? hd : fy;
-    for (int j = j0 + tid; j < j1; j += nt)
-      e_dec[m][(int64_t)row * e_ld[m] + j] = (j < fy) ? rec[e_fo[3] + j] : rec[e_fo[m] + (j - fy)];
-  }
-  if (e_yout && ych)
-    for (int o = tid; o < e_od; o += nt) e_yout[(int64_t)row * e_od + o] = rec[e_yoff + o];
-  if (e_rec) {
-    // the saved record: this workgroup's range of it (the whole row, or its chain's contiguous segments)
-    const int lo4 = all ? 0 : (L.ch_lo[ch] >> 2), hi4 = all ? (e_rs >> 2) : (L.ch_hi[ch] >> 2);
-    f32x4* d4 = reinterpret_cast<f32x4*>(e_rec + (int64_t)row * e_rs);
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(rec);
-    for (int idx = lo4 + tid; idx < hi4; idx += nt) d4[idx] = s4[idx];
-  }
-  mark(L, 20);
+  const int row = (int)blockIdx.x / L.nch, ch = (int)blockIdx.x - row * L.nch;
+  latent_fwd_row_body<PRE>(L, params, row, ch, lds, false);
 }
 
 template <bool PRE>
 __global__ __launch_bounds__(PRE ? LAT_PRE_THREADS : LAT_THREADS) void latent_bwd_row_kernel(const LatentDev L, const float* __restrict__ params,
                                                                      float* __restrict__ grads) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ LatOp ops[MFM_LAT_MAXOPS];
-  __shared__ int pfxN[MFM_LAT_MAXOPS];
-  const int RS = L.rec_size;
-  i32x4* tab = reinterpret_cast<i32x4*>(lds);                        // [MAXSTAGES][1024] items
-  float* rec = lds + MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
-  float* grd = rec + RS;
-  const int nch = L.nch;                           // 4: one modality chain of the row per workgroup (see the forward)
-  const int row = (int)blockIdx.x / nch, ch = (int)blockIdx.x - row * nch;
-  const bool all = nch == 1;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  int nib[MFM_LAT_MAXSTAGES];
-#pragma unroll
-  for (int i = 0; i < MFM_LAT_MAXSTAGES; ++i) nib[i] = L.nitems_bwd_c[ch][i];
-  {   // op table, item table and the saved record are requested together (one round trip)
-    const int nw = L.nops * (int)(sizeof(LatOp) / 4);
-    const int opv = reinterpret_cast<const int*>(L.ops)[min(tid, nw - 1)];
-    const int n4 = RS >> 2;
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(L.rec + (int64_t)row * RS);
-    f32x4* r4 = reinterpret_cast<f32x4*>(rec);
-    f32x4* g4 = reinterpret_cast<f32x4*>(grd);
-    const f32x4 rv = s4[min(tid, n4 - 1)];
-    const f32x4* sd4 = L.grd_seed ? reinterpret_cast<const f32x4*>(L.grd_seed + (int64_t)row * RS) : nullptr;
-    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 sv = sd4 ? sd4[min(tid, n4 - 1)] : zero;
-    load_items(L.items_bwd + (size_t)ch * (MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4), L.nstages, tab, tid);
-    if (tid < nw) reinterpret_cast<int*>(ops)[tid] = opv;
-    if (tid < L.nops) pfxN[tid] = L.ops[tid].pfx_n;
-    if (tid < n4) { r4[tid] = rv; g4[tid] = sv; }
-    for (int idx = tid + nt; idx < n4; idx += nt) { r4[idx] = s4[idx]; g4[idx] = sd4 ? sd4[idx] : zero; }
-  }
-  lds_barrier();
-  const int l = tid & 15;
-  const int wave0 = tid & ~63;
-  struct Slot { f32x4 w[8]; i32x4 e; };
-  auto fetch = [&](int s, Slot& t) {
-    t.e = tab[s * MFM_LAT_ROW_THREADS + tid];
-    const int K = t.e[1] & 0xFF, N = (t.e[1] >> 8) & 0xFF;
-    const float* wr = params + (unsigned)t.e[0];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) t.w[j] = *reinterpret_cast<const f32x4*>(wr + min(l + 16 * j, N - 1) * K);
-  };
-  Slot sa, sb, sl[PRE ? LAT_PRE_SLOTS : 1];
-  // PRE: walk position p = 0 .. 5 is stage nstages-1-p; slot p % 4; the first four positions are requested here
-  if constexpr (PRE) {
-#pragma unroll
-    for (int p = 0; p < LAT_PRE_SLOTS; ++p) fetch(max(L.nstages - 1 - p, 0), sl[p]);
-  } else {
-    fetch(L.nstages - 1, sa);
-  }
-  // ---- seeds
-  if (L.d_yhat_ext) {
-    for (int o = tid; o < L.od; o += nt) grd[L.yhat_off + o] = L.d_yhat_ext[(int64_t)row * L.od + o];
-  } else if (L.y && L.disc_w != 0.0f) {
-    if (L.loss_kind == 0) {
-      const float* y = reinterpret_cast<const float*>(L.y);
-      const float sc = L.disc_w / ((float)L.B * (float)L.od);
-      for (int o = tid; o < L.od; o += nt) {
-        const float df = rec[L.yhat_off + o] - y[(int64_t)row * L.od + o];
-        grd[L.yhat_off + o] = (df > 0.0f) ? sc : ((df < 0.0f) ? -sc : 0.0f);
-      }
-    } else if (tid == 0) {
-      const int64_t* y = reinterpret_cast<const int64_t*>(L.y);
-      const float sc = L.disc_w / (float)L.B;
-      const float* z = rec + L.yhat_off;
-      float mx = z[0];
-      for (int o = 1; o < L.od; ++o) mx = fmaxf(mx, z[o]);
-      float se = 0.0f;
-      for (int o = 0; o < L.od; ++o) se += expf(z[o] - mx);
-      const int lab = (int)y[row];
-      for (int o = 0; o < L.od; ++o) grd[L.yhat_off + o] = sc * (expf(z[o] - mx) / se - (o == lab ? 1.0f : 0.0f));
-    }
-  }
-  if (L.gen_w != 0.0f) {
-    const int fy = L.f_n[3];
-    for (int j = tid; j < fy; j += nt) {
-      float sm = 0.0f;
-      for (int m = 0; m < 3; ++m)
-        if (L.d_dec_init[m]) sm += L.d_dec_init[m][(int64_t)row * L.dec_ld[m] + j];
-      grd[L.f_off[3] + j] = sm;
-    }
-    for (int m = 0; m < 3; ++m) {
-      if (!L.d_dec_init[m]) continue;
-      for (int j = tid; j < L.f_n[m]; j += nt) grd[L.f_off[m] + j] = L.d_dec_init[m][(int64_t)row * L.dec_ld[m] + fy + j];
-    }
-    // the f segments come out of a relu layer (z -> f, second Linear): the record holds gradients wrt
-    // PRE-activations throughout (what the bias / weight gradients need), so the seeds are masked here and
-    // every later contribution is masked where it is accumulated (stage loop)
-    for (int m = 0; m < 4; ++m)
-      for (int j = tid; j < L.f_n[m]; j += nt)
-        if (!(rec[L.f_off[m] + j] > 0.0f)) grd[L.f_off[m] + j] = 0.0f;
-  }
-  const float reg_w = L.reg_w_ptr ? *L.reg_w_ptr : L.reg_w;
-  if (L.has_logvar && (L.reg_w_ptr || reg_w != 0.0f)) {
-    for (int m = 0; m < 4; ++m)
-      for (int j = tid; j < L.z_n[m]; j += nt) {
-        const float mu = rec[L.mu_off[m] + j], lv = rec[L.lv_off[m] + j];
-        grd[L.mu_off[m] + j] = reg_w * mu;
-        grd[L.lv_off[m] + j] = reg_w * (-0.5f) * (1.0f - expf(lv));
-      }
-  }
-  lds_barrier();
-  mark(L, 24);
-
-  auto stage = [&](int s, Slot& cur, Slot& nxt) {
-    const int sn = max(s - 1, 0);
-    mark(L, 25 + 3 * s);
-    // ---- pass 2a: dX[k] += sum_n g[n] W[n][k]   (per-wave skip and unconditional loads as in the forward)
-    if (wave0 < (PRE ? nib[s] : max(nib[s], nib[sn]))) {
-      const int N = (cur.e[1] >> 8) & 0xFF;
-      const int out_off = cur.e[2] & 0xFFFF, in_idx = (cur.e[2] >> 16) & 0xFFFF;
-      float gv[8];
-      if (wave0 < nib[s]) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) gv[j] = grd[out_off + min(l + 16 * j, N - 1)];
-      }
-      if constexpr (!PRE) fetch(sn, nxt);                // stage 0 requests its own weights again
-      if (wave0 < nib[s]) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float gj = (l + 16 * j < N) ? gv[j] : 0.0f;
-          acc += gj * cur.w[j];
-        }
-        float out[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float v = acc[c];
-          v += dpp_row<0xB1>(v); v += dpp_row<0x4E>(v);
-          v += dpp_row<0x141>(v); v += dpp_row<0x140>(v);
-          out[c] = v;
-        }
-        const float lo = (l & 1) ? out[1] : out[0], hi = (l & 1) ? out[3] : out[2];
-        const float v = (l & 2) ? hi : lo;
-        const int ew = cur.e[3];
-        if ((ew & 1) && l < 4) {
-          float f = 1.0f;
-          if ((ew & 2) && !(rec[in_idx + l] > 0.0f)) f = 0.0f;          // producer's relu
-          if (ew >> 2) f *= rec[(ew >> 2) - 1 + l];                     // producer's dropout mask (scaled)
-          atomicAdd(&grd[in_idx + l], v * f);
-        }
-      }
-    }
-    mark(L, 26 + 3 * s);
-    lds_barrier();
-    mark(L, 27 + 3 * s);
-  };
-  if constexpr (PRE) {
-#pragma unroll
-    for (int p = 0; p < LAT_PRE_STAGES; ++p) {
-      const int st = L.nstages - 1 - p;
-      if (st >= 0) stage(st, sl[p % LAT_PRE_SLOTS], sl[p % LAT_PRE_SLOTS]);
-      if (p + LAT_PRE_SLOTS < LAT_PRE_STAGES) fetch(max(L.nstages - 1 - (p + LAT_PRE_SLOTS), 0), sl[p % LAT_PRE_SLOTS]);
-    }
-  } else {
-    for (int s = L.nstages - 1; s >= 0; s -= 2) {
-      stage(s, sa, sb);
-      if (s >= 1) stage(s - 1, sb, sa);
-    }
-  }
-
-  // ---- bias gradients of all layers in one go (the record keeps every pre-activation gradient).  Inside
-  // the stage loop these atomics would sit between two weight prefetches in the in-order vmcnt queue, and
-  // every wait for weights would also wait for them.  Weight gradients: grouped GEMM over the two records.
-  for (int st = 0; st < L.nstages; ++st) {
-    const int ob = L.stage_begin[st], oe = L.stage_begin[st + 1];
-    const int totn = L.nitems_fwd[st] >> 2;
-    for (int item = tid; item < totn; item += nt) {
-      const int o = find_op(pfxN, ob, oe, item, 1);
-      const LatOp& op = ops[o];
-      if (!all && op.chain != ch) continue;         // another workgroup of this row holds that layer's gradients
-      const int n = item - pfxN[o];
-      atomicAdd(grads + op.b_off + n, grd[op.out_off + n]);
-    }
-  }
-  for (int m = 0; m < 4; ++m) {
-    if (!L.dh_last[m] || (!all && m != ch)) continue;
-    for (int k = tid; k < L.enc_n[m]; k += nt) L.dh_last[m][(int64_t)row * L.dh_ld[m] + k] = grd[L.in_off[m] + k];
-  }
-  if (L.grd_out) {
-    const int lo4 = all ? 0 : (L.ch_lo[ch] >> 2), hi4 = all ? (RS >> 2) : (L.ch_hi[ch] >> 2);
-    f32x4* d4 = reinterpret_cast<f32x4*>(L.grd_out + (int64_t)row * RS);
-    const f32x4* s4 = reinterpret_cast<const f32x4*>(grd);
-    for (int idx = lo4 + tid; idx < hi4; idx += nt) d4[idx] = s4[idx];
-  }
+  const int row = (int)blockIdx.x / L.nch, ch = (int)blockIdx.x - row * L.nch;
+  latent_bwd_row_body<PRE>(L, params, grads, row, ch, lds);
 }
 
 static int set_lds_limit(const void* fn, size_t bytes) {

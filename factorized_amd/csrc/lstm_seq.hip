@@ -373,7 +373,10 @@ bool bf16_seq_pays(int B) {
   return B >= (e ? atoi(e) : 192);
 }
 
-static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bool bwd, hipStream_t stream, bool bf16 = false) {
+struct FoldArgs { const LatentDev* lat; const float* params; float* grads; };
+
+static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bool bwd, hipStream_t stream, bool bf16 = false,
+                      const FoldArgs* fold = nullptr) {
   MFM_REQUIRE(descs_in && count_in >= 1 && count_in <= MFM_MAX_SEQ, "lstm_seq: count %d out of range", count_in);
   MFM_REQUIRE(T >= 1 && B >= 1, "lstm_seq: T=%d B=%d", T, B);
   // LSTMs too wide for the weight-resident kernels take the step-by-step path (lstm_step.hip); the rest of
@@ -389,6 +392,7 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     const bool force = getenv("MFM_SEQ_STEPWISE") != nullptr;          // testing: every LSTM step by step
     if (s.h > MFM_SEQ_MAX_RESIDENT_H || force) wide[nwide++] = s; else descs[count++] = s;
   }
+  if (fold && (nwide || bf16 || !use_small_path(B))) return MFM_ERR_UNSUPPORTED;
   if (nwide) {
     int rc = seq_stepwise(wide, nwide, T, B, bwd, stream);
     if (rc != MFM_OK) return rc;
@@ -426,6 +430,7 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     const size_t need = (bwd ? 2 * 4 * HK * 16 : 2 * HK * 16) * sizeof(float);
     if (need > lds_bytes) lds_bytes = need;
   }
+  if (fold) return seq_small_fold_launch(L, bwd, *fold->lat, fold->params, fold->grads, stream);
   if (bf16) return seq_bf16_launch(L, bwd, stream);      // bf16 MFMA operands: one kernel family for every batch size
   if (use_small_path(B)) return seq_small_launch(L, bwd, stream);
   // encoders and decoders run different kernels: a mixed call becomes two launches
@@ -452,6 +457,13 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     MFM_LAUNCH_CHECK(bwd ? "lstm_seq_bwd_kernel" : "lstm_seq_fwd_kernel");
   }
   return MFM_OK;
+}
+
+// encoder recurrences + their rows' latent chains in one launch (lstm_seq_small.hip); MFM_ERR_UNSUPPORTED: not applicable
+int seq_fold_launch(const MfmSeqDesc* descs, int count, int T, int B, bool bwd, const LatentDev& lat, const float* params,
+                    float* grads, hipStream_t stream) {
+  FoldArgs f = {&lat, params, grads};
+  return seq_launch(descs, count, T, B, bwd, stream, false, &f);
 }
 
 }  // namespace mfm

@@ -20,6 +20,8 @@ struct SeqLaunch {
 };
 
 int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream);
+struct LatentDev;
+int seq_small_fold_launch(SeqLaunch& L, bool bwd, const LatentDev& LD, const float* params, float* grads, hipStream_t stream);
 // lstm_seq_bf16.hip: bf16 MFMA operands, fp32 accumulate / cell state / saved activations
 int seq_bf16_launch(SeqLaunch& L, bool bwd, hipStream_t stream);
 bool bf16_seq_pays(int B);     // lstm_seq.hip: batch size from which a bf16 plan runs its recurrences on the bf16 kernels

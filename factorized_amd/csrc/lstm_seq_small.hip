@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "internal.h"
+#include "latent_row_dev.h"
 #include "lstm_seq_dev.h"
 
 namespace mfm {
@@ -774,6 +775,39 @@ static bool try_all_fat(const SeqLaunch& L, int total, int threads, size_t lds_b
          try_launch4<1, 8, 8, 2, 20, 22, 16, 12>(L, true, total, threads, lds_bytes, stream, err);
 }
 
+// Fold launch (MFM_KL_EF at small batches): the workgroup of (encoder e, batch row b) also runs modality chain e of row
+// b's latent stack -- forward right behind its last time step, backward ahead of its BPTT.  The four chains are
+// independent inside the stack and map one to one onto the four encoders, so nothing is exchanged between workgroups:
+// what used to be a launch boundary (~3 us) plus the chain kernel's cold prologue becomes a barrier.  One-row tiles
+// and the canonical size tuple only; anything else keeps the separate launches.
+template <bool BWD, int K0, int K1, int K2, int K3>
+__global__ __launch_bounds__(1024) void lstm_seq_small_fold_kernel(const SeqLaunch L, const LatentDev LD, const float* __restrict__ params,
+                                                                   float* __restrict__ grads) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int di = 0;
+  const int bid = blockIdx.x;
+#pragma unroll 1
+  for (int i = 1; i < L.count; ++i)
+    if (bid >= L.d[i].block_begin) di = i;
+  const SeqDev& d = L.d[di];
+  const int tile = bid - d.block_begin;          // == batch row (one-row tiles)
+  if constexpr (BWD) {
+    latent_bwd_row_body<false>(LD, params, grads, tile, di, lds);
+    __syncthreads();        // d h_T of this (row, encoder) is in memory (and the LDS is free) before the BPTT reads it
+  }
+#define MFM_ONE(IDX, KK)                                                        \
+  if (KK > 0 && di == IDX) {                                                    \
+    if (BWD) small_bwd_body<(KK > 0 ? KK : 2), 1, 16>(d, L.T, L.B, tile, lds);  \
+    else small_fwd_body<(KK > 0 ? KK : 2), 1>(d, L.T, L.B, tile, lds);          \
+  }
+  MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3)
+#undef MFM_ONE
+  if constexpr (!BWD) {
+    __syncthreads();        // every store of the last time step has been acknowledged: h_T of this row is readable
+    latent_fwd_row_body<false>(LD, params, tile, di, lds, true);
+  }
+}
+
 static size_t small_lds_bytes(const SeqLaunch& L, bool bwd, int R) {
   size_t lds_bytes = 0;
   for (int i = 0; i < L.count; ++i) {
@@ -844,6 +878,37 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
   else
     hipLaunchKernelGGL(lstm_seq_small_kernel<false>, dim3(total), dim3(max_threads), lds_bytes, stream, L);
   MFM_LAUNCH_CHECK(bwd ? "lstm_seq_small_bwd_kernel" : "lstm_seq_small_fwd_kernel");
+  return MFM_OK;
+}
+
+
+// MFM_OK: launched.  MFM_ERR_UNSUPPORTED: not a case the fold kernels take (the caller issues the separate launches).
+int seq_small_fold_launch(SeqLaunch& L, bool bwd, const LatentDev& LD, const float* params, float* grads, hipStream_t stream) {
+  if (const char* e = getenv("MFM_LATENT_FOLD")) { if (atoi(e) == 0) return MFM_ERR_UNSUPPORTED; }
+  if (getenv("MFM_SEQ_KS") || getenv("MFM_SEQ_ROWS")) return MFM_ERR_UNSUPPORTED;       // tuning overrides keep the plain launches
+  const int want[4] = {8, 2, 20, 30};
+  if (L.count != 4 || !LD.row_path || LD.nch != 4 || LD.pre || LD.B != L.B) return MFM_ERR_UNSUPPORTED;
+  for (int i = 0; i < 4; ++i)
+    if (L.d[i].hk4 != want[i] || L.d[i].is_dec) return MFM_ERR_UNSUPPORTED;
+  if (!((long)L.count * L.B < 6L * device_cus())) return MFM_ERR_UNSUPPORTED;          // one-row tiles only
+  int max_threads = 64, total = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (8 * L.d[i].Hp > max_threads) max_threads = 8 * L.d[i].Hp;
+    L.d[i].block_begin = total; total += L.B;
+  }
+  if (max_threads < 1024) max_threads = 1024;       // the chain's work items are tabulated for up to 1024 threads
+  size_t lds_bytes = small_lds_bytes(L, bwd, 1);
+  const size_t lat = ((size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + (bwd ? 2 : 1) * (size_t)LD.rec_size) * sizeof(float);
+  if (lat > lds_bytes) lds_bytes = lat;
+  if (lds_bytes > 160 * 1024) return MFM_ERR_UNSUPPORTED;
+  if (bwd) {
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_fold_kernel<true, 8, 2, 20, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL((lstm_seq_small_fold_kernel<true, 8, 2, 20, 30>), dim3(total), dim3(max_threads), lds_bytes, stream, L, LD, params, grads);
+  } else {
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_fold_kernel<false, 8, 2, 20, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL((lstm_seq_small_fold_kernel<false, 8, 2, 20, 30>), dim3(total), dim3(max_threads), lds_bytes, stream, L, LD, params, grads);
+  }
+  MFM_LAUNCH_CHECK("lstm_seq_small_fold_kernel");
   return MFM_OK;
 }
 

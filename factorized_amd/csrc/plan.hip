@@ -122,6 +122,7 @@ struct MfmPlan {
   size_t pool_used;
   uint64_t calls;
   const float* grads_prezeroed;     // gradient buffer cleared by the forward pass of the running fused step
+  int fold_state = 0;               // encoder + latent fold launches (lstm_seq_small.hip): 0 untried, 1 in use, -1 not applicable
   unsigned long long fc1_bwd_call = ~0ull;   // value of `calls` for which the forward already produced dH of the decoders (dec_fc1.hip)
 };
 
@@ -732,20 +733,9 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       RUN(K_PROJ, gemm_group_launch(g, P->n_enc, s, &zs, nullptr, 0, c.precision));
     }
   }
-  // F1: encoder recurrences (up to MFM_MAX_SEQ per launch)
-  for (int e0 = 0; e0 < P->n_enc; e0 += MFM_MAX_SEQ) {
-    MfmSeqDesc q[MFM_MAX_SEQ];
-    const int n = std::min(MFM_MAX_SEQ, P->n_enc - e0);
-    for (int e = 0; e < n; ++e) q[e] = seq_desc(P, P->enc[e0 + e], P->enc_p[e0 + e], params, W, false);
-    RUN(K_ENC_FWD, seq_bf16 ? mfm_lstm_seq_fwd_bf16(q, n, T, B, s) : mfm_lstm_seq_fwd(q, n, T, B, s));
-  }
-  if (V != 0) {
-    int rc = mfn_forward(P, params, train, seed, W, s);
-    if (rc != MFM_OK) return rc;
-  }
-  // F2: latent stack
+  // the latent stack's launch descriptor (used by F2, or by the fold launch of F1)
+  LatentDev L = P->lat;
   {
-    LatentDev L = P->lat;
     L.ops = reinterpret_cast<const LatOp*>(W + P->lat_ops_off);
     L.items_fwd = reinterpret_cast<const int*>(W + P->lat_items_off);
     L.items_bwd = L.items_fwd + (size_t)4 * MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
@@ -760,6 +750,32 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     L.yhat_out = yhat_out ? yhat_out : W + P->yhat;
     L.y = y; L.losses = losses; L.train = train;
     L.seed = seed * 0x9E3779B97F4A7C15ull + P->calls;
+  }
+  // F1: encoder recurrences (up to MFM_MAX_SEQ per launch).  MFM_KL_EF at small batches: the four encoders' workgroups
+  // also run their rows' latent chains (fold launch, lstm_seq_small.hip) and F2 disappears
+  bool folded = false;
+  if (V == 0 && !seq_bf16 && P->n_enc == 4 && P->fold_state >= 0) {
+    MfmSeqDesc q[4];
+    for (int e = 0; e < 4; ++e) q[e] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
+    int rc;
+    if (P->fold_state == 1) { Timer _t(P, s, K_ENC_FWD); rc = seq_fold_launch(q, 4, T, B, false, L, params, nullptr, s); }
+    else rc = seq_fold_launch(q, 4, T, B, false, L, params, nullptr, s);
+    if (rc == MFM_OK) { folded = true; P->fold_state = 1; }
+    else if (rc == MFM_ERR_UNSUPPORTED) P->fold_state = (P->fold_state == 0) ? -1 : P->fold_state;
+    else return rc;
+  }
+  for (int e0 = 0; e0 < P->n_enc && !folded; e0 += MFM_MAX_SEQ) {
+    MfmSeqDesc q[MFM_MAX_SEQ];
+    const int n = std::min(MFM_MAX_SEQ, P->n_enc - e0);
+    for (int e = 0; e < n; ++e) q[e] = seq_desc(P, P->enc[e0 + e], P->enc_p[e0 + e], params, W, false);
+    RUN(K_ENC_FWD, seq_bf16 ? mfm_lstm_seq_fwd_bf16(q, n, T, B, s) : mfm_lstm_seq_fwd(q, n, T, B, s));
+  }
+  if (V != 0) {
+    int rc = mfn_forward(P, params, train, seed, W, s);
+    if (rc != MFM_OK) return rc;
+  }
+  // F2: latent stack
+  if (!folded) {
     RUN(K_LAT_FWD, latent_fwd_launch(L, params, s));
   }
   // MMD regulariser of the non-KL MFM on z_l, z_a, z_v, z_y (mfm_model.py:540-541): value into the reg slot, its
@@ -1070,6 +1086,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     // (B2: the decoder weight gradients only feed Adam; they share the encoders' launch at the end)
   }
   // B3: latent stack
+  bool enc_bwd_done = false;
   {
     LatentDev L = P->lat;
     L.ops = reinterpret_cast<const LatOp*>(W + P->lat_ops_off);
@@ -1092,7 +1109,19 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     L.reg_w = c.lda_reg * c.reg_scale;
     L.disc_w = disc_on ? 1.0f : 0.0f;
     L.gen_w = gen_on ? 1.0f : 0.0f;
-    RUN(K_LAT_BWD, latent_bwd_launch(L, params, grads, s));
+    // MFM_KL_EF at small batches: the encoder BPTT workgroups run their rows' chains first (fold launch); B4 is then done too
+    if (V == 0 && !seq_bf16 && P->n_enc == 4 && P->fold_state == 1) {
+      MfmSeqDesc q[4];
+      for (int e = 0; e < 4; ++e) {
+        q[e] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
+        q[e].dh_ext = W + P->dh_last[e]; q[e].ld_dh = P->enc_h[e];
+      }
+      int rc;
+      { Timer _t(P, s, K_ENC_BWD); rc = seq_fold_launch(q, 4, T, B, true, L, params, grads, s); }
+      if (rc == MFM_OK) enc_bwd_done = true;
+      else if (rc != MFM_ERR_UNSUPPORTED) return rc;
+    }
+    if (!enc_bwd_done) RUN(K_LAT_BWD, latent_bwd_launch(L, params, grads, s));
     // weight gradients of the 22 latent Linears: dW[n][k] = sum_r G[r][out+n] X[r][in+k]
     const int rs = P->lat.rec_size;
     for (int i = 0; i < P->lat.nops; ++i) {
@@ -1113,7 +1142,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     if (rc != MFM_OK) return rc;
   }
   // B4: encoder BPTT (up to MFM_MAX_SEQ per launch)
-  for (int e0 = 0; e0 < P->n_enc; e0 += MFM_MAX_SEQ) {
+  for (int e0 = 0; e0 < P->n_enc && !enc_bwd_done; e0 += MFM_MAX_SEQ) {
     MfmSeqDesc q[MFM_MAX_SEQ];
     const int n = std::min(MFM_MAX_SEQ, P->n_enc - e0);
     for (int i = 0; i < n; ++i) {

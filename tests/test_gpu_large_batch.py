@@ -5,6 +5,8 @@ B > 512 ran on kernels no oracle comparison reached).  Kernels named here, by th
   gemm_f32_kernel<2, true>                             64x64 tiles: blocks64 >= 2 CUs, or MFM_GEMM_FR=2
   lstm_seq_kernel<false|true, 0|1>                     MFMA recurrences (16 rows per workgroup): B > 512
   lstm_seq_small_kernel4<.., R=4, ..>                  4-row VALU tiles: 384 < B <= 512
+  lstm_seq_small_fold_kernel<false|true, ...>          encoder recurrence + its row's latent chain in one workgroup (MFM_KL_EF,
+                                                       B <= 64, the default; MFM_LATENT_FOLD=0 -> separate launches)
   latent_fwd/bwd_row_kernel<false|true>                one workgroup per (row, modality chain): 4 B <= CUs (default at B <= 64);
                                                        MFM_LATENT_CHAINS=0 -> one per row, MFM_LATENT_PRE=1 -> <true>
   dec_fc1_kernel                                       decoder fc1 + squared error + dH in one launch: fp32, T*B <= 5120 (default at
@@ -127,7 +129,7 @@ def test_you_shape_large_batch_matches_oracle(monkeypatch):
 
 
 @pytest.mark.parametrize("variant", ["staged", "fr2", "fr4", "panel", "staged+fr2+mfma", "fc1gemm", "dwonepass", "nochains",
-                                     "latpre"])
+                                     "latpre", "nofold"])
 @pytest.mark.parametrize("name", cases.KLEF_CASES)
 def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
     """The same kernels forced onto every golden case (B = 1 .. 229, ragged sizes, T = 1, CE and 7-output heads):
@@ -153,8 +155,10 @@ def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
     # latent row kernels: one workgroup per (row, modality chain) is the default while 4 B <= CUs (every golden case with
     # B <= 64); "nochains" forces one workgroup per row, "latpre" the 512-thread chain workgroups that request weights
     # four stages ahead (opt-in, no measured gain)
-    for k in ("MFM_LATENT_CHAINS", "MFM_LATENT_PRE"):
+    for k in ("MFM_LATENT_CHAINS", "MFM_LATENT_PRE", "MFM_LATENT_FOLD"):
         monkeypatch.delenv(k, raising=False)
+    if "nofold" in variant:                 # default at B <= 64: lstm_seq_small_fold_kernel (the encoders' workgroups run
+        monkeypatch.setenv("MFM_LATENT_FOLD", "0")      # their rows' latent chains); here: separate chain launches
     if "nochains" in variant:
         monkeypatch.setenv("MFM_LATENT_CHAINS", "0")
     if "latpre" in variant:
