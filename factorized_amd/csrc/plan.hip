@@ -1476,7 +1476,11 @@ extern "C" double mfm_plan_kernel_flops(const MfmPlan* P, int kid) {
   switch (kid) {
     case K_PROJ: for (int e = 0; e < P->n_enc; ++e) f += TB * 2.0 * 4.0 * P->enc_h[e] * P->enc_d[e]; break;
     // (variants 1, 2 run the six encoder recurrences as two launches: this is the sum of both)
-    case K_ENC_FWD: case K_ENC_BWD: for (int e = 0; e < P->n_enc; ++e) f += TB * 2.0 * 4.0 * P->enc_h[e] * P->enc_h[e]; break;
+    case K_ENC_FWD: case K_ENC_BWD:
+      for (int e = 0; e < P->n_enc; ++e) f += TB * 2.0 * 4.0 * P->enc_h[e] * P->enc_h[e];
+      if (P->fold_state == 1)          // fold launches: the rows' latent chains run in the same workgroups
+        for (int i = 0; i < P->lat.nops; ++i) f += 2.0 * P->B * P->lat_ops[i].N * P->lat_ops[i].K;
+      break;
     case K_DEC_FWD: case K_DEC_BWD: for (int m = 0; m < 3; ++m) f += TB * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m]; break;
     case K_FC1_FWD: {
       for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m];

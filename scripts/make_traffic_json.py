@@ -17,6 +17,10 @@ GEMM_ORDER = {4: ["proj_gemm", "fc1_mse_gemm", "fc1_bwd_gemm", "dw_gemm"], 2: ["
 
 
 def classify(name):
+    if "lstm_seq_small_fold_kernel<false" in name:      # encoder recurrences + their rows' latent chains (B <= 64)
+        return "enc_seq_fwd"
+    if "lstm_seq_small_fold_kernel<true" in name:
+        return "enc_seq_bwd"
     if "lstm_seq_small_kernel4<false" in name or "lstm_seq_fwd" in name or "lstm_seq_small_kernel<false" in name:
         return "enc_seq_fwd" if ("8, 2, 20, 30" in name or "30, 20, 8, 2" in name) else "dec_seq_fwd"
     if "lstm_seq_small_kernel4<true" in name or "lstm_seq_bwd" in name or "lstm_seq_small_kernel<true" in name:
