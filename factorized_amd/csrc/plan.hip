@@ -313,6 +313,7 @@ static int build(MfmPlan* P) {
   // rows per workgroup: small batches want many workgroups, large ones fewer atomics
   const size_t LDS_BUDGET = 150 * 1024;
   int R = (c.B <= 64) ? 4 : ((c.B <= 1024) ? 8 : 16);
+  if (const char* e = getenv("MFM_LATENT_ROWS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) R = v; }   // tuning override
   if (((size_t)panel + 2 * (size_t)rs) * sizeof(float) <= LDS_BUDGET) {
     L.wpanel = panel;
     while (R > 1 && (2 * (size_t)R * rs + panel) * sizeof(float) > LDS_BUDGET) R >>= 1;
