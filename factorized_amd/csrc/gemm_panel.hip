@@ -1,5 +1,5 @@
 // Row-panel GEMM for the input projections at LARGE batch (round 2): one workgroup keeps a panel of A rows -- the
-// input batch x[t,b,:] for 64 (fp32) / 128 (bf16) rows, ALL D feature columns -- resident in LDS and walks every
+// input batch x[t,b,:] for 64-80 (fp32) / 96-160 (bf16) rows, ALL D feature columns -- resident in LDS and walks every
 // output column of every encoder that consumes it (x W_ih^T + b_ih + b_hh for the four gates of the early-fusion
 // encoder, the three modality encoders and, for the MFN variants, the three MFN LSTMs), streaming the weight tiles
 // from L2.
@@ -26,16 +26,19 @@ namespace mfm {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-template <bool BF16> struct PanelCfg;
-template <> struct PanelCfg<true> { static constexpr int BM = 128, BK = 64, WM = 4, WN = 2, FM = 2, FN = 4; };
-template <> struct PanelCfg<false> { static constexpr int BM = 64, BK = 32, WM = 2, WN = 4, FM = 2, FN = 2; };
 constexpr int PANEL_BN = 128;
 constexpr int PANEL_THREADS = 512;
 
-template <bool BF16>
+// Panel height.  The 8 waves form a WM x WN grid, each wave owning FM x FN 16x16 fragments: BM = 16 WM FM rows of the
+// panel, 16 WN FN = 128 columns of a job.  One workgroup per CU (the panel fills the LDS), so a launch runs in
+// ceil(panels / CUs) rounds and a round costs a + b BM (a: the 1.3 MB weight set streamed from L2 once per panel plus
+// the fixed parts, 59 rows' worth in fp32 and 128 in bf16; profiles/r02_gemm_panel.txt).  The launcher therefore
+// picks the height that minimises rounds x (a + BM): at T*B = 40960 that is 80 rows / 2 rounds in fp32 (64 rows took
+// 2.5 -> 3) and 160 rows / 1 round in bf16 (128 rows took 1.25 -> 2).
+template <bool BF16, int WM, int WN, int FM, int FN>
 __global__ __launch_bounds__(PANEL_THREADS) void gemm_panel_kernel(const PanelLaunch L) {
-  using Cfg = PanelCfg<BF16>;
-  constexpr int BM = Cfg::BM, BK = Cfg::BK, FM = Cfg::FM, FN = Cfg::FN;
+  static_assert(WM * WN == PANEL_THREADS / 64 && WN * FN * 16 == PANEL_BN, "wave grid must cover 8 waves x 128 columns");
+  constexpr int BM = 16 * WM * FM, BK = BF16 ? 64 : 32;
   constexpr int BN = PANEL_BN;
   constexpr int LDB = BK + (BF16 ? 8 : 4);            // elements per B-tile row in LDS
   constexpr int GB = BN * BK / 4 / PANEL_THREADS;      // 16-byte weight loads per thread and tile: 4 (bf16) / 2 (fp32)
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(PANEL_THREADS) void gemm_panel_kernel(const PanelLa
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int bi = lane & 15, q = lane >> 4;
-  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.x * BM;
 
   // ---- the A panel: rows m0 .. m0+BM-1, columns 0 .. K-1 (zero beyond), fetched once
@@ -222,7 +225,49 @@ __global__ __launch_bounds__(PANEL_THREADS) void gemm_panel_kernel(const PanelLa
   }
 }
 
-int gemm_panel_launch(PanelLaunch& L, const ZeroSpans* zs, int precision, hipStream_t stream) {
+// Panel height for a launch (0: none fits the LDS, or -- unless forced -- the tiled kernel is expected to be faster).
+static int panel_height(const PanelLaunch& L, int precision, bool force, size_t* lds_out) {
+  const bool bf16 = precision == 1;
+  const int BK = bf16 ? 64 : 32;
+  const int KT = cdiv(L.K, BK);
+  const size_t esz = bf16 ? 2 : 4;
+  const size_t lda = (size_t)KT * BK + (bf16 ? 8 : 4), ldb = (size_t)BK + (bf16 ? 8 : 4);
+  // candidate heights (the instantiations below), cheapest first by rounds x (a + BM); a height whose panel does not
+  // fit the 160 KB of LDS is skipped.  MFM_PANEL_BM forces one (tests, sweeps).
+  static const int cand32[] = {64, 80}, cand16[] = {128, 160, 96};
+  const int* cand = bf16 ? cand16 : cand32;
+  const int ncand = bf16 ? 3 : 2;
+  const double a = bf16 ? 128.0 : 59.0;      // fitted: fp32 rounds of 131 / 148 us at 64 / 80 rows, bf16 87 / 104 / 117 us at 96 / 128 / 160
+  const int forced = getenv("MFM_PANEL_BM") ? atoi(getenv("MFM_PANEL_BM")) : 0;
+  const long cus = device_cus();
+  int BM = 0;
+  size_t lds = 0;
+  double best = 0.0;
+  for (int i = 0; i < ncand; ++i) {
+    const size_t need = ((size_t)cand[i] * lda + 2 * (size_t)PANEL_BN * ldb) * esz;
+    if (need > 160 * 1024) continue;
+    if (forced && cand[i] != forced) continue;
+    const int panels = cdiv(L.M, cand[i]);
+    const long rounds = (panels + cus - 1) / cus;
+    const double cost = (double)rounds * (a + cand[i]);
+    if (BM == 0 || cost < best) { BM = cand[i]; lds = need; best = cost; }
+  }
+  if (BM == 0) return 0;
+  // against the tiled kernel, whose time grows with the rows alone (fp32 11.6 us, bf16 7.5 us per 1000 rows at the MOSI
+  // sizes, where a panel row of one round costs 1.06 / 0.41 us): the panel kernel pays from rounds x (a + BM) <
+  // 2.8 (fp32) / 4.7 (bf16) x rows per CU.  Both sides scale with the weight set, so the ratio carries to other shapes
+  // (MOSEI, D = 409: only 64-row fp32 panels fit, and T*B = 20480 stays on the tiled kernel -- measured 1.35 vs 1.40 ms).
+  if (!force && !forced && best >= (bf16 ? 4.7 : 2.8) * (double)L.M / (double)cus) return 0;
+  *lds_out = lds;
+  return BM;
+}
+
+bool gemm_panel_pays(const PanelLaunch& L, int precision, bool force) {
+  size_t lds = 0;
+  return L.M >= 1 && L.K >= 1 && panel_height(L, precision, force, &lds) > 0;
+}
+
+int gemm_panel_launch(PanelLaunch& L, const ZeroSpans* zs, int precision, bool force, hipStream_t stream) {
   MFM_REQUIRE(L.a && L.M >= 1 && L.K >= 1 && L.ngroups >= 1 && L.ngroups <= MFM_PANEL_MAXG, "gemm panel: bad launch (M=%d K=%d groups=%d)", L.M, L.K, L.ngroups);
   MFM_REQUIRE((int64_t)(L.M - 1) * L.lda + L.K < ((int64_t)1 << 29), "gemm panel: A spans >= 2^31 bytes");
   for (int i = 0; i < L.ngroups; ++i) {
@@ -241,18 +286,25 @@ int gemm_panel_launch(PanelLaunch& L, const ZeroSpans* zs, int precision, hipStr
     }
   }
   const bool bf16 = precision == 1;
-  const int BM = bf16 ? PanelCfg<true>::BM : PanelCfg<false>::BM;
-  const int BK = bf16 ? PanelCfg<true>::BK : PanelCfg<false>::BK;
-  const int KT = cdiv(L.K, BK);
-  const size_t esz = bf16 ? 2 : 4;
-  const size_t lda = (size_t)KT * BK + (bf16 ? 8 : 4), ldb = (size_t)BK + (bf16 ? 8 : 4);
-  const size_t lds = ((size_t)BM * lda + 2 * (size_t)PANEL_BN * ldb) * esz;
-  if (lds > 158 * 1024) { set_error("gemm panel: K=%d needs %zu bytes of LDS", L.K, lds); return MFM_ERR_UNSUPPORTED; }
-  const void* fn = bf16 ? (const void*)gemm_panel_kernel<true> : (const void*)gemm_panel_kernel<false>;
-  MFM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  size_t lds = 0;
+  const int BM = panel_height(L, precision, force, &lds);
+  if (BM == 0) { set_error("gemm panel: declined (K=%d does not fit the LDS, MFM_PANEL_BM names no built height, or the tiled kernel is cheaper)", L.K); return MFM_ERR_UNSUPPORTED; }
   const dim3 grid(cdiv(L.M, BM)), block(PANEL_THREADS);
-  if (bf16) hipLaunchKernelGGL(gemm_panel_kernel<true>, grid, block, lds, stream, L);
-  else hipLaunchKernelGGL(gemm_panel_kernel<false>, grid, block, lds, stream, L);
+#define MFM_PANEL_GO(B16, WM_, WN_, FM_, FN_)                                                                     \
+  do {                                                                                                            \
+    auto* fn = gemm_panel_kernel<B16, WM_, WN_, FM_, FN_>;                                                        \
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+    hipLaunchKernelGGL(fn, grid, block, lds, stream, L);                                                          \
+  } while (0)
+  if (bf16) {
+    if (BM == 128) MFM_PANEL_GO(true, 4, 2, 2, 4);
+    else if (BM == 160) MFM_PANEL_GO(true, 2, 4, 5, 2);
+    else MFM_PANEL_GO(true, 2, 4, 3, 2);
+  } else {
+    if (BM == 64) MFM_PANEL_GO(false, 2, 4, 2, 2);
+    else MFM_PANEL_GO(false, 1, 8, 5, 1);
+  }
+#undef MFM_PANEL_GO
   MFM_LAUNCH_CHECK("gemm_panel_kernel");
   return MFM_OK;
 }

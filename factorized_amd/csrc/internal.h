@@ -40,7 +40,9 @@ struct PanelLaunch {
   PanelGroup g[MFM_PANEL_MAXG]; int ngroups;
   float* zero_ptr[MFM_GEMM_ZSPANS]; int64_t zero_n[MFM_GEMM_ZSPANS];
 };
-int gemm_panel_launch(PanelLaunch& L, const ZeroSpans* zs, int precision, hipStream_t stream);
+// force = false: the launcher declines (MFM_ERR_UNSUPPORTED, no error text) when its cost model says the tiled kernel is faster
+int gemm_panel_launch(PanelLaunch& L, const ZeroSpans* zs, int precision, bool force, hipStream_t stream);
+bool gemm_panel_pays(const PanelLaunch& L, int precision, bool force);
 
 // dec_fc1.hip -- decoder fc1 forward + squared-error loss + backward to the hidden states, one launch (fp32)
 struct DecFc1Item {

@@ -707,12 +707,13 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       d.m = (int)TB; d.n = sb.Hp; d.n_valid = sb.h; d.k = P->enc_d[e]; d.batch = 4; d.split_k = 1;
       d.alpha = 1.0f;
     }
-    // large batches: the row-panel kernel reads x once for all encoders (gemm_panel.hip).  Measured crossover against
-    // the tiled kernel (profiles/r02_gemm_panel.txt): fp32 (64-row panels) from ~2 workgroup rounds, bf16 (128-row
-    // panels) from ~5/8 of one round; MFM_PANEL_MINROWS overrides the threshold
-    long min_rows = c.precision ? 128L * device_cus() * 5 / 8 : 64L * 2 * device_cus();
-    if (const char* e = getenv("MFM_PANEL_MINROWS")) min_rows = atol(e);
-    const bool panel = TB >= min_rows && P->n_enc <= MFM_PANEL_MAXG && (int64_t)TB * P->D < ((int64_t)1 << 29);
+    // large batches: the row-panel kernel reads x once for all encoders (gemm_panel.hip).  Its launcher picks the panel
+    // height and declines when its cost model favours the tiled kernel (measured crossover, profiles/r02_gemm_panel.txt:
+    // T*B ~ 10240 in both dtypes at the MOSI sizes -- equal at B = 512, panel 135 vs 166 us fp32 and 86 vs 104 us bf16 at
+    // B = 640); MFM_PANEL_MINROWS=n forces the panel kernel from n rows on (and the tiled one below)
+    const char* pe = getenv("MFM_PANEL_MINROWS");
+    const bool panel_forced = pe && TB >= atol(pe);
+    const bool panel = (pe ? panel_forced : TB >= 16L * device_cus()) && P->n_enc <= MFM_PANEL_MAXG && (int64_t)TB * P->D < ((int64_t)1 << 29);
     if (panel) {
       PanelLaunch PL;
       memset(&PL, 0, sizeof(PL));
@@ -726,10 +727,8 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
         G.c = W + sb.gates; G.ldc = 4 * (int64_t)sb.Hp;
         G.n = 4 * sb.Hp; G.seg = sb.Hp; G.seg_valid = sb.h; G.k_off = P->enc_xoff[e]; G.k_len = P->enc_d[e];
       }
-      int rc = MFM_ERR_UNSUPPORTED;
-      { Timer _t(P, s, K_PROJ); rc = gemm_panel_launch(PL, &zs, c.precision, s); }
-      if (rc == MFM_ERR_UNSUPPORTED) RUN(K_PROJ, gemm_group_launch(g, P->n_enc, s, &zs, nullptr, 0, c.precision));
-      else if (rc != MFM_OK) return rc;
+      if (gemm_panel_pays(PL, c.precision, panel_forced)) RUN(K_PROJ, gemm_panel_launch(PL, &zs, c.precision, panel_forced, s));
+      else RUN(K_PROJ, gemm_group_launch(g, P->n_enc, s, &zs, nullptr, 0, c.precision));
     } else {
       RUN(K_PROJ, gemm_group_launch(g, P->n_enc, s, &zs, nullptr, 0, c.precision));
     }

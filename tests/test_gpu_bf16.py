@@ -318,7 +318,7 @@ def _bf16_engine(cfgs):
     return e, w
 
 
-@pytest.fixture(params=["all-bf16", "default", "all-bf16+panel"])
+@pytest.fixture(params=["all-bf16", "default", "all-bf16+panel", "all-bf16+panel160", "all-bf16+panel96"])
 def seq_policy(request, monkeypatch):
     """a bf16 plan runs its recurrences on the bf16 MFMA kernels from B = 192 on and on the fp32 VALU kernels below
     (lstm_seq.hip::bf16_seq_pays); 'all-bf16' forces the bf16 kernels at every batch size."""
@@ -329,7 +329,13 @@ def seq_policy(request, monkeypatch):
     if "panel" in request.param:
         monkeypatch.setenv("MFM_PANEL_MINROWS", "1")    # gemm_panel_kernel<true> for the input projections
         monkeypatch.setenv("MFM_DW_ONEPASS_MINROWS", "1")   # and dw_onepass_kernel<true> for the LSTM weight gradients
+        bm = request.param.split("panel")[1]                # forced panel height (default: the launcher's pick, 128 here)
+        if bm:
+            monkeypatch.setenv("MFM_PANEL_BM", bm)
+        else:
+            monkeypatch.delenv("MFM_PANEL_BM", raising=False)
     else:
+        monkeypatch.delenv("MFM_PANEL_BM", raising=False)
         monkeypatch.delenv("MFM_PANEL_MINROWS", raising=False)
         monkeypatch.delenv("MFM_DW_ONEPASS_MINROWS", raising=False)
     return request.param

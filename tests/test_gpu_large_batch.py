@@ -12,8 +12,9 @@ B > 512 ran on kernels no oracle comparison reached).  Kernels named here, by th
   dec_fc1_kernel                                       decoder fc1 + squared error + dH in one launch: fp32, T*B <= 5120 (default at
                                                        the golden sizes; MFM_FC1_FUSED=0 -> the two GEMM launches)
   dw_onepass_kernel<false|true>                        LSTM weight gradients, one pass over dA: opt-in, MFM_DW_ONEPASS_MINROWS=1
-  gemm_panel_kernel<false|true>                        row-panel projection GEMM: T*B >= 2 rounds of panels (B >= 1639 fp32
-                                                       at T=20), or MFM_PANEL_MINROWS=1
+  gemm_panel_kernel<false|true, wave grid>             row-panel projection GEMM: T*B >= 2 rounds of panels (B >= 1639 fp32
+                                                       at T=20), or MFM_PANEL_MINROWS=1; panel height 64 / 80 rows (fp32),
+                                                       128 / 160 / 96 (bf16) picked per launch, MFM_PANEL_BM forces one
 
 Tolerance: 1e-4 relative fp32 (BASELINE.json north_star), forward losses + all 78 gradients + 3 Adam steps."""
 import numpy as np
@@ -128,8 +129,8 @@ def test_you_shape_large_batch_matches_oracle(monkeypatch):
     _compare(configs.you_configs(dropout=False), 640, 50, loss_kind="ce", adam_steps=2, tag="you")
 
 
-@pytest.mark.parametrize("variant", ["staged", "fr2", "fr4", "panel", "staged+fr2+mfma", "fc1gemm", "dwonepass", "nochains",
-                                     "latpre", "nofold"])
+@pytest.mark.parametrize("variant", ["staged", "fr2", "fr4", "panel", "panel80", "staged+fr2+mfma", "fc1gemm", "dwonepass",
+                                     "nochains", "latpre", "nofold"])
 @pytest.mark.parametrize("name", cases.KLEF_CASES)
 def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
     """The same kernels forced onto every golden case (B = 1 .. 229, ragged sizes, T = 1, CE and 7-output heads):
@@ -168,9 +169,13 @@ def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
     else:                                                   # over dA (opt-in: measured slower than the GEMMs)
         monkeypatch.delenv("MFM_DW_ONEPASS_MINROWS", raising=False)
     if "panel" in variant:
-        monkeypatch.setenv("MFM_PANEL_MINROWS", "1")    # gemm_panel_kernel<false>: the large-batch projection kernel
+        monkeypatch.setenv("MFM_PANEL_MINROWS", "1")    # gemm_panel_kernel<false, ..>: the large-batch projection kernel
     else:
         monkeypatch.delenv("MFM_PANEL_MINROWS", raising=False)
+    if variant == "panel80":                            # the 80-row panels (1 x 8 wave grid) the launcher picks when they
+        monkeypatch.setenv("MFM_PANEL_BM", "80")        # save a round of workgroups (T*B = 40960: 512 panels = 2 rounds)
+    else:
+        monkeypatch.delenv("MFM_PANEL_BM", raising=False)
     cs = cases.load_case(name)
     e = engine.MFMEngine(cs["cfgs"])
     w = synth.make_weights(e.layout.shapes, seed=1234)
