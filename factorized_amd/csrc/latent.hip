@@ -94,7 +94,7 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(const LatentDev
   build_prefix(L, pfxN, pfxK);
   float* rec = lds;
   const int RS = L.rec_size;
-  const int R = L.rows_per_wg;
+  const int R = L.rows_fwd;
   float* wp = lds + R * RS;
   constexpr bool staged = STAGED;
   const int row0 = blockIdx.x * R;
@@ -504,7 +504,7 @@ int latent_fwd_launch(const LatentDev& L, const float* params, hipStream_t strea
     MFM_LAUNCH_CHECK("latent_fwd_row_kernel");
     return MFM_OK;
   }
-  const int R = L.rows_per_wg;
+  const int R = L.rows_fwd;
   const size_t lds = ((size_t)R * L.rec_size + L.wpanel) * sizeof(float);
   MFM_REQUIRE(lds <= 156 * 1024, "latent_fwd: record + weight panel too large for LDS (%zu bytes)", lds);
   int rc = set_lds_limit(L.wpanel > 0 ? (const void*)latent_fwd_kernel<true> : (const void*)latent_fwd_kernel<false>, lds);
