@@ -385,11 +385,16 @@ def test_mfn_memory_dropout_statistics(eng):
 
 
 # ---------------------------------------------------------------------------------- MMD
-@pytest.mark.parametrize("B,dim", [(32, 32), (19, 80), (100, 8), (64, 256), (1, 16), (33, 5)])
-def test_mmd_matches_reference_formula(eng, B, dim):
+@pytest.mark.parametrize("rows", ["auto", "8", "32"])
+@pytest.mark.parametrize("B,dim", [(32, 32), (19, 80), (100, 8), (64, 256), (1, 16), (33, 5), (300, 24)])
+def test_mmd_matches_reference_formula(eng, B, dim, rows, monkeypatch):
     """mfm_mmd_fwd_bwd against the reference statement of loss_MMD / compute_kernel (mfm_model.py:14-34) in
-    float64 on the CPU: value and gradient wrt z."""
+    float64 on the CPU: value and gradient wrt z.  rows: mmd_kernel<8> (default for B <= 256) / mmd_kernel<32> forced."""
     from factorized_amd.mfm_model import loss_MMD
+    if rows == "auto":
+        monkeypatch.delenv("MFM_MMD_ROWS", raising=False)
+    else:
+        monkeypatch.setenv("MFM_MMD_ROWS", rows)
     rs = np.random.RandomState(B * 1000 + dim)
     zn = rs.normal(size=(B, dim)).astype(np.float32) * 1.3
     gn = rs.normal(size=(B, dim)).astype(np.float32)
