@@ -55,7 +55,6 @@ __global__ __launch_bounds__(256, (FR == 1) ? (VEC ? 5 : 4) : (FR == 2 ? 3 : 2))
   // share of every problem (a whole-launch remap left the XCDs with the long-K problems as stragglers).
   int pi = 0;
   const int bid = blockIdx.x;
-  if (bid >= g.gemm_blocks) { gemm_adam_tail(g); return; }       // optimizer tail workgroups (block-uniform)
 #pragma unroll
   for (int i = 1; i < MFM_GEMM_MAXP; ++i) pi += (bid >= g.begins[i]) ? 1 : 0;
   const GemmProblem& P = g.p[pi];
@@ -63,7 +62,7 @@ __global__ __launch_bounds__(256, (FR == 1) ? (VEC ? 5 : 4) : (FR == 2 ? 3 : 2))
   int local = bid - P.block_begin;
   {
     constexpr int NX = 8;
-    const int nb = ((pi + 1 < g.count) ? g.begins[pi + 1] : g.gemm_blocks) - P.block_begin;
+    const int nb = ((pi + 1 < g.count) ? g.begins[pi + 1] : (int)gridDim.x) - P.block_begin;
     const int x = local % NX, j = local / NX;
     const int per = nb / NX, rem = nb % NX;
     local = x * per + (x < rem ? x : rem) + j;
@@ -75,7 +74,7 @@ __global__ __launch_bounds__(256, (FR == 1) ? (VEC ? 5 : 4) : (FR == 2 ? 3 : 2))
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = split * P.k_per_split;
   const int kend = min(d.k, kbeg + P.k_per_split);
-  if (kbeg >= kend && split > 0) { gemm_tail_signal(g, true); return; }
+  if (kbeg >= kend && split > 0) return;
 
   const float* __restrict__ A = d.a + (int64_t)z * d.a_sz;
   const float* __restrict__ Bm = d.b + (int64_t)z * d.b_sz;
@@ -259,7 +258,6 @@ __global__ __launch_bounds__(256, (FR == 1) ? (VEC ? 5 : 4) : (FR == 2 ? 3 : 2))
   }
 
   gemm_epilogue<FR, TF>(g, d, pi, z, split, m0, n0, wm, wn, bi, q, tid, lane, wave, acc, tgt, do_mse);
-  gemm_tail_signal(g, d.accumulate != 0);
 }
 
 static int g_cus = 0;
@@ -276,7 +274,7 @@ int device_cus() {
 
 // Host-side launch of one group (count <= MFM_GEMM_MAXP).
 int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, const ZeroSpans* zs, const MseEpi* mse,
-                      int mse_count, int precision, const GemmEpiSet* epis, const AdamTail* adam) {
+                      int mse_count, int precision, const GemmEpiSet* epis) {
   MFM_REQUIRE(count >= 1 && count <= MFM_GEMM_MAXP, "gemm group: count %d out of range", count);
   const int cus = device_cus();
   GemmGroup g;
@@ -378,14 +376,6 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
     total += P.tiles_m * P.tiles_n * P.d.batch * split;
   }
   for (int i = count; i < MFM_GEMM_MAXP; ++i) g.begins[i] = 0x7fffffff;
-  g.gemm_blocks = total;
-  if (adam) {
-    MFM_REQUIRE(!bf16 && adam->p && adam->m && adam->v && adam->g && adam->counter && adam->n > 0 && (adam->n & 3) == 0 &&
-                    ((((uintptr_t)adam->p | (uintptr_t)adam->m | (uintptr_t)adam->v | (uintptr_t)adam->g) & 15) == 0),
-                "gemm group: optimizer tail needs the fp32 kernel, 16-byte aligned buffers and n %% 4 == 0");
-    g.adam = *adam;
-    total += (int)(((adam->n >> 2) + 256 * ADAM_TAIL_EPT - 1) / (256 * ADAM_TAIL_EPT));
-  }
   if (bf16) return gemm_bf16_launch_kernel(g, FR, total, stream);
   if (FR == 4) {
     if (vec) hipLaunchKernelGGL((gemm_f32_kernel<4, true>), dim3(total), dim3(256), 0, stream, g);

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, (FR == 1) ? 4 : 2) void gemm_bf16_kernel(const
   int local = bid - P.block_begin;
   {
     constexpr int NX = 8;
-    const int nb = ((pi + 1 < g.count) ? g.begins[pi + 1] : g.gemm_blocks) - P.block_begin;
+    const int nb = ((pi + 1 < g.count) ? g.begins[pi + 1] : (int)gridDim.x) - P.block_begin;
     const int x = local % NX, j = local / NX;
     const int per = nb / NX, rem = nb % NX;
     local = x * per + (x < rem ? x : rem) + j;

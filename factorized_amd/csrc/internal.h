@@ -6,7 +6,6 @@ namespace mfm {
 
 // gemm.hip
 #define MFM_GEMM_ZSPANS 4
-#define MFM_GEMM_MAXP 56   // problems per launch (the descriptors travel in the kernel-argument segment, ~9.6 KB)
 struct ZeroSpans { float* ptr[MFM_GEMM_ZSPANS]; int64_t n[MFM_GEMM_ZSPANS]; };   // spans (multiples of 4 floats, 16-byte aligned) a GEMM launch also clears
 // optional per-problem output transform, applied to the finished element v of C (non-accumulating problems):
 //   1  relu + dropout:  aux <- (v > 0) * scale,  v <- max(v, 0) * scale      scale = 0 | 1/(1-p) in train mode, else 1
@@ -20,21 +19,8 @@ struct MseEpi {          // squared-error epilogue of one product: target, d(out
 };
 // precision: 0 = fp32 operands on v_mfma_f32_16x16x4_f32, 1 = operands rounded to bf16 on the way into LDS,
 // v_mfma_f32_16x16x32_bf16 with fp32 accumulation (gemm_bf16.hip)
-// Optional optimizer tail of a grouped fp32 launch (the step's last one, the weight gradients): workgroups appended behind
-// the GEMM tiles apply the flat Adam update once `counter` (zeroed by the step's first launch) shows that every tile
-// workgroup has published its gradients -- see gemm.hip.  n must be a multiple of 4, the buffers 16-byte aligned.
-#define MFM_TAIL_SLOTS 64     // arrival counters of the optimizer tail ...
-#define MFM_TAIL_STRIDE 32    // ... one per 128-byte line
-struct AdamTail {
-  float *p, *m, *v;
-  const float* g;
-  int64_t n;
-  float beta1, beta2, eps, step_size, bc2_sqrt, grad_scale;
-  int* counter;      // master word + MFM_TAIL_SLOTS slot counters, MFM_TAIL_STRIDE ints apart
-};
 int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, const ZeroSpans* zs = nullptr,
-                      const MseEpi* mse = nullptr, int mse_count = 0, int precision = 0, const GemmEpiSet* epis = nullptr,
-                      const AdamTail* adam = nullptr);
+                      const MseEpi* mse = nullptr, int mse_count = 0, int precision = 0, const GemmEpiSet* epis = nullptr);
 int device_cus();
 
 // gemm_panel.hip -- row-panel GEMM for the large-batch input projections: the A rows stay in LDS, every column group

@@ -105,7 +105,6 @@ struct MfmPlan {
   int64_t cstar, h1, m1, att, attended, h2, m2, chat, a1, a2, gam1, gam2, mems, mem_out;
   int64_t zero_blk, zero_len;        // cleared by the step's first launch: dcx | zyin | d_hT | dmem | datt
   int64_t dhs_blk, dhs_len;          // the decoders' dH buffers (cleared by the first launch when the fused fc1 kernel runs)
-  int64_t sync_blk;                  // in front of dhs_blk, same zero span: the optimizer tail's arrival counters
   int64_t zyin, d_hT, dmem, datt;
   int64_t du1, du2, dchat, dh2, dlog, dh1, dcs;
   int64_t lat_seed;                  // variant 2: gradient seed record of the latent backward (d MMD / d z)
@@ -182,7 +181,6 @@ static int build(MfmPlan* P) {
     P->xhat[m] = carve(cur, TB * dd[m]);
     P->dxhat[m] = carve(cur, TB * dd[m]);
   }
-  P->sync_blk = carve(cur, (MFM_TAIL_SLOTS + 1) * MFM_TAIL_STRIDE);    // cleared with the dH block (zero span 3 starts here)
   P->dhs_blk = cur;                                // one block: the fused fc1 kernel adds into it (dec_fc1.hip), zero span 3
   for (int m = 0; m < 3; ++m) P->dec_dhs[m] = carve(cur, TB * P->dec[m].Hp);
   P->dhs_len = cur - P->dhs_blk;
@@ -693,7 +691,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
   long fc1_max_rows = 5120;                        // measured crossover (profiles/r02_dec_fc1.txt)
   if (const char* e = getenv("MFM_FC1_FUSED_MAXROWS")) fc1_max_rows = atol(e);
   const bool fc1_fused = fc1_env_on && TB <= fc1_max_rows;
-  if (train) { zs.ptr[3] = W + P->sync_blk; zs.n[3] = fc1_fused ? P->dhs_blk + P->dhs_len - P->sync_blk : (MFM_TAIL_SLOTS + 1) * MFM_TAIL_STRIDE; }
+  if (fc1_fused && train) { zs.ptr[3] = W + P->dhs_blk; zs.n[3] = P->dhs_len; }
   P->calls++;
 
   // bf16 plans: the recurrences' weight fragments, rounded and packed once per step (lstm_seq_bf16.hip)
@@ -1038,8 +1036,7 @@ static int mfn_backward(MfmPlan* P, const float* params, float* W, float* grads,
 }
 
 static int backward(MfmPlan* P, const float* params, const float* x, const void* y, int stage, float* W,
-                    float* grads, hipStream_t s, const ExtGrads* ext = nullptr, const AdamTail* adam = nullptr,
-                    bool* adam_done = nullptr) {
+                    float* grads, hipStream_t s, const ExtGrads* ext = nullptr) {
   const MfmPlanConfig& c = P->cfg;
   const int V = c.variant;
   const int T = P->T, B = P->B;
@@ -1207,19 +1204,8 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
         dA_gemms(P, P->dec[m], P->dec_p[m], W, grads, tail, W + P->dec_init[m], P->dec_h[m], P->dec_h[m], true, op);
       }
     if (DL.n_items > 0) RUN(K_DEC_DW, dw_onepass_launch(DL, c.precision, s));
-    if (adam && !c.precision && !tail.empty()) {
-      // fused step: the optimizer rides behind the tiles of the step's last launch (gemm.hip, optimizer tail)
-      const int n = (int)tail.size();
-      for (int done = 0; done < n; done += MFM_GEMM_MAXP) {
-        const int cnt = std::min(n - done, (int)MFM_GEMM_MAXP);
-        const bool last = done + cnt == n;
-        RUN(K_ENC_DW, gemm_group_launch(tail.data() + done, cnt, s, nullptr, nullptr, 0, 0, nullptr, last ? adam : nullptr));
-      }
-      if (adam_done) *adam_done = true;
-    } else {
-      RUN(K_ENC_DW, c.precision ? mfm_gemm_grouped_bf16(tail.data(), (int)tail.size(), s)
-                                  : mfm_gemm_grouped_f32(tail.data(), (int)tail.size(), s));
-    }
+    RUN(K_ENC_DW, c.precision ? mfm_gemm_grouped_bf16(tail.data(), (int)tail.size(), s)
+                                : mfm_gemm_grouped_f32(tail.data(), (int)tail.size(), s));
   }
   return MFM_OK;
 }
@@ -1352,25 +1338,11 @@ extern "C" int mfm_plan_train_step(MfmPlan* P, float* params, float* grads, floa
   float* xo[3] = {nullptr, nullptr, nullptr};
   int rc = forward(P, params, x, y, 1, seed, (float*)workspace, xo, nullptr, losses, s, grads);
   if (rc != MFM_OK) return rc;
-  // MFM_ADAM_FUSED=1 (opt-in, fp32 plans): Adam is applied by tail workgroups of the weight-gradient launch.  Parity-green
-  // and one launch less, but SLOWER (dW + Adam 39 us against 26 + 7.7: profiles/r02_adam_tail.txt) -- the arrival counting and
-  // the scoped gradient loads cost more than the launch boundary they replace
-  MFM_REQUIRE(step >= 1, "mfm_plan_train_step: step %d", step);
-  AdamTail at;
-  memset(&at, 0, sizeof(at));
-  const bool fuse = getenv("MFM_ADAM_FUSED") && atoi(getenv("MFM_ADAM_FUSED")) != 0 && P->cfg.precision == 0 && (P->n_params & 3) == 0 &&
-                    ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)adam_m | (uintptr_t)adam_v) & 15) == 0);
-  if (fuse) {
-    const double bc1 = 1.0 - pow((double)0.9f, (double)step), bc2 = 1.0 - pow((double)0.999f, (double)step);   // as adam_launch (elementwise.hip)
-    at.p = params; at.m = adam_m; at.v = adam_v; at.g = grads; at.n = P->n_params;
-    at.beta1 = 0.9f; at.beta2 = 0.999f; at.eps = 1e-8f; at.grad_scale = grad_scale;
-    at.step_size = (float)((double)lr / bc1); at.bc2_sqrt = (float)sqrt(bc2);
-    at.counter = reinterpret_cast<int*>((float*)workspace + P->sync_blk);
-  }
-  bool adam_done = false;
-  rc = backward(P, params, x, y, 0, (float*)workspace, grads, s, nullptr, fuse ? &at : nullptr, &adam_done);
+  // (Adam as tail workgroups of the weight-gradient launch was built and measured: slower, and its inactive code cost every
+  // grouped GEMM launch ~1.5 us -- removed again, profiles/r02_adam_tail.txt)
+  rc = backward(P, params, x, y, 0, (float*)workspace, grads, s);
   if (rc != MFM_OK) return rc;
-  if (!adam_done) RUN(K_ADAM, adam_launch(params, grads, adam_m, adam_v, P->n_params, step, lr, 0.9f, 0.999f, 1e-8f, grad_scale, s));
+  RUN(K_ADAM, adam_launch(params, grads, adam_m, adam_v, P->n_params, step, lr, 0.9f, 0.999f, 1e-8f, grad_scale, s));
   return MFM_OK;
 }
 

@@ -184,16 +184,10 @@ def test_staged_losses(stage):
             assert grad_err(g, p.grad.numpy()) < TOL, n
 
 
-@pytest.mark.parametrize("adam", ["launch", "tail"])
 @pytest.mark.parametrize("name", ["klef_b32_t20", "klef_b33_t7", "klef_odd_b19_t9", "klef_you_b32_t50"])
-def test_training_trajectory_matches_reference(name, adam, monkeypatch):
+def test_training_trajectory_matches_reference(name):
     """N fused steps (fwd+bwd+Adam, one C call each) vs the reference's own loss trace and final
-    parameters (golden), i.e. 'matched loss curves'.  adam = "tail": the optimizer applied by tail workgroups of the
-    weight-gradient launch (MFM_ADAM_FUSED=1, opt-in: gemm_common.h::gemm_adam_tail) instead of adam_kernel."""
-    if adam == "tail":
-        monkeypatch.setenv("MFM_ADAM_FUSED", "1")
-    else:
-        monkeypatch.delenv("MFM_ADAM_FUSED", raising=False)
+    parameters (golden), i.e. 'matched loss curves'."""
     cs = cases.load_case(name)
     e, _ = _engine(cs)
     gold = cs["gold"]
@@ -207,15 +201,15 @@ def test_training_trajectory_matches_reference(name, adam, monkeypatch):
             p1 = np.stack([cases.summarize(v.cpu().numpy()) for v in e.param_views().values()])
     trace = np.array(trace)
     ref = gold["trace"]
-    cases.report("klef_trace_rel_%s_%s" % (name, adam), np.max(np.abs(trace - ref) / np.maximum(np.abs(ref), 1e-2)))
+    cases.report("klef_trace_rel_%s" % name, np.max(np.abs(trace - ref) / np.maximum(np.abs(ref), 1e-2)))
     assert np.max(np.abs(trace - ref) / np.maximum(np.abs(ref), 1e-2)) < 20 * TOL, (trace[-1], ref[-1])
     assert np.max(np.abs(trace[0] - ref[0]) / np.maximum(np.abs(ref[0]), 1e-2)) < TOL
     scale1 = np.maximum(np.abs(gold["param_after1"][:, :1]), 1e-3)
     assert np.max(np.abs(p1 - gold["param_after1"]) / scale1) < 5 * TOL
     pl = np.stack([cases.summarize(v.cpu().numpy()) for v in e.param_views().values()])
     scale = np.maximum(np.abs(gold["param_after_last"][:, :1]), 1e-3)
-    cases.report("klef_param_after1_rel_%s_%s" % (name, adam), np.max(np.abs(p1 - gold["param_after1"]) / scale1))
-    cases.report("klef_param_after_last_rel_%s_%s" % (name, adam), np.max(np.abs(pl - gold["param_after_last"]) / scale))
+    cases.report("klef_param_after1_rel_%s" % name, np.max(np.abs(p1 - gold["param_after1"]) / scale1))
+    cases.report("klef_param_after_last_rel_%s" % name, np.max(np.abs(pl - gold["param_after_last"]) / scale))
     assert np.max(np.abs(pl - gold["param_after_last"]) / scale) < 50 * TOL
 
 
