@@ -23,6 +23,17 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
                       const MseEpi* mse = nullptr, int mse_count = 0, int precision = 0, const GemmEpiSet* epis = nullptr);
 int device_cus();
 
+// lin_rows.hip -- row-block linear layers C = epi(A W^T + bias) for few rows (the MFN attention block at small T*B): every
+// workgroup requests its whole 16 x k / 32 x k operand slices at once instead of walking K through a load ring.
+// kind / aux / p / op_id as GemmEpi (kinds 0, 1, 2).
+#define MFM_LINROWS_MAX 3
+struct LinRowsItem {
+  const float* a; int lda; const float* w; int ldw; const float* bias; float* c; int ldc; int n, k;
+  int kind; float* aux; float p; unsigned op_id;
+};
+bool lin_rows_supported(const LinRowsItem* items, int count, int M);
+int lin_rows_launch(const LinRowsItem* items, int count, int M, int train, unsigned long long seed, hipStream_t stream);
+
 // gemm_panel.hip -- row-panel GEMM for the large-batch input projections: the A rows stay in LDS, every column group
 // (weight block [n_valid, k_len] with row stride ldw, consuming panel columns [k_off, k_off + k_len)) is walked by the
 // same workgroup.  C columns [n_valid, n) are written as zeros (pad units).

@@ -592,15 +592,32 @@ static int mfn_forward(MfmPlan* P, const float* params, int train, uint64_t seed
       d.m = (int)TB; d.n = n; d.n_valid = n; d.k = k; d.batch = 1; d.split_k = 1; d.alpha = 1.0f;
       return d;
     };
+    // fp32 plans with few rows (T*B <= 2560): the four forward products as row-block launches (lin_rows.hip: all operands of a
+    // workgroup requested at once, ~10 instead of ~16.5 us per launch at T*B = 640; profiles/r02_lin_rows.txt); bf16 plans,
+    // larger batches and MFM_LIN_ROWS=0 keep the grouped GEMM
+    long lr_max = 2560;
+    if (const char* e = getenv("MFM_LIN_ROWS_MAXROWS")) lr_max = atol(e);
+    const bool lr_on = prec == 0 && TB <= lr_max && !(getenv("MFM_LIN_ROWS") && atoi(getenv("MFM_LIN_ROWS")) == 0);
+    auto rows = [&](const MfmGemmDesc& d, int kind, float* aux, float p, unsigned op_id) {
+      LinRowsItem it;
+      memset(&it, 0, sizeof(it));
+      it.a = d.a; it.lda = (int)d.a_sm; it.w = d.b; it.ldw = (int)d.b_sn; it.bias = d.bias; it.c = d.c; it.ldc = (int)d.ldc;
+      it.n = d.n; it.k = d.k; it.kind = kind; it.aux = aux; it.p = p; it.op_id = op_id;
+      return it;
+    };
     {   // h1 = drop(relu(att1_fc1(cStar)))
       MfmGemmDesc g = lin(W + P->cstar, A2, A2, pi.att1_1, c.nn1, W + P->h1, c.nn1, A2);
       GemmEpi e = {W + P->m1, c.drop_nn1, 1, 101u, 0};
+      LinRowsItem it = rows(g, 1, e.aux, e.p, e.op_id);
       es.epi = &e; es.count = 1;
-      RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
+      if (lr_on && lin_rows_supported(&it, 1, (int)TB)) RUN(K_MFN_ATT_FWD, lin_rows_launch(&it, 1, (int)TB, train, es.seed, s));
+      else RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
     }
     {   // logits = att1_fc2(h1)
       MfmGemmDesc g = lin(W + P->h1, c.nn1, c.nn1, pi.att1_2, A2, W + P->att, A2, c.nn1);
-      RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec));
+      LinRowsItem it = rows(g, 0, nullptr, 0.0f, 0u);
+      if (lr_on && lin_rows_supported(&it, 1, (int)TB)) RUN(K_MFN_ATT_FWD, lin_rows_launch(&it, 1, (int)TB, train, es.seed, s));
+      else RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec));
     }
     RUN(K_MFN_GLUE, mfn_softmax_fwd_launch(W + P->att, W + P->cstar, W + P->attended, TB, A2, s));
     {   // h2 = drop(relu(att2_fc1(attended))) ; a_n = gamma_n_fc1[:, :A2] attended + b   (the memory columns: mfn_mem)
@@ -609,14 +626,18 @@ static int mfn_forward(MfmPlan* P, const float* params, int train, uint64_t seed
       g[1] = lin(W + P->attended, A2, A2, pi.g1_1, c.g1, W + P->a1, c.g1, A2 + M);
       g[2] = lin(W + P->attended, A2, A2, pi.g2_1, c.g2, W + P->a2, c.g2, A2 + M);
       GemmEpi e = {W + P->m2, c.drop_nn2, 1, 102u, 0};
+      LinRowsItem it[3] = {rows(g[0], 1, e.aux, e.p, e.op_id), rows(g[1], 0, nullptr, 0.0f, 0u), rows(g[2], 0, nullptr, 0.0f, 0u)};
       es.epi = &e; es.count = 1;
-      RUN(K_MFN_ATT_FWD, gemm_group_launch(g, 3, s, nullptr, nullptr, 0, prec, &es));
+      if (lr_on && lin_rows_supported(it, 3, (int)TB)) RUN(K_MFN_ATT_FWD, lin_rows_launch(it, 3, (int)TB, train, es.seed, s));
+      else RUN(K_MFN_ATT_FWD, gemm_group_launch(g, 3, s, nullptr, nullptr, 0, prec, &es));
     }
     {   // cHat = tanh(att2_fc2(h2))
       MfmGemmDesc g = lin(W + P->h2, c.nn2, c.nn2, pi.att2_2, M, W + P->chat, M, c.nn2);
       GemmEpi e = {nullptr, 0.0f, 2, 0u, 0};
+      LinRowsItem it = rows(g, 2, nullptr, 0.0f, 0u);
       es.epi = &e; es.count = 1;
-      RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
+      if (lr_on && lin_rows_supported(&it, 1, (int)TB)) RUN(K_MFN_ATT_FWD, lin_rows_launch(&it, 1, (int)TB, train, es.seed, s));
+      else RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
     }
   }
   {   // gamma gates + memory update for all T (mfm_model.py:177-181)
