@@ -25,11 +25,13 @@ int device_cus();
 
 // lin_rows.hip -- row-block linear layers C = epi(A W^T + bias) for few rows (the MFN attention block at small T*B): every
 // workgroup requests its whole 16 x k / 32 x k operand slices at once instead of walking K through a load ring.
-// kind / aux / p / op_id as GemmEpi (kinds 0, 1, 2).
+// kind / aux / p / op_id as GemmEpi (kinds 0-3).
 #define MFM_LINROWS_MAX 3
 struct LinRowsItem {
   const float* a; int lda; const float* w; int ldw; const float* bias; float* c; int ldc; int n, k;
   int kind; float* aux; float p; unsigned op_id;
+  int trans;          // 0: W[n, k] (forward), 1: Wt[k, n] -- C = A Wt, the input-gradient products of the backward
+  int accumulate;     // atomicAdd into C (kind 0 only)
 };
 bool lin_rows_supported(const LinRowsItem* items, int count, int M);
 int lin_rows_launch(const LinRowsItem* items, int count, int M, int train, unsigned long long seed, hipStream_t stream);

@@ -592,10 +592,10 @@ static int mfn_forward(MfmPlan* P, const float* params, int train, uint64_t seed
       d.m = (int)TB; d.n = n; d.n_valid = n; d.k = k; d.batch = 1; d.split_k = 1; d.alpha = 1.0f;
       return d;
     };
-    // fp32 plans with few rows (T*B <= 2560): the four forward products as row-block launches (lin_rows.hip: all operands of a
-    // workgroup requested at once, ~10 instead of ~16.5 us per launch at T*B = 640; profiles/r02_lin_rows.txt); bf16 plans,
-    // larger batches and MFM_LIN_ROWS=0 keep the grouped GEMM
-    long lr_max = 2560;
+    // fp32 plans with few rows (T*B <= 5120, the measured crossover): the four forward products as row-block launches
+    // (lin_rows.hip: all operands of a workgroup requested at once, 9.2 instead of 13.7 us per launch at T*B = 640;
+    // profiles/r02_lin_rows.txt); bf16 plans, larger batches and MFM_LIN_ROWS=0 keep the grouped GEMM
+    long lr_max = 5120;
     if (const char* e = getenv("MFM_LIN_ROWS_MAXROWS")) lr_max = atol(e);
     const bool lr_on = prec == 0 && TB <= lr_max && !(getenv("MFM_LIN_ROWS") && atoi(getenv("MFM_LIN_ROWS")) == 0);
     auto rows = [&](const MfmGemmDesc& d, int kind, float* aux, float p, unsigned op_id) {
@@ -1005,29 +1005,48 @@ static int mfn_backward(MfmPlan* P, const float* params, float* W, float* grads,
     // one launch: dh2, d attended, softmax backward, dh1, d cStar and its scatter onto the LSTMs' dc (added into the zero block)
     RUN(K_MFN_ATT_BWD, mfn_att_fused_bwd_launch(F, s));
   } else {
+    // fp32 plans with few rows: the four input-gradient products as row-block launches too (lin_rows.hip, trans = 1)
+    long lr_max = 5120;
+    if (const char* e = getenv("MFM_LIN_ROWS_MAXROWS")) lr_max = atol(e);
+    const bool lr_on = prec == 0 && TB <= lr_max && !(getenv("MFM_LIN_ROWS") && atoi(getenv("MFM_LIN_ROWS")) == 0);
+    auto rows = [&](const MfmGemmDesc& d, int kind, float* aux) {
+      LinRowsItem it;
+      memset(&it, 0, sizeof(it));
+      it.a = d.a; it.lda = (int)d.a_sm; it.w = d.b; it.ldw = (int)d.b_sk; it.c = d.c; it.ldc = (int)d.ldc;
+      it.n = d.n; it.k = d.k; it.kind = kind; it.aux = aux; it.trans = 1; it.accumulate = d.accumulate;
+      return it;
+    };
     {   // dh2 = d(pre cHat) W_att2_fc2, times the relu / dropout mask of att2_fc1's output
       MfmGemmDesc g = nn(W + P->dchat, M, M, PW(P, params, pi.att2_2), c.nn2, c.nn2, W + P->dh2, c.nn2, TB, 0);
       GemmEpi e = {W + P->m2, 0.0f, 3, 0u, 0};
+      LinRowsItem it = rows(g, 3, e.aux);
       es.epi = &e; es.count = 1;
-      RUN(K_MFN_ATT_BWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
+      if (lr_on && lin_rows_supported(&it, 1, (int)TB)) RUN(K_MFN_ATT_BWD, lin_rows_launch(&it, 1, (int)TB, 1, 0ull, s));
+      else RUN(K_MFN_ATT_BWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
     }
     {   // d attended = dh2 W_att2_fc1 + du1 W_gamma1_fc1[:, :A2] + du2 W_gamma2_fc1[:, :A2]   (into the zero-filled buffer)
       MfmGemmDesc g[3];
       g[0] = nn(W + P->dh2, c.nn2, c.nn2, PW(P, params, pi.att2_1), A2, A2, W + P->datt, A2, TB, 1);
       g[1] = nn(W + P->du1, c.g1, c.g1, PW(P, params, pi.g1_1), A2 + M, A2, W + P->datt, A2, TB, 1);
       g[2] = nn(W + P->du2, c.g2, c.g2, PW(P, params, pi.g2_1), A2 + M, A2, W + P->datt, A2, TB, 1);
-      RUN(K_MFN_ATT_BWD, gemm_group_launch(g, 3, s, nullptr, nullptr, 0, prec));
+      LinRowsItem it[3] = {rows(g[0], 0, nullptr), rows(g[1], 0, nullptr), rows(g[2], 0, nullptr)};
+      if (lr_on && lin_rows_supported(it, 3, (int)TB)) RUN(K_MFN_ATT_BWD, lin_rows_launch(it, 3, (int)TB, 1, 0ull, s));
+      else RUN(K_MFN_ATT_BWD, gemm_group_launch(g, 3, s, nullptr, nullptr, 0, prec));
     }
     RUN(K_MFN_GLUE, mfn_softmax_bwd_launch(W + P->datt, W + P->att, W + P->cstar, W + P->dlog, W + P->dcs, TB, A2, s));
     {   // dh1 = d logits W_att1_fc2, times the mask of att1_fc1's output
       MfmGemmDesc g = nn(W + P->dlog, A2, A2, PW(P, params, pi.att1_2), c.nn1, c.nn1, W + P->dh1, c.nn1, TB, 0);
       GemmEpi e = {W + P->m1, 0.0f, 3, 0u, 0};
+      LinRowsItem it = rows(g, 3, e.aux);
       es.epi = &e; es.count = 1;
-      RUN(K_MFN_ATT_BWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
+      if (lr_on && lin_rows_supported(&it, 1, (int)TB)) RUN(K_MFN_ATT_BWD, lin_rows_launch(&it, 1, (int)TB, 1, 0ull, s));
+      else RUN(K_MFN_ATT_BWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
     }
     {   // d cStar += dh1 W_att1_fc1   (on top of the softmax kernel's d attended * attention)
       MfmGemmDesc g = nn(W + P->dh1, c.nn1, c.nn1, PW(P, params, pi.att1_1), A2, A2, W + P->dcs, A2, TB, 1);
-      RUN(K_MFN_ATT_BWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec));
+      LinRowsItem it = rows(g, 0, nullptr);
+      if (lr_on && lin_rows_supported(&it, 1, (int)TB)) RUN(K_MFN_ATT_BWD, lin_rows_launch(&it, 1, (int)TB, 1, 0ull, s));
+      else RUN(K_MFN_ATT_BWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec));
     }
     {   // d cStar -> d c_t of the three LSTMs
       MfnCs cs;

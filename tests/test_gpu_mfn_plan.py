@@ -46,7 +46,7 @@ def _oracle(variant, cfgs, w, gauss=None):
 @pytest.fixture(params=["att-fused", "att-rows", "att-gemm", "heads-gemm"], autouse=True)
 def att_path(request, monkeypatch):
     """Every test of this file runs on every form of the MFN attention block: the row-block forward launches (lin_rows_kernel,
-    the fp32 default up to T*B = 2560, forced here for any row count: "att-rows"), the grouped GEMMs + row kernels
+    the fp32 default up to T*B = 5120, forced here for any row count: "att-rows"), the grouped GEMMs + row kernels
     ("att-gemm": MFM_LIN_ROWS=0) and mfn_att_fwd_kernel / mfn_att_bwd_kernel (one launch per direction with every
     intermediate in LDS; opt-in with MFM_MFN_FUSED=1 because it measured slower, forced here for any row count)."""
     if request.param == "att-rows":
