@@ -7,7 +7,6 @@
 namespace mfm {
 
 #define MFM_GEMM_NEPI 4     // problems per launch that may carry an output transform (always the first ones)
-#define MFM_GEMM_MAXP 56   // problems per launch (the descriptors travel in the kernel-argument segment, ~9.6 KB)
 
 struct GemmProblem {
   MfmGemmDesc d;

@@ -1244,8 +1244,19 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
         dA_gemms(P, P->dec[m], P->dec_p[m], W, grads, tail, W + P->dec_init[m], P->dec_h[m], P->dec_h[m], true, op);
       }
     if (DL.n_items > 0) RUN(K_DEC_DW, dw_onepass_launch(DL, c.precision, s));
-    RUN(K_ENC_DW, c.precision ? mfm_gemm_grouped_bf16(tail.data(), (int)tail.size(), s)
-                                : mfm_gemm_grouped_f32(tail.data(), (int)tail.size(), s));
+    // fp32 plans at small T*B: the chunked kernel (gemm_tn.hip: one load round trip per workgroup instead of a 20-step ring;
+    // profiles/r02_gemm_tn.txt); MFM_GEMM_TN=0 / larger row counts / bf16 plans: the grouped GEMM
+    long tn_rows = 1024;         // measured crossover: 640 rows 21.7 vs 24.8 us, 1280 rows equal, 2560 rows 67 vs 59 us
+    if (const char* e = getenv("MFM_GEMM_TN_MAXROWS")) tn_rows = atol(e);
+    const bool tn_on = !c.precision && !(getenv("MFM_GEMM_TN") && atoi(getenv("MFM_GEMM_TN")) == 0);
+    const int ntail = (int)tail.size();
+    for (int done = 0; done < ntail; done += MFM_GEMM_MAXP) {
+      const int cnt = std::min(ntail - done, (int)MFM_GEMM_MAXP);
+      const MfmGemmDesc* td = tail.data() + done;
+      // (the gradient buffer was cleared at the start of the step, so the tail's non-accumulating products may add)
+      if (tn_on && gemm_tn_supported(td, cnt, (int)std::min(tn_rows, (long)INT32_MAX), true)) RUN(K_ENC_DW, gemm_tn_launch(td, cnt, (int)std::min(tn_rows, (long)INT32_MAX), true, s));
+      else RUN(K_ENC_DW, c.precision ? mfm_gemm_grouped_bf16(td, cnt, s) : mfm_gemm_grouped_f32(td, cnt, s));
+    }
   }
   return MFM_OK;
 }

@@ -12,6 +12,8 @@ B > 512 ran on kernels no oracle comparison reached).  Kernels named here, by th
   dec_fc1_kernel                                       decoder fc1 + squared error + dH in one launch: fp32, T*B <= 5120 (default at
                                                        the golden sizes; MFM_FC1_FUSED=0 -> the two GEMM launches)
   dw_onepass_kernel<false|true>                        LSTM weight gradients, one pass over dA: opt-in, MFM_DW_ONEPASS_MINROWS=1
+  gemm_tn_kernel<160>                                  all weight gradients as (tile, 160-row chunk) workgroups: fp32, T*B <= 1024
+                                                       (MFM_GEMM_TN_MAXROWS; MFM_GEMM_TN=0 -> grouped GEMM)
   gemm_panel_kernel<false|true, wave grid>             row-panel projection GEMM: T*B >= 2 rounds of panels (B >= 1639 fp32
                                                        at T=20), or MFM_PANEL_MINROWS=1; panel height 64 / 80 rows (fp32),
                                                        128 / 160 / 96 (bf16) picked per launch, MFM_PANEL_BM forces one
@@ -130,7 +132,7 @@ def test_you_shape_large_batch_matches_oracle(monkeypatch):
 
 
 @pytest.mark.parametrize("variant", ["staged", "fr2", "fr4", "panel", "panel80", "staged+fr2+mfma", "fc1gemm", "dwonepass",
-                                     "nochains", "latpre", "nofold"])
+                                     "nochains", "latpre", "nofold", "dwgemm", "dwtn"])
 @pytest.mark.parametrize("name", cases.KLEF_CASES)
 def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
     """The same kernels forced onto every golden case (B = 1 .. 229, ragged sizes, T = 1, CE and 7-output heads):
@@ -168,6 +170,14 @@ def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
         monkeypatch.setenv("MFM_DW_ONEPASS_MINROWS", "1")   # dw_onepass_kernel<false>: the LSTM weight gradients in one pass
     else:                                                   # over dA (opt-in: measured slower than the GEMMs)
         monkeypatch.delenv("MFM_DW_ONEPASS_MINROWS", raising=False)
+    # weight gradients: gemm_tn_kernel (row chunks, all operands requested at once) is the default up to T*B = 1024;
+    # "dwtn" forces it at every size (T*B up to 4580 here: 29 chunks), "dwgemm" the grouped GEMM at every size
+    for k in ("MFM_GEMM_TN", "MFM_GEMM_TN_MAXROWS"):
+        monkeypatch.delenv(k, raising=False)
+    if variant == "dwgemm":
+        monkeypatch.setenv("MFM_GEMM_TN", "0")
+    if variant == "dwtn":
+        monkeypatch.setenv("MFM_GEMM_TN_MAXROWS", "100000000")
     if "panel" in variant:
         monkeypatch.setenv("MFM_PANEL_MINROWS", "1")    # gemm_panel_kernel<false, ..>: the large-batch projection kernel
     else:
