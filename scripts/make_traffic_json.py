@@ -8,12 +8,13 @@ read  = 2 x FETCH_SIZE KiB (on gfx950 FETCH_SIZE counts 128-B requests as 64 B: 
 write = WRITE_SIZE KiB (uncalibrated)
 The grouped-GEMM launches of a step share one kernel symbol; they are told apart by their position between two Adam
 launches (plan.hip issues them in a fixed order): four per step when decoder fc1 runs as GEMMs, two (projection, weight
-gradients) when the fused dec_fc1_kernel takes fc1 + squared error + dH (the default up to 5120 rows)."""
+gradients) when the fused dec_fc1_kernel takes fc1 + squared error + dH (the default up to 5120 rows), one (projection) when
+the weight gradients run on gemm_tn_kernel (T*B <= 1024)."""
 import json
 import sqlite3
 import sys
 
-GEMM_ORDER = {4: ["proj_gemm", "fc1_mse_gemm", "fc1_bwd_gemm", "dw_gemm"], 2: ["proj_gemm", "dw_gemm"]}
+GEMM_ORDER = {4: ["proj_gemm", "fc1_mse_gemm", "fc1_bwd_gemm", "dw_gemm"], 2: ["proj_gemm", "dw_gemm"], 1: ["proj_gemm"]}
 
 
 def classify(name):
@@ -29,6 +30,8 @@ def classify(name):
         return "latent_fwd"
     if "latent_bwd" in name:
         return "latent_bwd"
+    if "gemm_tn_kernel" in name:       # the weight gradients at T*B <= 1024 (gemm_tn.hip): then the only grouped GEMM of a step
+        return "dw_gemm"               # is the projection launch
     if "gemm_f32_kernel" in name:
         return "gemm"
     if "dec_fc1_kernel" in name:
