@@ -44,6 +44,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmGroup g) {
   const GemmProblem& P = g.p[pi];
   const MfmGemmDesc& d = P.d;
   int local = bid - P.block_begin;
+  {
+    // workgroups go to the 8 XCDs round-robin by id and every XCD has its own L2: give each XCD one contiguous run of a
+    // problem's logical (chunk, tile) order, as gemm.hip does, so that the tiles sharing an operand slice meet in one L2
+    // (without it the launch pulled 45 MB through the fabric for ~8 MB of operands)
+    constexpr int NX = 8;
+    const int nb = ((pi + 1 < g.count) ? g.begins[pi + 1] : (int)gridDim.x) - P.block_begin;
+    const int x = local % NX, j = local / NX;
+    const int per = nb / NX, rem = nb % NX;
+    local = x * per + (x < rem ? x : rem) + j;
+  }
   const int tn = local % P.tiles_n; local /= P.tiles_n;
   const int tm = local % P.tiles_m; local /= P.tiles_m;
   const int z = local % d.batch;
