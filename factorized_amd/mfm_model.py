@@ -70,10 +70,13 @@ class _MMDFn(torch.autograd.Function):
 def loss_MMD(zy, gauss=None):
     """MMD between zy and a N(0,1) sample of the same shape -- mfm_model.py:25-34.  The reference
     draws the sample on the host; pass `gauss` to inject it (parity tests)."""
+    _require_cuda(zy, "loss_MMD")          # like every op of this package: no CPU path
     if gauss is None:
         gauss = torch.randn(zy.size(), device=zy.device, dtype=zy.dtype)
-    if zy.is_cuda and zy.dim() == 2 and zy.shape[1] <= 256:
+    if zy.dim() == 2 and zy.shape[1] <= 256:
         return _MMDFn.apply(zy, gauss)
+    # feature dimensions above the kernel's register budget (256; the reference's z sizes are 8..80) and inputs that are not
+    # [B, dim]: the reference's own composition of device ops (tests/test_gpu_ops.py::test_mmd_wide_features_device_ops)
     return compute_kernel(gauss, gauss).mean() + compute_kernel(zy, zy).mean() \
         - 2.0 * compute_kernel(gauss, zy).mean()
 

@@ -385,6 +385,32 @@ def test_mfn_memory_dropout_statistics(eng):
 
 
 # ---------------------------------------------------------------------------------- MMD
+def test_mmd_wide_features_device_ops(eng):
+    """dim > 256 is outside mmd_kernel's register budget: loss_MMD then composes the reference's formula from device ops
+    (never the CPU); value and gradient against float64.  A CPU tensor raises like every other op of the package."""
+    from factorized_amd.mfm_model import loss_MMD
+    from factorized_amd import _lib
+    rs = np.random.RandomState(77)
+    B, dim = 24, 300
+    zn = rs.normal(size=(B, dim)).astype(np.float32) * 1.1
+    gn = rs.normal(size=(B, dim)).astype(np.float32)
+
+    def ck(x, y):
+        return torch.exp(-((x.unsqueeze(1) - y.unsqueeze(0)) ** 2).mean(2) / float(dim))
+    zr = torch.tensor(zn, dtype=torch.float64, requires_grad=True)
+    gr = torch.tensor(gn, dtype=torch.float64)
+    ref = ck(gr, gr).mean() + ck(zr, zr).mean() - 2.0 * ck(gr, zr).mean()
+    ref.backward()
+    zd = torch.tensor(zn, device="cuda", requires_grad=True)
+    out = loss_MMD(zd, torch.tensor(gn, device="cuda"))
+    assert out.is_cuda
+    out.backward()
+    assert abs(out.item() - ref.item()) <= TOL * max(abs(ref.item()), 1e-3)
+    assert rel_err(zd.grad.cpu().numpy(), zr.grad.numpy()) < 10 * TOL
+    with pytest.raises(_lib.MfmError):
+        loss_MMD(torch.tensor(zn), torch.tensor(gn))
+
+
 @pytest.mark.parametrize("rows", ["auto", "8", "32"])
 @pytest.mark.parametrize("B,dim", [(32, 32), (19, 80), (100, 8), (64, 256), (1, 16), (33, 5), (300, 24)])
 def test_mmd_matches_reference_formula(eng, B, dim, rows, monkeypatch):

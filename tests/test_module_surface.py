@@ -48,7 +48,12 @@ def test_loss_helpers_match_oracle():
     mu, lv = torch.randn(7, 5, generator=g), torch.randn(7, 5, generator=g)
     assert torch.allclose(M.loss_KLD(mu, lv), O.kld_sum(mu, lv))
     z, gs = torch.randn(6, 4, generator=g), torch.randn(6, 4, generator=g)
-    assert torch.allclose(M.loss_MMD(z, gs), O.mmd(z, gs))
+    # loss_MMD itself is a HIP op (mmd_kernel) and refuses CPU tensors; its formula helper is the reference's compute_kernel
+    mmd = M.compute_kernel(gs, gs).mean() + M.compute_kernel(z, z).mean() - 2.0 * M.compute_kernel(gs, z).mean()
+    assert torch.allclose(mmd, O.mmd(z, gs))
+    with pytest.raises(Exception) as ei:
+        M.loss_MMD(z, gs)
+    assert "no CPU fallback" in str(ei.value)
 
 
 def test_ablation_and_missing_modality_classes_keep_reference_state_dict():
