@@ -132,7 +132,7 @@ def test_fused_mfn_plan_training_trajectory_matches_reference(name):
     trace, ref = np.array(trace), gold["trace"]
     terr = float(np.max(np.abs(trace - ref) / np.maximum(np.abs(ref), 1e-2)))
     cases.report("mfn_plan_trace_rel_%s" % name, terr)
-    assert terr < 5 * TOL, (trace[-1], ref[-1])
+    assert terr < 0.5 * TOL, (trace[-1], ref[-1])        # measured worst 1.3e-5 (MMD variant), profiles/r02_parity_worst.jsonl
     ok = ~np.isnan(gold["grad_summary"][:, 0])          # parameters that receive a gradient
     scale1 = np.maximum(np.abs(gold["param_after1"][:, :1]), 1e-3)
     e1 = float(np.max((np.abs(p1 - gold["param_after1"]) / scale1)[ok]))
@@ -141,7 +141,7 @@ def test_fused_mfn_plan_training_trajectory_matches_reference(name):
     el = float(np.max((np.abs(pl - gold["param_after_last"]) / scale)[ok]))
     cases.report("mfn_plan_param_after1_rel_%s" % name, e1)
     cases.report("mfn_plan_param_after_last_rel_%s" % name, el)
-    assert e1 < 5 * TOL and el < 20 * TOL, (e1, el)
+    assert e1 < 0.25 * TOL and el < 0.25 * TOL, (e1, el)      # measured worst 6.7e-6 / 6.8e-6
     # the unused MFN output layers never move (torch.optim.Adam skips parameters without a gradient)
     pv = e.param_views()
     w0 = synth.make_weights(e.layout.shapes, seed=1234)
