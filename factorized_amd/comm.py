@@ -97,6 +97,9 @@ class P2PAllReduce:
 
     def allreduce_adam(self, e, lr, grad_scale):
         """All-reduce of e.grads and the flat Adam update of e.params in the same launch."""
+        check = getattr(e, "_require_uniform_steps", None)
+        if check is not None:
+            check("P2PAllReduce.allreduce_adam")      # one bias-correction step for all tensors: refuse after staged steps
         e.step_count += 1
         gs = getattr(e, "group_steps", None)
         if gs:

@@ -14,7 +14,7 @@ CMU-MultimodalSDK word-level alignment exports) and the model input, with the re
   * X = concat(word embedding, acoustic, visual) along the feature axis (mfm_mosi.py:108-125), then
     `swapaxes(0, 1)` to time-major `[T, N, D]` (mfm_mosi.py:391-393).
 
-`load_aligned(path)` reads an .npz with per-split arrays (see its docstring); `train.DeviceDataset.from_arrays` puts the
+`save_aligned` / `load_aligned` write / read a pickle-free .npz of such segments (concatenated arrays + offsets); `train.DeviceDataset.from_arrays` puts the
 result into HBM in the `[nb, T, B, D]` batch layout of the fused step.
 """
 import numpy as np
@@ -75,12 +75,31 @@ def build_splits(splits, max_len, acoustic_cols=slice(1, 35)):
     return {name: (assemble(t, a, v, scale, acoustic_cols), y, ln) for name, (t, a, v, y, ln) in padded.items()}
 
 
+def save_aligned(path, splits):
+    """Write word-aligned segments in the pickle-free layout `load_aligned` reads: per split and modality ONE
+    concatenated array `<split>_<modality>` [sum(len_i), d] plus `<split>_offsets` [N + 1] (segment i = rows
+    offsets[i]:offsets[i+1] of all three modalities -- they are aligned word by word) and `<split>_label` [N]."""
+    blob = {}
+    for name, sp in splits.items():
+        lens = [int(np.asarray(s).shape[0]) for s in sp["text"]]
+        blob[name + "_offsets"] = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        for k in ("text", "acoustic", "visual"):
+            assert [int(np.asarray(s).shape[0]) for s in sp[k]] == lens, "modalities must be aligned word by word"
+            blob["%s_%s" % (name, k)] = np.concatenate([np.asarray(s, dtype=np.float32) for s in sp[k]], axis=0)
+        blob[name + "_label"] = np.asarray(sp["label"], dtype=np.float32)
+    np.savez(path, **blob)
+
+
 def load_aligned(path, max_len, acoustic_cols=slice(1, 35)):
-    """Read an .npz of word-aligned segments: for split in train/valid/test the object arrays `<split>_text`,
-    `<split>_acoustic`, `<split>_visual` (one [len_i, d] array per segment) and `<split>_label` [N]."""
-    z = np.load(path, allow_pickle=True)
+    """Read an .npz of word-aligned segments written by `save_aligned` (plain numeric arrays: concatenated segments +
+    offsets).  Loaded with allow_pickle=False -- a dataset file cannot execute code."""
+    z = np.load(path, allow_pickle=False)
     splits = {}
     for name in ("train", "valid", "test"):
-        splits[name] = dict(text=list(z[name + "_text"]), acoustic=list(z[name + "_acoustic"]),
-                            visual=list(z[name + "_visual"]), label=z[name + "_label"])
+        off = z[name + "_offsets"]
+        sp = {"label": z[name + "_label"]}
+        for k in ("text", "acoustic", "visual"):
+            flat = z["%s_%s" % (name, k)]
+            sp[k] = [flat[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+        splits[name] = sp
     return build_splits(splits, max_len, acoustic_cols)

@@ -440,7 +440,14 @@ class MFMEngine:
         """forward(train) + backward + Adam, one enqueue.  stage 0 = the joint loss of train_mfm
         (mfm_mosi.py:439); 1 = gen + reg, 2 = disc + reg (train_beta_vae, mfm_mosi.py:278-281), with Adam
         skipping the tensors the stage loss does not reach (`staged_adam`).  Returns the device tensor of loss
-        slots (no sync)."""
+        slots (no sync).
+
+        Caveat on staged runs: the default `staged_adam = "frozen"` reproduces the reference code on torch >= 2
+        (`zero_grad()` sets .grad to None, Adam skips the parameter).  The reference was written for PyTorch 0.4,
+        whose `zero_grad()` left zero tensors behind: there the decoders and the modality z->f MLPs keep moving in
+        stage 2 on their decaying first moment and their step counters keep advancing.  `staged_adam = "legacy"`
+        (driver flag --legacy-adam) is that behaviour; both are pinned to trajectories of the reference itself
+        (tests/golden/*_staged_*.npz: `frozen_*` from zero_grad(set_to_none=True), `legacy_*` from set_to_none=False)."""
         if check:
             self._check_inputs(x, y)
         T, B, _ = x.shape
@@ -489,7 +496,18 @@ class MFMEngine:
                    "mfm_plan_grad_step")
         return p.losses
 
+    def _require_uniform_steps(self, what):
+        """The flat Adam launches use ONE bias-correction step for every tensor.  After staged steps the per-group
+        counters differ (torch.optim.Adam counts per parameter): continuing with a flat update would silently jump
+        the gen / disc groups' step, so it is refused -- staged training goes through train_step(stage=...)."""
+        gs = self.group_steps
+        if not (gs["shared"] == gs["gen"] == gs["disc"] == self.step_count):
+            raise _lib.MfmError("%s: the Adam step counters of the tensor groups differ (%s, step_count %d) after "
+                                "staged training; the flat / data-parallel Adam update has one counter -- use "
+                                "train_step(stage=...)" % (what, dict(gs), self.step_count))
+
     def adam(self, lr=1e-3, grad_scale=1.0):
+        self._require_uniform_steps("MFMEngine.adam")
         self.step_count += 1
         for g in self.group_steps:
             self.group_steps[g] = self.step_count

@@ -80,7 +80,10 @@ class DataParallelStep:
                 engine.seed = int(engine.seed) + 7919 * r
         self.allreduce = allreduce            # comm.make_allreduce(...); default torch.distributed (RCCL)
         if world > 1:
-            engine.reg_scale = float(world)
+            # the KLD is a batch SUM (scaled by W so that the averaged gradient equals the global-batch one); the MMD
+            # regulariser of `MFM` is a statistic of the shard it is computed on: the data-parallel objective uses the
+            # mean over ranks of the shard-local MMDs, i.e. no extra factor
+            engine.reg_scale = 1.0 if getattr(engine, "variant", "kl_ef") == "mmd" else float(world)
             if allreduce is None:
                 from . import comm
                 self.allreduce = comm.TorchAllReduce()

@@ -59,7 +59,10 @@ def main():
     if args.legacy_adam:
         eng.staged_adam = "legacy"
     lr = 1e-3
-    best, bad, factor, patience = 999999.0, 0, 0.1, 10     # ReduceLROnPlateau('min') defaults
+    best = 999999.0                                        # best-valid rule of the checkpoint (:473; per stage :348)
+    # ReduceLROnPlateau(optimizer, 'min') defaults (:253, :417; stepped at :341 / :351 / :472): its OWN best value and
+    # bad-epoch counter, kept across both stages; "better" = below best * (1 - 1e-4)
+    sched_best, bad, factor, patience = float("inf"), 0, 0.1, 10
     bs = cfg["batchsize"]
     nb = Xtr.shape[1] // bs                                # floor division: the tail is dropped (:423)
     Xd = torch.from_numpy(np.ascontiguousarray(Xtr[:, :nb * bs].reshape(T, nb, bs, -1).transpose(1, 0, 2, 3))).to(dev)
@@ -84,8 +87,8 @@ def main():
         model.eval()
         out = eng.forward(xv, yv, train=False, want_xhat=False)
         valid_loss = eng.loss_dict(out["losses"])["disc"]
-        if valid_loss < best * (1 - 1e-4):
-            bad = 0
+        if valid_loss < sched_best * (1 - 1e-4):
+            sched_best, bad = valid_loss, 0
         else:
             bad += 1
             if bad > patience:

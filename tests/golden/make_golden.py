@@ -147,9 +147,12 @@ def run_case(name, variant, cfg_fn, overrides, B, T, steps, light=False):
           "bytes=%d" % os.path.getsize(os.path.join(HERE, name + ".npz")))
 
 
-def run_staged(name, B, T, n1, n2):
+def run_staged(name, B, T, n1, n2, variant="kl_ef"):
     """train_beta_vae's schedule (mfm_mosi.py:238-239, 278-284, 346-358): ONE Adam optimizer, `n1` steps on
-    gen + reg (stage 1), then `n2` steps on disc + reg (stage 2), on the reference MFM_KL_EF.  Two traces:
+    gen + reg (stage 1), then `n2` steps on disc + reg (stage 2), on the reference MFM_KL_EF (or, round 3, on
+    MFM_KL / MFM: the stage masks then also cover the Memory Fusion Network's tensors; MFM's loss_MMD sample is a
+    stored seeded sequence as in run_case).  Also stored: the gradient summaries of the first step of each stage
+    (NaN rows = parameters the stage loss does not reach).  Two traces:
     'frozen' with this torch's zero_grad (sets .grad to None -> Adam skips parameters the stage loss does not
     reach) and 'legacy' with zero_grad(set_to_none=False), which is what the reference's PyTorch 0.4 did (a
     zero gradient keeps the parameter moving on its decaying first moment)."""
@@ -158,8 +161,26 @@ def run_staged(name, B, T, n1, n2):
     xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7)
     x, y = torch.from_numpy(xn), torch.from_numpy(yn)
     out = {}
+    gauss = None
+    if variant == "mmd":
+        rs = np.random.RandomState(99)
+        sizes = [cfg["zl_size"], cfg["za_size"], cfg["zv_size"], cfg["zy_size"]]
+        gauss = [torch.from_numpy(rs.normal(size=(B, s)).astype(np.float32)) for s in sizes]
+        out["mmd_gauss"] = np.concatenate([g.numpy() for g in gauss], axis=1)
+
+    def losses_of(model):
+        if gauss is None:
+            return ref_losses(model, x, y, cfg, "l1")
+        it = iter(gauss)
+        orig = torch.randn
+        torch.randn = lambda *a, **k: next(it)     # loss_MMD's sample (mfm_model.py:26)
+        try:
+            return ref_losses(model, x, y, cfg, "l1")
+        finally:
+            torch.randn = orig
+
     for mode in ("frozen", "legacy"):
-        model = REF.MFM_KL_EF(*cfgs)
+        model = REF_CLASS[variant](*cfgs)
         shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
         w = synth.make_weights(shapes, seed=1234)
         model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()})
@@ -169,10 +190,14 @@ def run_staged(name, B, T, n1, n2):
         for s in range(n1 + n2):
             stage = 1 if s < n1 else 2
             opt.zero_grad(set_to_none=(mode == "frozen"))
-            terms, _ = ref_losses(model, x, y, cfg, "l1")
+            terms, _ = losses_of(model)
             reg = cfg["lda_mmd"] * terms["reg"]
             loss = terms["gen"] + reg if stage == 1 else terms["disc"] + reg      # mfm_mosi.py:278-281
             loss.backward()
+            if mode == "frozen" and s in (0, n1):
+                out["grad_summary_stage%d" % stage] = np.stack([
+                    summarize(p.grad) if p.grad is not None else np.full(10, np.nan)
+                    for _, p in model.named_parameters()])
             opt.step()
             trace.append([loss.item(), terms["disc"].item(), terms["gen"].item(), terms["reg"].item()])
             if s == n1 - 1:
@@ -233,7 +258,8 @@ def run_extra(name, B=12, T=6):
           "bytes=%d" % os.path.getsize(os.path.join(HERE, "extra_%s.npz" % name)))
 
 
-STAGED = [("klef_staged_b32_t20", 32, 20, 4, 4)]
+STAGED = [("klef_staged_b32_t20", 32, 20, 4, 4, "kl_ef"), ("kl_staged_b32_t20", 32, 20, 4, 4, "kl"),
+          ("mmd_staged_b32_t20", 32, 20, 4, 4, "mmd")]
 # BASELINE config 4 (MOSEI shape, large batch): summaries + loss trace only
 LIGHT = [("klef_mosei_b1024_t20", "kl_ef", C.mosei_configs, {}, 1024, 20, 8)]
 

@@ -175,7 +175,7 @@ def test_mfn_based_models_match_reference(name):
         opt.step()
     ref_trace = gold["trace"][:, 0]
     cases.report("module_mfn_trace_rel_%s" % variant, np.max(np.abs(np.array(trace) - ref_trace) / np.abs(ref_trace)))
-    assert np.max(np.abs(np.array(trace) - ref_trace) / np.abs(ref_trace)) < 0.05 * TOL      # measured worst 2.6e-7
+    assert np.max(np.abs(np.array(trace) - ref_trace) / np.abs(ref_trace)) < 0.1 * TOL      # measured worst 2.6e-7 (bound ~40x that: atomics order + Adam)
 
 
 @pytest.mark.gpu

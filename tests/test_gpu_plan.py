@@ -202,16 +202,18 @@ def test_training_trajectory_matches_reference(name):
     trace = np.array(trace)
     ref = gold["trace"]
     cases.report("klef_trace_rel_%s" % name, np.max(np.abs(trace - ref) / np.maximum(np.abs(ref), 1e-2)))
-    # measured worst over the four cases and all runs of round 2: 7.2e-7 (profiles/r02_parity_worst.jsonl); bound = TOL / 10
+    # measured worst over the four cases and all runs of round 2: 7.2e-7 (profiles/r02_parity_worst.jsonl).  Bounds: >= 10x
+    # the measured worst cases (the weight gradients are summed with atomics in a run-dependent order and Adam amplifies
+    # the last-bit differences over the steps: a 3x margin would flake on another clock state / CU count)
     assert np.max(np.abs(trace - ref) / np.maximum(np.abs(ref), 1e-2)) < 0.1 * TOL, (trace[-1], ref[-1])
     assert np.max(np.abs(trace[0] - ref[0]) / np.maximum(np.abs(ref[0]), 1e-2)) < TOL
     scale1 = np.maximum(np.abs(gold["param_after1"][:, :1]), 1e-3)
-    assert np.max(np.abs(p1 - gold["param_after1"]) / scale1) < 0.1 * TOL        # measured worst 3.2e-6
+    assert np.max(np.abs(p1 - gold["param_after1"]) / scale1) < 0.5 * TOL        # measured worst 3.2e-6
     pl = np.stack([cases.summarize(v.cpu().numpy()) for v in e.param_views().values()])
     scale = np.maximum(np.abs(gold["param_after_last"][:, :1]), 1e-3)
     cases.report("klef_param_after1_rel_%s" % name, np.max(np.abs(p1 - gold["param_after1"]) / scale1))
     cases.report("klef_param_after_last_rel_%s" % name, np.max(np.abs(pl - gold["param_after_last"]) / scale))
-    assert np.max(np.abs(pl - gold["param_after_last"]) / scale) < 0.1 * TOL      # measured worst 3.3e-6
+    assert np.max(np.abs(pl - gold["param_after_last"]) / scale) < 0.5 * TOL      # measured worst 3.3e-6
 
 
 def test_full_size_properties():

@@ -82,19 +82,24 @@ def test_numpy_cell_gate_order():
     assert np.allclose(c1.detach().numpy(), c2, atol=1e-6)
 
 
+@pytest.mark.parametrize("variant,gname", [("kl_ef", "klef_staged_b32_t20"), ("kl", "kl_staged_b32_t20"),
+                                           ("mmd", "mmd_staged_b32_t20")])
 @pytest.mark.parametrize("mode", ["frozen", "legacy"])
-def test_oracle_staged_training_matches_reference(mode):
+def test_oracle_staged_training_matches_reference(mode, variant, gname):
     """train_beta_vae's two-stage schedule on the oracle vs the reference's own trajectory (run_staged in
-    tests/golden/make_golden.py): pins oracle.stage_loss and both zero_grad semantics."""
+    tests/golden/make_golden.py): pins oracle.stage_loss and both zero_grad semantics, for all three classes."""
     torch.set_num_threads(1)
-    gold = np.load(cases.GOLDEN + "/klef_staged_b32_t20.npz")
+    gold = np.load(cases.GOLDEN + "/%s.npz" % gname)
     B, T, n1, n2 = (int(v) for v in gold["meta"])
     from factorized_amd import configs
     cfgs = configs.canonical_configs(dropout=False)
     cfg = cfgs[0]
-    model = O.build("kl_ef", cfgs)
+    model = O.build(variant, cfgs)
     O.load_numpy_weights(model, synth.make_weights(O.state_shapes(model), seed=1234))
     model.train()
+    if variant == "mmd":
+        g = torch.from_numpy(np.ascontiguousarray(gold["mmd_gauss"]))
+        model.mmd_gauss = list(torch.split(g, [cfg["zl_size"], cfg["za_size"], cfg["zv_size"], cfg["zy_size"]], dim=1))
     xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7)
     x, y = torch.from_numpy(xn), torch.from_numpy(yn)
     opt = torch.optim.Adam(model.parameters())
@@ -105,6 +110,12 @@ def test_oracle_staged_training_matches_reference(mode):
         terms = O.loss_terms(model, x, y, cfg)
         loss = O.stage_loss(terms, cfg, stage)
         loss.backward()
+        if mode == "frozen" and s in (0, n1):        # gradients of the first step of each stage; NaN rows = .grad is None
+            gs = gold["grad_summary_stage%d" % stage]
+            for i, p in enumerate(model.parameters()):
+                assert (p.grad is None) == bool(np.isnan(gs[i, 0])), (stage, i)
+                if p.grad is not None:
+                    assert np.allclose(cases.summarize(p.grad.numpy()), gs[i], rtol=2e-4, atol=2e-6), (stage, i)
         opt.step()
         trace.append([loss.item(), terms["disc"].item(), terms["gen"].item(), terms["reg"].item()])
         if s == n1 - 1:
