@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
                 ("c_sz", C.c_int64), ("ldc", C.c_int64), ("bias_sz", C.c_int64),
                 ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("n_valid", C.c_int32),
                 ("batch", C.c_int32), ("split_k", C.c_int32), ("accumulate", C.c_int32),
-                ("alpha", C.c_float)]
+                ("alpha", C.c_float), ("a_bf16", C.c_int32), ("c_bf16", C.c_int32), ("reserved_", C.c_int32 * 2)]
 
 
 class SeqDesc(C.Structure):
@@ -35,7 +35,8 @@ class SeqDesc(C.Structure):
                 ("h_init", C.c_void_p), ("ld_init", C.c_int64),
                 ("dh_ext", C.c_void_p), ("ld_dh", C.c_int64),
                 ("d_h_init", C.c_void_p), ("ld_dinit", C.c_int64),
-                ("h", C.c_int32), ("is_dec", C.c_int32), ("dc_ext", C.c_void_p), ("w_pack", C.c_void_p)]
+                ("h", C.c_int32), ("is_dec", C.c_int32), ("dc_ext", C.c_void_p), ("w_pack", C.c_void_p),
+                ("store_bf16", C.c_int32), ("reserved2_", C.c_int32), ("h_last", C.c_void_p)]
 
 
 class MemDesc(C.Structure):
@@ -156,8 +157,8 @@ def lib():
             fn = getattr(L, name)   # AttributeError if the ABI and the binding drift apart
             fn.restype = res
             fn.argtypes = args
-        if L.mfm_abi_version() != 1:
-            raise MfmError("libmfm_hip.so ABI version %d, binding expects 1" % L.mfm_abi_version())
+        if L.mfm_abi_version() != 2:
+            raise MfmError("libmfm_hip.so ABI version %d, binding expects 2" % L.mfm_abi_version())
         _lib = L
     return _lib
 

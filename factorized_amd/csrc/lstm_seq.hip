@@ -390,7 +390,10 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     if (s.is_dec) MFM_REQUIRE(s.w_ih && s.b_ih && s.b_hh && s.h_init, "lstm_seq[%d]: decoder needs w_ih/b/h_init", i);
     if (bwd) MFM_REQUIRE(s.dh_ext, "lstm_seq_bwd[%d]: dh_ext is null", i);
     const bool force = getenv("MFM_SEQ_STEPWISE") != nullptr;          // testing: every LSTM step by step
-    if (s.h > MFM_SEQ_MAX_RESIDENT_H || force) wide[nwide++] = s; else descs[count++] = s;
+    if (s.h > MFM_SEQ_MAX_RESIDENT_H || force) {
+      MFM_REQUIRE(!s.store_bf16 && !s.h_last, "lstm_seq[%d]: h = %d takes the step-by-step fp32 path, which has no bf16-resident form", i, s.h);
+      wide[nwide++] = s;
+    } else descs[count++] = s;
   }
   if (fold && (nwide || bf16 || !use_small_path(B))) return MFM_ERR_UNSUPPORTED;
   if (nwide) {
@@ -420,6 +423,9 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     d.d_h_init = s.d_h_init; d.ld_dinit = s.ld_dinit;
     d.dc_ext = s.dc_ext;
     d.w_pack = bf16 ? s.w_pack : nullptr;
+    d.h_last = bf16 ? s.h_last : nullptr;
+    d.store_bf16 = s.store_bf16;
+    MFM_REQUIRE(bf16 || (!s.store_bf16 && !s.h_last), "lstm_seq[%d]: store_bf16 / h_last are taken by the bf16 entry points only", i);
     d.h = s.h; d.Hp = round_up(s.h, 16);
     d.hk4 = round_up(cdiv(s.h, 4), 2);
     d.is_dec = s.is_dec;

@@ -59,11 +59,34 @@ __device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, int off) {
 __device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, int off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
 }
+// bf16-resident buffers (SeqDev::store_bf16): the same four values travel as 8 bytes; ST selects the element type, `off`
+// is a BYTE offset in both forms
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <bool ST>
+__device__ __forceinline__ f32x4 bldv(__amdgpu_buffer_rsrc_t r, int off) {
+  if constexpr (ST) {
+    const bf16x4 v = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    return __builtin_convertvector(v, f32x4);
+  } else {
+    return bld4(r, off);
+  }
+}
+template <bool ST>
+__device__ __forceinline__ void bstv(__amdgpu_buffer_rsrc_t r, int off, f32x4 v) {
+  if constexpr (ST) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4)), r, off, 0, 0);
+  else bst4(r, off, v);
+}
+template <bool ST>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slabv(const float* base, int64_t elem_off, int bytes) {
+  // elem_off counts ELEMENTS of the buffer's own type (bf16 when ST)
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(base) + elem_off * (ST ? 2 : 4)), 0, bytes, 0x00020000);
+}
 
 // --------------------------------------------------------------------------------- forward
 // KB = number of 32-wide k-blocks covering the hidden size (h <= 32 KB).
-template <int KB, int KIND>
+template <int KB, int KIND, bool ST>
 __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, const int B, const int tile, __bf16* lds) {
+  constexpr int ES = ST ? 2 : 4;          // bytes per stored gate / h element
   constexpr int HKP = KB * 32;
   constexpr int LROW = HKP + 8;      // bf16 elements per LDS row (16-byte pad)
   const int tid = threadIdx.x;
@@ -147,27 +170,30 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
   float* const cs_p = d.cs;
   float* const hs_p = d.hs;
   const int64_t row4 = 4 * (int64_t)Hp;
-  const int slab_g = B * 4 * Hp * 4, slab_h = B * Hp * 4;                    // bytes of one time step
-  const int voff_g = bvalid ? (b * 4 * Hp + u0 + 4 * q) * 4 : slab_g;          // idle lanes: out of range
+  const int slab_g = B * 4 * Hp * ES, slab_h = B * Hp * 4;                   // bytes of one time step (gates; cs)
+  const int slab_hs = B * Hp * ES;                                            // (hs)
+  const int voff_g = bvalid ? (b * 4 * Hp + u0 + 4 * q) * ES : slab_g;         // idle lanes: out of range
   const int voff_h = bvalid ? (b * Hp + u0 + 4 * q) * 4 : slab_h;
+  const int voff_hs = bvalid ? (b * Hp + u0 + 4 * q) * ES : slab_hs;
   const int gx_bytes = dec ? 0 : slab_g;                                      // decoders have no x-projection to fetch
   f32x4 gx[4];
   {
-    const __amdgpu_buffer_rsrc_t r0 = slab(gates_p, 0, gx_bytes);
+    const __amdgpu_buffer_rsrc_t r0 = slabv<ST>(gates_p, 0, gx_bytes);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) gx[g] = bld4(r0, voff_g + g * Hp * 4);
+    for (int g = 0; g < 4; ++g) gx[g] = bldv<ST>(r0, voff_g + g * Hp * ES);
   }
 
   float c[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 h_keep = f32x4{0.f, 0.f, 0.f, 0.f};
   int cur = 0;
   auto step = [&](const int t) {
     f32x4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = dec ? bias[g] : gx[g];
     {   // x-projection of step t+1 (the last step re-reads its own slab: unused)
-      const __amdgpu_buffer_rsrc_t rn = slab(gates_p, (int64_t)min(t + 1, T - 1) * B * row4, gx_bytes);
+      const __amdgpu_buffer_rsrc_t rn = slabv<ST>(gates_p, (int64_t)min(t + 1, T - 1) * B * row4, gx_bytes);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) gx[g] = bld4(rn, voff_g + g * Hp * 4);
+      for (int g = 0; g < 4; ++g) gx[g] = bldv<ST>(rn, voff_g + g * Hp * ES);
     }
     if (active && (dec || t > 0)) {
       const __bf16* hb = lds + cur * (16 * LROW) + bi * LROW + 8 * q;
@@ -192,12 +218,13 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
         hv[r] = go[r] * act_tanh(c[r]);
       }
       {
-        const __amdgpu_buffer_rsrc_t rg = slab(gates_p, (int64_t)t * B * row4, slab_g);
+        const __amdgpu_buffer_rsrc_t rg = slabv<ST>(gates_p, (int64_t)t * B * row4, slab_g);
         const __amdgpu_buffer_rsrc_t rc = slab(cs_p, (int64_t)t * B * Hp, slab_h);
-        const __amdgpu_buffer_rsrc_t rh = slab(hs_p, (int64_t)t * B * Hp, slab_h);
-        bst4(rg, voff_g, gi); bst4(rg, voff_g + Hp * 4, gf); bst4(rg, voff_g + 2 * Hp * 4, gg); bst4(rg, voff_g + 3 * Hp * 4, go);
+        const __amdgpu_buffer_rsrc_t rh = slabv<ST>(hs_p, (int64_t)t * B * Hp, slab_hs);
+        bstv<ST>(rg, voff_g, gi); bstv<ST>(rg, voff_g + Hp * ES, gf); bstv<ST>(rg, voff_g + 2 * Hp * ES, gg); bstv<ST>(rg, voff_g + 3 * Hp * ES, go);
         bst4(rc, voff_h, cv);
-        bst4(rh, voff_h, hv);
+        bstv<ST>(rh, voff_hs, hv);
+        h_keep = hv;
       }
       if (u0 + 4 * q < HKP) {
         const f32x4 hz = (b < B) ? hv : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -217,12 +244,17 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
     t0 = 1;
   }
   for (int t = t0; t < T; ++t) step(t);
+  if (d.h_last) {      // fp32 copy of h_{T-1} (the latent stack / the MFN heads read it; hs itself may be bf16)
+    const __amdgpu_buffer_rsrc_t rl = slab(d.h_last, 0, slab_h);
+    bst4(rl, voff_h, h_keep);
+  }
 }
 
 // --------------------------------------------------------------------------------- backward
 // The reduction runs over the gate columns in the padded numbering [4][HKP] (HKP = 32 KB): 4 KB k-blocks.
-template <int KB, int KIND>
+template <int KB, int KIND, bool ST>
 __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, const int B, const int tile, __bf16* lds) {
+  constexpr int ES = ST ? 2 : 4;
   constexpr int HKP = KB * 32;
   constexpr int NKB = 4 * KB;
   constexpr int LROW = 4 * HKP + 8;
@@ -280,10 +312,12 @@ __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, cons
   const float* const dh_p = d.dh_ext;
   const float* const dc_p = d.dc_ext;
   const int64_t row4 = 4 * (int64_t)Hp;
-  const int slab_g = B * 4 * Hp * 4, slab_h = B * Hp * 4;                    // bytes of one time step
-  const int voff_g = bvalid ? (b * 4 * Hp + u0 + 4 * q) * 4 : slab_g;          // idle lanes: out of range
+  const int slab_g = B * 4 * Hp * ES, slab_h = B * Hp * 4;                   // bytes of one time step (gates; cs, dc_ext)
+  const int slab_dh = B * Hp * ES;                                            // (the decoders' dh_ext)
+  const int voff_g = bvalid ? (b * 4 * Hp + u0 + 4 * q) * ES : slab_g;         // idle lanes: out of range
   const int voff_h = bvalid ? (b * Hp + u0 + 4 * q) * 4 : slab_h;
-  const int dhe_bytes = dec ? slab_h : 0;           // per-step external dh exists for decoders only
+  const int voff_dh = bvalid ? (b * Hp + u0 + 4 * q) * ES : slab_dh;
+  const int dhe_bytes = dec ? slab_dh : 0;          // per-step external dh exists for decoders only
   const int dce_bytes = dc_p ? slab_h : 0;          // optional external dc (MFN encoder LSTMs)
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
   // encoders receive an external gradient on h_{T-1} only: it seeds the recurrent term
@@ -301,11 +335,11 @@ __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, cons
   // saved activations of the step ABOUT to be processed: requested one step ahead, unconditionally (see slab())
   f32x4 n_gi, n_gf, n_gg, n_go, n_ct, n_cp, n_dhe, n_dce;
   auto fetch = [&](const int t) {
-    const __amdgpu_buffer_rsrc_t rg = slab(gates_p, (int64_t)t * B * row4, slab_g);
-    n_gi = bld4(rg, voff_g); n_gf = bld4(rg, voff_g + Hp * 4); n_gg = bld4(rg, voff_g + 2 * Hp * 4); n_go = bld4(rg, voff_g + 3 * Hp * 4);
+    const __amdgpu_buffer_rsrc_t rg = slabv<ST>(gates_p, (int64_t)t * B * row4, slab_g);
+    n_gi = bldv<ST>(rg, voff_g); n_gf = bldv<ST>(rg, voff_g + Hp * ES); n_gg = bldv<ST>(rg, voff_g + 2 * Hp * ES); n_go = bldv<ST>(rg, voff_g + 3 * Hp * ES);
     n_ct = bld4(slab(cs_p, (int64_t)t * B * Hp, slab_h), voff_h);
     n_cp = bld4(slab(cs_p, (int64_t)max(t - 1, 0) * B * Hp, t > 0 ? slab_h : 0), voff_h);     // c_{-1} = 0
-    n_dhe = bld4(slab(dh_p, (int64_t)t * B * Hp, dhe_bytes), voff_h);
+    n_dhe = bldv<ST>(slabv<ST>(dh_p, (int64_t)t * B * Hp, dhe_bytes), voff_dh);
     n_dce = bld4(slab(dc_p ? dc_p : cs_p, (int64_t)t * B * Hp, dce_bytes), voff_h);
   };
   fetch(T - 1);
@@ -328,8 +362,8 @@ __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, cons
       dc[r] = dct * gf[r];
     }
     {
-      const __amdgpu_buffer_rsrc_t rg = slab(gates_p, (int64_t)t * B * row4, slab_g);
-      bst4(rg, voff_g, dai); bst4(rg, voff_g + Hp * 4, daf); bst4(rg, voff_g + 2 * Hp * 4, dag); bst4(rg, voff_g + 3 * Hp * 4, dao);
+      const __amdgpu_buffer_rsrc_t rg = slabv<ST>(gates_p, (int64_t)t * B * row4, slab_g);
+      bstv<ST>(rg, voff_g, dai); bstv<ST>(rg, voff_g + Hp * ES, daf); bstv<ST>(rg, voff_g + 2 * Hp * ES, dag); bstv<ST>(rg, voff_g + 3 * Hp * ES, dao);
     }
 
     const bool need_rec = (t > 0) || dec;
@@ -383,14 +417,15 @@ __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, cons
 
 #define MFM_SEQB_CASES(BODY, KIND)                                        \
   switch (kb) {                                                           \
-    case 1: BODY<1, KIND>(d, L.T, L.B, tile, lds); break;                 \
-    case 2: BODY<2, KIND>(d, L.T, L.B, tile, lds); break;                 \
-    case 3: BODY<3, KIND>(d, L.T, L.B, tile, lds); break;                 \
-    case 4: BODY<4, KIND>(d, L.T, L.B, tile, lds); break;                 \
+    case 1: BODY<1, KIND, ST>(d, L.T, L.B, tile, lds); break;             \
+    case 2: BODY<2, KIND, ST>(d, L.T, L.B, tile, lds); break;             \
+    case 3: BODY<3, KIND, ST>(d, L.T, L.B, tile, lds); break;             \
+    case 4: BODY<4, KIND, ST>(d, L.T, L.B, tile, lds); break;             \
     default: break;                                                       \
   }
 
-template <bool BWD, int KIND>
+// ST: bf16-resident saved activations (every LSTM of a launch has the same SeqDev::store_bf16)
+template <bool BWD, int KIND, bool ST>
 __global__ __launch_bounds__(512) void lstm_seq_bf16_kernel(const SeqLaunch L) {
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
   int di = 0;
@@ -524,13 +559,20 @@ int seq_bf16_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
     }
     if (K.count == 0) continue;
     const dim3 grid(ktotal), block(64 * max_waves);
+    const bool st = K.d[0].store_bf16 != 0;
+    for (int i = 1; i < K.count; ++i)
+      MFM_REQUIRE((K.d[i].store_bf16 != 0) == st, "lstm_seq (bf16): the LSTMs of one launch must agree on store_bf16");
+#define MFM_SEQB_GO(BWD_, KIND_)                                                                                          \
+  do {                                                                                                                    \
+    if (st) hipLaunchKernelGGL((lstm_seq_bf16_kernel<BWD_, KIND_, true>), grid, block, lds_bytes, stream, K);             \
+    else hipLaunchKernelGGL((lstm_seq_bf16_kernel<BWD_, KIND_, false>), grid, block, lds_bytes, stream, K);               \
+  } while (0)
     if (bwd) {
-      if (kind) hipLaunchKernelGGL((lstm_seq_bf16_kernel<true, 1>), grid, block, lds_bytes, stream, K);
-      else hipLaunchKernelGGL((lstm_seq_bf16_kernel<true, 0>), grid, block, lds_bytes, stream, K);
+      if (kind) MFM_SEQB_GO(true, 1); else MFM_SEQB_GO(true, 0);
     } else {
-      if (kind) hipLaunchKernelGGL((lstm_seq_bf16_kernel<false, 1>), grid, block, lds_bytes, stream, K);
-      else hipLaunchKernelGGL((lstm_seq_bf16_kernel<false, 0>), grid, block, lds_bytes, stream, K);
+      if (kind) MFM_SEQB_GO(false, 1); else MFM_SEQB_GO(false, 0);
     }
+#undef MFM_SEQB_GO
     MFM_LAUNCH_CHECK(bwd ? "lstm_seq_bf16_bwd_kernel" : "lstm_seq_bf16_fwd_kernel");
   }
   return MFM_OK;

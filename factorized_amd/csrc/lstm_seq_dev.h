@@ -12,7 +12,9 @@ struct SeqDev {
   float* d_h_init; int64_t ld_dinit;
   const float* dc_ext;
   const void* w_pack;      // bf16 path: packed weight fragments (mfm_lstm_pack_bf16), or null
+  float* h_last;           // bf16 path, optional: fp32 copy of h_{T-1} [B, Hp]
   int h, Hp, hk4, is_dec, block_begin;
+  int store_bf16;          // bf16 path: gates / hs / the decoders' dh_ext are __bf16 buffers (MfmSeqDesc::store_bf16)
 };
 struct SeqLaunch {
   SeqDev d[MFM_MAX_SEQ];

@@ -597,7 +597,7 @@ def gemm_grouped(descs):
 
 
 def make_gemm(a, b, c, m, n, k, a_sm, a_sk, b_sk, b_sn, ldc, bias=None, bias2=None, n_valid=None, batch=1,
-              a_sz=0, b_sz=0, c_sz=0, bias_sz=0, accumulate=0, split_k=1, alpha=1.0, c2=None):
+              a_sz=0, b_sz=0, c_sz=0, bias_sz=0, accumulate=0, split_k=1, alpha=1.0, c2=None, a_bf16=False, c_bf16=False):
     d = _lib.GemmDesc()
     d.a, d.b, d.c = a.data_ptr(), b.data_ptr(), c.data_ptr()
     d.c2 = c2.data_ptr() if c2 is not None else None
@@ -609,11 +609,12 @@ def make_gemm(a, b, c, m, n, k, a_sm, a_sk, b_sk, b_sn, ldc, bias=None, bias2=No
     d.m, d.n, d.k = m, n, k
     d.n_valid = n if n_valid is None else n_valid
     d.batch, d.split_k, d.accumulate, d.alpha = batch, split_k, accumulate, alpha
+    d.a_bf16, d.c_bf16 = int(bool(a_bf16)), int(bool(c_bf16))
     return d
 
 
 def make_seq(gates, hs, cs, w_hh, h, w_ih=None, b_ih=None, b_hh=None, h_init=None, is_dec=False,
-             dh_ext=None, ld_dh=0, d_h_init=None, dc_ext=None, w_pack=None):
+             dh_ext=None, ld_dh=0, d_h_init=None, dc_ext=None, w_pack=None, store_bf16=False, h_last=None):
     d = _lib.SeqDesc()
     d.gates, d.hs, d.cs = gates.data_ptr(), hs.data_ptr(), cs.data_ptr()
     d.w_hh = w_hh.data_ptr()
@@ -629,6 +630,8 @@ def make_seq(gates, hs, cs, w_hh, h, w_ih=None, b_ih=None, b_hh=None, h_init=Non
     d.h, d.is_dec = h, int(is_dec)
     d.dc_ext = dc_ext.data_ptr() if dc_ext is not None else None
     d.w_pack = w_pack.data_ptr() if w_pack is not None else None
+    d.store_bf16 = int(bool(store_bf16))
+    d.h_last = h_last.data_ptr() if h_last is not None else None
     return d
 
 

@@ -39,7 +39,7 @@ extern "C" {
 #define MFM_ERR_HIP (-2)
 #define MFM_ERR_UNSUPPORTED (-3)
 
-#define MFM_ABI_VERSION 1
+#define MFM_ABI_VERSION 2
 
 int mfm_abi_version(void);
 const char* mfm_last_error(void);
@@ -63,6 +63,13 @@ typedef struct MfmGemmDesc {
   int64_t c_sz, ldc, bias_sz;
   int32_t m, n, k, n_valid, batch, split_k, accumulate;
   float alpha;
+  /* bf16-RESIDENT operands (ABI 2; mfm_gemm_grouped_bf16 only, 0 = the fp32 buffers described above).  A bf16 plan keeps
+   * its saved activations in HBM as bf16 (plan.hip): a_bf16 -> `a` points to __bf16 elements (strides count bf16
+   * elements; the unit-stride axis must start on 16-byte boundaries), loaded straight into the LDS image without a
+   * rounding pass; c_bf16 -> `c` (and c2) receive bf16 (nearest even) instead of fp32 -- plain, non-accumulating
+   * products only. */
+  int32_t a_bf16, c_bf16;
+  int32_t reserved_[2];
 } MfmGemmDesc;
 
 int mfm_gemm_grouped_f32(const MfmGemmDesc* descs /*host*/, int count, void* stream);
@@ -100,6 +107,14 @@ typedef struct MfmSeqDesc {
   void* w_pack;          /* bf16 entry points only, optional: mfm_lstm_pack_bytes(h, is_dec) bytes filled by
                             mfm_lstm_pack_bf16 from the CURRENT weights (bf16 MFMA fragments in lane order); NULL =
                             the recurrence kernels gather their fragments from the fp32 matrices themselves (slow) */
+  /* ABI 2, bf16 entry points only: bf16-RESIDENT saved activations.  store_bf16 != 0 -> `gates` (x-projection in,
+     activated gates / dA out), `hs` and the decoders' per-step `dh_ext` [T,B,Hp] are __bf16 buffers of the same shapes
+     (half the bytes of every time step; the cell state `cs`, dc_ext, the encoders' dh_ext [B, ld_dh], h_init and
+     d_h_init stay fp32).  The recurrent product rounds h_{t-1} / dA_t to bf16 anyway, so what is stored is exactly
+     what the MFMA consumed; the x-projection and the saved gate activations are rounded once more (nearest even). */
+  int32_t store_bf16;
+  int32_t reserved2_;
+  float* h_last;         /* optional [B, Hp] fp32: forward also writes h_{T-1} here (the latent stack's input stays fp32) */
 } MfmSeqDesc;
 
 int mfm_lstm_seq_fwd(const MfmSeqDesc* descs /*host*/, int count, int T, int B, void* stream);

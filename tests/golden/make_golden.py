@@ -151,7 +151,7 @@ def run_staged(name, B, T, n1, n2, variant="kl_ef"):
     """train_beta_vae's schedule (mfm_mosi.py:238-239, 278-284, 346-358): ONE Adam optimizer, `n1` steps on
     gen + reg (stage 1), then `n2` steps on disc + reg (stage 2), on the reference MFM_KL_EF (or, round 3, on
     MFM_KL / MFM: the stage masks then also cover the Memory Fusion Network's tensors; MFM's loss_MMD sample is a
-    stored seeded sequence as in run_case).  Also stored: the gradient summaries of the first step of each stage
+    stored seeded sequence as in run_case).  Also stored: the gradient summaries of both stage losses at the initial weights
     (NaN rows = parameters the stage loss does not reach).  Two traces:
     'frozen' with this torch's zero_grad (sets .grad to None -> Adam skips parameters the stage loss does not
     reach) and 'legacy' with zero_grad(set_to_none=False), which is what the reference's PyTorch 0.4 did (a
@@ -186,6 +186,15 @@ def run_staged(name, B, T, n1, n2, variant="kl_ef"):
         model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()})
         model.train()
         opt = torch.optim.Adam(model.parameters())
+        if mode == "frozen":      # gradients of both stage losses at the INITIAL weights (NaN rows: .grad is None)
+            for stage in (1, 2):
+                opt.zero_grad(set_to_none=True)
+                terms, _ = losses_of(model)
+                reg = cfg["lda_mmd"] * terms["reg"]
+                (terms["gen"] + reg if stage == 1 else terms["disc"] + reg).backward()
+                out["grad_summary_stage%d" % stage] = np.stack([
+                    summarize(p.grad) if p.grad is not None else np.full(10, np.nan)
+                    for _, p in model.named_parameters()])
         trace = []
         for s in range(n1 + n2):
             stage = 1 if s < n1 else 2
@@ -194,10 +203,6 @@ def run_staged(name, B, T, n1, n2, variant="kl_ef"):
             reg = cfg["lda_mmd"] * terms["reg"]
             loss = terms["gen"] + reg if stage == 1 else terms["disc"] + reg      # mfm_mosi.py:278-281
             loss.backward()
-            if mode == "frozen" and s in (0, n1):
-                out["grad_summary_stage%d" % stage] = np.stack([
-                    summarize(p.grad) if p.grad is not None else np.full(10, np.nan)
-                    for _, p in model.named_parameters()])
             opt.step()
             trace.append([loss.item(), terms["disc"].item(), terms["gen"].item(), terms["reg"].item()])
             if s == n1 - 1:

@@ -240,6 +240,88 @@ def test_bf16_lstm_seq_decoder_fwd_bwd(eng, h, B, T):
     assert rel_err(dinit.cpu().numpy(), dinit_ref) < 2e-3
 
 
+# ---------------------------------------------------------------------------------- bf16-RESIDENT saved activations
+def bfd(a):
+    """bf16 device tensor from an fp32 array"""
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda().bfloat16()
+
+
+def b2n(t):
+    return t.float().cpu().numpy().astype(np.float64)
+
+
+@pytest.mark.parametrize("h,d,B,T", [(8, 5, 32, 20), (24, 7, 33, 4), (32, 300, 32, 20), (80, 20, 17, 6), (120, 325, 40, 5), (36, 10, 300, 3)])
+def test_bf16_resident_encoder_fwd_bwd(eng, h, d, B, T):
+    """store_bf16: the x-projection is READ as bf16, activated gates / h are WRITTEN as bf16 (c stays fp32), h_{T-1} also
+    as fp32; BPTT reads the bf16 gates and leaves dA as bf16 in place.  Reference: the emulation fed with exactly the
+    stored (rounded) values -- what is left is the rounding of each output element (2^-9 relative)."""
+    rs = np.random.RandomState(h * 7 + B)
+    k = 1.0 / np.sqrt(h)
+    w_hh = rs.uniform(-k, k, size=(4 * h, h)).astype(np.float32)
+    Hp = (h + 15) // 16 * 16
+    gp = np.zeros((T, B, 4, Hp), dtype=np.float32)
+    gp[:, :, :, :h] = rs.normal(size=(T, B, 4, h))
+    gates = bfd(gp)
+    gx = b2n(gates)[:, :, :, :h].reshape(T, B, 4 * h)          # what the kernel reads
+    hs = torch.full((T, B, Hp), 9.0, device="cuda", dtype=torch.bfloat16)
+    cs = torch.full((T, B, Hp), 9.0, device="cuda")
+    h_last = torch.full((B, Hp), 7.0, device="cuda")
+    w_d = dev(w_hh)
+    seq_bf16([eng.make_seq(gates, hs, cs, w_d, h, store_bf16=True, h_last=h_last)], T, B)
+    g_ref, hs_ref, cs_ref = _emulate_fwd(gx, bf(w_hh), h, T, B)
+    hs_o, cs_o, g_o = b2n(hs), cs.cpu().numpy(), b2n(gates)
+    assert rel_err(hs_o[:, :, :h], hs_ref) < 6e-3
+    assert rel_err(cs_o[:, :, :h], cs_ref) < 2e-3
+    assert rel_err(g_o[:, :, :, :h], g_ref) < 6e-3
+    assert np.all(hs_o[:, :, h:] == 0.0) and np.all(cs_o[:, :, h:] == 0.0)
+    hl = h_last.cpu().numpy()
+    assert rel_err(hl[:, :h], hs_ref[-1]) < 2e-3 and np.all(hl[:, h:] == 0.0)
+    assert np.array_equal(bf(hl), hs_o[-1])                     # hs[T-1] is the rounding of the fp32 copy
+    # backward from the stored activations
+    dh_last = rs.normal(size=(B, h)).astype(np.float32)
+    seq_bf16([eng.make_seq(gates, hs, cs, w_d, h, dh_ext=dev(dh_last), ld_dh=h, store_bf16=True)], T, B, backward=True)
+    dA_ref, _ = _emulate_bwd(g_o[:, :, :, :h], cs_o.astype(np.float64)[:, :, :h], bf(w_hh), T, B, h, dh_last=dh_last.astype(np.float64))
+    dA = b2n(gates)
+    assert rel_err(dA[:, :, :, :h], dA_ref) < 8e-3
+    assert np.all(dA[:, :, :, h:] == 0.0)
+
+
+@pytest.mark.parametrize("h,B,T", [(24, 32, 20), (104, 32, 20), (24, 5, 1), (112, 33, 7), (104, 200, 6)])
+def test_bf16_resident_decoder_fwd_bwd(eng, h, B, T):
+    """decoders: hs (the fc1 operand) bf16, and in the BPTT the per-step external gradient dh_ext [T,B,Hp] is a bf16
+    buffer (written by the fc1-backward GEMM with c_bf16); d h_init stays fp32"""
+    rs = np.random.RandomState(h + B + T)
+    k = 1.0 / np.sqrt(h)
+    w_ih = rs.uniform(-k, k, size=(4 * h, h)).astype(np.float32)
+    w_hh = rs.uniform(-k, k, size=(4 * h, h)).astype(np.float32)
+    b_ih = rs.uniform(-k, k, size=4 * h).astype(np.float32)
+    b_hh = rs.uniform(-k, k, size=4 * h).astype(np.float32)
+    init = rs.normal(size=(B, h)).astype(np.float32)
+    Hp = (h + 15) // 16 * 16
+    gates = torch.full((T, B, 4, Hp), 3.0, device="cuda", dtype=torch.bfloat16)
+    hs = torch.full((T, B, Hp), 9.0, device="cuda", dtype=torch.bfloat16)
+    cs = torch.full((T, B, Hp), 9.0, device="cuda")
+    wi, wh, bi, bh, init_d = dev(w_ih), dev(w_hh), dev(b_ih), dev(b_hh), dev(init)
+    seq_bf16([eng.make_seq(gates, hs, cs, wh, h, w_ih=wi, b_ih=bi, b_hh=bh, h_init=init_d, is_dec=True, store_bf16=True)], T, B)
+    Wsum = bf(w_ih + w_hh)
+    g_ref, hs_ref, cs_ref = _emulate_fwd(None, Wsum, h, T, B, dec_init=init, W0b=bf(w_ih), bias=(b_ih + b_hh).astype(np.float64))
+    hs_o, cs_o, g_o = b2n(hs), cs.cpu().numpy(), b2n(gates)
+    assert rel_err(hs_o[:, :, :h], hs_ref) < 6e-3
+    assert rel_err(cs_o[:, :, :h], cs_ref) < 2e-3
+    assert np.all(hs_o[:, :, h:] == 0.0)
+    dH = rs.normal(size=(T, B, h)).astype(np.float32)
+    dH_p = np.zeros((T, B, Hp), dtype=np.float32)
+    dH_p[:, :, :h] = dH
+    dh_d = bfd(dH_p)
+    dinit = torch.full((B, h), 5.0, device="cuda")
+    seq_bf16([eng.make_seq(gates, hs, cs, wh, h, w_ih=wi, b_ih=bi, b_hh=bh, h_init=init_d, is_dec=True,
+                           dh_ext=dh_d, ld_dh=Hp, d_h_init=dinit, store_bf16=True)], T, B, backward=True)
+    dA_ref, dinit_ref = _emulate_bwd(g_o[:, :, :, :h], cs_o.astype(np.float64)[:, :, :h], Wsum, T, B, h,
+                                     dh_ext_all=b2n(dh_d)[:, :, :h], W0b=bf(w_ih))
+    assert rel_err(b2n(gates)[:, :, :, :h], dA_ref) < 8e-3
+    assert rel_err(dinit.cpu().numpy(), dinit_ref) < 8e-3
+
+
 def test_bf16_lstm_seq_four_in_one_launch_matches_single_launches(eng):
     """the four encoders of the plan (h = 32, 8, 80, 120) in one call == each alone, bit for bit"""
     rs = np.random.RandomState(3)

@@ -213,7 +213,19 @@ def test_hip_data_parallel_step_mfn_variants(variant, world, fused):
         worst = max(worst, cases.rel_err(got[n], p.detach().numpy()))
         wabs = max(wabs, float(np.max(np.abs(got[n] - p.detach().numpy()))))
     cases.report("dp_hip_params_abs_%s_W%d" % (variant, world), wabs)
-    assert wabs < 1e-4 and worst < 1e-3, (worst, wabs)
+    # Adam normalises by sqrt(v): an element whose gradient is rounding noise moves by up to lr per step in a direction the
+    # noise decides (measured 2.3e-4 on such elements of `MFM`, W = 2).  Elements with a significant step-0 gradient are
+    # held to the tight bound, the rest to "cannot have moved further than Adam moves" (the criterion of DESIGN.md section 2)
+    wsig = 0.0
+    for n, p in m.named_parameters():
+        d = np.abs(got[n] - p.detach().numpy())
+        if g0[n] is not None:
+            sig = np.abs(g0[n]) > 1e-3 * np.abs(g0[n]).max()
+            if sig.any():
+                wsig = max(wsig, float(d[sig].max()))
+        assert d.max() < 1.01 * STEPS * 1e-3, n
+    cases.report("dp_hip_params_abs_significant_%s_W%d" % (variant, world), wsig)
+    assert wsig < 5e-5, wsig
     assert np.max(np.abs(got_tr - trace) / np.maximum(np.abs(trace), 1e-2)) < 5e-5, (got_tr[-1], trace[-1])
 
 

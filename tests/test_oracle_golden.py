@@ -103,6 +103,15 @@ def test_oracle_staged_training_matches_reference(mode, variant, gname):
     xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7)
     x, y = torch.from_numpy(xn), torch.from_numpy(yn)
     opt = torch.optim.Adam(model.parameters())
+    if mode == "frozen":          # gradients of both stage losses at the initial weights; NaN rows = .grad is None
+        for stage in (1, 2):
+            opt.zero_grad(set_to_none=True)
+            O.stage_loss(O.loss_terms(model, x, y, cfg), cfg, stage).backward()
+            gs = gold["grad_summary_stage%d" % stage]
+            for i, p in enumerate(model.parameters()):
+                assert (p.grad is None) == bool(np.isnan(gs[i, 0])), (stage, i)
+                if p.grad is not None:
+                    assert np.allclose(cases.summarize(p.grad.numpy()), gs[i], rtol=2e-4, atol=2e-6), (stage, i)
     trace = []
     for s in range(n1 + n2):
         stage = 1 if s < n1 else 2
@@ -110,12 +119,6 @@ def test_oracle_staged_training_matches_reference(mode, variant, gname):
         terms = O.loss_terms(model, x, y, cfg)
         loss = O.stage_loss(terms, cfg, stage)
         loss.backward()
-        if mode == "frozen" and s in (0, n1):        # gradients of the first step of each stage; NaN rows = .grad is None
-            gs = gold["grad_summary_stage%d" % stage]
-            for i, p in enumerate(model.parameters()):
-                assert (p.grad is None) == bool(np.isnan(gs[i, 0])), (stage, i)
-                if p.grad is not None:
-                    assert np.allclose(cases.summarize(p.grad.numpy()), gs[i], rtol=2e-4, atol=2e-6), (stage, i)
         opt.step()
         trace.append([loss.item(), terms["disc"].item(), terms["gen"].item(), terms["reg"].item()])
         if s == n1 - 1:
