@@ -309,7 +309,15 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
   for (int i = 0; i < count; ++i) {
     const MfmGemmDesc& d = descs[i];
     MFM_REQUIRE(d.m > 0 && d.n > 0 && d.k >= 0 && d.batch > 0, "gemm[%d]: bad dims m=%d n=%d k=%d batch=%d", i, d.m, d.n, d.k, d.batch);
-    MFM_REQUIRE(d.a && d.b && d.c, "gemm[%d]: null operand", i);
+    MFM_REQUIRE(d.a && d.b && (d.c || (i < mse_count && !d.accumulate && !d.c_bf16)), "gemm[%d]: null operand", i);
+    if (d.a_bf16 || d.c_bf16) {
+      MFM_REQUIRE(precision == 1, "gemm[%d]: bf16-resident operands (a_bf16 / c_bf16) are taken by the bf16 entry point only", i);
+      MFM_REQUIRE(!d.c_bf16 || (!d.accumulate && d.split_k <= 1), "gemm[%d]: c_bf16 needs a plain (non-accumulating, unsplit) product", i);
+      MFM_REQUIRE(!d.a_bf16 || ((((uintptr_t)d.a) & 15) == 0 && (d.a_sz & 7) == 0 &&
+                                ((d.a_sk == 1 && (d.a_sm & 7) == 0) || (d.a_sm == 1 && d.a_sk != 1 && (d.a_sk & 7) == 0))),
+                  "gemm[%d]: a_bf16 needs a unit-stride axis on 16-byte boundaries (a_sm=%lld a_sk=%lld a_sz=%lld)", i,
+                  (long long)d.a_sm, (long long)d.a_sk, (long long)d.a_sz);
+    }
     MFM_REQUIRE(d.n_valid >= 0 && d.n_valid <= d.n, "gemm[%d]: n_valid %d > n %d", i, d.n_valid, d.n);
     MFM_REQUIRE(d.split_k <= 1 || d.accumulate, "gemm[%d]: split_k needs accumulate", i);
     {
@@ -344,6 +352,8 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
   // bf16 MFMA operands (precision 1) need every operand unit-stride along its 16-byte load groups; a group with an
   // oddly strided operand runs on the fp32 kernel's dword path instead
   const bool bf16 = (precision == 1) && vec;
+  for (int i = 0; i < count; ++i)
+    MFM_REQUIRE(bf16 || !(descs[i].a_bf16 || descs[i].c_bf16), "gemm[%d]: bf16-resident operands need unit-stride operands in the whole group", i);
   const int bk = bf16 ? BKB : BK;
   int total = 0;
   for (int i = 0; i < count; ++i) {

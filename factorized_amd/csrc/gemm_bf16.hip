@@ -63,12 +63,16 @@ __global__ __launch_bounds__(256, (FR == 1) ? 4 : 2) void gemm_bf16_kernel(const
   const int kend = min(d.k, kbeg + P.k_per_split);
   if (kbeg >= kend && split > 0) return;
 
-  const float* __restrict__ A = d.a + (int64_t)z * d.a_sz;
+  // a_bf16: the A operand is a bf16-RESIDENT buffer (saved hidden states / gate gradients of a bf16 plan): element size 2,
+  // no rounding pass -- the 16-byte loads go to the LDS image as they are (wave-uniform per problem)
+  const bool a16 = d.a_bf16 != 0;
+  const float* __restrict__ A = a16 ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(d.a) + (int64_t)z * d.a_sz)
+                                    : d.a + (int64_t)z * d.a_sz;
   const float* __restrict__ Bm = d.b + (int64_t)z * d.b_sz;
   const bool a_mcontig = (d.a_sm == 1 && d.a_sk != 1);
   const bool b_ncontig = (d.b_sn == 1 && d.b_sk != 1);
   const int a_sm = (int)d.a_sm, a_sk = (int)d.a_sk, b_sk = (int)d.b_sk, b_sn = (int)d.b_sn;
-  const int a_bytes = ((d.m - 1) * a_sm + (max(d.k, 1) - 1) * a_sk + 1) * 4;
+  const int a_bytes = ((d.m - 1) * a_sm + (max(d.k, 1) - 1) * a_sk + 1) * (a16 ? 2 : 4);
   const int b_bytes = ((max(d.k, 1) - 1) * b_sk + (max(d.n_valid, 1) - 1) * b_sn + 1) * 4;
   const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc((void*)Bm, 0, b_bytes, 0x00020000);
@@ -132,12 +136,60 @@ __global__ __launch_bounds__(256, (FR == 1) ? 4 : 2) void gemm_bf16_kernel(const
     }
   };
   const int a_rmax = d.m - 1, b_rmax = max(d.n_valid - 1, 0);
+  // ---- bf16-resident A: GA = FR 16-byte loads of 8 bf16 per thread and tile, kept as raw bits in ra[0 .. GA)
+  constexpr int GA = FR;
+  static_assert(GA <= G, "the bf16-resident loads reuse the fp32 staging registers");
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  //   k-contiguous (hs of a forward product): (row, 8 consecutive k) -> one ds_write_b128 into the [row][k] image
+  //   m-contiguous (dA of a weight-gradient product; only small leftovers come here -- the LSTM sums over the rows have
+  //   their own kernel, dw_bf16.hip): (k, 8 consecutive rows) -> eight 2-byte writes
+  auto load_a16 = [&](int k0) {
+#pragma unroll
+    for (int gi = 0; gi < GA; ++gi) {
+      const int l = tid + gi * 256;
+      int row, k;
+      if (a_mcontig) { k = l / (BM / 8); row = (l % (BM / 8)) * 8; }
+      else { row = l / (BKB / 8); k = (l % (BKB / 8)) * 8; }
+      const int gr = m0 + row, gk = k0 + k;
+      const int off = min(gr, a_rmax) * a_sm + min(gk, klast) * a_sk;
+      u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ares, off * 2, 0, 0));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {       // dword e holds elements 2e, 2e+1 along the contiguous axis
+        const int r0 = a_mcontig ? gr + 2 * e : gr, r1 = a_mcontig ? gr + 2 * e + 1 : gr;
+        const int c0 = a_mcontig ? gk : gk + 2 * e, c1 = a_mcontig ? gk : gk + 2 * e + 1;
+        const unsigned m0k = ((int)(r0 <= a_rmax) & (int)(c0 < kend)) ? 0x0000FFFFu : 0u;
+        const unsigned m1k = ((int)(r1 <= a_rmax) & (int)(c1 < kend)) ? 0xFFFF0000u : 0u;
+        v[e] &= (m0k | m1k);
+      }
+      ra[gi] = __builtin_bit_cast(f32x4, v);
+    }
+  };
+  auto store_a16 = [&](__bf16* img) {
+#pragma unroll
+    for (int gi = 0; gi < GA; ++gi) {
+      const int l = tid + gi * 256;
+      if (a_mcontig) {
+        const int k = l / (BM / 8), row = (l % (BM / 8)) * 8;
+        const u32x4 v = __builtin_bit_cast(u32x4, ra[gi]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned short bits = (unsigned short)((v[e >> 1] >> ((e & 1) * 16)) & 0xFFFFu);
+          *reinterpret_cast<unsigned short*>(img + (row + e) * LDK + k) = bits;
+        }
+      } else {
+        const int row = l / (BKB / 8), k = (l % (BKB / 8)) * 8;
+        *reinterpret_cast<f32x4*>(img + row * LDK + k) = ra[gi];
+      }
+    }
+  };
   auto load_tiles = [&](int k0) {
-    load_op(ra, ares, a_mcontig, BM, m0, a_rmax, a_sm, a_sk, k0);
+    if (a16) load_a16(k0);
+    else load_op(ra, ares, a_mcontig, BM, m0, a_rmax, a_sm, a_sk, k0);
     load_op(rb, bres, b_ncontig, BN, n0, b_rmax, b_sn, b_sk, k0);
   };
   auto store_tiles = [&](int img) {
-    store_op(ra, As2[img], a_mcontig, BM);
+    if (a16) store_a16(As2[img]);
+    else store_op(ra, As2[img], a_mcontig, BM);
     store_op(rb, Bs2[img], b_ncontig, BN);
   };
 

@@ -40,8 +40,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmGroup& g, const MfmGemmD
                                               const int bi, const int q, const int tid, const int lane, const int wave,
                                               f32x4 (&acc)[FR][FR], float (&tgt)[TF][TF][4], const bool do_mse) {
   const MseEpi& me = g.mse[do_mse ? pi : 0];
-  float* __restrict__ C = d.c + (int64_t)z * d.c_sz;
+  float* __restrict__ C = d.c ? d.c + (int64_t)z * d.c_sz : nullptr;
   float* __restrict__ C2 = d.c2 ? d.c2 + (int64_t)z * d.c_sz : nullptr;
+  // c_bf16 (bf16-resident outputs of a bf16 plan: the x-projection, dH): the same element offsets, 2-byte elements
+  const bool c16 = d.c_bf16 != 0;
+  __bf16* __restrict__ C16 = reinterpret_cast<__bf16*>(d.c) + (int64_t)z * d.c_sz;
+  __bf16* __restrict__ C216 = reinterpret_cast<__bf16*>(d.c2) + (int64_t)z * d.c_sz;
   float sq = 0.0f;
 #pragma unroll
   for (int fm = 0; fm < FR; ++fm)
@@ -82,12 +86,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmGroup& g, const MfmGemmD
             if (C2) atomicAdd(C2 + off, v);
           }
         } else {
-          C[off] = v;
-          if (C2) C2[off] = v;
+          if (c16) {
+            C16[off] = (__bf16)v;
+            if (C2) C216[off] = (__bf16)v;
+          } else {
+            if (C) C[off] = v;          // (null: a training step needs the squared error and d x_hat only, not x_hat itself)
+            if (C2) C2[off] = v;
+          }
           if (do_mse && col < d.n_valid) {
             const float diff = v - tgt[fm % TF][fn % TF][r];
             sq += diff * diff;
-            if (me.dxhat) me.dxhat[off] = me.grad_scale * diff;
+            if (me.dxhat) {
+              if (me.dxhat_bf16) reinterpret_cast<__bf16*>(me.dxhat)[off] = (__bf16)(me.grad_scale * diff);
+              else me.dxhat[off] = me.grad_scale * diff;
+            }
           }
         }
       }

@@ -207,7 +207,11 @@ __global__ __launch_bounds__(PANEL_THREADS) void gemm_panel_kernel(const PanelLa
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int row = m0 + wm * 16 * FM + fm * 16 + q * 4 + r;
-              if (row < L.M) G.c[(int64_t)row * G.ldc + col] = cv ? acc[fm][fn][r] + bsum : 0.0f;
+              if (row < L.M) {
+                const float v = cv ? acc[fm][fn][r] + bsum : 0.0f;
+                if (G.c_bf16) reinterpret_cast<__bf16*>(G.c)[(int64_t)row * G.ldc + col] = (__bf16)v;
+                else G.c[(int64_t)row * G.ldc + col] = v;
+              }
             }
         }
       }
@@ -286,6 +290,7 @@ int gemm_panel_launch(PanelLaunch& L, const ZeroSpans* zs, int precision, bool f
     }
   }
   const bool bf16 = precision == 1;
+  for (int i = 0; i < L.ngroups; ++i) MFM_REQUIRE(bf16 || !L.g[i].c_bf16, "gemm panel: group %d: c_bf16 needs the bf16 kernel", i);
   size_t lds = 0;
   const int BM = panel_height(L, precision, force, &lds);
   if (BM == 0) { set_error("gemm panel: declined (K=%d does not fit the LDS, MFM_PANEL_BM names no built height, or the tiled kernel is cheaper)", L.K); return MFM_ERR_UNSUPPORTED; }

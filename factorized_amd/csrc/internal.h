@@ -17,6 +17,7 @@ struct GemmEpi { float* aux; float p; int kind; unsigned op_id; int pad_; };
 struct GemmEpiSet { const GemmEpi* epi; int count; unsigned long long seed; int train; };
 struct MseEpi {          // squared-error epilogue of one product: target, d(output), loss slot, scales
   const float* x; int64_t ldx; float* dxhat; float* loss; float inv_count, grad_scale;
+  int dxhat_bf16, pad_;  // dxhat is a __bf16 buffer (bf16-resident plans)
 };
 // precision: 0 = fp32 operands on v_mfma_f32_16x16x4_f32, 1 = operands rounded to bf16 on the way into LDS,
 // v_mfma_f32_16x16x32_bf16 with fp32 accumulation (gemm_bf16.hip)
@@ -54,6 +55,7 @@ struct PanelGroup {
   // real unit when u < seg_valid, and then weight row / bias element (j / seg) * seg_valid + u produces it; pad
   // columns are written as zeros.  (One LSTM = one group: nseg 4, seg Hp, seg_valid h.)
   int n, seg, seg_valid, k_off, k_len;
+  int c_bf16, pad_;       // c is a __bf16 buffer (bf16-resident x-projection of a bf16 plan); ldc counts its elements
 };
 struct PanelLaunch {
   const float* a; int64_t lda; int M, K;

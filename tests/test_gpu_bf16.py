@@ -322,6 +322,58 @@ def test_bf16_resident_decoder_fwd_bwd(eng, h, B, T):
     assert rel_err(dinit.cpu().numpy(), dinit_ref) < 8e-3
 
 
+@pytest.mark.parametrize("fr", ["1", "2", "4"])
+@pytest.mark.parametrize("m,n,k", [(640, 300, 104), (37, 5, 24), (2048, 20, 24), (130, 70, 128), (1, 1, 8)])
+def test_bf16_resident_gemm_a_kcontig_and_c_out(eng, m, n, k, fr, monkeypatch):
+    """A = bf16-resident hidden states [m, Kp] (k-contiguous, a_bf16): no rounding pass, bits go straight to LDS; the
+    same product once with an fp32 C and once with a bf16 C (c_bf16: x-projection / dH of a bf16-resident plan)"""
+    monkeypatch.setenv("MFM_GEMM_FR", fr)
+    rs = np.random.RandomState(m + n + k)
+    Kp = (k + 15) // 16 * 16
+    A = np.zeros((m, Kp), dtype=np.float32)
+    A[:, :k] = rs.normal(size=(m, k))
+    W = rs.normal(size=(n, k)).astype(np.float32)
+    b1 = rs.normal(size=n).astype(np.float32)
+    a_d, w_d, b1_d = bfd(A), dev(W), dev(b1)
+    npad = n + 3
+    c32 = torch.full((m, npad), 7.0, device="cuda")
+    c16 = torch.full((m, npad), 7.0, device="cuda", dtype=torch.bfloat16)
+    gemm_bf16([eng.make_gemm(a_d, w_d, c32, m, npad, k, a_sm=Kp, a_sk=1, b_sk=1, b_sn=k, ldc=npad, bias=b1_d, n_valid=n, a_bf16=True),
+               eng.make_gemm(a_d, w_d, c16, m, npad, k, a_sm=Kp, a_sk=1, b_sk=1, b_sn=k, ldc=npad, bias=b1_d, n_valid=n, a_bf16=True, c_bf16=True)])
+    ref = b2n(a_d)[:, :k] @ bf(W).T + b1
+    out = c32.cpu().numpy()
+    assert rel_err(out[:, :n], ref) < 1e-5
+    assert np.all(out[:, n:] == 0.0)
+    o16 = b2n(c16)
+    assert np.array_equal(o16[:, :n], bf(out[:, :n]))            # the bf16 C is the rounding of the fp32 one
+    assert np.all(o16[:, n:] == 0.0)
+
+
+def test_bf16_resident_gemm_a_mcontig_small_product(eng):
+    """dW_ih += dA_0^T h_init of the decoders (K = B rows only): dA is a bf16-resident, m-contiguous operand batched over
+    the four gates; the generic kernel takes it on its slow path (8 two-byte LDS writes per load)"""
+    rs = np.random.RandomState(11)
+    R, h, Hp = 37, 24, 32
+    dA = np.zeros((R, 4, Hp), dtype=np.float32)
+    dA[:, :, :h] = rs.normal(size=(R, 4, h))
+    X = rs.normal(size=(R, h)).astype(np.float32)
+    da_d, x_d = bfd(dA), dev(X)
+    c1 = torch.zeros(4, h, h, device="cuda")
+    gemm_bf16([eng.make_gemm(da_d, x_d, c1, h, h, R, a_sm=1, a_sk=4 * Hp, b_sk=h, b_sn=1, ldc=h, batch=4,
+                             a_sz=Hp, c_sz=h * h, accumulate=1, split_k=0, a_bf16=True)])
+    ref = np.einsum("rgm,rn->gmn", b2n(da_d)[:, :, :h], bf(X))
+    assert rel_err(c1.cpu().numpy(), ref) < 2e-5
+
+
+def test_bf16_resident_flags_refused_by_fp32_entry_point(eng):
+    from factorized_amd import _lib
+    a, w = bfd(np.ones((16, 16))), dev(np.ones((16, 16)))
+    c = torch.zeros(16, 16, device="cuda")
+    d = eng.make_gemm(a, w, c, 16, 16, 16, a_sm=16, a_sk=1, b_sk=1, b_sn=16, ldc=16, a_bf16=True)
+    arr = (_lib.GemmDesc * 1)(d)
+    assert _lib.lib().mfm_gemm_grouped_f32(arr, 1, None) != 0
+
+
 def test_bf16_lstm_seq_four_in_one_launch_matches_single_launches(eng):
     """the four encoders of the plan (h = 32, 8, 80, 120) in one call == each alone, bit for bit"""
     rs = np.random.RandomState(3)
