@@ -1,0 +1,394 @@
+// Weight gradients of the LSTMs (and of the decoders' fc1) on a bf16-RESIDENT plan: ONE pass over the gate gradients.
+//
+// Reference: what loss.backward() accumulates into weight_ih / weight_hh / bias_ih / bias_hh of every nn.LSTMCell and into
+// decoderLSTM.fc1 (mfm_model.py:40-91 unrolled over T).  With A_t = the gate pre-activation gradients the BPTT left behind:
+//     dW_ih = sum_t A_t^T x_t        dW_hh = sum_{t>=1} A_t^T h_{t-1}        db_ih = db_hh = sum_t A_t^T 1
+//     dW_fc = sum_t dxhat_t^T h_t    db_fc = sum_t dxhat_t^T 1
+// i.e. per item ONE product  C[M, N] += A^T [seg_0 | seg_1]  over all T*B rows, plus the column sums of A.
+//
+// Why a kernel of its own (round 3): on a bf16-resident plan dA, h and (a padded copy of) x sit in HBM as bf16, ROW-major,
+// and the reduction runs over the rows -- both MFMA operands are "k-strided".  The grouped GEMM (gemm_bf16.hip) has to
+// transpose every tile through registers on its way into LDS and re-reads dA once per consumer (1.27 GB for ~0.4 GB of
+// operands at B=2048, 369 us: profiles/r02_roofline_table_l_bf16.txt).  Here nothing is transposed or converted in registers:
+//   * global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): the [32 rows][columns] slabs land in LDS in memory order,
+//     no staging registers, three chunks in flight per workgroup (counted vmcnt, raw s_barrier);
+//   * LDS -> MFMA fragments by ds_read_b64_tr_b16, the gfx950 transposing read: lane (bi, q) asks for 4 consecutive
+//     columns of row 4q + bi/4 and receives column bi of rows 4q .. 4q+3 (scripts/micro/glds_tr_probe.hip); two reads
+//     (rows +0, +16) make the 8-deep k slice of v_mfma_f32_16x16x32_bf16 -- A and B fragments use the same k assignment,
+//     and the MFMA sums over all of k;
+//   * a workgroup owns 96 columns of A and ALL N columns of the right-hand side for a range of rows, so A is read once and
+//     the right-hand side once per 96 A-columns -- from the SAME XCD's L2, because the M-tiles of one row range are
+//     consecutive workgroups of one XCD;
+//   * out-of-range DMA lanes write zeros (probed), so ragged row ranges and the t = 0 rows of h_{t-1} need no branches:
+//     their offsets are simply outside the buffer resource.
+// 512 threads = 8 waves as 2 (3 A fragments each) x 4 (N fragments, strided, <= 9 each): 27 accumulator tiles per wave.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "internal.h"
+
+namespace mfm {
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int DWB_THREADS = 512;
+constexpr int DWB_MF = 3;                       // A fragments per wave
+constexpr int DWB_MT = 2 * 16 * DWB_MF;         // A columns per workgroup: 96
+constexpr int DWB_NFW = 9;                      // N fragments per wave: N (padded) <= 16 * 4 * 9 = 576
+constexpr int DWB_KC = 32;                      // rows per chunk = one MFMA k-block
+constexpr int DWB_STAGES = 3;
+constexpr int DWB_MAXNI = 5;                    // LDS-DMA instructions per thread and chunk
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lds_base, int off, int row16_bytes) {
+  // two transposing reads: rows [0,16) and [16,32) of the chunk, 4 k each for this lane
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_base + off));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_base + off + row16_bytes));
+  const bf16x4 a = __builtin_bit_cast(bf16x4, lo), b = __builtin_bit_cast(bf16x4, hi);
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(DWB_THREADS) void dw_bf16_kernel(const DwbLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+
+  // ---- XCD-aware order: workgroup b runs on XCD b % 8; the M-tiles of one (item, row range) become consecutive
+  // workgroups of ONE XCD, so the right-hand side they all stream is fetched from HBM once and then hits that L2
+  int v;
+  {
+    const int nb = (int)gridDim.x, x = (int)blockIdx.x % 8, j = (int)blockIdx.x / 8;
+    const int per = nb / 8, rem = nb % 8;
+    v = x * per + (x < rem ? x : rem) + j;
+  }
+  int it = 0;
+#pragma unroll
+  for (int i = 1; i < MFM_DWB_MAXI; ++i) it += (i < L.n_items && v >= L.it[i].tile_begin) ? 1 : 0;
+  const DwbItem& I = L.it[it];
+  const int local = v - I.tile_begin;
+  const int mt = local % I.m_tiles, sp = local / I.m_tiles;
+  const int m0 = mt * DWB_MT;
+  const int r_begin = sp * I.rows_per_split, r_end = min(L.rows, r_begin + I.rows_per_split);
+  const int n_chunks = (r_end - r_begin + DWB_KC - 1) / DWB_KC;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bi = lane & 15, q = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- chunk image in LDS, in DMA piece order (16 bytes per piece, lane-linear): A [32][96] | seg0 [32][n0] | seg1 [32][n1]
+  const int n0 = I.seg[0].ncols, n1 = (I.nseg > 1) ? I.seg[1].ncols : 0;
+  const int pa = DWB_KC * DWB_MT / 8, p0 = DWB_KC * n0 / 8, p1 = DWB_KC * n1 / 8;      // pieces; each a multiple of 64
+  const int P = pa + p0 + p1;
+  const int NI = (P + DWB_THREADS - 1) / DWB_THREADS;
+  const int stage_bytes = NI * DWB_THREADS * 16;
+  const int NF = (n0 + n1) >> 4;
+
+  // ---- per-thread DMA plan: piece p = i * 512 + tid -> (image, row of the chunk, 8-column group).  Plain global addresses
+  // (global_load_dwordx4 ... lds), one 64-bit pointer per piece advanced by a per-piece stride each chunk; a piece that
+  // must read as zero -- rows of A at or beyond r_end, rows of h_{t-1} before the first time step, rows past the end of a
+  // segment, columns past a row's end, idle lanes of the last instruction -- is pointed at a 16-byte block of zeros.
+  const unsigned char* src[DWB_MAXNI];
+  int inc[DWB_MAXNI], row0[DWB_MAXNI], lo[DWB_MAXNI], hi[DWB_MAXNI];      // valid when lo <= row0 + 32 chunk < hi
+  const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(L.zeros);
+#pragma unroll
+  for (int i = 0; i < DWB_MAXNI; ++i) {
+    const int p = i * DWB_THREADS + tid;
+    src[i] = zsrc; inc[i] = 0; row0[i] = 0; lo[i] = 1; hi[i] = 0;          // never valid
+    if (p < pa) {
+      const int row = p / (DWB_MT / 8), c8 = p % (DWB_MT / 8);
+      if (m0 + c8 * 8 < I.lda) {                          // columns past the row end: zeros, not the next row's data
+        src[i] = reinterpret_cast<const unsigned char*>(I.a + (int64_t)(r_begin + row) * I.lda + m0 + c8 * 8);
+        inc[i] = DWB_KC * I.lda * 2; row0[i] = r_begin + row; lo[i] = 0; hi[i] = r_end;
+      }
+    } else if (p < P) {
+      // (both segments' fields are read with uniform indices and selected per lane: a divergent index into the kernel
+      // argument would turn every field into a vector load whose first use -- inside the time loop -- waits vmcnt(0))
+      const bool s1 = p >= pa + p0;
+      const __bf16* sp = s1 ? I.seg[1].p : I.seg[0].p;
+      const int sld = s1 ? I.seg[1].ld : I.seg[0].ld, sn = s1 ? n1 : n0, sc0 = s1 ? I.seg[1].col0 : I.seg[0].col0;
+      const int ssh = s1 ? I.seg[1].shift : I.seg[0].shift, srows = s1 ? I.seg[1].rows : I.seg[0].rows;
+      const int pp = p - pa - (s1 ? p0 : 0), g8 = sn / 8;
+      const int row = pp / g8, c8 = pp % g8;
+      // row r of the chunk pairs with row r - shift of the segment
+      src[i] = reinterpret_cast<const unsigned char*>(sp + (int64_t)(r_begin + row - ssh) * sld + sc0 + c8 * 8);
+      inc[i] = DWB_KC * sld * 2; row0[i] = r_begin + row - ssh; lo[i] = 0; hi[i] = srows;
+    }
+    // pin the plan in registers HERE: nothing of it may still be "in flight" for the compiler when the loop starts
+    asm volatile("" : "+v"(src[i]), "+v"(inc[i]), "+v"(row0[i]), "+v"(lo[i]), "+v"(hi[i]));
+  }
+  // live = false: the same NI instructions with every lane on the zero block -- the pipeline's tail keeps its instruction
+  // count, so the counted vmcnt waits stay valid
+  auto issue = [&](int chunk, int stage, bool live) {
+    unsigned char* base = dsm + stage * stage_bytes;
+#pragma unroll
+    for (int i = 0; i < DWB_MAXNI; ++i) {
+      if (i < NI) {                                       // NI is uniform: every wave issues the same NI instructions
+        const int row = row0[i] + chunk * DWB_KC;
+        const bool ok = live && row >= lo[i] && row < hi[i];
+        const unsigned char* g = ok ? src[i] + (int64_t)chunk * inc[i] : zsrc;
+        // inline asm on purpose: the compiler tracks an LDS-DMA builtin as a pending LDS write and drains it with
+        // vmcnt(0) before the next LDS read -- i.e. right behind the issue, which serialises the three-stage pipeline
+        // (seen in the ISA of the builtin form).  M0 = LDS byte address of THIS WAVE's lane 0 (the hardware adds 16 x the
+        // lane id inside the wave, not the thread id); one wait state after the M0 write.
+        const unsigned ldsaddr = (unsigned)(uintptr_t)(lds_void*)(base + i * DWB_THREADS * 16 + wave * 64 * 16);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(ldsaddr) : "memory", "m0");
+      }
+    }
+  };
+
+  // ---- fragment read offsets inside a stage (bytes): lane (bi, q) reads row 4q + bi/4, columns c .. c+3 with c = col0 + 4 (bi%4)
+  const int rrow = 4 * q + (bi >> 2), rcol = 4 * (bi & 3);
+  int a_off[DWB_MF];
+#pragma unroll
+  for (int i = 0; i < DWB_MF; ++i) a_off[i] = (rrow * DWB_MT + wm * 16 * DWB_MF + i * 16 + rcol) * 2;
+  int b_off[DWB_NFW], b_r16[DWB_NFW];
+  int njw = 0;
+#pragma unroll
+  for (int j = 0; j < DWB_NFW; ++j) {
+    const int nf = wn + 4 * j;
+    int n = nf * 16;
+    if (nf < NF) njw = j + 1;
+    if (n < n0) { b_off[j] = pa * 16 + (rrow * n0 + n + rcol) * 2; b_r16[j] = 16 * n0 * 2; }
+    else { n -= n0; b_off[j] = (pa + p0) * 16 + (rrow * max(n1, 16) + min(n, max(n1 - 16, 0)) + rcol) * 2; b_r16[j] = 16 * max(n1, 16) * 2; }
+  }
+  njw = __builtin_amdgcn_readfirstlane(njw);
+
+  f32x4 acc[DWB_MF][DWB_NFW], accb[DWB_MF];
+#pragma unroll
+  for (int i = 0; i < DWB_MF; ++i) {
+    accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < DWB_NFW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  const bool want_bias = (I.cb != nullptr) && (wn == 0);          // wave-uniform
+
+  // ---- pipeline: chunks c+1, c+2 in flight while chunk c is multiplied
+  issue(0, 0, true);
+  issue(1, 1, n_chunks > 1);
+  for (int c = 0; c < n_chunks; ++c) {
+    // chunk c = the older of the two outstanding groups: wait until only the younger group's NI instructions remain
+    if (NI == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (NI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (NI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (NI == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave's DMA of chunk c landed; chunk c-1 is consumed
+    issue(c + 2, (c + 2) % DWB_STAGES, c + 2 < n_chunks);
+    const unsigned char* st = dsm + (c % DWB_STAGES) * stage_bytes;
+    bf16x8 af[DWB_MF];
+#pragma unroll
+    for (int i = 0; i < DWB_MF; ++i) af[i] = tr_frag(st, a_off[i], 16 * DWB_MT * 2);
+    if (want_bias) {
+#pragma unroll
+      for (int i = 0; i < DWB_MF; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < DWB_NFW; ++j) {
+      if (j < njw) {                                      // scalar branch: njw is wave-uniform
+        const bf16x8 bf = tr_frag(st, b_off[j], b_r16[j]);
+#pragma unroll
+        for (int i = 0; i < DWB_MF; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the trailing dummies must land before the workgroup's LDS is released
+
+  // ---- add the tile into the gradient buffers.  Accumulator lane: rows (A columns) 4q + r, column bi of fragment j.
+  const int Hp = I.Hp, h = I.h;
+#pragma unroll
+  for (int j = 0; j < DWB_NFW; ++j) {
+    if (j >= njw) continue;
+    const int n = (wn + 4 * j) * 16 + bi;
+    float* dst = nullptr; float* dst2 = nullptr; int ldc = 0, col = 0;
+#pragma unroll
+    for (int o = 0; o < MFM_DWB_MAXOUT; ++o) {
+      if (o < I.nout && n >= I.out[o].n0 && n < I.out[o].n0 + I.out[o].nvalid) {
+        dst = I.out[o].c; dst2 = I.out[o].c2; ldc = I.out[o].ldc; col = n - I.out[o].n0;
+      }
+    }
+    if (!dst) continue;
+#pragma unroll
+    for (int i = 0; i < DWB_MF; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 16 * DWB_MF + i * 16 + 4 * q + r;
+        if (m >= I.M) continue;
+        const int g = m / Hp, u = m - g * Hp;
+        if (u >= h) continue;
+        const int64_t o = (int64_t)(g * h + u) * ldc + col;
+        atomicAdd(dst + o, acc[i][j][r]);
+        if (dst2) atomicAdd(dst2 + o, acc[i][j][r]);
+      }
+  }
+  if (want_bias && bi == 0) {
+#pragma unroll
+    for (int i = 0; i < DWB_MF; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 16 * DWB_MF + i * 16 + 4 * q + r;
+        if (m >= I.M) continue;
+        const int g = m / Hp, u = m - g * Hp;
+        if (u >= h) continue;
+        atomicAdd(I.cb + g * h + u, accb[i][r]);
+        if (I.cb2) atomicAdd(I.cb2 + g * h + u, accb[i][r]);
+      }
+  }
+}
+
+// x [rows, D] fp32 -> the bf16 image the kernel above streams: every modality slice padded to a multiple of 16 columns
+// (pad columns zero), row stride ldo
+struct XcvtArgs { const float* x; __bf16* out; int64_t rows; int D, ldo; int src0[3], n[3], dst0[3]; };
+__global__ __launch_bounds__(256) void x_to_bf16_kernel(const XcvtArgs A) {
+  const int64_t groups_per_row = A.ldo / 8;
+  const int64_t total = A.rows * groups_per_row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / groups_per_row;
+    const int c8 = (int)(i - r * groups_per_row) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c8 + e;
+      int src = -1;
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        if (c >= A.dst0[s] && c < A.dst0[s] + A.n[s]) src = A.src0[s] + (c - A.dst0[s]);
+      v[e] = src >= 0 ? A.x[r * A.D + src] : 0.0f;
+    }
+    const f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+    const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
+    *reinterpret_cast<bf16x8*>(A.out + r * A.ldo + c8) = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
+}  // namespace
+
+int x_to_bf16_launch(const float* x, void* out, int64_t rows, int D, int ldo, const int* src0, const int* n, const int* dst0,
+                     hipStream_t stream) {
+  MFM_REQUIRE(x && out && rows >= 1 && (ldo & 7) == 0, "x_to_bf16: bad arguments");
+  XcvtArgs A;
+  A.x = x; A.out = reinterpret_cast<__bf16*>(out); A.rows = rows; A.D = D; A.ldo = ldo;
+  for (int s = 0; s < 3; ++s) { A.src0[s] = src0[s]; A.n[s] = n[s]; A.dst0[s] = dst0[s]; }
+  const int64_t total = rows * (ldo / 8);
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(x_to_bf16_kernel, dim3(blocks), dim3(256), 0, stream, A);
+  MFM_LAUNCH_CHECK("x_to_bf16_kernel");
+  return MFM_OK;
+}
+
+int dw_bf16_supported(const DwbItem& I) {
+  if (!I.a || I.nseg < 1 || I.nseg > 2 || I.nout < 1 || I.nout > MFM_DWB_MAXOUT) return 0;
+  int np = 0;
+  for (int s = 0; s < I.nseg; ++s) {
+    if (!I.seg[s].p || (I.seg[s].ncols & 15) || I.seg[s].ncols < 16 || (I.seg[s].ld & 7) || (I.seg[s].col0 & 7)) return 0;
+    if ((((uintptr_t)I.seg[s].p) & 15) != 0) return 0;
+    np += I.seg[s].ncols;
+  }
+  if (np > 16 * 4 * DWB_NFW) return 0;
+  if ((I.lda & 7) || (((uintptr_t)I.a) & 15) != 0 || I.M < 1 || I.Hp < I.h || I.h < 1) return 0;
+  const int P = DWB_KC * (DWB_MT + np) / 8;
+  if ((P + DWB_THREADS - 1) / DWB_THREADS > DWB_MAXNI) return 0;
+  return 1;
+}
+
+// 256 bytes of zeros per device for the DMA lanes that must read as zero (allocated once per device, never freed: the one
+// exception to "the caller owns every buffer" in this library, next to the P2P staging blocks)
+static const void* zero_block() {
+  static void* z[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!z[dev]) {
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 256) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    z[dev] = p;
+  }
+  return z[dev];
+}
+
+int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
+  MFM_REQUIRE(L.n_items >= 1 && L.n_items <= MFM_DWB_MAXI && L.rows >= 1, "dw bf16: bad launch");
+  if (!L.zeros) L.zeros = zero_block();
+  MFM_REQUIRE(L.zeros, "dw bf16: no zero block");
+  double wsum = 0.0;
+  for (int i = 0; i < L.n_items; ++i) {
+    DwbItem& I = L.it[i];
+    MFM_REQUIRE(dw_bf16_supported(I), "dw bf16: item %d is not supported", i);
+    MFM_REQUIRE((int64_t)L.rows * I.lda * 2 < ((int64_t)1 << 31), "dw bf16: A spans >= 2^31 bytes");
+    for (int s = 0; s < I.nseg; ++s)
+      MFM_REQUIRE((int64_t)I.seg[s].rows * I.seg[s].ld * 2 < ((int64_t)1 << 31) && I.seg[s].shift >= 0, "dw bf16: segment %d spans >= 2^31 bytes", s);
+    I.m_tiles = (I.M + DWB_MT - 1) / DWB_MT;
+    int N = 0;
+    for (int s = 0; s < I.nseg; ++s) N += I.seg[s].ncols;
+    wsum += (double)I.m_tiles * (1.0 + N / 128.0);
+  }
+  // one workgroup per CU (the three chunk stages fill the LDS): row ranges sized so that the launch is ~3 rounds of
+  // workgroups, a range's cost taken as (fixed part + N / 128) per chunk (profiles/r02_dw_onepass.txt)
+  double target = 3.0 * device_cus();
+  if (const char* e = getenv("MFM_DWB_TARGET")) target = atof(e) * device_cus();
+  int tiles = 0;
+  size_t smem = 0;
+  for (int i = 0; i < L.n_items; ++i) {
+    DwbItem& I = L.it[i];
+    int N = 0;
+    for (int s = 0; s < I.nseg; ++s) N += I.seg[s].ncols;
+    int splits = (int)(target * (1.0 + N / 128.0) / wsum + 0.5);
+    const int max_splits = std::max(1, L.rows / (4 * DWB_KC));
+    splits = std::max(1, std::min(splits, max_splits));
+    I.rows_per_split = ((L.rows + splits - 1) / splits + DWB_KC - 1) / DWB_KC * DWB_KC;
+    I.splits = (L.rows + I.rows_per_split - 1) / I.rows_per_split;
+    I.tile_begin = tiles;
+    tiles += I.m_tiles * I.splits;
+    const int P = DWB_KC * (DWB_MT + N) / 8;
+    const int NI = (P + DWB_THREADS - 1) / DWB_THREADS;
+    smem = std::max(smem, (size_t)DWB_STAGES * NI * DWB_THREADS * 16);
+  }
+  static bool attr = false;
+  if (!attr) {
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  MFM_REQUIRE(smem <= 160 * 1024, "dw bf16: %zu bytes of LDS", smem);
+  hipLaunchKernelGGL(dw_bf16_kernel, dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
+  MFM_LAUNCH_CHECK("dw_bf16_kernel");
+  return MFM_OK;
+}
+
+}  // namespace mfm
+
+// Test / tuning entry point (not used by the plan, which builds DwbLaunch itself): one LSTM's weight gradients from
+// bf16-resident buffers.  dA [rows, 4 Hp] bf16, xb [rows, ldx] bf16 (columns [0, dx) used, dx padded to 16 by the caller's
+// layout), hs [rows, Hp] bf16 (row r pairs with hs[r - shift]); outputs fp32, accumulated into.
+extern "C" int mfm_dw_bf16_lstm(const void* dA, int32_t rows, int32_t h, const void* xb, int32_t ldx, int32_t dx,
+                                const void* hs, int32_t shift, float* dw_ih, float* dw_hh, float* dw_hh2, float* db_ih,
+                                float* db_hh, void* stream) {
+  using namespace mfm;
+  MFM_REQUIRE(dA && hs && dw_hh && rows >= 1 && h >= 1, "mfm_dw_bf16_lstm: bad arguments");
+  const int Hp = round_up(h, 16);
+  DwbLaunch L;
+  memset(&L, 0, sizeof(L));
+  L.rows = rows; L.n_items = 1;
+  DwbItem& I = L.it[0];
+  I.a = reinterpret_cast<const __bf16*>(dA); I.lda = 4 * Hp; I.M = 4 * Hp; I.Hp = Hp; I.h = h;
+  int n = 0;
+  if (xb) {
+    MFM_REQUIRE(dw_ih && dx >= 1, "mfm_dw_bf16_lstm: x given without dw_ih / dx");
+    I.seg[I.nseg].p = reinterpret_cast<const __bf16*>(xb); I.seg[I.nseg].ld = ldx; I.seg[I.nseg].ncols = round_up(dx, 16);
+    I.seg[I.nseg].col0 = 0; I.seg[I.nseg].shift = 0; I.seg[I.nseg].rows = rows; ++I.nseg;
+    I.out[I.nout].n0 = 0; I.out[I.nout].nvalid = dx; I.out[I.nout].c = dw_ih; I.out[I.nout].ldc = dx; ++I.nout;
+    n = round_up(dx, 16);
+  }
+  I.seg[I.nseg].p = reinterpret_cast<const __bf16*>(hs); I.seg[I.nseg].ld = Hp; I.seg[I.nseg].ncols = Hp;
+  I.seg[I.nseg].col0 = 0; I.seg[I.nseg].shift = shift; I.seg[I.nseg].rows = rows; ++I.nseg;
+  I.out[I.nout].n0 = n; I.out[I.nout].nvalid = h; I.out[I.nout].c = dw_hh; I.out[I.nout].c2 = dw_hh2; I.out[I.nout].ldc = h; ++I.nout;
+  I.cb = db_ih; I.cb2 = db_hh;
+  if (!dw_bf16_supported(I)) { set_error("mfm_dw_bf16_lstm: shape not supported (h=%d dx=%d ldx=%d)", h, dx, ldx); return MFM_ERR_UNSUPPORTED; }
+  return dw_bf16_launch(L, (hipStream_t)stream);
+}

@@ -91,6 +91,27 @@ struct DwLaunch { DwItem it[MFM_DW_MAXI]; int n_items, rows; };
 int dw_onepass_supported(const DwItem& I, int precision);
 int dw_onepass_launch(DwLaunch& L, int precision, hipStream_t stream);
 
+// dw_bf16.hip -- bf16-RESIDENT plans: every sum over the T*B rows that feeds an LSTM's (or a decoder fc1's) weight gradient
+// as one product C[M, N] += A^T [seg0 | seg1] per item, operands streamed by LDS-DMA and read with transposing LDS reads
+#define MFM_DWB_MAXI 12
+#define MFM_DWB_MAXOUT 4
+struct DwbSeg { const __bf16* p; int ld, ncols, col0, shift, rows, pad_; };   // columns [col0, col0 + ncols) of a [rows, ld] bf16 buffer; chunk row r reads row r - shift
+struct DwbOut { int n0, nvalid; float* c; float* c2; int ldc, pad_; };          // columns [n0, n0 + nvalid) of [seg0 | seg1] -> C[:, 0 .. nvalid) (row stride ldc)
+struct DwbItem {
+  const __bf16* a; int lda, M;          // A [rows, lda] bf16, columns [0, M) walked
+  int Hp, h;                            // A column m = g * Hp + u is a real unit when u < h, and then row g * h + u of C
+  int nseg, nout;
+  DwbSeg seg[2]; DwbOut out[MFM_DWB_MAXOUT];
+  float* cb; float* cb2;                // optional: column sums of A (bias gradients), indexed like the rows of C
+  int tile_begin, m_tiles, splits, rows_per_split;     // filled by dw_bf16_launch
+};
+struct DwbLaunch { DwbItem it[MFM_DWB_MAXI]; int n_items, rows; const void* zeros; };   // zeros: >= 16 bytes of device zeros (null: the launcher's own)
+int dw_bf16_supported(const DwbItem& I);
+int dw_bf16_launch(DwbLaunch& L, hipStream_t stream);
+// x [rows, D] fp32 -> bf16 [rows, ldo] with up to three column ranges moved to 16-aligned positions (pad columns zero)
+int x_to_bf16_launch(const float* x, void* out, int64_t rows, int D, int ldo, const int* src0, const int* n, const int* dst0,
+                     hipStream_t stream);
+
 // elementwise.hip
 struct MseItem {
   const float* xhat; const float* x; float* dxhat; float* loss_slot;

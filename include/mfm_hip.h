@@ -133,6 +133,18 @@ int mfm_lstm_seq_bwd_bf16(const MfmSeqDesc* descs /*host*/, int count, int T, in
 int mfm_lstm_seq_bwd(const MfmSeqDesc* descs /*host*/, int count, int T, int B, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * bf16-RESIDENT plans: all weight gradients of ONE LSTM from bf16 buffers in one pass over the gate gradients
+ * (csrc/dw_bf16.hip; what autograd accumulates into weight_ih / weight_hh / bias_ih / bias_hh of an nn.LSTMCell unrolled
+ * over T, reference mfm_model.py:56,83,85):
+ *   dw_ih [4h, dx] += sum_r dA[r]^T xb[r, :dx]      dw_hh [4h, h] (and dw_hh2) += sum_{r >= shift} dA[r]^T hs[r - shift]
+ *   db_ih, db_hh [4h] += sum_r dA[r]
+ * dA [rows, 4, Hp] bf16 (pad units zero), xb [rows, ldx] bf16 with ldx >= round_up(dx, 16) (NULL: no input product --
+ * the decoders, whose step input is h_{t-1}: pass dw_hh2 = dW_ih), hs [rows, Hp] bf16, shift = B (one time step).
+ * Test / tuning entry point; the fused plan builds the same launch for all LSTMs and the decoders' fc1 at once. */
+int mfm_dw_bf16_lstm(const void* dA, int32_t rows, int32_t h, const void* xb, int32_t ldx, int32_t dx, const void* hs,
+                     int32_t shift, float* dw_ih, float* dw_hh, float* dw_hh2, float* db_ih, float* db_hh, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Reconstruction loss + gradient, replaces nn.MSELoss over x_hat vs the input slices and its
  * backward (mfm_mosi.py:412,437):  loss_slot += sum((xhat-x)^2) * inv_count (un-weighted mean),
  * dxhat = grad_scale * (xhat - x).  x is a column slice of the [T,B,D] batch (row stride ldx).

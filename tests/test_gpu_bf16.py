@@ -374,6 +374,47 @@ def test_bf16_resident_flags_refused_by_fp32_entry_point(eng):
     assert _lib.lib().mfm_gemm_grouped_f32(arr, 1, None) != 0
 
 
+@pytest.mark.parametrize("h,dx,rows,shift", [(120, 325, 640, 32), (32, 300, 640, 32), (8, 5, 100, 5), (80, 20, 4580, 229),
+                                             (104, 0, 640, 32), (24, 0, 37, 37), (120, 325, 20480, 1024), (36, 37, 171, 19)])
+def test_bf16_resident_weight_gradients_one_pass(eng, h, dx, rows, shift):
+    """dw_bf16_kernel: dW_ih, dW_hh (+ the decoders' second target), db from bf16-resident dA / x / h in ONE pass: LDS-DMA
+    slabs in memory order, transposing LDS reads, ragged row ranges and the t = 0 rows of h_{t-1} as zero-filled DMA lanes.
+    Products of bf16 values are exact, so the fp64 reference over the stored values must match to fp32 summation error."""
+    import ctypes as C
+    from factorized_amd import _lib
+    rs = np.random.RandomState(h + dx + rows)
+    Hp = (h + 15) // 16 * 16
+    dA = np.zeros((rows, 4, Hp), dtype=np.float32)
+    dA[:, :, :h] = rs.normal(size=(rows, 4, h))
+    hs = np.zeros((rows, Hp), dtype=np.float32)
+    hs[:, :h] = rs.normal(size=(rows, h))
+    da_d, hs_d = bfd(dA), bfd(hs)
+    ldx = (dx + 15) // 16 * 16 + 8 if dx else 0
+    xb_d = None
+    if dx:
+        xb = rs.normal(size=(rows, ldx)).astype(np.float32)        # columns >= dx hold junk on purpose
+        xb_d = bfd(xb)
+    dw_ih = torch.full((4 * h, max(dx, 1)), 0.5, device="cuda")
+    dw_hh = torch.full((4 * h, h), 0.25, device="cuda")
+    dw_hh2 = torch.zeros(4 * h, h, device="cuda")
+    db1, db2 = torch.zeros(4 * h, device="cuda"), torch.full((4 * h,), 1.0, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    _lib.check(_lib.lib().mfm_dw_bf16_lstm(p(da_d), rows, h, p(xb_d), ldx, dx, p(hs_d), shift, p(dw_ih) if dx else C.c_void_p(0),
+                                           p(dw_hh), p(dw_hh2), p(db1), p(db2), None), "mfm_dw_bf16_lstm")
+    A = b2n(da_d)[:, :, :h].reshape(rows, 4 * h)
+    H = b2n(hs_d)[:, :h]
+    ref_hh = A[shift:].T @ H[:rows - shift] if rows > shift else np.zeros((4 * h, h))
+    scale = max(np.abs(ref_hh).max(), 1.0)
+    assert np.abs(dw_hh.cpu().numpy() - 0.25 - ref_hh).max() < 2e-5 * scale
+    assert np.abs(dw_hh2.cpu().numpy() - ref_hh).max() < 2e-5 * scale
+    ref_b = A.sum(0)
+    assert np.abs(db1.cpu().numpy() - ref_b).max() < 2e-5 * max(np.abs(ref_b).max(), 1.0)
+    assert np.abs(db2.cpu().numpy() - 1.0 - ref_b).max() < 2e-5 * max(np.abs(ref_b).max(), 1.0)
+    if dx:
+        ref_ih = A.T @ b2n(xb_d)[:, :dx]
+        assert np.abs(dw_ih.cpu().numpy() - 0.5 - ref_ih).max() < 2e-5 * max(np.abs(ref_ih).max(), 1.0)
+
+
 def test_bf16_lstm_seq_four_in_one_launch_matches_single_launches(eng):
     """the four encoders of the plan (h = 32, 8, 80, 120) in one call == each alone, bit for bit"""
     rs = np.random.RandomState(3)
