@@ -130,6 +130,7 @@ _SIGS = {
                                              C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(AdamSpan),
                                              C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mfm_plan_latent_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "mfm_plan_seq_layout": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "mfm_plan_mfn_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mfm_plan_flops_per_step": (C.c_double, [C.c_void_p]),
     "mfm_plan_bytes_per_step": (C.c_double, [C.c_void_p]),

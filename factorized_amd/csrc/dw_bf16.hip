@@ -44,7 +44,7 @@ constexpr int DWB_MT = 2 * 16 * DWB_MF;         // A columns per workgroup: 96
 constexpr int DWB_NFW = 9;                      // N fragments per wave: N (padded) <= 16 * 4 * 9 = 576
 constexpr int DWB_KC = 32;                      // rows per chunk = one MFMA k-block
 constexpr int DWB_STAGES = 3;
-constexpr int DWB_MAXNI = 5;                    // LDS-DMA instructions per thread and chunk
+constexpr int DWB_MAXNI = 6;                    // LDS-DMA instructions per thread and chunk
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lds_base, int off, int row16_bytes) {
   // two transposing reads: rows [0,16) and [16,32) of the chunk, 4 k each for this lane
@@ -175,7 +175,8 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_bf16_kernel(const DwbLaunch L)
   issue(1, 1, n_chunks > 1);
   for (int c = 0; c < n_chunks; ++c) {
     // chunk c = the older of the two outstanding groups: wait until only the younger group's NI instructions remain
-    if (NI == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    if (NI == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (NI == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if (NI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if (NI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if (NI == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");

@@ -72,7 +72,9 @@ __global__ __launch_bounds__(256, (FR == 1) ? 4 : 2) void gemm_bf16_kernel(const
   const bool a_mcontig = (d.a_sm == 1 && d.a_sk != 1);
   const bool b_ncontig = (d.b_sn == 1 && d.b_sk != 1);
   const int a_sm = (int)d.a_sm, a_sk = (int)d.a_sk, b_sk = (int)d.b_sk, b_sn = (int)d.b_sn;
-  const int a_bytes = ((d.m - 1) * a_sm + (max(d.k, 1) - 1) * a_sk + 1) * (a16 ? 2 : 4);
+  // (bf16: rounded up to whole dwords -- the range check is per dword, an odd element count would zero the last element)
+  const int a_bytes = a16 ? ((((d.m - 1) * a_sm + (max(d.k, 1) - 1) * a_sk + 1) * 2 + 3) & ~3)
+                          : ((d.m - 1) * a_sm + (max(d.k, 1) - 1) * a_sk + 1) * 4;
   const int b_bytes = ((max(d.k, 1) - 1) * b_sk + (max(d.n_valid, 1) - 1) * b_sn + 1) * 4;
   const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc((void*)Bm, 0, b_bytes, 0x00020000);

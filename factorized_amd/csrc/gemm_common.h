@@ -97,8 +97,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmGroup& g, const MfmGemmD
             const float diff = v - tgt[fm % TF][fn % TF][r];
             sq += diff * diff;
             if (me.dxhat) {
-              if (me.dxhat_bf16) reinterpret_cast<__bf16*>(me.dxhat)[off] = (__bf16)(me.grad_scale * diff);
-              else me.dxhat[off] = me.grad_scale * diff;
+              const int64_t doff = me.ld_dxhat ? (int64_t)row * me.ld_dxhat + col : off;
+              if (me.dxhat_bf16) reinterpret_cast<__bf16*>(me.dxhat)[doff] = (__bf16)(me.grad_scale * diff);
+              else me.dxhat[doff] = me.grad_scale * diff;
             }
           }
         }

@@ -17,7 +17,8 @@ struct GemmEpi { float* aux; float p; int kind; unsigned op_id; int pad_; };
 struct GemmEpiSet { const GemmEpi* epi; int count; unsigned long long seed; int train; };
 struct MseEpi {          // squared-error epilogue of one product: target, d(output), loss slot, scales
   const float* x; int64_t ldx; float* dxhat; float* loss; float inv_count, grad_scale;
-  int dxhat_bf16, pad_;  // dxhat is a __bf16 buffer (bf16-resident plans)
+  int dxhat_bf16;        // dxhat is a __bf16 buffer (bf16-resident plans)
+  int ld_dxhat;          // row stride of dxhat in elements (0: that of the product's C)
 };
 // precision: 0 = fp32 operands on v_mfma_f32_16x16x4_f32, 1 = operands rounded to bf16 on the way into LDS,
 // v_mfma_f32_16x16x32_bf16 with fp32 accumulation (gemm_bf16.hip)

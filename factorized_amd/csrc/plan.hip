@@ -123,6 +123,12 @@ struct MfmPlan {
   uint64_t calls;
   const float* grads_prezeroed;     // gradient buffer cleared by the forward pass of the running fused step
   int fold_state = 0;               // encoder + latent fold launches (lstm_seq_small.hip): 0 untried, 1 in use, -1 not applicable
+  // ---- bf16 plans (decided once, when the plan is built)
+  bool seq_bf16 = false;            // the recurrences run on the bf16 MFMA kernels (lstm_seq_bf16.hip)
+  bool st16 = false;                // bf16-RESIDENT saved activations: gates / dA, hs, dH, d x_hat live in HBM as bf16 (round 3)
+  int64_t h_last[6];                // st16: fp32 copy of h_{T-1} per encoder [B, Hp] (the latent stack / the MFN heads read it)
+  int64_t x16; int x16_ld, x16_off[3];   // st16: bf16 image of the batch [T*B, x16_ld], every modality slice on a 16-column boundary
+  int dxh_ld[3];                    // st16: row stride of the bf16 d x_hat buffers
   unsigned long long fc1_bwd_call = ~0ull;   // value of `calls` for which the forward already produced dH of the decoders (dec_fc1.hip)
 };
 
@@ -155,16 +161,40 @@ static int build(MfmPlan* P) {
   int64_t cur = 0;
   const int64_t TB = (int64_t)c.T * c.B;
   P->n_enc = (V == 0) ? 4 : 6;
+  // bf16 plans: kernel family of the recurrences, and whether the saved activations are bf16-resident.  bf16-resident needs the
+  // bf16 recurrences for every LSTM (h <= 128: the step-by-step path of wider ones is fp32) and shapes the one-pass
+  // weight-gradient kernel takes (dw_bf16.hip); MFM_BF16_STORE=0 keeps the round-2 form (fp32 buffers, rounding on load).
+  P->seq_bf16 = c.precision && bf16_seq_pays(c.B);
+  {
+    bool ok = P->seq_bf16 && !getenv("MFM_SEQ_STEPWISE") && !(getenv("MFM_BF16_STORE") && atoi(getenv("MFM_BF16_STORE")) == 0);
+    const int Dp = round_up(c.d_l, 16) + round_up(c.d_a, 16) + round_up(c.d_v, 16);
+    int hmax = 0, np_max = 0;
+    for (int e = 0; e < P->n_enc; ++e) {
+      int h, xc;
+      if (e < 3) { h = (e == 0 ? c.zl : (e == 1 ? c.za : c.zv)); xc = round_up(dd[e], 16); }
+      else if (V == 0) { h = ze; xc = Dp; }
+      else { h = mh[e - 3]; xc = round_up(dd[e - 3], 16); }
+      hmax = std::max(hmax, h);
+      np_max = std::max(np_max, xc + round_up(h, 16));
+    }
+    for (int m = 0; m < 3; ++m) hmax = std::max(hmax, c.fy + fm[m]);
+    ok = ok && hmax <= MFM_SEQ_MAX_RESIDENT_H && np_max <= 576 && (32 * (96 + np_max) / 8 + 511) / 512 <= 6;
+    ok = ok && TB * 4 * round_up(hmax, 16) * 2 < ((int64_t)1 << 31) && TB * Dp * 2 < ((int64_t)1 << 31);
+    P->st16 = ok;
+    if (getenv("MFM_PLAN_DEBUG")) fprintf(stderr, "[mfm plan] bf16: recurrences on the bf16 kernels %d, bf16-resident activations %d\n", (int)P->seq_bf16, (int)P->st16);
+  }
+  const int ESH = P->st16 ? 2 : 1;          // bf16-resident buffers take half the floats
   for (int e = 0; e < P->n_enc; ++e) {
     if (e < 3) { P->enc_d[e] = dd[e]; P->enc_xoff[e] = dx[e]; P->enc_h[e] = (e == 0 ? c.zl : (e == 1 ? c.za : c.zv)); P->enc_p[e] = pi.enc[e]; }
     else if (V == 0) { P->enc_d[e] = P->D; P->enc_xoff[e] = 0; P->enc_h[e] = ze; P->enc_p[e] = pi.enc[3]; }
     else { P->enc_d[e] = dd[e - 3]; P->enc_xoff[e] = dx[e - 3]; P->enc_h[e] = mh[e - 3]; P->enc_p[e] = pi.mfl[e - 3]; }
     SeqBuf& s = P->enc[e];
     s.h = P->enc_h[e]; s.Hp = round_up(s.h, 16);
-    s.gates = carve(cur, TB * 4 * s.Hp);
-    s.hs = carve(cur, TB * s.Hp);
+    s.gates = carve(cur, TB * 4 * s.Hp / ESH);
+    s.hs = carve(cur, TB * s.Hp / ESH);
     s.cs = carve(cur, TB * s.Hp);
     s.wpack = c.precision ? carve(cur, mfm_lstm_pack_bytes(s.h, 0) / 4) : -1;
+    P->h_last[e] = P->st16 ? carve(cur, (int64_t)c.B * s.Hp) : -1;
     if (e < 4) P->dh_last[e] = -1;
     if (e < 3 || V == 0) P->dh_last[e] = carve(cur, (int64_t)c.B * P->enc_h[e]);
   }
@@ -172,18 +202,27 @@ static int build(MfmPlan* P) {
     P->dec_d[m] = dd[m]; P->dec_h[m] = c.fy + fm[m]; P->dec_p[m] = pi.dec[m]; P->dec_xoff[m] = dx[m];
     SeqBuf& s = P->dec[m];
     s.h = P->dec_h[m]; s.Hp = round_up(s.h, 16);
-    s.gates = carve(cur, TB * 4 * s.Hp);
-    s.hs = carve(cur, TB * s.Hp);
+    s.gates = carve(cur, TB * 4 * s.Hp / ESH);
+    s.hs = carve(cur, TB * s.Hp / ESH);
     s.cs = carve(cur, TB * s.Hp);
     s.wpack = c.precision ? carve(cur, mfm_lstm_pack_bytes(s.h, 1) / 4) : -1;
     P->dec_init[m] = carve(cur, (int64_t)c.B * s.h);
     P->dec_dinit[m] = carve(cur, (int64_t)c.B * s.h);
     P->xhat[m] = carve(cur, TB * dd[m]);
-    P->dxhat[m] = carve(cur, TB * dd[m]);
+    // st16: d x_hat as bf16 with rows padded to 8 columns (16-byte rows; the pad columns are never written and stay zero)
+    P->dxh_ld[m] = P->st16 ? round_up(dd[m], 8) : dd[m];
+    P->dxhat[m] = carve(cur, TB * P->dxh_ld[m] / ESH);
   }
   P->dhs_blk = cur;                                // one block: the fused fc1 kernel adds into it (dec_fc1.hip), zero span 3
-  for (int m = 0; m < 3; ++m) P->dec_dhs[m] = carve(cur, TB * P->dec[m].Hp);
+  for (int m = 0; m < 3; ++m) P->dec_dhs[m] = carve(cur, TB * P->dec[m].Hp / ESH);
   P->dhs_len = cur - P->dhs_blk;
+  P->x16 = -1; P->x16_ld = 0;
+  if (P->st16) {
+    int at = 0;
+    for (int m = 0; m < 3; ++m) { P->x16_off[m] = at; at += round_up(dd[m], 16); }
+    P->x16_ld = at;
+    P->x16 = carve(cur, TB * P->x16_ld / 2);
+  }
   // ---- Memory Fusion Network (variants 1, 2): every [T*B, .] tensor of the attention block and the memory recurrence
   P->tot = P->A2 = P->nzy = 0;
   if (V != 0) {
@@ -501,6 +540,7 @@ static MfmSeqDesc seq_desc(const MfmPlan* P, const SeqBuf& sb, int pbase, const 
   d.b_hh = params + P->off[pbase + B_HH];
   d.h = sb.h; d.is_dec = dec ? 1 : 0;
   if (sb.wpack >= 0 && sb.h <= MFM_SEQ_MAX_RESIDENT_H) d.w_pack = W + sb.wpack;   // bf16 plans: fragments packed by K_PACK
+  d.store_bf16 = P->st16 ? 1 : 0;
   return d;
 }
 
@@ -553,7 +593,8 @@ static bool mfn_heads_desc(const MfmPlan* P, const float* params, float* W, MfnH
   H.tot = P->tot; H.nheads = (c.variant == 1) ? 2 : 1; H.zy = c.zy; H.nzy = P->nzy;
   for (int m = 0; m < 3; ++m) {
     const SeqBuf& sb = P->enc[3 + m];
-    H.seg[m] = W + sb.hs + (int64_t)(P->T - 1) * P->B * sb.Hp; H.seg_ld[m] = sb.Hp; H.seg_n[m] = sb.h;
+    H.seg[m] = P->st16 ? W + P->h_last[3 + m] : W + sb.hs + (int64_t)(P->T - 1) * P->B * sb.Hp;
+    H.seg_ld[m] = sb.Hp; H.seg_n[m] = sb.h;
   }
   H.w[0] = PW(P, params, pi.to_z[3]); H.b[0] = PW(P, params, pi.to_z[3] + 1);
   if (H.nheads == 2) { H.w[1] = PW(P, params, pi.to_lv[3]); H.b[1] = PW(P, params, pi.to_lv[3] + 1); }
@@ -667,7 +708,7 @@ static int mfn_forward(MfmPlan* P, const float* params, int train, uint64_t seed
         const SeqBuf* sb = sg < 3 ? &P->enc[3 + sg] : nullptr;
         MfmGemmDesc d;
         memset(&d, 0, sizeof(d));
-        d.a = sb ? W + sb->hs + (int64_t)(T - 1) * B * sb->Hp : W + P->mem_out;
+        d.a = sb ? (P->st16 ? W + P->h_last[3 + sg] : W + sb->hs + (int64_t)(T - 1) * B * sb->Hp) : W + P->mem_out;
         d.a_sm = sb ? sb->Hp : M; d.a_sk = 1;
         const int k = sb ? sb->h : M;
         d.b = PW(P, params, widx) + koff; d.b_sn = P->tot + M; d.b_sk = 1;
@@ -711,12 +752,13 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
   const bool fc1_env_on = !(getenv("MFM_FC1_FUSED") && atoi(getenv("MFM_FC1_FUSED")) == 0);
   long fc1_max_rows = 5120;                        // measured crossover (profiles/r02_dec_fc1.txt)
   if (const char* e = getenv("MFM_FC1_FUSED_MAXROWS")) fc1_max_rows = atol(e);
-  const bool fc1_fused = fc1_env_on && TB <= fc1_max_rows;
+  const bool fc1_fused = fc1_env_on && TB <= fc1_max_rows && !P->st16;      // (the fused kernel reads fp32 hidden states)
   if (fc1_fused && train) { zs.ptr[3] = W + P->dhs_blk; zs.n[3] = P->dhs_len; }
   P->calls++;
 
   // bf16 plans: the recurrences' weight fragments, rounded and packed once per step (lstm_seq_bf16.hip)
-  const bool seq_bf16 = c.precision && bf16_seq_pays(B);
+  const bool seq_bf16 = P->seq_bf16;
+  const bool st16 = P->st16;
   if (seq_bf16) {
     MfmSeqDesc q[9];
     int n = 0;
@@ -736,6 +778,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       d.a = x + P->enc_xoff[e]; d.a_sm = P->D; d.a_sk = 1; d.a_sz = 0;
       d.b = params + P->off[pb + W_IH]; d.b_sz = (int64_t)sb.h * P->enc_d[e]; d.b_sn = P->enc_d[e]; d.b_sk = 1;
       d.c = W + sb.gates; d.c_sz = sb.Hp; d.ldc = 4 * (int64_t)sb.Hp;
+      d.c_bf16 = st16 ? 1 : 0;                        // bf16-resident x-projection (same element offsets)
       d.bias = params + P->off[pb + B_IH]; d.bias2 = params + P->off[pb + B_HH]; d.bias_sz = sb.h;
       d.m = (int)TB; d.n = sb.Hp; d.n_valid = sb.h; d.k = P->enc_d[e]; d.batch = 4; d.split_k = 1;
       d.alpha = 1.0f;
@@ -757,7 +800,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
         PanelGroup& G = PL.g[PL.ngroups++];
         G.w = params + P->off[pb + W_IH]; G.ldw = P->enc_d[e];
         G.bias = params + P->off[pb + B_IH]; G.bias2 = params + P->off[pb + B_HH];
-        G.c = W + sb.gates; G.ldc = 4 * (int64_t)sb.Hp;
+        G.c = W + sb.gates; G.ldc = 4 * (int64_t)sb.Hp; G.c_bf16 = st16 ? 1 : 0;
         G.n = 4 * sb.Hp; G.seg = sb.Hp; G.seg_valid = sb.h; G.k_off = P->enc_xoff[e]; G.k_len = P->enc_d[e];
       }
       if (gemm_panel_pays(PL, c.precision, panel_forced)) RUN(K_PROJ, gemm_panel_launch(PL, &zs, c.precision, panel_forced, s));
@@ -775,7 +818,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     if (getenv("MFM_LATENT_DBG")) L.dbg = reinterpret_cast<unsigned long long*>(W + P->dbg_off);
     for (int e = 0; e < 4; ++e) {
       if (e == 3 && V != 0) { L.enc_h[e] = W + P->zyin; L.enc_ld[e] = P->nzy; continue; }
-      L.enc_h[e] = W + P->enc[e].hs + (int64_t)(T - 1) * B * P->enc[e].Hp;
+      L.enc_h[e] = st16 ? W + P->h_last[e] : W + P->enc[e].hs + (int64_t)(T - 1) * B * P->enc[e].Hp;
       L.enc_ld[e] = P->enc[e].Hp;
     }
     for (int m = 0; m < 3; ++m) { L.dec_init[m] = W + P->dec_init[m]; L.dec_ld[m] = P->dec_h[m]; }
@@ -800,7 +843,10 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
   for (int e0 = 0; e0 < P->n_enc && !folded; e0 += MFM_MAX_SEQ) {
     MfmSeqDesc q[MFM_MAX_SEQ];
     const int n = std::min(MFM_MAX_SEQ, P->n_enc - e0);
-    for (int e = 0; e < n; ++e) q[e] = seq_desc(P, P->enc[e0 + e], P->enc_p[e0 + e], params, W, false);
+    for (int e = 0; e < n; ++e) {
+      q[e] = seq_desc(P, P->enc[e0 + e], P->enc_p[e0 + e], params, W, false);
+      if (st16) q[e].h_last = W + P->h_last[e0 + e];
+    }
     RUN(K_ENC_FWD, seq_bf16 ? mfm_lstm_seq_fwd_bf16(q, n, T, B, s) : mfm_lstm_seq_fwd(q, n, T, B, s));
   }
   if (V != 0) {
@@ -844,9 +890,11 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       const int pb = P->dec_p[m];
       xh[m] = (xhat_out && xhat_out[m]) ? xhat_out[m] : W + P->xhat[m];
       MfmGemmDesc& d = g[m];
-      d.a = W + sb.hs; d.a_sm = sb.Hp; d.a_sk = 1;
+      d.a = W + sb.hs; d.a_sm = sb.Hp; d.a_sk = 1; d.a_bf16 = st16 ? 1 : 0;
       d.b = params + P->off[pb + FC_W]; d.b_sn = sb.h; d.b_sk = 1;
       d.c = xh[m]; d.ldc = P->dec_d[m];
+      // bf16-resident training steps need the squared error and d x_hat only: x_hat itself (53 MB at B=2048) is not written
+      if (st16 && train && !(xhat_out && xhat_out[m])) d.c = nullptr;
       d.bias = params + P->off[pb + FC_B];
       d.m = (int)TB; d.n = P->dec_d[m]; d.n_valid = d.n; d.k = sb.h; d.batch = 1; d.split_k = 1; d.alpha = 1.0f;
     }
@@ -861,6 +909,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       me[m].loss = losses + 1 + m;
       me[m].inv_count = (float)(1.0 / cnt);
       me[m].grad_scale = (float)(2.0 * lda[m] / cnt);
+      if (st16) { me[m].dxhat_bf16 = 1; me[m].ld_dxhat = P->dxh_ld[m]; }
     }
     int rc = MFM_ERR_UNSUPPORTED;
     if (fc1_fused) {
@@ -893,6 +942,7 @@ static void dA_gemms(const MfmPlan* P, const SeqBuf& sb, int pb, float* W, float
   memset(&base, 0, sizeof(base));
   base.a_sz = sb.Hp; base.a_sm = 1; base.a_sk = 4 * (int64_t)sb.Hp;
   base.m = sb.h; base.batch = 4; base.accumulate = 1; base.split_k = 0; base.alpha = 1.0f;
+  base.a_bf16 = P->st16 ? 1 : 0;      // (bf16-resident plans come here for the decoders' t = 0 product only)
   // recurrent product sum_{t>=1} dA_t^T h_{t-1}
   if (T > 1 && !only_init) {
     MfmGemmDesc d = base;
@@ -974,7 +1024,7 @@ static int mfn_backward(MfmPlan* P, const float* params, float* W, float* grads,
       int koff = 0;
       for (int sg = 0; sg < 4; ++sg) {
         const SeqBuf* sb = sg < 3 ? &P->enc[3 + sg] : nullptr;
-        const float* seg = sb ? W + sb->hs + (int64_t)(T - 1) * B * sb->Hp : W + P->mem_out;
+        const float* seg = sb ? (P->st16 ? W + P->h_last[3 + sg] : W + sb->hs + (int64_t)(T - 1) * B * sb->Hp) : W + P->mem_out;
         const int k = sb ? sb->h : M;
         tn(dz, P->nzy, c.zy, seg, sb ? sb->Hp : M, k, grads + P->off[widx] + koff, tot + M, B);
         koff += k;
@@ -1086,7 +1136,15 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
   if (P->grads_prezeroed != grads) MFM_HIP_CHECK(hipMemsetAsync(grads, 0, (size_t)P->n_params * sizeof(float), s));
   P->grads_prezeroed = nullptr;
   const bool gen_on = (stage != 2), disc_on = (stage != 1);
-  const bool seq_bf16 = c.precision && bf16_seq_pays(B);
+  const bool seq_bf16 = P->seq_bf16;
+  const bool st16 = P->st16;
+  MFM_REQUIRE(!(ext && st16), "plan: backward for external upstream gradients is not available on a bf16-resident plan "
+                              "(the module path runs fp32 plans)");
+  // bf16-resident plans: every sum over the T*B rows that feeds an LSTM's or a decoder fc1's weight gradient is an item of
+  // ONE dw_bf16_kernel launch behind the encoder BPTT
+  DwbLaunch DB;
+  memset(&DB, 0, sizeof(DB));
+  DB.rows = (int)TB;
   // every weight-gradient product only feeds the optimizer: they are collected here and issued as ONE grouped
   // launch behind the encoder BPTT (49 problems at the canonical wiring) instead of three launches on the chain
   std::vector<MfmGemmDesc> tail;
@@ -1101,11 +1159,22 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       d.alpha = 1.0f; d.batch = 1;
       // dH = dx_hat Wfc  (pad units -> exact zeros)
       const float* dxh = (ext && ext->d_xhat[m]) ? ext->d_xhat[m] : W + P->dxhat[m];
-      d.a = dxh; d.a_sm = P->dec_d[m]; d.a_sk = 1;
+      d.a = dxh; d.a_sm = st16 ? P->dxh_ld[m] : P->dec_d[m]; d.a_sk = 1; d.a_bf16 = st16 ? 1 : 0;
       d.b = params + P->off[pb + FC_W]; d.b_sk = sb.h; d.b_sn = 1;
-      d.c = W + P->dec_dhs[m]; d.ldc = sb.Hp;
+      d.c = W + P->dec_dhs[m]; d.ldc = sb.Hp; d.c_bf16 = st16 ? 1 : 0;
       d.m = (int)TB; d.n = sb.Hp; d.n_valid = sb.h; d.k = P->dec_d[m]; d.split_k = 1;
       g.push_back(d);
+      if (st16) {
+        // dWfc = dx_hat^T H and dbfc = column sums of dx_hat: one item of the one-pass launch
+        DwbItem& I = DB.it[DB.n_items++];
+        I.a = reinterpret_cast<const __bf16*>(W + P->dxhat[m]); I.lda = P->dxh_ld[m]; I.M = P->dec_d[m];
+        I.Hp = P->dxh_ld[m]; I.h = P->dec_d[m];
+        I.nseg = 1; I.seg[0].p = reinterpret_cast<const __bf16*>(W + sb.hs); I.seg[0].ld = sb.Hp; I.seg[0].ncols = sb.Hp;
+        I.seg[0].col0 = 0; I.seg[0].shift = 0; I.seg[0].rows = (int)TB;
+        I.nout = 1; I.out[0].n0 = 0; I.out[0].nvalid = sb.h; I.out[0].c = grads + P->off[pb + FC_W]; I.out[0].ldc = sb.h;
+        I.cb = grads + P->off[pb + FC_B];
+        continue;
+      }
       // dWfc = dx_hat^T H
       MfmGemmDesc w;
       memset(&w, 0, sizeof(w));
@@ -1216,7 +1285,49 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
   {
     long dw_min_rows = 1L << 60;
     if (const char* e = getenv("MFM_DW_ONEPASS_MINROWS")) dw_min_rows = atol(e);
-    const bool onepass = TB >= dw_min_rows && (int64_t)TB * P->D < ((int64_t)1 << 29);
+    const bool onepass = !st16 && TB >= dw_min_rows && (int64_t)TB * P->D < ((int64_t)1 << 29);
+    if (st16) {
+      // the batch as bf16, modality slices on 16-column boundaries (what the one-pass kernel streams by LDS-DMA)
+      const int src0[3] = {0, c.d_l, c.d_l + c.d_a}, nn[3] = {c.d_l, c.d_a, c.d_v};
+      RUN(K_PACK, x_to_bf16_launch(x, W + P->x16, TB, P->D, P->x16_ld, src0, nn, P->x16_off, s));
+      auto lstm_item = [&](const SeqBuf& sb, int pb, int xcol0, int xcols, bool dec, int e) {
+        DwbItem& I = DB.it[DB.n_items++];
+        I.a = reinterpret_cast<const __bf16*>(W + sb.gates); I.lda = 4 * sb.Hp; I.M = 4 * sb.Hp; I.Hp = sb.Hp; I.h = sb.h;
+        int n = 0;
+        if (!dec) {
+          DwbSeg& S = I.seg[I.nseg++];
+          S.p = reinterpret_cast<const __bf16*>(W + P->x16); S.ld = P->x16_ld; S.col0 = xcol0; S.ncols = xcols; S.shift = 0; S.rows = (int)TB;
+          // output columns: one range per modality slice inside [xcol0, xcol0 + xcols)
+          const int dd_[3] = {c.d_l, c.d_a, c.d_v};
+          int dst = 0;
+          for (int m = 0; m < 3; ++m) {
+            if (P->x16_off[m] < xcol0 || P->x16_off[m] >= xcol0 + xcols) continue;
+            DwbOut& O = I.out[I.nout++];
+            O.n0 = P->x16_off[m] - xcol0; O.nvalid = dd_[m]; O.c = grads + P->off[pb + W_IH] + dst; O.ldc = P->enc_d[e];
+            dst += dd_[m];
+          }
+          n = xcols;
+        }
+        DwbSeg& S = I.seg[I.nseg++];
+        S.p = reinterpret_cast<const __bf16*>(W + sb.hs); S.ld = sb.Hp; S.col0 = 0; S.ncols = sb.Hp; S.shift = B; S.rows = (int)TB;
+        DwbOut& O = I.out[I.nout++];
+        O.n0 = n; O.nvalid = sb.h; O.c = grads + P->off[pb + W_HH]; O.ldc = sb.h;
+        if (dec) O.c2 = grads + P->off[pb + W_IH];          // steps >= 1 feed h back as the input (mfm_model.py:85)
+        I.cb = grads + P->off[pb + B_IH]; I.cb2 = grads + P->off[pb + B_HH];
+      };
+      for (int e = 0; e < P->n_enc; ++e) {
+        const bool whole = (V == 0 && e == 3);                 // the early-fusion encoder consumes every slice
+        const int mod = whole ? 0 : (e < 3 ? e : e - 3);
+        lstm_item(P->enc[e], P->enc_p[e], whole ? 0 : P->x16_off[mod], whole ? P->x16_ld : round_up(P->enc_d[e], 16), false, e);
+      }
+      if (gen_on)
+        for (int m = 0; m < 3; ++m) {
+          lstm_item(P->dec[m], P->dec_p[m], 0, 0, true, 0);
+          dA_gemms(P, P->dec[m], P->dec_p[m], W, grads, tail, W + P->dec_init[m], P->dec_h[m], P->dec_h[m], true, true);
+        }
+      MFM_REQUIRE(DB.n_items <= MFM_DWB_MAXI, "plan: %d one-pass items", DB.n_items);
+      RUN(K_DEC_DW, dw_bf16_launch(DB, s));
+    }
     DwLaunch DL;
     memset(&DL, 0, sizeof(DL));
     DL.rows = (int)TB;
@@ -1231,12 +1342,12 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       I.c_b = grads + P->off[pb + B_IH]; I.c_b2 = grads + P->off[pb + B_HH];
       return I;
     };
-    for (int e = 0; e < P->n_enc; ++e) {
+    for (int e = 0; e < P->n_enc && !st16; ++e) {
       DwItem I = item(P->enc[e], P->enc_p[e], x + P->enc_xoff[e], P->D, P->enc_d[e], false);
       if (onepass && DL.n_items < MFM_DW_MAXI && dw_onepass_supported(I, c.precision)) DL.it[DL.n_items++] = I;
       else dA_gemms(P, P->enc[e], P->enc_p[e], W, grads, tail, x + P->enc_xoff[e], P->D, P->enc_d[e], false);
     }
-    if (gen_on)
+    if (gen_on && !st16)
       for (int m = 0; m < 3; ++m) {
         DwItem I = item(P->dec[m], P->dec_p[m], nullptr, 0, 0, true);
         const bool op = onepass && DL.n_items < MFM_DW_MAXI && dw_onepass_supported(I, c.precision);
@@ -1436,6 +1547,25 @@ extern "C" int mfm_plan_latent_layout(const MfmPlan* P, int64_t* out) {
   out[12] = P->lay_c1;
   out[21] = P->lat.yhat_off;
   out[22] = P->lat.row_path;
+  return MFM_OK;
+}
+
+extern "C" int mfm_plan_seq_layout(const MfmPlan* P, int32_t which, int64_t* out) {
+  if (!P || !out) { set_error("mfm_plan_seq_layout: null argument"); return MFM_ERR_ARG; }
+  MFM_REQUIRE(which >= 0 && which < P->n_enc + 3, "mfm_plan_seq_layout: LSTM %d of %d", which, P->n_enc + 3);
+  for (int i = 0; i < 12; ++i) out[i] = 0;
+  const bool dec = which >= P->n_enc;
+  const mfm::SeqBuf& sb = dec ? P->dec[which - P->n_enc] : P->enc[which];
+  const int64_t f = (int64_t)sizeof(float);
+  out[0] = sb.gates * f; out[1] = sb.hs * f; out[2] = sb.cs * f; out[3] = sb.h; out[4] = sb.Hp; out[5] = P->st16 ? 1 : 0;
+  out[6] = dec ? 1 : 0;
+  if (dec) {
+    const int m = which - P->n_enc;
+    out[7] = P->dec_dhs[m] * f; out[8] = P->dxhat[m] * f; out[9] = P->dxh_ld[m]; out[10] = P->dec_d[m];
+  } else {
+    out[7] = P->h_last[which] >= 0 ? P->h_last[which] * f : -1;
+  }
+  out[11] = P->seq_bf16 ? 1 : 0;
   return MFM_OK;
 }
 

@@ -537,6 +537,31 @@ class MFMEngine:
         lay["width"]["fy_to_y"] = int(out[16])
         return rec, grd, lay
 
+    def seq_buffers(self, T, B, which):
+        """Saved activations of LSTM `which` (encoders in plan order, then the three decoders) as views of the plan workspace
+        (mfm_plan_seq_layout): gates [T,B,4,Hp], hs [T,B,Hp] (bf16 tensors on a bf16-resident plan), cs (fp32); decoders also
+        dhs [T,B,Hp] and dxhat [T*B, ld]; encoders h_last [B,Hp] or None.  Tests / tuning aids."""
+        p = self.plan(T, B)
+        out = (C.c_int64 * 12)()
+        _lib.check(_lib.lib().mfm_plan_seq_layout(p.handle, int(which), out), "mfm_plan_seq_layout")
+        h, Hp, st16, dec = int(out[3]), int(out[4]), bool(out[5]), bool(out[6])
+        ws = p.workspace
+
+        def v(off, shape, half):
+            n = int(np.prod(shape))
+            if half:
+                return ws[off: off + 2 * n].view(torch.bfloat16).view(*shape)
+            return ws[off: off + 4 * n].view(torch.float32).view(*shape)
+        res = dict(h=h, Hp=Hp, bf16_resident=st16, bf16_recurrence=bool(out[11]),
+                   gates=v(out[0], (T, B, 4, Hp), st16), hs=v(out[1], (T, B, Hp), st16), cs=v(out[2], (T, B, Hp), False))
+        if dec:
+            res["dhs"] = v(out[7], (T, B, Hp), st16)
+            res["dxhat"] = v(out[8], (T * B, int(out[9])), st16)
+            res["d"] = int(out[10])
+        else:
+            res["h_last"] = v(out[7], (B, Hp), False) if out[7] >= 0 else None
+        return res
+
     def mfn_buffers(self, T, B):
         """variants "kl" / "mmd": views of the MFN's [T*B, .] workspace tensors (mfm_plan_mfn_layout).  Tests / tuning."""
         p = self.plan(T, B)

@@ -354,6 +354,14 @@ int mfm_plan_latent_layout(const MfmPlan* plan, int64_t* out /*[32]*/);
  * out[15] T*B. */
 int mfm_plan_mfn_layout(const MfmPlan* plan, int64_t* out /*[16]*/);
 
+/* Where LSTM `which` keeps its saved activations inside the workspace (tests / tuning aids).  which: 0 .. n_enc-1 the
+ * encoders in plan order (l, a, v, early-fusion | l, a, v, MFN l, a, v), then the three decoders.  Byte offsets out[0] gates
+ * [T,B,4,Hp], out[1] hs [T,B,Hp], out[2] cs [T,B,Hp] (always fp32); out[3] h, out[4] Hp; out[5] 1 when the plan is
+ * bf16-RESIDENT: gates, hs, the decoders' dH and d x_hat are __bf16 buffers; out[6] 1 for a decoder; decoders: out[7] dH
+ * [T,B,Hp], out[8] d x_hat [T*B, out[9]] (out[10] real columns); encoders: out[7] the fp32 copy of h_{T-1} [B,Hp] (-1: none);
+ * out[11] 1 when the recurrences run on the bf16 MFMA kernels. */
+int mfm_plan_seq_layout(const MfmPlan* plan, int32_t which, int64_t* out /*[12]*/);
+
 /* Algorithmic work of one training step at this plan's (T,B):
  * 3 x forward FLOPs; activation+input bytes per sample plus 10 P 4 parameter/optimizer bytes. */
 double mfm_plan_flops_per_step(const MfmPlan* plan);

@@ -323,13 +323,13 @@ def test_bf16_resident_decoder_fwd_bwd(eng, h, B, T):
 
 
 @pytest.mark.parametrize("fr", ["1", "2", "4"])
-@pytest.mark.parametrize("m,n,k", [(640, 300, 104), (37, 5, 24), (2048, 20, 24), (130, 70, 128), (1, 1, 8)])
+@pytest.mark.parametrize("m,n,k", [(640, 300, 104), (37, 5, 24), (2048, 20, 24), (130, 70, 128), (1, 1, 8), (5, 24, 5), (33, 104, 300)])
 def test_bf16_resident_gemm_a_kcontig_and_c_out(eng, m, n, k, fr, monkeypatch):
     """A = bf16-resident hidden states [m, Kp] (k-contiguous, a_bf16): no rounding pass, bits go straight to LDS; the
     same product once with an fp32 C and once with a bf16 C (c_bf16: x-projection / dH of a bf16-resident plan)"""
     monkeypatch.setenv("MFM_GEMM_FR", fr)
     rs = np.random.RandomState(m + n + k)
-    Kp = (k + 15) // 16 * 16
+    Kp = (k + 7) // 8 * 8          # rows padded to 16 bytes (d x_hat [rows, round_up(d, 8)]; K = 5: an odd element count)
     A = np.zeros((m, Kp), dtype=np.float32)
     A[:, :k] = rs.normal(size=(m, k))
     W = rs.normal(size=(n, k)).astype(np.float32)

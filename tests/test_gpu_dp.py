@@ -220,7 +220,9 @@ def test_hip_data_parallel_step_mfn_variants(variant, world, fused):
     for n, p in m.named_parameters():
         d = np.abs(got[n] - p.detach().numpy())
         if g0[n] is not None:
-            sig = np.abs(g0[n]) > 1e-3 * np.abs(g0[n]).max()
+            # (and above the noise floor of the atomic summation order, ~1e-8: fy_to_y_fc1.bias is ~0 by construction here --
+            # cancelling L1 signs, max |g| 1.9e-9 -- and every one of its elements would otherwise count as significant)
+            sig = (np.abs(g0[n]) > 1e-3 * np.abs(g0[n]).max()) & (np.abs(g0[n]) > 1e-6)
             if sig.any():
                 wsig = max(wsig, float(d[sig].max()))
         assert d.max() < 1.01 * STEPS * 1e-3, n
