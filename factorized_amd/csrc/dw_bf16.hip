@@ -43,7 +43,8 @@ constexpr int DWB_MF = 3;                       // A fragments per wave
 constexpr int DWB_MT = 2 * 16 * DWB_MF;         // A columns per workgroup: 96
 constexpr int DWB_NFW = 9;                      // N fragments per wave: N (padded) <= 16 * 4 * 9 = 576
 constexpr int DWB_KC = 32;                      // rows per chunk = one MFMA k-block
-constexpr int DWB_STAGES = 3;
+constexpr int DWB_MIN_STAGES = 3, DWB_MAX_STAGES = 12;    // chunks of LDS an item rotates through (DwbItem::stages)
+constexpr int DWB_MAX_WAIT = 24;                           // largest counted vmcnt wait: (stages - 2) x instructions per chunk
 constexpr int DWB_MAXNI = 6;                    // LDS-DMA instructions per thread and chunk
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lds_base, int off, int row16_bytes) {
@@ -170,20 +171,28 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_bf16_kernel(const DwbLaunch L)
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
   const bool want_bias = (I.cb != nullptr) && (wn == 0);          // wave-uniform
 
-  // ---- pipeline: chunks c+1, c+2 in flight while chunk c is multiplied
-  issue(0, 0, true);
-  issue(1, 1, n_chunks > 1);
+  // ---- pipeline: S - 1 chunks in flight while chunk c is multiplied.  S (DwbItem::stages) grows as the chunk image
+  // shrinks: what bounds a narrow item (a decoder: 8 KB per chunk) is the DMA latency per chunk divided by the chunks in
+  // flight, not bandwidth -- with 3 stages the 22 narrow M-tiles of the MOSI plan spent ~1 us per 8-24 KB chunk.
+  const int S = I.stages;
+  const int wait_n = (S - 2) * NI;                          // instructions that may stay outstanding when chunk c is needed
+  for (int k = 0; k < S - 1; ++k) issue(k, k, k < n_chunks);
+  int stage = 0, nxt = S - 1;
   for (int c = 0; c < n_chunks; ++c) {
-    // chunk c = the older of the two outstanding groups: wait until only the younger group's NI instructions remain
-    if (NI == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (NI == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if (NI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (NI == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (NI == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    // chunk c is the oldest outstanding group: wait until only the S - 2 younger groups' instructions remain
+    switch (wait_n) {
+#define MFM_DWB_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+      MFM_DWB_W(1) MFM_DWB_W(2) MFM_DWB_W(3) MFM_DWB_W(4) MFM_DWB_W(5) MFM_DWB_W(6) MFM_DWB_W(7) MFM_DWB_W(8)
+      MFM_DWB_W(9) MFM_DWB_W(10) MFM_DWB_W(11) MFM_DWB_W(12) MFM_DWB_W(13) MFM_DWB_W(14) MFM_DWB_W(15) MFM_DWB_W(16)
+      MFM_DWB_W(17) MFM_DWB_W(18) MFM_DWB_W(19) MFM_DWB_W(20) MFM_DWB_W(21) MFM_DWB_W(22) MFM_DWB_W(23) MFM_DWB_W(24)
+#undef MFM_DWB_W
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave's DMA of chunk c landed; chunk c-1 is consumed
-    issue(c + 2, (c + 2) % DWB_STAGES, c + 2 < n_chunks);
-    const unsigned char* st = dsm + (c % DWB_STAGES) * stage_bytes;
+    issue(c + S - 1, nxt, c + S - 1 < n_chunks);
+    const unsigned char* st = dsm + stage * stage_bytes;
+    nxt = stage;
+    stage = (stage + 1 == S) ? 0 : stage + 1;
     bf16x8 af[DWB_MF];
 #pragma unroll
     for (int i = 0; i < DWB_MF; ++i) af[i] = tr_frag(st, a_off[i], 16 * DWB_MT * 2);
@@ -203,6 +212,7 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_bf16_kernel(const DwbLaunch L)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the trailing dummies must land before the workgroup's LDS is released
 
   // ---- add the tile into the gradient buffers.  Accumulator lane: rows (A columns) 4q + r, column bi of fragment j.
+  if (L.debug_no_epilogue == 1) return;     // (tuning aid: MFM_DWB_NOEPI=1 measures the streaming part alone)
   const int Hp = I.Hp, h = I.h;
 #pragma unroll
   for (int j = 0; j < DWB_NFW; ++j) {
@@ -225,6 +235,11 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_bf16_kernel(const DwbLaunch L)
         const int g = m / Hp, u = m - g * Hp;
         if (u >= h) continue;
         const int64_t o = (int64_t)(g * h + u) * ldc + col;
+        if (L.debug_no_epilogue == 2) {      // EXPERIMENT (wrong results across XCDs): L2-local atomics
+          __hip_atomic_fetch_add(dst + o, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (dst2) __hip_atomic_fetch_add(dst2 + o, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          continue;
+        }
         atomicAdd(dst + o, acc[i][j][r]);
         if (dst2) atomicAdd(dst2 + o, acc[i][j][r]);
       }
@@ -317,6 +332,7 @@ static const void* zero_block() {
 int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
   MFM_REQUIRE(L.n_items >= 1 && L.n_items <= MFM_DWB_MAXI && L.rows >= 1, "dw bf16: bad launch");
   if (!L.zeros) L.zeros = zero_block();
+  L.debug_no_epilogue = getenv("MFM_DWB_NOEPI") ? atoi(getenv("MFM_DWB_NOEPI")) : 0;
   MFM_REQUIRE(L.zeros, "dw bf16: no zero block");
   double wsum = 0.0;
   for (int i = 0; i < L.n_items; ++i) {
@@ -330,9 +346,9 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
     for (int s = 0; s < I.nseg; ++s) N += I.seg[s].ncols;
     wsum += (double)I.m_tiles * (1.0 + N / 128.0);
   }
-  // one workgroup per CU (the three chunk stages fill the LDS): row ranges sized so that the launch is ~3 rounds of
+  // one workgroup per CU (the chunk stages fill the LDS): row ranges sized so that the launch is ~2 rounds of
   // workgroups, a range's cost taken as (fixed part + N / 128) per chunk (profiles/r02_dw_onepass.txt)
-  double target = 3.0 * device_cus();
+  double target = 2.0 * device_cus();       // measured at B = 2048: 3 -> 198 us, 2 -> 169 us, 1 -> 233 us (the partial tiles' atomics against load balance)
   if (const char* e = getenv("MFM_DWB_TARGET")) target = atof(e) * device_cus();
   int tiles = 0;
   size_t smem = 0;
@@ -349,7 +365,13 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
     tiles += I.m_tiles * I.splits;
     const int P = DWB_KC * (DWB_MT + N) / 8;
     const int NI = (P + DWB_THREADS - 1) / DWB_THREADS;
-    smem = std::max(smem, (size_t)DWB_STAGES * NI * DWB_THREADS * 16);
+    // stages: as many as fit ~144 KB, the counted wait and the cap (MFM_DWB_STAGES forces a count, clamped)
+    int S = (int)((144 * 1024) / ((size_t)NI * DWB_THREADS * 16));
+    S = std::min(S, DWB_MAX_WAIT / NI + 2);
+    if (const char* e = getenv("MFM_DWB_STAGES")) S = std::min(S, atoi(e));
+    S = std::max(DWB_MIN_STAGES, std::min(S, DWB_MAX_STAGES));
+    I.stages = S;
+    smem = std::max(smem, (size_t)S * NI * DWB_THREADS * 16);
   }
   static bool attr = false;
   if (!attr) {

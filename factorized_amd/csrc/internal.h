@@ -104,9 +104,9 @@ struct DwbItem {
   int nseg, nout;
   DwbSeg seg[2]; DwbOut out[MFM_DWB_MAXOUT];
   float* cb; float* cb2;                // optional: column sums of A (bias gradients), indexed like the rows of C
-  int tile_begin, m_tiles, splits, rows_per_split;     // filled by dw_bf16_launch
+  int tile_begin, m_tiles, splits, rows_per_split, stages, pad_;     // filled by dw_bf16_launch
 };
-struct DwbLaunch { DwbItem it[MFM_DWB_MAXI]; int n_items, rows; const void* zeros; };   // zeros: >= 16 bytes of device zeros (null: the launcher's own)
+struct DwbLaunch { DwbItem it[MFM_DWB_MAXI]; int n_items, rows; const void* zeros; int debug_no_epilogue, pad_; };   // zeros: >= 16 bytes of device zeros (null: the launcher's own)
 int dw_bf16_supported(const DwbItem& I);
 int dw_bf16_launch(DwbLaunch& L, hipStream_t stream);
 // x [rows, D] fp32 -> bf16 [rows, ldo] with up to three column ranges moved to 16-aligned positions (pad columns zero)

@@ -166,7 +166,13 @@ static int build(MfmPlan* P) {
   // weight-gradient kernel takes (dw_bf16.hip); MFM_BF16_STORE=0 keeps the round-2 form (fp32 buffers, rounding on load).
   P->seq_bf16 = c.precision && bf16_seq_pays(c.B);
   {
-    bool ok = P->seq_bf16 && !getenv("MFM_SEQ_STEPWISE") && !(getenv("MFM_BF16_STORE") && atoi(getenv("MFM_BF16_STORE")) == 0);
+    // default from T*B = 16384 rows: below, the fused decoder-fc1 launch and the chunked weight-gradient kernels of the
+    // fp32-stored form win (measured at the MOSI sizes, B = 256 / 512 / 1024 / 2048 / 4096: 0.468 vs 0.418, 0.568 vs 0.523,
+    // 0.665 vs 0.704, 0.93 vs 1.146, 1.73 vs 2.20 ms); MFM_BF16_STORE=1 forces it on for every size, =0 off
+    const char* se = getenv("MFM_BF16_STORE");
+    long st_minrows = 16384;
+    if (const char* e = getenv("MFM_BF16_STORE_MINROWS")) st_minrows = atol(e);
+    bool ok = P->seq_bf16 && !getenv("MFM_SEQ_STEPWISE") && (se ? atoi(se) != 0 : TB >= st_minrows);
     const int Dp = round_up(c.d_l, 16) + round_up(c.d_a, 16) + round_up(c.d_v, 16);
     int hmax = 0, np_max = 0;
     for (int e = 0; e < P->n_enc; ++e) {

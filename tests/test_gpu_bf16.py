@@ -499,8 +499,10 @@ def seq_policy(request, monkeypatch):
     (lstm_seq.hip::bf16_seq_pays); 'all-bf16' forces the bf16 kernels at every batch size."""
     if request.param.startswith("all-bf16"):
         monkeypatch.setenv("MFM_BF16_SEQ_MINB", "1")
+        monkeypatch.setenv("MFM_BF16_STORE", "1")       # and the bf16-RESIDENT saved activations (default from T*B = 16384)
     else:
         monkeypatch.delenv("MFM_BF16_SEQ_MINB", raising=False)
+        monkeypatch.delenv("MFM_BF16_STORE", raising=False)
     if "panel" in request.param:
         monkeypatch.setenv("MFM_PANEL_MINROWS", "1")    # gemm_panel_kernel<true> for the input projections
         monkeypatch.setenv("MFM_DW_ONEPASS_MINROWS", "1")   # and dw_onepass_kernel<true> for the LSTM weight gradients
@@ -584,6 +586,36 @@ def test_bf16_loss_curve_tracks_fp32_reference(name, seq_policy):
     cases.report("bf16_trace_rel_%s_%s" % (name, seq_policy), dev_)
     assert dev_ < 2e-3, (trace[-1], ref[-1])
     assert trace[-1, 0] < trace[0, 0]                  # and it trains
+
+
+def test_bf16_resident_plan_selection_and_stored_dtypes(monkeypatch):
+    """which bf16 plans keep their saved activations as bf16 (default: from T*B = 16384 rows), and that the buffers really
+    hold bf16: hs[T-1] is the bf16 rounding of the fp32 h_{T-1} copy the latent stack reads, the gates are activations"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from factorized_amd import engine
+    monkeypatch.delenv("MFM_BF16_STORE", raising=False)
+    monkeypatch.delenv("MFM_BF16_SEQ_MINB", raising=False)
+    cfgs = configs.canonical_configs(dropout=False)
+    cfg = cfgs[0]
+    for prec, B, T, want in (("bf16", 32, 20, False), ("bf16", 256, 20, False), ("bf16", 1024, 20, True), ("fp32", 1024, 20, False)):
+        e = engine.MFMEngine(cfgs, precision=prec)
+        e.load_weights(synth.make_weights(e.layout.shapes, seed=1234))
+        xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7)
+        x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
+        e.forward(x, y, train=True, want_xhat=False)
+        sb = e.seq_buffers(T, B, 3)                      # the early-fusion encoder
+        assert sb["bf16_resident"] == want, (prec, B)
+        assert sb["bf16_recurrence"] == (prec == "bf16" and B >= 192)
+        if want:
+            assert sb["hs"].dtype == torch.bfloat16 and sb["gates"].dtype == torch.bfloat16 and sb["cs"].dtype == torch.float32
+            h = sb["h"]
+            hl = sb["h_last"].cpu().numpy()
+            assert np.array_equal(bf(hl), b2n(sb["hs"])[T - 1])
+            g = b2n(sb["gates"])[:, :, :, :h]
+            assert np.all((g[:, :, [0, 1, 3]] >= 0.0) & (g[:, :, [0, 1, 3]] <= 1.0)) and np.all(np.abs(g[:, :, 2]) <= 1.0)
+            dec = e.seq_buffers(T, B, 4)                  # decoder l
+            assert dec["dxhat"].dtype == torch.bfloat16 and dec["dhs"].dtype == torch.bfloat16
 
 
 def test_bf16_large_batch_mosei_loss_curve():
