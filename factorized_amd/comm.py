@@ -91,7 +91,7 @@ class P2PAllReduce:
     def __call__(self, t):
         if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
             raise _lib.MfmError("P2PAllReduce: contiguous fp32 device tensor expected")
-        stream = torch.cuda.current_stream(t.device).cuda_stream
+        stream = torch._C._cuda_getCurrentRawStream(t.device.index)
         _lib.check(self._L.mfm_p2p_allreduce(self._h, C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(stream)),
                    "mfm_p2p_allreduce")
 
@@ -105,7 +105,7 @@ class P2PAllReduce:
         if gs:
             for g in gs:
                 gs[g] = e.step_count
-        stream = torch.cuda.current_stream(e.grads.device).cuda_stream
+        stream = torch._C._cuda_getCurrentRawStream(e.grads.device.index)
         _lib.check(self._L.mfm_p2p_allreduce_adam(self._h, C.c_void_p(e.grads.data_ptr()), C.c_void_p(e.params.data_ptr()),
                                                   C.c_void_p(e.adam_m.data_ptr()), C.c_void_p(e.adam_v.data_ptr()),
                                                   e.grads.numel(), e.step_count, lr, 0.9, 0.999, 1e-8, grad_scale,

@@ -25,8 +25,10 @@ The fastest way to train is not this autograd path but `factorized_amd.engine.MF
 """
 import ctypes as C
 import os
+import weakref
 from collections import OrderedDict
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -353,31 +355,68 @@ def decoder_group(pairs, t):
 
 
 # ----------------------------------------------------------------------------------- fused engine on module storage
+# id(Parameter) -> (weakref to the Parameter, weakref to its model): lets factorized_amd.optim.Adam find the fused model a
+# parameter belongs to without putting an (unpicklable) attribute on the Parameter itself
+_PARAM_OWNERS = {}
+
+
+def _owner_of(p):
+    ent = _PARAM_OWNERS.get(id(p))
+    if ent is None or ent[0]() is not p:
+        return None
+    return ent[1]()
+
+
 class _FusedEngineMixin:
     """Gives a model class the `engine` property: an MFMEngine (the one-call fused plan) whose flat parameter buffer
     IS the module's parameter storage -- every nn.Parameter becomes a view into it on first CUDA use, so
     `model.engine.train_step(x, y)` and a reference-style `loss.backward(); optimizer.step()` update the same numbers.
     Also whole-module checkpoints (torch.save(model, path) / torch.load, reference mfm_mosi.py:342-346, 473-481) and
     copy.deepcopy: the engine holds native plan handles and device workspaces, which are dropped from the pickled
-    state and re-adopted lazily."""
+    state and re-adopted lazily.
+
+    Flat gradients (round 3): the model also owns ONE flat gradient buffer with the engine's layout; a backward that
+    produces all gradients at once (MFM_KL_EF's fused plan) writes into it and every `p.grad` is a persistent view of it, so
+    the reference's unchanged loop costs no per-tensor host work in backward / zero_grad / optimizer.step
+    (factorized_amd.optim.Adam).  `fast_grads = False` restores the per-tensor autograd path (parameter hooks,
+    torch.autograd.grad on parameters)."""
     _engine_variant = "kl_ef"
+    fast_grads = True
 
     def _init_engine_slots(self):
         self._param_names = [n for n, _ in self.named_parameters()]
         self._plist = [p for _, p in self.named_parameters()]      # Parameter objects survive .to()/.cuda()
         self._engine = None
+        self._grad_flat = None          # flat gradient buffer (engine layout); p.grad = views of it
+        self._grad_present = np.ones(len(self._plist), dtype=bool)     # tensors that received a gradient since zero_grad
+        self._grad_fresh = True         # the flat buffer holds zeros: the next backward may overwrite instead of add
+        self._flat_leaf = None
+        self._register_params()
+
+    def _register_params(self):
+        me = weakref.ref(self)
+        for p in self._plist:
+            _PARAM_OWNERS[id(p)] = (weakref.ref(p), me)
 
     def __getstate__(self):
         state = dict(self.__dict__)
         state["_engine"] = None
+        state["_grad_flat"] = None
+        state["_flat_leaf"] = None
         return state
 
     def __setstate__(self, state):
         nn.Module.__setstate__(self, state)
         self._engine = None
+        self._grad_flat = None
+        self._flat_leaf = None
+        self._grad_fresh = True
         # `_plist` must hold the SAME Parameter objects as the sub-modules (pickle keeps identity through its memo;
         # rebuild defensively in case a custom unpickler did not)
         self._plist = [p for _, p in self.named_parameters()]
+        if not hasattr(self, "_grad_present") or len(self._grad_present) != len(self._plist):
+            self._grad_present = np.ones(len(self._plist), dtype=bool)
+        self._register_params()
 
     def _flat_ok(self):
         if self._engine is None:
@@ -399,6 +438,8 @@ class _FusedEngineMixin:
         for n, p in pd.items():
             p.data = views[n]
         self._engine = eng
+        self._grad_flat = None
+        self._grad_fresh = True
 
     @property
     def engine(self):
@@ -409,6 +450,50 @@ class _FusedEngineMixin:
                 raise _lib.MfmError("%s: parameters are on %s; move the model to the GPU first" % (type(self).__name__, dev))
             self._adopt(dev)
         return self._engine
+
+    # ------------------------------------------------------------------ flat gradients
+    def _flat_grads(self):
+        eng = self.engine
+        if self._grad_flat is None or self._grad_flat.device != eng.params.device or self._grad_flat.numel() != eng.layout.total:
+            self._grad_flat = torch.zeros_like(eng.params)
+            self._grad_fresh = True
+        return self._grad_flat
+
+    def _grad_views_attached(self):
+        g = self._grad_flat
+        if g is None or self._engine is None:
+            return False
+        lay = self._engine.layout
+        g0, g1 = self._plist[0].grad, self._plist[-1].grad
+        return (g0 is not None and g1 is not None and g0.data_ptr() == g.data_ptr() + 4 * lay.slots[0][0]
+                and g1.data_ptr() == g.data_ptr() + 4 * lay.slots[-1][0])
+
+    def _attach_grad_views(self):
+        g = self._flat_grads()
+        for p, (o, n, shp) in zip(self._plist, self._engine.layout.slots):
+            p.grad = g[o:o + n].view(shp)
+
+    def _zero_flat_grads(self, set_to_none=True):
+        """optimizer.zero_grad() of factorized_amd.optim.Adam: one launch; set_to_none=True marks every tensor as
+        'no gradient yet' (the optimizer skips what the next backward does not reach, like torch with .grad = None)"""
+        self._grad_flat.zero_()
+        self._grad_fresh = True
+        if set_to_none:
+            self._grad_present[:] = False
+
+    def _group_masks(self):
+        """which tensors each upstream gradient of the factorized model reaches exclusively: d y_hat -> the classifier;
+        d x_hat_m -> decoder m and its z -> f MLP (the staged losses of train_beta_vae, reference mfm_mosi.py:278-281)"""
+        mk = getattr(self, "_masks", None)
+        if mk is None:
+            names = self._param_names
+            def sel(*prefixes):
+                return np.array([n.startswith(prefixes) for n in names], dtype=bool)
+            mk = dict(disc=sel("fy_to_y_"), l=sel("decoder_l.", "zl_to_fl_"), a=sel("decoder_a.", "za_to_fa_"),
+                      v=sel("decoder_v.", "zv_to_fv_"))
+            mk["shared"] = ~(mk["disc"] | mk["l"] | mk["a"] | mk["v"])
+            self._masks = mk
+        return mk
 
 
 # ----------------------------------------------------------------------------------- MFM_KL_EF
@@ -464,6 +549,74 @@ class _KLEFFn(torch.autograd.Function):
         return (None, None) + tuple(flat[o:o + n].view(shp) for o, n, shp in lay.slots)
 
 
+class _KLEFFastFn(torch.autograd.Function):
+    """_KLEFFn without per-tensor autograd traffic: the only differentiable input is a dummy leaf; backward writes ALL
+    parameter gradients into the model's flat gradient buffer (adding when something is already there) and makes sure
+    every `p.grad` is its view of that buffer."""
+
+    @staticmethod
+    def forward(ctx, x, module, leaf):
+        if x.requires_grad:
+            raise _lib.MfmError("MFM_KL_EF.forward: the input requires grad; the fused plan does not produce d loss / d x "
+                                "(the reference never asks for it) -- detach the batch")
+        eng = module.engine
+        out = eng.forward(x, None, train=module.training, want_xhat=True)
+        kld = out["losses"][4].clone()
+        ctx.module = module
+        plan = eng.plan(x.shape[0], x.shape[1])
+        ctx.plan, ctx.serial = plan, plan.fwd_serial
+        ctx.save_for_backward(x)
+        # an output the loss does not use must arrive in backward as None, not as a zero tensor: that is how the stage
+        # losses (gen + reg: y_hat unused; disc + reg: the reconstructions unused) tell which tensors get NO gradient
+        ctx.set_materialize_grads(False)
+        return out["x_l_hat"], out["x_a_hat"], out["x_v_hat"], out["y_hat"], kld
+
+    @staticmethod
+    def backward(ctx, d_xl, d_xa, d_xv, d_y, d_kld):
+        (x,) = ctx.saved_tensors
+        module = ctx.module
+        eng = module.engine
+        T, B, _ = x.shape
+        plan = ctx.plan
+        if eng.plan(T, B) is not plan or plan.fwd_serial != ctx.serial:
+            raise RuntimeError("MFM_KL_EF backward: another forward with the same (T=%d, B=%d) ran on this model since "
+                               "the graph was built; its activations replaced this one's in the plan workspace.  Call "
+                               "backward() before the next forward (gradient accumulation over several forwards: "
+                               "backward each one first)" % (T, B))
+        if plan.consumed:
+            raise RuntimeError("MFM_KL_EF backward: this graph was already back-propagated (BPTT overwrites the saved "
+                               "gates in place; retain_graph is not supported on the fused plan)")
+        plan.consumed = True
+        d_l, d_a, d_v = eng.cfg["input_dims"]
+        dev = x.device
+        mk = module._group_masks()
+        present = mk["shared"].copy()
+        for key, g in (("l", d_xl), ("a", d_xa), ("v", d_xv), ("disc", d_y)):
+            if g is not None:
+                present |= mk[key]
+
+        def z(t, shape):
+            return torch.zeros(shape, device=dev) if t is None else t.contiguous().float()
+        d_xl, d_xa, d_xv = z(d_xl, (T, B, d_l)), z(d_xa, (T, B, d_a)), z(d_xv, (T, B, d_v))
+        d_y = z(d_y, (B, eng.cfg["output_dim"]))
+        d_kld = z(d_kld, ()).reshape(1)
+        flat = module._flat_grads()
+        attached = module._grad_views_attached()
+        if module._grad_fresh or not attached:
+            # nothing accumulated since zero_grad (or the gradients were None / somebody else's tensors): the plan writes
+            # the flat buffer directly
+            eng.backward_ext(x, d_xl, d_xa, d_xv, d_y, d_kld, out=flat)
+            if not attached:
+                module._attach_grad_views()
+                module._grad_present[:] = False
+        else:
+            eng.backward_ext(x, d_xl, d_xa, d_xv, d_y, d_kld)
+            flat.add_(eng.grads)
+        module._grad_fresh = False
+        module._grad_present |= present
+        return None, None, None
+
+
 class MFM_KL_EF(_FusedEngineMixin, nn.Module):
     def __init__(self, config, NN1Config, NN2Config, gamma1Config, gamma2Config, outConfig):
         super(MFM_KL_EF, self).__init__()
@@ -510,7 +663,12 @@ class MFM_KL_EF(_FusedEngineMixin, nn.Module):
         if not (x.dtype == torch.float32 and x.is_contiguous()):
             x = x.contiguous().float()
         _ = self.engine
-        x_l_hat, x_a_hat, x_v_hat, y_hat, kld = _KLEFFn.apply(x, self, *self._plist)
+        if self.fast_grads:
+            if self._flat_leaf is None or self._flat_leaf.device != x.device:
+                self._flat_leaf = torch.zeros((), device=x.device, requires_grad=True)
+            x_l_hat, x_a_hat, x_v_hat, y_hat, kld = _KLEFFastFn.apply(x, self, self._flat_leaf)
+        else:
+            x_l_hat, x_a_hat, x_v_hat, y_hat, kld = _KLEFFn.apply(x, self, *self._plist)
         decoded = [x_l_hat, x_a_hat, x_v_hat, y_hat]
         missing_loss = 0.0
         return decoded, kld, missing_loss

@@ -1,0 +1,177 @@
+"""Drop-in `optim.Adam` for the reference's UNCHANGED training loops (reference mfm_mosi.py:403, 427-441):
+
+    import factorized_amd.optim as optim                       # instead of: import torch.optim as optim
+    from factorized_amd.mfm_model import MFM_KL_EF              # instead of: from mfm_model import MFM_KL_EF
+    ...
+    optimizer = optim.Adam(model.parameters())                  # :403, before model.to(device) as in the reference
+    ...
+    optimizer.zero_grad(); decoded, reg, missing = model.forward(batch_X); ...; loss.backward(); optimizer.step()
+
+`Adam` is a `torch.optim.Optimizer` (so `ReduceLROnPlateau(optimizer, 'min')`, `param_groups[0]['lr']`, `zero_grad()` work as
+in the reference).  Parameters that belong to a model with the fused engine (`MFM_KL_EF`, `MFM_KL`, `MFM`: every
+nn.Parameter is a view into ONE flat buffer) and whose `.grad`s are the views of the model's flat gradient buffer (what
+`MFM_KL_EF`'s backward leaves behind) are updated by ONE launch of `mfm_adam_flat` -- or `mfm_adam_flat_spans` when some
+tensors received no gradient: like torch.optim.Adam, a parameter without a gradient is skipped and step counts are kept
+per tensor.  Everything else (other modules, models on the composed autograd path) goes through a stock
+`torch.optim.Adam` with the same hyper-parameters.  `torch.optim.Adam` itself keeps working too -- it is just host-bound
+(78 tensors per step); see INTEGRATION.md for the measured step times.
+
+`zero_grad()` of this class clears a fused model's flat gradient buffer with one launch and marks every tensor "no gradient
+yet" (= torch's `set_to_none=True`: the next `step()` skips tensors the next backward does not reach) while leaving the
+`.grad` views attached; `zero_grad(set_to_none=False)` keeps zero gradients in place, which is the reference's PyTorch-0.4
+behaviour (a tensor that once had a gradient keeps moving on its decaying first moment)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ReduceLROnPlateau = torch.optim.lr_scheduler.ReduceLROnPlateau      # convenience: `optim.lr_scheduler` users import torch's
+lr_scheduler = torch.optim.lr_scheduler
+SGD = torch.optim.SGD
+
+
+def _owner(p):
+    from .mfm_model import _owner_of
+    return _owner_of(p)
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0 or amsgrad:
+            raise ValueError("factorized_amd.optim.Adam: weight_decay / amsgrad are not used by the reference and not built")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False)
+        super().__init__(params, defaults)
+        self._fused = {}            # id(module) -> state of a fused model: flat moments, per-tensor step counts
+        self._fallback = None       # stock torch.optim.Adam over everything that is not fused
+        self._fallback_ids = None
+        self._fm_cache = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _fused_modules(self, group):
+        """models whose parameter list lies entirely inside `group` (the reference has one group: model.parameters());
+        cached per group while its parameter list is the same list of the same length"""
+        key = (id(group["params"]), len(group["params"]), id(group["params"][0]) if group["params"] else 0)
+        hit = self._fm_cache.get(id(group))
+        if hit is not None and hit[0] == key and all(r() is not None for r in hit[2]):
+            return hit[1]
+        import weakref
+        ids = {id(p) for p in group["params"]}
+        seen, out = set(), []
+        for p in group["params"]:
+            m = _owner(p)
+            if m is None or id(m) in seen:
+                continue
+            seen.add(id(m))
+            if all(id(q) in ids for q in m._plist):
+                out.append(m)
+        self._fm_cache[id(group)] = (key, out, [weakref.ref(m) for m in out])
+        return out
+
+    def _state_for(self, m, eng):
+        st = self._fused.get(id(m))
+        if st is None or st["m"].numel() != eng.layout.total or st["m"].device != eng.params.device:
+            st = dict(m=torch.zeros_like(eng.params), v=torch.zeros_like(eng.params),
+                      steps=np.zeros(len(eng.layout.slots), dtype=np.int64))
+            self._fused[id(m)] = st
+        return st
+
+    def _fused_step(self, m, group):
+        eng = m.engine
+        gflat = getattr(m, "_grad_flat", None)
+        if gflat is None or not m._grad_views_attached():
+            return False                     # gradients are ordinary per-tensor tensors: the stock optimizer handles them
+        st = self._state_for(m, eng)
+        lr, (b1, b2), eps = group["lr"], group["betas"], group["eps"]
+        if torch.is_tensor(lr):
+            lr = float(lr)
+        present = m._grad_present
+        L = _lib.lib()
+        stream = C.c_void_p(torch._C._cuda_getCurrentRawStream(eng.params.device.index))
+        ptr = lambda t: C.c_void_p(t.data_ptr())
+        steps = st["steps"]
+        if present.all() and (steps == steps[0]).all():
+            steps += 1
+            _lib.check(L.mfm_adam_flat(ptr(eng.params), ptr(gflat), ptr(st["m"]), ptr(st["v"]), eng.layout.total, int(steps[0]),
+                                       lr, b1, b2, eps, 1.0, stream), "mfm_adam_flat")
+            return True
+        # some tensors have no gradient (stage losses, unused layers): contiguous runs of present tensors with equal
+        # step counts become spans (tensor starts are 64-float aligned: span bounds are multiples of 4)
+        order = np.argsort([o for o, _, _ in eng.layout.slots])
+        starts = [eng.layout.slots[i][0] for i in order] + [eng.layout.total]
+        spans = []
+        for k, i in enumerate(order):
+            if not present[i]:
+                continue
+            steps[i] += 1
+            b, e_, s_ = starts[k], starts[k + 1], int(steps[i])
+            if spans and spans[-1][1] == b and spans[-1][2] == s_:
+                spans[-1] = (spans[-1][0], e_, s_)
+            else:
+                spans.append((b, e_, s_))
+        for k in range(0, len(spans), _lib.MFM_ADAM_MAX_SPANS):
+            part = spans[k:k + _lib.MFM_ADAM_MAX_SPANS]
+            arr = (_lib.AdamSpan * len(part))()
+            for j, (b, e_, s_) in enumerate(part):
+                arr[j].begin, arr[j].end, arr[j].step = b, e_, s_
+            _lib.check(L.mfm_adam_flat_spans(ptr(eng.params), ptr(gflat), ptr(st["m"]), ptr(st["v"]), arr, len(part), lr, b1, b2,
+                                             eps, 1.0, stream), "mfm_adam_flat_spans")
+        return True
+
+    def _fallback_step(self, rest):
+        if not rest:
+            return
+        ids = tuple(id(p) for _, ps in rest for p in ps)
+        if self._fallback is None or self._fallback_ids != ids:
+            groups = [dict(params=ps, lr=g["lr"], betas=g["betas"], eps=g["eps"]) for g, ps in rest]
+            self._fallback = torch.optim.Adam(groups)
+            self._fallback_ids = ids
+        for fg, (g, _) in zip(self._fallback.param_groups, rest):
+            fg["lr"], fg["betas"], fg["eps"] = g["lr"], g["betas"], g["eps"]      # schedulers act on OUR groups
+        self._fallback.step()
+
+    # ------------------------------------------------------------------ Optimizer interface
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        rest = []
+        for group in self.param_groups:
+            stepped, ndone = [], 0
+            for m in self._fused_modules(group):
+                if m._plist[0].is_cuda and self._fused_step(m, group):
+                    stepped.append(m)
+                    ndone += len(m._plist)
+            if ndone == len(group["params"]):
+                continue                              # (the reference's case: one model, one group, nothing left)
+            done = {id(p) for m in stepped for p in m._plist}
+            left = [p for p in group["params"] if id(p) not in done]
+            if left:
+                rest.append((group, left))
+        self._fallback_step(rest)
+        return loss
+
+    def zero_grad(self, set_to_none=True):
+        cleared, nh, total = [], 0, 0
+        for group in self.param_groups:
+            total += len(group["params"])
+            for m in self._fused_modules(group):
+                if getattr(m, "_grad_flat", None) is not None and m._grad_views_attached():
+                    m._zero_flat_grads(set_to_none)
+                    cleared.append(m)
+                    nh += len(m._plist)
+        if nh == total:
+            return
+        handled = {id(p) for m in cleared for p in m._plist}
+        for group in self.param_groups:
+            for p in group["params"]:
+                if id(p) in handled or p.grad is None:
+                    continue
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.detach_()
+                    p.grad.zero_()
