@@ -21,11 +21,14 @@ def extra_configs():
     return cfgs
 
 
-def load_extra(name):
+SIZES = ["small", "canonical"]        # extra_<name>.npz (odd sizes, B=12, T=6) / extra2_<name>.npz (canonical MOSI dims, B=33, T=20)
+
+
+def load_extra(name, size="small"):
     """-> (six configs, golden npz, x [T,B,D] float32, [gauss tensors in loss_MMD call order])"""
-    cfgs = extra_configs()
+    cfgs = extra_configs() if size == "small" else C.canonical_configs(dropout=False)
     cfg = cfgs[0]
-    gold = np.load(os.path.join(GOLDEN, "extra_%s.npz" % name))
+    gold = np.load(os.path.join(GOLDEN, "%s_%s.npz" % ("extra" if size == "small" else "extra2", name)))
     B, T = (int(v) for v in gold["meta"])
     x, _ = synth.make_batch(cfg["input_dims"], B, T, seed=7)
     gauss = []

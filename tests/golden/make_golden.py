@@ -221,14 +221,18 @@ EXTRA_SIZES = dict(input_dims=[37, 3, 11], h_dims=[40, 12, 20], memsize=24, zl_s
 EXTRA = ["M_A", "M_B", "M_C", "M_D", "MFM_missing", "seq2seq", "basic_missing"]
 
 
-def run_extra(name, B=12, T=6):
-    """ablations M_A..M_D (mfm_model.py:201-467) and the missing-modality family (:766-1017): the REFERENCE classes'
+def run_extra(name, B=12, T=6, canonical=False):
+    """(canonical=True, round 3: a second size per class -- the canonical MOSI dims at B=33, T=20 -> extra2_<name>.npz)
+    ablations M_A..M_D (mfm_model.py:201-467) and the missing-modality family (:766-1017): the REFERENCE classes'
     forward outputs (summaries of every returned tensor, in order) and the gradient summaries of a scalar objective
     that touches every output (oracle/mfm_oracle_extra.py::test_objective).  loss_MMD's torch.randn samples are
     replaced by a seeded sequence that is stored next to the results."""
     from oracle import mfm_oracle_extra as X
-    cfgs = C.canonical_configs(dropout=False, **EXTRA_SIZES)
-    cfgs[1]["shapes"], cfgs[2]["shapes"], cfgs[3]["shapes"], cfgs[4]["shapes"] = 36, 20, 28, 44
+    if canonical:
+        cfgs = C.canonical_configs(dropout=False)
+    else:
+        cfgs = C.canonical_configs(dropout=False, **EXTRA_SIZES)
+        cfgs[1]["shapes"], cfgs[2]["shapes"], cfgs[3]["shapes"], cfgs[4]["shapes"] = 36, 20, 28, 44
     cfg = cfgs[0]
     model = getattr(REF, name)(*cfgs)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -258,9 +262,10 @@ def run_extra(name, B=12, T=6):
            "meta": np.array([B, T])}
     if gauss:
         res["gauss"] = np.concatenate([g.numpy() for g in gauss], axis=1)
-    np.savez_compressed(os.path.join(HERE, "extra_%s.npz" % name), **res)
-    print("extra_" + name, "objective=%.6f" % res["objective"], "outputs=%d" % len(flat),
-          "bytes=%d" % os.path.getsize(os.path.join(HERE, "extra_%s.npz" % name)))
+    tag = "extra2_" if canonical else "extra_"
+    np.savez_compressed(os.path.join(HERE, "%s%s.npz" % (tag, name)), **res)
+    print(tag + name, "objective=%.6f" % res["objective"], "outputs=%d" % len(flat),
+          "bytes=%d" % os.path.getsize(os.path.join(HERE, "%s%s.npz" % (tag, name))))
 
 
 STAGED = [("klef_staged_b32_t20", 32, 20, 4, 4, "kl_ef"), ("kl_staged_b32_t20", 32, 20, 4, 4, "kl"),
@@ -283,6 +288,10 @@ if __name__ == "__main__":
         if only and ("extra_" + name) not in only:
             continue
         run_extra(name)
+    for name in EXTRA:
+        if only and ("extra2_" + name) not in only:
+            continue
+        run_extra(name, B=33, T=20, canonical=True)
     for case in LIGHT:
         if only and case[0] not in only:
             continue

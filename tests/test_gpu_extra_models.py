@@ -10,18 +10,19 @@ from oracle import mfm_oracle_extra as X
 from factorized_amd import synth
 from tests import cases
 from tests.cases import grad_err, rel_err
-from tests.extra_cases import EXTRA, load_extra
+from tests.extra_cases import EXTRA, SIZES, load_extra
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+@pytest.mark.parametrize("size", SIZES)
 @pytest.mark.parametrize("name", EXTRA)
-def test_extra_model_matches_oracle_and_reference(name):
+def test_extra_model_matches_oracle_and_reference(name, size):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from factorized_amd import mfm_model as M
-    cfgs, gold, xn, gauss = load_extra(name)
+    cfgs, gold, xn, gauss = load_extra(name, size)
     ref = X.CLASSES[name](*cfgs)
     w = synth.make_weights({k: tuple(v.shape) for k, v in ref.state_dict().items()}, seed=1234)
     ref.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()})
@@ -42,7 +43,7 @@ def test_extra_model_matches_oracle_and_reference(name):
         assert tuple(a.shape) == tuple(b.shape), i
         if b.numel() and float(b.detach().abs().max()) > 0:
             worst = max(worst, rel_err(a.detach().cpu().numpy(), b.detach().numpy()))
-    cases.report("extra_outputs_rel_%s" % name, worst)
+    cases.report("extra_outputs_rel_%s_%s" % (name, size), worst)
     assert worst < TOL
     got = np.stack([cases.summarize(o.detach().cpu().numpy()) for o in flat])
     scale = np.maximum(np.abs(gold["out_summary"][:, :1]), 1e-6)
@@ -65,7 +66,7 @@ def test_extra_model_matches_oracle_and_reference(name):
         err = grad_err(p.grad.cpu().numpy(), q.grad.numpy(), abs_slack=1e-8)
         if err > wg[1]:
             wg = (n, err)
-    cases.report("extra_grad_%s" % name, wg[1])
+    cases.report("extra_grad_%s_%s" % (name, size), wg[1])
     assert wg[1] < TOL, wg
     gs = gold["grad_summary"]
     ok = ~np.isnan(gs[:, 0])

@@ -7,13 +7,14 @@ import torch
 from oracle import mfm_oracle_extra as X
 from factorized_amd import synth
 from tests import cases
-from tests.extra_cases import EXTRA, extra_configs, load_extra
+from tests.extra_cases import EXTRA, SIZES, extra_configs, load_extra
 
 
+@pytest.mark.parametrize("size", SIZES)
 @pytest.mark.parametrize("name", EXTRA)
-def test_oracle_extra_matches_reference(name):
+def test_oracle_extra_matches_reference(name, size):
     torch.set_num_threads(1)
-    cfgs, gold, x, gauss = load_extra(name)
+    cfgs, gold, x, gauss = load_extra(name, size)
     m = X.CLASSES[name](*cfgs)
     assert [n for n, _ in m.named_parameters()] == list(gold["param_names"])
     w = synth.make_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1234)
