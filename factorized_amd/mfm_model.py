@@ -557,8 +557,8 @@ class _KLEFFastFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, module, leaf):
         if x.requires_grad:
-            raise _lib.MfmError("MFM_KL_EF.forward: the input requires grad; the fused plan does not produce d loss / d x "
-                                "(the reference never asks for it) -- detach the batch")
+            raise _lib.MfmError("%s.forward: the input requires grad; the fused plan does not produce d loss / d x "
+                                "(the reference never asks for it) -- detach the batch" % type(module).__name__)
         eng = module.engine
         out = eng.forward(x, None, train=module.training, want_xhat=True)
         kld = out["losses"][4].clone()
@@ -1090,7 +1090,14 @@ class MFN(nn.Module):
 
 class _FactorizedMFN(_FusedEngineMixin, nn.Module):
     """Shared body of MFM (MMD regulariser, mfm_model.py:469-555) and MFM_KL (KLD, :662-764): the
-    three HIP sequence encoders/decoders around the MFN fusion encoder."""
+    three HIP sequence encoders/decoders around the MFN fusion encoder.
+
+    `MFM_KL.forward` is ONE call of the fused plan (variant "kl", like MFM_KL_EF) since round 3 -- its backward takes
+    arbitrary upstream gradients (mfm_plan_backward_ext), so the reference's unchanged loop runs on it: `fused_forward =
+    False`, an input that requires grad, or a stream under graph capture select the composed autograd path below.  `MFM`
+    stays on the composed path: the plan forms the MMD regulariser's gradient itself (scaled by config["lda_mmd"]) and
+    cannot honour an arbitrary upstream weight on it; `model.engine.train_step` is its fused form."""
+    fused_forward = True
 
     def __init__(self, use_kl, config, NN1Config, NN2Config, gamma1Config, gamma2Config, outConfig):
         super(_FactorizedMFN, self).__init__()
@@ -1139,6 +1146,15 @@ class _FactorizedMFN(_FusedEngineMixin, nn.Module):
 
     def forward(self, x):
         _require_cuda(x, "%s.forward" % type(self).__name__)
+        if (self._use_kl and self.fused_forward and self.fast_grads and not x.requires_grad
+                and not torch.cuda.is_current_stream_capturing()):
+            if not (x.dtype == torch.float32 and x.is_contiguous()):
+                x = x.contiguous().float()
+            _ = self.engine
+            if self._flat_leaf is None or self._flat_leaf.device != x.device:
+                self._flat_leaf = torch.zeros((), device=x.device, requires_grad=True)
+            x_l_hat, x_a_hat, x_v_hat, y_hat, kld = _KLEFFastFn.apply(x, self, self._flat_leaf)
+            return [x_l_hat, x_a_hat, x_v_hat, y_hat], kld, 0.0
         x_l = x[:, :, :self.d_l]
         x_a = x[:, :, self.d_l:self.d_l + self.d_a]
         x_v = x[:, :, self.d_l + self.d_a:]

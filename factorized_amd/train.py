@@ -132,6 +132,10 @@ class GraphedModuleStep:
                              "its one-call fused engine: model.engine.train_step(x, y)")
         dev = next(model.parameters()).device
         self.model, self.cfg = model, cfg
+        # the composed autograd path is what gets captured (MFM_KL's default forward is the fused plan since round 3, whose
+        # dropout seed would be frozen into the captured kernel arguments like MFM_KL_EF's)
+        if hasattr(model, "fused_forward"):
+            model.fused_forward = False
         d = cfg["input_dims"]
         self.x = torch.zeros(T, B, sum(d), device=dev)
         ce = cfg.get("loss", "l1") == "ce"

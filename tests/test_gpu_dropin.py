@@ -18,9 +18,9 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _model(cfgs, fast=True):
-    from factorized_amd.mfm_model import MFM_KL_EF
-    model = MFM_KL_EF(*cfgs)
+def _model(cfgs, fast=True, cls="MFM_KL_EF"):
+    from factorized_amd import mfm_model as M
+    model = getattr(M, cls)(*cfgs)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     w = synth.make_weights(shapes, seed=1234)
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()})
@@ -86,6 +86,29 @@ def test_unchanged_reference_loop_follows_reference_trajectory(which, fast):
         assert model._grad_views_attached() and optimizer._fallback is None
         g = model._grad_flat
         assert all(p.grad.data_ptr() >= g.data_ptr() and p.grad.data_ptr() < g.data_ptr() + 4 * g.numel() for p in model.parameters())
+
+
+def test_unchanged_reference_loop_mfm_kl_on_the_fused_plan():
+    """train_mfm instantiates MFM_KL for config['type'] == 'kl' (reference mfm_mosi.py:398-399): the same unchanged loop, the
+    model's forward is one call of the fused plan (variant "kl"), gradients land in the flat buffer, one fused Adam launch"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import factorized_amd.optim as optim
+    cs = cases.load_case("kl_b32_t20")
+    cfg, gold = cs["cfg"], cs["gold"]
+    model = _model(cs["cfgs"], True, "MFM_KL")
+    optimizer = optim.Adam(model.parameters())
+    model = model.to("cuda")
+    X, y = torch.from_numpy(cs["x"]).cuda(), torch.from_numpy(cs["y"]).cuda()
+    trace = _reference_loop(model, optimizer, X, y, cfg, cs["steps"])
+    ref = gold["trace"]
+    terr = float(np.max(np.abs(trace - ref) / np.maximum(np.abs(ref), 1e-2)))
+    cases.report("dropin_trace_rel_mfm_kl", terr)
+    assert terr < 0.5 * TOL, (trace[-1], ref[-1])
+    assert model._grad_views_attached() and optimizer._fallback is None
+    # the unused MFN output layers never received a gradient and never moved (Adam skips them like torch does)
+    w0 = synth.make_weights({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
+    assert np.array_equal(model.mfn_encoder.out_fc1.weight.detach().cpu().numpy(), w0["mfn_encoder.out_fc1.weight"])
 
 
 @pytest.mark.parametrize("mode", ["frozen", "legacy"])

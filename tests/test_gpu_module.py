@@ -127,10 +127,11 @@ def _ref_loss_generic(model, x, y, cfg):
     return disc + gen + cfg["lda_mmd"] * reg + missing, decoded, reg
 
 
-@pytest.mark.parametrize("name", ["kl_b32_t20", "mmd_b32_t20"])
-def test_mfn_based_models_match_reference(name):
+@pytest.mark.parametrize("name,fused", [("kl_b32_t20", True), ("kl_b32_t20", False), ("mmd_b32_t20", False)])
+def test_mfn_based_models_match_reference(name, fused):
     """MFM_KL / MFM (with the MFN fusion encoder) against the reference's golden outputs and the
-    oracle's gradients; trained 5 steps with torch.optim.Adam like mfm_mosi.py:403-441."""
+    oracle's gradients; trained 5 steps with torch.optim.Adam like mfm_mosi.py:403-441.  MFM_KL both ways: its default
+    forward (one call of the fused plan, round 3) and the composed autograd path (`fused_forward = False`)."""
     _need_gpu()
     from factorized_amd import mfm_model as M
     cs = cases.load_case(name)
@@ -144,6 +145,7 @@ def test_mfn_based_models_match_reference(name):
     model.load_state_dict(ref.state_dict())
     model = model.cuda()
     model.train()
+    model.fused_forward = fused
     x, y = torch.from_numpy(cs["x"]), torch.from_numpy(cs["y"])
     xd, yd = x.cuda(), y.cuda()
     if variant == "mmd":
