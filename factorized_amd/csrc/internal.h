@@ -77,6 +77,18 @@ struct DecFc1Item {
 struct DecFc1Launch { DecFc1Item it[3]; int n_items, rows, with_bwd, bf16; };   // bf16: operands rounded to bf16 (RNE) first
 int dec_fc1_launch(DecFc1Launch& L, bool dhs_zeroed, hipStream_t stream);
 
+// dec_fc1_large.hip -- bf16-resident plans, large T*B: decoder fc1 + squared error + d x_hat + dH in one launch of
+// persistent workgroups (the W image stays in LDS; H in, d x_hat and dH out are bf16 buffers)
+struct DecFc1LargeItem {
+  const void* hs; const float* w; const float* bias; const float* x;   // H [rows, Hp] bf16, Wfc [d, h] fp32, b [d], target columns (row stride ldx)
+  void* dxhat; void* dhs; float* loss;                                   // [rows, ld_dxhat] bf16, [rows, Hp] bf16, loss slot
+  int64_t ldx; int d, h, Hp, ld_dxhat; float inv_count, grad_scale;
+  int wg_begin, wg_count;                                                // filled by dec_fc1_large_launch
+};
+struct DecFc1LargeLaunch { DecFc1LargeItem it[3]; int n_items, rows; };
+int dec_fc1_large_supported(const DecFc1LargeItem& I);
+int dec_fc1_large_launch(DecFc1LargeLaunch& L, hipStream_t stream);
+
 // dw_onepass.hip -- all weight gradients of one LSTM as ONE product over the rows (large T*B)
 #define MFM_DW_MAXI 12
 struct DwItem {

@@ -918,6 +918,28 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       if (st16) { me[m].dxhat_bf16 = 1; me[m].ld_dxhat = P->dxh_ld[m]; }
     }
     int rc = MFM_ERR_UNSUPPORTED;
+    // bf16-resident training steps: fc1, the squared error, d x_hat and dH in one launch of persistent workgroups
+    // (dec_fc1_large.hip); MFM_FC1_LARGE=0 keeps the two grouped GEMMs
+    if (st16 && train && !(xhat_out && (xhat_out[0] || xhat_out[1] || xhat_out[2])) &&
+        !(getenv("MFM_FC1_LARGE") && atoi(getenv("MFM_FC1_LARGE")) == 0)) {
+      DecFc1LargeLaunch FL;
+      memset(&FL, 0, sizeof(FL));
+      FL.n_items = 3; FL.rows = (int)TB;
+      bool ok = true;
+      for (int m = 0; m < 3; ++m) {
+        DecFc1LargeItem& I = FL.it[m];
+        I.hs = g[m].a; I.w = g[m].b; I.bias = g[m].bias; I.x = me[m].x; I.ldx = me[m].ldx;
+        I.dxhat = me[m].dxhat; I.ld_dxhat = P->dxh_ld[m]; I.dhs = W + P->dec_dhs[m]; I.loss = me[m].loss;
+        I.d = P->dec_d[m]; I.h = P->dec[m].h; I.Hp = P->dec[m].Hp;
+        I.inv_count = me[m].inv_count; I.grad_scale = me[m].grad_scale;
+        ok = ok && dec_fc1_large_supported(I);
+      }
+      if (ok) {
+        { Timer _t(P, s, K_FC1_FWD); rc = dec_fc1_large_launch(FL, s); }
+        if (rc != MFM_OK) return rc;
+        P->fc1_bwd_call = P->calls;               // dH is done: the backward skips its fc1 GEMM
+      }
+    }
     if (fc1_fused) {
       DecFc1Launch FL;
       memset(&FL, 0, sizeof(FL));
