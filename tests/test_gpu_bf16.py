@@ -518,12 +518,19 @@ def seq_policy(request, monkeypatch):
     return request.param
 
 
+# The tensors whose bf16 gradient error is the largest in every case: the first layer of the z_y -> f_y MLP.  f_y feeds all
+# three decoders and the classifier, so d f_y is a sum of four back-propagated terms of mixed sign (the three reconstruction
+# chains' rounding errors do not cancel the way their values do); measured 3.8e-2 (fp32-stored) / 6.1e-2 (bf16-resident) at
+# B = 229, everything else stays below 2.2e-2.
+NOISY_BF16_TENSORS = ("zy_to_fy_fc1.", "zy_to_fy_fc2.")
+
+
 @pytest.mark.parametrize("name", ["klef_b32_t20", "klef_b33_t7", "klef_b1_t20", "klef_b5_t1", "klef_b229_t20",
                                   "klef_you_b32_t50", "klef_mosei_b64_t20", "klef_odd_b19_t9"])
 def test_bf16_forward_and_gradients_near_fp32_reference(name, seq_policy):
     """bounds (measured worst case in brackets): loss terms within 1e-3 relative of the
-    reference's fp32 golden [7e-5]; every parameter gradient within 8e-2 of the oracle's in relative L2 norm
-    [4.0e-2, one tensor at B=229] and cosine > 0.995 [1 - 7.4e-4]."""
+    reference's fp32 golden [7e-5]; parameter gradients within 3e-2 of the oracle's in relative L2 norm, the two z_y -> f_y
+    layers (NOISY_BF16_TENSORS) within 8e-2 [6.1e-2 at B=229, bf16-resident]; cosine > 0.995 [1 - 7.4e-4]."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     cs = cases.load_case(name)
@@ -548,7 +555,7 @@ def test_bf16_forward_and_gradients_near_fp32_reference(name, seq_policy):
     O.loss_terms(m, x, y, cfg, cs["loss_kind"])["loss"].backward()
     e.backward(xd, yd, stage=0)
     gv = e.grad_views()
-    worst_g, worst_c = ("", 0.0), ("", 1.0)
+    worst_g, worst_c, worst_rest = ("", 0.0), ("", 1.0), ("", 0.0)
     for n, p in m.named_parameters():
         g, r = gv[n].cpu().numpy().astype(np.float64).ravel(), p.grad.numpy().astype(np.float64).ravel()
         nr = np.linalg.norm(r)
@@ -560,9 +567,13 @@ def test_bf16_forward_and_gradients_near_fp32_reference(name, seq_policy):
             worst_g = (n, rel)
         if cos < worst_c[1]:
             worst_c = (n, cos)
+        if not n.startswith(NOISY_BF16_TENSORS) and rel > worst_rest[1]:
+            worst_rest = (n, rel)
     cases.report("bf16_grad_relL2_%s_%s" % (name, seq_policy), worst_g[1])
+    cases.report("bf16_grad_relL2_rest_%s_%s" % (name, seq_policy), worst_rest[1])
     cases.report("bf16_grad_one_minus_cos_%s_%s" % (name, seq_policy), 1.0 - worst_c[1])
     assert worst_g[1] < 8e-2, worst_g
+    assert worst_rest[1] < 3e-2, worst_rest
     assert worst_c[1] > 0.995, worst_c
     # not accidentally the fp32 path
     assert worst_g[1] > 1e-5
