@@ -86,6 +86,8 @@ _SIGS = {
     "mfm_lstm_seq_bwd": (C.c_int, [C.POINTER(SeqDesc), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mfm_dw_bf16_lstm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mfm_dw_f32_lstm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mfm_mmd_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mfm_mfn_mem_fwd": (C.c_int, [C.POINTER(MemDesc), C.c_void_p]),
     "mfm_mfn_mem_bwd": (C.c_int, [C.POINTER(MemDesc), C.c_void_p]),

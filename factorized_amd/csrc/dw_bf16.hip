@@ -55,7 +55,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lds_base, int off
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(DWB_THREADS) void dw_bf16_kernel(const DwbLaunch L) {
+// F32 = true (round 3, fp32 plans at large T*B; OPT-IN, see the status note at the launcher): the same one-pass structure on
+// fp32 buffers and v_mfma_f32_16x16x4_f32 -- 16-row chunks (four 4-deep k-steps), 4 floats per DMA piece, fragments by plain
+// ds_read_b32 (lane (bi, q) reads element [row 4 ks + q][column bi] of the memory-order slab: no transposition problem at 4
+// bytes per element).  The column groups of odd slab rows are rotated by 16 floats on their way in (the DMA source address
+// is free, the LDS side is lane-linear), so the two rows a 32-lane half of a fragment read touches fall on different banks.
+template <bool F32>
+__global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch L) {
+  constexpr int ES = F32 ? 4 : 2;                 // bytes per operand element
+  constexpr int EPP = 16 / ES;                    // elements per 16-byte DMA piece
+  constexpr int KC = F32 ? 16 : DWB_KC;           // rows per chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
 
   // ---- XCD-aware order: workgroup b runs on XCD b % 8; the M-tiles of one (item, row range) become consecutive
@@ -74,7 +83,7 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_bf16_kernel(const DwbLaunch L)
   const int mt = local % I.m_tiles, sp = local / I.m_tiles;
   const int m0 = mt * DWB_MT;
   const int r_begin = sp * I.rows_per_split, r_end = min(L.rows, r_begin + I.rows_per_split);
-  const int n_chunks = (r_end - r_begin + DWB_KC - 1) / DWB_KC;
+  const int n_chunks = (r_end - r_begin + KC - 1) / KC;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,7 +92,7 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_bf16_kernel(const DwbLaunch L)
 
   // ---- chunk image in LDS, in DMA piece order (16 bytes per piece, lane-linear): A [32][96] | seg0 [32][n0] | seg1 [32][n1]
   const int n0 = I.seg[0].ncols, n1 = (I.nseg > 1) ? I.seg[1].ncols : 0;
-  const int pa = DWB_KC * DWB_MT / 8, p0 = DWB_KC * n0 / 8, p1 = DWB_KC * n1 / 8;      // pieces; each a multiple of 64
+  const int pa = KC * DWB_MT / EPP, p0 = KC * n0 / EPP, p1 = KC * n1 / EPP;            // pieces; each a multiple of 64
   const int P = pa + p0 + p1;
   const int NI = (P + DWB_THREADS - 1) / DWB_THREADS;
   const int stage_bytes = NI * DWB_THREADS * 16;
@@ -100,24 +109,30 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_bf16_kernel(const DwbLaunch L)
   for (int i = 0; i < DWB_MAXNI; ++i) {
     const int p = i * DWB_THREADS + tid;
     src[i] = zsrc; inc[i] = 0; row0[i] = 0; lo[i] = 1; hi[i] = 0;          // never valid
+    // F32: the column groups of odd slab rows are rotated by 4 pieces (16 floats): LDS position c of row `row` holds source
+    // group (c + 4 (row & 1)) mod groups-per-row (bank spreading for the b32 fragment reads, see the kernel comment)
+    const unsigned char* abase = reinterpret_cast<const unsigned char*>(I.a);
     if (p < pa) {
-      const int row = p / (DWB_MT / 8), c8 = p % (DWB_MT / 8);
-      if (m0 + c8 * 8 < I.lda) {                          // columns past the row end: zeros, not the next row's data
-        src[i] = reinterpret_cast<const unsigned char*>(I.a + (int64_t)(r_begin + row) * I.lda + m0 + c8 * 8);
-        inc[i] = DWB_KC * I.lda * 2; row0[i] = r_begin + row; lo[i] = 0; hi[i] = r_end;
+      constexpr int GPR = DWB_MT / EPP;
+      const int row = p / GPR, cpos = p % GPR;
+      const int cg = F32 ? (cpos + 4 * (row & 1)) % GPR : cpos;
+      if (m0 + cg * EPP < I.lda) {                        // columns past the row end: zeros, not the next row's data
+        src[i] = abase + ((int64_t)(r_begin + row) * I.lda + m0 + cg * EPP) * ES;
+        inc[i] = KC * I.lda * ES; row0[i] = r_begin + row; lo[i] = 0; hi[i] = r_end;
       }
     } else if (p < P) {
       // (both segments' fields are read with uniform indices and selected per lane: a divergent index into the kernel
       // argument would turn every field into a vector load whose first use -- inside the time loop -- waits vmcnt(0))
       const bool s1 = p >= pa + p0;
-      const __bf16* sp = s1 ? I.seg[1].p : I.seg[0].p;
+      const unsigned char* sp = reinterpret_cast<const unsigned char*>(s1 ? I.seg[1].p : I.seg[0].p);
       const int sld = s1 ? I.seg[1].ld : I.seg[0].ld, sn = s1 ? n1 : n0, sc0 = s1 ? I.seg[1].col0 : I.seg[0].col0;
       const int ssh = s1 ? I.seg[1].shift : I.seg[0].shift, srows = s1 ? I.seg[1].rows : I.seg[0].rows;
-      const int pp = p - pa - (s1 ? p0 : 0), g8 = sn / 8;
-      const int row = pp / g8, c8 = pp % g8;
+      const int pp = p - pa - (s1 ? p0 : 0), gpr = sn / EPP;
+      const int row = pp / gpr, cpos = pp % gpr;
+      const int cg = F32 ? (cpos + 4 * (row & 1)) % gpr : cpos;
       // row r of the chunk pairs with row r - shift of the segment
-      src[i] = reinterpret_cast<const unsigned char*>(sp + (int64_t)(r_begin + row - ssh) * sld + sc0 + c8 * 8);
-      inc[i] = DWB_KC * sld * 2; row0[i] = r_begin + row - ssh; lo[i] = 0; hi[i] = srows;
+      src[i] = sp + ((int64_t)(r_begin + row - ssh) * sld + sc0 + cg * EPP) * ES;
+      inc[i] = KC * sld * ES; row0[i] = r_begin + row - ssh; lo[i] = 0; hi[i] = srows;
     }
     // pin the plan in registers HERE: nothing of it may still be "in flight" for the compiler when the loop starts
     asm volatile("" : "+v"(src[i]), "+v"(inc[i]), "+v"(row0[i]), "+v"(lo[i]), "+v"(hi[i]));
@@ -129,7 +144,7 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_bf16_kernel(const DwbLaunch L)
 #pragma unroll
     for (int i = 0; i < DWB_MAXNI; ++i) {
       if (i < NI) {                                       // NI is uniform: every wave issues the same NI instructions
-        const int row = row0[i] + chunk * DWB_KC;
+        const int row = row0[i] + chunk * KC;
         const bool ok = live && row >= lo[i] && row < hi[i];
         const unsigned char* g = ok ? src[i] + (int64_t)chunk * inc[i] : zsrc;
         // inline asm on purpose: the compiler tracks an LDS-DMA builtin as a pending LDS write and drains it with
@@ -142,20 +157,34 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_bf16_kernel(const DwbLaunch L)
     }
   };
 
-  // ---- fragment read offsets inside a stage (bytes): lane (bi, q) reads row 4q + bi/4, columns c .. c+3 with c = col0 + 4 (bi%4)
+  // ---- fragment read offsets inside a stage (bytes)
+  // bf16: lane (bi, q) reads row 4q + bi/4, columns c .. c+3 with c = col0 + 4 (bi%4) (transposing read; second read +16 rows)
+  // F32:  lane (bi, q) reads element [row q (+ 4 per k-step)][column col0 + bi], the column group rotated like the DMA did
   const int rrow = 4 * q + (bi >> 2), rcol = 4 * (bi & 3);
+  auto f32_pos = [&](int width, int col0) {           // float index of (row q, column col0 + bi) in a [16][width] slab
+    const int gpr = width / 4;
+    return q * width + ((col0 / 4 - 4 * (q & 1) + gpr) % gpr) * 4 + bi;
+  };
   int a_off[DWB_MF];
 #pragma unroll
-  for (int i = 0; i < DWB_MF; ++i) a_off[i] = (rrow * DWB_MT + wm * 16 * DWB_MF + i * 16 + rcol) * 2;
-  int b_off[DWB_NFW], b_r16[DWB_NFW];
+  for (int i = 0; i < DWB_MF; ++i)
+    a_off[i] = F32 ? f32_pos(DWB_MT, wm * 16 * DWB_MF + i * 16) * 4 : (rrow * DWB_MT + wm * 16 * DWB_MF + i * 16 + rcol) * 2;
+  int b_off[DWB_NFW], b_r16[DWB_NFW];               // b_r16: bf16: bytes of 16 slab rows; F32: bytes of one k-step (4 rows)
   int njw = 0;
 #pragma unroll
   for (int j = 0; j < DWB_NFW; ++j) {
     const int nf = wn + 4 * j;
     int n = nf * 16;
     if (nf < NF) njw = j + 1;
-    if (n < n0) { b_off[j] = pa * 16 + (rrow * n0 + n + rcol) * 2; b_r16[j] = 16 * n0 * 2; }
-    else { n -= n0; b_off[j] = (pa + p0) * 16 + (rrow * max(n1, 16) + min(n, max(n1 - 16, 0)) + rcol) * 2; b_r16[j] = 16 * max(n1, 16) * 2; }
+    if (n < n0) {
+      b_off[j] = pa * 16 + (F32 ? f32_pos(n0, n) * 4 : (rrow * n0 + n + rcol) * 2);
+      b_r16[j] = F32 ? 4 * n0 * 4 : 16 * n0 * 2;
+    } else {
+      n -= n0;
+      const int w1 = max(n1, 16), nc = min(n, max(n1 - 16, 0));
+      b_off[j] = (pa + p0) * 16 + (F32 ? f32_pos(w1, nc) * 4 : (rrow * w1 + nc + rcol) * 2);
+      b_r16[j] = F32 ? 4 * w1 * 4 : 16 * w1 * 2;
+    }
   }
   njw = __builtin_amdgcn_readfirstlane(njw);
 
@@ -193,19 +222,40 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_bf16_kernel(const DwbLaunch L)
     const unsigned char* st = dsm + stage * stage_bytes;
     nxt = stage;
     stage = (stage + 1 == S) ? 0 : stage + 1;
-    bf16x8 af[DWB_MF];
+    if constexpr (F32) {
 #pragma unroll
-    for (int i = 0; i < DWB_MF; ++i) af[i] = tr_frag(st, a_off[i], 16 * DWB_MT * 2);
-    if (want_bias) {
+      for (int ks = 0; ks < KC / 4; ++ks) {
+        float af[DWB_MF];
 #pragma unroll
-      for (int i = 0; i < DWB_MF; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
-    }
+        for (int i = 0; i < DWB_MF; ++i) af[i] = *reinterpret_cast<const float*>(st + a_off[i] + ks * (4 * DWB_MT * 4));
+        if (want_bias) {
 #pragma unroll
-    for (int j = 0; j < DWB_NFW; ++j) {
-      if (j < njw) {                                      // scalar branch: njw is wave-uniform
-        const bf16x8 bf = tr_frag(st, b_off[j], b_r16[j]);
+          for (int i = 0; i < DWB_MF; ++i) accb[i] = mma16x16x4(af[i], 1.0f, accb[i]);
+        }
 #pragma unroll
-        for (int i = 0; i < DWB_MF; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < DWB_NFW; ++j) {
+          if (j < njw) {                                    // scalar branch: njw is wave-uniform
+            const float bf = *reinterpret_cast<const float*>(st + b_off[j] + ks * b_r16[j]);
+#pragma unroll
+            for (int i = 0; i < DWB_MF; ++i) acc[i][j] = mma16x16x4(af[i], bf, acc[i][j]);
+          }
+        }
+      }
+    } else {
+      bf16x8 af[DWB_MF];
+#pragma unroll
+      for (int i = 0; i < DWB_MF; ++i) af[i] = tr_frag(st, a_off[i], 16 * DWB_MT * 2);
+      if (want_bias) {
+#pragma unroll
+        for (int i = 0; i < DWB_MF; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < DWB_NFW; ++j) {
+        if (j < njw) {                                      // scalar branch: njw is wave-uniform
+          const bf16x8 bf = tr_frag(st, b_off[j], b_r16[j]);
+#pragma unroll
+          for (int i = 0; i < DWB_MF; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+        }
       }
     }
   }
@@ -235,11 +285,6 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_bf16_kernel(const DwbLaunch L)
         const int g = m / Hp, u = m - g * Hp;
         if (u >= h) continue;
         const int64_t o = (int64_t)(g * h + u) * ldc + col;
-        if (L.debug_no_epilogue == 2) {      // EXPERIMENT (wrong results across XCDs): L2-local atomics
-          __hip_atomic_fetch_add(dst + o, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          if (dst2) __hip_atomic_fetch_add(dst2 + o, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          continue;
-        }
         atomicAdd(dst + o, acc[i][j][r]);
         if (dst2) atomicAdd(dst2 + o, acc[i][j][r]);
       }
@@ -299,16 +344,19 @@ int x_to_bf16_launch(const float* x, void* out, int64_t rows, int D, int ldo, co
   return MFM_OK;
 }
 
-int dw_bf16_supported(const DwbItem& I) {
+int dw_bf16_supported(const DwbItem& I, int f32) {
   if (!I.a || I.nseg < 1 || I.nseg > 2 || I.nout < 1 || I.nout > MFM_DWB_MAXOUT) return 0;
   int np = 0;
   for (int s = 0; s < I.nseg; ++s) {
-    if (!I.seg[s].p || (I.seg[s].ncols & 15) || I.seg[s].ncols < 16 || (I.seg[s].ld & 7) || (I.seg[s].col0 & 7)) return 0;
-    if ((((uintptr_t)I.seg[s].p) & 15) != 0) return 0;
+    if (!I.seg[s].p || (I.seg[s].ncols & 15) || I.seg[s].ncols < 16) return 0;
+    // bf16 slabs: 16-byte pieces of 8 elements on 16-byte boundaries; fp32: any dword-aligned column range of the batch
+    // (global_load_dwordx4 ... lds takes dword-aligned sources: tests with ld = 325, first column 305)
+    if (!f32 && ((I.seg[s].ld & 7) || (I.seg[s].col0 & 7) || (((uintptr_t)I.seg[s].p) & 15) != 0)) return 0;
+    if (f32 && (((uintptr_t)I.seg[s].p) & 3) != 0) return 0;
     np += I.seg[s].ncols;
   }
   if (np > 16 * 4 * DWB_NFW) return 0;
-  if ((I.lda & 7) || (((uintptr_t)I.a) & 15) != 0 || I.M < 1 || I.Hp < I.h || I.h < 1) return 0;
+  if ((I.lda & (f32 ? 3 : 7)) || (((uintptr_t)I.a) & 15) != 0 || I.M < 1 || I.Hp < I.h || I.h < 1) return 0;
   const int P = DWB_KC * (DWB_MT + np) / 8;
   if ((P + DWB_THREADS - 1) / DWB_THREADS > DWB_MAXNI) return 0;
   return 1;
@@ -337,10 +385,11 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
   double wsum = 0.0;
   for (int i = 0; i < L.n_items; ++i) {
     DwbItem& I = L.it[i];
-    MFM_REQUIRE(dw_bf16_supported(I), "dw bf16: item %d is not supported", i);
-    MFM_REQUIRE((int64_t)L.rows * I.lda * 2 < ((int64_t)1 << 31), "dw bf16: A spans >= 2^31 bytes");
+    MFM_REQUIRE(dw_bf16_supported(I, L.f32), "dw one-pass: item %d is not supported", i);
+    const int64_t es = L.f32 ? 4 : 2;
+    MFM_REQUIRE((int64_t)DWB_KC * I.lda * es < ((int64_t)1 << 31), "dw one-pass: A row stride too large");
     for (int s = 0; s < I.nseg; ++s)
-      MFM_REQUIRE((int64_t)I.seg[s].rows * I.seg[s].ld * 2 < ((int64_t)1 << 31) && I.seg[s].shift >= 0, "dw bf16: segment %d spans >= 2^31 bytes", s);
+      MFM_REQUIRE((int64_t)DWB_KC * I.seg[s].ld * es < ((int64_t)1 << 31) && I.seg[s].shift >= 0, "dw one-pass: segment %d row stride too large", s);
     I.m_tiles = (I.M + DWB_MT - 1) / DWB_MT;
     int N = 0;
     for (int s = 0; s < I.nseg; ++s) N += I.seg[s].ncols;
@@ -375,36 +424,44 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
   }
   static bool attr = false;
   if (!attr) {
-    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
-  MFM_REQUIRE(smem <= 160 * 1024, "dw bf16: %zu bytes of LDS", smem);
-  hipLaunchKernelGGL(dw_bf16_kernel, dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
-  MFM_LAUNCH_CHECK("dw_bf16_kernel");
+  MFM_REQUIRE(smem <= 160 * 1024, "dw one-pass: %zu bytes of LDS", smem);
+  // STATUS of the fp32 form: parity-green (tests/test_gpu_large_batch.py), but at B = 2048 it runs 666 us (+ 94 us of tail
+  // GEMM) against 626 us for the grouped GEMM: its main loop keeps the fp32 matrix pipe ~43 % busy (one ds_read_b32 and its
+  // wait per three MFMAs; batching a k-step's reads ahead of its MFMAs made it 779 us) -> opt-in, MFM_DW_F32_MINROWS
+  if (L.f32) hipLaunchKernelGGL(dw_stream_kernel<true>, dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
+  else hipLaunchKernelGGL(dw_stream_kernel<false>, dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
+  MFM_LAUNCH_CHECK("dw_stream_kernel");
   return MFM_OK;
 }
 
 }  // namespace mfm
 
-// Test / tuning entry point (not used by the plan, which builds DwbLaunch itself): one LSTM's weight gradients from
-// bf16-resident buffers.  dA [rows, 4 Hp] bf16, xb [rows, ldx] bf16 (columns [0, dx) used, dx padded to 16 by the caller's
-// layout), hs [rows, Hp] bf16 (row r pairs with hs[r - shift]); outputs fp32, accumulated into.
-extern "C" int mfm_dw_bf16_lstm(const void* dA, int32_t rows, int32_t h, const void* xb, int32_t ldx, int32_t dx,
-                                const void* hs, int32_t shift, float* dw_ih, float* dw_hh, float* dw_hh2, float* db_ih,
-                                float* db_hh, void* stream) {
+// Test / tuning entry points (not used by the plan, which builds DwbLaunch itself): one LSTM's weight gradients from
+// bf16-resident (f32 = 0) or fp32 (f32 = 1) buffers.  dA [rows, 4 Hp], xb [rows, ldx] (columns [xcol0, xcol0 + dx) used), hs
+// [rows, Hp] (row r pairs with hs[r - shift]); outputs fp32, accumulated into.
+static int dw_lstm_entry(int f32, const void* dA, int32_t rows, int32_t h, const void* xb, int32_t ldx, int32_t xcol0, int32_t dx,
+                         const void* hs, int32_t shift, float* dw_ih, float* dw_hh, float* dw_hh2, float* db_ih, float* db_hh,
+                         void* stream) {
   using namespace mfm;
-  MFM_REQUIRE(dA && hs && dw_hh && rows >= 1 && h >= 1, "mfm_dw_bf16_lstm: bad arguments");
+  MFM_REQUIRE(dA && hs && dw_hh && rows >= 1 && h >= 1, "mfm_dw_*_lstm: bad arguments");
   const int Hp = round_up(h, 16);
   DwbLaunch L;
   memset(&L, 0, sizeof(L));
-  L.rows = rows; L.n_items = 1;
+  L.rows = rows; L.n_items = 1; L.f32 = f32;
   DwbItem& I = L.it[0];
   I.a = reinterpret_cast<const __bf16*>(dA); I.lda = 4 * Hp; I.M = 4 * Hp; I.Hp = Hp; I.h = h;
   int n = 0;
   if (xb) {
-    MFM_REQUIRE(dw_ih && dx >= 1, "mfm_dw_bf16_lstm: x given without dw_ih / dx");
+    MFM_REQUIRE(dw_ih && dx >= 1, "mfm_dw_*_lstm: x given without dw_ih / dx");
     I.seg[I.nseg].p = reinterpret_cast<const __bf16*>(xb); I.seg[I.nseg].ld = ldx; I.seg[I.nseg].ncols = round_up(dx, 16);
-    I.seg[I.nseg].col0 = 0; I.seg[I.nseg].shift = 0; I.seg[I.nseg].rows = rows; ++I.nseg;
+    I.seg[I.nseg].col0 = xcol0; I.seg[I.nseg].shift = 0;
+    // (fp32: a slab wider than what is left of the LAST row would leave the buffer: the caller's plan moves that row to a
+    // K = 1 GEMM; the test entry point simply requires the slack to exist or the slab to fit)
+    I.seg[I.nseg].rows = rows; ++I.nseg;
     I.out[I.nout].n0 = 0; I.out[I.nout].nvalid = dx; I.out[I.nout].c = dw_ih; I.out[I.nout].ldc = dx; ++I.nout;
     n = round_up(dx, 16);
   }
@@ -412,6 +469,18 @@ extern "C" int mfm_dw_bf16_lstm(const void* dA, int32_t rows, int32_t h, const v
   I.seg[I.nseg].col0 = 0; I.seg[I.nseg].shift = shift; I.seg[I.nseg].rows = rows; ++I.nseg;
   I.out[I.nout].n0 = n; I.out[I.nout].nvalid = h; I.out[I.nout].c = dw_hh; I.out[I.nout].c2 = dw_hh2; I.out[I.nout].ldc = h; ++I.nout;
   I.cb = db_ih; I.cb2 = db_hh;
-  if (!dw_bf16_supported(I)) { set_error("mfm_dw_bf16_lstm: shape not supported (h=%d dx=%d ldx=%d)", h, dx, ldx); return MFM_ERR_UNSUPPORTED; }
+  if (!dw_bf16_supported(I, f32)) { set_error("mfm_dw_*_lstm: shape not supported (h=%d dx=%d ldx=%d)", h, dx, ldx); return MFM_ERR_UNSUPPORTED; }
   return dw_bf16_launch(L, (hipStream_t)stream);
+}
+
+extern "C" int mfm_dw_bf16_lstm(const void* dA, int32_t rows, int32_t h, const void* xb, int32_t ldx, int32_t dx,
+                                const void* hs, int32_t shift, float* dw_ih, float* dw_hh, float* dw_hh2, float* db_ih,
+                                float* db_hh, void* stream) {
+  return dw_lstm_entry(0, dA, rows, h, xb, ldx, 0, dx, hs, shift, dw_ih, dw_hh, dw_hh2, db_ih, db_hh, stream);
+}
+
+extern "C" int mfm_dw_f32_lstm(const float* dA, int32_t rows, int32_t h, const float* x, int32_t ldx, int32_t xcol0, int32_t dx,
+                               const float* hs, int32_t shift, float* dw_ih, float* dw_hh, float* dw_hh2, float* db_ih,
+                               float* db_hh, void* stream) {
+  return dw_lstm_entry(1, dA, rows, h, x, ldx, xcol0, dx, hs, shift, dw_ih, dw_hh, dw_hh2, db_ih, db_hh, stream);
 }

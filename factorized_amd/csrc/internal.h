@@ -118,8 +118,8 @@ struct DwbItem {
   float* cb; float* cb2;                // optional: column sums of A (bias gradients), indexed like the rows of C
   int tile_begin, m_tiles, splits, rows_per_split, stages, pad_;     // filled by dw_bf16_launch
 };
-struct DwbLaunch { DwbItem it[MFM_DWB_MAXI]; int n_items, rows; const void* zeros; int debug_no_epilogue, pad_; };   // zeros: >= 16 bytes of device zeros (null: the launcher's own)
-int dw_bf16_supported(const DwbItem& I);
+struct DwbLaunch { DwbItem it[MFM_DWB_MAXI]; int n_items, rows; const void* zeros; int debug_no_epilogue; int f32; };   // f32: the buffers hold fp32 (round 3; element counts / strides then count floats)   // zeros: >= 16 bytes of device zeros (null: the launcher's own)
+int dw_bf16_supported(const DwbItem& I, int f32 = 0);
 int dw_bf16_launch(DwbLaunch& L, hipStream_t stream);
 // x [rows, D] fp32 -> bf16 [rows, ldo] with up to three column ranges moved to 16-aligned positions (pad columns zero)
 int x_to_bf16_launch(const float* x, void* out, int64_t rows, int D, int ldo, const int* src0, const int* n, const int* dst0,

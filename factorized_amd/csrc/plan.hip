@@ -1356,6 +1356,59 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       MFM_REQUIRE(DB.n_items <= MFM_DWB_MAXI, "plan: %d one-pass items", DB.n_items);
       RUN(K_DEC_DW, dw_bf16_launch(DB, s));
     }
+    // fp32 plans at large T*B (round 3): the LSTMs' sums over the rows on the fp32 form of the one-pass kernel
+    // (dw_stream_kernel<true>: the batch and the fp32 dA / h buffers streamed by LDS-DMA in memory order, exact fp32 MFMA
+    // chains); MFM_DW_F32_MINROWS moves the threshold (0 = off)
+    long f32_min_rows = 0;          // measured slower than the grouped GEMM (dw_bf16.hip, launcher note): opt-in
+    if (const char* e = getenv("MFM_DW_F32_MINROWS")) f32_min_rows = atol(e);
+    const bool f32pass = !c.precision && !onepass && f32_min_rows > 0 && TB >= f32_min_rows && TB > 1;
+    bool f32_done[9] = {false, false, false, false, false, false, false, false, false};
+    if (f32pass) {
+      DwbLaunch DF;
+      memset(&DF, 0, sizeof(DF));
+      DF.rows = (int)TB; DF.f32 = 1;
+      auto lstm_item32 = [&](const SeqBuf& sb, int pb, const float* xin, int xcol0, int kin, bool dec) -> bool {
+        DwbItem I;
+        memset(&I, 0, sizeof(I));
+        I.a = reinterpret_cast<const __bf16*>(W + sb.gates); I.lda = 4 * sb.Hp; I.M = 4 * sb.Hp; I.Hp = sb.Hp; I.h = sb.h;
+        int n = 0;
+        bool last_row_apart = false;
+        if (!dec) {
+          DwbSeg& S = I.seg[I.nseg++];
+          S.p = reinterpret_cast<const __bf16*>(xin); S.ld = P->D; S.col0 = xcol0; S.ncols = round_up(kin, 16); S.shift = 0;
+          // a slab wider than what is left of the row runs into the next row -- harmless, those columns are never stored --
+          // but behind the LAST row it would leave the batch buffer: that row's input product goes to the tail GEMM (K = 1)
+          last_row_apart = xcol0 + S.ncols > P->D;
+          S.rows = last_row_apart ? (int)TB - 1 : (int)TB;
+          DwbOut& O = I.out[I.nout++];
+          O.n0 = 0; O.nvalid = kin; O.c = grads + P->off[pb + W_IH]; O.ldc = kin;
+          n = S.ncols;
+        }
+        DwbSeg& S = I.seg[I.nseg++];
+        S.p = reinterpret_cast<const __bf16*>(W + sb.hs); S.ld = sb.Hp; S.col0 = 0; S.ncols = sb.Hp; S.shift = B; S.rows = (int)TB;
+        DwbOut& O = I.out[I.nout++];
+        O.n0 = n; O.nvalid = sb.h; O.c = grads + P->off[pb + W_HH]; O.ldc = sb.h;
+        if (dec) O.c2 = grads + P->off[pb + W_IH];
+        I.cb = grads + P->off[pb + B_IH]; I.cb2 = grads + P->off[pb + B_HH];
+        if (DF.n_items >= MFM_DWB_MAXI || !dw_bf16_supported(I, 1)) return false;
+        DF.it[DF.n_items++] = I;
+        if (last_row_apart) {
+          MfmGemmDesc d;
+          memset(&d, 0, sizeof(d));
+          d.a_sz = sb.Hp; d.a_sm = 1; d.a_sk = 4 * (int64_t)sb.Hp; d.m = sb.h; d.batch = 4; d.accumulate = 1; d.split_k = 1; d.alpha = 1.0f;
+          d.a = W + sb.gates + (TB - 1) * 4 * sb.Hp;
+          d.b = xin + (TB - 1) * P->D + xcol0; d.b_sk = P->D; d.b_sn = 1;
+          d.k = 1; d.n = kin; d.n_valid = kin;
+          d.c = grads + P->off[pb + W_IH]; d.c_sz = (int64_t)sb.h * kin; d.ldc = kin;
+          tail.push_back(d);
+        }
+        return true;
+      };
+      for (int e = 0; e < P->n_enc; ++e) f32_done[e] = lstm_item32(P->enc[e], P->enc_p[e], x, P->enc_xoff[e], P->enc_d[e], false);
+      if (gen_on)
+        for (int m = 0; m < 3; ++m) f32_done[6 + m] = lstm_item32(P->dec[m], P->dec_p[m], nullptr, 0, 0, true);
+      if (DF.n_items > 0) RUN(K_DEC_DW, dw_bf16_launch(DF, s));
+    }
     DwLaunch DL;
     memset(&DL, 0, sizeof(DL));
     DL.rows = (int)TB;
@@ -1371,6 +1424,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       return I;
     };
     for (int e = 0; e < P->n_enc && !st16; ++e) {
+      if (f32_done[e]) continue;
       DwItem I = item(P->enc[e], P->enc_p[e], x + P->enc_xoff[e], P->D, P->enc_d[e], false);
       if (onepass && DL.n_items < MFM_DW_MAXI && dw_onepass_supported(I, c.precision)) DL.it[DL.n_items++] = I;
       else dA_gemms(P, P->enc[e], P->enc_p[e], W, grads, tail, x + P->enc_xoff[e], P->D, P->enc_d[e], false);
@@ -1378,8 +1432,8 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     if (gen_on && !st16)
       for (int m = 0; m < 3; ++m) {
         DwItem I = item(P->dec[m], P->dec_p[m], nullptr, 0, 0, true);
-        const bool op = onepass && DL.n_items < MFM_DW_MAXI && dw_onepass_supported(I, c.precision);
-        if (op) DL.it[DL.n_items++] = I;
+        const bool op = f32_done[6 + m] || (onepass && DL.n_items < MFM_DW_MAXI && dw_onepass_supported(I, c.precision));
+        if (op && !f32_done[6 + m]) DL.it[DL.n_items++] = I;
         dA_gemms(P, P->dec[m], P->dec_p[m], W, grads, tail, W + P->dec_init[m], P->dec_h[m], P->dec_h[m], true, op);
       }
     if (DL.n_items > 0) RUN(K_DEC_DW, dw_onepass_launch(DL, c.precision, s));

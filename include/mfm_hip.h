@@ -143,6 +143,11 @@ int mfm_lstm_seq_bwd(const MfmSeqDesc* descs /*host*/, int count, int T, int B, 
  * Test / tuning entry point; the fused plan builds the same launch for all LSTMs and the decoders' fc1 at once. */
 int mfm_dw_bf16_lstm(const void* dA, int32_t rows, int32_t h, const void* xb, int32_t ldx, int32_t dx, const void* hs,
                      int32_t shift, float* dw_ih, float* dw_hh, float* dw_hh2, float* db_ih, float* db_hh, void* stream);
+/* The same one pass over fp32 buffers (fp32 plans at large T*B): dA [rows, 4, Hp], hs [rows, Hp] fp32; x is the batch itself,
+ * [rows, ldx] fp32, of which columns [xcol0, xcol0 + dx) are this LSTM's input (any dword-aligned column range). */
+int mfm_dw_f32_lstm(const float* dA, int32_t rows, int32_t h, const float* x, int32_t ldx, int32_t xcol0, int32_t dx,
+                    const float* hs, int32_t shift, float* dw_ih, float* dw_hh, float* dw_hh2, float* db_ih, float* db_hh,
+                    void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Reconstruction loss + gradient, replaces nn.MSELoss over x_hat vs the input slices and its

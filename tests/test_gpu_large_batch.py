@@ -132,7 +132,7 @@ def test_you_shape_large_batch_matches_oracle(monkeypatch):
 
 
 @pytest.mark.parametrize("variant", ["staged", "fr2", "fr4", "panel", "panel80", "staged+fr2+mfma", "fc1gemm", "dwonepass",
-                                     "nochains", "latpre", "nofold", "dwgemm", "dwtn"])
+                                     "nochains", "latpre", "nofold", "dwgemm", "dwtn", "dwf32"])
 @pytest.mark.parametrize("name", cases.KLEF_CASES)
 def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
     """The same kernels forced onto every golden case (B = 1 .. 229, ragged sizes, T = 1, CE and 7-output heads):
@@ -174,6 +174,11 @@ def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
     # "dwtn" forces it at every size (T*B up to 4580 here: 29 chunks), "dwgemm" the grouped GEMM at every size
     for k in ("MFM_GEMM_TN", "MFM_GEMM_TN_MAXROWS"):
         monkeypatch.delenv(k, raising=False)
+    # "dwf32": dw_stream_kernel<true>, the fp32 form of the LDS-DMA one-pass kernel (round 3, opt-in: slower than the GEMMs)
+    if variant == "dwf32":
+        monkeypatch.setenv("MFM_DW_F32_MINROWS", "1")
+    else:
+        monkeypatch.delenv("MFM_DW_F32_MINROWS", raising=False)
     if variant == "dwgemm":
         monkeypatch.setenv("MFM_GEMM_TN", "0")
     if variant == "dwtn":
@@ -220,3 +225,46 @@ def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
     gs = gold["grad_summary"]
     scale = np.maximum(np.abs(gs[:, :1]), 1e-6)
     assert np.max(np.abs(np.stack(rows) - gs) / scale) < 5 * TOL
+
+
+@pytest.mark.parametrize("h,D,xcol0,dx,rows,shift", [(120, 325, 0, 325, 640, 32), (32, 325, 0, 300, 640, 32), (8, 325, 300, 5, 100, 5),
+                                                      (80, 325, 305, 20, 4580, 229), (104, 0, 0, 0, 640, 32), (24, 0, 0, 0, 37, 37),
+                                                      (120, 410, 0, 410, 5120, 256), (36, 51, 40, 11, 171, 19)])
+def test_fp32_weight_gradients_one_pass(h, D, xcol0, dx, rows, shift):
+    """dw_stream_kernel<true> (round 3): dW_ih, dW_hh (+ the decoders' second target), db of one LSTM from fp32 dA / x / h in
+    ONE pass -- LDS-DMA slabs in memory order (x is the batch itself: any dword-aligned column range, row stride D), b32
+    fragment reads, v_mfma_f32_16x16x4_f32; exact fp32 FMA chains, so the fp64 reference must match to summation error"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ctypes as C
+    from factorized_amd import _lib
+    rs = np.random.RandomState(h + dx + rows)
+    Hp = (h + 15) // 16 * 16
+    dA = np.zeros((rows, 4, Hp), dtype=np.float32)
+    dA[:, :, :h] = rs.normal(size=(rows, 4, h))
+    hs = np.zeros((rows, Hp), dtype=np.float32)
+    hs[:, :h] = rs.normal(size=(rows, h))
+    da_d, hs_d = torch.from_numpy(dA).cuda(), torch.from_numpy(hs).cuda()
+    x_d = None
+    if dx:
+        x = rs.normal(size=(rows, D)).astype(np.float32)
+        x_d = torch.from_numpy(x).cuda()
+    dw_ih = torch.full((4 * h, max(dx, 1)), 0.5, device="cuda")
+    dw_hh = torch.full((4 * h, h), 0.25, device="cuda")
+    dw_hh2 = torch.zeros(4 * h, h, device="cuda")
+    db1, db2 = torch.zeros(4 * h, device="cuda"), torch.full((4 * h,), 1.0, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    _lib.check(_lib.lib().mfm_dw_f32_lstm(p(da_d), rows, h, p(x_d), D, xcol0, dx, p(hs_d), shift, p(dw_ih) if dx else C.c_void_p(0),
+                                          p(dw_hh), p(dw_hh2), p(db1), p(db2), None), "mfm_dw_f32_lstm")
+    A = dA[:, :, :h].reshape(rows, 4 * h).astype(np.float64)
+    H = hs[:, :h].astype(np.float64)
+    ref_hh = A[shift:].T @ H[:rows - shift] if rows > shift else np.zeros((4 * h, h))
+    scale = max(np.abs(ref_hh).max(), 1.0)
+    assert np.abs(dw_hh.cpu().numpy() - 0.25 - ref_hh).max() < 1e-5 * scale
+    assert np.abs(dw_hh2.cpu().numpy() - ref_hh).max() < 1e-5 * scale
+    ref_b = A.sum(0)
+    assert np.abs(db1.cpu().numpy() - ref_b).max() < 1e-5 * max(np.abs(ref_b).max(), 1.0)
+    assert np.abs(db2.cpu().numpy() - 1.0 - ref_b).max() < 1e-5 * max(np.abs(ref_b).max(), 1.0)
+    if dx:
+        ref_ih = A.T @ x[:, xcol0:xcol0 + dx].astype(np.float64)
+        assert np.abs(dw_ih.cpu().numpy() - 0.5 - ref_ih).max() < 1e-5 * max(np.abs(ref_ih).max(), 1.0)
