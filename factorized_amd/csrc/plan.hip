@@ -292,9 +292,16 @@ static int build(MfmPlan* P) {
   P->lay_c1 = c1_off; P->lay_mc = mc_off;
   const int64_t* o = P->off;
   int st = 0;
-  // encoder fc1 (mfm_model.py:60-61)
-  for (int e = 0; e < nfc; ++e)
+  // encoder fc1 (mfm_model.py:60-61).  Batches beyond the row kernels' range (staged kernels, latent.hip) give the
+  // early-fusion encoder's fc1 a stage of its own: the four heads together are the largest weight span (89 KB at the MOSI
+  // sizes), alone it is 58 KB, and the LDS that frees doubles the rows a workgroup carries (backward 4 -> 8).
+  const int lat_row_maxb = getenv("MFM_LATENT_ROW_MAXB") ? atoi(getenv("MFM_LATENT_ROW_MAXB")) : 256;   // tuning override
+  bool split0 = V == 0 && c.B > lat_row_maxb && c.B > 4 * device_cus();   // (up to 4 rows x CUs one round of 4-row workgroups does)
+  if (const char* e = getenv("MFM_LATENT_SPLIT0")) split0 = V == 0 && atoi(e) != 0;
+  for (int e = 0; e < nfc; ++e) {
+    if (split0 && e == 3) ++st;
     add_op(P->lat_ops, L, st, e, L.in_off[e], last_off[e], in_n[e], in_n[e], o[pi.enc[e] + FC_W], o[pi.enc[e] + FC_B], 0, -1, 0.f);
+  }
   ++st;
   // mu heads (mfm_model.py:630-639 / 737-744).  The logvar heads only feed the KLD, nothing downstream waits
   // for them, so they ride along with the classifier's first layer (the row kernels give every
@@ -382,8 +389,7 @@ static int build(MfmPlan* P) {
   // Latency path (latent.hip, row kernels): one row per workgroup while that still fits the chip in one
   // wave of workgroups and every layer meets the vector-load shape requirements.
   {
-    const int row_maxb = getenv("MFM_LATENT_ROW_MAXB") ? atoi(getenv("MFM_LATENT_ROW_MAXB")) : 256;   // tuning override
-    bool ok = c.B <= row_maxb && (size_t)2 * rs * sizeof(float) <= 24 * 1024 && P->n_params < (1ll << 31);
+    bool ok = c.B <= lat_row_maxb && !split0 && (size_t)2 * rs * sizeof(float) <= 24 * 1024 && P->n_params < (1ll << 31);
     ok = ok && (in_n[0] + in_n[1] + in_n[2] + in_n[3] <= MFM_LAT_ROW_THREADS);     // prologue: one input element per thread
     for (int i = 0; i < L.nops && ok; ++i) {
       const LatOp& op = P->lat_ops[i];

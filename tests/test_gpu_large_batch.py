@@ -132,7 +132,7 @@ def test_you_shape_large_batch_matches_oracle(monkeypatch):
 
 
 @pytest.mark.parametrize("variant", ["staged", "fr2", "fr4", "panel", "panel80", "staged+fr2+mfma", "fc1gemm", "dwonepass",
-                                     "nochains", "latpre", "nofold", "dwgemm", "dwtn", "dwf32"])
+                                     "nochains", "latpre", "nofold", "dwgemm", "dwtn", "dwf32", "staged+split0"])
 @pytest.mark.parametrize("name", cases.KLEF_CASES)
 def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
     """The same kernels forced onto every golden case (B = 1 .. 229, ragged sizes, T = 1, CE and 7-output heads):
@@ -144,6 +144,10 @@ def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
     monkeypatch.delenv("MFM_SEQ_ROWS", raising=False)
     if "staged" in variant:
         monkeypatch.setenv("MFM_LATENT_PATH", "staged")
+    if "split0" in variant:          # the early-fusion encoder's fc1 as a stage of its own (default beyond B = 4 x CUs:
+        monkeypatch.setenv("MFM_LATENT_SPLIT0", "1")    # a 58 KB instead of an 89 KB weight panel, 8-row backward workgroups)
+    else:
+        monkeypatch.delenv("MFM_LATENT_SPLIT0", raising=False)
     if "fr2" in variant:
         monkeypatch.setenv("MFM_GEMM_FR", "2")
     if "fr4" in variant:
