@@ -67,6 +67,15 @@ struct PanelLaunch {
 int gemm_panel_launch(PanelLaunch& L, const ZeroSpans* zs, int precision, bool force, hipStream_t stream);
 bool gemm_panel_pays(const PanelLaunch& L, int precision, bool force);
 
+// proj_bf16.hip -- the same projections for a bf16-RESIDENT plan: weights packed once per step into a bf16 tile image
+// (proj_bf16_pack_launch), tiles by LDS-DMA, bf16 results by 8-byte stores, the padded bf16 image of x as a side output
+struct ProjPlan { int ntiles, nbias, BM, S; size_t lds; int tile0[MFM_PANEL_MAXG], kt0[MFM_PANEL_MAXG], nkt[MFM_PANEL_MAXG], nchunks[MFM_PANEL_MAXG], bias_off[MFM_PANEL_MAXG]; };
+int proj_bf16_plan(const PanelLaunch& L, ProjPlan* out);      // 1: supported (only the groups' shapes, M and K are read)
+// scratch: wimg = ntiles * 8192 bytes (16-byte aligned), bimg = nbias floats
+int proj_bf16_pack_launch(const PanelLaunch& L, const ProjPlan& P, void* wimg, float* bimg, hipStream_t stream);
+int proj_bf16_launch(const PanelLaunch& L, const ProjPlan& P, const void* wimg, const float* bimg, void* x16, int x16_ld,
+                     const int* xsrc0, const int* xn, const int* xdst0, const ZeroSpans* zs, hipStream_t stream);
+
 // dec_fc1.hip -- decoder fc1 forward + squared-error loss + backward to the hidden states, one launch (fp32)
 struct DecFc1Item {
   const float* hs; const float* w; const float* bias; const float* x;   // H [rows, Hp], Wfc [d, h], b [d], target columns (row stride ldx)
@@ -84,9 +93,11 @@ struct DecFc1LargeItem {
   void* dxhat; void* dhs; float* loss;                                   // [rows, ld_dxhat] bf16, [rows, Hp] bf16, loss slot
   int64_t ldx; int d, h, Hp, ld_dxhat; float inv_count, grad_scale;
   int wg_begin, wg_count;                                                // filled by dec_fc1_large_launch
+  void* wimg;     // optional scratch, dec_fc1_large_wimg_bytes(): the bf16 image of Wfc, packed once per launch instead of once per workgroup
 };
-struct DecFc1LargeLaunch { DecFc1LargeItem it[3]; int n_items, rows; };
+struct DecFc1LargeLaunch { DecFc1LargeItem it[3]; int n_items, rows, dbg; };   // dbg: tuning aid (MFM_FC1_LARGE_DBG)
 int dec_fc1_large_supported(const DecFc1LargeItem& I);
+size_t dec_fc1_large_wimg_bytes(int d);
 int dec_fc1_large_launch(DecFc1LargeLaunch& L, hipStream_t stream);
 
 // dw_onepass.hip -- all weight gradients of one LSTM as ONE product over the rows (large T*B)

@@ -129,6 +129,11 @@ struct MfmPlan {
   int64_t h_last[6];                // st16: fp32 copy of h_{T-1} per encoder [B, Hp] (the latent stack / the MFN heads read it)
   int64_t x16; int x16_ld, x16_off[3];   // st16: bf16 image of the batch [T*B, x16_ld], every modality slice on a 16-column boundary
   int dxh_ld[3];                    // st16: row stride of the bf16 d x_hat buffers
+  int64_t fc1_wimg[3];              // st16: scratch for the decoder fc1 weight images (dec_fc1_large.hip)
+  bool proj16 = false;              // st16: the projections run on proj_bf16_kernel (which also writes x16)
+  mfm::ProjPlan pj;                 // its tile image layout, panel height and pipeline depth
+  int64_t pj_wimg, pj_bimg;         // scratch: packed bf16 weight tiles, combined biases
+  unsigned long long x16_call = ~0ull;   // value of `calls` for which the forward already produced x16
   unsigned long long fc1_bwd_call = ~0ull;   // value of `calls` for which the forward already produced dH of the decoders (dec_fc1.hip)
 };
 
@@ -228,6 +233,22 @@ static int build(MfmPlan* P) {
     for (int m = 0; m < 3; ++m) { P->x16_off[m] = at; at += round_up(dd[m], 16); }
     P->x16_ld = at;
     P->x16 = carve(cur, TB * P->x16_ld / 2);
+    for (int m = 0; m < 3; ++m) P->fc1_wimg[m] = carve(cur, (int64_t)(dec_fc1_large_wimg_bytes(dd[m]) + 3) / 4);
+    // the projections of this plan: proj_bf16.hip when its panel fits the LDS (MFM_PROJ16=0: gemm_panel / tiled GEMM)
+    PanelLaunch PL;
+    memset(&PL, 0, sizeof(PL));
+    PL.M = (int)TB; PL.K = P->D; PL.ngroups = P->n_enc;
+    for (int e = 0; e < P->n_enc && e < MFM_PANEL_MAXG; ++e) {
+      PanelGroup& G = PL.g[e];
+      G.n = 4 * P->enc[e].Hp; G.seg = P->enc[e].Hp; G.seg_valid = P->enc[e].h; G.k_off = P->enc_xoff[e]; G.k_len = P->enc_d[e];
+    }
+    const char* pe = getenv("MFM_PROJ16");
+    P->proj16 = (!pe || atoi(pe) != 0) && P->n_enc <= MFM_PANEL_MAXG && TB * P->D < ((int64_t)1 << 29) && proj_bf16_plan(PL, &P->pj);
+    if (P->proj16) {
+      P->pj_wimg = carve(cur, (int64_t)P->pj.ntiles * 2048);
+      P->pj_bimg = carve(cur, P->pj.nbias);
+    }
+    if (getenv("MFM_PLAN_DEBUG")) fprintf(stderr, "[mfm plan] bf16-resident projections: proj_bf16_kernel %d (%d tiles, %d-row panels, %d stages)\n", (int)P->proj16, P->pj.ntiles, P->pj.BM, P->pj.S);
   }
   // ---- Memory Fusion Network (variants 1, 2): every [T*B, .] tensor of the attention block and the memory recurrence
   P->tot = P->A2 = P->nzy = 0;
@@ -802,7 +823,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     const char* pe = getenv("MFM_PANEL_MINROWS");
     const bool panel_forced = pe && TB >= atol(pe);
     const bool panel = (pe ? panel_forced : TB >= 16L * device_cus()) && P->n_enc <= MFM_PANEL_MAXG && (int64_t)TB * P->D < ((int64_t)1 << 29);
-    if (panel) {
+    if (panel || (st16 && P->proj16)) {
       PanelLaunch PL;
       memset(&PL, 0, sizeof(PL));
       PL.a = x; PL.lda = P->D; PL.M = (int)TB; PL.K = P->D;
@@ -815,7 +836,12 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
         G.c = W + sb.gates; G.ldc = 4 * (int64_t)sb.Hp; G.c_bf16 = st16 ? 1 : 0;
         G.n = 4 * sb.Hp; G.seg = sb.Hp; G.seg_valid = sb.h; G.k_off = P->enc_xoff[e]; G.k_len = P->enc_d[e];
       }
-      if (gemm_panel_pays(PL, c.precision, panel_forced)) RUN(K_PROJ, gemm_panel_launch(PL, &zs, c.precision, panel_forced, s));
+      if (st16 && P->proj16) {
+        const int src0[3] = {0, c.d_l, c.d_l + c.d_a}, nn[3] = {c.d_l, c.d_a, c.d_v};
+        RUN(K_PACK, proj_bf16_pack_launch(PL, P->pj, W + P->pj_wimg, W + P->pj_bimg, s));
+        RUN(K_PROJ, proj_bf16_launch(PL, P->pj, W + P->pj_wimg, W + P->pj_bimg, W + P->x16, P->x16_ld, src0, nn, P->x16_off, &zs, s));
+        P->x16_call = P->calls;
+      } else if (gemm_panel_pays(PL, c.precision, panel_forced)) RUN(K_PROJ, gemm_panel_launch(PL, &zs, c.precision, panel_forced, s));
       else RUN(K_PROJ, gemm_group_launch(g, P->n_enc, s, &zs, nullptr, 0, c.precision));
     } else {
       RUN(K_PROJ, gemm_group_launch(g, P->n_enc, s, &zs, nullptr, 0, c.precision));
@@ -938,6 +964,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
         I.dxhat = me[m].dxhat; I.ld_dxhat = P->dxh_ld[m]; I.dhs = W + P->dec_dhs[m]; I.loss = me[m].loss;
         I.d = P->dec_d[m]; I.h = P->dec[m].h; I.Hp = P->dec[m].Hp;
         I.inv_count = me[m].inv_count; I.grad_scale = me[m].grad_scale;
+        I.wimg = W + P->fc1_wimg[m];
         ok = ok && dec_fc1_large_supported(I);
       }
       if (ok) {
@@ -1323,7 +1350,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     if (st16) {
       // the batch as bf16, modality slices on 16-column boundaries (what the one-pass kernel streams by LDS-DMA)
       const int src0[3] = {0, c.d_l, c.d_l + c.d_a}, nn[3] = {c.d_l, c.d_a, c.d_v};
-      RUN(K_PACK, x_to_bf16_launch(x, W + P->x16, TB, P->D, P->x16_ld, src0, nn, P->x16_off, s));
+      if (P->x16_call != P->calls) RUN(K_PACK, x_to_bf16_launch(x, W + P->x16, TB, P->D, P->x16_ld, src0, nn, P->x16_off, s));
       auto lstm_item = [&](const SeqBuf& sb, int pb, int xcol0, int xcols, bool dec, int e) {
         DwbItem& I = DB.it[DB.n_items++];
         I.a = reinterpret_cast<const __bf16*>(W + sb.gates); I.lda = 4 * sb.Hp; I.M = 4 * sb.Hp; I.Hp = sb.Hp; I.h = sb.h;

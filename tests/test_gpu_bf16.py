@@ -493,7 +493,7 @@ def _bf16_engine(cfgs):
     return e, w
 
 
-@pytest.fixture(params=["all-bf16", "default", "all-bf16+panel", "all-bf16+panel160", "all-bf16+panel96"])
+@pytest.fixture(params=["all-bf16", "default", "all-bf16+panel", "all-bf16+panel160", "all-bf16+panel96", "all-bf16+proj128", "all-bf16+proj64", "all-bf16+fc1r16"])
 def seq_policy(request, monkeypatch):
     """a bf16 plan runs its recurrences on the bf16 MFMA kernels from B = 192 on and on the fp32 VALU kernels below
     (lstm_seq.hip::bf16_seq_pays); 'all-bf16' forces the bf16 kernels at every batch size."""
@@ -503,7 +503,19 @@ def seq_policy(request, monkeypatch):
     else:
         monkeypatch.delenv("MFM_BF16_SEQ_MINB", raising=False)
         monkeypatch.delenv("MFM_BF16_STORE", raising=False)
+    # bf16-resident plans project on proj_bf16_kernel (proj_bf16.hip; it also writes the bf16 image of x the one-pass weight
+    # gradients stream); "projNN" forces its panel height, "panel*" switches it off: gemm_panel_kernel<true> + x_to_bf16_kernel
+    # decoder fc1 of a bf16-resident plan: dec_fc1_large64_kernel (64-row tiles); "fc1r16" = the 16-row kernel it replaced
+    if "fc1r16" in request.param:
+        monkeypatch.setenv("MFM_FC1_LARGE_ROWS", "16")
+    else:
+        monkeypatch.delenv("MFM_FC1_LARGE_ROWS", raising=False)
+    monkeypatch.delenv("MFM_PROJ16", raising=False)
+    monkeypatch.delenv("MFM_PROJ16_BM", raising=False)
+    if "proj" in request.param:
+        monkeypatch.setenv("MFM_PROJ16_BM", request.param.split("proj")[1])
     if "panel" in request.param:
+        monkeypatch.setenv("MFM_PROJ16", "0")
         monkeypatch.setenv("MFM_PANEL_MINROWS", "1")    # gemm_panel_kernel<true> for the input projections
         monkeypatch.setenv("MFM_DW_ONEPASS_MINROWS", "1")   # and dw_onepass_kernel<true> for the LSTM weight gradients
         bm = request.param.split("panel")[1]                # forced panel height (default: the launcher's pick, 128 here)
