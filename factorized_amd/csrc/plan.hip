@@ -171,11 +171,12 @@ static int build(MfmPlan* P) {
   // weight-gradient kernel takes (dw_bf16.hip); MFM_BF16_STORE=0 keeps the round-2 form (fp32 buffers, rounding on load).
   P->seq_bf16 = c.precision && bf16_seq_pays(c.B);
   {
-    // default from T*B = 16384 rows: below, the fused decoder-fc1 launch and the chunked weight-gradient kernels of the
-    // fp32-stored form win (measured at the MOSI sizes, B = 256 / 512 / 1024 / 2048 / 4096: 0.468 vs 0.418, 0.568 vs 0.523,
-    // 0.665 vs 0.704, 0.93 vs 1.146, 1.73 vs 2.20 ms); MFM_BF16_STORE=1 forces it on for every size, =0 off
+    // default from T*B = 5120 rows.  Measured at the MOSI sizes (bf16-resident vs fp32-stored, ms per step; B = 192 / 256 /
+    // 384 / 512 / 768 / 1024): 0.400 vs 0.378, 0.411 vs 0.418, 0.436 vs 0.471, 0.446 vs 0.521, 0.477 vs 0.603, 0.509 vs 0.706
+    // (before proj_bf16.hip and the 64-row decoder fc1 the crossover was at T*B = 16384); MFM_BF16_STORE=1 forces it on for
+    // every size, =0 off
     const char* se = getenv("MFM_BF16_STORE");
-    long st_minrows = 16384;
+    long st_minrows = 5120;
     if (const char* e = getenv("MFM_BF16_STORE_MINROWS")) st_minrows = atol(e);
     bool ok = P->seq_bf16 && !getenv("MFM_SEQ_STEPWISE") && (se ? atoi(se) != 0 : TB >= st_minrows);
     const int Dp = round_up(c.d_l, 16) + round_up(c.d_a, 16) + round_up(c.d_v, 16);
@@ -1802,13 +1803,19 @@ extern "C" double mfm_plan_kernel_flops(const MfmPlan* P, int kid) {
       break;
     }
     case K_FC1_BWD: for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m]; break;   // dH only
-    case K_DEC_DW: break;   // merged into K_ENC_DW
-    case K_ENC_DW:
-      for (int e = 0; e < P->n_enc; ++e) f += TB * 2.0 * 4.0 * P->enc_h[e] * (P->enc_d[e] + P->enc_h[e]);
-      for (int m = 0; m < 3; ++m) f += TB * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m];
-      for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m];            // dWfc
-      for (int i = 0; i < P->lat.nops; ++i) f += 2.0 * P->B * P->lat_ops[i].N * P->lat_ops[i].K;   // latent dW
+    // weight gradients: one grouped launch (K_ENC_DW) -- except on bf16-resident plans, where the sums over the T*B rows
+    // (LSTMs, decoder fc1) run on the one-pass kernel (K_DEC_DW) and K_ENC_DW keeps the B-row products
+    case K_DEC_DW: case K_ENC_DW: {
+      double rows_f = 0.0, rest = 0.0;
+      for (int e = 0; e < P->n_enc; ++e) rows_f += TB * 2.0 * 4.0 * P->enc_h[e] * (P->enc_d[e] + P->enc_h[e]);
+      for (int m = 0; m < 3; ++m) rows_f += (TB - P->B) * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m];
+      for (int m = 0; m < 3; ++m) rows_f += TB * 2.0 * P->dec_h[m] * P->dec_d[m];            // dWfc
+      for (int m = 0; m < 3; ++m) rest += (double)P->B * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m];      // the decoders' t = 0 product
+      for (int i = 0; i < P->lat.nops; ++i) rest += 2.0 * P->B * P->lat_ops[i].N * P->lat_ops[i].K;   // latent dW
+      if (P->st16) f = (kid == K_DEC_DW) ? rows_f : rest;
+      else f = (kid == K_ENC_DW) ? rows_f + rest : 0.0;
       break;
+    }
     // Memory Fusion Network (variants 1, 2), GEMM form: per-launch AVERAGE over the launches that share the timer id
     case K_MFN_ATT_FWD: {
       const MfmPlanConfig& c = P->cfg;
