@@ -60,6 +60,24 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int off_bytes, 
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off_bytes, 0, 0);
 }
 
+// A thread's resident weights: elements [k0, k0 + MEM_MAXW) of one weight row (zero beyond n).  Whole, 16-byte aligned
+// slices arrive as 8 independent 16-byte loads; the first version's 32 clamped dword loads per slice made the forward's
+// prologue address-rate bound (96 loads x 32 cache lines per wave instruction: 18 of the 40 us of a T = 20 launch,
+// scripts/bench_mfn_mem.py).
+__device__ __forceinline__ void load_wslice(float (&w)[32], const float* __restrict__ row, int k0, int n, bool act) {
+  const float* src = row + k0;
+  if (act && k0 + 32 <= n && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    f32x4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = reinterpret_cast<const f32x4*>(src)[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { w[4 * i] = v[i][0]; w[4 * i + 1] = v[i][1]; w[4 * i + 2] = v[i][2]; w[4 * i + 3] = v[i][3]; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) w[i] = (act && k0 + i < n) ? row[min(k0 + i, n - 1)] : 0.0f;
+  }
+}
+
 // Matvec operand layout (round 2): lane q of a QA- / QB-lane group owns the CONTIGUOUS slice k in [32 q, 32 q + 32) of the
 // reduction dimension, so its 32 vector elements arrive as 8 ds_read_b128 (the first version interleaved k = q + Q i:
 // 96 ds_read_b32 per thread and step made the kernels LDS-instruction bound, ~2 us per step).  LDS vectors are padded to
@@ -95,11 +113,7 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_fwd_kernel(const MemDev P) {
   const int jn = netA ? ja - H1 : ja;
   const float* wm = netA ? d.w2m : d.w1m;
   float wA[MEM_MAXW];
-#pragma unroll
-  for (int i = 0; i < MEM_MAXW; ++i) {
-    const int k = MEM_MAXW * qa + i;
-    wA[i] = (actA && k < M) ? wm[(int64_t)jn * P.ldw + min(k, M - 1)] : 0.0f;
-  }
+  load_wslice(wA, wm + (int64_t)jn * P.ldw, MEM_MAXW * qa, M, actA);
   float* abuf = netA ? d.a2 : d.a1;
   const int Hn = netA ? H2 : H1;
   const float pA = netA ? d.p2 : d.p1;
@@ -109,12 +123,8 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_fwd_kernel(const MemDev P) {
   const bool actB = tid < nB;
   const int mb = min(tid, nB - 1) / QB, qb = tid % QB;
   float wB1[MEM_MAXW], wB2[MEM_MAXW];
-#pragma unroll
-  for (int i = 0; i < MEM_MAXW; ++i) {
-    const int k = MEM_MAXW * qb + i;
-    wB1[i] = (actB && k < H1) ? d.w1b[(int64_t)mb * H1 + min(k, H1 - 1)] : 0.0f;
-    wB2[i] = (actB && k < H2) ? d.w2b[(int64_t)mb * H2 + min(k, H2 - 1)] : 0.0f;
-  }
+  load_wslice(wB1, d.w1b + (int64_t)mb * H1, MEM_MAXW * qb, H1, actB);
+  load_wslice(wB2, d.w2b + (int64_t)mb * H2, MEM_MAXW * qb, H2, actB);
   const float bb1 = d.b1b[mb], bb2 = d.b2b[mb];
 
   const uint64_t seed = d.seed + (d.seed_dev ? *d.seed_dev : 0ull);
@@ -185,24 +195,53 @@ __global__ __launch_bounds__(MAXT) void mfn_mem_fwd_kernel(const MemDev P) {
     cur ^= 1;
   }
   if (actB && qb == 0 && d.mem_out) d.mem_out[mrow] = memr;
-  // ---- heads on mfn_last = [h_l, h_a, h_v](T-1) | mem_T (mem_T sits in memb[cur]): 8 lanes per output, K = tot + M
+  // ---- heads on mfn_last = [h_l, h_a, h_v](T-1) | mem_T: 8 lanes per output, K = tot + M.  The input vector is staged in
+  // LDS first (over the recurrence's buffers, which nobody reads any more), so the dot products run without the
+  // per-element segment branches and their loads go out back to back
   if (P.hd.on) {
     const MfnHeadsDev& H = P.hd;
     const int KT = H.tot + M, nout = H.nheads * H.zy;
     const int q8 = tid & 7;
     const int n0 = H.seg_n[0], n1 = n0 + H.seg_n[1];
+    const bool staged = KT <= 2 * MP + H1P + P.H2P;          // (wave-uniform)
+    float* vec = lds;
+    if (staged) {
+      for (int k = tid; k < H.tot; k += blockDim.x) {
+        float v;
+        if (k < n0) v = H.seg[0][(int64_t)row * H.seg_ld[0] + k];
+        else if (k < n1) v = H.seg[1][(int64_t)row * H.seg_ld[1] + (k - n0)];
+        else v = H.seg[2][(int64_t)row * H.seg_ld[2] + (k - n1)];
+        vec[k] = v;
+      }
+      if (stB) vec[H.tot + mb] = memr;
+      __syncthreads();
+    }
     for (int o = tid >> 3; o < nout; o += (int)blockDim.x >> 3) {
       const int hd = o / H.zy, n = o - hd * H.zy;
       const float* wr = H.w[hd] + (int64_t)n * KT;
       float s = 0.0f;
+      if (staged) {
+        float s1 = 0.0f;
+        int k = q8;
+        for (; k + 56 < KT; k += 64) {
+          float wv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) wv[u] = wr[k + 8 * u];
+#pragma unroll
+          for (int u = 0; u < 8; u += 2) { s = fmaf(wv[u], vec[k + 8 * u], s); s1 = fmaf(wv[u + 1], vec[k + 8 * u + 8], s1); }
+        }
+        for (; k < KT; k += 8) s = fmaf(wr[k], vec[k], s);
+        s += s1;
+      } else {
 #pragma unroll 8
-      for (int k = q8; k < KT; k += 8) {
-        float v;
-        if (k < n0) v = H.seg[0][(int64_t)row * H.seg_ld[0] + k];
-        else if (k < n1) v = H.seg[1][(int64_t)row * H.seg_ld[1] + (k - n0)];
-        else if (k < H.tot) v = H.seg[2][(int64_t)row * H.seg_ld[2] + (k - n1)];
-        else v = memb[cur * MP + (k - H.tot)];
-        s = fmaf(wr[k], v, s);
+        for (int k = q8; k < KT; k += 8) {
+          float v;
+          if (k < n0) v = H.seg[0][(int64_t)row * H.seg_ld[0] + k];
+          else if (k < n1) v = H.seg[1][(int64_t)row * H.seg_ld[1] + (k - n0)];
+          else if (k < H.tot) v = H.seg[2][(int64_t)row * H.seg_ld[2] + (k - n1)];
+          else v = memb[cur * MP + (k - H.tot)];
+          s = fmaf(wr[k], v, s);
+        }
       }
       s = group_sum(s, 8);
       if (q8 == 0) H.zyin[(int64_t)row * H.nzy + hd * H.zy + n] = s + H.b[hd][n];

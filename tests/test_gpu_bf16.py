@@ -493,7 +493,7 @@ def _bf16_engine(cfgs):
     return e, w
 
 
-@pytest.fixture(params=["all-bf16", "default", "all-bf16+panel", "all-bf16+panel160", "all-bf16+panel96", "all-bf16+proj128", "all-bf16+proj64", "all-bf16+fc1r16"])
+@pytest.fixture(params=["all-bf16", "default", "all-bf16+panel", "all-bf16+panel160", "all-bf16+panel96", "all-bf16+proj128", "all-bf16+proj64", "all-bf16+fc1r16", "all-bf16+tnsplit"])
 def seq_policy(request, monkeypatch):
     """a bf16 plan runs its recurrences on the bf16 MFMA kernels from B = 192 on and on the fp32 VALU kernels below
     (lstm_seq.hip::bf16_seq_pays); 'all-bf16' forces the bf16 kernels at every batch size."""
@@ -505,6 +505,12 @@ def seq_policy(request, monkeypatch):
         monkeypatch.delenv("MFM_BF16_STORE", raising=False)
     # bf16-resident plans project on proj_bf16_kernel (proj_bf16.hip; it also writes the bf16 image of x the one-pass weight
     # gradients stream); "projNN" forces its panel height, "panel*" switches it off: gemm_panel_kernel<true> + x_to_bf16_kernel
+    # "tnsplit": the B-row products of fp32 operands (the latent stack's weight gradients) on gemm_tn_kernel, the rest of
+    # the last launch on the grouped bf16 GEMM (default from B = 1024)
+    if "tnsplit" in request.param:
+        monkeypatch.setenv("MFM_GEMM_TN_BF16_MINB", "1")
+    else:
+        monkeypatch.delenv("MFM_GEMM_TN_BF16_MINB", raising=False)
     # decoder fc1 of a bf16-resident plan: dec_fc1_large64_kernel (64-row tiles); "fc1r16" = the 16-row kernel it replaced
     if "fc1r16" in request.param:
         monkeypatch.setenv("MFM_FC1_LARGE_ROWS", "16")
