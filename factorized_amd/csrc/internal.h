@@ -237,6 +237,7 @@ struct LatentDev {
                                        // walks the stages (the MMD regulariser's d reg / d z of the non-KL MFM)
   unsigned long long* dbg;             // optional: block 0 / thread 0 writes s_memtime at phase marks
   int B, rows_per_wg, rows_fwd, train, has_logvar;     // rows per workgroup of the staged kernels: backward / forward
+  int mfma;                            // staged kernels: the layers' products on v_mfma_f32_16x16x4_f32 (rows per workgroup <= 16, every K % 4 == 0)
   int row_path;                        // 1: one batch row per workgroup, weights read straight from L2 (latent.hip)
   // row path: per-thread work items of every stage, precomputed by the host ([nstages][MFM_LAT_ROW_THREADS] int4,
   // encoding in latent.hip) and the number of threads that have an item in each stage

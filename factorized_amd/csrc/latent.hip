@@ -54,10 +54,13 @@ __device__ __forceinline__ void copy_span(const float* __restrict__ src, float* 
 // previous stage's compute), the LDS writes happen when the panel is free.  Covers the first
 // 8*nt chunks; copy_span handles a longer tail.
 constexpr int PRE_U = 8;
+// Buffer loads whose range is the span: a lane past the end reads 0 WITHOUT a memory request.  (The first version clamped
+// the index instead: every stage then pulled 8 * nt * 16 bytes = 128 KB through the CU whatever the span's length --
+// 0.9 MB instead of 228 KB per workgroup at ~10 B/clk, which was most of the staged kernels' time.)
 __device__ __forceinline__ void span_load(const float* __restrict__ src, int n4, int tid, int nt, f32x4 (&pre)[PRE_U]) {
-  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, n4 * 16, 0x00020000);
 #pragma unroll
-  for (int u = 0; u < PRE_U; ++u) pre[u] = s4[min(tid + u * nt, max(n4 - 1, 0))];
+  for (int u = 0; u < PRE_U; ++u) pre[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (tid + u * nt) * 16, 0, 0));
 }
 __device__ __forceinline__ void span_store(const float* __restrict__ src, float* __restrict__ dst, int n4, int tid,
                                            int nt, const f32x4 (&pre)[PRE_U]) {
@@ -127,6 +130,71 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(const LatentDev
     // a quad split the reduction dim in interleaved 16-byte chunks (ds_read_b128 for the weight row
     // and for each of the 4 activation rows: 5 LDS reads per 16 FMAs), all-reduce with two DPP adds,
     // then lane q finishes batch row q.  All 1024 threads have work (sum N x 4 ~ 1000 items).
+    if (STAGED && L.mfma) {
+      // MFMA form (round 3).  The quad form below reads 5 bytes of LDS per multiply-add (a 16-byte weight chunk and four
+      // 16-byte activation chunks per 16 FMAs).  Here a wave owns a fragment of 16 output columns of one layer for ALL rows of the
+      // workgroup (<= 16): D[row][n] += x[row][k] w[n][k] on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains), lane (bi, q)
+      // supplying x[row bi][k] and w[n0 + bi][k] for k = 16 j + 4 q + e in MFMA step e of chunk j -- both operands of four
+      // steps arrive as ONE 16-byte read each: 0.5 bytes of LDS per multiply-add.  Measured (B = 2048, profiles/r03_latent_mfma.txt):
+      // 43.6 -> 39.4 us forward, 67.2 -> 60.0 us backward -- a stage's ~6000 cycles are mostly the serial bookkeeping
+      // around the product (op look-up, bias, dropout stream, record writes: LDS round trips at one wave's pace), which
+      // both forms share.
+      const int lane = tid & 63, wave = tid >> 6, nwv = nt >> 6;
+      const int bi = lane & 15, q = lane >> 4;
+      int units = 0;
+      for (int o = ob; o < oe; ++o) units += (ops[o].N + 15) >> 4;
+      for (int u = wave; u < units; u += nwv) {
+        int o = ob, f = u;
+        while (f >= ((ops[o].N + 15) >> 4)) { f -= (ops[o].N + 15) >> 4; ++o; }
+        const LatOp op = ops[o];
+        const int n = f * 16 + bi;
+        const float* ap = rec + min(bi, nrows - 1) * RS + op.in_off + 4 * q;
+        const float* wq = wp + (op.w_off - woff0) + (int64_t)min(n, op.N - 1) * op.K + 4 * q;
+        // four independent accumulation chains (a single one is 30 dependent MFMAs deep for K = 120: ~1500 cycles of
+        // issue-to-result latency), two chunks per trip so that their four reads are in flight together
+        f32x4 ac[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ac[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < op.K; kc += 32) {
+          const bool ok0 = kc + 4 * q < op.K, ok1 = kc + 16 + 4 * q < op.K;     // (K % 4 == 0: a chunk is whole or absent)
+          const int k0 = ok0 ? kc : 0, k1 = ok1 ? kc + 16 : 0;
+          f32x4 av0 = *reinterpret_cast<const f32x4*>(ap + k0), wv0 = *reinterpret_cast<const f32x4*>(wq + k0);
+          f32x4 av1 = *reinterpret_cast<const f32x4*>(ap + k1), wv1 = *reinterpret_cast<const f32x4*>(wq + k1);
+          if (!ok0) av0 = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (!ok1) av1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ac[e] = mma16x16x4(av0[e], wv0[e], ac[e]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ac[e] = mma16x16x4(av1[e], wv1[e], ac[e]);
+        }
+        const f32x4 acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
+        // accumulator register r of lane (bi, q): row 4q + r, column n
+        if (n < op.N) {
+          const float bv = wp[(op.b_off - woff0) + n];
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int r = 4 * q + r4;
+            if (r < nrows) {
+              float v = acc[r4] + bv;
+              if (op.relu) v = fmaxf(v, 0.0f);
+              if (op.mask_off >= 0) {
+                float mk = 1.0f;
+                if (L.train && op.drop_p > 0.0f) {
+                  const uint64_t idx = ((uint64_t)o << 40) + (uint64_t)(row0 + r) * (uint64_t)op.N + (uint64_t)n;
+                  mk = (rng_uniform(L.seed, idx) < op.drop_p) ? 0.0f : 1.0f / (1.0f - op.drop_p);
+                }
+                v *= mk;
+                rec[r * RS + op.mask_off + n] = mk;
+              }
+              rec[r * RS + op.out_off + n] = v;
+            }
+          }
+        }
+      }
+      lds_barrier();
+      mark(L, 3 + 2 * s);
+      continue;
+    }
     const int nch = (nrows + 3) >> 2;
     const int total = 4 * nch * (pfxN[oe - 1] + ops[oe - 1].N);
     for (int item4 = tid; item4 < ((total + 3) & ~3); item4 += nt) {
@@ -387,6 +455,44 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_kernel(const LatentDev
     // pass 2a: grad wrt the input segment (LDS atomics: several ops may share an input).
     // work item = (input column k of one op, n-quarter q, chunk of 4 rows): the quad splits the output
     // dim in interleaved chunks of 4, all-reduces with DPP, lane q adds batch row q.
+    if (STAGED && L.mfma) {
+      // MFMA form: a wave owns 16 input columns k of one layer for all rows: D[row][k] += g[row][n] w[n][k]; lane (bi, q)
+      // supplies g[row bi][n] (one 16-byte read per four steps) and w[n][k0 + bi] (four 4-byte reads: a column of the
+      // row-major weight) for n = 16 j + 4 q + e
+      const int lane = tid & 63, wave = tid >> 6, nwv = nt >> 6;
+      const int bi = lane & 15, q = lane >> 4;
+      int units = 0;
+      for (int o = ob; o < oe; ++o) units += (ops[o].K + 15) >> 4;
+      for (int u = wave; u < units; u += nwv) {
+        int o = ob, f = u;
+        while (f >= ((ops[o].K + 15) >> 4)) { f -= (ops[o].K + 15) >> 4; ++o; }
+        const LatOp op = ops[o];
+        const int k = f * 16 + bi;
+        const float* gp = grd + min(bi, nrows - 1) * RS + op.out_off + 4 * q;
+        const float* wq = wp + (op.w_off - woff0) + min(k, op.K - 1);
+        f32x4 ac[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ac[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nc = 0; nc < op.N; nc += 16) {
+          const int n0 = nc + 4 * q;
+          // (record segments are padded to multiples of 4 floats: a chunk that starts inside the segment can be read whole)
+          const f32x4 gv = *reinterpret_cast<const f32x4*>(gp + (n0 < op.N ? nc : 0));
+          float wv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) wv[e] = wq[min(n0 + e, op.N - 1) * op.K];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ac[e] = mma16x16x4(n0 + e < op.N ? gv[e] : 0.0f, wv[e], ac[e]);
+        }
+        const f32x4 acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
+        if (k < op.K) {
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int r = 4 * q + r4;
+            if (r < nrows) atomicAdd(&grd[r * RS + op.in_off + k], acc[r4]);
+          }
+        }
+      }
+    } else {
     const int nch = (nrows + 3) >> 2;
     total = 4 * nch * (pfxK[oe - 1] + ops[oe - 1].K);
     for (int item4 = tid; item4 < ((total + 3) & ~3); item4 += nt) {
@@ -433,6 +539,7 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_kernel(const LatentDev
       const float lo = (q & 1) ? acc[1] : acc[0], hi = (q & 1) ? acc[3] : acc[2];
       const float v = (q & 2) ? hi : lo;
       if (live && r0 + q < nrows) atomicAdd(&grd[(r0 + q) * RS + op.in_off + k], v);
+    }
     }
     mark(L, 26 + 3 * s);
     // pass 2b: bias gradients (column sums over this workgroup's rows).  The WEIGHT gradients

@@ -396,6 +396,14 @@ static int build(MfmPlan* P) {
     while (R > 1 && 2 * (size_t)R * rs * sizeof(float) > LDS_BUDGET) R >>= 1;
   }
   L.rows_per_wg = R;
+  // the staged kernels' products on the fp32 MFMA (latent.hip) when the weight panel is staged and every layer's K is a
+  // multiple of 4; MFM_LATENT_MFMA=0 keeps the quad form
+  {
+    bool ok = L.wpanel > 0 && R <= 16;
+    for (int i = 0; i < L.nops && ok; ++i) ok = (P->lat_ops[i].K & 3) == 0 && ((P->lat_ops[i].w_off - L.span_off[P->lat_ops[i].stage]) & 3) == 0;
+    if (const char* e = getenv("MFM_LATENT_MFMA")) ok = ok && atoi(e) != 0;
+    L.mfma = ok ? 1 : 0;
+  }
   // the forward keeps ONE record per row in LDS (the backward two), so it can take more rows per workgroup: a workgroup's
   // time is mostly the six stage spans it streams from L2 (140 KB, ~17 of ~30 us at 4 rows), not the rows' arithmetic
   {

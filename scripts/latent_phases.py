@@ -23,7 +23,7 @@ torch.cuda.synchronize()
 p = e.plan(20, B)
 off = _lib.lib().mfm_plan_debug_offset(p.handle)
 ts = p.workspace[off:off + 64 * 8].view(torch.int64).cpu().numpy()
-NS = 6
+NS = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 f = ts[:24]
 print("latent_fwd (cycles, workgroup 0):")
 print("  prologue(load inputs+ops) %d" % (f[1] - f[0]))

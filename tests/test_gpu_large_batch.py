@@ -132,7 +132,7 @@ def test_you_shape_large_batch_matches_oracle(monkeypatch):
 
 
 @pytest.mark.parametrize("variant", ["staged", "fr2", "fr4", "panel", "panel80", "staged+fr2+mfma", "fc1gemm", "dwonepass",
-                                     "nochains", "latpre", "nofold", "dwgemm", "dwtn", "dwf32", "staged+split0"])
+                                     "nochains", "latpre", "nofold", "dwgemm", "dwtn", "dwf32", "staged+split0", "staged+quad"])
 @pytest.mark.parametrize("name", cases.KLEF_CASES)
 def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
     """The same kernels forced onto every golden case (B = 1 .. 229, ragged sizes, T = 1, CE and 7-output heads):
@@ -144,6 +144,11 @@ def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
     monkeypatch.delenv("MFM_SEQ_ROWS", raising=False)
     if "staged" in variant:
         monkeypatch.setenv("MFM_LATENT_PATH", "staged")
+    # the staged kernels' products run on v_mfma_f32_16x16x4_f32 by default; "quad" = the VALU quad form they replaced
+    if "quad" in variant:
+        monkeypatch.setenv("MFM_LATENT_MFMA", "0")
+    else:
+        monkeypatch.delenv("MFM_LATENT_MFMA", raising=False)
     if "split0" in variant:          # the early-fusion encoder's fc1 as a stage of its own (default beyond B = 4 x CUs:
         monkeypatch.setenv("MFM_LATENT_SPLIT0", "1")    # a 58 KB instead of an 89 KB weight panel, 8-row backward workgroups)
     else:
