@@ -60,8 +60,12 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lds_base, int off
 // ds_read_b32 (lane (bi, q) reads element [row 4 ks + q][column bi] of the memory-order slab: no transposition problem at 4
 // bytes per element).  The column groups of odd slab rows are rotated by 16 floats on their way in (the DMA source address
 // is free, the LDS side is lane-linear), so the two rows a 32-lane half of a fragment read touches fall on different banks.
-template <bool F32>
+// MF: A fragments per wave (the workgroup owns MT = 32 MF columns of A), NFW: N fragments per wave (N <= 64 NFW).  (3, 9) is the
+// general form; (4, 8) -- 128-column M-tiles, N <= 512 -- re-reads the right-hand side once per 128 instead of once per 96
+// columns of A and has no half-empty last tile for M = 128 / 256 / 512 (the launcher picks it when every item fits).
+template <bool F32, int MF, int NFW>
 __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch L) {
+  constexpr int MT = 2 * 16 * MF;
   constexpr int ES = F32 ? 4 : 2;                 // bytes per operand element
   constexpr int EPP = 16 / ES;                    // elements per 16-byte DMA piece
   constexpr int KC = F32 ? 16 : DWB_KC;           // rows per chunk
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
   const DwbItem& I = L.it[it];
   const int local = v - I.tile_begin;
   const int mt = local % I.m_tiles, sp = local / I.m_tiles;
-  const int m0 = mt * DWB_MT;
+  const int m0 = mt * MT;
   const int r_begin = sp * I.rows_per_split, r_end = min(L.rows, r_begin + I.rows_per_split);
   const int n_chunks = (r_end - r_begin + KC - 1) / KC;
 
@@ -92,11 +96,15 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
 
   // ---- chunk image in LDS, in DMA piece order (16 bytes per piece, lane-linear): A [32][96] | seg0 [32][n0] | seg1 [32][n1]
   const int n0 = I.seg[0].ncols, n1 = (I.nseg > 1) ? I.seg[1].ncols : 0;
-  const int pa = KC * DWB_MT / EPP, p0 = KC * n0 / EPP, p1 = KC * n1 / EPP;            // pieces; each a multiple of 64
+  const int pa = KC * MT / EPP, p0 = KC * n0 / EPP, p1 = KC * n1 / EPP;            // pieces; each a multiple of 64
   const int P = pa + p0 + p1;
   const int NI = (P + DWB_THREADS - 1) / DWB_THREADS;
   const int stage_bytes = NI * DWB_THREADS * 16;
   const int NF = (n0 + n1) >> 4;
+  // bf16 images whose rows are a multiple of 256 bytes (128 / 256 columns) would put the 16 rows of a transposing fragment
+  // read on the same banks: their 16-byte pieces are rotated by 2 (row & 7) positions on the way in (the DMA source address
+  // is free), and the fragment reads below undo it
+  auto bf_rot = [](int width, int row) { return ((width & 127) == 0) ? (2 * (row & 7)) % (width >> 3) : 0; };
 
   // ---- per-thread DMA plan: piece p = i * 512 + tid -> (image, row of the chunk, 8-column group).  Plain global addresses
   // (global_load_dwordx4 ... lds), one 64-bit pointer per piece advanced by a per-piece stride each chunk; a piece that
@@ -113,9 +121,9 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
     // group (c + 4 (row & 1)) mod groups-per-row (bank spreading for the b32 fragment reads, see the kernel comment)
     const unsigned char* abase = reinterpret_cast<const unsigned char*>(I.a);
     if (p < pa) {
-      constexpr int GPR = DWB_MT / EPP;
+      constexpr int GPR = MT / EPP;
       const int row = p / GPR, cpos = p % GPR;
-      const int cg = F32 ? (cpos + 4 * (row & 1)) % GPR : cpos;
+      const int cg = F32 ? (cpos + 4 * (row & 1)) % GPR : (cpos + bf_rot(MT, row)) % GPR;
       if (m0 + cg * EPP < I.lda) {                        // columns past the row end: zeros, not the next row's data
         src[i] = abase + ((int64_t)(r_begin + row) * I.lda + m0 + cg * EPP) * ES;
         inc[i] = KC * I.lda * ES; row0[i] = r_begin + row; lo[i] = 0; hi[i] = r_end;
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
       const int ssh = s1 ? I.seg[1].shift : I.seg[0].shift, srows = s1 ? I.seg[1].rows : I.seg[0].rows;
       const int pp = p - pa - (s1 ? p0 : 0), gpr = sn / EPP;
       const int row = pp / gpr, cpos = pp % gpr;
-      const int cg = F32 ? (cpos + 4 * (row & 1)) % gpr : cpos;
+      const int cg = F32 ? (cpos + 4 * (row & 1)) % gpr : (cpos + bf_rot(sn, row)) % gpr;
       // row r of the chunk pairs with row r - shift of the segment
       src[i] = sp + ((int64_t)(r_begin + row - ssh) * sld + sc0 + cg * EPP) * ES;
       inc[i] = KC * sld * ES; row0[i] = r_begin + row - ssh; lo[i] = 0; hi[i] = srows;
@@ -165,35 +173,39 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
     const int gpr = width / 4;
     return q * width + ((col0 / 4 - 4 * (q & 1) + gpr) % gpr) * 4 + bi;
   };
-  int a_off[DWB_MF];
+  auto bf_pos = [&](int width, int col) {            // bf16 element index of (row rrow, column col) in a [32][width] slab
+    const int gpr = width >> 3, rot = bf_rot(width, rrow);
+    return rrow * width + (((col >> 3) - rot + gpr) % gpr) * 8 + (col & 7);
+  };
+  int a_off[MF];
 #pragma unroll
-  for (int i = 0; i < DWB_MF; ++i)
-    a_off[i] = F32 ? f32_pos(DWB_MT, wm * 16 * DWB_MF + i * 16) * 4 : (rrow * DWB_MT + wm * 16 * DWB_MF + i * 16 + rcol) * 2;
-  int b_off[DWB_NFW], b_r16[DWB_NFW];               // b_r16: bf16: bytes of 16 slab rows; F32: bytes of one k-step (4 rows)
+  for (int i = 0; i < MF; ++i)
+    a_off[i] = F32 ? f32_pos(MT, wm * 16 * MF + i * 16) * 4 : bf_pos(MT, wm * 16 * MF + i * 16 + rcol) * 2;
+  int b_off[NFW], b_r16[NFW];               // b_r16: bf16: bytes of 16 slab rows; F32: bytes of one k-step (4 rows)
   int njw = 0;
 #pragma unroll
-  for (int j = 0; j < DWB_NFW; ++j) {
+  for (int j = 0; j < NFW; ++j) {
     const int nf = wn + 4 * j;
     int n = nf * 16;
     if (nf < NF) njw = j + 1;
     if (n < n0) {
-      b_off[j] = pa * 16 + (F32 ? f32_pos(n0, n) * 4 : (rrow * n0 + n + rcol) * 2);
+      b_off[j] = pa * 16 + (F32 ? f32_pos(n0, n) * 4 : bf_pos(n0, n + rcol) * 2);
       b_r16[j] = F32 ? 4 * n0 * 4 : 16 * n0 * 2;
     } else {
       n -= n0;
       const int w1 = max(n1, 16), nc = min(n, max(n1 - 16, 0));
-      b_off[j] = (pa + p0) * 16 + (F32 ? f32_pos(w1, nc) * 4 : (rrow * w1 + nc + rcol) * 2);
+      b_off[j] = (pa + p0) * 16 + (F32 ? f32_pos(w1, nc) * 4 : bf_pos(w1, nc + rcol) * 2);
       b_r16[j] = F32 ? 4 * w1 * 4 : 16 * w1 * 2;
     }
   }
   njw = __builtin_amdgcn_readfirstlane(njw);
 
-  f32x4 acc[DWB_MF][DWB_NFW], accb[DWB_MF];
+  f32x4 acc[MF][NFW], accb[MF];
 #pragma unroll
-  for (int i = 0; i < DWB_MF; ++i) {
+  for (int i = 0; i < MF; ++i) {
     accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < DWB_NFW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NFW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   bf16x8 ones;
 #pragma unroll
@@ -225,36 +237,36 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
     if constexpr (F32) {
 #pragma unroll
       for (int ks = 0; ks < KC / 4; ++ks) {
-        float af[DWB_MF];
+        float af[MF];
 #pragma unroll
-        for (int i = 0; i < DWB_MF; ++i) af[i] = *reinterpret_cast<const float*>(st + a_off[i] + ks * (4 * DWB_MT * 4));
+        for (int i = 0; i < MF; ++i) af[i] = *reinterpret_cast<const float*>(st + a_off[i] + ks * (4 * MT * 4));
         if (want_bias) {
 #pragma unroll
-          for (int i = 0; i < DWB_MF; ++i) accb[i] = mma16x16x4(af[i], 1.0f, accb[i]);
+          for (int i = 0; i < MF; ++i) accb[i] = mma16x16x4(af[i], 1.0f, accb[i]);
         }
 #pragma unroll
-        for (int j = 0; j < DWB_NFW; ++j) {
+        for (int j = 0; j < NFW; ++j) {
           if (j < njw) {                                    // scalar branch: njw is wave-uniform
             const float bf = *reinterpret_cast<const float*>(st + b_off[j] + ks * b_r16[j]);
 #pragma unroll
-            for (int i = 0; i < DWB_MF; ++i) acc[i][j] = mma16x16x4(af[i], bf, acc[i][j]);
+            for (int i = 0; i < MF; ++i) acc[i][j] = mma16x16x4(af[i], bf, acc[i][j]);
           }
         }
       }
     } else {
-      bf16x8 af[DWB_MF];
+      bf16x8 af[MF];
 #pragma unroll
-      for (int i = 0; i < DWB_MF; ++i) af[i] = tr_frag(st, a_off[i], 16 * DWB_MT * 2);
+      for (int i = 0; i < MF; ++i) af[i] = tr_frag(st, a_off[i], 16 * MT * 2);
       if (want_bias) {
 #pragma unroll
-        for (int i = 0; i < DWB_MF; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+        for (int i = 0; i < MF; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
       }
 #pragma unroll
-      for (int j = 0; j < DWB_NFW; ++j) {
+      for (int j = 0; j < NFW; ++j) {
         if (j < njw) {                                      // scalar branch: njw is wave-uniform
           const bf16x8 bf = tr_frag(st, b_off[j], b_r16[j]);
 #pragma unroll
-          for (int i = 0; i < DWB_MF; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+          for (int i = 0; i < MF; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
         }
       }
     }
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
   if (L.debug_no_epilogue == 1) return;     // (tuning aid: MFM_DWB_NOEPI=1 measures the streaming part alone)
   const int Hp = I.Hp, h = I.h;
 #pragma unroll
-  for (int j = 0; j < DWB_NFW; ++j) {
+  for (int j = 0; j < NFW; ++j) {
     if (j >= njw) continue;
     const int n = (wn + 4 * j) * 16 + bi;
     float* dst = nullptr; float* dst2 = nullptr; int ldc = 0, col = 0;
@@ -277,10 +289,10 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
     }
     if (!dst) continue;
 #pragma unroll
-    for (int i = 0; i < DWB_MF; ++i)
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 16 * DWB_MF + i * 16 + 4 * q + r;
+        const int m = m0 + wm * 16 * MF + i * 16 + 4 * q + r;
         if (m >= I.M) continue;
         const int g = m / Hp, u = m - g * Hp;
         if (u >= h) continue;
@@ -291,10 +303,10 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
   }
   if (want_bias && bi == 0) {
 #pragma unroll
-    for (int i = 0; i < DWB_MF; ++i)
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 16 * DWB_MF + i * 16 + 4 * q + r;
+        const int m = m0 + wm * 16 * MF + i * 16 + 4 * q + r;
         if (m >= I.M) continue;
         const int g = m / Hp, u = m - g * Hp;
         if (u >= h) continue;
@@ -355,7 +367,7 @@ int dw_bf16_supported(const DwbItem& I, int f32) {
     if (f32 && (((uintptr_t)I.seg[s].p) & 3) != 0) return 0;
     np += I.seg[s].ncols;
   }
-  if (np > 16 * 4 * DWB_NFW) return 0;
+  if (np > 16 * 4 * DWB_NFW) return 0;        // (the general form; the launcher decides about the 128-column one)
   if ((I.lda & (f32 ? 3 : 7)) || (((uintptr_t)I.a) & 15) != 0 || I.M < 1 || I.Hp < I.h || I.h < 1) return 0;
   const int P = DWB_KC * (DWB_MT + np) / 8;
   if ((P + DWB_THREADS - 1) / DWB_THREADS > DWB_MAXNI) return 0;
@@ -390,7 +402,22 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
     MFM_REQUIRE((int64_t)DWB_KC * I.lda * es < ((int64_t)1 << 31), "dw one-pass: A row stride too large");
     for (int s = 0; s < I.nseg; ++s)
       MFM_REQUIRE((int64_t)DWB_KC * I.seg[s].ld * es < ((int64_t)1 << 31) && I.seg[s].shift >= 0, "dw one-pass: segment %d row stride too large", s);
-    I.m_tiles = (I.M + DWB_MT - 1) / DWB_MT;
+  }
+  // tile shape: 128-column M-tiles with <= 512 right-hand-side columns when every item fits (bf16 form only), else 96 / 576
+  // (measured, MOSI sizes: T*B = 40960 rows 180 vs 173 us -- the streaming part is 24 us shorter, 134 vs 158, but the same
+  // number of workgroups now adds 128-column partial tiles: 46 instead of 15 us of atomics -- T*B = 81920 rows 269 vs 309 us:
+  // the wide form from 65536 rows on; MFM_DWB_MF=4 / 3 forces one)
+  const int mf_env = getenv("MFM_DWB_MF") ? atoi(getenv("MFM_DWB_MF")) : 0;
+  bool wide = !L.f32 && mf_env != 3 && (mf_env == 4 || L.rows >= 65536);
+  for (int i = 0; i < L.n_items && wide; ++i) {
+    int N = 0;
+    for (int s = 0; s < L.it[i].nseg; ++s) N += L.it[i].seg[s].ncols;
+    wide = N <= 16 * 4 * 8 && (DWB_KC * (128 + N) / 8 + DWB_THREADS - 1) / DWB_THREADS <= DWB_MAXNI;
+  }
+  const int MT = wide ? 128 : DWB_MT;
+  for (int i = 0; i < L.n_items; ++i) {
+    DwbItem& I = L.it[i];
+    I.m_tiles = (I.M + MT - 1) / MT;
     int N = 0;
     for (int s = 0; s < I.nseg; ++s) N += I.seg[s].ncols;
     wsum += (double)I.m_tiles * (1.0 + N / 128.0);
@@ -412,7 +439,7 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
     I.splits = (L.rows + I.rows_per_split - 1) / I.rows_per_split;
     I.tile_begin = tiles;
     tiles += I.m_tiles * I.splits;
-    const int P = DWB_KC * (DWB_MT + N) / 8;
+    const int P = DWB_KC * (MT + N) / 8;
     const int NI = (P + DWB_THREADS - 1) / DWB_THREADS;
     // stages: as many as fit ~144 KB, the counted wait and the cap (MFM_DWB_STAGES forces a count, clamped)
     int S = (int)((144 * 1024) / ((size_t)NI * DWB_THREADS * 16));
@@ -424,16 +451,18 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
   }
   static bool attr = false;
   if (!attr) {
-    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_stream_kernel<false, 3, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_stream_kernel<false, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_stream_kernel<true, 3, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
   MFM_REQUIRE(smem <= 160 * 1024, "dw one-pass: %zu bytes of LDS", smem);
   // STATUS of the fp32 form: parity-green (tests/test_gpu_large_batch.py), but at B = 2048 it runs 666 us (+ 94 us of tail
   // GEMM) against 626 us for the grouped GEMM: its main loop keeps the fp32 matrix pipe ~43 % busy (one ds_read_b32 and its
   // wait per three MFMAs; batching a k-step's reads ahead of its MFMAs made it 779 us) -> opt-in, MFM_DW_F32_MINROWS
-  if (L.f32) hipLaunchKernelGGL(dw_stream_kernel<true>, dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
-  else hipLaunchKernelGGL(dw_stream_kernel<false>, dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
+  if (L.f32) hipLaunchKernelGGL((dw_stream_kernel<true, 3, 9>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
+  else if (wide) hipLaunchKernelGGL((dw_stream_kernel<false, 4, 8>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
+  else hipLaunchKernelGGL((dw_stream_kernel<false, 3, 9>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
   MFM_LAUNCH_CHECK("dw_stream_kernel");
   return MFM_OK;
 }

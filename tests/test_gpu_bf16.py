@@ -376,12 +376,15 @@ def test_bf16_resident_flags_refused_by_fp32_entry_point(eng):
 
 @pytest.mark.parametrize("h,dx,rows,shift", [(120, 325, 640, 32), (32, 300, 640, 32), (8, 5, 100, 5), (80, 20, 4580, 229),
                                              (104, 0, 640, 32), (24, 0, 37, 37), (120, 325, 20480, 1024), (36, 37, 171, 19)])
-def test_bf16_resident_weight_gradients_one_pass(eng, h, dx, rows, shift):
-    """dw_bf16_kernel: dW_ih, dW_hh (+ the decoders' second target), db from bf16-resident dA / x / h in ONE pass: LDS-DMA
+@pytest.mark.parametrize("mf", [3, 4])
+def test_bf16_resident_weight_gradients_one_pass(eng, h, dx, rows, shift, mf, monkeypatch):
+    """(mf: 96- / 128-column M-tiles, dw_stream_kernel<false, 3, 9> / <false, 4, 8>)
+    dw_bf16_kernel: dW_ih, dW_hh (+ the decoders' second target), db from bf16-resident dA / x / h in ONE pass: LDS-DMA
     slabs in memory order, transposing LDS reads, ragged row ranges and the t = 0 rows of h_{t-1} as zero-filled DMA lanes.
     Products of bf16 values are exact, so the fp64 reference over the stored values must match to fp32 summation error."""
     import ctypes as C
     from factorized_amd import _lib
+    monkeypatch.setenv("MFM_DWB_MF", str(mf))
     rs = np.random.RandomState(h + dx + rows)
     Hp = (h + 15) // 16 * 16
     dA = np.zeros((rows, 4, Hp), dtype=np.float32)
@@ -493,7 +496,7 @@ def _bf16_engine(cfgs):
     return e, w
 
 
-@pytest.fixture(params=["all-bf16", "default", "all-bf16+panel", "all-bf16+panel160", "all-bf16+panel96", "all-bf16+proj128", "all-bf16+proj64", "all-bf16+fc1r16", "all-bf16+tnsplit"])
+@pytest.fixture(params=["all-bf16", "default", "all-bf16+panel", "all-bf16+panel160", "all-bf16+panel96", "all-bf16+proj128", "all-bf16+proj64", "all-bf16+fc1r16", "all-bf16+tnsplit", "all-bf16+dwmf4"])
 def seq_policy(request, monkeypatch):
     """a bf16 plan runs its recurrences on the bf16 MFMA kernels from B = 192 on and on the fp32 VALU kernels below
     (lstm_seq.hip::bf16_seq_pays); 'all-bf16' forces the bf16 kernels at every batch size."""
@@ -505,6 +508,12 @@ def seq_policy(request, monkeypatch):
         monkeypatch.delenv("MFM_BF16_STORE", raising=False)
     # bf16-resident plans project on proj_bf16_kernel (proj_bf16.hip; it also writes the bf16 image of x the one-pass weight
     # gradients stream); "projNN" forces its panel height, "panel*" switches it off: gemm_panel_kernel<true> + x_to_bf16_kernel
+    # one-pass weight gradients: 96-column M-tiles; from T*B = 65536 rows 128-column ones (dw_stream_kernel<false, 4, 8>) when
+    # every item has <= 512 right-hand columns: "dwmf4" forces those
+    if "dwmf4" in request.param:
+        monkeypatch.setenv("MFM_DWB_MF", "4")
+    else:
+        monkeypatch.delenv("MFM_DWB_MF", raising=False)
     # "tnsplit": the B-row products of fp32 operands (the latent stack's weight gradients) on gemm_tn_kernel, the rest of
     # the last launch on the grouped bf16 GEMM (default from B = 1024)
     if "tnsplit" in request.param:
