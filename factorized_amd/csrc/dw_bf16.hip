@@ -422,23 +422,38 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
     for (int s = 0; s < I.nseg; ++s) N += I.seg[s].ncols;
     wsum += (double)I.m_tiles * (1.0 + N / 128.0);
   }
-  // one workgroup per CU (the chunk stages fill the LDS): row ranges sized so that the launch is ~2 rounds of
-  // workgroups, a range's cost taken as (fixed part + N / 128) per chunk (profiles/r02_dw_onepass.txt)
-  double target = 2.0 * device_cus();       // measured at B = 2048: 3 -> 198 us, 2 -> 169 us, 1 -> 233 us (the partial tiles' atomics against load balance)
-  if (const char* e = getenv("MFM_DWB_TARGET")) target = atof(e) * device_cus();
+  // one workgroup per CU (the chunk stages fill the LDS), so the launch runs in whole ROUNDS of workgroups: row ranges sized
+  // so that it fills `rounds` rounds and not one workgroup more -- a range's cost taken as (fixed part + N / 128) per chunk
+  // (profiles/r02_dw_onepass.txt).  One round up to 32768 rows, two above: every workgroup ends with its partial tile's
+  // atomics, so few long ranges win while the rows are few (measured, MOSI sizes, T*B = 5120 / 10240 / 20480 / 40960 rows,
+  // us at 0.5 / 0.75 / 1 / 2 x CUs workgroups: 56 / 59 / 89 / 99, 94 / 73 / 106 / 107, 175 / 122 / 145 / 125, 335 / 229 / 267 / 173:
+  // "1 x CUs" came out at a few workgroups more than CUs and ran two rounds).  MFM_DWB_TARGET = workgroups / CUs (no fitting).
+  const int cus = device_cus();
+  const int rounds = L.rows <= 32768 ? 1 : 2;
+  const char* tenv = getenv("MFM_DWB_TARGET");
   int tiles = 0;
   size_t smem = 0;
+  for (double fill = 0.98; ; fill -= 0.04) {
+    const double target = tenv ? atof(tenv) * cus : fill * rounds * cus;
+    tiles = 0;
+    for (int i = 0; i < L.n_items; ++i) {
+      DwbItem& I = L.it[i];
+      int N = 0;
+      for (int s = 0; s < I.nseg; ++s) N += I.seg[s].ncols;
+      int splits = (int)(target * (1.0 + N / 128.0) / wsum + 0.5);
+      const int max_splits = std::max(1, L.rows / (4 * DWB_KC));
+      splits = std::max(1, std::min(splits, max_splits));
+      I.rows_per_split = ((L.rows + splits - 1) / splits + DWB_KC - 1) / DWB_KC * DWB_KC;
+      I.splits = (L.rows + I.rows_per_split - 1) / I.rows_per_split;
+      I.tile_begin = tiles;
+      tiles += I.m_tiles * I.splits;
+    }
+    if (tenv || tiles <= rounds * cus || fill < 0.3) break;
+  }
   for (int i = 0; i < L.n_items; ++i) {
     DwbItem& I = L.it[i];
     int N = 0;
     for (int s = 0; s < I.nseg; ++s) N += I.seg[s].ncols;
-    int splits = (int)(target * (1.0 + N / 128.0) / wsum + 0.5);
-    const int max_splits = std::max(1, L.rows / (4 * DWB_KC));
-    splits = std::max(1, std::min(splits, max_splits));
-    I.rows_per_split = ((L.rows + splits - 1) / splits + DWB_KC - 1) / DWB_KC * DWB_KC;
-    I.splits = (L.rows + I.rows_per_split - 1) / I.rows_per_split;
-    I.tile_begin = tiles;
-    tiles += I.m_tiles * I.splits;
     const int P = DWB_KC * (MT + N) / 8;
     const int NI = (P + DWB_THREADS - 1) / DWB_THREADS;
     // stages: as many as fit ~144 KB, the counted wait and the cap (MFM_DWB_STAGES forces a count, clamped)

@@ -502,7 +502,7 @@ def seq_policy(request, monkeypatch):
     (lstm_seq.hip::bf16_seq_pays); 'all-bf16' forces the bf16 kernels at every batch size."""
     if request.param.startswith("all-bf16"):
         monkeypatch.setenv("MFM_BF16_SEQ_MINB", "1")
-        monkeypatch.setenv("MFM_BF16_STORE", "1")       # and the bf16-RESIDENT saved activations (default from T*B = 5120)
+        monkeypatch.setenv("MFM_BF16_STORE", "1")       # and the bf16-RESIDENT saved activations (default from T*B = 3840)
     else:
         monkeypatch.delenv("MFM_BF16_SEQ_MINB", raising=False)
         monkeypatch.delenv("MFM_BF16_STORE", raising=False)
@@ -627,7 +627,7 @@ def test_bf16_loss_curve_tracks_fp32_reference(name, seq_policy):
 
 
 def test_bf16_resident_plan_selection_and_stored_dtypes(monkeypatch):
-    """which bf16 plans keep their saved activations as bf16 (default: from T*B = 5120 rows), and that the buffers really
+    """which bf16 plans keep their saved activations as bf16 (default: from T*B = 3840 rows), and that the buffers really
     hold bf16: hs[T-1] is the bf16 rounding of the fp32 h_{T-1} copy the latent stack reads, the gates are activations"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -636,7 +636,7 @@ def test_bf16_resident_plan_selection_and_stored_dtypes(monkeypatch):
     monkeypatch.delenv("MFM_BF16_SEQ_MINB", raising=False)
     cfgs = configs.canonical_configs(dropout=False)
     cfg = cfgs[0]
-    for prec, B, T, want in (("bf16", 32, 20, False), ("bf16", 192, 20, False), ("bf16", 256, 20, True), ("bf16", 1024, 20, True), ("fp32", 1024, 20, False)):
+    for prec, B, T, want in (("bf16", 32, 20, False), ("bf16", 128, 20, False), ("bf16", 192, 20, True), ("bf16", 1024, 20, True), ("fp32", 1024, 20, False)):
         e = engine.MFMEngine(cfgs, precision=prec)
         e.load_weights(synth.make_weights(e.layout.shapes, seed=1234))
         xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7)

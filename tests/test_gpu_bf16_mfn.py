@@ -47,7 +47,7 @@ def seq_policy(request, monkeypatch):
     (lstm_seq.hip::bf16_seq_pays); 'default': the plan's own selection"""
     if request.param == "all-bf16":
         monkeypatch.setenv("MFM_BF16_SEQ_MINB", "1")
-        monkeypatch.setenv("MFM_BF16_STORE", "1")       # and the bf16-RESIDENT saved activations (default from T*B = 5120)
+        monkeypatch.setenv("MFM_BF16_STORE", "1")       # and the bf16-RESIDENT saved activations (default from T*B = 3840)
     else:
         monkeypatch.delenv("MFM_BF16_SEQ_MINB", raising=False)
         monkeypatch.delenv("MFM_BF16_STORE", raising=False)
