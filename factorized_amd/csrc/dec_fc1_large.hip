@@ -29,6 +29,7 @@
 #include <algorithm>
 
 #include "internal.h"
+#include "pack_dev.h"
 
 namespace mfm {
 
@@ -44,7 +45,7 @@ constexpr int FL_WAVES = 8;
 constexpr int FL_ROWS = 16;
 constexpr int FL_MAXKB = 4;          // hidden size <= 128: k-blocks of 32 in product 1, output fragments <= 8 in product 2
 constexpr int FL_MAXF = 3;           // output fragments per wave in product 1: d <= 16 * 8 * 3 = 384
-constexpr int FL_LDW = 128 + 8;      // bf16 elements per row of the W image / the H tile (pad: 16 bytes)
+constexpr int FL_LDW = FC1_LDW;      // bf16 elements per row of the W image / the H tile (128 + 8: pad of 16 bytes; pack_dev.h)
 
 __device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 
@@ -468,21 +469,9 @@ __global__ __launch_bounds__(FL_THREADS) void dec_fc1_large64_kernel(const DecFc
   }
 }
 
-// the bf16 image of Wfc the workgroups keep in LDS: [NB2 * 32][FL_LDW], rows n >= d and columns k >= h zero
-struct Fc1PackArgs { const float* w[3]; __bf16* out[3]; int d[3], h[3], rows[3], begin[4]; int n; };
+// the bf16 image of Wfc the workgroups keep in LDS: [NB2 * 32][FL_LDW], rows n >= d and columns k >= h zero (pack_dev.h)
 __global__ __launch_bounds__(256) void fc1_pack_kernel(const Fc1PackArgs A) {
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  if (gid >= A.begin[A.n]) return;
-  int m = 0;
-#pragma unroll
-  for (int i = 1; i < 3; ++i)
-    if (i < A.n && gid >= A.begin[i]) m = i;
-  const int idx = gid - A.begin[m];
-  const int n = idx / (FL_LDW / 8), k8 = (idx - n * (FL_LDW / 8)) * 8;
-  bf16x8 v;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = (__bf16)((n < A.d[m] && k8 + e < A.h[m]) ? A.w[m][(int64_t)n * A.h[m] + k8 + e] : 0.0f);
-  *reinterpret_cast<bf16x8*>(A.out[m] + (size_t)n * FL_LDW + k8) = v;
+  fc1_pack_body(A, (int64_t)blockIdx.x * 256 + threadIdx.x);
 }
 
 }  // namespace
@@ -504,6 +493,34 @@ static size_t fl_lds_bytes(const DecFc1LargeItem& I, int rows_per_tile) {
   const int NF1 = (I.d + 15) / 16, NB2 = (NF1 * 16 + 31) / 32;
   if (rows_per_tile == FL_R64) return ((size_t)NB2 * 32 * FL_LDW + (size_t)FL_R64 * FL_LDW + (size_t)FL_R64 * (NB2 * 32 + 8)) * 2;
   return ((size_t)NB2 * 32 * FL_LDW + (size_t)FL_ROWS * FL_LDW + (size_t)FL_ROWS * (NB2 * 32 + 8)) * 2 + (size_t)4 * FL_ROWS * FL_LDW * 4;
+}
+
+// the pack arguments of a launch's items (those that carry a wimg scratch)
+int fc1_pack_prepare(const DecFc1LargeLaunch& L, Fc1PackArgs* out) {
+  Fc1PackArgs& A = *out;
+  memset(&A, 0, sizeof(A));
+  int at = 0;
+  for (int i = 0; i < L.n_items; ++i) {
+    const DecFc1LargeItem& I = L.it[i];
+    if (!I.wimg) continue;
+    MFM_REQUIRE((((uintptr_t)I.wimg) & 15) == 0, "dec fc1 (large): item %d: weight image scratch not 16-byte aligned", i);
+    const int rows = (int)(dec_fc1_large_wimg_bytes(I.d) / (FL_LDW * 2));
+    A.w[A.n] = I.w; A.out[A.n] = reinterpret_cast<__bf16*>(I.wimg); A.d[A.n] = I.d; A.h[A.n] = I.h; A.rows[A.n] = rows;
+    A.begin[A.n] = at; at += rows * (FL_LDW / 8);
+    ++A.n;
+  }
+  for (int i = A.n; i < 4; ++i) A.begin[i] = at;
+  return MFM_OK;
+}
+
+// true when dec_fc1_large_launch would take the 64-row kernel (the only one that reads the packed images)
+bool dec_fc1_large_uses_wimg(const DecFc1LargeLaunch& L) {
+  if (getenv("MFM_FC1_LARGE_ROWS") && atoi(getenv("MFM_FC1_LARGE_ROWS")) == 16) return false;
+  for (int i = 0; i < L.n_items; ++i)
+    if (fl_lds_bytes(L.it[i], FL_R64) > 156 * 1024 || (L.it[i].ld_dxhat & 3) || (L.it[i].Hp >> 3) > 16 ||
+        (int64_t)L.rows * L.it[i].ldx >= ((int64_t)1 << 29))
+      return false;
+  return true;
 }
 
 int dec_fc1_large_launch(DecFc1LargeLaunch& L, hipStream_t stream) {
@@ -546,22 +563,14 @@ int dec_fc1_large_launch(DecFc1LargeLaunch& L, hipStream_t stream) {
     attr = true;
   }
   if (RT == FL_R64) {
-    Fc1PackArgs A;
-    memset(&A, 0, sizeof(A));
-    int at = 0;
-    for (int i = 0; i < L.n_items; ++i) {
-      const DecFc1LargeItem& I = L.it[i];
-      if (!I.wimg) continue;
-      MFM_REQUIRE((((uintptr_t)I.wimg) & 15) == 0, "dec fc1 (large): item %d: weight image scratch not 16-byte aligned", i);
-      const int rows = (int)(dec_fc1_large_wimg_bytes(I.d) / (FL_LDW * 2));
-      A.w[A.n] = I.w; A.out[A.n] = reinterpret_cast<__bf16*>(I.wimg); A.d[A.n] = I.d; A.h[A.n] = I.h; A.rows[A.n] = rows;
-      A.begin[A.n] = at; at += rows * (FL_LDW / 8);
-      ++A.n;
-    }
-    for (int i = A.n; i < 4; ++i) A.begin[i] = at;
-    if (A.n > 0) {
-      hipLaunchKernelGGL(fc1_pack_kernel, dim3((at + 255) / 256), dim3(256), 0, stream, A);
-      MFM_LAUNCH_CHECK("fc1_pack_kernel");
+    if (!L.packed) {          // (the plan packs the images with the step's other weight images: pack_all_launch)
+      Fc1PackArgs A;
+      const int rc = fc1_pack_prepare(L, &A);
+      if (rc != MFM_OK) return rc;
+      if (A.n > 0) {
+        hipLaunchKernelGGL(fc1_pack_kernel, dim3((A.begin[A.n] + 255) / 256), dim3(256), 0, stream, A);
+        MFM_LAUNCH_CHECK("fc1_pack_kernel");
+      }
     }
   } else {
     for (int i = 0; i < L.n_items; ++i) L.it[i].wimg = nullptr;

@@ -95,7 +95,8 @@ struct DecFc1LargeItem {
   int wg_begin, wg_count;                                                // filled by dec_fc1_large_launch
   void* wimg;     // optional scratch, dec_fc1_large_wimg_bytes(): the bf16 image of Wfc, packed once per launch instead of once per workgroup
 };
-struct DecFc1LargeLaunch { DecFc1LargeItem it[3]; int n_items, rows, dbg; };   // dbg: tuning aid (MFM_FC1_LARGE_DBG)
+struct DecFc1LargeLaunch { DecFc1LargeItem it[3]; int n_items, rows, dbg, packed; };   // dbg: tuning aid (MFM_FC1_LARGE_DBG); packed: the weight images are already built
+bool dec_fc1_large_uses_wimg(const DecFc1LargeLaunch& L);
 int dec_fc1_large_supported(const DecFc1LargeItem& I);
 size_t dec_fc1_large_wimg_bytes(int d);
 int dec_fc1_large_launch(DecFc1LargeLaunch& L, hipStream_t stream);

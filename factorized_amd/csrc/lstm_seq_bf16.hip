@@ -25,6 +25,7 @@
 
 #include "internal.h"
 #include "lstm_seq_dev.h"
+#include "pack_dev.h"
 
 namespace mfm {
 
@@ -447,57 +448,30 @@ __global__ __launch_bounds__(512) void lstm_seq_bf16_kernel(const SeqLaunch L) {
 // wave w is one 16-byte element at [(w * nfrag + f) * 64 + lane] -- and the recurrences start with 16-32 coalesced
 // loads.  Pack order per LSTM: encoder [fwd W_hh | bwd W_hh]; decoder [fwd W_ih+W_hh | fwd W_ih | bwd W_ih+W_hh |
 // bwd W_ih].  Every pack has (Hp/16) * 4 * KB * 64 fragments.
-struct PackItem { const float* w_hh; const float* w_ih; bf16x8* out; int h, Hp, KB, is_dec, frag_begin; };
-struct PackLaunch { PackItem it[MFM_MAX_SEQ * 2]; int count; };
-
+// (the structs and the device body live in pack_dev.h: the step's three weight images are packed by ONE launch)
 __global__ __launch_bounds__(256) void lstm_pack_bf16_kernel(const PackLaunch L) {
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int ii = 0;
-#pragma unroll 1
-  for (int i = 1; i < L.count; ++i)
-    if (gid >= L.it[i].frag_begin) ii = i;
-  const PackItem& it = L.it[ii];
-  const int h = it.h, KB = it.KB, HKP = KB * 32;
-  const int per_pack = (it.Hp >> 4) * 4 * KB * 64;
-  const int npack = it.is_dec ? 4 : 2;
-  int f = (int)(gid - it.frag_begin);
-  if (f >= per_pack * npack) return;
-  const int which = f / per_pack;
-  f -= which * per_pack;
-  const int lane = f & 63;
-  int r = f >> 6;
-  const int bi = lane & 15, q = lane >> 4;
-  const bool bwd = it.is_dec ? (which >= 2) : (which == 1);
-  // MODE: 0 W_hh, 1 W_ih, 2 W_ih + W_hh
-  const int mode = it.is_dec ? ((which & 1) ? 1 : 2) : 0;
-  float v[8];
-  if (!bwd) {
-    const int kb = r % KB; r /= KB;
-    const int g = r & 3, wave = r >> 2;
-    const int unit = wave * 16 + bi;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = kb * 32 + 8 * q + j;
-      const bool ok = unit < h && k < h;
-      const int off = ok ? (g * h + unit) * h + k : 0;
-      const float x = mode == 0 ? it.w_hh[off] : (mode == 1 ? it.w_ih[off] : it.w_ih[off] + it.w_hh[off]);
-      v[j] = ok ? x : 0.0f;
-    }
-  } else {
-    const int nkb = 4 * KB;
-    const int kb = r % nkb, wave = r / nkb;
-    const int unit = wave * 16 + bi;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = kb * 32 + 8 * q + j;
-      const int g = k / HKP, up = k % HKP;
-      const bool ok = unit < h && up < h;
-      const int off = ok ? (g * h + up) * h + unit : 0;
-      const float x = mode == 0 ? it.w_hh[off] : (mode == 1 ? it.w_ih[off] : it.w_ih[off] + it.w_hh[off]);
-      v[j] = ok ? x : 0.0f;
-    }
+  lstm_pack_body(L, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+// fills `out` for up to MFM_MAX_SEQ * 2 LSTMs (out->total = fragments, 0: nothing to pack)
+int lstm_pack_prepare(const MfmSeqDesc* descs, int count, PackLaunch* out) {
+  memset(out, 0, sizeof(*out));
+  MFM_REQUIRE(descs && count >= 0 && count <= MFM_MAX_SEQ * 2, "lstm pack: %d descriptors", count);
+  int64_t total = 0;
+  for (int i = 0; i < count; ++i) {
+    const MfmSeqDesc& s = descs[i];
+    if (s.h > MFM_SEQ_MAX_RESIDENT_H) continue;      // step-by-step fp32 path: nothing to pack
+    MFM_REQUIRE(s.h >= 1 && s.w_hh && s.w_pack, "mfm_lstm_pack_bf16: h=%d, w_hh / w_pack must be set", s.h);
+    if (s.is_dec) MFM_REQUIRE(s.w_ih, "mfm_lstm_pack_bf16: decoder needs w_ih");
+    PackItem& it = out->it[out->count++];
+    it.w_hh = s.w_hh; it.w_ih = s.w_ih; it.out = reinterpret_cast<pk_bf16x8*>(s.w_pack);
+    it.h = s.h; it.Hp = round_up(s.h, 16); it.KB = cdiv(s.h, 32); it.is_dec = s.is_dec;
+    MFM_REQUIRE(total < (int64_t)1 << 30, "mfm_lstm_pack_bf16: too many fragments");
+    it.frag_begin = (int)total;
+    total += (int64_t)(s.is_dec ? 4 : 2) * (it.Hp >> 4) * 4 * it.KB * 64;
   }
-  it.out[(int64_t)which * per_pack + (f & ~63) + lane] = pack8(v);
+  out->total = total;
+  return MFM_OK;
 }
 
 }  // namespace mfm
@@ -511,25 +485,12 @@ extern "C" int64_t mfm_lstm_pack_bytes(int32_t h, int32_t is_dec) {
 extern "C" int mfm_lstm_pack_bf16(const MfmSeqDesc* descs, int count, void* stream) {
   using namespace mfm;
   MFM_REQUIRE(descs && count >= 1, "mfm_lstm_pack_bf16: no descriptors");
-  int done = 0;
-  while (done < count) {
+  for (int done = 0; done < count; done += MFM_MAX_SEQ * 2) {
     PackLaunch L;
-    memset(&L, 0, sizeof(L));
-    int64_t total = 0;
-    while (done < count && L.count < MFM_MAX_SEQ * 2) {
-      const MfmSeqDesc& s = descs[done++];
-      if (s.h > MFM_SEQ_MAX_RESIDENT_H) continue;      // step-by-step fp32 path: nothing to pack
-      MFM_REQUIRE(s.h >= 1 && s.w_hh && s.w_pack, "mfm_lstm_pack_bf16: h=%d, w_hh / w_pack must be set", s.h);
-      if (s.is_dec) MFM_REQUIRE(s.w_ih, "mfm_lstm_pack_bf16: decoder needs w_ih");
-      PackItem& it = L.it[L.count++];
-      it.w_hh = s.w_hh; it.w_ih = s.w_ih; it.out = reinterpret_cast<bf16x8*>(s.w_pack);
-      it.h = s.h; it.Hp = round_up(s.h, 16); it.KB = cdiv(s.h, 32); it.is_dec = s.is_dec;
-      MFM_REQUIRE(total < (int64_t)1 << 30, "mfm_lstm_pack_bf16: too many fragments");
-      it.frag_begin = (int)total;
-      total += (int64_t)(s.is_dec ? 4 : 2) * (it.Hp >> 4) * 4 * it.KB * 64;
-    }
+    const int rc = lstm_pack_prepare(descs + done, std::min(count - done, MFM_MAX_SEQ * 2), &L);
+    if (rc != MFM_OK) return rc;
     if (L.count == 0) continue;
-    hipLaunchKernelGGL(lstm_pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, L);
+    hipLaunchKernelGGL(lstm_pack_bf16_kernel, dim3((unsigned)((L.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, L);
     MFM_LAUNCH_CHECK("lstm_pack_bf16_kernel");
   }
   return MFM_OK;

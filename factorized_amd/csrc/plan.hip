@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "internal.h"
+#include "pack_dev.h"
 #include "lstm_seq_dev.h"
 
 namespace mfm {
@@ -134,6 +135,7 @@ struct MfmPlan {
   mfm::ProjPlan pj;                 // its tile image layout, panel height and pipeline depth
   int64_t pj_wimg, pj_bimg;         // scratch: packed bf16 weight tiles, combined biases
   unsigned long long x16_call = ~0ull;   // value of `calls` for which the forward already produced x16
+  unsigned long long pj_pack_call = ~0ull, fc1_pack_call = ~0ull;   // ... for which the step's pack launch built these images
   unsigned long long fc1_bwd_call = ~0ull;   // value of `calls` for which the forward already produced dH of the decoders (dec_fc1.hip)
 };
 
@@ -807,7 +809,47 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     int n = 0;
     for (int e = 0; e < P->n_enc; ++e) q[n++] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
     for (int m = 0; m < 3; ++m) q[n++] = seq_desc(P, P->dec[m], P->dec_p[m], params, W, true);
-    RUN(K_PACK, mfm_lstm_pack_bf16(q, n, s));
+    // ONE launch for every weight image of the step (pack_dev.h): the recurrences' fragments, and on bf16-resident plans the
+    // projection tiles + biases and the decoders' fc1 images
+    PackLaunch PKL;
+    { const int rc0 = lstm_pack_prepare(q, n, &PKL); if (rc0 != MFM_OK) return rc0; }
+    PjPackDev PJD;
+    Fc1PackArgs FCA;
+    const PjPackDev* pjp = nullptr;
+    const Fc1PackArgs* fcp = nullptr;
+    if (st16 && P->proj16) {
+      PanelLaunch PL;
+      memset(&PL, 0, sizeof(PL));
+      PL.ngroups = P->n_enc;
+      for (int e = 0; e < P->n_enc; ++e) {
+        const SeqBuf& sb = P->enc[e];
+        const int pb = P->enc_p[e];
+        PanelGroup& G = PL.g[e];
+        G.w = params + P->off[pb + W_IH]; G.ldw = P->enc_d[e];
+        G.bias = params + P->off[pb + B_IH]; G.bias2 = params + P->off[pb + B_HH];
+        G.n = 4 * sb.Hp; G.seg = sb.Hp; G.seg_valid = sb.h; G.k_off = P->enc_xoff[e]; G.k_len = P->enc_d[e];
+      }
+      const int rc0 = proj_pack_prepare(PL, P->pj, W + P->pj_wimg, W + P->pj_bimg, &PJD);
+      if (rc0 != MFM_OK) return rc0;
+      pjp = &PJD; P->pj_pack_call = P->calls;
+    }
+    if (st16 && train && !(xhat_out && (xhat_out[0] || xhat_out[1] || xhat_out[2])) &&
+        !(getenv("MFM_FC1_LARGE") && atoi(getenv("MFM_FC1_LARGE")) == 0)) {
+      DecFc1LargeLaunch FLp;
+      memset(&FLp, 0, sizeof(FLp));
+      FLp.n_items = 3; FLp.rows = (int)TB;
+      for (int m = 0; m < 3; ++m) {
+        DecFc1LargeItem& I = FLp.it[m];
+        I.w = params + P->off[P->dec_p[m] + FC_W]; I.d = P->dec_d[m]; I.h = P->dec[m].h; I.Hp = P->dec[m].Hp;
+        I.ld_dxhat = P->dxh_ld[m]; I.ldx = P->D; I.wimg = W + P->fc1_wimg[m];
+      }
+      if (dec_fc1_large_uses_wimg(FLp)) {
+        const int rc0 = fc1_pack_prepare(FLp, &FCA);
+        if (rc0 != MFM_OK) return rc0;
+        fcp = &FCA; P->fc1_pack_call = P->calls;
+      }
+    }
+    RUN(K_PACK, pack_all_launch(&PKL, pjp, fcp, s));
   }
 
   // F0: input projections
@@ -848,7 +890,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       }
       if (st16 && P->proj16) {
         const int src0[3] = {0, c.d_l, c.d_l + c.d_a}, nn[3] = {c.d_l, c.d_a, c.d_v};
-        RUN(K_PACK, proj_bf16_pack_launch(PL, P->pj, W + P->pj_wimg, W + P->pj_bimg, s));
+        if (P->pj_pack_call != P->calls) RUN(K_PACK, proj_bf16_pack_launch(PL, P->pj, W + P->pj_wimg, W + P->pj_bimg, s));
         RUN(K_PROJ, proj_bf16_launch(PL, P->pj, W + P->pj_wimg, W + P->pj_bimg, W + P->x16, P->x16_ld, src0, nn, P->x16_off, &zs, s));
         P->x16_call = P->calls;
       } else if (gemm_panel_pays(PL, c.precision, panel_forced)) RUN(K_PROJ, gemm_panel_launch(PL, &zs, c.precision, panel_forced, s));
@@ -976,6 +1018,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
         I.inv_count = me[m].inv_count; I.grad_scale = me[m].grad_scale;
         I.wimg = W + P->fc1_wimg[m];
         ok = ok && dec_fc1_large_supported(I);
+        FL.packed = (P->fc1_pack_call == P->calls) ? 1 : 0;
       }
       if (ok) {
         { Timer _t(P, s, K_FC1_FWD); rc = dec_fc1_large_launch(FL, s); }

@@ -27,6 +27,7 @@
 #include <algorithm>
 
 #include "internal.h"
+#include "pack_dev.h"
 
 namespace mfm {
 
@@ -37,8 +38,6 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int PJ_THREADS = 512;
-constexpr int PJ_BN = 128, PJ_BK = 32;
-constexpr int PJ_TILE = PJ_BN * PJ_BK;            // elements of a weight tile (8 KB)
 constexpr int PJ_MAXG = MFM_PANEL_MAXG;
 
 struct PjGroupDev { __bf16* c; int64_t ldc; int n, kt0, kt1, bias_off; };
@@ -49,58 +48,18 @@ struct PjDev {
   PjGroupDev g[PJ_MAXG]; int ngroups, ntiles, nbias, S, dbg;
   float* zero_ptr[MFM_GEMM_ZSPANS]; int64_t zero_n[MFM_GEMM_ZSPANS];
 };
-struct PjPackGroup { const float* w; const float* bias; const float* bias2; int64_t ldw; int n, seg, seg_valid, k_off, k_len, kt0, nkt, tile0, nchunks, bias_off; };
-struct PjPackDev { PjPackGroup g[PJ_MAXG]; int ngroups, ntiles, nbias; __bf16* wimg; float* bimg; };
-
-// position (in 16-byte chunks) of chunk c of tile row nn: 16 consecutive rows at one c cover the 16 slots of a 256-byte
-// bank row exactly once (rows nn and nn+4 share slot group 4 (nn & 3) and are told apart by c ^ ((nn >> 2) & 3))
-__host__ __device__ inline int tile_slot(int nn, int c) { return nn * 4 + (c ^ ((nn >> 2) & 3)); }
-
 __global__ __launch_bounds__(256) void proj_pack_kernel(const PjPackDev L) {
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t nchunk = (int64_t)L.ntiles * (PJ_TILE / 8);
-  if (gid < nchunk) {
-    const int t = (int)(gid / (PJ_TILE / 8));
-    const int within = (int)(gid - (int64_t)t * (PJ_TILE / 8));
-    const int nn = within >> 2, c = within & 3;
-    int gi = 0;
-#pragma unroll 1
-    for (int i = 1; i < L.ngroups; ++i)
-      if (t >= L.g[i].tile0) gi = i;
-    const PjPackGroup& G = L.g[gi];
-    const int lt = t - G.tile0;
-    const int chunk = lt / G.nkt, kt = G.kt0 + (lt - chunk * G.nkt);
-    // tile row 16 fn + i of a wave's 32 rows carries the wave's column 8 (i / 4) + 4 fn + i % 4 (see the kernel's epilogue)
-    const int wr = nn & 31, fn = wr >> 4, i = wr & 15;
-    const int n = chunk * PJ_BN + (nn & ~31) + 8 * (i >> 2) + 4 * fn + (i & 3);
-    const int sg = n / G.seg, u = n - sg * G.seg;
-    const bool nok = n < G.n && u < G.seg_valid;
-    const int64_t wrow = nok ? (int64_t)(sg * G.seg_valid + u) * G.ldw : 0;
-    bf16x8 v;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ko = kt * PJ_BK + c * 8 + j - G.k_off;
-      const bool ok = nok && ko >= 0 && ko < G.k_len;
-      v[j] = (__bf16)(ok ? G.w[wrow + ko] : 0.0f);
-    }
-    *reinterpret_cast<bf16x8*>(L.wimg + (int64_t)t * PJ_TILE + tile_slot(nn, c) * 8) = v;
-    return;
-  }
-  const int64_t b = gid - nchunk;
-  if (b >= L.nbias) return;
-  int gi = 0;
-#pragma unroll 1
-  for (int i = 1; i < L.ngroups; ++i)
-    if (b >= L.g[i].bias_off) gi = i;
-  const PjPackGroup& G = L.g[gi];
-  const int n = (int)(b - G.bias_off);
-  const int sg = n / G.seg, u = n - sg * G.seg;
-  float s = 0.0f;
-  if (n < G.n && u < G.seg_valid) {
-    if (G.bias) s += G.bias[sg * G.seg_valid + u];
-    if (G.bias2) s += G.bias2[sg * G.seg_valid + u];
-  }
-  L.bimg[b] = s;
+  proj_pack_body(L, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+// every weight image of the step in one launch: blocks [0, b1) the recurrences' fragments, [b1, b2) the projection tiles
+// and biases, [b2, ..) the decoders' fc1 images (pack_dev.h)
+struct PackAllDev { PackLaunch lstm; PjPackDev proj; Fc1PackArgs fc1; int b1, b2; };
+__global__ __launch_bounds__(256) void pack_all_kernel(const PackAllDev A) {
+  const int b = (int)blockIdx.x;
+  if (b < A.b1) lstm_pack_body(A.lstm, (int64_t)b * 256 + threadIdx.x);
+  else if (b < A.b2) proj_pack_body(A.proj, (int64_t)(b - A.b1) * 256 + threadIdx.x);
+  else fc1_pack_body(A.fc1, (int64_t)(b - A.b2) * 256 + threadIdx.x);
 }
 
 // 8 compute waves = 2 (rows) x 4 (columns), a wave owns FM x 2 fragments of 16 x 16: BM = 32 FM rows, 128 columns per job;
@@ -230,7 +189,7 @@ __global__ __launch_bounds__(PJ_THREADS + 64) void proj_bf16_kernel(const PjDev 
 #pragma unroll
           for (int fn = 0; fn < FN; ++fn) {
             const int nn = wn * 32 + fn * 16 + bi;
-            wf[fn] = *reinterpret_cast<const bf16x8*>(B + tile_slot(nn, q) * 16);
+            wf[fn] = *reinterpret_cast<const bf16x8*>(B + pj_tile_slot(nn, q) * 16);
           }
 #pragma unroll
           for (int fm = 0; fm < FM; ++fm)
@@ -307,9 +266,9 @@ int proj_bf16_plan(const PanelLaunch& L, ProjPlan* out) {
   return out->BM != 0;
 }
 
-int proj_bf16_pack_launch(const PanelLaunch& L, const ProjPlan& P, void* wimg, float* bimg, hipStream_t stream) {
+int proj_pack_prepare(const PanelLaunch& L, const ProjPlan& P, void* wimg, float* bimg, PjPackDev* out) {
   MFM_REQUIRE(wimg && bimg && (((uintptr_t)wimg) & 15) == 0 && (((uintptr_t)bimg) & 15) == 0, "proj bf16 pack: bad scratch");
-  PjPackDev D;
+  PjPackDev& D = *out;
   memset(&D, 0, sizeof(D));
   for (int i = 0; i < L.ngroups; ++i) {
     const PanelGroup& G = L.g[i];
@@ -320,9 +279,32 @@ int proj_bf16_pack_launch(const PanelLaunch& L, const ProjPlan& P, void* wimg, f
   }
   D.ngroups = L.ngroups; D.ntiles = P.ntiles; D.nbias = P.nbias;
   D.wimg = reinterpret_cast<__bf16*>(wimg); D.bimg = bimg;
+  return MFM_OK;
+}
+
+int proj_bf16_pack_launch(const PanelLaunch& L, const ProjPlan& P, void* wimg, float* bimg, hipStream_t stream) {
+  PjPackDev D;
+  const int rc = proj_pack_prepare(L, P, wimg, bimg, &D);
+  if (rc != MFM_OK) return rc;
   const int64_t total = (int64_t)P.ntiles * (PJ_TILE / 8) + P.nbias;
   hipLaunchKernelGGL(proj_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, D);
   MFM_LAUNCH_CHECK("proj_pack_kernel");
+  return MFM_OK;
+}
+
+// any of the three parts may be null / empty
+int pack_all_launch(const PackLaunch* lstm, const PjPackDev* proj, const Fc1PackArgs* fc1, hipStream_t stream) {
+  PackAllDev A;
+  memset(&A, 0, sizeof(A));
+  int64_t n1 = 0, n2 = 0, n3 = 0;
+  if (lstm && lstm->count > 0) { A.lstm = *lstm; n1 = (lstm->total + 255) / 256; }
+  if (proj && proj->ntiles > 0) { A.proj = *proj; n2 = ((int64_t)proj->ntiles * (PJ_TILE / 8) + proj->nbias + 255) / 256; }
+  if (fc1 && fc1->n > 0) { A.fc1 = *fc1; n3 = (fc1->begin[fc1->n] + 255) / 256; }
+  if (n1 + n2 + n3 == 0) return MFM_OK;
+  MFM_REQUIRE(n1 + n2 + n3 < ((int64_t)1 << 30), "pack: too many blocks");
+  A.b1 = (int)n1; A.b2 = (int)(n1 + n2);
+  hipLaunchKernelGGL(pack_all_kernel, dim3((unsigned)(n1 + n2 + n3)), dim3(256), 0, stream, A);
+  MFM_LAUNCH_CHECK("pack_all_kernel");
   return MFM_OK;
 }
 
