@@ -188,8 +188,10 @@ int mmd_launch(const float* z, int64_t ldz, const float* g, int64_t ldg, int B, 
                float dz_scale, hipStream_t stream);
 // up to 4 terms that share B, the row strides and the loss slot in one launch
 struct MmdItem { const float* z; const float* g; float* dz; int dim; };
+// scratch (optional, mmd_scratch_floats(B, count) floats, 16-byte aligned): large batches run as Gram-matrix GEMMs (mmd.hip)
 int mmd_group_launch(const MmdItem* items, int count, int64_t ldz, int64_t ldg, int64_t lddz, int B, float* loss,
-                     float dz_scale, hipStream_t stream);
+                     float dz_scale, hipStream_t stream, float* scratch = nullptr);
+int64_t mmd_scratch_floats(int B, int count);
 
 // latent.hip -- the fused "latent stack": encoder fc1 heads, mu/logvar heads, z->f MLPs,
 // classifier, KLD and discriminative loss, interpreted from a small op table.

@@ -6,6 +6,10 @@
 // The reference materialises three [B, B, dim] tensors per term and four terms per step; here a
 // workgroup owns 32 (small batches: 8) rows i, walks j in tiles of 32 staged in LDS (rows padded to an odd stride), computes
 // the three kernel values of a pair once, and contracts them against the tile for the gradient.
+#include <string.h>
+
+#include <algorithm>
+
 #include "internal.h"
 
 namespace mfm {
@@ -121,11 +125,128 @@ __global__ __launch_bounds__(256) void mmd_kernel(const MmdGroup G, int B, float
   if (tid == 0 && loss) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * loss_scale);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GEMM form for LARGE batches (round 3).  The kernel above walks all B^2 pairs on the VALU with B / 32 workgroups per term:
+// 1.1 ms at B = 1024 (44 % of the MFM step).  With |a - b|^2 = |a|^2 + |b|^2 - 2 a.b the three distance matrices are Gram
+// matrices and the gradient is two more products -- all on the grouped fp32 MFMA GEMM:
+//   1. ZZ = Z Z^T, GZ = Z G^T, GG = G G^T                                   (12 problems, K = dim)
+//   2. mmd_k_kernel: K = exp(-(n_i + n_j - 2 gram) / dim^2) in place (the norms are the Gram diagonals), the loss, the row
+//      sums s_i = sum_j Kgz_ij - Kzz_ij, and dz_i <- coef s_i z_i
+//   3. dz += coef Kzz Z - coef Kgz G                                        (8 accumulating problems, K = B)
+// from d mmd / d z_i = 4 / (B^2 dim^2) sum_j [ Kgz_ij (z_i - g_j) - Kzz_ij (z_i - z_j) ].  Scratch: 3 B x ldb floats per term.
+struct MmdKTerm { const float* z; float* dz; float* zz; float* gz; const float* gg; int dim, pad_; };
+struct MmdKGroup { MmdKTerm t[4]; };
+
+__global__ __launch_bounds__(256) void mmd_k_kernel(const MmdKGroup G, int B, int64_t ldb, int64_t ldz, int64_t lddz,
+                                                    float* __restrict__ loss, float loss_scale, float coef_scale) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const MmdKTerm& M = G.t[blockIdx.y];
+  float* nz = lds;                 // [B] |z_j|^2
+  float* ng = lds + B;             // [B] |g_j|^2
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float inv_k2 = 1.0f / ((float)M.dim * (float)M.dim);
+  for (int j = tid; j < B; j += 256) { nz[j] = M.zz[(int64_t)j * ldb + j]; ng[j] = M.gg[(int64_t)j * ldb + j]; }
+  __syncthreads();
+  float part = 0.0f;
+  // one wave per row i: j runs over the lanes (coalesced rows of the three matrices)
+  for (int i = blockIdx.x * 4 + wave; i < B; i += gridDim.x * 4) {
+    float* zzr = M.zz + (int64_t)i * ldb;
+    float* gzr = M.gz + (int64_t)i * ldb;
+    const float* ggr = M.gg + (int64_t)i * ldb;
+    const float nzi = nz[i], ngi = ng[i];
+    float rs = 0.0f;
+    for (int j = lane; j < B; j += 64) {
+      const float kzz = __expf(-fmaxf(nzi + nz[j] - 2.0f * zzr[j], 0.0f) * inv_k2);
+      const float kgz = __expf(-fmaxf(nzi + ng[j] - 2.0f * gzr[j], 0.0f) * inv_k2);
+      const float kgg = __expf(-fmaxf(ngi + ng[j] - 2.0f * ggr[j], 0.0f) * inv_k2);
+      part += kzz + kgg - 2.0f * kgz;
+      rs += kgz - kzz;
+      zzr[j] = kzz; gzr[j] = kgz;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rs += __shfl_xor(rs, o, 64);
+    if (M.dz) {
+      const float c = 4.0f * loss_scale * inv_k2 * coef_scale * rs;
+      for (int k = lane; k < M.dim; k += 64) M.dz[(int64_t)i * lddz + k] = c * M.z[(int64_t)i * ldz + k];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  if (lane == 0) red[wave] = part;
+  __syncthreads();
+  if (tid == 0 && loss) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * loss_scale);
+}
+
 }  // namespace
 
+int64_t mmd_scratch_floats(int B, int count) { return (int64_t)count * 3 * B * round_up(B, 4); }
+
+static int mmd_gemm_form(const MmdItem* items, int count, int64_t ldz, int64_t ldg, int64_t lddz, int B, float* loss,
+                         float dz_scale, float* scratch, hipStream_t stream) {
+  const int64_t ldb = round_up(B, 4);
+  MFM_REQUIRE((((uintptr_t)scratch) & 15) == 0 && 2 * (size_t)B * sizeof(float) <= 64 * 1024, "mmd (gemm form): scratch alignment / B = %d", B);
+  MfmGemmDesc g[12];
+  memset(g, 0, sizeof(g));
+  MmdKGroup K;
+  memset(&K, 0, sizeof(K));
+  int n = 0;
+  for (int e = 0; e < count; ++e) {
+    float* zz = scratch + (int64_t)(3 * e) * B * ldb;
+    float* gz = zz + (int64_t)B * ldb;
+    float* gg = gz + (int64_t)B * ldb;
+    const float* A[3] = {items[e].z, items[e].z, items[e].g};
+    const int64_t lA[3] = {ldz, ldz, ldg};
+    const float* Bm[3] = {items[e].z, items[e].g, items[e].g};
+    const int64_t lB[3] = {ldz, ldg, ldg};
+    float* C[3] = {zz, gz, gg};
+    for (int p = 0; p < 3; ++p) {
+      MfmGemmDesc& d = g[n++];
+      d.a = A[p]; d.a_sm = lA[p]; d.a_sk = 1;
+      d.b = Bm[p]; d.b_sk = 1; d.b_sn = lB[p];              // B^T: element (k, n) = row n, column k
+      d.c = C[p]; d.ldc = ldb;
+      d.m = B; d.n = B; d.n_valid = B; d.k = items[e].dim; d.batch = 1; d.split_k = 1; d.alpha = 1.0f;
+    }
+    K.t[e].z = items[e].z; K.t[e].dz = items[e].dz; K.t[e].zz = zz; K.t[e].gz = gz; K.t[e].gg = gg; K.t[e].dim = items[e].dim;
+  }
+  int rc = gemm_group_launch(g, n, stream);
+  if (rc != MFM_OK) return rc;
+  const float loss_scale = 1.0f / ((float)B * (float)B);
+  const dim3 grid(std::min(cdiv(B, 4), 2 * device_cus()), count);
+  hipLaunchKernelGGL(mmd_k_kernel, grid, dim3(256), 2 * (size_t)B * sizeof(float), stream, K, B, ldb, ldz, lddz, loss, loss_scale, dz_scale);
+  MFM_LAUNCH_CHECK("mmd_k_kernel");
+  bool any_dz = false;
+  for (int e = 0; e < count; ++e) any_dz = any_dz || items[e].dz;
+  if (!any_dz) return MFM_OK;
+  memset(g, 0, sizeof(g));
+  n = 0;
+  for (int e = 0; e < count; ++e) {
+    if (!items[e].dz) continue;
+    const float coef = 4.0f * loss_scale * dz_scale / ((float)items[e].dim * (float)items[e].dim);
+    for (int p = 0; p < 2; ++p) {
+      MfmGemmDesc& d = g[n++];
+      d.a = p == 0 ? K.t[e].zz : K.t[e].gz; d.a_sm = ldb; d.a_sk = 1;
+      d.b = p == 0 ? items[e].z : items[e].g; d.b_sk = p == 0 ? ldz : ldg; d.b_sn = 1;
+      d.c = items[e].dz; d.ldc = lddz;
+      d.m = B; d.n = items[e].dim; d.n_valid = items[e].dim; d.k = B; d.batch = 1; d.split_k = 0; d.accumulate = 1;
+      d.alpha = p == 0 ? coef : -coef;
+    }
+  }
+  return gemm_group_launch(g, n, stream);
+}
+
 int mmd_group_launch(const MmdItem* items, int count, int64_t ldz, int64_t ldg, int64_t lddz, int B, float* loss,
-                     float dz_scale, hipStream_t stream) {
+                     float dz_scale, hipStream_t stream, float* scratch) {
   MFM_REQUIRE(B >= 1 && count >= 1 && count <= 4, "mmd: B=%d terms=%d", B, count);
+  // large batches with scratch from the caller: the GEMM form (measured crossover: plan.hip)
+  if (scratch) {
+    bool ok = B <= 8192;
+    for (int i = 0; i < count; ++i)
+      ok = ok && items[i].z && items[i].g && items[i].dim >= 1 && (ldz & 3) == 0 && (ldg & 3) == 0 &&
+           (((uintptr_t)items[i].z) & 15) == 0 && (((uintptr_t)items[i].g) & 15) == 0;
+    if (ok) return mmd_gemm_form(items, count, ldz, ldg, lddz, B, loss, dz_scale, scratch, stream);
+  }
   MmdGroup G;
   memset(&G, 0, sizeof(G));
   int dmax = 0;
@@ -154,7 +275,7 @@ int mmd_group_launch(const MmdItem* items, int count, int64_t ldz, int64_t ldg, 
 int mmd_launch(const float* z, int64_t ldz, const float* g, int64_t ldg, int B, int dim, float* loss, float* dz, int64_t lddz,
                float dz_scale, hipStream_t stream) {
   MmdItem it = {z, g, dz, dim};
-  return mmd_group_launch(&it, 1, ldz, ldg, lddz, B, loss, dz_scale, stream);
+  return mmd_group_launch(&it, 1, ldz, ldg, lddz, B, loss, dz_scale, stream, nullptr);
 }
 
 }  // namespace mfm

@@ -109,6 +109,7 @@ struct MfmPlan {
   int64_t zyin, d_hT, dmem, datt;
   int64_t du1, du2, dchat, dh2, dlog, dh1, dcs;
   int64_t lat_seed;                  // variant 2: gradient seed record of the latent backward (d MMD / d z)
+  int64_t mmd_scr;                   // variant 2, large B: Gram / kernel matrices of the MMD's GEMM form (-1: row kernel)
   int z_seg[4];                      // variant 2: record offsets of z_l, z_a, z_v, z_y
   const float* gauss;                // variant 2: caller's N(0,1) sample [B, zl+za+zv+zy]
   int64_t ws_floats;
@@ -540,6 +541,14 @@ static int build(MfmPlan* P) {
   P->lat_grd = carve(cur, (int64_t)c.B * rs);
   P->lat_rec = carve(cur, (int64_t)c.B * rs);
   P->lat_seed = (V == 2) ? carve(cur, (int64_t)c.B * rs) : -1;
+  // MMD beyond the reference's batch size: scratch for the Gram-matrix form (mmd.hip).  Measured (MOSI sizes, us for the four
+  // terms, row kernel vs GEMM form): B = 32: 18.8 vs 20.8, 64: 31 vs 21, 96: 44 vs 22, 128: 56 vs 22, 256: 105 vs 29, 512: 556 vs 50,
+  // 1024: 1099 vs 117 -> from B = 48; MFM_MMD_GEMM_MINB moves the threshold (0 = never)
+  {
+    long minb = 48;
+    if (const char* e = getenv("MFM_MMD_GEMM_MINB")) minb = atol(e);
+    P->mmd_scr = (V == 2 && minb > 0 && c.B >= minb && c.B <= 8192) ? carve(cur, mmd_scratch_floats(c.B, 4)) : -1;
+  }
   if (V != 0) P->dh_last[3] = carve(cur, (int64_t)c.B * P->nzy);     // d loss / d [mu_y | logvar_y] (or z_y)
   P->yhat = carve(cur, (int64_t)c.B * c.output_dim);
   P->ones = carve(cur, TB);
@@ -959,7 +968,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       it[e].z = W + P->lat_rec + P->z_seg[e]; it[e].g = P->gauss + goff; it[e].dz = W + P->lat_seed + P->z_seg[e]; it[e].dim = zn[e];
       goff += zn[e];
     }
-    RUN(K_MMD, mmd_group_launch(it, 4, rs, gl, rs, B, losses + 4, c.lda_reg, s));     // the four terms in one launch
+    RUN(K_MMD, mmd_group_launch(it, 4, rs, gl, rs, B, losses + 4, c.lda_reg, s, P->mmd_scr >= 0 ? W + P->mmd_scr : nullptr));     // the four terms in one launch (large B: three)
   }
   // F3: decoder recurrences
   {

@@ -212,6 +212,47 @@ def test_fused_mfn_plan_odd_sizes_and_large_batch_vs_oracle(variant, B, T, od, p
         assert d.max() < 1.01 * 3e-3, n
 
 
+@pytest.mark.parametrize("B,T,force", [(32, 20, True), (33, 3, True), (270, 4, False)])
+def test_mmd_gemm_form_matches_oracle(B, T, force, monkeypatch):
+    """MMD of the non-KL MFM as Gram-matrix GEMMs (mmd.hip, the default from B = 48; forced onto smaller batches here):
+    regulariser value, every gradient (the MMD gradient enters through the latent backward's seed record) against the
+    oracle at canonical sizes; B = 33 / 270 leave ragged last rows in the B x B matrices."""
+    _need_gpu()
+    if force:
+        monkeypatch.setenv("MFM_MMD_GEMM_MINB", "1")
+    else:
+        monkeypatch.delenv("MFM_MMD_GEMM_MINB", raising=False)
+    cfgs = configs.canonical_configs(dropout=False)
+    cfg = cfgs[0]
+    e, w = _engine(cfgs, "mmd")
+    xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=29)
+    gl = cfg["zl_size"] + cfg["za_size"] + cfg["zv_size"] + cfg["zy_size"]
+    gauss = torch.from_numpy(np.random.RandomState(6).normal(size=(B, gl)).astype(np.float32))
+    e.gauss = gauss.cuda()
+    torch.set_num_threads(4)
+    m = _oracle("mmd", cfgs, w, gauss)
+    x, y = torch.from_numpy(xn), torch.from_numpy(yn)
+    terms = O.loss_terms(m, x, y, cfg)
+    terms["loss"].backward()
+    xd, yd = x.cuda(), y.cuda()
+    out = e.forward(xd, yd, train=True, want_xhat=False)
+    ld = e.loss_dict(out["losses"])
+    for k in ("disc", "gen", "reg", "loss"):
+        ref = float(terms[k].detach())
+        assert abs(ld[k] - ref) <= TOL * max(abs(ref), 1e-3), (k, ld[k], ref)
+    e.backward(xd, yd, stage=0)
+    gv = e.grad_views()
+    worst = ("", 0.0)
+    for n, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        err = grad_err(gv[n].cpu().numpy(), p.grad.numpy())
+        if err > worst[1]:
+            worst = (n, err)
+    cases.report("mmd_gemm_form_B%d" % B, worst[1])
+    assert worst[1] < TOL, "worst gradient mismatch %s: %.3e" % worst
+
+
 class _StepMask(torch.nn.Module):
     """nn.Dropout stand-in for the oracle's per-timestep MFN dropouts: multiplies call t by mask[t]."""
 
