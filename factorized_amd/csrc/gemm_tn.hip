@@ -62,12 +62,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmGroup g) {
   const int kbeg = split * P.k_per_split;
   const int klen = min(d.k - kbeg, P.k_per_split);          // 1 .. TN_KC rows of this chunk
 
-  const float* __restrict__ A = d.a + (int64_t)z * d.a_sz;
+  const float* A = d.a + (int64_t)z * d.a_sz;
   const float* __restrict__ Bm = d.b + (int64_t)z * d.b_sz;
   const int a_sk = (int)d.a_sk, b_sk = (int)d.b_sk;
   // descriptors end at the last valid element: a 16-byte group that runs past it (or past its row's valid columns)
   // returns zeros / neighbours' values for the excess elements, which only reach outputs that are never stored
-  const int a_bytes = ((d.m - 1) + (d.k - 1) * a_sk + 1) * 4;
+  // a_bf16 (bf16-resident plans: the decoders' dA buffers): A holds __bf16 elements, addressed by the same element strides
+  const bool a16 = d.a_bf16 != 0;
+  if (a16) A = reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(d.a) + (int64_t)z * d.a_sz);
+  const int a_elems = (d.m - 1) + (d.k - 1) * a_sk + 1;
+  const int a_bytes = a16 ? ((a_elems * 2 + 3) & ~3) : a_elems * 4;
   const int b_bytes = ((max(d.n_valid, 1) - 1) + (d.k - 1) * b_sk + 1) * 4;
   const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc((void*)Bm, 0, b_bytes, 0x00020000);
@@ -81,7 +85,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmGroup g) {
     const bool rok = r < klen;
     const int offa = (rok & (m0 + 4 * c4 < d.m)) ? ((kbeg + r) * a_sk + m0 + 4 * c4) * 4 : -16;
     const int offb = (rok & (n0 + 4 * c4 < d.n_valid)) ? ((kbeg + r) * b_sk + n0 + 4 * c4) * 4 : -16;
-    ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ares, offa, 0, 0));
+    if (a16) {        // (wave-uniform) four bf16 values = one 8-byte load
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+      const u32x2_t raw = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(ares, offa >= 0 ? offa >> 1 : -16, 0, 0));
+      ra[j] = __builtin_convertvector(__builtin_bit_cast(bf16x4_t, raw), f32x4);
+    } else {
+      ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ares, offa, 0, 0));
+    }
     rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bres, offb, 0, 0));
   }
   // elements past the valid columns of a straddling group hold the neighbours' values: zero them, so that no Inf / NaN
@@ -154,6 +165,8 @@ bool gemm_tn_supported(const MfmGemmDesc* descs, int count, int max_rows, bool c
     // a non-accumulating product (C = ...) is taken when the caller vouches that C holds zeros: 0 + v is v exactly
     if (d.a_sm != 1 || d.b_sn != 1 || (!d.accumulate && !c_is_zero) || d.bias || d.bias2) return no("not an accumulating TN product");
     if (d.k > max_rows) return no("too many rows");
+    if (d.a_bf16 && ((d.a_sk & 3) || (d.a_sz & 3) || (reinterpret_cast<uintptr_t>(d.a) & 7))) return no("bf16 A not 8-byte shaped");
+    if (d.c_bf16) return no("bf16 output");
     const int64_t lim = (int64_t)1 << 29;
     if ((int64_t)(d.k - 1) * d.a_sk + d.m >= lim || (int64_t)(d.k - 1) * d.b_sk + d.n >= lim) return false;
   }

@@ -1537,18 +1537,19 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     long tn_rows = 1024;         // measured crossover: 640 rows 21.7 vs 24.8 us, 1280 rows equal, 2560 rows 67 vs 59 us
     if (const char* e = getenv("MFM_GEMM_TN_MAXROWS")) tn_rows = atol(e);
     const bool tn_on = !c.precision && !(getenv("MFM_GEMM_TN") && atoi(getenv("MFM_GEMM_TN")) == 0);
-    // bf16 plans: the products over B rows of fp32 operands (the latent stack's 22 Linears: both records are fp32) go to the
-    // chunked fp32 kernel too -- 22 small outputs with K = B are all split-K prologue on the grouped kernel (48 us at
+    // bf16 plans: the products over B rows (the latent stack's 22 Linears on their fp32 records, the decoders' t = 0 products
+    // on bf16-resident dA) go to the chunked fp32 kernel too -- 22 small outputs with K = B are all split-K prologue on the grouped kernel (48 us at
     // B = 2048) -- the rest (bf16-resident operands, sums over T*B rows) stays on the grouped bf16 GEMM
-    // (two launches instead of one: pays from B ~ 1024 -- measured B = 256 / 512 / 2048 / 4096: 19 vs 13, 21 vs 16, 34 vs 49,
-    // 45 vs 88 us; MFM_GEMM_TN_BF16_MINB moves the threshold)
-    const long tn16_minb = getenv("MFM_GEMM_TN_BF16_MINB") ? atol(getenv("MFM_GEMM_TN_BF16_MINB")) : 1024;
+    // (bf16-resident plans: that is the whole tail, one launch either way -- B = 192 / 256 / 512 / 1024 / 2048: 9.8 vs 11.8,
+    // 10.0 vs 12.9, 11.2 vs 16.2, 16.4 vs 23.8, 22.2 vs 48.5 us; fp32-stored bf16 plans, B < 192, keep the one grouped launch;
+    // MFM_GEMM_TN_BF16_MINB moves the threshold)
+    const long tn16_minb = getenv("MFM_GEMM_TN_BF16_MINB") ? atol(getenv("MFM_GEMM_TN_BF16_MINB")) : 192;
     if (c.precision && B >= tn16_minb && !(getenv("MFM_GEMM_TN") && atoi(getenv("MFM_GEMM_TN")) == 0)) {
       long tn_rows16 = 8192;
       if (const char* e = getenv("MFM_GEMM_TN_MAXROWS_BF16")) tn_rows16 = atol(e);
       std::vector<MfmGemmDesc> small, rest;
       for (const MfmGemmDesc& d : tail)
-        ((!d.a_bf16 && !d.c_bf16 && d.k <= tn_rows16 && d.k <= 4L * B && gemm_tn_supported(&d, 1, (int)tn_rows16, true)) ? small : rest).push_back(d);
+        ((!d.c_bf16 && d.k <= tn_rows16 && d.k <= 4L * B && gemm_tn_supported(&d, 1, (int)tn_rows16, true)) ? small : rest).push_back(d);
       for (size_t done = 0; done < small.size(); done += MFM_GEMM_MAXP) {
         const int cnt = (int)std::min(small.size() - done, (size_t)MFM_GEMM_MAXP);
         RUN(K_ENC_DW, gemm_tn_launch(small.data() + done, cnt, (int)tn_rows16, true, s));

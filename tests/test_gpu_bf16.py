@@ -515,7 +515,7 @@ def seq_policy(request, monkeypatch):
     else:
         monkeypatch.delenv("MFM_DWB_MF", raising=False)
     # "tnsplit": the B-row products of fp32 operands (the latent stack's weight gradients) on gemm_tn_kernel, the rest of
-    # the last launch on the grouped bf16 GEMM (default from B = 1024)
+    # the last launch on the grouped bf16 GEMM (default from B = 192)
     if "tnsplit" in request.param:
         monkeypatch.setenv("MFM_GEMM_TN_BF16_MINB", "1")
     else:
