@@ -112,6 +112,23 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmGroup g) {
   }
   __syncthreads();
 
+  // ---- optional: column sums of the A slice (bias gradients riding on their weight gradient's product; internal.h).  The
+  // condition is uniform over the workgroup.
+  {
+    float* csum;
+    { unsigned long long bits = ((unsigned long long)(unsigned)d.reserved_[1] << 32) | (unsigned)d.reserved_[0]; csum = reinterpret_cast<float*>(bits); }
+    if (csum && tn == 0 && z == 0) {
+      __shared__ float cs[4][TN_T];
+      const int c = tid & 31, part = tid >> 5;
+      float sacc = 0.0f;
+      for (int r = part; r < klen; r += 8) sacc += As[r * TN_T + ((c + 16 * (r & 1)) & 31)];
+      sacc += __shfl_xor(sacc, 32, 64);              // the two row parts of a wave
+      if (lane < 32) cs[wave][c] = sacc;
+      __syncthreads();
+      if (tid < TN_T && m0 + tid < d.m) atomicAdd(csum + m0 + tid, d.alpha * (cs[0][tid] + cs[1][tid] + cs[2][tid] + cs[3][tid]));
+    }
+  }
+
   // ---- wave (wm, wn): fragment rows m0 + 16 wm .., columns n0 + 16 wn ..
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   {

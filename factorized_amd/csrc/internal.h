@@ -1,5 +1,6 @@
 // Internal (non-ABI) declarations shared between the .hip translation units of libmfm_hip.so.
 #pragma once
+#include <string.h>
 #include "common.h"
 
 namespace mfm {
@@ -22,6 +23,11 @@ struct MseEpi {          // squared-error epilogue of one product: target, d(out
 };
 // precision: 0 = fp32 operands on v_mfma_f32_16x16x4_f32, 1 = operands rounded to bf16 on the way into LDS,
 // v_mfma_f32_16x16x32_bf16 with fp32 accumulation (gemm_bf16.hip)
+// internal use of MfmGemmDesc::reserved_ (8 bytes, zero for every caller of the C ABI): TN products on gemm_tn_kernel can
+// also add the column sums of their A operand (sum over the rows k of A[k][m], times alpha) into a vector -- the bias
+// gradient that belongs to a weight gradient dW = G^T X -- from the slices they have in LDS anyway
+static inline void gemm_set_colsum(MfmGemmDesc& d, float* p) { memcpy(d.reserved_, &p, sizeof(p)); }
+static inline float* gemm_get_colsum_host(const MfmGemmDesc& d) { float* p; memcpy(&p, d.reserved_, sizeof(p)); return p; }
 int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, const ZeroSpans* zs = nullptr,
                       const MseEpi* mse = nullptr, int mse_count = 0, int precision = 0, const GemmEpiSet* epis = nullptr);
 int device_cus();
@@ -240,6 +246,7 @@ struct LatentDev {
                                        // walks the stages (the MMD regulariser's d reg / d z of the non-KL MFM)
   unsigned long long* dbg;             // optional: block 0 / thread 0 writes s_memtime at phase marks
   int B, rows_per_wg, rows_fwd, train, has_logvar;     // rows per workgroup of the staged kernels: backward / forward
+  int skip_bias;                       // staged backward: leave the bias gradients to the weight-gradient launch (gemm_tn column sums)
   int mfma;                            // staged kernels: the layers' products on v_mfma_f32_16x16x4_f32 (rows per workgroup <= 16, every K % 4 == 0)
   int row_path;                        // 1: one batch row per workgroup, weights read straight from L2 (latent.hip)
   // row path: per-thread work items of every stage, precomputed by the host ([nstages][MFM_LAT_ROW_THREADS] int4,

@@ -546,7 +546,7 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_kernel(const LatentDev
     // dW = G^T X are left to a grouped MFMA GEMM over the two records (plan.hip): writing 57k
     // floats per workgroup from here is store-issue bound (~7 B/clk/CU: 25 us at B=32), and
     // cross-XCD atomics on them were worse.
-    total = pfxN[oe - 1] + ops[oe - 1].N;
+    total = L.skip_bias ? 0 : pfxN[oe - 1] + ops[oe - 1].N;      // (skip_bias: column sums of the weight-gradient launch, gemm_tn.hip)
     for (int item = tid; item < total; item += nt) {
       const int o = find_op(pfxN, ob, oe, item, 1);
       const LatOp& op = ops[o];

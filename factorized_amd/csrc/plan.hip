@@ -1365,6 +1365,18 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       if (rc == MFM_OK) enc_bwd_done = true;
       else if (rc != MFM_ERR_UNSUPPORTED) return rc;
     }
+    // bf16 plans from B = 192 send the latent weight gradients to gemm_tn_kernel (end of this function): the staged backward
+    // then leaves the bias gradients to that launch's column sums instead of adding 1180 words per workgroup into the same
+    // addresses (10 of its 60 us at B = 2048, profiles/r03_latent_mfma.txt); MFM_LATENT_BIAS_TN=0 keeps the atomics
+    bool bias_in_tail = false;
+    if (!enc_bwd_done && !L.row_path && c.precision && B <= 8192 && !(getenv("MFM_GEMM_TN") && atoi(getenv("MFM_GEMM_TN")) == 0) &&
+        !(getenv("MFM_LATENT_BIAS_TN") && atoi(getenv("MFM_LATENT_BIAS_TN")) == 0)) {
+      const long minb = getenv("MFM_GEMM_TN_BF16_MINB") ? atol(getenv("MFM_GEMM_TN_BF16_MINB")) : 192;
+      long rows16 = 8192;
+      if (const char* e = getenv("MFM_GEMM_TN_MAXROWS_BF16")) rows16 = atol(e);
+      bias_in_tail = B >= minb && B <= rows16;
+    }
+    L.skip_bias = bias_in_tail ? 1 : 0;
     if (!enc_bwd_done) RUN(K_LAT_BWD, latent_bwd_launch(L, params, grads, s));
     // weight gradients of the 22 latent Linears: dW[n][k] = sum_r G[r][out+n] X[r][in+k]
     const int rs = P->lat.rec_size;
@@ -1377,6 +1389,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       d.b = W + P->lat_rec + op.in_off; d.b_sk = rs; d.b_sn = 1;
       d.c = grads + op.w_off; d.ldc = op.K;
       d.m = op.N; d.n = op.K; d.n_valid = op.K; d.k = P->B;
+      if (bias_in_tail) gemm_set_colsum(d, grads + op.b_off);
       tail.push_back(d);
     }
   }
@@ -1554,6 +1567,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
         const int cnt = (int)std::min(small.size() - done, (size_t)MFM_GEMM_MAXP);
         RUN(K_ENC_DW, gemm_tn_launch(small.data() + done, cnt, (int)tn_rows16, true, s));
       }
+      for (const MfmGemmDesc& d : rest) MFM_REQUIRE(!gemm_get_colsum_host(d), "plan: a product that carries bias column sums did not reach the chunked kernel");
       tail.swap(rest);
     }
     const int ntail = (int)tail.size();
