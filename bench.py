@@ -176,6 +176,23 @@ def main():
             tt = torch.tensor([1e3 * ev0.elapsed_time(ev1) / 50], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             coll_us[name] = round(float(tt.item()), 1)
+    exposed_us = None
+    if world > 1:
+        # what the exchange ADDS to a step: the same K steps without it (fwd + bwd + Adam on the local gradients), timed the
+        # same way.  Last: the replicas diverge from here on.
+        def run_local(n, first=0):
+            for i in range(n):
+                x, y = data.batch(my_batches[(first + i) % len(my_batches)])
+                e.grad_step(x, y, check=False)
+                e.adam(lr=1e-3, grad_scale=1.0 / world)
+        run_local(5)
+        barrier()
+        t0 = time.perf_counter()
+        run_local(args.steps, args.warmup + 10)
+        barrier()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        exposed_us = round(1e6 * (dt - float(tt.item())) / args.steps, 1)
     timed = e.collect_timing(T, B)[dom]
     e.set_timing(T, B, 0)
 
@@ -216,7 +233,8 @@ def main():
                        "params": e.layout.numel,
                        "collective": allreduce.name if allreduce is not None else None,
                        "replicas_in_sync": in_sync,
-                       "collective_us_per_call": coll_us if world > 1 else None},
+                       "collective_us_per_call": coll_us if world > 1 else None,
+                       "exposed_collective_us": exposed_us},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 4),
                          "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 6), "traffic": traffic,

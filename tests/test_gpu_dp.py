@@ -285,6 +285,9 @@ def test_bench_ranks_on_one_device_stay_in_sync(n, extra):
     assert out["config"]["global_batch"] == 32 * n
     assert out["config"]["collective"] in ("p2p-two-shot", "rccl")
     assert out["value"] > 0
+    # the exchange's cost inside a step: the timed K steps minus the same K steps on local gradients (a float; on one
+    # shared device it also contains the ranks' queueing behind each other, so only its presence is checked here)
+    assert isinstance(out["config"]["exposed_collective_us"], float)
 
 
 def _nccl_world1(q):
