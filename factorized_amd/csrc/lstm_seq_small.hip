@@ -22,11 +22,13 @@
 // Buffers, layouts and the encoder/decoder forms are exactly those of lstm_seq.hip.
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "internal.h"
 #include "latent_row_dev.h"
 #include "lstm_seq_dev.h"
+#include "proj_role_dev.h"
 
 namespace mfm {
 
@@ -136,8 +138,12 @@ __device__ __forceinline__ void stage_gates2(const SeqDev& d, int mode, int g, f
 // 2 loads per step (80 instructions per step, ~0.5 us of a 1.4 us step; profiles/r01 seq experiments).
 // Instead the owners drop (i, f, g, o, c, h) into an LDS record and 6*Hp*R/64 waves write it out after
 // the step's barrier; the encoders' x-projections are fetched two steps ahead by 4*Hp*R/64 waves.
-template <int KQ, int R>
-__device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds) {
+// FLG (encoders of the fold launch with projection role workgroups, proj_role_dev.h): the x-projections of a time step
+// are produced inside this launch; the fetching waves check the step's block flags (requested one step earlier) before they
+// request its values, and read them with agent-scope loads.
+template <int KQ, int R, bool FLG = false>
+__device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds,
+                                               const unsigned* flg = nullptr, const unsigned epoch = 0, const int ncb = 0) {
   constexpr int HK = 4 * KQ;                    // padded hidden extent of the matvec
   constexpr int HKB = (HK + 15) / 16 * 16;      // == Hp
   constexpr int NTH = 8 * HKB;                  // threads this LSTM uses (blockDim may be larger)
@@ -237,11 +243,23 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
     xl[i] = (g * HKB + unit) * R + r;
     xpf[i] = 0.0f;
   }
+  // FLG: only the waves that fetch projections look at flags (wave-uniform)
+  const bool fetch_wave = FLG && !dec && (tid & ~63) < 4 * HKB * R && (tid & ~63) < NTH;
+  unsigned fv = 0;
   if (!dec) {
+    if constexpr (FLG) {
+      if (fetch_wave) {
+        const int t1 = (T > 1) ? 1 : 0;
+        proj_flags_wait(flg, proj_flags_load(flg, ncb), epoch, ncb);
+        proj_flags_wait(flg + t1 * PROJ_ROLE_FLAGS, proj_flags_load(flg + t1 * PROJ_ROLE_FLAGS, ncb), epoch, ncb);
+        fv = proj_flags_load(flg + min(2, T - 1) * PROJ_ROLE_FLAGS, ncb);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NXL; ++i) {
-      const float v0 = xp[i][0];
-      xpf[i] = xp[i][(T > 1) ? gstep : 0];
+      float v0;
+      if constexpr (FLG) { v0 = ld_agent((const float*)xp[i]); xpf[i] = ld_agent((const float*)xp[i] + ((T > 1) ? gstep : 0)); }
+      else { v0 = xp[i][0]; xpf[i] = xp[i][(T > 1) ? gstep : 0]; }
       if (xok[i]) xbuf[xl[i]] = v0;
     }
   }
@@ -320,8 +338,17 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
     for (int i = 0; i < NXL; ++i) xn[i] = 0.0f;
     if (!dec) {
       const int64_t off = (int64_t)min(t + 2, T - 1) * gstep;
+      if constexpr (FLG) {
+        if (fetch_wave) {
+          proj_flags_wait(flg + min(t + 2, T - 1) * PROJ_ROLE_FLAGS, fv, epoch, ncb);
 #pragma unroll
-      for (int i = 0; i < NXL; ++i) xn[i] = xp[i][off];
+          for (int i = 0; i < NXL; ++i) xn[i] = ld_agent((const float*)xp[i] + off);
+          fv = proj_flags_load(flg + min(t + 3, T - 1) * PROJ_ROLE_FLAGS, ncb);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) xn[i] = xp[i][off];
+      }
     }
     // all-reduce the four k-slices of the quad, keep the sums of batch row q, add bias / x-projection
     float mine[2];
@@ -808,6 +835,38 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_fold_kernel(const SeqLaun
   }
 }
 
+// Forward fold launch with projection role workgroups (proj_role_dev.h): blocks [0, n_role) produce the x-projections
+// (and clear the launch's zero spans), blocks [n_role, n_role + 4 B) are the fold launch's (encoder, row) workgroups.
+template <int K0, int K1, int K2, int K3>
+__global__ __launch_bounds__(1024) void lstm_seq_small_foldproj_kernel(const SeqLaunch L, const LatentDev LD, const ProjRole PR,
+                                                                       const float* __restrict__ params) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int bid = blockIdx.x;
+  if (bid < PR.n_role) { proj_role_body(L, PR, lds); return; }
+  int di = 0;
+#pragma unroll 1
+  for (int i = 1; i < L.count; ++i)
+    if (bid >= L.d[i].block_begin) di = i;
+  const SeqDev& d = L.d[di];
+  const int tile = bid - d.block_begin;
+  const unsigned* flg = PR.flags + (int64_t)di * L.T * PROJ_ROLE_FLAGS;
+  const int ncb = PR.e[di].ncb;
+#define MFM_ONE(IDX, KK) \
+  if (KK > 0 && di == IDX) small_fwd_body<(KK > 0 ? KK : 2), 1, true>(d, L.T, L.B, tile, lds, flg, PR.epoch, ncb);
+  MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3)
+#undef MFM_ONE
+  // the loss slots are cleared by the producers of t = 0: all of them have passed before this row's chain adds to them
+  if (threadIdx.x < 64) {
+#pragma unroll 1
+    for (int e = 0; e < 4; ++e) {
+      const unsigned* f0 = PR.flags + (int64_t)e * L.T * PROJ_ROLE_FLAGS;
+      proj_flags_wait(f0, proj_flags_load(f0, PR.e[e].ncb), PR.epoch, PR.e[e].ncb);
+    }
+  }
+  __syncthreads();        // every store of the last time step has been acknowledged: h_T of this row is readable
+  latent_fwd_row_body<false>(LD, params, tile, di, lds, true);
+}
+
 static size_t small_lds_bytes(const SeqLaunch& L, bool bwd, int R) {
   size_t lds_bytes = 0;
   for (int i = 0; i < L.count; ++i) {
@@ -883,6 +942,56 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
 
 
 // MFM_OK: launched.  MFM_ERR_UNSUPPORTED: not a case the fold kernels take (the caller issues the separate launches).
+// Projection role workgroups for a forward fold launch: shapes the role kernel takes and enough idle CUs
+bool seq_small_foldproj_supported(int T, int B, const int* h, const int* k, int n_enc) {
+  if (const char* e = getenv("MFM_PROJ_FOLD")) { if (atoi(e) == 0) return false; }
+  if (getenv("MFM_SEQ_KS") || getenv("MFM_SEQ_ROWS")) return false;
+  if (const char* e = getenv("MFM_LATENT_FOLD")) { if (atoi(e) == 0) return false; }
+  if (n_enc != 4 || T < 1 || B < 1 || B > PROJ_ROLE_CB) return false;
+  if (device_cus() - 4 * B < PROJ_ROLE_SLOTS) return false;
+  int slots = 0, kmax = 0;
+  for (int e = 0; e < 4; ++e) {
+    if (k[e] < 1 || k[e] > 128 * PROJ_ROLE_MAXG) return false;
+    slots += 4 * round_up(h[e], 16) / PROJ_ROLE_CB;
+    if (4 * round_up(h[e], 16) / PROJ_ROLE_CB > PROJ_ROLE_FLAGS) return false;
+    kmax = std::max(kmax, k[e]);
+  }
+  if (slots > PROJ_ROLE_SLOTS) return false;
+  const int ks = proj_role_kstride(kmax);
+  return ((size_t)3 * PROJ_ROLE_CB * ks + 16 * PROJ_ROLE_PW) * sizeof(float) <= 160 * 1024;
+}
+
+int seq_small_foldproj_launch(SeqLaunch& L, const LatentDev& LD, ProjRole& PR, const float* params, hipStream_t stream) {
+  const int want[4] = {8, 2, 20, 30};
+  if (L.count != 4 || !LD.row_path || LD.nch != 4 || LD.pre || LD.B != L.B) return MFM_ERR_UNSUPPORTED;
+  for (int i = 0; i < 4; ++i)
+    if (L.d[i].hk4 != want[i] || L.d[i].is_dec) return MFM_ERR_UNSUPPORTED;
+  int hh[4], kk[4];
+  for (int i = 0; i < 4; ++i) { hh[i] = L.d[i].h; kk[i] = PR.e[i].k; }
+  if (!seq_small_foldproj_supported(L.T, L.B, hh, kk, 4)) return MFM_ERR_UNSUPPORTED;
+  int n_role = (device_cus() - 4 * L.B) / PROJ_ROLE_SLOTS * PROJ_ROLE_SLOTS;
+  if (const char* e = getenv("MFM_PROJ_FOLD_ROLES")) { const int v = atoi(e) / PROJ_ROLE_SLOTS * PROJ_ROLE_SLOTS; if (v >= PROJ_ROLE_SLOTS) n_role = v; }
+  PR.n_role = n_role; PR.groups = n_role / PROJ_ROLE_SLOTS;
+  int kmax = 0, cb = 0;
+  for (int i = 0; i < 4; ++i) {
+    kmax = std::max(kmax, PR.e[i].k);
+    PR.e[i].cb_begin = cb; PR.e[i].ncb = 4 * L.d[i].Hp / PROJ_ROLE_CB;
+    cb += PR.e[i].ncb;
+  }
+  PR.kstride = proj_role_kstride(kmax);
+  int total = n_role;
+  for (int i = 0; i < 4; ++i) { L.d[i].block_begin = total; total += L.B; }
+  size_t lds_bytes = small_lds_bytes(L, false, 1);
+  const size_t lat = ((size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + (size_t)LD.rec_size) * sizeof(float);
+  const size_t role = ((size_t)3 * PROJ_ROLE_CB * PR.kstride + 16 * PROJ_ROLE_PW) * sizeof(float);
+  lds_bytes = std::max(lds_bytes, std::max(lat, role));
+  if (lds_bytes > 160 * 1024) return MFM_ERR_UNSUPPORTED;
+  MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_foldproj_kernel<8, 2, 20, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL((lstm_seq_small_foldproj_kernel<8, 2, 20, 30>), dim3(total), dim3(1024), lds_bytes, stream, L, LD, PR, params);
+  MFM_LAUNCH_CHECK("lstm_seq_small_foldproj_kernel");
+  return MFM_OK;
+}
+
 int seq_small_fold_launch(SeqLaunch& L, bool bwd, const LatentDev& LD, const float* params, float* grads, hipStream_t stream) {
   if (const char* e = getenv("MFM_LATENT_FOLD")) { if (atoi(e) == 0) return MFM_ERR_UNSUPPORTED; }
   if (getenv("MFM_SEQ_KS") || getenv("MFM_SEQ_ROWS")) return MFM_ERR_UNSUPPORTED;       // tuning overrides keep the plain launches

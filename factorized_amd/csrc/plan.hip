@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "internal.h"
+#include "proj_role_dev.h"
 #include "pack_dev.h"
 #include "lstm_seq_dev.h"
 
@@ -125,6 +126,8 @@ struct MfmPlan {
   uint64_t calls;
   const float* grads_prezeroed;     // gradient buffer cleared by the forward pass of the running fused step
   int fold_state = 0;               // encoder + latent fold launches (lstm_seq_small.hip): 0 untried, 1 in use, -1 not applicable
+  int projfold_state = 0;           // projection role workgroups in the forward fold launch (proj_role_dev.h): 0 / 1 / -1 alike
+  int64_t pf_flags = -1;            // their flag words [4][T][16] (u32)
   // ---- bf16 plans (decided once, when the plan is built)
   bool seq_bf16 = false;            // the recurrences run on the bf16 MFMA kernels (lstm_seq_bf16.hip)
   bool st16 = false;                // bf16-RESIDENT saved activations: gates / dA, hs, dH, d x_hat live in HBM as bf16 (round 3)
@@ -537,6 +540,7 @@ static int build(MfmPlan* P) {
 
   P->lat_ops_off = carve(cur, (int64_t)(sizeof(P->lat_ops) / (sizeof(float))));
   P->dbg_off = carve(cur, 128);     // 64 x u64 debug timestamps
+  P->pf_flags = (V == 0) ? carve(cur, (int64_t)4 * P->T * PROJ_ROLE_FLAGS) : -1;
   P->lat_items_off = carve(cur, (int64_t)P->lat_items.size());
   P->lat_grd = carve(cur, (int64_t)c.B * rs);
   P->lat_rec = carve(cur, (int64_t)c.B * rs);
@@ -861,8 +865,17 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     RUN(K_PACK, pack_all_launch(&PKL, pjp, fcp, s));
   }
 
-  // F0: input projections
-  {
+  // F0: input projections.  MFM_KL_EF at B <= 32 (fp32 plans on the fold launches): produced
+  // by role workgroups of the encoder launch itself (proj_role_dev.h), which also clear the zero spans
+  bool proj_in_fold = false;
+  if (V == 0 && !seq_bf16 && c.precision == 0 && P->n_enc == 4 && P->fold_state >= 0 && P->projfold_state >= 0 && P->pf_flags >= 0 &&
+      TB * P->D < ((int64_t)1 << 28)) {
+    int hh[4], kk[4];
+    for (int e = 0; e < 4; ++e) { hh[e] = P->enc[e].h; kk[e] = P->enc_d[e]; }
+    proj_in_fold = seq_small_foldproj_supported(T, B, hh, kk, 4);
+    if (!proj_in_fold) P->projfold_state = -1;
+  }
+  auto run_f0 = [&]() -> int {
     MfmGemmDesc g[6];
     memset(g, 0, sizeof(g));
     for (int e = 0; e < P->n_enc; ++e) {
@@ -907,7 +920,9 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     } else {
       RUN(K_PROJ, gemm_group_launch(g, P->n_enc, s, &zs, nullptr, 0, c.precision));
     }
-  }
+    return MFM_OK;
+  };
+  if (!proj_in_fold) { const int rc0 = run_f0(); if (rc0 != MFM_OK) return rc0; }
   // the latent stack's launch descriptor (used by F2, or by the fold launch of F1)
   LatentDev L = P->lat;
   {
@@ -929,7 +944,31 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
   // F1: encoder recurrences (up to MFM_MAX_SEQ per launch).  MFM_KL_EF at small batches: the four encoders' workgroups
   // also run their rows' latent chains (fold launch, lstm_seq_small.hip) and F2 disappears
   bool folded = false;
-  if (V == 0 && !seq_bf16 && P->n_enc == 4 && P->fold_state >= 0) {
+  if (proj_in_fold) {
+    MfmSeqDesc q[4];
+    for (int e = 0; e < 4; ++e) q[e] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
+    ProjRole PR;
+    memset(&PR, 0, sizeof(PR));
+    PR.x = x; PR.ldx = P->D; PR.x_rows = (int)TB;
+    PR.flags = reinterpret_cast<unsigned*>(W + P->pf_flags); PR.epoch = (unsigned)P->calls;
+    PR.zs = zs;
+    PR.loss_ptr = zs.ptr[0]; PR.loss_n = (int)zs.n[0];
+    PR.zs.ptr[0] = nullptr; PR.zs.n[0] = 0;
+    for (int e = 0; e < 4; ++e) {
+      const int pb = P->enc_p[e];
+      PR.e[e].w = params + P->off[pb + W_IH]; PR.e[e].b_ih = params + P->off[pb + B_IH]; PR.e[e].b_hh = params + P->off[pb + B_HH];
+      PR.e[e].k_off = P->enc_xoff[e]; PR.e[e].k = P->enc_d[e];
+    }
+    int rc;
+    { Timer _t(P, s, K_ENC_FWD); rc = seq_foldproj_launch(q, 4, T, B, L, params, PR, s); }
+    if (rc == MFM_OK) { folded = true; P->projfold_state = 1; P->fold_state = 1; }
+    else if (rc == MFM_ERR_UNSUPPORTED) {
+      P->projfold_state = -1;
+      const int rc0 = run_f0();
+      if (rc0 != MFM_OK) return rc0;
+    } else return rc;
+  }
+  if (!folded && V == 0 && !seq_bf16 && P->n_enc == 4 && P->fold_state >= 0) {
     MfmSeqDesc q[4];
     for (int e = 0; e < 4; ++e) q[e] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
     int rc;
