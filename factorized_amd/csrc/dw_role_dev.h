@@ -1,0 +1,180 @@
+// Weight gradients as ROLE workgroups of the encoder BPTT launch (round 3, MFM_KL_EF at B <= 32).
+//
+// Every weight-gradient product of the step is a sum over rows, C[m, n] += sum_r A[r, m] B[r, n] (gemm_tn.hip), and at the
+// reference's batch size they were a launch of their own behind the encoder BPTT: ~18 us plus the boundary, while the BPTT
+// itself keeps only 4 B <= 128 of the 256 CUs busy for ~43 us.  Here the idle CUs run those products INSIDE the BPTT launch:
+//   * a role workgroup (1024 threads) is four SLOTS of 256 threads, each with the arithmetic of gemm_tn_kernel on one
+//     (tile, 128-row chunk) block per iteration: whole operand slices requested at once, 32 MFMA steps per wave;
+//   * a device table built once per plan gives every slot its block per iteration ([iteration][slot]), ordered by when the
+//     A operand becomes final: first the decoder-side products (final before the launch) and the latent stack's (after the
+//     rows' chains at the head of this launch), one chunk per block, partial tile added with atomics; then every ENCODER
+//     tile stays with one slot for all its chunks, from the last time steps to the first, accumulates in registers and
+//     is added to the gradient once (the launch it replaces spent its time on ~1.5 M memory-side atomics);
+//   * the BPTT workgroup of (encoder e, row b) writes dA_t with agent-scope stores and, one step later -- when those stores
+//     are acknowledged anyway (s_waitcnt vmcnt(#loads of the newer prefetch)) -- stamps flags[e][t][b] with the launch's
+//     epoch; a block whose chunk starts at time step t0 polls the B stamps of (e, t0) and reads dA with agent-scope loads.
+// No deadlock: the BPTT workgroups have the lower block ids and never wait.  What stays exposed is the last chunk
+// (time steps 0..3): one round of blocks behind the end of the BPTT.
+#pragma once
+#include "internal.h"
+#include "lstm_seq_dev.h"
+
+namespace mfm {
+
+constexpr int DWR_KC = 128;            // rows per chunk
+constexpr int DWR_T = 32;              // tile edge
+constexpr int DWR_MAXP = 56;
+constexpr int DWR_ROWS = 32;           // stamp words per (encoder, time step): B <= 32
+constexpr int DWR_TABLE_CAP = 16384;   // table entries carved in the plan workspace
+
+struct DwRoleProblem {
+  const float* a; const float* b; float* c; float* c2;
+  int a_sz, b_sz, c_sz, a_sk, b_sk, ldc, m, n_valid, k, tiles_m, tiles_n, kps, batch;
+  float alpha;
+};
+struct DwRole {
+  DwRoleProblem p[DWR_MAXP];
+  int count, n_iter, n_role, T, B, any_dep;
+  const int4* table;                   // [n_iter][4 n_role]: x = problem (-1: idle), y = tile (tn + tiles_n (tm + tiles_m z)), z = chunk,
+                                       // w = dep | t0 << 8 | FIRST << 24 | LAST << 25 | accumulator << 26
+  unsigned* flags;                     // [4][T][32] BPTT stamps, then [4][B] latent-chain stamps
+  unsigned epoch;
+};
+// dep codes of a table entry
+constexpr int DWR_DEP_NONE = 0, DWR_DEP_LATENT = 5;     // 1..4: encoder e = dep - 1
+constexpr int DWR_FIRST = 1 << 24, DWR_LAST = 1 << 25, DWR_ACC1 = 1 << 26;
+
+int seq_small_folddw_launch(SeqLaunch& L, const LatentDev& LD, DwRole& DR, const float* params, float* grads, hipStream_t stream);
+int seq_folddw_launch(const MfmSeqDesc* descs, int count, int T, int B, const LatentDev& lat, const float* params, float* grads,
+                      DwRole& dr, hipStream_t stream);
+bool seq_small_folddw_supported(int T, int B);
+
+__device__ __forceinline__ void dwr_stamp(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// wave-level wait for `n` stamps at f[0..n) (n <= 128)
+__device__ __forceinline__ void dwr_wait(const unsigned* f, int n, unsigned epoch) {
+  const int lane = threadIdx.x & 63;
+  const long long t0 = wall_clock64();
+  for (;;) {
+    const unsigned v0 = __hip_atomic_load(f + (lane < n ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned v1 = __hip_atomic_load(f + (lane + 64 < n ? lane + 64 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__builtin_amdgcn_ballot_w64(v0 != epoch || v1 != epoch) == 0ull) return;
+    if (wall_clock64() - t0 > 5000000ll) return;          // ~50 ms: a broken producer becomes a parity failure, not a hung GPU
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
+__device__ __forceinline__ void dw_role_body(const DwRole& DR, float* lds) {
+  constexpr int LOADS = DWR_KC * (DWR_T / 4) / 256;
+  const int tid = threadIdx.x, sub = tid >> 8, t = tid & 255;
+  const int lane = t & 63, wave = t >> 6;
+  const int bi = lane & 15, q = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  float* As = lds + sub * (2 * DWR_KC * DWR_T);
+  float* Bs = As + DWR_KC * DWR_T;
+  const int r = blockIdx.x - 4 * DR.B;           // role index
+  const int nslots = 4 * DR.n_role, slot = 4 * r + sub;
+  f32x4 accs[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 1
+  for (int it = 0; it < DR.n_iter; ++it) {
+    int4 ent = DR.table[(int64_t)it * nslots + slot];
+    ent.x = __builtin_amdgcn_readfirstlane(ent.x); ent.y = __builtin_amdgcn_readfirstlane(ent.y);
+    ent.z = __builtin_amdgcn_readfirstlane(ent.z); ent.w = __builtin_amdgcn_readfirstlane(ent.w);
+    const bool active = ent.x >= 0;
+    const DwRoleProblem& P = DR.p[active ? ent.x : 0];
+    int local = ent.y;
+    const int tn = local % P.tiles_n; local /= P.tiles_n;
+    const int tm = local % P.tiles_m;
+    const int z = local / P.tiles_m;
+    const int m0 = tm * DWR_T, n0 = tn * DWR_T;
+    const int kbeg = ent.z * P.kps;
+    const int klen = active ? min(P.k - kbeg, P.kps) : 0;
+    const int dep = ent.w & 255, t0 = (ent.w >> 8) & 0xffff;
+    f32x4 ra[LOADS], rb[LOADS];
+    const float* A = P.a + (int64_t)z * P.a_sz;
+    const float* Bm = P.b + (int64_t)z * P.b_sz;
+    const int a_bytes = ((P.m - 1) + (P.k - 1) * P.a_sk + 1) * 4;
+    const int b_bytes = ((max(P.n_valid, 1) - 1) + (P.k - 1) * P.b_sk + 1) * 4;
+    const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc((void*)Bm, 0, b_bytes, 0x00020000);
+    // the B operand (batch columns, hidden states, records of the forward) never depends on this launch: requested before
+    // the wait for the A operand's stamps
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < LOADS; ++j) {
+        const int idx = t + j * 256;
+        const int rr = idx >> 3, c4 = idx & 7;
+        const int offb = ((rr < klen) & (n0 + 4 * c4 < P.n_valid)) ? ((kbeg + rr) * P.b_sk + n0 + 4 * c4) * 4 : -16;
+        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bres, offb, 0, 0));
+      }
+    }
+    // ONE wave per slot polls (a thousand waves re-reading four flag lines at the memory side wait on each other)
+    if (active && dep != DWR_DEP_NONE && wave == 0) {
+      if (dep == DWR_DEP_LATENT) dwr_wait(DR.flags + 4 * DR.T * DWR_ROWS, 4 * DR.B, DR.epoch);      // [4][B] dense
+      else dwr_wait(DR.flags + ((dep - 1) * DR.T + t0) * DWR_ROWS, DR.B, DR.epoch);
+    }
+    if (DR.any_dep) __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < LOADS; ++j) {
+        const int idx = t + j * 256;
+        const int rr = idx >> 3, c4 = idx & 7;
+        const int offa = ((rr < klen) & (m0 + 4 * c4 < P.m)) ? ((kbeg + rr) * P.a_sk + m0 + 4 * c4) * 4 : -16;
+        // A may have been written inside this launch (dA, the latent gradients): agent-scope load (sc1)
+        ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ares, offa, 0, 16));
+      }
+#pragma unroll
+      for (int j = 0; j < LOADS; ++j) {
+        const int idx = t + j * 256;
+        const int rr = idx >> 3, c4 = idx & 7;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ra[j][e] = (m0 + 4 * c4 + e < P.m) ? ra[j][e] : 0.0f;
+          rb[j][e] = (n0 + 4 * c4 + e < P.n_valid) ? rb[j][e] : 0.0f;
+        }
+        const int sw = (4 * c4 + 16 * (rr & 1)) & 31;
+        *reinterpret_cast<f32x4*>(As + rr * DWR_T + sw) = ra[j];
+        *reinterpret_cast<f32x4*>(Bs + rr * DWR_T + sw) = rb[j];
+      }
+    }
+    __syncthreads();
+    if (active) {
+      const bool a1 = (ent.w & DWR_ACC1) != 0;
+      f32x4 acc = a1 ? accs[1] : accs[0];
+      if (ent.w & DWR_FIRST) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int rot = 16 * (q & 1);
+      const float* ap = As + q * DWR_T + ((16 * wm + bi + rot) & 31);
+      const float* bp = Bs + q * DWR_T + ((16 * wn + bi + rot) & 31);
+      const int nks = (klen + 3) >> 2;               // rows klen .. 4 nks - 1 of the images are zeros (loaded out of range)
+      int ks = 0;
+      for (; ks + 4 <= nks; ks += 4) {
+        float a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = ap[(ks + u) * 4 * DWR_T]; b[u] = bp[(ks + u) * 4 * DWR_T]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = mma16x16x4(a[u], b[u], acc);
+      }
+      for (; ks < nks; ++ks) acc = mma16x16x4(ap[ks * 4 * DWR_T], bp[ks * 4 * DWR_T], acc);
+      if (a1) accs[1] = acc; else accs[0] = acc;
+      if (ent.w & DWR_LAST) {
+        float* __restrict__ C = P.c + (int64_t)z * P.c_sz;
+        float* __restrict__ C2 = P.c2 ? P.c2 + (int64_t)z * P.c_sz : nullptr;
+        const int col = n0 + 16 * wn + bi;
+        if (col < P.n_valid) {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int row = m0 + 16 * wm + 4 * q + rr;
+            if (row < P.m) {
+              const float v = P.alpha * acc[rr];
+              atomicAdd(C + (int64_t)row * P.ldc + col, v);
+              if (C2) atomicAdd(C2 + (int64_t)row * P.ldc + col, v);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();          // the images are free for the next block
+  }
+}
+
+}  // namespace mfm

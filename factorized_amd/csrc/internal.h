@@ -262,6 +262,7 @@ struct LatentDev {
   int nitems_fwd_c[4][MFM_LAT_MAXSTAGES], nitems_bwd_c[4][MFM_LAT_MAXSTAGES];
   uint64_t seed;
   float reg_w, disc_w, gen_w;
+  int grd_agent;          // grd_out leaves with agent-scope stores (read inside the same launch, dw_role_dev.h)
 };
 int latent_fwd_launch(const LatentDev& L, const float* params, hipStream_t stream);
 // lstm_seq.hip / lstm_seq_small.hip -- the encoder recurrences of MFM_KL_EF with their rows' latent chains folded in

@@ -474,7 +474,12 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
     const int lo4 = all ? 0 : (L.ch_lo[ch] >> 2), hi4 = all ? (RS >> 2) : (L.ch_hi[ch] >> 2);
     f32x4* d4 = reinterpret_cast<f32x4*>(L.grd_out + (int64_t)row * RS);
     const f32x4* s4 = reinterpret_cast<const f32x4*>(grd);
-    for (int idx = lo4 + tid; idx < hi4; idx += nt) d4[idx] = s4[idx];
+    if (L.grd_agent) {        // read by weight-gradient role workgroups of the same launch (dw_role_dev.h): agent-scope stores
+      float* d1 = L.grd_out + (int64_t)row * RS;
+      for (int idx = 4 * lo4 + tid; idx < 4 * hi4; idx += nt) __hip_atomic_store(d1 + idx, grd[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      for (int idx = lo4 + tid; idx < hi4; idx += nt) d4[idx] = s4[idx];
+    }
   }
 }
 

@@ -27,6 +27,7 @@
 #include "internal.h"
 #include "lstm_seq_dev.h"
 #include "proj_role_dev.h"
+#include "dw_role_dev.h"
 
 namespace mfm {
 
@@ -374,7 +375,7 @@ bool bf16_seq_pays(int B) {
   return B >= (e ? atoi(e) : 192);
 }
 
-struct FoldArgs { const LatentDev* lat; const float* params; float* grads; ProjRole* pr; };
+struct FoldArgs { const LatentDev* lat; const float* params; float* grads; ProjRole* pr; DwRole* dr; };
 
 static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bool bwd, hipStream_t stream, bool bf16 = false,
                       const FoldArgs* fold = nullptr) {
@@ -438,6 +439,7 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     if (need > lds_bytes) lds_bytes = need;
   }
   if (fold && fold->pr) return seq_small_foldproj_launch(L, *fold->lat, *fold->pr, fold->params, stream);
+  if (fold && fold->dr) return seq_small_folddw_launch(L, *fold->lat, *fold->dr, fold->params, fold->grads, stream);
   if (fold) return seq_small_fold_launch(L, bwd, *fold->lat, fold->params, fold->grads, stream);
   if (bf16) return seq_bf16_launch(L, bwd, stream);      // bf16 MFMA operands: one kernel family for every batch size
   if (use_small_path(B)) return seq_small_launch(L, bwd, stream);
@@ -470,16 +472,25 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
 // encoder recurrences + their rows' latent chains in one launch (lstm_seq_small.hip); MFM_ERR_UNSUPPORTED: not applicable
 int seq_fold_launch(const MfmSeqDesc* descs, int count, int T, int B, bool bwd, const LatentDev& lat, const float* params,
                     float* grads, hipStream_t stream) {
-  FoldArgs f = {&lat, params, grads, nullptr};
+  FoldArgs f = {&lat, params, grads, nullptr, nullptr};
   return seq_launch(descs, count, T, B, bwd, stream, false, &f);
 }
 // the forward fold launch with projection role workgroups in front (proj_role_dev.h)
 int seq_foldproj_launch(const MfmSeqDesc* descs, int count, int T, int B, const LatentDev& lat, const float* params, ProjRole& pr,
                         hipStream_t stream) {
-  FoldArgs f = {&lat, params, nullptr, &pr};
+  FoldArgs f = {&lat, params, nullptr, &pr, nullptr};
   return seq_launch(descs, count, T, B, false, stream, false, &f);
 }
 
+}  // namespace mfm
+
+namespace mfm {
+// the backward fold launch with weight-gradient role workgroups behind the BPTT workgroups (dw_role_dev.h)
+int seq_folddw_launch(const MfmSeqDesc* descs, int count, int T, int B, const LatentDev& lat, const float* params, float* grads,
+                      DwRole& dr, hipStream_t stream) {
+  FoldArgs f = {&lat, params, grads, nullptr, &dr};
+  return seq_launch(descs, count, T, B, true, stream, false, &f);
+}
 }  // namespace mfm
 
 extern "C" int mfm_lstm_seq_fwd(const MfmSeqDesc* descs, int count, int T, int B, void* stream) {

@@ -29,6 +29,7 @@
 #include "latent_row_dev.h"
 #include "lstm_seq_dev.h"
 #include "proj_role_dev.h"
+#include "dw_role_dev.h"
 
 namespace mfm {
 
@@ -414,8 +415,12 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
 // gate columns per lane (c = 32 m + 4 q + e, one ds_read_b128 per 4 columns).  Built on the hypothesis that the step is
 // VALU-issue bound (~165 instructions per wave and step, 56 of them the recurrent FMAs); measured no faster (see
 // seq_small_launch), so it is opt-in (MFM_SEQ_KS=8) and parity-tested only.
-template <int KQ, int R, int KS = 16>
-__device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds) {
+// PUB (encoders of the fold launch with weight-gradient role workgroups, dw_role_dev.h): dA_t leaves with agent-scope stores
+// and one step later, once those stores are acknowledged, stamp[t * DWR_ROWS] <- epoch tells the role workgroups that this
+// row's dA of the time steps >= t is in memory.
+template <int KQ, int R, int KS = 16, bool PUB = false>
+__device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds,
+                                               unsigned* stamp = nullptr, const unsigned epoch = 0) {
   constexpr int HK = 4 * KQ;                       // padded hidden extent
   constexpr int HKB = (HK + 15) / 16 * 16;         // per-gate extent of the dA panel (multiple of 16) == Hp
   static_assert(KS == 16 || (KS == 8 && R == 1), "8 k-slices: one-row tiles only");
@@ -564,6 +569,8 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
     float pn[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) pn[i] = fetch(i, max(t - 2, 0));
+    // everything older than these NLD loads -- the dA stores of step t + 1 among it -- has been acknowledged
+    if constexpr (PUB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
     const float dh = dh_rec + ext;
     const float tc = act_tanh(ct);
     const float dot = dh * tc;
@@ -587,9 +594,13 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
         if (fok[i]) sbuf[(par ^ 1) * (NV * HKB * R) + fl[i]] = pf[i];
     }
     lds_barrier();
+    if constexpr (PUB) {
+      if (tid == 0 && t + 1 < T) dwr_stamp(stamp + (t + 1) * DWR_ROWS, epoch);
+    }
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
-      if (sok[i]) *sp[i] = db[sl[i]];
+      if constexpr (PUB) { if (sok[i]) __hip_atomic_store((float*)sp[i], db[sl[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      else { if (sok[i]) *sp[i] = db[sl[i]]; }
       sp[i] -= gstep;
     }
 #pragma unroll
@@ -684,6 +695,10 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
   if (dec) load_wT(1);                 // grad wrt the step-0 input goes through W_ih only (peeled)
   step(0);
   if (dec && bvalid && d.d_h_init && mu < h) d.d_h_init[(int64_t)b * d.ld_dinit + mu] = dh_rec;
+  if constexpr (PUB) {
+    __syncthreads();                   // (waits for every outstanding store of every wave)
+    if (tid == 0) dwr_stamp(stamp, epoch);
+  }
 }
 
 #define MFM_SMALL_CASES(BODY)                                                                \
@@ -867,6 +882,30 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_foldproj_kernel(const Seq
   latent_fwd_row_body<false>(LD, params, tile, di, lds, true);
 }
 
+// Backward fold launch with weight-gradient role workgroups (dw_role_dev.h): blocks [0, 4 B) are the fold launch's
+// (encoder, row) workgroups, blocks [4 B, 4 B + n_role) run the table of weight-gradient blocks.
+template <int K0, int K1, int K2, int K3>
+__global__ __launch_bounds__(1024) void lstm_seq_small_folddw_kernel(const SeqLaunch L, const LatentDev LD, const DwRole DR,
+                                                                     const float* __restrict__ params, float* __restrict__ grads) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int bid = blockIdx.x;
+  if (bid >= 4 * L.B) { dw_role_body(DR, lds); return; }
+  int di = 0;
+#pragma unroll 1
+  for (int i = 1; i < L.count; ++i)
+    if (bid >= L.d[i].block_begin) di = i;
+  const SeqDev& d = L.d[di];
+  const int tile = bid - d.block_begin;          // == batch row (one-row tiles)
+  latent_bwd_row_body<false>(LD, params, grads, tile, di, lds);
+  __syncthreads();        // d h_T of this (row, encoder) is in memory (and the LDS is free) before the BPTT reads it
+  if (threadIdx.x == 0) dwr_stamp(DR.flags + 4 * L.T * DWR_ROWS + di * L.B + tile, DR.epoch);
+  unsigned* stamp = DR.flags + (int64_t)di * L.T * DWR_ROWS + tile;
+#define MFM_ONE(IDX, KK) \
+  if (KK > 0 && di == IDX) small_bwd_body<(KK > 0 ? KK : 2), 1, 16, true>(d, L.T, L.B, tile, lds, stamp, DR.epoch);
+  MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3)
+#undef MFM_ONE
+}
+
 static size_t small_lds_bytes(const SeqLaunch& L, bool bwd, int R) {
   size_t lds_bytes = 0;
   for (int i = 0; i < L.count; ++i) {
@@ -942,6 +981,36 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
 
 
 // MFM_OK: launched.  MFM_ERR_UNSUPPORTED: not a case the fold kernels take (the caller issues the separate launches).
+bool seq_small_folddw_supported(int T, int B) {
+  if (const char* e = getenv("MFM_DW_FOLD")) { if (atoi(e) == 0) return false; }
+  if (getenv("MFM_SEQ_KS") || getenv("MFM_SEQ_ROWS")) return false;
+  if (const char* e = getenv("MFM_LATENT_FOLD")) { if (atoi(e) == 0) return false; }
+  return T >= 1 && B >= 1 && B <= DWR_ROWS && device_cus() - 4 * B >= 32;
+}
+
+int seq_small_folddw_launch(SeqLaunch& L, const LatentDev& LD, DwRole& DR, const float* params, float* grads, hipStream_t stream) {
+  const int want[4] = {8, 2, 20, 30};
+  if (L.count != 4 || !LD.row_path || LD.nch != 4 || LD.pre || LD.B != L.B) return MFM_ERR_UNSUPPORTED;
+  for (int i = 0; i < 4; ++i)
+    if (L.d[i].hk4 != want[i] || L.d[i].is_dec) return MFM_ERR_UNSUPPORTED;
+  if (!seq_small_folddw_supported(L.T, L.B)) return MFM_ERR_UNSUPPORTED;
+  const int n_role = DR.n_role;          // the block table was laid out for this many role workgroups
+  if (n_role < 1 || n_role > device_cus() - 4 * L.B) return MFM_ERR_UNSUPPORTED;
+  DR.T = L.T; DR.B = L.B;
+  int total = 0;
+  for (int i = 0; i < 4; ++i) { L.d[i].block_begin = total; total += L.B; }
+  total += n_role;
+  size_t lds_bytes = small_lds_bytes(L, true, 1);
+  const size_t lat = ((size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + 2 * (size_t)LD.rec_size) * sizeof(float);
+  const size_t role = (size_t)4 * 2 * DWR_KC * DWR_T * sizeof(float);
+  lds_bytes = std::max(lds_bytes, std::max(lat, role));
+  if (lds_bytes > 160 * 1024) return MFM_ERR_UNSUPPORTED;
+  MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_folddw_kernel<8, 2, 20, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL((lstm_seq_small_folddw_kernel<8, 2, 20, 30>), dim3(total), dim3(1024), lds_bytes, stream, L, LD, DR, params, grads);
+  MFM_LAUNCH_CHECK("lstm_seq_small_folddw_kernel");
+  return MFM_OK;
+}
+
 // Projection role workgroups for a forward fold launch: shapes the role kernel takes and enough idle CUs
 bool seq_small_foldproj_supported(int T, int B, const int* h, const int* k, int n_enc) {
   if (const char* e = getenv("MFM_PROJ_FOLD")) { if (atoi(e) == 0) return false; }

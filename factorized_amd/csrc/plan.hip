@@ -26,6 +26,7 @@
 
 #include "internal.h"
 #include "proj_role_dev.h"
+#include "dw_role_dev.h"
 #include "pack_dev.h"
 #include "lstm_seq_dev.h"
 
@@ -128,6 +129,11 @@ struct MfmPlan {
   int fold_state = 0;               // encoder + latent fold launches (lstm_seq_small.hip): 0 untried, 1 in use, -1 not applicable
   int projfold_state = 0;           // projection role workgroups in the forward fold launch (proj_role_dev.h): 0 / 1 / -1 alike
   int64_t pf_flags = -1;            // their flag words [4][T][16] (u32)
+  int dwfold_state = 0;             // weight-gradient role workgroups in the backward fold launch (dw_role_dev.h): 0 / 1 / -1
+  int64_t dw_flags = -1, dw_table = -1;     // stamps [4][T][32] + [4][B]; block table [DWR_TABLE_CAP] int4
+  std::vector<int> dw_table_host;   // the table as uploaded (4 ints per block)
+  int dw_table_key = -1;            // what it was built for (stage / upstream-gradient form)
+  const float* dw_table_ws = nullptr;       // the workspace that holds it
   // ---- bf16 plans (decided once, when the plan is built)
   bool seq_bf16 = false;            // the recurrences run on the bf16 MFMA kernels (lstm_seq_bf16.hip)
   bool st16 = false;                // bf16-RESIDENT saved activations: gates / dA, hs, dH, d x_hat live in HBM as bf16 (round 3)
@@ -541,6 +547,10 @@ static int build(MfmPlan* P) {
   P->lat_ops_off = carve(cur, (int64_t)(sizeof(P->lat_ops) / (sizeof(float))));
   P->dbg_off = carve(cur, 128);     // 64 x u64 debug timestamps
   P->pf_flags = (V == 0) ? carve(cur, (int64_t)4 * P->T * PROJ_ROLE_FLAGS) : -1;
+  if (V == 0 && c.B <= DWR_ROWS) {
+    P->dw_flags = carve(cur, (int64_t)4 * P->T * DWR_ROWS + 4 * DWR_ROWS);
+    P->dw_table = carve(cur, (int64_t)DWR_TABLE_CAP * 4);
+  }
   P->lat_items_off = carve(cur, (int64_t)P->lat_items.size());
   P->lat_grd = carve(cur, (int64_t)c.B * rs);
   P->lat_rec = carve(cur, (int64_t)c.B * rs);
@@ -1287,6 +1297,105 @@ static int mfn_backward(MfmPlan* P, const float* params, float* W, float* grads,
   return MFM_OK;
 }
 
+// Descriptor table and block list of the weight-gradient role workgroups (dw_role_dev.h).  The block list depends on the
+// products' shapes and on which buffer their A operand lives in, not on addresses that change per call: it is built once per
+// (plan, stage form) and uploaded into the workspace.  MFM_ERR_UNSUPPORTED: a product the role blocks do not take.
+static int dw_role_build(MfmPlan* P, const std::vector<MfmGemmDesc>& all, float* W, int key, hipStream_t s, DwRole* out) {
+  const int T = P->T, B = P->B;
+  const int64_t TB = (int64_t)T * B;
+  const int n = (int)all.size();
+  if (n < 1 || n > DWR_MAXP || !gemm_tn_supported(all.data(), n, INT32_MAX, true)) return MFM_ERR_UNSUPPORTED;
+  DwRole& DR = *out;
+  memset(&DR, 0, sizeof(DR));
+  DR.count = n;
+  int dep[DWR_MAXP], tbase[DWR_MAXP];
+  const int64_t lim = (int64_t)1 << 29;
+  for (int i = 0; i < n; ++i) {
+    const MfmGemmDesc& d = all[i];
+    if (d.a_bf16 || d.c_bf16 || gemm_get_colsum_host(d)) return MFM_ERR_UNSUPPORTED;
+    if (d.a_sz >= lim || d.b_sz >= lim || d.c_sz >= lim || d.a_sk >= lim || d.b_sk >= lim || d.ldc >= lim) return MFM_ERR_UNSUPPORTED;
+    DwRoleProblem& q = DR.p[i];
+    q.a = d.a; q.b = d.b; q.c = d.c; q.c2 = d.c2;
+    q.a_sz = (int)d.a_sz; q.b_sz = (int)d.b_sz; q.c_sz = (int)d.c_sz; q.a_sk = (int)d.a_sk; q.b_sk = (int)d.b_sk; q.ldc = (int)d.ldc;
+    q.m = d.m; q.n_valid = (d.n_valid <= 0 || d.n_valid > d.n) ? d.n : d.n_valid; q.k = d.k; q.batch = d.batch; q.alpha = d.alpha;
+    q.tiles_m = cdiv(d.m, DWR_T); q.tiles_n = cdiv(d.n, DWR_T);
+    int split = cdiv(d.k, DWR_KC);
+    q.kps = round_up(cdiv(d.k, split), 4);
+    dep[i] = DWR_DEP_NONE; tbase[i] = 0;
+    for (int e = 0; e < 4; ++e) {
+      const float* g0 = W + P->enc[e].gates;
+      const int64_t step = (int64_t)B * 4 * P->enc[e].Hp;
+      if (d.a >= g0 && d.a < g0 + TB * 4 * P->enc[e].Hp) { dep[i] = e + 1; tbase[i] = (int)((d.a - g0) / step); }
+    }
+    if (d.a >= W + P->lat_grd && d.a < W + P->lat_grd + (int64_t)B * P->lat.rec_size) dep[i] = DWR_DEP_LATENT;
+    if (getenv("MFM_DW_FOLD_NODEP")) dep[i] = DWR_DEP_NONE;       // timing experiment only (wrong gradients): nothing waits
+  }
+  int n_role = device_cus() - 4 * B;
+  if (const char* e = getenv("MFM_DW_FOLD_ROLES")) { const int v = atoi(e); if (v >= 1 && v <= n_role) n_role = v; }
+  if (n_role < 1) return MFM_ERR_UNSUPPORTED;
+  DR.n_role = n_role;
+  const int nslots = 4 * n_role;
+  if (P->dw_table_key != key || P->dw_table_host.empty()) {
+    // phase A: one block per (tile, chunk) of the products whose A operand does not come from the encoder BPTT
+    struct Unit { int p, tile, chunk, w; };
+    std::vector<Unit> ua;
+    for (int pass = 0; pass < 2; ++pass)          // final-before-the-launch operands first, the latent stack's behind them
+      for (int i = 0; i < n; ++i) {
+        if (dep[i] != (pass == 0 ? DWR_DEP_NONE : DWR_DEP_LATENT)) continue;
+        const DwRoleProblem& q = DR.p[i];
+        const int split = cdiv(q.k, q.kps);
+        for (int sp = 0; sp < split; ++sp)
+          for (int tile = 0; tile < q.tiles_m * q.tiles_n * q.batch; ++tile) ua.push_back({i, tile, sp, dep[i] | DWR_FIRST | DWR_LAST});
+      }
+    const int rows_a = cdiv((int)ua.size(), nslots);
+    // phase B: every encoder tile stays with one slot for all its chunks (last time steps first) and is added once
+    struct Tile { int p, tile; };
+    std::vector<Tile> te;
+    int max_split = 0;
+    for (int i = 0; i < n; ++i) {
+      if (dep[i] < 1 || dep[i] > 4) continue;
+      const DwRoleProblem& q = DR.p[i];
+      max_split = std::max(max_split, cdiv(q.k, q.kps));
+      for (int tile = 0; tile < q.tiles_m * q.tiles_n * q.batch; ++tile) te.push_back({i, tile});
+    }
+    const int nacc = cdiv((int)te.size(), nslots);
+    if (nacc > 2) return MFM_ERR_UNSUPPORTED;
+    const int n_iter = rows_a + nacc * max_split;
+    if ((int64_t)n_iter * nslots > DWR_TABLE_CAP) return MFM_ERR_UNSUPPORTED;
+    P->dw_table_host.assign((size_t)n_iter * nslots * 4, 0);
+    for (size_t i = 0; i < (size_t)n_iter * nslots; ++i) P->dw_table_host[4 * i] = -1;
+    auto put = [&](int row, int slot, int p, int tile, int chunk, int w) {
+      int* e = &P->dw_table_host[((size_t)row * nslots + slot) * 4];
+      e[0] = p; e[1] = tile; e[2] = chunk; e[3] = w;
+    };
+    for (size_t u = 0; u < ua.size(); ++u) put((int)(u / nslots), (int)(u % nslots), ua[u].p, ua[u].tile, ua[u].chunk, ua[u].w);
+    for (size_t j = 0; j < te.size(); ++j) {
+      const DwRoleProblem& q = DR.p[te[j].p];
+      const int split = cdiv(q.k, q.kps);
+      const int slot = (int)(j % nslots), acc = (int)(j / nslots);
+      for (int c = 0; c < split; ++c) {            // c-th block of this tile: chunk split - 1 - c
+        const int sp = split - 1 - c;
+        const int t0 = tbase[te[j].p] + (sp * q.kps) / B;
+        int w = dep[te[j].p] | (t0 << 8) | (acc ? DWR_ACC1 : 0);
+        if (c == 0) w |= DWR_FIRST;
+        if (c == split - 1) w |= DWR_LAST;
+        put(rows_a + (max_split - split + c) * nacc + acc, slot, te[j].p, te[j].tile, sp, w);
+      }
+    }
+    P->dw_table_key = key;
+    P->dw_table_ws = nullptr;
+  }
+  if (P->dw_table_ws != W) {
+    MFM_HIP_CHECK(hipMemcpyAsync(W + P->dw_table, P->dw_table_host.data(), P->dw_table_host.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    P->dw_table_ws = W;
+  }
+  DR.n_iter = (int)(P->dw_table_host.size() / 4 / nslots);
+  DR.any_dep = 0;
+  for (int i = 0; i < n; ++i) DR.any_dep |= (dep[i] != DWR_DEP_NONE);
+  DR.table = reinterpret_cast<const int4*>(W + P->dw_table);
+  return MFM_OK;
+}
+
 static int backward(MfmPlan* P, const float* params, const float* x, const void* y, int stage, float* W,
                     float* grads, hipStream_t s, const ExtGrads* ext = nullptr) {
   const MfmPlanConfig& c = P->cfg;
@@ -1392,6 +1501,22 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     L.reg_w = c.lda_reg * c.reg_scale;
     L.disc_w = disc_on ? 1.0f : 0.0f;
     L.gen_w = gen_on ? 1.0f : 0.0f;
+    // weight gradients of the 22 latent Linears: dW[n][k] = sum_r G[r][out+n] X[r][in+k]
+    const int rs = P->lat.rec_size;
+    auto latent_products = [&](std::vector<MfmGemmDesc>& out, bool colsum) {
+      for (int i = 0; i < P->lat.nops; ++i) {
+        const LatOp& op = P->lat_ops[i];
+        MfmGemmDesc d;
+        memset(&d, 0, sizeof(d));
+        d.alpha = 1.0f; d.batch = 1; d.split_k = 1; d.accumulate = 0;
+        d.a = W + P->lat_grd + op.out_off; d.a_sm = 1; d.a_sk = rs;
+        d.b = W + P->lat_rec + op.in_off; d.b_sk = rs; d.b_sn = 1;
+        d.c = grads + op.w_off; d.ldc = op.K;
+        d.m = op.N; d.n = op.K; d.n_valid = op.K; d.k = P->B;
+        if (colsum) gemm_set_colsum(d, grads + op.b_off);
+        out.push_back(d);
+      }
+    };
     // MFM_KL_EF at small batches: the encoder BPTT workgroups run their rows' chains first (fold launch); B4 is then done too
     if (V == 0 && !seq_bf16 && P->n_enc == 4 && P->fold_state == 1) {
       MfmSeqDesc q[4];
@@ -1399,7 +1524,28 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
         q[e] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
         q[e].dh_ext = W + P->dh_last[e]; q[e].ld_dh = P->enc_h[e];
       }
-      int rc;
+      int rc = MFM_ERR_UNSUPPORTED;
+      // B <= 32: the idle CUs of this launch run every weight-gradient product of the step (dw_role_dev.h); B5 disappears
+      if (!st16 && c.precision == 0 && P->dwfold_state >= 0 && P->dw_table >= 0 && seq_small_folddw_supported(T, B) &&
+          !getenv("MFM_DW_ONEPASS_MINROWS") && !getenv("MFM_DW_F32_MINROWS") && !(getenv("MFM_GEMM_TN") && atoi(getenv("MFM_GEMM_TN")) == 0)) {
+        std::vector<MfmGemmDesc> all = tail;
+        latent_products(all, false);
+        for (int e = 0; e < 4; ++e) dA_gemms(P, P->enc[e], P->enc_p[e], W, grads, all, x + P->enc_xoff[e], P->D, P->enc_d[e], false);
+        if (gen_on)
+          for (int m = 0; m < 3; ++m) dA_gemms(P, P->dec[m], P->dec_p[m], W, grads, all, W + P->dec_init[m], P->dec_h[m], P->dec_h[m], true, false);
+        DwRole DR;
+        const int key = (gen_on ? 1 : 0) | (disc_on ? 2 : 0) | (ext ? 4 : 0);
+        const int brc = dw_role_build(P, all, W, key, s, &DR);
+        if (brc == MFM_OK) {
+          LatentDev L2 = L;
+          L2.grd_agent = 1;
+          DR.flags = reinterpret_cast<unsigned*>(W + P->dw_flags); DR.epoch = (unsigned)P->calls;
+          { Timer _t(P, s, K_ENC_BWD); rc = seq_folddw_launch(q, 4, T, B, L2, params, grads, DR, s); }
+          if (rc == MFM_OK) { P->dwfold_state = 1; return MFM_OK; }      // every gradient of the step is on its way
+          if (rc != MFM_ERR_UNSUPPORTED) return rc;
+        } else if (brc != MFM_ERR_UNSUPPORTED) return brc;
+        P->dwfold_state = -1;
+      }
       { Timer _t(P, s, K_ENC_BWD); rc = seq_fold_launch(q, 4, T, B, true, L, params, grads, s); }
       if (rc == MFM_OK) enc_bwd_done = true;
       else if (rc != MFM_ERR_UNSUPPORTED) return rc;
@@ -1417,20 +1563,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     }
     L.skip_bias = bias_in_tail ? 1 : 0;
     if (!enc_bwd_done) RUN(K_LAT_BWD, latent_bwd_launch(L, params, grads, s));
-    // weight gradients of the 22 latent Linears: dW[n][k] = sum_r G[r][out+n] X[r][in+k]
-    const int rs = P->lat.rec_size;
-    for (int i = 0; i < P->lat.nops; ++i) {
-      const LatOp& op = P->lat_ops[i];
-      MfmGemmDesc d;
-      memset(&d, 0, sizeof(d));
-      d.alpha = 1.0f; d.batch = 1; d.split_k = 1; d.accumulate = 0;
-      d.a = W + P->lat_grd + op.out_off; d.a_sm = 1; d.a_sk = rs;
-      d.b = W + P->lat_rec + op.in_off; d.b_sk = rs; d.b_sn = 1;
-      d.c = grads + op.w_off; d.ldc = op.K;
-      d.m = op.N; d.n = op.K; d.n_valid = op.K; d.k = P->B;
-      if (bias_in_tail) gemm_set_colsum(d, grads + op.b_off);
-      tail.push_back(d);
-    }
+    latent_products(tail, bias_in_tail);
   }
   // Memory Fusion Network (variants 1, 2): from d [mu_y | logvar_y] back to d h_T / d c_t of its three LSTMs
   if (V != 0) {
