@@ -35,6 +35,7 @@ struct DwRoleProblem {
 struct DwRole {
   DwRoleProblem p[DWR_MAXP];
   int count, n_iter, n_role, T, B, any_dep;
+  int bf16;                            // bf16 plans: both operands rounded to bf16 (RNE) on the way into LDS, fp32 accumulation
   const int4* table;                   // [n_iter][4 n_role]: x = problem (-1: idle), y = tile (tn + tiles_n (tm + tiles_m z)), z = chunk,
                                        // w = dep | t0 << 8 | FIRST << 24 | LAST << 25 | accumulator << 26
   unsigned* flags;                     // [4][T][32] BPTT stamps, then [4][B] latent-chain stamps
@@ -131,6 +132,7 @@ __device__ __forceinline__ void dw_role_body(const DwRole& DR, float* lds) {
         for (int e = 0; e < 4; ++e) {
           ra[j][e] = (m0 + 4 * c4 + e < P.m) ? ra[j][e] : 0.0f;
           rb[j][e] = (n0 + 4 * c4 + e < P.n_valid) ? rb[j][e] : 0.0f;
+          if (DR.bf16) { ra[j][e] = (float)(__bf16)ra[j][e]; rb[j][e] = (float)(__bf16)rb[j][e]; }
         }
         const int sw = (4 * c4 + 16 * (rr & 1)) & 31;
         *reinterpret_cast<f32x4*>(As + rr * DWR_T + sw) = ra[j];

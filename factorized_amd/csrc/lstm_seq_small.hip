@@ -569,8 +569,6 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
     float pn[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) pn[i] = fetch(i, max(t - 2, 0));
-    // everything older than these NLD loads -- the dA stores of step t + 1 among it -- has been acknowledged
-    if constexpr (PUB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
     const float dh = dh_rec + ext;
     const float tc = act_tanh(ct);
     const float dot = dh * tc;
@@ -593,6 +591,9 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
       for (int i = 0; i < NLD; ++i)
         if (fok[i]) sbuf[(par ^ 1) * (NV * HKB * R) + fl[i]] = pf[i];
     }
+    // PUB: everything older than this step's NLD prefetch loads -- the dA stores of step t + 1 among it -- has been
+    // acknowledged (asked for as late as the step allows: the write-through stores have had a whole step)
+    if constexpr (PUB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
     lds_barrier();
     if constexpr (PUB) {
       if (tid == 0 && t + 1 < T) dwr_stamp(stamp + (t + 1) * DWR_ROWS, epoch);

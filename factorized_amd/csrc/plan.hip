@@ -878,7 +878,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
   // F0: input projections.  MFM_KL_EF at B <= 32 (fp32 plans on the fold launches): produced
   // by role workgroups of the encoder launch itself (proj_role_dev.h), which also clear the zero spans
   bool proj_in_fold = false;
-  if (V == 0 && !seq_bf16 && c.precision == 0 && P->n_enc == 4 && P->fold_state >= 0 && P->projfold_state >= 0 && P->pf_flags >= 0 &&
+  if (V == 0 && !seq_bf16 && !st16 && P->n_enc == 4 && P->fold_state >= 0 && P->projfold_state >= 0 && P->pf_flags >= 0 &&
       TB * P->D < ((int64_t)1 << 28)) {
     int hh[4], kk[4];
     for (int e = 0; e < 4; ++e) { hh[e] = P->enc[e].h; kk[e] = P->enc_d[e]; }
@@ -963,6 +963,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     PR.flags = reinterpret_cast<unsigned*>(W + P->pf_flags); PR.epoch = (unsigned)P->calls;
     PR.zs = zs;
     PR.loss_ptr = zs.ptr[0]; PR.loss_n = (int)zs.n[0];
+    PR.bf16 = c.precision ? 1 : 0;
     PR.zs.ptr[0] = nullptr; PR.zs.n[0] = 0;
     for (int e = 0; e < 4; ++e) {
       const int pb = P->enc_p[e];
@@ -1526,7 +1527,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       }
       int rc = MFM_ERR_UNSUPPORTED;
       // B <= 32: the idle CUs of this launch run every weight-gradient product of the step (dw_role_dev.h); B5 disappears
-      if (!st16 && c.precision == 0 && P->dwfold_state >= 0 && P->dw_table >= 0 && seq_small_folddw_supported(T, B) &&
+      if (!st16 && P->dwfold_state >= 0 && P->dw_table >= 0 && seq_small_folddw_supported(T, B) &&
           !getenv("MFM_DW_ONEPASS_MINROWS") && !getenv("MFM_DW_F32_MINROWS") && !(getenv("MFM_GEMM_TN") && atoi(getenv("MFM_GEMM_TN")) == 0)) {
         std::vector<MfmGemmDesc> all = tail;
         latent_products(all, false);
@@ -1540,6 +1541,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
           LatentDev L2 = L;
           L2.grd_agent = 1;
           DR.flags = reinterpret_cast<unsigned*>(W + P->dw_flags); DR.epoch = (unsigned)P->calls;
+          DR.bf16 = c.precision ? 1 : 0;
           { Timer _t(P, s, K_ENC_BWD); rc = seq_folddw_launch(q, 4, T, B, L2, params, grads, DR, s); }
           if (rc == MFM_OK) { P->dwfold_state = 1; return MFM_OK; }      // every gradient of the step is on its way
           if (rc != MFM_ERR_UNSUPPORTED) return rc;
@@ -2057,6 +2059,16 @@ extern "C" double mfm_plan_kernel_flops(const MfmPlan* P, int kid) {
       for (int e = 0; e < P->n_enc; ++e) f += TB * 2.0 * 4.0 * P->enc_h[e] * P->enc_h[e];
       if (P->fold_state == 1)          // fold launches: the rows' latent chains run in the same workgroups
         for (int i = 0; i < P->lat.nops; ++i) f += 2.0 * P->B * P->lat_ops[i].N * P->lat_ops[i].K;
+      // role workgroups (B <= 32): the forward launch also produces the input projections, the backward launch every
+      // weight gradient of the step (proj_role_dev.h, dw_role_dev.h)
+      if (kid == K_ENC_FWD && P->projfold_state == 1) f += mfm_plan_kernel_flops(P, K_PROJ);
+      if (kid == K_ENC_BWD && P->dwfold_state == 1) {
+        for (int e = 0; e < P->n_enc; ++e) f += TB * 2.0 * 4.0 * P->enc_h[e] * (P->enc_d[e] + P->enc_h[e]);
+        for (int m = 0; m < 3; ++m) f += (TB - P->B) * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m];
+        for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m];                      // dWfc
+        for (int m = 0; m < 3; ++m) f += (double)P->B * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m];      // the decoders' t = 0 product
+        for (int i = 0; i < P->lat.nops; ++i) f += 2.0 * P->B * P->lat_ops[i].N * P->lat_ops[i].K;  // latent dW
+      }
       break;
     case K_DEC_FWD: case K_DEC_BWD: for (int m = 0; m < 3; ++m) f += TB * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m]; break;
     case K_FC1_FWD: {

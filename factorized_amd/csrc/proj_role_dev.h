@@ -32,6 +32,7 @@ struct ProjRole {
   int n_role, groups, kstride;            // groups = n_role / 32
   unsigned* flags; unsigned epoch;        // flags[(e * T + t) * 16 + block]
   float* loss_ptr; int loss_n;            // loss slots: cleared with agent-scope stores before any flag of t = 0 is raised
+  int bf16;                               // bf16 plans: x and W_ih rounded to bf16 (RNE) on the way into LDS, fp32 accumulation
   ProjRoleEnc e[4];
   ZeroSpans zs;                           // cleared with plain stores (read by later launches only)
 };
@@ -99,9 +100,13 @@ __device__ __forceinline__ void proj_role_body(const SeqLaunch& L, const ProjRol
       const int i = tid + j * 1024;
       lrow[j] = i / G; lgr[j] = i - lrow[j] * G;
     }
+    const bool rb = PR.bf16 != 0;
     auto zero_tail = [&](f32x4 v, int gr) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = (4 * gr + c < K) ? v[c] : 0.0f;
+      for (int c = 0; c < 4; ++c) {
+        v[c] = (4 * gr + c < K) ? v[c] : 0.0f;
+        if (rb) v[c] = (float)(__bf16)v[c];
+      }
       return v;
     };
     auto load_x = [&](int t, f32x4 (&rx)[PROJ_ROLE_MAXG]) {
