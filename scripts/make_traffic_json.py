@@ -18,6 +18,10 @@ GEMM_ORDER = {4: ["proj_gemm", "fc1_mse_gemm", "fc1_bwd_gemm", "dw_gemm"], 2: ["
 
 
 def classify(name):
+    if "lstm_seq_small_foldproj_kernel" in name:        # ... with the projection role workgroups in front (B <= 32)
+        return "enc_seq_fwd"
+    if "lstm_seq_small_folddw_kernel" in name:          # ... with the weight-gradient role workgroups behind (B <= 32)
+        return "enc_seq_bwd"
     if "lstm_seq_small_fold_kernel<false" in name:      # encoder recurrences + their rows' latent chains (B <= 64)
         return "enc_seq_fwd"
     if "lstm_seq_small_fold_kernel<true" in name:
