@@ -47,7 +47,7 @@ constexpr int DWR_FIRST = 1 << 24, DWR_LAST = 1 << 25, DWR_ACC1 = 1 << 26;
 
 int seq_small_folddw_launch(SeqLaunch& L, const LatentDev& LD, DwRole& DR, const float* params, float* grads, hipStream_t stream);
 int seq_folddw_launch(const MfmSeqDesc* descs, int count, int T, int B, const LatentDev& lat, const float* params, float* grads,
-                      DwRole& dr, hipStream_t stream);
+                      DwRole& dr, hipStream_t stream, const float* const* wt_imgs = nullptr);
 bool seq_small_folddw_supported(int T, int B);
 
 __device__ __forceinline__ void dwr_stamp(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -267,7 +267,8 @@ struct LatentDev {
 int latent_fwd_launch(const LatentDev& L, const float* params, hipStream_t stream);
 // lstm_seq.hip / lstm_seq_small.hip -- the encoder recurrences of MFM_KL_EF with their rows' latent chains folded in
 int seq_fold_launch(const MfmSeqDesc* descs, int count, int T, int B, bool bwd, const LatentDev& lat, const float* params,
-                    float* grads, hipStream_t stream);
+                    float* grads, hipStream_t stream, const float* const* wt_imgs = nullptr);
+int seq_bwd_img_launch(const MfmSeqDesc* descs, int count, int T, int B, const float* const* wt_imgs, hipStream_t stream);
 int latent_bwd_launch(const LatentDev& L, const float* params, float* grads, hipStream_t stream);
 
 }  // namespace mfm

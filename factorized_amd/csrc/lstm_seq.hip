@@ -375,7 +375,7 @@ bool bf16_seq_pays(int B) {
   return B >= (e ? atoi(e) : 192);
 }
 
-struct FoldArgs { const LatentDev* lat; const float* params; float* grads; ProjRole* pr; DwRole* dr; };
+struct FoldArgs { const LatentDev* lat; const float* params; float* grads; ProjRole* pr; DwRole* dr; const float* const* wt_imgs; };
 
 static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bool bwd, hipStream_t stream, bool bf16 = false,
                       const FoldArgs* fold = nullptr) {
@@ -397,7 +397,9 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
       wide[nwide++] = s;
     } else descs[count++] = s;
   }
-  if (fold && (nwide || bf16 || !use_small_path(B))) return MFM_ERR_UNSUPPORTED;
+  if (fold && !fold->lat && !fold->pr && !fold->dr) {      // (images only: a plain launch)
+    if (nwide || bf16 || !use_small_path(B) || getenv("MFM_SEQ_KS") || getenv("MFM_SEQ_ROWS")) fold = nullptr;
+  } else if (fold && (nwide || bf16 || !use_small_path(B))) return MFM_ERR_UNSUPPORTED;
   if (nwide) {
     int rc = seq_stepwise(wide, nwide, T, B, bwd, stream);
     if (rc != MFM_OK) return rc;
@@ -407,8 +409,11 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
   // round of workgroups (B >= 128 with four LSTMs) the widest LSTM must not start in the last round
   // (B=2048: encoder recurrences 154 -> 132 us forward, 163 -> 151 us backward).  While everything is
   // resident at once the caller's order is kept: widest-first measured 0.8 % slower per step at B=32.
-  if ((long)count * B > (long)device_cus() && !getenv("MFM_SEQ_KEEP_ORDER"))
+  bool sorted = false;
+  if ((long)count * B > (long)device_cus() && !getenv("MFM_SEQ_KEEP_ORDER")) {
     std::stable_sort(descs, descs + count, [](const MfmSeqDesc& a, const MfmSeqDesc& b) { return a.h > b.h; });
+    sorted = true;
+  }
   SeqLaunch L;
   memset(&L, 0, sizeof(L));
   L.count = count; L.T = T; L.B = B;
@@ -427,6 +432,7 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     d.w_pack = bf16 ? s.w_pack : nullptr;
     d.h_last = bf16 ? s.h_last : nullptr;
     d.store_bf16 = s.store_bf16;
+    d.wt_img = (fold && fold->wt_imgs && bwd && !sorted && !nwide && count == count_in) ? fold->wt_imgs[i] : nullptr;
     MFM_REQUIRE(bf16 || (!s.store_bf16 && !s.h_last), "lstm_seq[%d]: store_bf16 / h_last are taken by the bf16 entry points only", i);
     d.h = s.h; d.Hp = round_up(s.h, 16);
     d.hk4 = round_up(cdiv(s.h, 4), 2);
@@ -437,6 +443,10 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     const size_t HK = (size_t)d.hk4 * 4;
     const size_t need = (bwd ? 2 * 4 * HK * 16 : 2 * HK * 16) * sizeof(float);
     if (need > lds_bytes) lds_bytes = need;
+  }
+  if (fold && !fold->lat) {          // images only: the plain one-row launch (one-row tiles: checked by the caller's conditions)
+    if ((long)L.count * L.B >= 6L * device_cus()) for (int i = 0; i < L.count; ++i) L.d[i].wt_img = nullptr;
+    return seq_small_launch(L, bwd, stream);
   }
   if (fold && fold->pr) return seq_small_foldproj_launch(L, *fold->lat, *fold->pr, fold->params, stream);
   if (fold && fold->dr) return seq_small_folddw_launch(L, *fold->lat, *fold->dr, fold->params, fold->grads, stream);
@@ -471,24 +481,29 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
 
 // encoder recurrences + their rows' latent chains in one launch (lstm_seq_small.hip); MFM_ERR_UNSUPPORTED: not applicable
 int seq_fold_launch(const MfmSeqDesc* descs, int count, int T, int B, bool bwd, const LatentDev& lat, const float* params,
-                    float* grads, hipStream_t stream) {
-  FoldArgs f = {&lat, params, grads, nullptr, nullptr};
+                    float* grads, hipStream_t stream, const float* const* wt_imgs) {
+  FoldArgs f = {&lat, params, grads, nullptr, nullptr, wt_imgs};
   return seq_launch(descs, count, T, B, bwd, stream, false, &f);
 }
 // the forward fold launch with projection role workgroups in front (proj_role_dev.h)
 int seq_foldproj_launch(const MfmSeqDesc* descs, int count, int T, int B, const LatentDev& lat, const float* params, ProjRole& pr,
                         hipStream_t stream) {
-  FoldArgs f = {&lat, params, nullptr, &pr, nullptr};
+  FoldArgs f = {&lat, params, nullptr, &pr, nullptr, nullptr};
   return seq_launch(descs, count, T, B, false, stream, false, &f);
 }
 
 }  // namespace mfm
 
 namespace mfm {
+// plain BPTT launch whose one-row workgroups take their transposed weights from this step's images (proj_role_dev.h)
+int seq_bwd_img_launch(const MfmSeqDesc* descs, int count, int T, int B, const float* const* wt_imgs, hipStream_t stream) {
+  FoldArgs f = {nullptr, nullptr, nullptr, nullptr, nullptr, wt_imgs};
+  return seq_launch(descs, count, T, B, true, stream, false, &f);
+}
 // the backward fold launch with weight-gradient role workgroups behind the BPTT workgroups (dw_role_dev.h)
 int seq_folddw_launch(const MfmSeqDesc* descs, int count, int T, int B, const LatentDev& lat, const float* params, float* grads,
-                      DwRole& dr, hipStream_t stream) {
-  FoldArgs f = {&lat, params, grads, nullptr, &dr};
+                      DwRole& dr, hipStream_t stream, const float* const* wt_imgs) {
+  FoldArgs f = {&lat, params, grads, nullptr, &dr, wt_imgs};
   return seq_launch(descs, count, T, B, true, stream, false, &f);
 }
 }  // namespace mfm

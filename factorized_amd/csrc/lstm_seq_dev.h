@@ -15,6 +15,7 @@ struct SeqDev {
   float* h_last;           // bf16 path, optional: fp32 copy of h_{T-1} [B, Hp]
   int h, Hp, hk4, is_dec, block_begin;
   int store_bf16;          // bf16 path: gates / hs / the decoders' dh_ext are __bf16 buffers (MfmSeqDesc::store_bf16)
+  const float* wt_img;     // fp32 one-row BPTT, optional: this step's transposed weights in thread order (proj_role_dev.h), or null
 };
 struct SeqLaunch {
   SeqDev d[MFM_MAX_SEQ];

@@ -449,6 +449,20 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
 
   float wa[NW], wb[NW];
   auto load_wT = [&](int mode) {
+    // this step's transposed weights, already in thread order (written by the role workgroups of the forward launch,
+    // proj_role_dev.h): coalesced loads straight into the registers instead of two staging rounds through LDS
+    if constexpr (KS == 16 && R == 1) {
+      if (d.wt_img && mode != 1) {
+        const float* img = d.wt_img + (tid < NTH ? tid : 0);
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { wa[i] = img[(int64_t)i * NTH]; wb[i] = img[(int64_t)(NW + i) * NTH]; }
+        if (tid >= NTH) {
+#pragma unroll
+          for (int i = 0; i < NW; ++i) { wa[i] = 0.0f; wb[i] = 0.0f; }
+        }
+        return;
+      }
+    }
     const int uac = min(ua, h - 1), ubc = min(ub, h - 1);
     constexpr int PG = (R == 1) ? 2 : 1;          // gates staged per round (the panel holds PG blocks: small_lds_bytes)
 #pragma unroll

@@ -129,6 +129,8 @@ struct MfmPlan {
   int fold_state = 0;               // encoder + latent fold launches (lstm_seq_small.hip): 0 untried, 1 in use, -1 not applicable
   int projfold_state = 0;           // projection role workgroups in the forward fold launch (proj_role_dev.h): 0 / 1 / -1 alike
   int64_t pf_flags = -1;            // their flag words [4][T][16] (u32)
+  int64_t wt_img[7] = {-1, -1, -1, -1, -1, -1, -1};     // transposed-weight images of the 4 encoders + 3 decoders (proj_role_dev.h)
+  unsigned long long wt_call = ~0ull;       // value of `calls` whose forward wrote them
   int dwfold_state = 0;             // weight-gradient role workgroups in the backward fold launch (dw_role_dev.h): 0 / 1 / -1
   int64_t dw_flags = -1, dw_table = -1;     // stamps [4][T][32] + [4][B]; block table [DWR_TABLE_CAP] int4
   std::vector<int> dw_table_host;   // the table as uploaded (4 ints per block)
@@ -548,6 +550,11 @@ static int build(MfmPlan* P) {
   P->dbg_off = carve(cur, 128);     // 64 x u64 debug timestamps
   P->pf_flags = (V == 0) ? carve(cur, (int64_t)4 * P->T * PROJ_ROLE_FLAGS) : -1;
   if (V == 0 && c.B <= DWR_ROWS) {
+    for (int i = 0; i < 7; ++i) {
+      const int hk4 = round_up(cdiv(i < 4 ? P->enc[i].h : P->dec[i - 4].h, 4), 2);
+      const int64_t HKB = round_up(4 * hk4, 16);
+      P->wt_img[i] = carve(cur, 4 * HKB * HKB);
+    }
     P->dw_flags = carve(cur, (int64_t)4 * P->T * DWR_ROWS + 4 * DWR_ROWS);
     P->dw_table = carve(cur, (int64_t)DWR_TABLE_CAP * 4);
   }
@@ -964,6 +971,20 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     PR.zs = zs;
     PR.loss_ptr = zs.ptr[0]; PR.loss_n = (int)zs.n[0];
     PR.bf16 = c.precision ? 1 : 0;
+    // training steps: the BPTT launches of this step take their transposed weights from images the role workgroups write
+    if (train && P->wt_img[0] >= 0 && !(getenv("MFM_WT_IMG") && atoi(getenv("MFM_WT_IMG")) == 0)) {
+      for (int i = 0; i < 7; ++i) {
+        const bool dec = i >= 4;
+        const SeqBuf& sb = dec ? P->dec[i - 4] : P->enc[i];
+        const int pb = dec ? P->dec_p[i - 4] : P->enc_p[i];
+        WtImgItem& I = PR.wt[i];
+        I.w_hh = params + P->off[pb + W_HH];
+        I.w_ih = dec ? params + P->off[pb + W_IH] : nullptr;       // decoders, steps >= 1: W_ih + W_hh (mfm_model.py:85)
+        I.img = W + P->wt_img[i]; I.h = sb.h;
+        I.HKB = round_up(4 * round_up(cdiv(sb.h, 4), 2), 16);
+      }
+      PR.n_wt = 7;
+    }
     PR.zs.ptr[0] = nullptr; PR.zs.n[0] = 0;
     for (int e = 0; e < 4; ++e) {
       const int pb = P->enc_p[e];
@@ -972,7 +993,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     }
     int rc;
     { Timer _t(P, s, K_ENC_FWD); rc = seq_foldproj_launch(q, 4, T, B, L, params, PR, s); }
-    if (rc == MFM_OK) { folded = true; P->projfold_state = 1; P->fold_state = 1; }
+    if (rc == MFM_OK) { folded = true; P->projfold_state = 1; P->fold_state = 1; if (PR.n_wt) P->wt_call = P->calls; }
     else if (rc == MFM_ERR_UNSUPPORTED) {
       P->projfold_state = -1;
       const int rc0 = run_f0();
@@ -1474,7 +1495,10 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
         q[m].dh_ext = W + P->dec_dhs[m]; q[m].ld_dh = P->dec[m].Hp;
         q[m].d_h_init = W + P->dec_dinit[m]; q[m].ld_dinit = P->dec_h[m];
       }
-      RUN(K_DEC_BWD, seq_bf16 ? mfm_lstm_seq_bwd_bf16(q, 3, T, B, s) : mfm_lstm_seq_bwd(q, 3, T, B, s));
+      const bool imgs_on = !seq_bf16 && P->wt_call == P->calls;
+      const float* dimg[3] = {imgs_on ? W + P->wt_img[4] : nullptr, imgs_on ? W + P->wt_img[5] : nullptr, imgs_on ? W + P->wt_img[6] : nullptr};
+      if (imgs_on) RUN(K_DEC_BWD, seq_bwd_img_launch(q, 3, T, B, dimg, s));
+      else RUN(K_DEC_BWD, seq_bf16 ? mfm_lstm_seq_bwd_bf16(q, 3, T, B, s) : mfm_lstm_seq_bwd(q, 3, T, B, s));
     }
     // (B2: the decoder weight gradients only feed Adam; they share the encoders' launch at the end)
   }
@@ -1526,6 +1550,9 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
         q[e].dh_ext = W + P->dh_last[e]; q[e].ld_dh = P->enc_h[e];
       }
       int rc = MFM_ERR_UNSUPPORTED;
+      const bool imgs_on = P->wt_call == P->calls;
+      const float* eimg[4] = {imgs_on ? W + P->wt_img[0] : nullptr, imgs_on ? W + P->wt_img[1] : nullptr,
+                              imgs_on ? W + P->wt_img[2] : nullptr, imgs_on ? W + P->wt_img[3] : nullptr};
       // B <= 32: the idle CUs of this launch run every weight-gradient product of the step (dw_role_dev.h); B5 disappears
       if (!st16 && P->dwfold_state >= 0 && P->dw_table >= 0 && seq_small_folddw_supported(T, B) &&
           !getenv("MFM_DW_ONEPASS_MINROWS") && !getenv("MFM_DW_F32_MINROWS") && !(getenv("MFM_GEMM_TN") && atoi(getenv("MFM_GEMM_TN")) == 0)) {
@@ -1542,13 +1569,13 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
           L2.grd_agent = 1;
           DR.flags = reinterpret_cast<unsigned*>(W + P->dw_flags); DR.epoch = (unsigned)P->calls;
           DR.bf16 = c.precision ? 1 : 0;
-          { Timer _t(P, s, K_ENC_BWD); rc = seq_folddw_launch(q, 4, T, B, L2, params, grads, DR, s); }
+          { Timer _t(P, s, K_ENC_BWD); rc = seq_folddw_launch(q, 4, T, B, L2, params, grads, DR, s, imgs_on ? eimg : nullptr); }
           if (rc == MFM_OK) { P->dwfold_state = 1; return MFM_OK; }      // every gradient of the step is on its way
           if (rc != MFM_ERR_UNSUPPORTED) return rc;
         } else if (brc != MFM_ERR_UNSUPPORTED) return brc;
         P->dwfold_state = -1;
       }
-      { Timer _t(P, s, K_ENC_BWD); rc = seq_fold_launch(q, 4, T, B, true, L, params, grads, s); }
+      { Timer _t(P, s, K_ENC_BWD); rc = seq_fold_launch(q, 4, T, B, true, L, params, grads, s, imgs_on ? eimg : nullptr); }
       if (rc == MFM_OK) enc_bwd_done = true;
       else if (rc != MFM_ERR_UNSUPPORTED) return rc;
     }

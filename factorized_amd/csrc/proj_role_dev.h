@@ -27,6 +27,12 @@ constexpr int PROJ_ROLE_FLAGS = 16;       // flag words per (encoder, time step)
 constexpr int PROJ_ROLE_PW = 4 * 96 + 4;  // floats per wave in the partial-tile buffer ([reg][96] + skew)
 
 struct ProjRoleEnc { const float* w; const float* b_ih; const float* b_hh; int k_off, k, cb_begin, ncb; };
+// Transposed-weight images for the one-row BPTT kernels of the same step (lstm_seq_small.hip, small_bwd_body<.., KS = 16>):
+// img[s][tid], s = which * 4 NG + g * NG + i, holds W[g h + 16 i + (tid & 15)][2 (tid >> 4) + which] (mode 2: W_ih + W_hh,
+// the decoders' steps >= 1), zero outside the valid units.  Written by the role workgroups once their projections are done
+// -- the BPTT launches come later in the stream, so nothing has to be signalled.
+struct WtImgItem { const float* w_hh; const float* w_ih; float* img; int h, HKB; };
+constexpr int PROJ_ROLE_WT = 7;
 struct ProjRole {
   const float* x; int ldx; int x_rows;    // x[T * B, ldx]
   int n_role, groups, kstride;            // groups = n_role / 32
@@ -35,6 +41,7 @@ struct ProjRole {
   int bf16;                               // bf16 plans: x and W_ih rounded to bf16 (RNE) on the way into LDS, fp32 accumulation
   ProjRoleEnc e[4];
   ZeroSpans zs;                           // cleared with plain stores (read by later launches only)
+  WtImgItem wt[PROJ_ROLE_WT]; int n_wt;   // transposed-weight images to produce (training steps)
 };
 
 // LDS row stride of the operand images: k padded to 16, then to an odd number of 16-byte groups (the 16 rows of a fragment
@@ -181,6 +188,25 @@ __device__ __forceinline__ void proj_role_body(const SeqLaunch& L, const ProjRol
       __syncthreads();
       if (tid == 0) __hip_atomic_store(PR.flags + ((int64_t)e * T + t) * PROJ_ROLE_FLAGS + cbl, PR.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       cur ^= 1;
+    }
+  }
+  // transposed-weight images for the BPTT launches of this step
+#pragma unroll 1
+  for (int w = 0; w < PR.n_wt; ++w) {
+    const WtImgItem& I = PR.wt[w];
+    const int NG = I.HKB >> 4, NTH = 8 * I.HKB, h = I.h;
+    const int total = 8 * NG * NTH;
+    for (int idx = r * 1024 + tid; idx < total; idx += PR.n_role * 1024) {
+      const int s = idx / NTH, t2 = idx - s * NTH;
+      const int which = s / (4 * NG), rem = s - which * 4 * NG;
+      const int g = rem / NG, i = rem - g * NG;
+      const int j = 16 * i + (t2 & 15), u = 2 * (t2 >> 4) + which;
+      float v = 0.0f;
+      if (j < h && u < h) {
+        v = I.w_hh[((int64_t)g * h + j) * h + u];
+        if (I.w_ih) v += I.w_ih[((int64_t)g * h + j) * h + u];
+      }
+      I.img[idx] = v;
     }
   }
   // the launch's zero spans, spread over the role workgroups
