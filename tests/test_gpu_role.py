@@ -29,7 +29,7 @@ def _engine(cfgs, precision="fp32"):
 
 
 def _off(monkeypatch, off):
-    for k in ("MFM_PROJ_FOLD", "MFM_DW_FOLD"):
+    for k in ("MFM_PROJ_FOLD", "MFM_DW_FOLD", "MFM_WT_IMG"):
         if off:
             monkeypatch.setenv(k, "0")
         else:
@@ -142,3 +142,29 @@ def test_role_workgroups_bf16_plan(monkeypatch):
     for n in g0:
         den = max(np.linalg.norm(g0[n]), 1e-9)
         assert np.linalg.norm(g1[n] - g0[n]) / den < 2e-2, n
+
+
+@pytest.mark.parametrize("B,T", [(16, 1), (16, 7), (32, 2), (32, 20)])
+def test_one_call_step_equals_forward_plus_backward(B, T, monkeypatch):
+    """grad_step (one enqueue; the role workgroups also clear the gradient buffer and the loss slots) repeated on the same
+    batch: same losses and gradients every time as forward() + backward(), with the role workgroups and without."""
+    cfgs = C.canonical_configs(dropout=False)
+    outs = []
+    for off in (False, True):
+        _off(monkeypatch, off)
+        e, _ = _engine(cfgs)
+        xn, yn = synth.make_batch(cfgs[0]["input_dims"], B, T, seed=7)
+        x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
+        for rep in range(3):                       # repeated: a hand-over that is only usually in time would show up
+            l = e.grad_step(x, y)
+            torch.cuda.synchronize()
+            outs.append((e.loss_dict(l), e.grads.cpu().numpy().copy()))
+        out = e.forward(x, y, train=True, want_xhat=False)
+        e.backward(x, y, stage=0)
+        torch.cuda.synchronize()
+        outs.append((e.loss_dict(out["losses"]), e.grads.cpu().numpy().copy()))
+    ref_l, ref_g = outs[-1]
+    for ld, g in outs[:-1]:
+        for k in ref_l:
+            assert abs(ld[k] - ref_l[k]) <= 1e-5 * max(abs(ref_l[k]), 1e-3), (k, ld[k], ref_l[k])
+        assert grad_err(g, ref_g) < 2e-5
