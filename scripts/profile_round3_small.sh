@@ -29,5 +29,8 @@ MFM_PROJ_FOLD=0 MFM_DW_FOLD=0 python bench.py --steps 400 --warmup 40 $NB > $O/b
 MFM_PROJ_FOLD=0 MFM_DW_FOLD=0 python bench.py --dtype bf16 --steps 400 --warmup 40 $NB > $O/bench_B32_bf16_roles_off.json 2>/dev/null
 python bench.py --steps 400 --warmup 40 --breakdown $NB 2> $O/breakdown_B32.txt > /dev/null
 for B in 8 16 24 32 33 48 64; do python bench.py --batch $B --steps 200 --warmup 20 $NB 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('B=%d  %.4f ms  %.0f samples/s' % ($B, d['ms_per_step'], d['value']))"; done > $O/batch_sweep_small.txt
+MFM_PROJ_FOLD=0 MFM_DW_FOLD=0 MFM_WT_IMG=0 python bench.py --steps 400 --warmup 40 $NB > $O/bench_B32_round2_launches.json 2>/dev/null
+# two ranks on this one device (what the exchange adds to a step when its peers are local: exposed_collective_us)
+MFM_BENCH_ONE_DEVICE=1 MFM_P2P_TIMEOUT_MS=20000 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 200 --warmup 20 $NB > $O/bench_dp2_one_device.json 2>/dev/null
 rm -rf $O/*/*.db $O/*/*.db.tmp $O/*/*.csv
-ls -la $O; cat $O/kernel_stats_h32.txt | head -14; cat $O/roofline_table_h32.txt | head -30; cat $O/bench_B32_400.json $O/bench_B32_roles_off.json | cut -c1-260; cat $O/batch_sweep_small.txt
+ls -la $O; cat $O/kernel_stats_h32.txt | head -14; cat $O/roofline_table_h32.txt | head -30; cat $O/bench_B32_400.json $O/bench_B32_roles_off.json $O/bench_B32_round2_launches.json | cut -c1-260; cat $O/bench_dp2_one_device.json | cut -c1-900; cat $O/traffic_B32.json | head -30; cat $O/batch_sweep_small.txt
