@@ -214,6 +214,7 @@ struct LatOp {
   int pfx_n, pfx_k;             // exclusive prefix sums of N / K over the ops of the same stage (host-filled)
   int chain;                    // modality chain of the layer: 0 l, 1 a, 2 v, 3 y (incl. the classifier)
 };
+struct WtImgItem;
 struct LatentDev {
   // Op table in DEVICE memory (uploaded once by mfm_plan_init_workspace).  It must not live in the
   // kernel-argument segment: the kernels index it with a per-lane op id, and a divergent index
@@ -267,7 +268,10 @@ struct LatentDev {
 int latent_fwd_launch(const LatentDev& L, const float* params, hipStream_t stream);
 // lstm_seq.hip / lstm_seq_small.hip -- the encoder recurrences of MFM_KL_EF with their rows' latent chains folded in
 int seq_fold_launch(const MfmSeqDesc* descs, int count, int T, int B, bool bwd, const LatentDev& lat, const float* params,
-                    float* grads, hipStream_t stream, const float* const* wt_imgs = nullptr);
+                    float* grads, hipStream_t stream, const float* const* wt_imgs = nullptr, const struct WtImgItem* img_items = nullptr,
+                    int n_img_items = 0, bool* img_written = nullptr);
+int seq_fwd_img_launch(const MfmSeqDesc* descs, int count, int T, int B, const struct WtImgItem* items, int n_items, bool* written,
+                       hipStream_t stream);
 int seq_bwd_img_launch(const MfmSeqDesc* descs, int count, int T, int B, const float* const* wt_imgs, hipStream_t stream);
 int latent_bwd_launch(const LatentDev& L, const float* params, float* grads, hipStream_t stream);
 

@@ -375,7 +375,8 @@ bool bf16_seq_pays(int B) {
   return B >= (e ? atoi(e) : 192);
 }
 
-struct FoldArgs { const LatentDev* lat; const float* params; float* grads; ProjRole* pr; DwRole* dr; const float* const* wt_imgs; };
+struct FoldArgs { const LatentDev* lat; const float* params; float* grads; ProjRole* pr; DwRole* dr; const float* const* wt_imgs;
+                  const WtImgItem* img_items; int n_img_items; bool* img_written; };
 
 static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bool bwd, hipStream_t stream, bool bf16 = false,
                       const FoldArgs* fold = nullptr) {
@@ -398,6 +399,7 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     } else descs[count++] = s;
   }
   if (fold && !fold->lat && !fold->pr && !fold->dr) {      // (images only: a plain launch)
+    if (fold->img_written) *fold->img_written = false;
     if (nwide || bf16 || !use_small_path(B) || getenv("MFM_SEQ_KS") || getenv("MFM_SEQ_ROWS")) fold = nullptr;
   } else if (fold && (nwide || bf16 || !use_small_path(B))) return MFM_ERR_UNSUPPORTED;
   if (nwide) {
@@ -444,13 +446,27 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     const size_t need = (bwd ? 2 * 4 * HK * 16 : 2 * HK * 16) * sizeof(float);
     if (need > lds_bytes) lds_bytes = need;
   }
+  if (fold && fold->img_written) *fold->img_written = false;
+  if (fold && fold->img_items && !bwd && !bf16 && !sorted && !nwide && fold->n_img_items <= MFM_WT_MAX && use_small_path(B)) {
+    L.n_img = fold->n_img_items;
+    for (int i = 0; i < L.n_img; ++i) L.img[i] = fold->img_items[i];
+  }
+  if (fold && !fold->lat && fold->img_items) {      // forward launch with image-writer blocks behind the rows
+    const int rc = seq_small_launch(L, false, stream);
+    if (rc == MFM_OK && fold->img_written) *fold->img_written = L.n_img > 0;
+    return rc;
+  }
   if (fold && !fold->lat) {          // images only: the plain one-row launch (one-row tiles: checked by the caller's conditions)
     if ((long)L.count * L.B >= 6L * device_cus()) for (int i = 0; i < L.count; ++i) L.d[i].wt_img = nullptr;
     return seq_small_launch(L, bwd, stream);
   }
   if (fold && fold->pr) return seq_small_foldproj_launch(L, *fold->lat, *fold->pr, fold->params, stream);
   if (fold && fold->dr) return seq_small_folddw_launch(L, *fold->lat, *fold->dr, fold->params, fold->grads, stream);
-  if (fold) return seq_small_fold_launch(L, bwd, *fold->lat, fold->params, fold->grads, stream);
+  if (fold) {
+    const int rc = seq_small_fold_launch(L, bwd, *fold->lat, fold->params, fold->grads, stream);
+    if (rc == MFM_OK && fold->img_written) *fold->img_written = !bwd && L.n_img > 0;
+    return rc;
+  }
   if (bf16) return seq_bf16_launch(L, bwd, stream);      // bf16 MFMA operands: one kernel family for every batch size
   if (use_small_path(B)) return seq_small_launch(L, bwd, stream);
   // encoders and decoders run different kernels: a mixed call becomes two launches
@@ -481,29 +497,37 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
 
 // encoder recurrences + their rows' latent chains in one launch (lstm_seq_small.hip); MFM_ERR_UNSUPPORTED: not applicable
 int seq_fold_launch(const MfmSeqDesc* descs, int count, int T, int B, bool bwd, const LatentDev& lat, const float* params,
-                    float* grads, hipStream_t stream, const float* const* wt_imgs) {
-  FoldArgs f = {&lat, params, grads, nullptr, nullptr, wt_imgs};
+                    float* grads, hipStream_t stream, const float* const* wt_imgs, const WtImgItem* img_items, int n_img_items,
+                    bool* img_written) {
+  FoldArgs f = {&lat, params, grads, nullptr, nullptr, wt_imgs, img_items, n_img_items, img_written};
   return seq_launch(descs, count, T, B, bwd, stream, false, &f);
 }
 // the forward fold launch with projection role workgroups in front (proj_role_dev.h)
 int seq_foldproj_launch(const MfmSeqDesc* descs, int count, int T, int B, const LatentDev& lat, const float* params, ProjRole& pr,
                         hipStream_t stream) {
-  FoldArgs f = {&lat, params, nullptr, &pr, nullptr, nullptr};
+  FoldArgs f = {&lat, params, nullptr, &pr, nullptr, nullptr, nullptr, 0, nullptr};
   return seq_launch(descs, count, T, B, false, stream, false, &f);
 }
 
 }  // namespace mfm
 
 namespace mfm {
+// forward launch with a few blocks behind the recurrence rows that write this step's transposed-weight images (lstm_seq_dev.h);
+// *written: whether they did (one-row tiles and idle CUs left)
+int seq_fwd_img_launch(const MfmSeqDesc* descs, int count, int T, int B, const WtImgItem* items, int n_items, bool* written,
+                       hipStream_t stream) {
+  FoldArgs f = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, items, n_items, written};
+  return seq_launch(descs, count, T, B, false, stream, false, &f);
+}
 // plain BPTT launch whose one-row workgroups take their transposed weights from this step's images (proj_role_dev.h)
 int seq_bwd_img_launch(const MfmSeqDesc* descs, int count, int T, int B, const float* const* wt_imgs, hipStream_t stream) {
-  FoldArgs f = {nullptr, nullptr, nullptr, nullptr, nullptr, wt_imgs};
+  FoldArgs f = {nullptr, nullptr, nullptr, nullptr, nullptr, wt_imgs, nullptr, 0, nullptr};
   return seq_launch(descs, count, T, B, true, stream, false, &f);
 }
 // the backward fold launch with weight-gradient role workgroups behind the BPTT workgroups (dw_role_dev.h)
 int seq_folddw_launch(const MfmSeqDesc* descs, int count, int T, int B, const LatentDev& lat, const float* params, float* grads,
                       DwRole& dr, hipStream_t stream, const float* const* wt_imgs) {
-  FoldArgs f = {&lat, params, grads, nullptr, &dr, wt_imgs};
+  FoldArgs f = {&lat, params, grads, nullptr, &dr, wt_imgs, nullptr, 0, nullptr};
   return seq_launch(descs, count, T, B, true, stream, false, &f);
 }
 }  // namespace mfm

@@ -17,10 +17,43 @@ struct SeqDev {
   int store_bf16;          // bf16 path: gates / hs / the decoders' dh_ext are __bf16 buffers (MfmSeqDesc::store_bf16)
   const float* wt_img;     // fp32 one-row BPTT, optional: this step's transposed weights in thread order (proj_role_dev.h), or null
 };
+// Transposed-weight images for the one-row BPTT kernels of the same step (lstm_seq_small.hip, small_bwd_body<.., KS = 16>):
+// img[s][tid], s = which * 4 NG + g * NG + i, holds W[g h + 16 i + (tid & 15)][2 (tid >> 4) + which] (w_ih set: W_ih + W_hh,
+// the decoders' steps >= 1), zero outside the valid units.  Written by workgroups that have nothing else to do in a FORWARD
+// launch of the step -- the projection role workgroups once their items are done (proj_role_dev.h), or a few blocks appended to
+// the recurrence launch -- and read by the BPTT launches, which come later in the stream: nothing has to be signalled.
+struct WtImgItem { const float* w_hh; const float* w_ih; float* img; int h, HKB; };
+constexpr int MFM_WT_MAX = MFM_MAX_SEQ + 3;
 struct SeqLaunch {
   SeqDev d[MFM_MAX_SEQ];
   int count, T, B;
+  // forward launches, optional: blocks [img_begin, img_begin + n_img_blocks) write the images of `img` and leave
+  int n_img, img_begin, n_img_blocks;
+  WtImgItem img[MFM_WT_MAX];
 };
+
+// writer r of nr (any block size)
+__device__ __forceinline__ void wt_img_write(const WtImgItem* items, const int n, const int r, const int nr) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+#pragma unroll 1
+  for (int w = 0; w < n; ++w) {
+    const WtImgItem& I = items[w];
+    const int NG = I.HKB >> 4, NTH = 8 * I.HKB, h = I.h;
+    const int total = 8 * NG * NTH;
+    for (int idx = r * nt + tid; idx < total; idx += nr * nt) {
+      const int s = idx / NTH, t2 = idx - s * NTH;
+      const int which = s / (4 * NG), rem = s - which * 4 * NG;
+      const int g = rem / NG, i = rem - g * NG;
+      const int j = 16 * i + (t2 & 15), u = 2 * (t2 >> 4) + which;
+      float v = 0.0f;
+      if (j < h && u < h) {
+        v = I.w_hh[((int64_t)g * h + j) * h + u];
+        if (I.w_ih) v += I.w_ih[((int64_t)g * h + j) * h + u];
+      }
+      I.img[idx] = v;
+    }
+  }
+}
 
 int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream);
 struct LatentDev;

@@ -765,6 +765,9 @@ __global__ __launch_bounds__(KS == 16 ? 1024 : 512) void lstm_seq_small_kernel4(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int di = 0;
   const int bid = blockIdx.x;
+  if constexpr (!BWD) {      // blocks behind the recurrence rows: this step's transposed-weight images (lstm_seq_dev.h)
+    if (L.n_img > 0 && bid >= L.img_begin) { wt_img_write(L.img, L.n_img, bid - L.img_begin, L.n_img_blocks); return; }
+  }
 #pragma unroll 1
   for (int i = 1; i < L.count; ++i)
     if (bid >= L.d[i].block_begin) di = i;
@@ -843,6 +846,9 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_fold_kernel(const SeqLaun
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int di = 0;
   const int bid = blockIdx.x;
+  if constexpr (!BWD) {      // blocks behind the recurrence rows: this step's transposed-weight images (lstm_seq_dev.h)
+    if (L.n_img > 0 && bid >= L.img_begin) { wt_img_write(L.img, L.n_img, bid - L.img_begin, L.n_img_blocks); return; }
+  }
 #pragma unroll 1
   for (int i = 1; i < L.count; ++i)
     if (bid >= L.d[i].block_begin) di = i;
@@ -958,6 +964,10 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
     const size_t lds_bytes = small_lds_bytes(L, bwd, R);
     hipError_t err = hipSuccess;
     bool done = false;
+    // forward, one-row tiles, idle CUs left: a few more blocks write this step's transposed-weight images
+    const int rows_total = total;
+    L.n_img_blocks = 0;
+    if (!bwd && R == 1 && L.n_img > 0 && cus - total >= 8) { L.img_begin = total; L.n_img_blocks = std::min(cus - total, 64); total += L.n_img_blocks; }
     // backward, one-row tiles: MFM_SEQ_KS=8 selects 8 k-slices per unit pair (half the threads, twice the FMAs each).
     // Opt-in: measured equal (encoders 30.5 vs 29.8 us) or slower (decoders 37.9 vs 32.6 us, 24 spilled registers) at B=32
     // (profiles/r02_seq_ks8.txt) -- the step is a latency chain (LDS hand-over, barrier, reduction), not issue-bound enough
@@ -972,10 +982,13 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
     if (done) {
       if (err != hipSuccess) return hip_fail(err, "hipFuncSetAttribute(lstm_seq_small_kernel4)");
       MFM_LAUNCH_CHECK(bwd ? "lstm_seq_small_bwd_kernel4" : "lstm_seq_small_fwd_kernel4");
+      if (L.n_img_blocks == 0) L.n_img = 0;        // (tells the caller that no images were written)
       return MFM_OK;
     }
+    (void)rows_total;
     R = 4;    // no specialised kernel for this size tuple: generic 16-variant kernel, 4-row tiles
   }
+  L.n_img = 0; L.n_img_blocks = 0;
   const int tiles = cdiv(L.B, 4);
   int total = 0;
   for (int i = 0; i < L.count; ++i) { L.d[i].block_begin = total; total += tiles; }
@@ -1090,6 +1103,9 @@ int seq_small_fold_launch(SeqLaunch& L, bool bwd, const LatentDev& LD, const flo
     L.d[i].block_begin = total; total += L.B;
   }
   if (max_threads < 1024) max_threads = 1024;       // the chain's work items are tabulated for up to 1024 threads
+  L.n_img_blocks = 0;
+  if (!bwd && L.n_img > 0 && device_cus() - total >= 8) { L.img_begin = total; L.n_img_blocks = std::min(device_cus() - total, 64); total += L.n_img_blocks; }
+  else L.n_img = 0;
   size_t lds_bytes = small_lds_bytes(L, bwd, 1);
   const size_t lat = ((size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + (bwd ? 2 : 1) * (size_t)LD.rec_size) * sizeof(float);
   if (lat > lds_bytes) lds_bytes = lat;

@@ -129,7 +129,7 @@ struct MfmPlan {
   int fold_state = 0;               // encoder + latent fold launches (lstm_seq_small.hip): 0 untried, 1 in use, -1 not applicable
   int projfold_state = 0;           // projection role workgroups in the forward fold launch (proj_role_dev.h): 0 / 1 / -1 alike
   int64_t pf_flags = -1;            // their flag words [4][T][16] (u32)
-  int64_t wt_img[7] = {-1, -1, -1, -1, -1, -1, -1};     // transposed-weight images of the 4 encoders + 3 decoders (proj_role_dev.h)
+  int64_t wt_img[mfm::MFM_WT_MAX] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};     // transposed-weight images: encoders in plan order, then the 3 decoders (lstm_seq_dev.h)
   unsigned long long wt_call = ~0ull;       // value of `calls` whose forward wrote them
   int dwfold_state = 0;             // weight-gradient role workgroups in the backward fold launch (dw_role_dev.h): 0 / 1 / -1
   int64_t dw_flags = -1, dw_table = -1;     // stamps [4][T][32] + [4][B]; block table [DWR_TABLE_CAP] int4
@@ -549,12 +549,15 @@ static int build(MfmPlan* P) {
   P->lat_ops_off = carve(cur, (int64_t)(sizeof(P->lat_ops) / (sizeof(float))));
   P->dbg_off = carve(cur, 128);     // 64 x u64 debug timestamps
   P->pf_flags = (V == 0) ? carve(cur, (int64_t)4 * P->T * PROJ_ROLE_FLAGS) : -1;
-  if (V == 0 && c.B <= DWR_ROWS) {
-    for (int i = 0; i < 7; ++i) {
-      const int hk4 = round_up(cdiv(i < 4 ? P->enc[i].h : P->dec[i - 4].h, 4), 2);
-      const int64_t HKB = round_up(4 * hk4, 16);
+  if (c.B <= 80 && !P->seq_bf16) {        // (one-row BPTT tiles and idle CUs next to the forward rows: small batches)
+    for (int i = 0; i < P->n_enc + 3; ++i) {
+      const int hh = i < P->n_enc ? P->enc[i].h : P->dec[i - P->n_enc].h;
+      if (hh > MFM_SEQ_MAX_RESIDENT_H) continue;
+      const int64_t HKB = round_up(4 * round_up(cdiv(hh, 4), 2), 16);
       P->wt_img[i] = carve(cur, 4 * HKB * HKB);
     }
+  }
+  if (V == 0 && c.B <= DWR_ROWS) {
     P->dw_flags = carve(cur, (int64_t)4 * P->T * DWR_ROWS + 4 * DWR_ROWS);
     P->dw_table = carve(cur, (int64_t)DWR_TABLE_CAP * 4);
   }
@@ -940,6 +943,27 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     return MFM_OK;
   };
   if (!proj_in_fold) { const int rc0 = run_f0(); if (rc0 != MFM_OK) return rc0; }
+  // training steps: this step's transposed-weight images for the one-row BPTT kernels (lstm_seq_dev.h), written by idle
+  // workgroups of the encoder recurrence launch
+  WtImgItem wt_items[MFM_WT_MAX];
+  int n_wt_items = 0;
+  if (train && !seq_bf16 && !(getenv("MFM_WT_IMG") && atoi(getenv("MFM_WT_IMG")) == 0)) {
+    bool all = true;
+    for (int i = 0; i < P->n_enc + 3; ++i) all = all && P->wt_img[i] >= 0;
+    if (all) {
+      n_wt_items = P->n_enc + 3;
+      for (int i = 0; i < n_wt_items; ++i) {
+        const bool dec = i >= P->n_enc;
+        const SeqBuf& sb = dec ? P->dec[i - P->n_enc] : P->enc[i];
+        const int pb = dec ? P->dec_p[i - P->n_enc] : P->enc_p[i];
+        WtImgItem& I = wt_items[i];
+        I.w_hh = params + P->off[pb + W_HH];
+        I.w_ih = dec ? params + P->off[pb + W_IH] : nullptr;       // decoders, steps >= 1: W_ih + W_hh (mfm_model.py:85)
+        I.img = W + P->wt_img[i]; I.h = sb.h;
+        I.HKB = round_up(4 * round_up(cdiv(sb.h, 4), 2), 16);
+      }
+    }
+  }
   // the latent stack's launch descriptor (used by F2, or by the fold launch of F1)
   LatentDev L = P->lat;
   {
@@ -972,19 +996,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     PR.loss_ptr = zs.ptr[0]; PR.loss_n = (int)zs.n[0];
     PR.bf16 = c.precision ? 1 : 0;
     // training steps: the BPTT launches of this step take their transposed weights from images the role workgroups write
-    if (train && P->wt_img[0] >= 0 && !(getenv("MFM_WT_IMG") && atoi(getenv("MFM_WT_IMG")) == 0)) {
-      for (int i = 0; i < 7; ++i) {
-        const bool dec = i >= 4;
-        const SeqBuf& sb = dec ? P->dec[i - 4] : P->enc[i];
-        const int pb = dec ? P->dec_p[i - 4] : P->enc_p[i];
-        WtImgItem& I = PR.wt[i];
-        I.w_hh = params + P->off[pb + W_HH];
-        I.w_ih = dec ? params + P->off[pb + W_IH] : nullptr;       // decoders, steps >= 1: W_ih + W_hh (mfm_model.py:85)
-        I.img = W + P->wt_img[i]; I.h = sb.h;
-        I.HKB = round_up(4 * round_up(cdiv(sb.h, 4), 2), 16);
-      }
-      PR.n_wt = 7;
-    }
+    if (n_wt_items == 7) { for (int i = 0; i < 7; ++i) PR.wt[i] = wt_items[i]; PR.n_wt = 7; }
     PR.zs.ptr[0] = nullptr; PR.zs.n[0] = 0;
     for (int e = 0; e < 4; ++e) {
       const int pb = P->enc_p[e];
@@ -1004,9 +1016,10 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     MfmSeqDesc q[4];
     for (int e = 0; e < 4; ++e) q[e] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
     int rc;
-    if (P->fold_state == 1) { Timer _t(P, s, K_ENC_FWD); rc = seq_fold_launch(q, 4, T, B, false, L, params, nullptr, s); }
-    else rc = seq_fold_launch(q, 4, T, B, false, L, params, nullptr, s);
-    if (rc == MFM_OK) { folded = true; P->fold_state = 1; }
+    bool wrote = false;
+    if (P->fold_state == 1) { Timer _t(P, s, K_ENC_FWD); rc = seq_fold_launch(q, 4, T, B, false, L, params, nullptr, s, nullptr, n_wt_items ? wt_items : nullptr, n_wt_items, &wrote); }
+    else rc = seq_fold_launch(q, 4, T, B, false, L, params, nullptr, s, nullptr, n_wt_items ? wt_items : nullptr, n_wt_items, &wrote);
+    if (rc == MFM_OK) { folded = true; P->fold_state = 1; if (wrote) P->wt_call = P->calls; }
     else if (rc == MFM_ERR_UNSUPPORTED) P->fold_state = (P->fold_state == 0) ? -1 : P->fold_state;
     else return rc;
   }
@@ -1017,7 +1030,11 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       q[e] = seq_desc(P, P->enc[e0 + e], P->enc_p[e0 + e], params, W, false);
       if (st16) q[e].h_last = W + P->h_last[e0 + e];
     }
-    RUN(K_ENC_FWD, seq_bf16 ? mfm_lstm_seq_fwd_bf16(q, n, T, B, s) : mfm_lstm_seq_fwd(q, n, T, B, s));
+    if (!seq_bf16 && n_wt_items && e0 == 0 && n == P->n_enc) {
+      bool wrote = false;
+      RUN(K_ENC_FWD, seq_fwd_img_launch(q, n, T, B, wt_items, n_wt_items, &wrote, s));
+      if (wrote) P->wt_call = P->calls;
+    } else RUN(K_ENC_FWD, seq_bf16 ? mfm_lstm_seq_fwd_bf16(q, n, T, B, s) : mfm_lstm_seq_fwd(q, n, T, B, s));
   }
   if (V != 0) {
     int rc = mfn_forward(P, params, train, seed, W, s);
@@ -1496,7 +1513,8 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
         q[m].d_h_init = W + P->dec_dinit[m]; q[m].ld_dinit = P->dec_h[m];
       }
       const bool imgs_on = !seq_bf16 && P->wt_call == P->calls;
-      const float* dimg[3] = {imgs_on ? W + P->wt_img[4] : nullptr, imgs_on ? W + P->wt_img[5] : nullptr, imgs_on ? W + P->wt_img[6] : nullptr};
+      const int ne = P->n_enc;
+      const float* dimg[3] = {imgs_on ? W + P->wt_img[ne] : nullptr, imgs_on ? W + P->wt_img[ne + 1] : nullptr, imgs_on ? W + P->wt_img[ne + 2] : nullptr};
       if (imgs_on) RUN(K_DEC_BWD, seq_bwd_img_launch(q, 3, T, B, dimg, s));
       else RUN(K_DEC_BWD, seq_bf16 ? mfm_lstm_seq_bwd_bf16(q, 3, T, B, s) : mfm_lstm_seq_bwd(q, 3, T, B, s));
     }
@@ -1615,7 +1633,11 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
         q[i].dh_ext = W + P->dh_last[e]; q[i].ld_dh = P->enc_h[e];
       }
     }
-    RUN(K_ENC_BWD, seq_bf16 ? mfm_lstm_seq_bwd_bf16(q, n, T, B, s) : mfm_lstm_seq_bwd(q, n, T, B, s));
+    if (!seq_bf16 && P->wt_call == P->calls && e0 == 0 && n == P->n_enc) {
+      const float* eimg[MFM_MAX_SEQ];
+      for (int i = 0; i < n; ++i) eimg[i] = W + P->wt_img[i];
+      RUN(K_ENC_BWD, seq_bwd_img_launch(q, n, T, B, eimg, s));
+    } else RUN(K_ENC_BWD, seq_bf16 ? mfm_lstm_seq_bwd_bf16(q, n, T, B, s) : mfm_lstm_seq_bwd(q, n, T, B, s));
   }
   // B5: all weight gradients on the grouped TN GEMM.  Opt-in (MFM_DW_ONEPASS_MINROWS=<T*B from which to use it>): the
   // LSTMs' sums over the rows on the one-pass kernel (dw_onepass.hip) -- parity-tested, measured slower at B=2048

@@ -27,11 +27,6 @@ constexpr int PROJ_ROLE_FLAGS = 16;       // flag words per (encoder, time step)
 constexpr int PROJ_ROLE_PW = 4 * 96 + 4;  // floats per wave in the partial-tile buffer ([reg][96] + skew)
 
 struct ProjRoleEnc { const float* w; const float* b_ih; const float* b_hh; int k_off, k, cb_begin, ncb; };
-// Transposed-weight images for the one-row BPTT kernels of the same step (lstm_seq_small.hip, small_bwd_body<.., KS = 16>):
-// img[s][tid], s = which * 4 NG + g * NG + i, holds W[g h + 16 i + (tid & 15)][2 (tid >> 4) + which] (mode 2: W_ih + W_hh,
-// the decoders' steps >= 1), zero outside the valid units.  Written by the role workgroups once their projections are done
-// -- the BPTT launches come later in the stream, so nothing has to be signalled.
-struct WtImgItem { const float* w_hh; const float* w_ih; float* img; int h, HKB; };
 constexpr int PROJ_ROLE_WT = 7;
 struct ProjRole {
   const float* x; int ldx; int x_rows;    // x[T * B, ldx]
@@ -190,25 +185,8 @@ __device__ __forceinline__ void proj_role_body(const SeqLaunch& L, const ProjRol
       cur ^= 1;
     }
   }
-  // transposed-weight images for the BPTT launches of this step
-#pragma unroll 1
-  for (int w = 0; w < PR.n_wt; ++w) {
-    const WtImgItem& I = PR.wt[w];
-    const int NG = I.HKB >> 4, NTH = 8 * I.HKB, h = I.h;
-    const int total = 8 * NG * NTH;
-    for (int idx = r * 1024 + tid; idx < total; idx += PR.n_role * 1024) {
-      const int s = idx / NTH, t2 = idx - s * NTH;
-      const int which = s / (4 * NG), rem = s - which * 4 * NG;
-      const int g = rem / NG, i = rem - g * NG;
-      const int j = 16 * i + (t2 & 15), u = 2 * (t2 >> 4) + which;
-      float v = 0.0f;
-      if (j < h && u < h) {
-        v = I.w_hh[((int64_t)g * h + j) * h + u];
-        if (I.w_ih) v += I.w_ih[((int64_t)g * h + j) * h + u];
-      }
-      I.img[idx] = v;
-    }
-  }
+  // transposed-weight images for the BPTT launches of this step (lstm_seq_dev.h)
+  wt_img_write(PR.wt, PR.n_wt, r, PR.n_role);
   // the launch's zero spans, spread over the role workgroups
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
