@@ -967,7 +967,12 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
     // forward, one-row tiles, idle CUs left: a few more blocks write this step's transposed-weight images
     const int rows_total = total;
     L.n_img_blocks = 0;
-    if (!bwd && R == 1 && L.n_img > 0 && cus - total >= 8) { L.img_begin = total; L.n_img_blocks = std::min(cus - total, 64); total += L.n_img_blocks; }
+    // (no idle CU left: the writers still pay -- they run in the launch's last round, ~2 us, against ~9 us of staging saved;
+    //  MFM_WT_IMG_FULL=0: only with idle CUs)
+    static const bool img_full = !(getenv("MFM_WT_IMG_FULL") && atoi(getenv("MFM_WT_IMG_FULL")) == 0);
+    if (!bwd && R == 1 && L.n_img > 0 && (cus - total >= 8 || img_full)) {
+      L.img_begin = total; L.n_img_blocks = cus - total >= 8 ? std::min(cus - total, 64) : 32; total += L.n_img_blocks;
+    }
     // backward, one-row tiles: MFM_SEQ_KS=8 selects 8 k-slices per unit pair (half the threads, twice the FMAs each).
     // Opt-in: measured equal (encoders 30.5 vs 29.8 us) or slower (decoders 37.9 vs 32.6 us, 24 spilled registers) at B=32
     // (profiles/r02_seq_ks8.txt) -- the step is a latency chain (LDS hand-over, barrier, reduction), not issue-bound enough
@@ -1104,7 +1109,10 @@ int seq_small_fold_launch(SeqLaunch& L, bool bwd, const LatentDev& LD, const flo
   }
   if (max_threads < 1024) max_threads = 1024;       // the chain's work items are tabulated for up to 1024 threads
   L.n_img_blocks = 0;
-  if (!bwd && L.n_img > 0 && device_cus() - total >= 8) { L.img_begin = total; L.n_img_blocks = std::min(device_cus() - total, 64); total += L.n_img_blocks; }
+  static const bool img_full = !(getenv("MFM_WT_IMG_FULL") && atoi(getenv("MFM_WT_IMG_FULL")) == 0);
+  if (!bwd && L.n_img > 0 && (device_cus() - total >= 8 || img_full)) {
+    L.img_begin = total; L.n_img_blocks = device_cus() - total >= 8 ? std::min(device_cus() - total, 64) : 32; total += L.n_img_blocks;
+  }
   else L.n_img = 0;
   size_t lds_bytes = small_lds_bytes(L, bwd, 1);
   const size_t lat = ((size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + (bwd ? 2 : 1) * (size_t)LD.rec_size) * sizeof(float);

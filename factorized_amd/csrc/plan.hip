@@ -549,7 +549,7 @@ static int build(MfmPlan* P) {
   P->lat_ops_off = carve(cur, (int64_t)(sizeof(P->lat_ops) / (sizeof(float))));
   P->dbg_off = carve(cur, 128);     // 64 x u64 debug timestamps
   P->pf_flags = (V == 0) ? carve(cur, (int64_t)4 * P->T * PROJ_ROLE_FLAGS) : -1;
-  if (c.B <= 80 && !P->seq_bf16) {        // (one-row BPTT tiles and idle CUs next to the forward rows: small batches)
+  if ((long)(P->n_enc > 3 ? P->n_enc : 3) * c.B < 6L * device_cus() && !P->seq_bf16) {        // (one-row BPTT tiles)
     for (int i = 0; i < P->n_enc + 3; ++i) {
       const int hh = i < P->n_enc ? P->enc[i].h : P->dec[i - P->n_enc].h;
       if (hh > MFM_SEQ_MAX_RESIDENT_H) continue;
