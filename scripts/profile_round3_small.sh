@@ -15,8 +15,12 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/$d -o pmc_fetch -- python $R/bench.
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/$d -o pmc_write -- python $R/bench.py --steps 30 --warmup 5 $NB > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc $PMC_SQ -d $O/$d -o pmc_sq -- python $R/bench.py --steps 30 --warmup 5 $NB > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/b32 -o ktrace -- python $R/bench.py --dtype bf16 --steps 200 --warmup 20 $NB > $O/bench_under_rocprof_b32.json 2>/dev/null
+for m in kl mmd; do
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/m_$m -o ktrace -- python $R/bench.py --model $m --steps 200 --warmup 20 $NB > $O/bench_under_rocprof_m_$m.json 2>/dev/null
+done
 cd $R
-for d in h32 b32; do
+for m in kl mmd; do python bench.py --model $m --steps 400 --warmup 40 $NB > $O/bench_B32_$m.json 2>/dev/null; done
+for d in h32 b32 m_kl m_mmd; do
   f=$(ls $O/$d/ktrace*.db 2>/dev/null | head -1)
   [ -n "$f" ] && python scripts/rocprof_summary.py $f > $O/kernel_stats_$d.txt
 done
