@@ -134,6 +134,8 @@ struct MfmPlan {
   int dwfold_state = 0;             // weight-gradient role workgroups in the backward fold launch (dw_role_dev.h): 0 / 1 / -1
   int64_t dw_flags = -1, dw_table = -1;     // stamps [4][T][32] + [4][B]; block table [DWR_TABLE_CAP] int4
   std::vector<int> dw_table_host;   // the table as uploaded (4 ints per block)
+  unsigned dw_epoch = 0;            // stamp value of the next backward launch with role workgroups (its own counter: two backward
+                                    // calls behind one forward must not see each other's stamps)
   int dw_table_key = -1;            // what it was built for (stage / upstream-gradient form)
   const float* dw_table_ws = nullptr;       // the workspace that holds it
   // ---- bf16 plans (decided once, when the plan is built)
@@ -1585,7 +1587,8 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
         if (brc == MFM_OK) {
           LatentDev L2 = L;
           L2.grd_agent = 1;
-          DR.flags = reinterpret_cast<unsigned*>(W + P->dw_flags); DR.epoch = (unsigned)P->calls;
+          DR.flags = reinterpret_cast<unsigned*>(W + P->dw_flags); DR.epoch = ++P->dw_epoch;
+          if (DR.epoch == 0) DR.epoch = ++P->dw_epoch;           // (0 is what a fresh workspace holds)
           DR.bf16 = c.precision ? 1 : 0;
           { Timer _t(P, s, K_ENC_BWD); rc = seq_folddw_launch(q, 4, T, B, L2, params, grads, DR, s, imgs_on ? eimg : nullptr); }
           if (rc == MFM_OK) { P->dwfold_state = 1; return MFM_OK; }      // every gradient of the step is on its way
