@@ -58,6 +58,10 @@ def main():
     # MFM_BENCH_ONE_DEVICE=1 (testing only): every rank uses cuda:0 and the collectives run on gloo, so the
     # multi-process path can be exercised on a 1-GPU box; the number it prints is not a scaling result.
     one_dev = os.environ.get("MFM_BENCH_ONE_DEVICE") == "1"
+    if one_dev and world > 1:
+        # several ranks drive ONE GPU at the same time: the in-launch hand-overs of the role workgroups need the device to
+        # themselves (lstm_seq_small.hip, shared_device()); the separate launches are used instead
+        os.environ["MFM_SHARED_DEVICE"] = "1"
     if one_dev:
         local_rank = 0
     torch.cuda.set_device(local_rank)

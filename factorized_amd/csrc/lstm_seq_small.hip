@@ -144,7 +144,8 @@ __device__ __forceinline__ void stage_gates2(const SeqDev& d, int mode, int g, f
 // request its values, and read them with agent-scope loads.
 template <int KQ, int R, bool FLG = false>
 __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds,
-                                               const unsigned* flg = nullptr, const unsigned epoch = 0, const int ncb = 0) {
+                                               const unsigned* flg = nullptr, const unsigned epoch = 0, const int ncb = 0,
+                                               float* poison = nullptr) {
   constexpr int HK = 4 * KQ;                    // padded hidden extent of the matvec
   constexpr int HKB = (HK + 15) / 16 * 16;      // == Hp
   constexpr int NTH = 8 * HKB;                  // threads this LSTM uses (blockDim may be larger)
@@ -251,8 +252,8 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
     if constexpr (FLG) {
       if (fetch_wave) {
         const int t1 = (T > 1) ? 1 : 0;
-        proj_flags_wait(flg, proj_flags_load(flg, ncb), epoch, ncb);
-        proj_flags_wait(flg + t1 * PROJ_ROLE_FLAGS, proj_flags_load(flg + t1 * PROJ_ROLE_FLAGS, ncb), epoch, ncb);
+        proj_flags_wait(flg, proj_flags_load(flg, ncb), epoch, ncb, poison);
+        proj_flags_wait(flg + t1 * PROJ_ROLE_FLAGS, proj_flags_load(flg + t1 * PROJ_ROLE_FLAGS, ncb), epoch, ncb, poison);
         fv = proj_flags_load(flg + min(2, T - 1) * PROJ_ROLE_FLAGS, ncb);
       }
     }
@@ -341,7 +342,7 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
       const int64_t off = (int64_t)min(t + 2, T - 1) * gstep;
       if constexpr (FLG) {
         if (fetch_wave) {
-          proj_flags_wait(flg + min(t + 2, T - 1) * PROJ_ROLE_FLAGS, fv, epoch, ncb);
+          proj_flags_wait(flg + min(t + 2, T - 1) * PROJ_ROLE_FLAGS, fv, epoch, ncb, poison);
 #pragma unroll
           for (int i = 0; i < NXL; ++i) xn[i] = ld_agent((const float*)xp[i] + off);
           fv = proj_flags_load(flg + min(t + 3, T - 1) * PROJ_ROLE_FLAGS, ncb);
@@ -888,7 +889,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_foldproj_kernel(const Seq
   const unsigned* flg = PR.flags + (int64_t)di * L.T * PROJ_ROLE_FLAGS;
   const int ncb = PR.e[di].ncb;
 #define MFM_ONE(IDX, KK) \
-  if (KK > 0 && di == IDX) small_fwd_body<(KK > 0 ? KK : 2), 1, true>(d, L.T, L.B, tile, lds, flg, PR.epoch, ncb);
+  if (KK > 0 && di == IDX) small_fwd_body<(KK > 0 ? KK : 2), 1, true>(d, L.T, L.B, tile, lds, flg, PR.epoch, ncb, LD.losses);
   MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3)
 #undef MFM_ONE
   // the loss slots are cleared by the producers of t = 0: all of them have passed before this row's chain adds to them
@@ -896,7 +897,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_foldproj_kernel(const Seq
 #pragma unroll 1
     for (int e = 0; e < 4; ++e) {
       const unsigned* f0 = PR.flags + (int64_t)e * L.T * PROJ_ROLE_FLAGS;
-      proj_flags_wait(f0, proj_flags_load(f0, PR.e[e].ncb), PR.epoch, PR.e[e].ncb);
+      proj_flags_wait(f0, proj_flags_load(f0, PR.e[e].ncb), PR.epoch, PR.e[e].ncb, LD.losses);
     }
   }
   __syncthreads();        // every store of the last time step has been acknowledged: h_T of this row is readable
@@ -1014,7 +1015,13 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
 
 
 // MFM_OK: launched.  MFM_ERR_UNSUPPORTED: not a case the fold kernels take (the caller issues the separate launches).
+// MFM_SHARED_DEVICE=1: other processes / streams run kernels on this GPU at the same time.  The in-launch hand-overs count on
+// this launch becoming resident workgroup by workgroup in block order; launches of two queues that together exceed the CUs
+// can block each other's producers until the waits give up (and poison their results) -- so they are switched off.
+static bool shared_device() { const char* e = getenv("MFM_SHARED_DEVICE"); return e && atoi(e) != 0; }
+
 bool seq_small_folddw_supported(int T, int B) {
+  if (shared_device()) return false;
   if (const char* e = getenv("MFM_DW_FOLD")) { if (atoi(e) == 0) return false; }
   if (getenv("MFM_SEQ_KS") || getenv("MFM_SEQ_ROWS")) return false;
   if (const char* e = getenv("MFM_LATENT_FOLD")) { if (atoi(e) == 0) return false; }
@@ -1046,6 +1053,7 @@ int seq_small_folddw_launch(SeqLaunch& L, const LatentDev& LD, DwRole& DR, const
 
 // Projection role workgroups for a forward fold launch: shapes the role kernel takes and enough idle CUs
 bool seq_small_foldproj_supported(int T, int B, const int* h, const int* k, int n_enc) {
+  if (shared_device()) return false;
   if (const char* e = getenv("MFM_PROJ_FOLD")) { if (atoi(e) == 0) return false; }
   if (getenv("MFM_SEQ_KS") || getenv("MFM_SEQ_ROWS")) return false;
   if (const char* e = getenv("MFM_LATENT_FOLD")) { if (atoi(e) == 0) return false; }

@@ -1590,6 +1590,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
           DR.flags = reinterpret_cast<unsigned*>(W + P->dw_flags); DR.epoch = ++P->dw_epoch;
           if (DR.epoch == 0) DR.epoch = ++P->dw_epoch;           // (0 is what a fresh workspace holds)
           DR.bf16 = c.precision ? 1 : 0;
+          DR.poison = grads;
           { Timer _t(P, s, K_ENC_BWD); rc = seq_folddw_launch(q, 4, T, B, L2, params, grads, DR, s, imgs_on ? eimg : nullptr); }
           if (rc == MFM_OK) { P->dwfold_state = 1; return MFM_OK; }      // every gradient of the step is on its way
           if (rc != MFM_ERR_UNSUPPORTED) return rc;

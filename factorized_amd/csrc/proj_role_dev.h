@@ -61,13 +61,18 @@ __device__ __forceinline__ unsigned proj_flags_load(const unsigned* f, int ncb) 
   return ld_agent_u(f + (lane < ncb ? lane : 0));
 }
 // spin until ready; gives up after ~50 ms so that a broken producer shows up as a parity failure, not as a hung GPU
-__device__ __forceinline__ void proj_flags_wait(const unsigned* f, unsigned v, unsigned epoch, int ncb) {
+// (a wait that gave up also stores a NaN into `poison` -- a loss slot: results that did not wait for their inputs must not look valid)
+__device__ __forceinline__ void proj_flags_wait(const unsigned* f, unsigned v, unsigned epoch, int ncb, float* poison) {
   if (proj_flags_ready(v, epoch, ncb)) return;
   const long long t0 = wall_clock64();
   do {
     __builtin_amdgcn_s_sleep(2);
     v = proj_flags_load(f, ncb);
-  } while (!proj_flags_ready(v, epoch, ncb) && wall_clock64() - t0 < 5000000ll);
+    if (wall_clock64() - t0 >= 5000000ll) {
+      if (poison && (threadIdx.x & 63) == 0) __hip_atomic_store(poison, __builtin_nanf(""), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  } while (!proj_flags_ready(v, epoch, ncb));
 }
 
 __device__ __forceinline__ void proj_role_body(const SeqLaunch& L, const ProjRole& PR, float* lds) {

@@ -41,6 +41,7 @@ def _worker(rank, world, port, fused, ret, variant="kl_ef", precision="fp32"):
     os.environ["MFM_DP_FUSED_ADAM"] = "1" if fused else "0"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
+    os.environ["MFM_SHARED_DEVICE"] = "1"       # the ranks share one GPU: no in-launch hand-overs (lstm_seq_small.hip)
     try:
         from factorized_amd import comm, engine, train
         cfgs = configs.canonical_configs(dropout=False)

@@ -168,3 +168,24 @@ def test_one_call_step_equals_forward_plus_backward(B, T, monkeypatch):
         for k in ref_l:
             assert abs(ld[k] - ref_l[k]) <= 1e-5 * max(abs(ref_l[k]), 1e-3), (k, ld[k], ref_l[k])
         assert grad_err(g, ref_g) < 2e-5
+
+
+def test_shared_device_switch_restores_separate_launches(monkeypatch):
+    """MFM_SHARED_DEVICE=1 (several processes / streams on one GPU: two queues' launches could block each other's producers):
+    no in-launch hand-overs -- the projection and weight-gradient launches are back; the weight images (no hand-over) stay."""
+    cfgs = C.canonical_configs(dropout=False)
+    B, T = 32, 20
+    _off(monkeypatch, False)
+    monkeypatch.setenv("MFM_SHARED_DEVICE", "1")
+    e, _ = _engine(cfgs)
+    xn, yn = synth.make_batch(cfgs[0]["input_dims"], B, T, seed=7)
+    x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
+    e.train_step(x, y)
+    e.set_timing(T, B, (1 << 30) - 1)
+    for _ in range(2):
+        e.train_step(x, y)
+    torch.cuda.synchronize()
+    tab = e.collect_timing(T, B)
+    e.set_timing(T, B, 0)
+    launches = {k: v["count"] for k, v in tab.items() if v["count"]}
+    assert launches.get("proj_gemm", 0) == 2 and launches.get("dw_gemm", 0) == 2, launches
