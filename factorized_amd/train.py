@@ -64,6 +64,31 @@ class DeviceDataset:
         return self.X[i], self.y[i]
 
 
+def _mark_shared_device(engine):
+    """Ranks that drive the SAME GPU (one-device test set-ups) must not use the in-launch hand-overs of the small-batch step
+    (csrc/lstm_seq_small.hip, shared_device(): two queues' launches can block each other's producers): compare (host, device)
+    across the ranks and export MFM_SHARED_DEVICE=1 when two ranks collide.  One process per GPU -- the deployment -- is unaffected."""
+    try:
+        import socket
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+            return
+        dev = torch.device(getattr(engine, "device", "cuda"))
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        try:
+            ident = str(torch.cuda.get_device_properties(idx).uuid)
+        except Exception:
+            ident = "%s:%d:%s" % (socket.gethostname(), idx, os.environ.get("HIP_VISIBLE_DEVICES", ""))
+        mine = (socket.gethostname(), ident)
+        allv = [None] * dist.get_world_size()
+        dist.all_gather_object(allv, mine)
+        if len(set(allv)) < len(allv):
+            os.environ["MFM_SHARED_DEVICE"] = "1"
+    except Exception:
+        pass
+
+
 class DataParallelStep:
     """step(x, y): fused single-GPU step, or fwd/bwd + all-reduce + Adam when world > 1."""
 
@@ -87,6 +112,7 @@ class DataParallelStep:
             if allreduce is None:
                 from . import comm
                 self.allreduce = comm.TorchAllReduce()
+            _mark_shared_device(engine)
 
     def step(self, x, y):
         e = self.e
