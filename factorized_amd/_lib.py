@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libmfm_hip.so")
 MFM_KLEF_NPARAM = 78
 MFM_LOSS_SLOTS = 8
 MFM_MAX_SEQ = 6
+ABI_VERSION = 3
 
 
 class MfmError(RuntimeError):
@@ -97,6 +98,10 @@ _SIGS = {
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mfm_adam_flat_spans": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AdamSpan), C.c_int32,
                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "mfm_adam_flat_guarded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "mfm_adam_flat_spans_guarded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AdamSpan), C.c_int32,
+                                              C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "mfm_p2p_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),
     "mfm_p2p_handle_bytes": (C.c_int, []),
     "mfm_p2p_export": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -107,6 +112,9 @@ _SIGS = {
     "mfm_p2p_allreduce_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                          C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                          C.c_void_p]),
+    "mfm_p2p_allreduce_adam_guarded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                                 C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                                 C.c_int64, C.c_void_p]),
     "mfm_p2p_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "mfm_p2p_destroy": (None, [C.c_void_p]),
     "mfm_plan_num_params": (C.c_int, [C.c_int32]),
@@ -131,6 +139,10 @@ _SIGS = {
     "mfm_plan_train_step_staged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(AdamSpan),
                                              C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mfm_plan_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "mfm_plan_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
+    "mfm_plan_state_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "mfm_plan_clear_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mfm_plan_latent_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mfm_plan_seq_layout": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "mfm_plan_mfn_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
@@ -162,8 +174,8 @@ def lib():
             fn = getattr(L, name)   # AttributeError if the ABI and the binding drift apart
             fn.restype = res
             fn.argtypes = args
-        if L.mfm_abi_version() != 2:
-            raise MfmError("libmfm_hip.so ABI version %d, binding expects 2" % L.mfm_abi_version())
+        if L.mfm_abi_version() != ABI_VERSION:
+            raise MfmError("libmfm_hip.so ABI version %d, binding expects %d" % (L.mfm_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 

@@ -106,10 +106,13 @@ class P2PAllReduce:
             for g in gs:
                 gs[g] = e.step_count
         stream = torch._C._cuda_getCurrentRawStream(e.grads.device.index)
-        _lib.check(self._L.mfm_p2p_allreduce_adam(self._h, C.c_void_p(e.grads.data_ptr()), C.c_void_p(e.params.data_ptr()),
-                                                  C.c_void_p(e.adam_m.data_ptr()), C.c_void_p(e.adam_v.data_ptr()),
-                                                  e.grads.numel(), e.step_count, lr, 0.9, 0.999, 1e-8, grad_scale,
-                                                  C.c_void_p(stream)), "mfm_p2p_allreduce_adam")
+        # guard word of the gradient buffer (engine.FlatLayout.guard): a rank whose step lost a hand-over tells the others in
+        # its first-push flags, and then NO rank applies the update (csrc/p2p.hip)
+        guard = getattr(getattr(e, "layout", None), "guard", -1)
+        _lib.check(self._L.mfm_p2p_allreduce_adam_guarded(self._h, C.c_void_p(e.grads.data_ptr()), C.c_void_p(e.params.data_ptr()),
+                                                          C.c_void_p(e.adam_m.data_ptr()), C.c_void_p(e.adam_v.data_ptr()),
+                                                          e.grads.numel(), e.step_count, lr, 0.9, 0.999, 1e-8, grad_scale,
+                                                          int(guard), C.c_void_p(stream)), "mfm_p2p_allreduce_adam_guarded")
 
     def timed_out(self):
         v = C.c_int32(0)

@@ -18,6 +18,7 @@
 #pragma once
 #include "internal.h"
 #include "lstm_seq_dev.h"
+#include "proj_role_dev.h"
 
 namespace mfm {
 
@@ -39,8 +40,10 @@ struct DwRole {
   const int4* table;                   // [n_iter][4 n_role]: x = problem (-1: idle), y = tile (tn + tiles_n (tm + tiles_m z)), z = chunk,
                                        // w = dep | t0 << 8 | FIRST << 24 | LAST << 25 | accumulator << 26
   unsigned* flags;                     // [4][T][32] BPTT stamps, then [4][B] latent-chain stamps
-  unsigned epoch;
-  float* poison;                       // a wait that gave up stores a NaN here (the gradient buffer: the optimizer makes it loud)
+  unsigned epoch;                      // host part of the launch's epoch (proj_role_dev.h, ho_epoch)
+  const unsigned* tick;                // device part: the plan's backward replay counter
+  HoCtl ctl;                           // time-out, status word, poison (= the gradient guard: the optimizer skips the step)
+  int fault;                           // fault injection (tests): the BPTT workgroup of (encoder 0, row 0) does not stamp t = 0
 };
 // dep codes of a table entry
 constexpr int DWR_DEP_NONE = 0, DWR_DEP_LATENT = 5;     // 1..4: encoder e = dep - 1
@@ -54,22 +57,19 @@ bool seq_small_folddw_supported(int T, int B);
 __device__ __forceinline__ void dwr_stamp(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // wave-level wait for `n` stamps at f[0..n) (n <= 128)
-__device__ __forceinline__ void dwr_wait(const unsigned* f, int n, unsigned epoch, float* poison) {
+__device__ __forceinline__ void dwr_wait(const unsigned* f, int n, unsigned epoch, const HoCtl& ctl) {
   const int lane = threadIdx.x & 63;
   const long long t0 = wall_clock64();
   for (;;) {
     const unsigned v0 = __hip_atomic_load(f + (lane < n ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned v1 = __hip_atomic_load(f + (lane + 64 < n ? lane + 64 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (__builtin_amdgcn_ballot_w64(v0 != epoch || v1 != epoch) == 0ull) return;
-    if (wall_clock64() - t0 > 5000000ll) {                // ~50 ms: a broken producer becomes a loud failure, not a hung GPU
-      if (poison && lane == 0) __hip_atomic_store(poison, __builtin_nanf(""), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
+    if (wall_clock64() - t0 > ctl.timeout) { ho_give_up(ctl); return; }      // (default ~50 ms: proj_role_dev.h, HoCtl)
     __builtin_amdgcn_s_sleep(8);
   }
 }
 
-__device__ __forceinline__ void dw_role_body(const DwRole& DR, float* lds) {
+__device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned epoch, float* lds) {
   constexpr int LOADS = DWR_KC * (DWR_T / 4) / 256;
   const int tid = threadIdx.x, sub = tid >> 8, t = tid & 255;
   const int lane = t & 63, wave = t >> 6;
@@ -115,8 +115,8 @@ __device__ __forceinline__ void dw_role_body(const DwRole& DR, float* lds) {
     }
     // ONE wave per slot polls (a thousand waves re-reading four flag lines at the memory side wait on each other)
     if (active && dep != DWR_DEP_NONE && wave == 0) {
-      if (dep == DWR_DEP_LATENT) dwr_wait(DR.flags + 4 * DR.T * DWR_ROWS, 4 * DR.B, DR.epoch, DR.poison);      // [4][B] dense
-      else dwr_wait(DR.flags + ((dep - 1) * DR.T + t0) * DWR_ROWS, DR.B, DR.epoch, DR.poison);
+      if (dep == DWR_DEP_LATENT) dwr_wait(DR.flags + 4 * DR.T * DWR_ROWS, 4 * DR.B, epoch, DR.ctl);      // [4][B] dense
+      else dwr_wait(DR.flags + ((dep - 1) * DR.T + t0) * DWR_ROWS, DR.B, epoch, DR.ctl);
     }
     if (DR.any_dep) __syncthreads();
     if (active) {

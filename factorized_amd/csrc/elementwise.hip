@@ -87,7 +87,10 @@ int mse_group_launch(const MseItem* items, int count, hipStream_t stream) {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    float beta1, float beta2, float eps, float step_size,
-                                                   float bc2_sqrt, float grad_scale) {
+                                                   float bc2_sqrt, float grad_scale, const float* __restrict__ guard) {
+  // guard word (mfm_adam_flat_guarded): anything but 0.0f -- the plan stores a NaN -- means the gradients of this step cannot
+  // be trusted; p, m and v stay as they are (uniform branch, one cached load per thread)
+  if (guard && !(guard[0] == 0.0f)) return;
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1,
-                float beta2, float eps, float grad_scale, hipStream_t stream) {
+                float beta2, float eps, float grad_scale, hipStream_t stream, const float* guard) {
   MFM_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam: bad arguments (n=%lld step=%d)", (long long)n, step);
   MFM_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam: buffers must be 16-byte aligned");
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
@@ -128,7 +131,7 @@ int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, int ste
   if (nb < 1) nb = 1;
   if (nb > 2048) nb = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3((int)nb), dim3(256), 0, stream, p, g, m, v, n, beta1, beta2, eps, step_size,
-                     bc2_sqrt, grad_scale);
+                     bc2_sqrt, grad_scale, guard);
   MFM_LAUNCH_CHECK("adam_kernel");
   return MFM_OK;
 }
@@ -146,7 +149,8 @@ struct AdamSpansDev {
 __global__ __launch_bounds__(256) void adam_spans_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v, int64_t n4,
                                                          const AdamSpansDev S, float beta1, float beta2, float eps,
-                                                         float grad_scale) {
+                                                         float grad_scale, const float* __restrict__ guard) {
+  if (guard && !(guard[0] == 0.0f)) return;          // (adam_kernel)
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     float step_size = 0.0f, bc2_sqrt = 1.0f;
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256) void adam_spans_kernel(float* __restrict__ p, 
 }
 
 int adam_spans_launch(float* p, const float* g, float* m, float* v, const MfmAdamSpan* spans, int nspans, float lr,
-                      float beta1, float beta2, float eps, float grad_scale, hipStream_t stream) {
+                      float beta1, float beta2, float eps, float grad_scale, hipStream_t stream, const float* guard) {
   MFM_REQUIRE(p && g && m && v && spans && nspans >= 1 && nspans <= MFM_ADAM_MAX_SPANS, "adam spans: bad arguments (nspans=%d)", nspans);
   MFM_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam spans: buffers must be 16-byte aligned");
   AdamSpansDev S;
@@ -201,7 +205,7 @@ int adam_spans_launch(float* p, const float* g, float* m, float* v, const MfmAda
   int64_t nb = (n4 + 255) / 256;
   if (nb < 1) nb = 1;
   if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(adam_spans_kernel, dim3((int)nb), dim3(256), 0, stream, p, g, m, v, n4, S, beta1, beta2, eps, grad_scale);
+  hipLaunchKernelGGL(adam_spans_kernel, dim3((int)nb), dim3(256), 0, stream, p, g, m, v, n4, S, beta1, beta2, eps, grad_scale, guard);
   MFM_LAUNCH_CHECK("adam_spans_kernel");
   return MFM_OK;
 }
@@ -240,6 +244,16 @@ extern "C" int mfm_mse_fwd_bwd(const float* xhat, const float* x, int64_t ldx, i
 extern "C" int mfm_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr,
                              float beta1, float beta2, float eps, float grad_scale, void* stream) {
   return mfm::adam_launch(p, g, m, v, n, step, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream);
+}
+
+extern "C" int mfm_adam_flat_guarded(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr,
+                                     float beta1, float beta2, float eps, float grad_scale, const float* guard, void* stream) {
+  return mfm::adam_launch(p, g, m, v, n, step, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream, guard);
+}
+extern "C" int mfm_adam_flat_spans_guarded(float* p, const float* g, float* m, float* v, const MfmAdamSpan* spans, int32_t nspans,
+                                           float lr, float beta1, float beta2, float eps, float grad_scale, const float* guard,
+                                           void* stream) {
+  return mfm::adam_spans_launch(p, g, m, v, spans, nspans, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream, guard);
 }
 
 extern "C" int mfm_adam_flat_spans(float* p, const float* g, float* m, float* v, const MfmAdamSpan* spans, int32_t nspans,

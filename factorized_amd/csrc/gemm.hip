@@ -295,7 +295,7 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
                   "gemm group: output transform %d needs a plain (non-accumulating, unbatched) product", i);
       g.epi[i] = e;
     }
-    g.epi_count = epis->count; g.epi_train = epis->train; g.epi_seed = epis->seed;
+    g.epi_count = epis->count; g.epi_train = epis->train; g.epi_seed = epis->seed; g.epi_tick = epis->tick;
   }
   if (zs) {
     for (int i = 0; i < MFM_GEMM_ZSPANS; ++i) {

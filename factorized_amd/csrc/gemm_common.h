@@ -29,6 +29,7 @@ struct GemmGroup {
   GemmEpi epi[MFM_GEMM_NEPI];
   int epi_count, epi_train;
   unsigned long long epi_seed;
+  const unsigned long long* epi_tick;
 };
 
 
@@ -70,7 +71,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmGroup& g, const MfmGemmD
             float mk = 1.0f;
             if (g.epi_train && ep.p > 0.0f) {
               const uint64_t idx = ((uint64_t)ep.op_id << 40) + (uint64_t)row * (uint64_t)d.n_valid + (uint64_t)col;
-              mk = (rng_uniform(g.epi_seed, idx) < ep.p) ? 0.0f : 1.0f / (1.0f - ep.p);
+              mk = (rng_uniform(g.epi_seed + (g.epi_tick ? *g.epi_tick : 0ull), idx) < ep.p) ? 0.0f : 1.0f / (1.0f - ep.p);
             }
             ep.aux[off] = (v > 0.0f) ? mk : 0.0f;
             v = fmaxf(v, 0.0f) * mk;

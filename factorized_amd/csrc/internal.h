@@ -15,7 +15,8 @@ struct ZeroSpans { float* ptr[MFM_GEMM_ZSPANS]; int64_t n[MFM_GEMM_ZSPANS]; };  
 //   3  v <- v * aux                                                            (backward of kind 1)
 // aux is addressed like C (row * ldc + col).  The dropout stream is keyed by (seed, op_id, row, col).
 struct GemmEpi { float* aux; float p; int kind; unsigned op_id; int pad_; };
-struct GemmEpiSet { const GemmEpi* epi; int count; unsigned long long seed; int train; };
+struct GemmEpiSet { const GemmEpi* epi; int count; unsigned long long seed; int train;
+                    const unsigned long long* tick; };   // tick: optional device word added to seed (the plan's replay counter)
 struct MseEpi {          // squared-error epilogue of one product: target, d(output), loss slot, scales
   const float* x; int64_t ldx; float* dxhat; float* loss; float inv_count, grad_scale;
   int dxhat_bf16;        // dxhat is a __bf16 buffer (bf16-resident plans)
@@ -49,7 +50,8 @@ struct LinRowsItem {
   int accumulate;     // atomicAdd into C (kind 0 only)
 };
 bool lin_rows_supported(const LinRowsItem* items, int count, int M);
-int lin_rows_launch(const LinRowsItem* items, int count, int M, int train, unsigned long long seed, hipStream_t stream);
+int lin_rows_launch(const LinRowsItem* items, int count, int M, int train, unsigned long long seed, hipStream_t stream,
+                    const unsigned long long* tick = nullptr);
 
 // gemm_panel.hip -- row-panel GEMM for the large-batch input projections: the A rows stay in LDS, every column group
 // (weight block [n_valid, k_len] with row stride ldw, consuming panel columns [k_off, k_off + k_len)) is walked by the
@@ -149,10 +151,11 @@ struct MseItem {
   int64_t ldx, rows; int d; float inv_count, grad_scale; int block_begin;
 };
 int mse_group_launch(const MseItem* items, int count, hipStream_t stream);
+// guard: optional device float; the update is skipped unless it is exactly 0 (include/mfm_hip.h, mfm_adam_flat_guarded)
 int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1,
-                float beta2, float eps, float grad_scale, hipStream_t stream);
+                float beta2, float eps, float grad_scale, hipStream_t stream, const float* guard = nullptr);
 int adam_spans_launch(float* p, const float* g, float* m, float* v, const MfmAdamSpan* spans, int nspans, float lr,
-                      float beta1, float beta2, float eps, float grad_scale, hipStream_t stream);
+                      float beta1, float beta2, float eps, float grad_scale, hipStream_t stream, const float* guard = nullptr);
 int fill_launch(float* p, int64_t n, float val, hipStream_t stream);
 
 // mfn_att.hip -- row-wise glue of the MFN attention block (everything between its GEMMs)
@@ -262,6 +265,8 @@ struct LatentDev {
   int row_threads;                     // threads per row-path workgroup: 512 when no chain stage has more items, else 1024
   int nitems_fwd_c[4][MFM_LAT_MAXSTAGES], nitems_bwd_c[4][MFM_LAT_MAXSTAGES];
   uint64_t seed;
+  const unsigned long long* tick;      // optional device word added to `seed` when the kernel runs (the plan's replay counter:
+                                       // a captured hipGraph draws new masks on every replay)
   float reg_w, disc_w, gen_w;
   int grd_agent;          // grd_out leaves with agent-scope stores (read inside the same launch, dw_role_dev.h)
 };

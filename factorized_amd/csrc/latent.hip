@@ -181,7 +181,7 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(const LatentDev
                 float mk = 1.0f;
                 if (L.train && op.drop_p > 0.0f) {
                   const uint64_t idx = ((uint64_t)o << 40) + (uint64_t)(row0 + r) * (uint64_t)op.N + (uint64_t)n;
-                  mk = (rng_uniform(L.seed, idx) < op.drop_p) ? 0.0f : 1.0f / (1.0f - op.drop_p);
+                  mk = (rng_uniform(L.seed + (L.tick ? *L.tick : 0ull), idx) < op.drop_p) ? 0.0f : 1.0f / (1.0f - op.drop_p);
                 }
                 v *= mk;
                 rec[r * RS + op.mask_off + n] = mk;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_fwd_kernel(const LatentDev
           float mk = 1.0f;
           if (L.train && op.drop_p > 0.0f) {
             const uint64_t idx = ((uint64_t)o << 40) + (uint64_t)(row0 + r) * (uint64_t)op.N + (uint64_t)n;
-            mk = (rng_uniform(L.seed, idx) < op.drop_p) ? 0.0f : 1.0f / (1.0f - op.drop_p);
+            mk = (rng_uniform(L.seed + (L.tick ? *L.tick : 0ull), idx) < op.drop_p) ? 0.0f : 1.0f / (1.0f - op.drop_p);
           }
           v *= mk;
           rec[r * RS + op.mask_off + n] = mk;

@@ -197,7 +197,7 @@ __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const fl
             float mk = 1.0f;
             if (L.train && op.drop_p > 0.0f) {
               const uint64_t idx = ((uint64_t)o << 40) + (uint64_t)row * (uint64_t)op.N + (uint64_t)n;
-              mk = (rng_uniform(L.seed, idx) < op.drop_p) ? 0.0f : 1.0f / (1.0f - op.drop_p);
+              mk = (rng_uniform(L.seed + (L.tick ? *L.tick : 0ull), idx) < op.drop_p) ? 0.0f : 1.0f / (1.0f - op.drop_p);
             }
             v *= mk;
             rec[op.mask_off + n] = mk;

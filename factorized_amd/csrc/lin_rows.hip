@@ -29,6 +29,7 @@ struct LinRowsDev {
   LinRowsDevItem it[MFM_LINROWS_MAX];
   int count, M, train;
   unsigned long long seed;
+  const unsigned long long* tick;
 };
 
 // PA / PWT: 16-byte loads per thread for the A slice (16 x k) and the W slice (32 x k)
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(LR_THREADS) void lin_rows_kernel(const LinRowsDev L
         float mk = 1.0f;
         if (L.train && I.p > 0.0f) {
           const uint64_t idx = ((uint64_t)I.op_id << 40) + (uint64_t)row * (uint64_t)I.n + (uint64_t)col;
-          mk = (rng_uniform(L.seed, idx) < I.p) ? 0.0f : 1.0f / (1.0f - I.p);
+          mk = (rng_uniform(L.seed + (L.tick ? *L.tick : 0ull), idx) < I.p) ? 0.0f : 1.0f / (1.0f - I.p);
         }
         I.aux[off] = (v > 0.0f) ? mk : 0.0f;
         v = fmaxf(v, 0.0f) * mk;
@@ -181,11 +182,12 @@ bool lin_rows_supported(const LinRowsItem* items, int count, int M) {
   return true;
 }
 
-int lin_rows_launch(const LinRowsItem* items, int count, int M, int train, unsigned long long seed, hipStream_t stream) {
+int lin_rows_launch(const LinRowsItem* items, int count, int M, int train, unsigned long long seed, hipStream_t stream,
+                    const unsigned long long* tick) {
   MFM_REQUIRE(lin_rows_supported(items, count, M), "lin_rows: unsupported shapes (count %d, M %d)", count, M);
   LinRowsDev L;
   memset(&L, 0, sizeof(L));
-  L.count = count; L.M = M; L.train = train; L.seed = seed;
+  L.count = count; L.M = M; L.train = train; L.seed = seed; L.tick = tick;
   const int row_tiles = cdiv(M, LR_ROWS);
   int total = 0, kmax = 0;
   size_t img = 0;

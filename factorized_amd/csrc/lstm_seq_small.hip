@@ -145,7 +145,7 @@ __device__ __forceinline__ void stage_gates2(const SeqDev& d, int mode, int g, f
 template <int KQ, int R, bool FLG = false>
 __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds,
                                                const unsigned* flg = nullptr, const unsigned epoch = 0, const int ncb = 0,
-                                               float* poison = nullptr) {
+                                               const HoCtl ctl = HoCtl{nullptr, nullptr, 5000000ll, 1u}) {
   constexpr int HK = 4 * KQ;                    // padded hidden extent of the matvec
   constexpr int HKB = (HK + 15) / 16 * 16;      // == Hp
   constexpr int NTH = 8 * HKB;                  // threads this LSTM uses (blockDim may be larger)
@@ -252,8 +252,8 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
     if constexpr (FLG) {
       if (fetch_wave) {
         const int t1 = (T > 1) ? 1 : 0;
-        proj_flags_wait(flg, proj_flags_load(flg, ncb), epoch, ncb, poison);
-        proj_flags_wait(flg + t1 * PROJ_ROLE_FLAGS, proj_flags_load(flg + t1 * PROJ_ROLE_FLAGS, ncb), epoch, ncb, poison);
+        proj_flags_wait(flg, proj_flags_load(flg, ncb), epoch, ncb, ctl);
+        proj_flags_wait(flg + t1 * PROJ_ROLE_FLAGS, proj_flags_load(flg + t1 * PROJ_ROLE_FLAGS, ncb), epoch, ncb, ctl);
         fv = proj_flags_load(flg + min(2, T - 1) * PROJ_ROLE_FLAGS, ncb);
       }
     }
@@ -342,7 +342,7 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
       const int64_t off = (int64_t)min(t + 2, T - 1) * gstep;
       if constexpr (FLG) {
         if (fetch_wave) {
-          proj_flags_wait(flg + min(t + 2, T - 1) * PROJ_ROLE_FLAGS, fv, epoch, ncb, poison);
+          proj_flags_wait(flg + min(t + 2, T - 1) * PROJ_ROLE_FLAGS, fv, epoch, ncb, ctl);
 #pragma unroll
           for (int i = 0; i < NXL; ++i) xn[i] = ld_agent((const float*)xp[i] + off);
           fv = proj_flags_load(flg + min(t + 3, T - 1) * PROJ_ROLE_FLAGS, ncb);
@@ -421,7 +421,8 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
 // row's dA of the time steps >= t is in memory.
 template <int KQ, int R, int KS = 16, bool PUB = false>
 __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds,
-                                               unsigned* stamp = nullptr, const unsigned epoch = 0) {
+                                               unsigned* stamp = nullptr, const unsigned epoch = 0,
+                                               const bool skip_final_stamp = false) {
   constexpr int HK = 4 * KQ;                       // padded hidden extent
   constexpr int HKB = (HK + 15) / 16 * 16;         // per-gate extent of the dA panel (multiple of 16) == Hp
   static_assert(KS == 16 || (KS == 8 && R == 1), "8 k-slices: one-row tiles only");
@@ -713,7 +714,7 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
   if (dec && bvalid && d.d_h_init && mu < h) d.d_h_init[(int64_t)b * d.ld_dinit + mu] = dh_rec;
   if constexpr (PUB) {
     __syncthreads();                   // (waits for every outstanding store of every wave)
-    if (tid == 0) dwr_stamp(stamp, epoch);
+    if (tid == 0 && !skip_final_stamp) dwr_stamp(stamp, epoch);      // (skipped only by the fault injection of the tests)
   }
 }
 
@@ -879,7 +880,8 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_foldproj_kernel(const Seq
                                                                        const float* __restrict__ params) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int bid = blockIdx.x;
-  if (bid < PR.n_role) { proj_role_body(L, PR, lds); return; }
+  const unsigned epoch = ho_epoch(PR.epoch, PR.tick);
+  if (bid < PR.n_role) { proj_role_body(L, PR, epoch, lds); return; }
   int di = 0;
 #pragma unroll 1
   for (int i = 1; i < L.count; ++i)
@@ -889,7 +891,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_foldproj_kernel(const Seq
   const unsigned* flg = PR.flags + (int64_t)di * L.T * PROJ_ROLE_FLAGS;
   const int ncb = PR.e[di].ncb;
 #define MFM_ONE(IDX, KK) \
-  if (KK > 0 && di == IDX) small_fwd_body<(KK > 0 ? KK : 2), 1, true>(d, L.T, L.B, tile, lds, flg, PR.epoch, ncb, LD.losses);
+  if (KK > 0 && di == IDX) small_fwd_body<(KK > 0 ? KK : 2), 1, true>(d, L.T, L.B, tile, lds, flg, epoch, ncb, PR.ctl);
   MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3)
 #undef MFM_ONE
   // the loss slots are cleared by the producers of t = 0: all of them have passed before this row's chain adds to them
@@ -897,7 +899,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_foldproj_kernel(const Seq
 #pragma unroll 1
     for (int e = 0; e < 4; ++e) {
       const unsigned* f0 = PR.flags + (int64_t)e * L.T * PROJ_ROLE_FLAGS;
-      proj_flags_wait(f0, proj_flags_load(f0, PR.e[e].ncb), PR.epoch, PR.e[e].ncb, LD.losses);
+      proj_flags_wait(f0, proj_flags_load(f0, PR.e[e].ncb), epoch, PR.e[e].ncb, PR.ctl);
     }
   }
   __syncthreads();        // every store of the last time step has been acknowledged: h_T of this row is readable
@@ -911,7 +913,12 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_folddw_kernel(const SeqLa
                                                                      const float* __restrict__ params, float* __restrict__ grads) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int bid = blockIdx.x;
-  if (bid >= 4 * L.B) { dw_role_body(DR, lds); return; }
+  const unsigned epoch = ho_epoch(DR.epoch, DR.tick);
+  if (bid >= 4 * L.B) { dw_role_body(DR, epoch, lds); return; }
+  // a plan whose status word is set (a hand-over of this or of an earlier step gave up: the forward's projections may be
+  // garbage) must not train: the guard word of the gradient buffer makes the optimizer skip (and travels through the all-reduce)
+  if (bid == 0 && threadIdx.x == 0 && DR.ctl.status && DR.ctl.poison && *DR.ctl.status != 0u)
+    __hip_atomic_store(DR.ctl.poison, __builtin_nanf(""), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int di = 0;
 #pragma unroll 1
   for (int i = 1; i < L.count; ++i)
@@ -920,10 +927,11 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_folddw_kernel(const SeqLa
   const int tile = bid - d.block_begin;          // == batch row (one-row tiles)
   latent_bwd_row_body<false>(LD, params, grads, tile, di, lds);
   __syncthreads();        // d h_T of this (row, encoder) is in memory (and the LDS is free) before the BPTT reads it
-  if (threadIdx.x == 0) dwr_stamp(DR.flags + 4 * L.T * DWR_ROWS + di * L.B + tile, DR.epoch);
+  if (threadIdx.x == 0) dwr_stamp(DR.flags + 4 * L.T * DWR_ROWS + di * L.B + tile, epoch);
   unsigned* stamp = DR.flags + (int64_t)di * L.T * DWR_ROWS + tile;
+  const bool fault = DR.fault != 0 && bid == 0;
 #define MFM_ONE(IDX, KK) \
-  if (KK > 0 && di == IDX) small_bwd_body<(KK > 0 ? KK : 2), 1, 16, true>(d, L.T, L.B, tile, lds, stamp, DR.epoch);
+  if (KK > 0 && di == IDX) small_bwd_body<(KK > 0 ? KK : 2), 1, 16, true>(d, L.T, L.B, tile, lds, stamp, epoch, fault);
   MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3)
 #undef MFM_ONE
 }
@@ -1015,13 +1023,10 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
 
 
 // MFM_OK: launched.  MFM_ERR_UNSUPPORTED: not a case the fold kernels take (the caller issues the separate launches).
-// MFM_SHARED_DEVICE=1: other processes / streams run kernels on this GPU at the same time.  The in-launch hand-overs count on
-// this launch becoming resident workgroup by workgroup in block order; launches of two queues that together exceed the CUs
-// can block each other's producers until the waits give up (and poison their results) -- so they are switched off.
-static bool shared_device() { const char* e = getenv("MFM_SHARED_DEVICE"); return e && atoi(e) != 0; }
-
+// Whether the plan may use the role-workgroup launches at all is the plan's "handover" option (plan.hip): the in-launch
+// hand-overs count on this launch becoming resident workgroup by workgroup in block order; launches of two queues that
+// together exceed the CUs can block each other's producers until the waits give up (status word, poisoned gradient guard).
 bool seq_small_folddw_supported(int T, int B) {
-  if (shared_device()) return false;
   if (const char* e = getenv("MFM_DW_FOLD")) { if (atoi(e) == 0) return false; }
   if (getenv("MFM_SEQ_KS") || getenv("MFM_SEQ_ROWS")) return false;
   if (const char* e = getenv("MFM_LATENT_FOLD")) { if (atoi(e) == 0) return false; }
@@ -1053,7 +1058,6 @@ int seq_small_folddw_launch(SeqLaunch& L, const LatentDev& LD, DwRole& DR, const
 
 // Projection role workgroups for a forward fold launch: shapes the role kernel takes and enough idle CUs
 bool seq_small_foldproj_supported(int T, int B, const int* h, const int* k, int n_enc) {
-  if (shared_device()) return false;
   if (const char* e = getenv("MFM_PROJ_FOLD")) { if (atoi(e) == 0) return false; }
   if (getenv("MFM_SEQ_KS") || getenv("MFM_SEQ_ROWS")) return false;
   if (const char* e = getenv("MFM_LATENT_FOLD")) { if (atoi(e) == 0) return false; }

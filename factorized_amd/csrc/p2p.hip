@@ -78,19 +78,29 @@ __device__ __forceinline__ f32x4 load4_sys(const float* p) {
   return f32x4{a[0], a[1], b[0], b[1]};
 }
 
-// thread t < W waits until flags[t] reaches `epoch`; returns after a block barrier + acquire fence
-__device__ __forceinline__ void wait_flags(const int* flags, int stride, int W, int epoch, int64_t timeout, int* err) {
+// A flag word is 2 * epoch + bad: the low bit of a FIRST-push flag says that the sending rank's gradients carry a raised guard
+// word (mfm_p2p_allreduce_adam_guarded: a hand-over of its step gave up, include/mfm_hip.h) -- every workgroup of every rank
+// sees the bits of all ranks before it touches a parameter, so all replicas skip the same steps.
+// thread t < W waits until flags[t] reaches `epoch`; returns (after a block barrier + acquire fence) whether any flag had its
+// low bit set
+__device__ __forceinline__ bool wait_flags(const int* flags, int stride, int W, int epoch, int64_t timeout, int* err) {
+  __shared__ int any_bad;
+  if (threadIdx.x == 0) any_bad = 0;
+  __syncthreads();
   if ((int)threadIdx.x < W) {
     const int* f = flags + (int64_t)threadIdx.x * stride;
     const int64_t t0 = wall_clock64();
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+    int v;
+    while (((v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) >> 1) < epoch) {
       __builtin_amdgcn_s_sleep(2);
       // give up after `timeout`, and at once when an earlier wait of this rank already did
       if (wall_clock64() - t0 > timeout || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
         atomicExch(err, 1);
+        v = 0;
         break;
       }
     }
+    if (v & 1) any_bad = 1;
   }
   // one acquire per workgroup (the wave that polled): it invalidates this CU's vector L1 and the L2's
   // non-coherent lines; the staging block itself is uncached, so this is insurance, not the mechanism
@@ -98,18 +108,19 @@ __device__ __forceinline__ void wait_flags(const int* flags, int stride, int W, 
   if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 #endif
   __syncthreads();
+  return any_bad != 0;
 }
 
 // every wave waits for its own stores to be acknowledged, then ONE wave does the system-scope release (an L2
 // write-back on gfx950: once per workgroup, not once per wave) and raises the flags
-__device__ __forceinline__ void publish(int* const* flags, int slot, int W, int epoch) {
+__device__ __forceinline__ void publish(int* const* flags, int slot, int W, int epoch, int bad = 0) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   if (threadIdx.x < 64) {
 #ifndef P2P_EXPERIMENT_NO_SYSTEM_FENCE
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
 #endif
-    if ((int)threadIdx.x < W) __hip_atomic_store(flags[threadIdx.x] + slot, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((int)threadIdx.x < W) __hip_atomic_store(flags[threadIdx.x] + slot, 2 * epoch + bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -137,9 +148,11 @@ __device__ __forceinline__ void adam4(const AdamArgs& a, int64_t idx, int64_t n,
 
 template <bool ADAM>
 __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev d, float* __restrict__ buf, int64_t n, int epoch,
-                                                                   int64_t timeout, const AdamArgs ad) {
+                                                                   int64_t timeout, const AdamArgs ad, const int64_t guard_idx) {
   const int w = blockIdx.x, tid = threadIdx.x;
   const int W = d.W, me = d.rank;
+  // this rank's guard word (written by an earlier launch: the same value in every workgroup)
+  const int bad_local = (ADAM && guard_idx >= 0 && !(buf[guard_idx] == 0.0f)) ? 1 : 0;
   const int64_t SL = d.SL, CL = d.CL, cb = (int64_t)w * CL;
   // All loops over ranks are unrolled to P2P_MAXR with clamped indices and predicated stores: the loads of
   // one pass are then issued back to back instead of one dependent round trip per rank.
@@ -157,9 +170,9 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev
       if (i < W) store4_sys(d.stage[s] + (int64_t)me * SL + cb + k, v[i]);
     }
   }
-  publish(d.f1, me * P2P_WGS + w, W, epoch);
+  publish(d.f1, me * P2P_WGS + w, W, epoch, bad_local);
   // ---- reduce my slice's chunk in rank order, push 2: the result -> every rank's result row `me`
-  wait_flags(d.f1[me] + w, P2P_WGS, W, epoch, timeout, d.err);
+  const bool skip = wait_flags(d.f1[me] + w, P2P_WGS, W, epoch, timeout, d.err);
   for (int64_t k = (int64_t)tid * 4; k < CL && cb + k < SL; k += P2P_THREADS * 4) {
     const float* src = d.stage[me] + cb + k;
     f32x4 v[P2P_MAXR];
@@ -175,11 +188,11 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev
       if (i < W) store4_sys(d.res[p] + (int64_t)me * SL + cb + k, acc);
     }
     store4_bounded(buf, (int64_t)me * SL + cb + k, n, acc);
-    if (ADAM) adam4(ad, (int64_t)me * SL + cb + k, n, acc);
+    if (ADAM && !skip) adam4(ad, (int64_t)me * SL + cb + k, n, acc);
   }
   publish(d.f2, me * P2P_WGS + w, W, epoch);
   // ---- gather: foreign result rows -> my gradient buffer
-  wait_flags(d.f2[me] + w, P2P_WGS, W, epoch, timeout, d.err);
+  (void)wait_flags(d.f2[me] + w, P2P_WGS, W, epoch, timeout, d.err);
   for (int64_t k = (int64_t)tid * 4; k < CL && cb + k < SL; k += P2P_THREADS * 4) {
     f32x4 v[P2P_MAXR];
 #pragma unroll
@@ -192,13 +205,15 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev
       const int s = (me + min(i, W - 1)) % W;
       if (i < W) {
         store4_bounded(buf, (int64_t)s * SL + cb + k, n, v[i]);
-        if (ADAM) adam4(ad, (int64_t)s * SL + cb + k, n, v[i]);
+        if (ADAM && !skip) adam4(ad, (int64_t)s * SL + cb + k, n, v[i]);
       }
     }
   }
 }
 
-__global__ __launch_bounds__(P2P_THREADS) void adam_only_kernel(const float* __restrict__ g, int64_t n, const AdamArgs ad) {
+__global__ __launch_bounds__(P2P_THREADS) void adam_only_kernel(const float* __restrict__ g, int64_t n, const AdamArgs ad,
+                                                                const int64_t guard_idx) {
+  if (guard_idx >= 0 && !(g[guard_idx] == 0.0f)) return;
   for (int64_t k = ((int64_t)blockIdx.x * P2P_THREADS + threadIdx.x) * 4; k < n; k += (int64_t)P2P_WGS * P2P_THREADS * 4)
     adam4(ad, k, n, load4_bounded(g, k, n));
 }
@@ -315,24 +330,25 @@ int mfm_p2p_connect_bases(void* handle, const void* const* bases) {
   return MFM_OK;
 }
 
-static int p2p_launch(void* handle, float* buf, int64_t n, void* stream, const AdamArgs* ad, const char* who) {
+static int p2p_launch(void* handle, float* buf, int64_t n, void* stream, const AdamArgs* ad, const char* who, int64_t guard_idx = -1) {
   P2P* h = static_cast<P2P*>(handle);
   if (!h || !buf) { set_error("%s: null argument", who); return MFM_ERR_ARG; }
   if (!h->connected) { set_error("%s: mfm_p2p_connect has not been called", who); return MFM_ERR_ARG; }
   if (n < 0 || n > h->max_elems) { set_error("%s: n=%lld exceeds max_elems=%lld", who, (long long)n, (long long)h->max_elems); return MFM_ERR_ARG; }
   if ((reinterpret_cast<uintptr_t>(buf) & 15) != 0) { set_error("%s: buffer must be 16-byte aligned", who); return MFM_ERR_ARG; }
   if (n == 0) return MFM_OK;
+  if (guard_idx >= n) { set_error("%s: guard index %lld outside the buffer of %lld elements", who, (long long)guard_idx, (long long)n); return MFM_ERR_ARG; }
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (h->d.W == 1) {            // one rank: the sum is the buffer itself; only the optimizer is left to do
     if (!ad) return MFM_OK;
-    hipLaunchKernelGGL(adam_only_kernel, dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, buf, n, *ad);
+    hipLaunchKernelGGL(adam_only_kernel, dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, buf, n, *ad, guard_idx);
   } else {
     h->epoch += 1;
     if (ad)
-      hipLaunchKernelGGL(p2p_allreduce_kernel<true>, dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, h->d, buf, n, h->epoch, h->timeout_ticks, *ad);
+      hipLaunchKernelGGL(p2p_allreduce_kernel<true>, dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, h->d, buf, n, h->epoch, h->timeout_ticks, *ad, guard_idx);
     else
       hipLaunchKernelGGL(p2p_allreduce_kernel<false>, dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, h->d, buf, n, h->epoch, h->timeout_ticks,
-                         AdamArgs{});
+                         AdamArgs{}, (int64_t)-1);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, who);
@@ -345,6 +361,11 @@ int mfm_p2p_allreduce(void* handle, float* buf, int64_t n, void* stream) {
 
 int mfm_p2p_allreduce_adam(void* handle, float* grads, float* p, float* m, float* v, int64_t n, int32_t step, float lr, float beta1,
                            float beta2, float eps, float grad_scale, void* stream) {
+  return mfm_p2p_allreduce_adam_guarded(handle, grads, p, m, v, n, step, lr, beta1, beta2, eps, grad_scale, -1, stream);
+}
+
+int mfm_p2p_allreduce_adam_guarded(void* handle, float* grads, float* p, float* m, float* v, int64_t n, int32_t step, float lr,
+                                   float beta1, float beta2, float eps, float grad_scale, int64_t guard_index, void* stream) {
   if (!p || !m || !v || step < 1) { set_error("mfm_p2p_allreduce_adam: bad arguments (step=%d)", step); return MFM_ERR_ARG; }
   if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) != 0) {
     set_error("mfm_p2p_allreduce_adam: buffers must be 16-byte aligned");
@@ -353,7 +374,7 @@ int mfm_p2p_allreduce_adam(void* handle, float* grads, float* p, float* m, float
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   AdamArgs ad{p, m, v, beta1, beta2, eps, (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale};
-  return p2p_launch(handle, grads, n, stream, &ad, "mfm_p2p_allreduce_adam");
+  return p2p_launch(handle, grads, n, stream, &ad, "mfm_p2p_allreduce_adam", guard_index);
 }
 
 int mfm_p2p_status(void* handle, int32_t* timed_out) {

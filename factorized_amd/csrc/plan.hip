@@ -151,6 +151,20 @@ struct MfmPlan {
   unsigned long long x16_call = ~0ull;   // value of `calls` for which the forward already produced x16
   unsigned long long pj_pack_call = ~0ull, fc1_pack_call = ~0ull;   // ... for which the step's pack launch built these images
   unsigned long long fc1_bwd_call = ~0ull;   // value of `calls` for which the forward already produced dH of the decoders (dec_fc1.hip)
+  // ---- per-plan switches (mfm_plan_set_option, include/mfm_hip.h)
+  int opt_handover = 1;             // in-launch hand-overs (role workgroups) allowed
+  int64_t opt_timeout_us = 50000;   // how long their consumers spin before they give up
+  int64_t opt_guard = -1;           // element offset of the guard word in the gradient buffer (-1: none)
+  int opt_fault = 0;                // one-shot fault injection (tests)
+  bool ever_handover = false;       // a role-workgroup launch has run on this plan (its status word may be set)
+  // device-side state, right behind the plan's loss slots (mfm_plan_state_layout): float offsets relative to `losses`
+  static constexpr int ST_STATUS = MFM_LOSS_SLOTS, ST_TICK = MFM_LOSS_SLOTS + 2, ST_DW_TICK = MFM_LOSS_SLOTS + 4;
+  unsigned* status_ptr(float* W) const { return reinterpret_cast<unsigned*>(W + losses + ST_STATUS); }
+  unsigned* tick_ptr(float* W) const { return reinterpret_cast<unsigned*>(W + losses + ST_TICK); }      // low word of the u64 replay counter
+  unsigned* dw_tick_ptr(float* W) const { return reinterpret_cast<unsigned*>(W + losses + ST_DW_TICK); }
+  mfm::HoCtl ho_ctl(float* W, float* poison, unsigned bit) const {
+    return mfm::HoCtl{status_ptr(W), poison, opt_timeout_us * 100ll /* 100 MHz wall clock */, bit};
+  }
 };
 
 namespace mfm {
@@ -578,10 +592,33 @@ static int build(MfmPlan* P) {
   if (V != 0) P->dh_last[3] = carve(cur, (int64_t)c.B * P->nzy);     // d loss / d [mu_y | logvar_y] (or z_y)
   P->yhat = carve(cur, (int64_t)c.B * c.output_dim);
   P->ones = carve(cur, TB);
-  P->losses = carve(cur, MFM_LOSS_SLOTS);
+  P->losses = carve(cur, 64);        // loss slots [MFM_LOSS_SLOTS], then the plan's device-side state (MfmPlan::ST_*)
   P->ws_floats = cur;
   return MFM_OK;
 }
+
+// Replay counters (mfm_plan_state_layout): device words that only a CAPTURED step advances -- one tick node behind the
+// forward, one behind a backward with role workgroups -- so that every replay of a hipGraph draws new dropout masks and
+// stamps its hand-over flags with an epoch of its own (the kernel arguments of a captured launch are frozen; the host part
+// of both, the plan's call counter, is what eager calls advance).
+__global__ void tick_kernel(unsigned long long* t64, unsigned* t32) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (t64) *t64 += 1ull;
+    if (t32) *t32 += 1u;
+  }
+}
+// non-role backward of a plan whose forward may have raised the status word: keep the step away from the parameters
+__global__ void guard_propagate_kernel(const unsigned* status, float* guard) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && *status != 0u) *guard = __builtin_nanf("");
+}
+static bool stream_capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return st == hipStreamCaptureStatusActive;
+}
+// host part of a hand-over epoch: consecutive launches of one plan -- eager calls and replays of graphs captured at
+// different call counts, in any order -- must never carry the same value (epoch = this + replay counter, ho_epoch)
+static unsigned epoch_base(uint64_t calls) { return (unsigned)calls * 0x9E3779B1u; }
 
 struct Timer {
   MfmPlan* P; hipStream_t s; int kid; TimingPair* tp;
@@ -694,6 +731,7 @@ static int mfn_forward(MfmPlan* P, const float* params, int train, uint64_t seed
   GemmEpiSet es;
   memset(&es, 0, sizeof(es));
   es.seed = seed * 0x9E3779B97F4A7C15ull + P->calls; es.train = train;
+  es.tick = reinterpret_cast<const unsigned long long*>(P->tick_ptr(W));
   MfnAttFused F;
   if (mfn_fused_desc(P, params, W, F)) {
     F.train = train; F.seed = es.seed;
@@ -731,13 +769,13 @@ static int mfn_forward(MfmPlan* P, const float* params, int train, uint64_t seed
       GemmEpi e = {W + P->m1, c.drop_nn1, 1, 101u, 0};
       LinRowsItem it = rows(g, 1, e.aux, e.p, e.op_id);
       es.epi = &e; es.count = 1;
-      if (lr_on && lin_rows_supported(&it, 1, (int)TB)) RUN(K_MFN_ATT_FWD, lin_rows_launch(&it, 1, (int)TB, train, es.seed, s));
+      if (lr_on && lin_rows_supported(&it, 1, (int)TB)) RUN(K_MFN_ATT_FWD, lin_rows_launch(&it, 1, (int)TB, train, es.seed, s, es.tick));
       else RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
     }
     {   // logits = att1_fc2(h1)
       MfmGemmDesc g = lin(W + P->h1, c.nn1, c.nn1, pi.att1_2, A2, W + P->att, A2, c.nn1);
       LinRowsItem it = rows(g, 0, nullptr, 0.0f, 0u);
-      if (lr_on && lin_rows_supported(&it, 1, (int)TB)) RUN(K_MFN_ATT_FWD, lin_rows_launch(&it, 1, (int)TB, train, es.seed, s));
+      if (lr_on && lin_rows_supported(&it, 1, (int)TB)) RUN(K_MFN_ATT_FWD, lin_rows_launch(&it, 1, (int)TB, train, es.seed, s, es.tick));
       else RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec));
     }
     RUN(K_MFN_GLUE, mfn_softmax_fwd_launch(W + P->att, W + P->cstar, W + P->attended, TB, A2, s));
@@ -749,7 +787,7 @@ static int mfn_forward(MfmPlan* P, const float* params, int train, uint64_t seed
       GemmEpi e = {W + P->m2, c.drop_nn2, 1, 102u, 0};
       LinRowsItem it[3] = {rows(g[0], 1, e.aux, e.p, e.op_id), rows(g[1], 0, nullptr, 0.0f, 0u), rows(g[2], 0, nullptr, 0.0f, 0u)};
       es.epi = &e; es.count = 1;
-      if (lr_on && lin_rows_supported(it, 3, (int)TB)) RUN(K_MFN_ATT_FWD, lin_rows_launch(it, 3, (int)TB, train, es.seed, s));
+      if (lr_on && lin_rows_supported(it, 3, (int)TB)) RUN(K_MFN_ATT_FWD, lin_rows_launch(it, 3, (int)TB, train, es.seed, s, es.tick));
       else RUN(K_MFN_ATT_FWD, gemm_group_launch(g, 3, s, nullptr, nullptr, 0, prec, &es));
     }
     {   // cHat = tanh(att2_fc2(h2))
@@ -757,7 +795,7 @@ static int mfn_forward(MfmPlan* P, const float* params, int train, uint64_t seed
       GemmEpi e = {nullptr, 0.0f, 2, 0u, 0};
       LinRowsItem it = rows(g, 2, nullptr, 0.0f, 0u);
       es.epi = &e; es.count = 1;
-      if (lr_on && lin_rows_supported(&it, 1, (int)TB)) RUN(K_MFN_ATT_FWD, lin_rows_launch(&it, 1, (int)TB, train, es.seed, s));
+      if (lr_on && lin_rows_supported(&it, 1, (int)TB)) RUN(K_MFN_ATT_FWD, lin_rows_launch(&it, 1, (int)TB, train, es.seed, s, es.tick));
       else RUN(K_MFN_ATT_FWD, gemm_group_launch(&g, 1, s, nullptr, nullptr, 0, prec, &es));
     }
   }
@@ -771,6 +809,7 @@ static int mfn_forward(MfmPlan* P, const float* params, int train, uint64_t seed
     md.gam1 = W + P->gam1; md.gam2 = W + P->gam2; md.mems = W + P->mems; md.mem_out = W + P->mem_out;
     md.T = T; md.B = B; md.M = M; md.H1 = c.g1; md.H2 = c.g2; md.train = train;
     md.p1 = c.drop_g1; md.p2 = c.drop_g2; md.seed = es.seed ^ 0x5DEECE66Dull;
+    md.seed_dev = reinterpret_cast<const uint64_t*>(es.tick);
     MfnHeadsDev H;
     mfn_heads_desc(P, params, W, H);
     RUN(K_MFN_MEM_FWD, mfn_mem_fwd_launch(&md, &H, s));
@@ -890,8 +929,9 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
   // F0: input projections.  MFM_KL_EF at B <= 32 (fp32 plans on the fold launches): produced
   // by role workgroups of the encoder launch itself (proj_role_dev.h), which also clear the zero spans
   bool proj_in_fold = false;
+  const bool capturing = stream_capturing(s);
   if (V == 0 && !seq_bf16 && !st16 && P->n_enc == 4 && P->fold_state >= 0 && P->projfold_state >= 0 && P->pf_flags >= 0 &&
-      TB * P->D < ((int64_t)1 << 28)) {
+      P->opt_handover && TB * P->D < ((int64_t)1 << 28)) {
     int hh[4], kk[4];
     for (int e = 0; e < 4; ++e) { hh[e] = P->enc[e].h; kk[e] = P->enc_d[e]; }
     proj_in_fold = seq_small_foldproj_supported(T, B, hh, kk, 4);
@@ -983,6 +1023,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     L.yhat_out = yhat_out ? yhat_out : W + P->yhat;
     L.y = y; L.losses = losses; L.train = train;
     L.seed = seed * 0x9E3779B97F4A7C15ull + P->calls;
+    L.tick = reinterpret_cast<const unsigned long long*>(P->tick_ptr(W));
   }
   // F1: encoder recurrences (up to MFM_MAX_SEQ per launch).  MFM_KL_EF at small batches: the four encoders' workgroups
   // also run their rows' latent chains (fold launch, lstm_seq_small.hip) and F2 disappears
@@ -993,7 +1034,11 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     ProjRole PR;
     memset(&PR, 0, sizeof(PR));
     PR.x = x; PR.ldx = P->D; PR.x_rows = (int)TB;
-    PR.flags = reinterpret_cast<unsigned*>(W + P->pf_flags); PR.epoch = (unsigned)P->calls;
+    PR.flags = reinterpret_cast<unsigned*>(W + P->pf_flags); PR.epoch = epoch_base(P->calls); PR.tick = P->tick_ptr(W);
+    // a consumer that gives up: status bit 0, NaN into the regulariser slot (what the module path returns as `kld`)
+    PR.ctl = P->ho_ctl(W, losses + 4, 1u);
+    PR.fault = (P->opt_fault == 1) ? 1 : 0;
+    if (PR.fault) P->opt_fault = 0;
     PR.zs = zs;
     PR.loss_ptr = zs.ptr[0]; PR.loss_n = (int)zs.n[0];
     PR.bf16 = c.precision ? 1 : 0;
@@ -1007,7 +1052,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     }
     int rc;
     { Timer _t(P, s, K_ENC_FWD); rc = seq_foldproj_launch(q, 4, T, B, L, params, PR, s); }
-    if (rc == MFM_OK) { folded = true; P->projfold_state = 1; P->fold_state = 1; if (PR.n_wt) P->wt_call = P->calls; }
+    if (rc == MFM_OK) { folded = true; P->projfold_state = 1; P->fold_state = 1; P->ever_handover = true; if (PR.n_wt) P->wt_call = P->calls; }
     else if (rc == MFM_ERR_UNSUPPORTED) {
       P->projfold_state = -1;
       const int rc0 = run_f0();
@@ -1143,6 +1188,11 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     if (rc == MFM_ERR_UNSUPPORTED) RUN(K_FC1_FWD, gemm_group_launch(g, 3, s, nullptr, me, 3, c.precision));
   }
   (void)pi;
+  // captured into a hipGraph: every replay advances the device half of the call counter (dropout streams, hand-over epochs)
+  if (capturing) {
+    hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned long long*>(P->tick_ptr(W)), (unsigned*)nullptr);
+    MFM_LAUNCH_CHECK("tick_kernel");
+  }
   return MFM_OK;
 }
 
@@ -1447,6 +1497,15 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
                                 "(the regulariser's gradient is formed inside the plan)");
   if (P->grads_prezeroed != grads) MFM_HIP_CHECK(hipMemsetAsync(grads, 0, (size_t)P->n_params * sizeof(float), s));
   P->grads_prezeroed = nullptr;
+  // the guard word of this gradient buffer (plan option "grad_guard_offset"): NaN while the plan's status word is set
+  float* const guard = (P->opt_guard >= 0 && P->opt_guard < P->n_params) ? grads + P->opt_guard : nullptr;
+  struct GuardAtExit {      // the role-workgroup launch does it itself; every other way out of this function: one tiny launch,
+    MfmPlan* P; float* W; float* guard; hipStream_t s; bool armed;      // only on plans that ever used a hand-over
+    ~GuardAtExit() {
+      if (armed && guard && P->ever_handover)
+        hipLaunchKernelGGL(guard_propagate_kernel, dim3(1), dim3(64), 0, s, P->status_ptr(W), guard);
+    }
+  } guard_at_exit{P, W, guard, s, true};
   const bool gen_on = (stage != 2), disc_on = (stage != 1);
   const bool seq_bf16 = P->seq_bf16;
   const bool st16 = P->st16;
@@ -1574,7 +1633,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       const float* eimg[4] = {imgs_on ? W + P->wt_img[0] : nullptr, imgs_on ? W + P->wt_img[1] : nullptr,
                               imgs_on ? W + P->wt_img[2] : nullptr, imgs_on ? W + P->wt_img[3] : nullptr};
       // B <= 32: the idle CUs of this launch run every weight-gradient product of the step (dw_role_dev.h); B5 disappears
-      if (!st16 && P->dwfold_state >= 0 && P->dw_table >= 0 && seq_small_folddw_supported(T, B) &&
+      if (!st16 && P->dwfold_state >= 0 && P->dw_table >= 0 && P->opt_handover && seq_small_folddw_supported(T, B) &&
           !getenv("MFM_DW_ONEPASS_MINROWS") && !getenv("MFM_DW_F32_MINROWS") && !(getenv("MFM_GEMM_TN") && atoi(getenv("MFM_GEMM_TN")) == 0)) {
         std::vector<MfmGemmDesc> all = tail;
         latent_products(all, false);
@@ -1587,12 +1646,22 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
         if (brc == MFM_OK) {
           LatentDev L2 = L;
           L2.grd_agent = 1;
-          DR.flags = reinterpret_cast<unsigned*>(W + P->dw_flags); DR.epoch = ++P->dw_epoch;
-          if (DR.epoch == 0) DR.epoch = ++P->dw_epoch;           // (0 is what a fresh workspace holds)
+          DR.flags = reinterpret_cast<unsigned*>(W + P->dw_flags); DR.epoch = epoch_base(++P->dw_epoch); DR.tick = P->dw_tick_ptr(W);
           DR.bf16 = c.precision ? 1 : 0;
-          DR.poison = grads;
+          // a block that gives up: status bit 1, NaN into the gradient guard (no guard word: into the first gradient)
+          DR.ctl = P->ho_ctl(W, guard ? guard : grads, 2u);
+          DR.fault = (P->opt_fault == 2) ? 1 : 0;
+          if (DR.fault) P->opt_fault = 0;
           { Timer _t(P, s, K_ENC_BWD); rc = seq_folddw_launch(q, 4, T, B, L2, params, grads, DR, s, imgs_on ? eimg : nullptr); }
-          if (rc == MFM_OK) { P->dwfold_state = 1; return MFM_OK; }      // every gradient of the step is on its way
+          if (rc == MFM_OK) {             // every gradient of the step is on its way
+            P->dwfold_state = 1; P->ever_handover = true;
+            guard_at_exit.armed = false;
+            if (stream_capturing(s)) {
+              hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, s, (unsigned long long*)nullptr, P->dw_tick_ptr(W));
+              MFM_LAUNCH_CHECK("tick_kernel");
+            }
+            return MFM_OK;
+          }
           if (rc != MFM_ERR_UNSUPPORTED) return rc;
         } else if (brc != MFM_ERR_UNSUPPORTED) return brc;
         P->dwfold_state = -1;
@@ -1847,6 +1916,9 @@ extern "C" int mfm_plan_create(const MfmPlanConfig* cfg, const int64_t* param_of
   }
   P->n_params = n_params_total;
   P->timing_mask = 0; P->timing_every = 1; P->pool_used = 0; P->calls = 0; P->grads_prezeroed = nullptr;
+  // MFM_SHARED_DEVICE=1 (several ranks / processes drive this GPU): the default of the "handover" option for plans created
+  // from now on; the host side sets the option itself where it can tell (train.py::_mark_shared_device)
+  if (const char* e = getenv("MFM_SHARED_DEVICE")) P->opt_handover = atoi(e) == 0;
   int rc = build(P);
   if (rc != MFM_OK) { delete P; return rc; }
   *out = P;
@@ -1882,6 +1954,46 @@ extern "C" int mfm_plan_init_workspace(MfmPlan* P, void* workspace, void* stream
   MFM_HIP_CHECK(hipMemcpyAsync(W + P->lat_items_off, P->lat_items.data(), P->lat_items.size() * sizeof(int),
                                hipMemcpyHostToDevice, s));
   return fill_launch(W + P->ones, (int64_t)P->T * P->B, 1.0f, s);
+}
+
+extern "C" int mfm_plan_set_option(MfmPlan* P, const char* key, int64_t value) {
+  if (!P || !key) { set_error("mfm_plan_set_option: null argument"); return MFM_ERR_ARG; }
+  if (!strcmp(key, "handover")) {
+    P->opt_handover = value != 0;
+    // (the launch-form states restart: "in use" must describe the launches the next call issues -- mfm_plan_kernel_flops)
+    if (P->projfold_state == 1 || !P->opt_handover) P->projfold_state = 0;
+    if (P->dwfold_state == 1 || !P->opt_handover) P->dwfold_state = 0;
+  }
+  else if (!strcmp(key, "handover_timeout_us")) { MFM_REQUIRE(value >= 1 && value <= 10000000, "mfm_plan_set_option: handover_timeout_us %lld", (long long)value); P->opt_timeout_us = value; }
+  else if (!strcmp(key, "grad_guard_offset")) { MFM_REQUIRE(value >= -1 && value < P->n_params, "mfm_plan_set_option: grad_guard_offset %lld outside the buffer of %lld elements", (long long)value, (long long)P->n_params); P->opt_guard = value; }
+  else if (!strcmp(key, "inject_fault")) { MFM_REQUIRE(value >= 0 && value <= 2, "mfm_plan_set_option: inject_fault %lld", (long long)value); P->opt_fault = (int)value; }
+  else { set_error("mfm_plan_set_option: unknown key '%s'", key); return MFM_ERR_ARG; }
+  return MFM_OK;
+}
+extern "C" int mfm_plan_get_option(const MfmPlan* P, const char* key, int64_t* value) {
+  if (!P || !key || !value) { set_error("mfm_plan_get_option: null argument"); return MFM_ERR_ARG; }
+  if (!strcmp(key, "handover")) *value = P->opt_handover;
+  else if (!strcmp(key, "handover_timeout_us")) *value = P->opt_timeout_us;
+  else if (!strcmp(key, "grad_guard_offset")) *value = P->opt_guard;
+  else if (!strcmp(key, "inject_fault")) *value = P->opt_fault;
+  // read-only: whether the last forward / backward of the plan ran on role workgroups
+  else if (!strcmp(key, "proj_roles_active")) *value = P->projfold_state == 1;
+  else if (!strcmp(key, "dw_roles_active")) *value = P->dwfold_state == 1;
+  else { set_error("mfm_plan_get_option: unknown key '%s'", key); return MFM_ERR_ARG; }
+  return MFM_OK;
+}
+extern "C" int mfm_plan_state_layout(const MfmPlan* P, int64_t* out) {
+  if (!P || !out) { set_error("mfm_plan_state_layout: null argument"); return MFM_ERR_ARG; }
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  const int64_t f = (int64_t)sizeof(float);
+  out[0] = P->losses * f; out[1] = (P->losses + MfmPlan::ST_STATUS) * f; out[2] = (P->losses + MfmPlan::ST_TICK) * f;
+  out[3] = (P->losses + MfmPlan::ST_DW_TICK) * f;
+  return MFM_OK;
+}
+extern "C" int mfm_plan_clear_status(MfmPlan* P, void* workspace, void* stream) {
+  if (!P || !workspace) { set_error("mfm_plan_clear_status: null argument"); return MFM_ERR_ARG; }
+  MFM_HIP_CHECK(hipMemsetAsync(P->status_ptr((float*)workspace), 0, sizeof(unsigned), (hipStream_t)stream));
+  return MFM_OK;
 }
 
 extern "C" int mfm_plan_forward(MfmPlan* P, const float* params, const float* x, const void* y, int train,
@@ -1941,7 +2053,8 @@ extern "C" int mfm_plan_train_step(MfmPlan* P, float* params, float* grads, floa
   // grouped GEMM launch ~1.5 us -- removed again, profiles/r02_adam_tail.txt)
   rc = backward(P, params, x, y, 0, (float*)workspace, grads, s);
   if (rc != MFM_OK) return rc;
-  RUN(K_ADAM, adam_launch(params, grads, adam_m, adam_v, P->n_params, step, lr, 0.9f, 0.999f, 1e-8f, grad_scale, s));
+  const float* guard = (P->opt_guard >= 0 && P->opt_guard < P->n_params) ? grads + P->opt_guard : nullptr;
+  RUN(K_ADAM, adam_launch(params, grads, adam_m, adam_v, P->n_params, step, lr, 0.9f, 0.999f, 1e-8f, grad_scale, s, guard));
   return MFM_OK;
 }
 
@@ -1960,7 +2073,8 @@ extern "C" int mfm_plan_train_step_staged(MfmPlan* P, float* params, float* grad
   if (rc != MFM_OK) return rc;
   rc = backward(P, params, x, y, stage, (float*)workspace, grads, s);
   if (rc != MFM_OK) return rc;
-  RUN(K_ADAM, adam_spans_launch(params, grads, adam_m, adam_v, spans, nspans, lr, 0.9f, 0.999f, 1e-8f, grad_scale, s));
+  const float* guard = (P->opt_guard >= 0 && P->opt_guard < P->n_params) ? grads + P->opt_guard : nullptr;
+  RUN(K_ADAM, adam_spans_launch(params, grads, adam_m, adam_v, spans, nspans, lr, 0.9f, 0.999f, 1e-8f, grad_scale, s, guard));
   return MFM_OK;
 }
 

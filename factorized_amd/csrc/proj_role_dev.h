@@ -28,10 +28,31 @@ constexpr int PROJ_ROLE_PW = 4 * 96 + 4;  // floats per wave in the partial-tile
 
 struct ProjRoleEnc { const float* w; const float* b_ih; const float* b_hh; int k_off, k, cb_begin, ncb; };
 constexpr int PROJ_ROLE_WT = 7;
+// What a consumer does when its producer does not show up (shared by the projection and weight-gradient hand-overs): after
+// `timeout` ticks of the 100 MHz wall clock it gives up, ORs `bit` into the plan's sticky STATUS word (the host reads it at its
+// next sync, raises and switches the plan to separate launches; every backward of a plan whose status is non-zero poisons the
+// gradient guard, so the optimizer skips the step: include/mfm_hip.h, plan options) and stores a NaN into `poison`.
+struct HoCtl { unsigned* status; float* poison; long long timeout; unsigned bit; };
+__device__ __forceinline__ void ho_give_up(const HoCtl& c) {
+  if ((threadIdx.x & 63) == 0) {
+    if (c.status) __hip_atomic_fetch_or(c.status, c.bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c.poison) __hip_atomic_store(c.poison, __builtin_nanf(""), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// epoch of a launch = host part (a function of the plan's call counter) + a device word that only captured hipGraphs advance
+// (one tick node per replay: plan.hip), never 0 (what a fresh workspace holds)
+__device__ __forceinline__ unsigned ho_epoch(unsigned base, const unsigned* tick) {
+  const unsigned e = base + (tick ? *tick : 0u);
+  return e ? e : 0x5bd1e995u;
+}
+
 struct ProjRole {
   const float* x; int ldx; int x_rows;    // x[T * B, ldx]
   int n_role, groups, kstride;            // groups = n_role / 32
-  unsigned* flags; unsigned epoch;        // flags[(e * T + t) * 16 + block]
+  unsigned* flags; unsigned epoch;        // flags[(e * T + t) * 16 + block]; epoch: host part (ho_epoch)
+  const unsigned* tick;                   // device part of the epoch (low word of the plan's replay counter)
+  HoCtl ctl;                              // consumer side: time-out, status word, poison
+  int fault;                              // fault injection (tests): role workgroup 0 does not raise its first flag
   float* loss_ptr; int loss_n;            // loss slots: cleared with agent-scope stores before any flag of t = 0 is raised
   int bf16;                               // bf16 plans: x and W_ih rounded to bf16 (RNE) on the way into LDS, fp32 accumulation
   ProjRoleEnc e[4];
@@ -60,22 +81,19 @@ __device__ __forceinline__ unsigned proj_flags_load(const unsigned* f, int ncb) 
   const int lane = threadIdx.x & 63;
   return ld_agent_u(f + (lane < ncb ? lane : 0));
 }
-// spin until ready; gives up after ~50 ms so that a broken producer shows up as a parity failure, not as a hung GPU
-// (a wait that gave up also stores a NaN into `poison` -- a loss slot: results that did not wait for their inputs must not look valid)
-__device__ __forceinline__ void proj_flags_wait(const unsigned* f, unsigned v, unsigned epoch, int ncb, float* poison) {
+// spin until ready; gives up after ctl.timeout (default ~50 ms) so that a broken or blocked producer becomes a reported,
+// survivable failure (ho_give_up), not a hung GPU and not a plausible-looking result
+__device__ __forceinline__ void proj_flags_wait(const unsigned* f, unsigned v, unsigned epoch, int ncb, const HoCtl& ctl) {
   if (proj_flags_ready(v, epoch, ncb)) return;
   const long long t0 = wall_clock64();
   do {
     __builtin_amdgcn_s_sleep(2);
     v = proj_flags_load(f, ncb);
-    if (wall_clock64() - t0 >= 5000000ll) {
-      if (poison && (threadIdx.x & 63) == 0) __hip_atomic_store(poison, __builtin_nanf(""), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
+    if (wall_clock64() - t0 >= ctl.timeout) { ho_give_up(ctl); return; }
   } while (!proj_flags_ready(v, epoch, ncb));
 }
 
-__device__ __forceinline__ void proj_role_body(const SeqLaunch& L, const ProjRole& PR, float* lds) {
+__device__ __forceinline__ void proj_role_body(const SeqLaunch& L, const ProjRole& PR, const unsigned epoch, float* lds) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = blockIdx.x;
   const int slot = r & (PROJ_ROLE_SLOTS - 1), grp = r >> 5;
@@ -186,7 +204,8 @@ __device__ __forceinline__ void proj_role_body(const SeqLaunch& L, const ProjRol
       if (tn < T) park(Xs + (cur ^ 1) * (PROJ_ROLE_CB * ks), rx);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every store of this thread has been acknowledged
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(PR.flags + ((int64_t)e * T + t) * PROJ_ROLE_FLAGS + cbl, PR.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0 && !(PR.fault && r == 0 && t == grp))
+        __hip_atomic_store(PR.flags + ((int64_t)e * T + t) * PROJ_ROLE_FLAGS + cbl, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       cur ^= 1;
     }
   }

@@ -11,6 +11,7 @@ hot loop mfm_mosi.py:424-442).
 PyTorch is used for device memory, streams and torch.distributed only.
 """
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -206,12 +207,18 @@ class FlatLayout:
         self.offsets = OrderedDict((n, placed[n]) for n in self.shapes)
         # (offset, numel, shape) in state_dict order: per-tensor views of any buffer with this layout
         self.slots = [(placed[n], int(np.prod(self.shapes[n])), tuple(self.shapes[n])) for n in self.shapes]
+        # one spare granule behind the last tensor: element `guard` of a GRADIENT buffer with this layout is the guard word of
+        # the guarded Adam launches (include/mfm_hip.h): the fused plan stores a NaN there when an in-launch hand-over of the
+        # step gave up, the optimizer then leaves the parameters alone; being part of the buffer it rides through the
+        # data-parallel all-reduce, so every rank takes the same decision
+        self.guard = cur
+        cur += ALIGN
         self.total = cur
         self.numel = sum(int(np.prod(s)) for s in self.shapes.values())
         # contiguous runs of tensors that belong to the same staged-training group, in physical order:
         # [(group, begin, end)] with 64-float aligned bounds (Adam over spans, mfm_adam_flat_spans)
         self.group_spans = []
-        ends = [placed[n] for n in order[1:]] + [cur]
+        ends = [placed[n] for n in order[1:]] + [self.guard]
         for name, end in zip(order, ends):
             g = _staged_group(name)
             if self.group_spans and self.group_spans[-1][0] == g:
@@ -273,9 +280,30 @@ class _Plan:
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=engine.device)
         _lib.check(_lib.lib().mfm_plan_init_workspace(handle, _ptr(self.workspace), _stream()),
                    "mfm_plan_init_workspace")
-        self.losses = torch.zeros(_lib.MFM_LOSS_SLOTS, dtype=torch.float32, device=engine.device)
+        self.set_option("grad_guard_offset", engine.layout.guard)
+        self.set_option("handover", 1 if engine.handover else 0)
+        if engine.handover_timeout_us is not None:
+            self.set_option("handover_timeout_us", int(engine.handover_timeout_us))
+        # the plan's device-side state lives in its workspace (mfm_plan_state_layout): the loss slots and, right behind them,
+        # the sticky status word of the in-launch hand-overs -- one 64-byte block, one copy when the host looks at the losses
+        lay = (C.c_int64 * 8)()
+        _lib.check(_lib.lib().mfm_plan_state_layout(handle, lay), "mfm_plan_state_layout")
+        assert lay[1] == lay[0] + 4 * _lib.MFM_LOSS_SLOTS
+        wf = self.workspace.view(torch.float32)
+        self.state = wf[lay[0] // 4: lay[0] // 4 + 16]
+        self.losses = self.state[:_lib.MFM_LOSS_SLOTS]
+        self.tick = self.workspace[lay[2]: lay[2] + 8].view(torch.int64)          # replay counters (captured steps)
+        self.dw_tick = self.workspace[lay[3]: lay[3] + 4].view(torch.int32)
         self.fwd_serial = 0        # forwards run on this workspace so far (autograd path: whose activations it holds)
         self.consumed = False      # the last forward's activations were overwritten by a backward
+
+    def set_option(self, key, value):
+        _lib.check(_lib.lib().mfm_plan_set_option(self.handle, key.encode(), int(value)), "mfm_plan_set_option(%s)" % key)
+
+    def get_option(self, key):
+        v = C.c_int64(0)
+        _lib.check(_lib.lib().mfm_plan_get_option(self.handle, key.encode(), C.byref(v)), "mfm_plan_get_option(%s)" % key)
+        return int(v.value)
 
     def __del__(self):
         try:
@@ -317,6 +345,13 @@ class MFMEngine:
         self.precision = precision
         self.seed = 1234
         self._plans = {}
+        # In-launch hand-overs of the B <= 32 step (role workgroups, csrc/proj_role_dev.h / dw_role_dev.h): on by default; they
+        # need the launch to have the GPU to itself.  A consumer that gives up waiting raises the plan's status word and poisons
+        # the gradient guard (the optimizer skips the step); check_status() / loss_dict() then raise and switch every plan of
+        # this engine to the separate launches for the rest of the run.
+        self.handover = os.environ.get("MFM_SHARED_DEVICE", "0") in ("", "0")
+        self.handover_timeout_us = None      # None = the library's default (50 ms)
+        self.handover_failures = 0
         # Staged training (train_beta_vae): Adam step counters per tensor group.  "frozen" = torch >= 2 semantics
         # (zero_grad sets .grad to None, Adam skips such parameters: a group without a gradient in the current
         # stage keeps its values and moments); "legacy" = torch 0.4 semantics (zero_grad leaves zero tensors
@@ -355,6 +390,38 @@ class MFMEngine:
             p = _Plan(self, int(T), int(B), self.reg_scale)
             self._plans[key] = p
         return p
+
+    def set_handover(self, on):
+        """Allow / forbid the in-launch hand-overs on every plan of this engine (existing and future ones)."""
+        self.handover = bool(on)
+        for p in self._plans.values():
+            p.set_option("handover", 1 if on else 0)
+
+    def check_status(self, state_host=None, raise_on_error=True):
+        """Look at the status words of this engine's plans (synchronises unless `state_host` -- a host copy of one plan's
+        state block, (plan, ndarray) -- is given).  A non-zero word means a hand-over inside a launch gave up waiting (another
+        process / stream kept its producers off the GPU): the steps since then were skipped by the optimizer.  The word is
+        cleared, the hand-overs are switched off for the rest of the run (separate launches: nothing can wait any more) and
+        MfmError is raised; the caller may catch it and carry on training."""
+        bad = 0
+        items = [state_host] if state_host is not None else [(p, None) for p in self._plans.values()]
+        for p, host in items:
+            if host is None:
+                host = p.state.detach().cpu().numpy()
+            word = int(host[_lib.MFM_LOSS_SLOTS:_lib.MFM_LOSS_SLOTS + 1].view(np.uint32)[0])
+            if word:
+                bad |= word
+                _lib.check(_lib.lib().mfm_plan_clear_status(p.handle, _ptr(p.workspace), _stream()), "mfm_plan_clear_status")
+        if bad:
+            self.handover_failures += 1
+            self.set_handover(False)
+            if raise_on_error:
+                raise _lib.MfmError(
+                    "an in-launch hand-over of the fused step gave up waiting (status 0x%x: %s): other work on this GPU kept the "
+                    "producer workgroups off the device.  The affected steps were NOT applied to the parameters; the engine now "
+                    "uses separate launches (set_handover(True) re-enables the role workgroups)."
+                    % (bad, " + ".join(n for b, n in ((1, "projections"), (2, "weight gradients")) if bad & b)))
+        return bad
 
     def _gauss_for(self, p, B):
         """variant "mmd": hand the plan the N(0,1) sample loss_MMD draws per forward (reference mfm_model.py:26)."""
@@ -516,9 +583,10 @@ class MFMEngine:
         self.step_count += 1
         for g in self.group_steps:
             self.group_steps[g] = self.step_count
-        _lib.check(_lib.lib().mfm_adam_flat(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m),
-                                            _ptr(self.adam_v), self.layout.total, self.step_count, lr,
-                                            0.9, 0.999, 1e-8, grad_scale, _stream()), "mfm_adam_flat")
+        guard = C.c_void_p(self.grads.data_ptr() + 4 * self.layout.guard)
+        _lib.check(_lib.lib().mfm_adam_flat_guarded(_ptr(self.params), _ptr(self.grads), _ptr(self.adam_m),
+                                                    _ptr(self.adam_v), self.layout.total, self.step_count, lr,
+                                                    0.9, 0.999, 1e-8, grad_scale, guard, _stream()), "mfm_adam_flat_guarded")
 
     def latent_record(self, T, B):
         """(activation record, gradient record, layout dict) of the latent stack for the plan at (T,B): views into
@@ -581,8 +649,18 @@ class MFMEngine:
                     h2=v(5, TB, n2), m2=v(6, TB, n2), chat=v(7, TB, M), mem_out=v(8, B, M), zyin=v(9, B, nzy))
 
     def loss_dict(self, losses):
-        """Host view of the loss slots (synchronises)."""
-        l = losses.detach().cpu().numpy()
+        """Host view of the loss slots (synchronises).  When `losses` is a plan's own loss tensor the same copy brings the
+        plan's status word along (check_status)."""
+        plan = None
+        for p in self._plans.values():
+            if p.losses.data_ptr() == losses.data_ptr():
+                plan = p
+        if plan is not None:
+            st = plan.state.detach().cpu().numpy()
+            self.check_status((plan, st))
+            l = st[:_lib.MFM_LOSS_SLOTS]
+        else:
+            l = losses.detach().cpu().numpy()
         c = self.cfg
         gen = c["lda_xl"] * l[1] + c["lda_xa"] * l[2] + c["lda_xv"] * l[3]
         return dict(disc=float(l[0]), gen_l=float(l[1]), gen_a=float(l[2]), gen_v=float(l[3]), gen=float(gen),

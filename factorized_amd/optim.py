@@ -91,15 +91,18 @@ class Adam(torch.optim.Optimizer):
         stream = C.c_void_p(torch._C._cuda_getCurrentRawStream(eng.params.device.index))
         ptr = lambda t: C.c_void_p(t.data_ptr())
         steps = st["steps"]
+        # guard word of the flat gradient buffer: the plan's backward stores a NaN there when a hand-over inside one of its
+        # launches gave up -- the launch below then leaves parameters and moments alone (engine.check_status() reports it)
+        guard = C.c_void_p(gflat.data_ptr() + 4 * eng.layout.guard)
         if present.all() and (steps == steps[0]).all():
             steps += 1
-            _lib.check(L.mfm_adam_flat(ptr(eng.params), ptr(gflat), ptr(st["m"]), ptr(st["v"]), eng.layout.total, int(steps[0]),
-                                       lr, b1, b2, eps, 1.0, stream), "mfm_adam_flat")
+            _lib.check(L.mfm_adam_flat_guarded(ptr(eng.params), ptr(gflat), ptr(st["m"]), ptr(st["v"]), eng.layout.total,
+                                               int(steps[0]), lr, b1, b2, eps, 1.0, guard, stream), "mfm_adam_flat_guarded")
             return True
         # some tensors have no gradient (stage losses, unused layers): contiguous runs of present tensors with equal
         # step counts become spans (tensor starts are 64-float aligned: span bounds are multiples of 4)
         order = np.argsort([o for o, _, _ in eng.layout.slots])
-        starts = [eng.layout.slots[i][0] for i in order] + [eng.layout.total]
+        starts = [eng.layout.slots[i][0] for i in order] + [eng.layout.guard]
         spans = []
         for k, i in enumerate(order):
             if not present[i]:
@@ -115,8 +118,8 @@ class Adam(torch.optim.Optimizer):
             arr = (_lib.AdamSpan * len(part))()
             for j, (b, e_, s_) in enumerate(part):
                 arr[j].begin, arr[j].end, arr[j].step = b, e_, s_
-            _lib.check(L.mfm_adam_flat_spans(ptr(eng.params), ptr(gflat), ptr(st["m"]), ptr(st["v"]), arr, len(part), lr, b1, b2,
-                                             eps, 1.0, stream), "mfm_adam_flat_spans")
+            _lib.check(L.mfm_adam_flat_spans_guarded(ptr(eng.params), ptr(gflat), ptr(st["m"]), ptr(st["v"]), arr, len(part), lr, b1,
+                                                     b2, eps, 1.0, guard, stream), "mfm_adam_flat_spans_guarded")
         return True
 
     def _fallback_step(self, rest):

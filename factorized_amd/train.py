@@ -66,8 +66,9 @@ class DeviceDataset:
 
 def _mark_shared_device(engine):
     """Ranks that drive the SAME GPU (one-device test set-ups) must not use the in-launch hand-overs of the small-batch step
-    (csrc/lstm_seq_small.hip, shared_device(): two queues' launches can block each other's producers): compare (host, device)
-    across the ranks and export MFM_SHARED_DEVICE=1 when two ranks collide.  One process per GPU -- the deployment -- is unaffected."""
+    (plan option "handover": two queues' launches can block each other's producers): compare (host, device) across the ranks and,
+    when two ranks collide, switch the hand-overs of this engine off (and export MFM_SHARED_DEVICE=1, the default for engines
+    created later).  One process per GPU -- the deployment -- is unaffected."""
     try:
         import socket
         import torch
@@ -84,7 +85,9 @@ def _mark_shared_device(engine):
         allv = [None] * dist.get_world_size()
         dist.all_gather_object(allv, mine)
         if len(set(allv)) < len(allv):
-            os.environ["MFM_SHARED_DEVICE"] = "1"
+            os.environ["MFM_SHARED_DEVICE"] = "1"          # (engines / plans created from now on)
+            if hasattr(engine, "set_handover"):
+                engine.set_handover(False)                 # this engine and its existing plans
     except Exception:
         pass
 

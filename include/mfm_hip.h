@@ -39,7 +39,7 @@ extern "C" {
 #define MFM_ERR_HIP (-2)
 #define MFM_ERR_UNSUPPORTED (-3)
 
-#define MFM_ABI_VERSION 2
+#define MFM_ABI_VERSION 3
 
 int mfm_abi_version(void);
 const char* mfm_last_error(void);
@@ -215,10 +215,20 @@ int mfm_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, int32
  * treatment of parameters whose .grad is None (skipped; per-parameter step counters), which staged training
  * relies on: train_beta_vae (reference mfm_mosi.py:278-281, 346-358) trains gen+reg first -- the classifier gets no
  * gradient -- then disc+reg -- the decoders and the modality z->f MLPs get none.  begin/end are multiples of 4. */
+/* Guarded forms (ABI 3): `guard` is an optional device pointer to ONE float -- by convention a spare element of the gradient
+ * buffer itself, so that it travels through the data-parallel all-reduce with the gradients.  The kernels read it first and
+ * leave p, m and v untouched unless it is exactly 0.0f.  The fused plan stores a NaN there when an in-launch hand-over of the
+ * step gave up waiting (plan option "grad_guard_offset", below): a step whose gradients cannot be trusted does not reach the
+ * parameters.  guard == NULL: the unguarded update above. */
+int mfm_adam_flat_guarded(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr,
+                          float beta1, float beta2, float eps, float grad_scale, const float* guard, void* stream);
+
 #define MFM_ADAM_MAX_SPANS 8
 typedef struct MfmAdamSpan { int64_t begin, end; int32_t step; int32_t reserved; } MfmAdamSpan;
 int mfm_adam_flat_spans(float* p, const float* g, float* m, float* v, const MfmAdamSpan* spans /*host*/, int32_t nspans,
                         float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+int mfm_adam_flat_spans_guarded(float* p, const float* g, float* m, float* v, const MfmAdamSpan* spans /*host*/, int32_t nspans,
+                                float lr, float beta1, float beta2, float eps, float grad_scale, const float* guard, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Gradient all-reduce of the data-parallel step (the reference has no multi-GPU
@@ -243,6 +253,12 @@ int mfm_p2p_allreduce(void* handle, float* buf /*16-byte aligned*/, int64_t n /*
  * kernel as each reduced slice arrives: all-reduce + optimizer in one launch.  `grads` still receives the sum. */
 int mfm_p2p_allreduce_adam(void* handle, float* grads, float* p, float* m, float* v, int64_t n, int32_t step,
                            float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* ABI 3: the same with a guard word (mfm_adam_flat_guarded): element `guard_index` of `grads` (-1: none).  A rank whose guard
+ * is raised says so in its first-push flags; every rank then completes the exchange (the sum carries the NaN too) but NO rank
+ * touches p, m, v -- the replicas skip the same steps and stay bit-identical. */
+int mfm_p2p_allreduce_adam_guarded(void* handle, float* grads, float* p, float* m, float* v, int64_t n, int32_t step,
+                                   float lr, float beta1, float beta2, float eps, float grad_scale, int64_t guard_index,
+                                   void* stream);
 int mfm_p2p_status(void* handle, int32_t* timed_out /*1 if any wait gave up since create (synchronises)*/);
 void mfm_p2p_destroy(void* handle);
 
@@ -342,6 +358,31 @@ int mfm_plan_train_step_staged(MfmPlan* plan, float* params, float* grads, float
                                const float* x, const void* y, uint64_t seed, int32_t stage,
                                const MfmAdamSpan* spans /*host*/, int32_t nspans, float lr, float grad_scale,
                                void* workspace, float* losses, void* stream);
+
+/* ---- per-plan switches (ABI 3).  Everything a plan decides is decided from its sizes; these are the switches a caller (or
+ * a test) may set explicitly.  Unknown keys return MFM_ERR_ARG.
+ *   "handover"            1 (default): B <= 32 plans of MFM_KL_EF run their input projections and weight gradients on role
+ *                         workgroups INSIDE the encoder launches (in-launch hand-overs; the launch needs the GPU to itself).
+ *                         0: separate launches, no workgroup ever waits for another one.  The host flips it to 0 when a
+ *                         hand-over timed out (mfm_plan_status) or when several ranks share one device.
+ *   "handover_timeout_us" how long a consumer spins before it gives up (default 50000).
+ *   "grad_guard_offset"   element offset inside the gradient buffer of the guard word of mfm_adam_flat_guarded (default -1:
+ *                         none; a wait that gives up then stores its NaN into grads[0]).  With an offset set, the plan's own
+ *                         Adam launches are guarded, and every backward stores a NaN there while the status word is non-zero.
+ *   "inject_fault"        fault injection for tests, one shot: 1 = one projection producer of the next forward does not raise
+ *                         its flag; 2 = one BPTT workgroup of the next backward does not stamp its last gate gradients.
+ *                         The waiting side must time out, set the status word and poison the guard. */
+int mfm_plan_set_option(MfmPlan* plan, const char* key, int64_t value);
+int mfm_plan_get_option(const MfmPlan* plan, const char* key, int64_t* value);
+
+/* Device-side state of a plan inside its workspace: out[0] byte offset of the plan's own loss slots [MFM_LOSS_SLOTS] floats
+ * (used when `losses` is NULL), out[1] byte offset of the STATUS word (uint32, right behind them: 0 = fine; bit 0 a consumer of
+ * projections gave up waiting, bit 1 a weight-gradient block did; sticky -- only the host clears it, mfm_plan_clear_status),
+ * out[2] byte offset of the replay counter (uint64) and out[3] of the backward replay counter (uint32): device words a
+ * captured hipGraph advances on every replay (the dropout streams and the hand-over epochs add them), out[4..7] reserved. */
+int mfm_plan_state_layout(const MfmPlan* plan, int64_t* out /*[8]*/);
+/* enqueue the clearing of the status word */
+int mfm_plan_clear_status(MfmPlan* plan, void* workspace, void* stream);
 
 /* Where the latent stack keeps its per-row record inside the workspace (tests and tuning aids: dropout masks and
  * pre-activation gradients can be read back from the workspace tensor).  out[0] byte offset of the activation
