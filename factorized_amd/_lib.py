@@ -100,6 +100,8 @@ _SIGS = {
                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mfm_adam_flat_guarded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                         C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "mfm_adam_flat_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "mfm_adam_flat_spans_guarded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AdamSpan), C.c_int32,
                                               C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "mfm_p2p_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_void_p)]),

@@ -136,6 +136,50 @@ int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, int ste
   return MFM_OK;
 }
 
+// ---------------------------------------------------------------- Adam with its step count and learning rate in device memory
+// A captured hipGraph freezes kernel arguments: the bias corrections of adam_kernel (functions of the step count, formed on the
+// host) would be those of the capture call on every replay.  Here thread 0 of each workgroup forms them from a device counter
+// (double precision, like the host path), and a one-thread launch behind it advances the counter -- unless the guard says the
+// step was skipped.
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                       float beta1, float beta2, float eps, float grad_scale,
+                                                       const int* __restrict__ step_dev, const float* __restrict__ lr_dev,
+                                                       const float* __restrict__ guard) {
+  if (guard && !(guard[0] == 0.0f)) return;
+  __shared__ float sh[2];
+  if (threadIdx.x == 0) {
+    const double step = (double)(*step_dev + 1);
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    sh[0] = (float)((double)*lr_dev / bc1);
+    sh[1] = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  const float step_size = sh[0], bc2_sqrt = sh[1];
+  const int64_t n4 = n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gg = gv[j] * grad_scale;
+      mv[j] = mv[j] + (1.0f - beta1) * (gg - mv[j]);
+      vv[j] = vv[j] * beta2 + (1.0f - beta2) * gg * gg;
+      const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+      pv[j] = pv[j] - step_size * mv[j] / denom;
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+}
+__global__ void adam_step_tick_kernel(int* step_dev, const float* guard) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && !(guard && !(guard[0] == 0.0f))) *step_dev += 1;
+}
+
 // ---------------------------------------------------------------- Adam over spans of the flat buffer
 // Staged training (train_beta_vae, reference mfm_mosi.py:278-281) leaves whole groups of tensors without a
 // gradient; torch.optim.Adam skips a parameter whose .grad is None and keeps a step counter PER PARAMETER, so a
@@ -254,6 +298,22 @@ extern "C" int mfm_adam_flat_spans_guarded(float* p, const float* g, float* m, f
                                            float lr, float beta1, float beta2, float eps, float grad_scale, const float* guard,
                                            void* stream) {
   return mfm::adam_spans_launch(p, g, m, v, spans, nspans, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream, guard);
+}
+
+extern "C" int mfm_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, int32_t* step_dev, const float* lr_dev,
+                                 float beta1, float beta2, float eps, float grad_scale, const float* guard, void* stream) {
+  using namespace mfm;
+  MFM_REQUIRE(p && g && m && v && step_dev && lr_dev && n > 0 && (n & 3) == 0, "mfm_adam_flat_dev: bad arguments (n=%lld, a multiple of 4)", (long long)n);
+  MFM_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "mfm_adam_flat_dev: buffers must be 16-byte aligned");
+  int64_t nb = ((n >> 2) + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3((int)nb), dim3(256), 0, s, p, g, m, v, n, beta1, beta2, eps, grad_scale,
+                     (const int*)step_dev, lr_dev, guard);
+  MFM_LAUNCH_CHECK("adam_dev_kernel");
+  hipLaunchKernelGGL(adam_step_tick_kernel, dim3(1), dim3(64), 0, s, (int*)step_dev, guard);
+  MFM_LAUNCH_CHECK("adam_step_tick_kernel");
+  return MFM_OK;
 }
 
 extern "C" int mfm_adam_flat_spans(float* p, const float* g, float* m, float* v, const MfmAdamSpan* spans, int32_t nspans,

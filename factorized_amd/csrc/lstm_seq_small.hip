@@ -33,6 +33,15 @@
 
 namespace mfm {
 
+// Barrier that also waits for this wave's outstanding GLOBAL stores.  `__syncthreads()` alone does not: its workgroup-scope
+// release needs no vmcnt wait on gfx950 outside threadgroup-split mode (the waves of a workgroup share one L1), so a flag
+// raised right behind it can overtake the data it announces -- measured round 4: 32 wrong weight gradients in 6000 steps at
+// T <= 2, always the smallest encoder, none with the wait (profiles/r04_handover_safety.txt).
+__device__ __forceinline__ void sync_stores() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
@@ -713,7 +722,7 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
   step(0);
   if (dec && bvalid && d.d_h_init && mu < h) d.d_h_init[(int64_t)b * d.ld_dinit + mu] = dh_rec;
   if constexpr (PUB) {
-    __syncthreads();                   // (waits for every outstanding store of every wave)
+    sync_stores();                     // every dA store of every wave has been acknowledged
     if (tid == 0 && !skip_final_stamp) dwr_stamp(stamp, epoch);      // (skipped only by the fault injection of the tests)
   }
 }
@@ -858,7 +867,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_fold_kernel(const SeqLaun
   const int tile = bid - d.block_begin;          // == batch row (one-row tiles)
   if constexpr (BWD) {
     latent_bwd_row_body<false>(LD, params, grads, tile, di, lds);
-    __syncthreads();        // d h_T of this (row, encoder) is in memory (and the LDS is free) before the BPTT reads it
+    sync_stores();           // d h_T of this (row, encoder) is in memory (and the LDS is free) before the BPTT reads it
   }
 #define MFM_ONE(IDX, KK)                                                        \
   if (KK > 0 && di == IDX) {                                                    \
@@ -868,7 +877,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_fold_kernel(const SeqLaun
   MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3)
 #undef MFM_ONE
   if constexpr (!BWD) {
-    __syncthreads();        // every store of the last time step has been acknowledged: h_T of this row is readable
+    sync_stores();           // every store of the last time step has been acknowledged: h_T of this row is readable
     latent_fwd_row_body<false>(LD, params, tile, di, lds, true);
   }
 }
@@ -902,7 +911,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_foldproj_kernel(const Seq
       proj_flags_wait(f0, proj_flags_load(f0, PR.e[e].ncb), epoch, PR.e[e].ncb, PR.ctl);
     }
   }
-  __syncthreads();        // every store of the last time step has been acknowledged: h_T of this row is readable
+  sync_stores();           // every store of the last time step has been acknowledged: h_T of this row is readable
   latent_fwd_row_body<false>(LD, params, tile, di, lds, true);
 }
 
@@ -926,7 +935,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_folddw_kernel(const SeqLa
   const SeqDev& d = L.d[di];
   const int tile = bid - d.block_begin;          // == batch row (one-row tiles)
   latent_bwd_row_body<false>(LD, params, grads, tile, di, lds);
-  __syncthreads();        // d h_T of this (row, encoder) is in memory (and the LDS is free) before the BPTT reads it
+  sync_stores();           // d h_T of this (row, encoder) is in memory (and the LDS is free) before the BPTT reads it
   if (threadIdx.x == 0) dwr_stamp(DR.flags + 4 * L.T * DWR_ROWS + di * L.B + tile, epoch);
   unsigned* stamp = DR.flags + (int64_t)di * L.T * DWR_ROWS + tile;
   const bool fault = DR.fault != 0 && bid == 0;

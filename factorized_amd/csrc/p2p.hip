@@ -114,6 +114,9 @@ __device__ __forceinline__ bool wait_flags(const int* flags, int stride, int W, 
 // every wave waits for its own stores to be acknowledged, then ONE wave does the system-scope release (an L2
 // write-back on gfx950: once per workgroup, not once per wave) and raises the flags
 __device__ __forceinline__ void publish(int* const* flags, int slot, int W, int epoch, int bad = 0) {
+  // (explicit: a workgroup-scope release needs no vmcnt wait on gfx950 outside threadgroup-split mode, so the fence alone
+  // would let the flag below overtake the other waves' stores -- the hole found in the role-workgroup hand-overs, round 4)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   if (threadIdx.x < 64) {

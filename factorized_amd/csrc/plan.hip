@@ -730,7 +730,7 @@ static int mfn_forward(MfmPlan* P, const float* params, int train, uint64_t seed
   const int prec = c.precision;
   GemmEpiSet es;
   memset(&es, 0, sizeof(es));
-  es.seed = seed * 0x9E3779B97F4A7C15ull + P->calls; es.train = train;
+  es.seed = seed * 0x9E3779B97F4A7C15ull + P->calls * 0xD1B54A32D192ED03ull; es.train = train;
   es.tick = reinterpret_cast<const unsigned long long*>(P->tick_ptr(W));
   MfnAttFused F;
   if (mfn_fused_desc(P, params, W, F)) {
@@ -1022,7 +1022,9 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     L.rec = W + P->lat_rec;
     L.yhat_out = yhat_out ? yhat_out : W + P->yhat;
     L.y = y; L.losses = losses; L.train = train;
-    L.seed = seed * 0x9E3779B97F4A7C15ull + P->calls;
+    // (+ the replay counter, added by the kernels; the large odd stride keeps eager calls and replays of captured steps on
+    // distinct streams)
+    L.seed = seed * 0x9E3779B97F4A7C15ull + P->calls * 0xD1B54A32D192ED03ull;
     L.tick = reinterpret_cast<const unsigned long long*>(P->tick_ptr(W));
   }
   // F1: encoder recurrences (up to MFM_MAX_SEQ per launch).  MFM_KL_EF at small batches: the four encoders' workgroups

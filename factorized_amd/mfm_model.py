@@ -418,6 +418,17 @@ class _FusedEngineMixin:
             self._grad_present = np.ones(len(self._plist), dtype=bool)
         self._register_params()
 
+    def _fast_ok(self):
+        """The flat-gradient path bypasses autograd for the parameters: every tensor gets a gradient view and the fused optimizer
+        updates it.  That is wrong for a frozen parameter (requires_grad=False must stay without a gradient and untouched) and
+        invisible to parameter hooks, so both fall back to the per-tensor autograd path (`fast_grads = False` semantics)."""
+        if not self.fast_grads:
+            return False
+        for p in self._plist:
+            if not p.requires_grad or p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
+                return False
+        return True
+
     def _flat_ok(self):
         if self._engine is None:
             return False
@@ -663,7 +674,7 @@ class MFM_KL_EF(_FusedEngineMixin, nn.Module):
         if not (x.dtype == torch.float32 and x.is_contiguous()):
             x = x.contiguous().float()
         _ = self.engine
-        if self.fast_grads:
+        if self._fast_ok():
             if self._flat_leaf is None or self._flat_leaf.device != x.device:
                 self._flat_leaf = torch.zeros((), device=x.device, requires_grad=True)
             x_l_hat, x_a_hat, x_v_hat, y_hat, kld = _KLEFFastFn.apply(x, self, self._flat_leaf)
@@ -1146,8 +1157,8 @@ class _FactorizedMFN(_FusedEngineMixin, nn.Module):
 
     def forward(self, x):
         _require_cuda(x, "%s.forward" % type(self).__name__)
-        if (self._use_kl and self.fused_forward and self.fast_grads and not x.requires_grad
-                and not torch.cuda.is_current_stream_capturing()):
+        # (capturable since ABI 3: the plan's dropout streams and hand-over epochs add device words a captured step advances)
+        if self._use_kl and self.fused_forward and self._fast_ok() and not x.requires_grad:
             if not (x.dtype == torch.float32 and x.is_contiguous()):
                 x = x.contiguous().float()
             _ = self.engine

@@ -38,15 +38,22 @@ def _owner(p):
 
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, capturable=False):
         if weight_decay != 0 or amsgrad:
             raise ValueError("factorized_amd.optim.Adam: weight_decay / amsgrad are not used by the reference and not built")
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False)
         super().__init__(params, defaults)
-        self._fused = {}            # id(module) -> state of a fused model: flat moments, per-tensor step counts
+        import weakref
+        # module -> state of a fused model: flat moments, per-tensor step counts (weak keys: a model that is gone takes its
+        # optimizer state with it)
+        self._fused = weakref.WeakKeyDictionary()
         self._fallback = None       # stock torch.optim.Adam over everything that is not fused
         self._fallback_ids = None
         self._fm_cache = {}
+        self._pending_fused = None  # fused states of a load_state_dict() waiting for their models' first step
+        # capturable=True (torch.optim.Adam's flag): step count and learning rate of the fused update live in device memory
+        # (mfm_adam_flat_dev), so a whole training step can be captured into a hipGraph and replayed (train.GraphedModuleStep)
+        self._capturable = bool(capturable)
 
     # ------------------------------------------------------------------ helpers
     def _fused_modules(self, group):
@@ -70,12 +77,36 @@ class Adam(torch.optim.Optimizer):
         return out
 
     def _state_for(self, m, eng):
-        st = self._fused.get(id(m))
+        st = self._fused.get(m)
         if st is None or st["m"].numel() != eng.layout.total or st["m"].device != eng.params.device:
             st = dict(m=torch.zeros_like(eng.params), v=torch.zeros_like(eng.params),
                       steps=np.zeros(len(eng.layout.slots), dtype=np.int64))
-            self._fused[id(m)] = st
+            if self._pending_fused:                     # state restored by load_state_dict(), in the order it was saved
+                saved = self._pending_fused.pop(0)
+                if saved["m"].numel() == eng.layout.total and len(saved["steps"]) == len(eng.layout.slots):
+                    st["m"].copy_(saved["m"]); st["v"].copy_(saved["v"])
+                    st["steps"][:] = np.asarray(saved["steps"], dtype=np.int64)
+            self._fused[m] = st
         return st
+
+    def _device_scalars(self, st, eng, lr):
+        """capturable mode: the step counter and the learning rate as device words of this model's state"""
+        dev = eng.params.device
+        if "step_dev" not in st:
+            st["step_dev"] = torch.full((1,), int(st["steps"][0]), dtype=torch.int32, device=dev)
+            st["lr_dev"] = torch.zeros(1, dtype=torch.float32, device=dev)
+            st["lr_host"] = None
+        if torch.is_tensor(lr):
+            if lr.is_cuda and lr.dtype == torch.float32:
+                return st["step_dev"], lr                     # the caller's own device scalar (GraphedModuleStep.set_lr)
+            lr = float(lr)
+        if st["lr_host"] != lr:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.MfmError("factorized_amd.optim.Adam(capturable=True): the learning rate changed inside a stream "
+                                    "capture; pass lr as a float32 device tensor or change it between replays")
+            st["lr_dev"].fill_(lr)
+            st["lr_host"] = lr
+        return st["step_dev"], st["lr_dev"]
 
     def _fused_step(self, m, group):
         eng = m.engine
@@ -84,7 +115,7 @@ class Adam(torch.optim.Optimizer):
             return False                     # gradients are ordinary per-tensor tensors: the stock optimizer handles them
         st = self._state_for(m, eng)
         lr, (b1, b2), eps = group["lr"], group["betas"], group["eps"]
-        if torch.is_tensor(lr):
+        if torch.is_tensor(lr) and not self._capturable:
             lr = float(lr)
         present = m._grad_present
         L = _lib.lib()
@@ -94,6 +125,15 @@ class Adam(torch.optim.Optimizer):
         # guard word of the flat gradient buffer: the plan's backward stores a NaN there when a hand-over inside one of its
         # launches gave up -- the launch below then leaves parameters and moments alone (engine.check_status() reports it)
         guard = C.c_void_p(gflat.data_ptr() + 4 * eng.layout.guard)
+        if self._capturable:
+            if not (present.all() and (steps == steps[0]).all()):
+                raise _lib.MfmError("factorized_amd.optim.Adam(capturable=True): every tensor needs a gradient in every step (one "
+                                    "device-side step counter); staged losses train through the eager optimizer")
+            step_dev, lr_dev = self._device_scalars(st, eng, group["lr"])
+            _lib.check(L.mfm_adam_flat_dev(ptr(eng.params), ptr(gflat), ptr(st["m"]), ptr(st["v"]), eng.layout.total, ptr(step_dev),
+                                           ptr(lr_dev), b1, b2, eps, 1.0, guard, stream), "mfm_adam_flat_dev")
+            steps += 1           # (host mirror: exact in eager use, a lower bound under graph replay -- see state_dict())
+            return True
         if present.all() and (steps == steps[0]).all():
             steps += 1
             _lib.check(L.mfm_adam_flat_guarded(ptr(eng.params), ptr(gflat), ptr(st["m"]), ptr(st["v"]), eng.layout.total,
@@ -130,9 +170,49 @@ class Adam(torch.optim.Optimizer):
             groups = [dict(params=ps, lr=g["lr"], betas=g["betas"], eps=g["eps"]) for g, ps in rest]
             self._fallback = torch.optim.Adam(groups)
             self._fallback_ids = ids
+            fb = getattr(self, "_pending_fallback", None)
+            if fb is not None:
+                self._fallback.load_state_dict(fb)
+                self._pending_fallback = None
         for fg, (g, _) in zip(self._fallback.param_groups, rest):
             fg["lr"], fg["betas"], fg["eps"] = g["lr"], g["betas"], g["eps"]      # schedulers act on OUR groups
         self._fallback.step()
+
+    def reset_state(self):
+        """moments and step counters of every fused model back to zero, in place (a captured graph keeps pointing at them)"""
+        for st in self._fused.values():
+            st["m"].zero_(); st["v"].zero_(); st["steps"][:] = 0
+            if "step_dev" in st:
+                st["step_dev"].zero_()
+
+    # ------------------------------------------------------------------ checkpoints
+    def state_dict(self):
+        """torch's dict plus the flat Adam state of every fused model under "fused" (in the order the models appear in the
+        parameter groups): first / second moments and per-tensor step counts (capturable mode: the device counter)."""
+        sd = super().state_dict()
+        fused = []
+        for group in self.param_groups:
+            for m in self._fused_modules(group):
+                st = self._fused.get(m)
+                if st is None:
+                    continue
+                steps = st["steps"].copy()
+                if "step_dev" in st:
+                    steps[:] = int(st["step_dev"].item())
+                fused.append(dict(m=st["m"].detach().clone(), v=st["v"].detach().clone(), steps=steps.tolist()))
+        sd["fused"] = fused
+        if self._fallback is not None:
+            sd["fallback"] = self._fallback.state_dict()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        fused = sd.pop("fused", None)
+        fb = sd.pop("fallback", None)
+        super().load_state_dict(sd)
+        self._fused.clear()
+        self._pending_fused = [dict(m=f["m"], v=f["v"], steps=list(f["steps"])) for f in fused] if fused else None
+        self._pending_fallback = fb
 
     # ------------------------------------------------------------------ Optimizer interface
     @torch.no_grad()

@@ -146,32 +146,33 @@ class GraphedModuleStep:
     the captured graph halves the step (MFM_KL 5.9 -> 2.7 ms, MFM 5.0 -> 2.6 ms at B=32, T=20).  Inputs are
     copied into static buffers, losses stay on the device (the reference's per-step `.item()` is the caller's
     choice), the learning rate is a device scalar (`set_lr`) so ReduceLROnPlateau keeps working.
-    `MFM_KL_EF` has the one-call fused engine (`model.engine.train_step`), which is 10x faster still.
+    Round 4: `MFM_KL_EF` and the fused `MFM_KL` are captured too -- the reference's UNCHANGED loop around ONE plan call per
+    direction.  What a captured launch freezes (kernel arguments) is split from what must change per replay: the plan's
+    dropout streams and the epochs of its in-launch hand-overs add device words that a tick node inside the graph advances
+    (csrc/plan.hip), and the optimizer is `factorized_amd.optim.Adam(capturable=True)` -- one flat launch whose step count and
+    learning rate are device words.  (`model.engine.train_step(x, y)`, no torch loss ops at all, is still the fastest form.)
 
-    Dropout stays random under replay: torch's generators advance a device offset, and the MFN memory kernel
-    adds a device word that the graph itself advances to its host seed (MfmMemDesc.seed_dev).
+    Dropout stays random under replay: torch's generators advance a device offset, the MFN memory kernel and the fused plans
+    add a device word that the graph itself advances to their host seeds (MfmMemDesc.seed_dev, mfm_plan_state_layout).
     """
 
     def __init__(self, model, cfg, B, T, lr=1e-3, warmup=3):
-        from .mfm_model import MFM_KL_EF
-        if isinstance(model, MFM_KL_EF):
-            # the fused plan bakes its dropout seed (host value x call counter) into the captured kernel
-            # arguments: every replay would reuse one set of masks
-            raise ValueError("GraphedModuleStep is for the module-path classes (MFM, MFM_KL); MFM_KL_EF trains through "
-                             "its one-call fused engine: model.engine.train_step(x, y)")
         dev = next(model.parameters()).device
         self.model, self.cfg = model, cfg
-        # the composed autograd path is what gets captured (MFM_KL's default forward is the fused plan since round 3, whose
-        # dropout seed would be frozen into the captured kernel arguments like MFM_KL_EF's)
-        if hasattr(model, "fused_forward"):
-            model.fused_forward = False
+        fused = hasattr(model, "_fast_ok") and model._fast_ok() and (
+            type(model).__name__ == "MFM_KL_EF" or (getattr(model, "fused_forward", False) and getattr(model, "_use_kl", False)))
+        self.fused = fused
         d = cfg["input_dims"]
         self.x = torch.zeros(T, B, sum(d), device=dev)
         ce = cfg.get("loss", "l1") == "ce"
         self.y = torch.zeros(B, dtype=torch.int64, device=dev) if ce else \
             torch.zeros((B,) if cfg["output_dim"] == 1 else (B, cfg["output_dim"]), device=dev)
-        self.lr = torch.tensor(float(lr), device=dev)
-        self.opt = torch.optim.Adam(model.parameters(), lr=self.lr, capturable=True)
+        self.lr = torch.tensor([float(lr)], device=dev) if fused else torch.tensor(float(lr), device=dev)
+        if fused:
+            from . import optim as our_optim
+            self.opt = our_optim.Adam(model.parameters(), lr=self.lr, capturable=True)
+        else:
+            self.opt = torch.optim.Adam(model.parameters(), lr=self.lr, capturable=True)
         disc_fn = torch.nn.CrossEntropyLoss() if ce else torch.nn.L1Loss()
         mse = torch.nn.MSELoss()
 
@@ -203,6 +204,8 @@ class GraphedModuleStep:
                 for v in st.values():
                     if torch.is_tensor(v):
                         v.zero_()
+            if fused:
+                self.opt.reset_state()
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):

@@ -223,6 +223,13 @@ int mfm_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, int32
 int mfm_adam_flat_guarded(float* p, const float* g, float* m, float* v, int64_t n, int32_t step, float lr,
                           float beta1, float beta2, float eps, float grad_scale, const float* guard, void* stream);
 
+/* Capturable form (ABI 3): the 0-based count of updates applied so far and the learning rate live in device memory
+ * (`step_dev`, `lr_dev`); the bias corrections are formed on the device and a one-thread launch behind the update advances the
+ * counter (not when the guard skipped the step).  This is what a hipGraph of a whole training step replays: kernel arguments
+ * are frozen at capture, device words are not (torch.optim.Adam(capturable=True) semantics).  n: a multiple of 4. */
+int mfm_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, int32_t* step_dev, const float* lr_dev,
+                      float beta1, float beta2, float eps, float grad_scale, const float* guard, void* stream);
+
 #define MFM_ADAM_MAX_SPANS 8
 typedef struct MfmAdamSpan { int64_t begin, end; int32_t step; int32_t reserved; } MfmAdamSpan;
 int mfm_adam_flat_spans(float* p, const float* g, float* m, float* v, const MfmAdamSpan* spans /*host*/, int32_t nspans,

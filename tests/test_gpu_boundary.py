@@ -158,9 +158,8 @@ def test_klef_backward_refuses_stale_or_consumed_activations():
     # the input gradient is not produced by the fused plan: ask for it and it says so
     with pytest.raises(_lib.MfmError, match="requires grad"):
         model.forward(x.clone().requires_grad_(True))
-    # graph replay would freeze the plan's dropout masks: refused
-    with pytest.raises(ValueError, match="fused engine"):
-        train.GraphedModuleStep(model, cfg, cs["B"], cs["T"])
+    # (graph replay of the fused plan: tests/test_gpu_graph.py -- refused until round 4, when the dropout streams and the
+    # hand-over epochs got device words that a captured step advances)
 
 
 def test_mfn_model_input_gradient_matches_oracle():
