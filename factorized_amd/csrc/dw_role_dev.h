@@ -4,7 +4,8 @@
 // reference's batch size they were a launch of their own behind the encoder BPTT: ~18 us plus the boundary, while the BPTT
 // itself keeps only 4 B <= 128 of the 256 CUs busy for ~43 us.  Here the idle CUs run those products INSIDE the BPTT launch:
 //   * a role workgroup (1024 threads) is four SLOTS of 256 threads, each with the arithmetic of gemm_tn_kernel on one
-//     (tile, 128-row chunk) block per iteration: whole operand slices requested at once, 32 MFMA steps per wave;
+//     (tile, 128-row chunk) block per iteration: whole operand slices requested at once, 32 MFMA steps per wave; the four
+//     slots of a workgroup hold tiles that share their A slice (round 4), which is fetched once;
 //   * a device table built once per plan gives every slot its block per iteration ([iteration][slot]), ordered by when the
 //     A operand becomes final: first the decoder-side products (final before the launch) and the latent stack's (after the
 //     rows' chains at the head of this launch), one chunk per block, partial tile added with atomics; then every ENCODER
@@ -31,6 +32,7 @@ constexpr int DWR_TABLE_CAP = 16384;   // table entries carved in the plan works
 struct DwRoleProblem {
   const float* a; const float* b; float* c; float* c2;
   int a_sz, b_sz, c_sz, a_sk, b_sk, ldc, m, n_valid, k, tiles_m, tiles_n, kps, batch;
+  int b_shift;                         // chunk row r pairs with row r - b_shift of B (rows r < b_shift contribute nothing)
   float alpha;
 };
 struct DwRole {
@@ -38,7 +40,8 @@ struct DwRole {
   int count, n_iter, n_role, T, B, any_dep;
   int bf16;                            // bf16 plans: both operands rounded to bf16 (RNE) on the way into LDS, fp32 accumulation
   const int4* table;                   // [n_iter][4 n_role]: x = problem (-1: idle), y = tile (tn + tiles_n (tm + tiles_m z)), z = chunk,
-                                       // w = dep | t0 << 8 | FIRST << 24 | LAST << 25 | accumulator << 26
+                                       // w = dep | t0 << 8 | FIRST << 24 | LAST << 25 | accumulator << 26 | STORE << 27; the active slots
+                                       // of a workgroup are a prefix and share (A operand, z, tm, chunk, dep, t0) with its slot 0
   unsigned* flags;                     // [4][T][32] BPTT stamps, then [4][B] latent-chain stamps
   unsigned epoch;                      // host part of the launch's epoch (proj_role_dev.h, ho_epoch)
   const unsigned* tick;                // device part: the plan's backward replay counter
@@ -47,7 +50,7 @@ struct DwRole {
 };
 // dep codes of a table entry
 constexpr int DWR_DEP_NONE = 0, DWR_DEP_LATENT = 5;     // 1..4: encoder e = dep - 1
-constexpr int DWR_FIRST = 1 << 24, DWR_LAST = 1 << 25, DWR_ACC1 = 1 << 26;
+constexpr int DWR_FIRST = 1 << 24, DWR_LAST = 1 << 25, DWR_ACC1 = 1 << 26, DWR_STORE = 1 << 27;
 
 int seq_small_folddw_launch(SeqLaunch& L, const LatentDev& LD, DwRole& DR, const float* params, float* grads, hipStream_t stream);
 int seq_folddw_launch(const MfmSeqDesc* descs, int count, int T, int B, const LatentDev& lat, const float* params, float* grads,
@@ -70,76 +73,90 @@ __device__ __forceinline__ void dwr_wait(const unsigned* f, int n, unsigned epoc
 }
 
 __device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned epoch, float* lds) {
-  constexpr int LOADS = DWR_KC * (DWR_T / 4) / 256;
+  // One role workgroup = four slots of 256 threads that work on tiles with the SAME A slice (same rows, same 32 columns of
+  // the gate-gradient / upstream-gradient operand: the dW_ih, dW_hh and bias tiles of one gate block, the column tiles of one
+  // decoder fc1 row block ...): the slice is fetched once per workgroup -- one 16-byte agent-scope load per thread -- instead
+  // of once per tile.  Agent-scope loads come from the memory side, so this is what the launch's HBM traffic is made of:
+  // 44 -> ~15 MB of reads per launch at the canonical sizes (round 4, profiles/r04_traffic_B32.json).
+  constexpr int BL = DWR_KC * (DWR_T / 4) / 256;       // 16-byte loads per thread for a slot's B slice
   const int tid = threadIdx.x, sub = tid >> 8, t = tid & 255;
   const int lane = t & 63, wave = t >> 6;
   const int bi = lane & 15, q = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
-  float* As = lds + sub * (2 * DWR_KC * DWR_T);
-  float* Bs = As + DWR_KC * DWR_T;
+  float* As = lds;                                                 // [DWR_KC][32], shared
+  float* Bs = lds + (1 + sub) * (DWR_KC * DWR_T);                  // [DWR_KC][32] per slot
   const int r = blockIdx.x - 4 * DR.B;           // role index
   const int nslots = 4 * DR.n_role, slot = 4 * r + sub;
   f32x4 accs[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll 1
   for (int it = 0; it < DR.n_iter; ++it) {
     int4 ent = DR.table[(int64_t)it * nslots + slot];
+    int4 ea = DR.table[(int64_t)it * nslots + 4 * r];              // slot 0 describes the workgroup's A slice
     ent.x = __builtin_amdgcn_readfirstlane(ent.x); ent.y = __builtin_amdgcn_readfirstlane(ent.y);
     ent.z = __builtin_amdgcn_readfirstlane(ent.z); ent.w = __builtin_amdgcn_readfirstlane(ent.w);
-    const bool active = ent.x >= 0;
+    ea.x = __builtin_amdgcn_readfirstlane(ea.x); ea.y = __builtin_amdgcn_readfirstlane(ea.y);
+    ea.z = __builtin_amdgcn_readfirstlane(ea.z); ea.w = __builtin_amdgcn_readfirstlane(ea.w);
+    const bool active = ent.x >= 0, gactive = ea.x >= 0;
     const DwRoleProblem& P = DR.p[active ? ent.x : 0];
-    int local = ent.y;
-    const int tn = local % P.tiles_n; local /= P.tiles_n;
-    const int tm = local % P.tiles_m;
-    const int z = local / P.tiles_m;
+    const DwRoleProblem& PA = DR.p[gactive ? ea.x : 0];
+    int la = ea.y;
+    la /= PA.tiles_n;
+    const int tm = la % PA.tiles_m, z = la / PA.tiles_m;           // (the same for every active slot of the workgroup)
+    const int tn = ent.y % P.tiles_n;
     const int m0 = tm * DWR_T, n0 = tn * DWR_T;
-    const int kbeg = ent.z * P.kps;
-    const int klen = active ? min(P.k - kbeg, P.kps) : 0;
-    const int dep = ent.w & 255, t0 = (ent.w >> 8) & 0xffff;
-    f32x4 ra[LOADS], rb[LOADS];
-    const float* A = P.a + (int64_t)z * P.a_sz;
+    const int kbeg = ea.z * PA.kps;
+    const int klen = gactive ? min(PA.k - kbeg, PA.kps) : 0;
+    const int dep = ea.w & 255, t0 = (ea.w >> 8) & 0xffff;
+    f32x4 rb[BL];
+    const float* A = PA.a + (int64_t)z * PA.a_sz;
     const float* Bm = P.b + (int64_t)z * P.b_sz;
-    const int a_bytes = ((P.m - 1) + (P.k - 1) * P.a_sk + 1) * 4;
-    const int b_bytes = ((max(P.n_valid, 1) - 1) + (P.k - 1) * P.b_sk + 1) * 4;
+    const int a_bytes = ((PA.m - 1) + (PA.k - 1) * PA.a_sk + 1) * 4;
+    const int b_bytes = ((max(P.n_valid, 1) - 1) + (max(P.k - P.b_shift, 1) - 1) * P.b_sk + 1) * 4;
     const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc((void*)Bm, 0, b_bytes, 0x00020000);
     // the B operand (batch columns, hidden states, records of the forward) never depends on this launch: requested before
-    // the wait for the A operand's stamps
+    // the wait for the A operand's stamps.  Row kbeg + rr of the chunk pairs with row kbeg + rr - b_shift of B (the
+    // recurrent product sum_t dA_t^T h_{t-1}: rows of the first time step read zeros)
     if (active) {
 #pragma unroll
-      for (int j = 0; j < LOADS; ++j) {
+      for (int j = 0; j < BL; ++j) {
         const int idx = t + j * 256;
         const int rr = idx >> 3, c4 = idx & 7;
-        const int offb = ((rr < klen) & (n0 + 4 * c4 < P.n_valid)) ? ((kbeg + rr) * P.b_sk + n0 + 4 * c4) * 4 : -16;
+        const int br = kbeg + rr - P.b_shift;
+        const int offb = ((rr < klen) & (br >= 0) & (n0 + 4 * c4 < P.n_valid)) ? (br * P.b_sk + n0 + 4 * c4) * 4 : -16;
         rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bres, offb, 0, 0));
       }
     }
-    // ONE wave per slot polls (a thousand waves re-reading four flag lines at the memory side wait on each other)
-    if (active && dep != DWR_DEP_NONE && wave == 0) {
+    // ONE wave per workgroup polls (many waves re-reading a few flag lines at the memory side wait on each other)
+    if (gactive && dep != DWR_DEP_NONE && tid < 64) {
       if (dep == DWR_DEP_LATENT) dwr_wait(DR.flags + 4 * DR.T * DWR_ROWS, 4 * DR.B, epoch, DR.ctl);      // [4][B] dense
       else dwr_wait(DR.flags + ((dep - 1) * DR.T + t0) * DWR_ROWS, DR.B, epoch, DR.ctl);
     }
     if (DR.any_dep) __syncthreads();
+    {
+      // A may have been written inside this launch (dA, the latent gradients): agent-scope load (sc1), one per thread
+      const int rr = tid >> 3, c4 = tid & 7;
+      const int offa = (gactive & (rr < klen) & (m0 + 4 * c4 < PA.m)) ? ((kbeg + rr) * PA.a_sk + m0 + 4 * c4) * 4 : -16;
+      f32x4 ra = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ares, offa, 0, 16));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ra[e] = (m0 + 4 * c4 + e < PA.m) ? ra[e] : 0.0f;
+        if (DR.bf16) ra[e] = (float)(__bf16)ra[e];
+      }
+      const int sw = (4 * c4 + 16 * (rr & 1)) & 31;
+      *reinterpret_cast<f32x4*>(As + rr * DWR_T + sw) = ra;
+    }
     if (active) {
 #pragma unroll
-      for (int j = 0; j < LOADS; ++j) {
-        const int idx = t + j * 256;
-        const int rr = idx >> 3, c4 = idx & 7;
-        const int offa = ((rr < klen) & (m0 + 4 * c4 < P.m)) ? ((kbeg + rr) * P.a_sk + m0 + 4 * c4) * 4 : -16;
-        // A may have been written inside this launch (dA, the latent gradients): agent-scope load (sc1)
-        ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ares, offa, 0, 16));
-      }
-#pragma unroll
-      for (int j = 0; j < LOADS; ++j) {
+      for (int j = 0; j < BL; ++j) {
         const int idx = t + j * 256;
         const int rr = idx >> 3, c4 = idx & 7;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          ra[j][e] = (m0 + 4 * c4 + e < P.m) ? ra[j][e] : 0.0f;
           rb[j][e] = (n0 + 4 * c4 + e < P.n_valid) ? rb[j][e] : 0.0f;
-          if (DR.bf16) { ra[j][e] = (float)(__bf16)ra[j][e]; rb[j][e] = (float)(__bf16)rb[j][e]; }
+          if (DR.bf16) rb[j][e] = (float)(__bf16)rb[j][e];
         }
         const int sw = (4 * c4 + 16 * (rr & 1)) & 31;
-        *reinterpret_cast<f32x4*>(As + rr * DWR_T + sw) = ra[j];
         *reinterpret_cast<f32x4*>(Bs + rr * DWR_T + sw) = rb[j];
       }
     }
@@ -172,8 +189,13 @@ __device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned ep
             const int row = m0 + 16 * wm + 4 * q + rr;
             if (row < P.m) {
               const float v = P.alpha * acc[rr];
-              atomicAdd(C + (int64_t)row * P.ldc + col, v);
-              if (C2) atomicAdd(C2 + (int64_t)row * P.ldc + col, v);
+              if (ent.w & DWR_STORE) {             // the tile's only contribution, into a buffer that holds zeros: a plain store
+                C[(int64_t)row * P.ldc + col] = v;
+                if (C2) C2[(int64_t)row * P.ldc + col] = v;
+              } else {
+                atomicAdd(C + (int64_t)row * P.ldc + col, v);
+                if (C2) atomicAdd(C2 + (int64_t)row * P.ldc + col, v);
+              }
             }
           }
         }

@@ -1411,15 +1411,27 @@ static int dw_role_build(MfmPlan* P, const std::vector<MfmGemmDesc>& all, float*
     q.a = d.a; q.b = d.b; q.c = d.c; q.c2 = d.c2;
     q.a_sz = (int)d.a_sz; q.b_sz = (int)d.b_sz; q.c_sz = (int)d.c_sz; q.a_sk = (int)d.a_sk; q.b_sk = (int)d.b_sk; q.ldc = (int)d.ldc;
     q.m = d.m; q.n_valid = (d.n_valid <= 0 || d.n_valid > d.n) ? d.n : d.n_valid; q.k = d.k; q.batch = d.batch; q.alpha = d.alpha;
-    q.tiles_m = cdiv(d.m, DWR_T); q.tiles_n = cdiv(d.n, DWR_T);
-    int split = cdiv(d.k, DWR_KC);
-    q.kps = round_up(cdiv(d.k, split), 4);
+    q.b_shift = 0;
     dep[i] = DWR_DEP_NONE; tbase[i] = 0;
-    for (int e = 0; e < 4; ++e) {
-      const float* g0 = W + P->enc[e].gates;
-      const int64_t step = (int64_t)B * 4 * P->enc[e].Hp;
-      if (d.a >= g0 && d.a < g0 + TB * 4 * P->enc[e].Hp) { dep[i] = e + 1; tbase[i] = (int)((d.a - g0) / step); }
+    // products over an LSTM's gate gradients: which buffer (the encoders' are written inside the launch) and, for the
+    // recurrent product sum_{t >= 1} dA_t^T h_{t-1} -- A one time step into the buffer -- the SAME rows as the input and
+    // bias products of that LSTM with B shifted instead, so that the three share their A slices (dw_role_dev.h)
+    for (int e = 0; e < 7; ++e) {
+      const SeqBuf& sb = e < 4 ? P->enc[e] : P->dec[e - 4];
+      const float* g0 = W + sb.gates;
+      const int64_t step = (int64_t)B * 4 * sb.Hp;
+      if (d.a >= g0 && d.a < g0 + TB * 4 * sb.Hp) {
+        const int tb = (int)((d.a - g0) / step);
+        if (e < 4) { dep[i] = e + 1; tbase[i] = tb; }
+        if (tb == 1 && d.a == g0 + step && d.k == (int)(TB - B)) {
+          q.a = g0; q.k = (int)TB; q.b_shift = B;
+          if (e < 4) tbase[i] = 0;
+        }
+      }
     }
+    q.tiles_m = cdiv(d.m, DWR_T); q.tiles_n = cdiv(d.n, DWR_T);
+    const int split = cdiv(q.k, DWR_KC);
+    q.kps = round_up(cdiv(q.k, split), 4);
     if (d.a >= W + P->lat_grd && d.a < W + P->lat_grd + (int64_t)B * P->lat.rec_size) dep[i] = DWR_DEP_LATENT;
     if (getenv("MFM_DW_FOLD_NODEP")) dep[i] = DWR_DEP_NONE;       // timing experiment only (wrong gradients): nothing waits
   }
@@ -1429,50 +1441,73 @@ static int dw_role_build(MfmPlan* P, const std::vector<MfmGemmDesc>& all, float*
   DR.n_role = n_role;
   const int nslots = 4 * n_role;
   if (P->dw_table_key != key || P->dw_table_host.empty()) {
-    // phase A: one block per (tile, chunk) of the products whose A operand does not come from the encoder BPTT
-    struct Unit { int p, tile, chunk, w; };
-    std::vector<Unit> ua;
-    for (int pass = 0; pass < 2; ++pass)          // final-before-the-launch operands first, the latent stack's behind them
-      for (int i = 0; i < n; ++i) {
-        if (dep[i] != (pass == 0 ? DWR_DEP_NONE : DWR_DEP_LATENT)) continue;
-        const DwRoleProblem& q = DR.p[i];
-        const int split = cdiv(q.k, q.kps);
-        for (int sp = 0; sp < split; ++sp)
-          for (int tile = 0; tile < q.tiles_m * q.tiles_n * q.batch; ++tile) ua.push_back({i, tile, sp, dep[i] | DWR_FIRST | DWR_LAST});
-      }
-    const int rows_a = cdiv((int)ua.size(), nslots);
-    // phase B: every encoder tile stays with one slot for all its chunks (last time steps first) and is added once
-    struct Tile { int p, tile; };
-    std::vector<Tile> te;
-    int max_split = 0;
+    // tiles that read the same A slice -- same operand, gate block z, row tile tm, and therefore the same chunks -- form a
+    // GROUP; a role workgroup takes up to four tiles of one group per iteration (its four slots share the A image)
+    struct Group { const float* a; int a_sk, a_sz, k, kps, m, z, tm, dep, tbase; std::vector<std::pair<int, int>> tiles; };   // tiles: (problem, tile id)
+    std::vector<Group> groups;
     for (int i = 0; i < n; ++i) {
-      if (dep[i] < 1 || dep[i] > 4) continue;
       const DwRoleProblem& q = DR.p[i];
-      max_split = std::max(max_split, cdiv(q.k, q.kps));
-      for (int tile = 0; tile < q.tiles_m * q.tiles_n * q.batch; ++tile) te.push_back({i, tile});
+      for (int z = 0; z < q.batch; ++z)
+        for (int tm = 0; tm < q.tiles_m; ++tm) {
+          Group* g = nullptr;
+          for (auto& c : groups)
+            if (c.a == q.a && c.a_sk == q.a_sk && c.a_sz == q.a_sz && c.k == q.k && c.kps == q.kps && c.m == q.m && c.z == z &&
+                c.tm == tm && c.dep == dep[i] && c.tbase == tbase[i]) { g = &c; break; }
+          if (!g) { groups.push_back(Group{q.a, q.a_sk, q.a_sz, q.k, q.kps, q.m, z, tm, dep[i], tbase[i], {}}); g = &groups.back(); }
+          for (int tn = 0; tn < q.tiles_n; ++tn) g->tiles.push_back({i, tn + q.tiles_n * (tm + q.tiles_m * z)});
+        }
     }
-    const int nacc = cdiv((int)te.size(), nslots);
+    // a workgroup item: up to four tiles of one group
+    struct Item { int grp, first, count, chunk; };
+    // phase A: one item per (tile set, chunk) of the groups whose A operand does not come from the encoder BPTT, partial
+    // tiles added with atomics: operands that are final before the launch first, the latent stack's behind them
+    std::vector<Item> ua;
+    for (int pass = 0; pass < 2; ++pass)
+      for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const Group& g = groups[gi];
+        if (g.dep != (pass == 0 ? DWR_DEP_NONE : DWR_DEP_LATENT)) continue;
+        const int split = cdiv(g.k, g.kps);
+        for (int sp = 0; sp < split; ++sp)
+          for (int f = 0; f < (int)g.tiles.size(); f += 4) ua.push_back({(int)gi, f, std::min(4, (int)g.tiles.size() - f), sp});
+      }
+    const int rows_a = cdiv((int)ua.size(), n_role);
+    // phase B: every encoder tile set stays with one workgroup for all its chunks (last time steps first); each tile is
+    // accumulated in registers and written once -- a plain store, the gradient buffer holds zeros and nobody else adds there
+    std::vector<Item> te;
+    int max_split = 0;
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+      const Group& g = groups[gi];
+      if (g.dep < 1 || g.dep > 4) continue;
+      max_split = std::max(max_split, cdiv(g.k, g.kps));
+      for (int f = 0; f < (int)g.tiles.size(); f += 4) te.push_back({(int)gi, f, std::min(4, (int)g.tiles.size() - f), 0});
+    }
+    const int nacc = cdiv((int)te.size(), n_role);
     if (nacc > 2) return MFM_ERR_UNSUPPORTED;
     const int n_iter = rows_a + nacc * max_split;
     if ((int64_t)n_iter * nslots > DWR_TABLE_CAP) return MFM_ERR_UNSUPPORTED;
     P->dw_table_host.assign((size_t)n_iter * nslots * 4, 0);
     for (size_t i = 0; i < (size_t)n_iter * nslots; ++i) P->dw_table_host[4 * i] = -1;
-    auto put = [&](int row, int slot, int p, int tile, int chunk, int w) {
-      int* e = &P->dw_table_host[((size_t)row * nslots + slot) * 4];
-      e[0] = p; e[1] = tile; e[2] = chunk; e[3] = w;
+    auto put = [&](int row, int wg, const Item& it, int chunk, int w) {
+      const Group& g = groups[it.grp];
+      for (int s4 = 0; s4 < it.count; ++s4) {
+        int* e = &P->dw_table_host[((size_t)row * nslots + 4 * wg + s4) * 4];
+        e[0] = g.tiles[it.first + s4].first; e[1] = g.tiles[it.first + s4].second; e[2] = chunk; e[3] = w;
+      }
     };
-    for (size_t u = 0; u < ua.size(); ++u) put((int)(u / nslots), (int)(u % nslots), ua[u].p, ua[u].tile, ua[u].chunk, ua[u].w);
+    for (size_t u = 0; u < ua.size(); ++u)
+      put((int)(u / n_role), (int)(u % n_role), ua[u], ua[u].chunk, groups[ua[u].grp].dep | DWR_FIRST | DWR_LAST);
+    const bool store_ok = !getenv("MFM_DW_FOLD_ATOMICS");           // (A/B timing: MFM_DW_FOLD_ATOMICS=1 keeps the atomics)
     for (size_t j = 0; j < te.size(); ++j) {
-      const DwRoleProblem& q = DR.p[te[j].p];
-      const int split = cdiv(q.k, q.kps);
-      const int slot = (int)(j % nslots), acc = (int)(j / nslots);
-      for (int c = 0; c < split; ++c) {            // c-th block of this tile: chunk split - 1 - c
+      const Group& g = groups[te[j].grp];
+      const int split = cdiv(g.k, g.kps);
+      const int wg = (int)(j % n_role), acc = (int)(j / n_role);
+      for (int c = 0; c < split; ++c) {            // c-th block of this tile set: chunk split - 1 - c
         const int sp = split - 1 - c;
-        const int t0 = tbase[te[j].p] + (sp * q.kps) / B;
-        int w = dep[te[j].p] | (t0 << 8) | (acc ? DWR_ACC1 : 0);
+        const int t0 = g.tbase + (sp * g.kps) / B;
+        int w = g.dep | (t0 << 8) | (acc ? DWR_ACC1 : 0) | (store_ok ? DWR_STORE : 0);
         if (c == 0) w |= DWR_FIRST;
         if (c == split - 1) w |= DWR_LAST;
-        put(rows_a + (max_split - split + c) * nacc + acc, slot, te[j].p, te[j].tile, sp, w);
+        put(rows_a + (max_split - split + c) * nacc + acc, wg, te[j], sp, w);
       }
     }
     P->dw_table_key = key;
