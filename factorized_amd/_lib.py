@@ -37,7 +37,7 @@ class SeqDesc(C.Structure):
                 ("dh_ext", C.c_void_p), ("ld_dh", C.c_int64),
                 ("d_h_init", C.c_void_p), ("ld_dinit", C.c_int64),
                 ("h", C.c_int32), ("is_dec", C.c_int32), ("dc_ext", C.c_void_p), ("w_pack", C.c_void_p),
-                ("store_bf16", C.c_int32), ("reserved2_", C.c_int32), ("h_last", C.c_void_p)]
+                ("store_bf16", C.c_int32), ("bf16_dot", C.c_int32), ("h_last", C.c_void_p)]
 
 
 class MemDesc(C.Structure):

@@ -446,6 +446,8 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     const size_t need = (bwd ? 2 * 4 * HK * 16 : 2 * HK * 16) * sizeof(float);
     if (need > lds_bytes) lds_bytes = need;
   }
+  L.bf16_dot = 1;
+  for (int i = 0; i < count; ++i) L.bf16_dot &= (descs[i].bf16_dot != 0);
   if (fold && fold->img_written) *fold->img_written = false;
   if (fold && fold->img_items && !bwd && !bf16 && !sorted && !nwide && fold->n_img_items <= MFM_WT_MAX && use_small_path(B)) {
     L.n_img = fold->n_img_items;

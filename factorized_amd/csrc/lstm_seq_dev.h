@@ -30,6 +30,7 @@ struct SeqLaunch {
   // forward launches, optional: blocks [img_begin, img_begin + n_img_blocks) write the images of `img` and leave
   int n_img, img_begin, n_img_blocks;
   WtImgItem img[MFM_WT_MAX];
+  int bf16_dot;            // one-row forward kernels: recurrent product on bf16 dot products (MfmSeqDesc::bf16_dot on every LSTM)
 };
 
 // writer r of nr (any block size)

@@ -151,7 +151,11 @@ __device__ __forceinline__ void stage_gates2(const SeqDev& d, int mode, int g, f
 // FLG (encoders of the fold launch with projection role workgroups, proj_role_dev.h): the x-projections of a time step
 // are produced inside this launch; the fetching waves check the step's block flags (requested one step earlier) before they
 // request its values, and read them with agent-scope loads.
-template <int KQ, int R, bool FLG = false>
+// BF (one-row tiles, bf16 plans below the batch size of the bf16 MFMA kernels; round 4): the recurrent product on
+// v_dot2c_f32_bf16 -- W packed as bf16 pairs in half the registers, h_{t-1} exchanged through LDS as bf16 (what the bf16 MFMA
+// kernels feed their matrix cores: same rounding points), fp32 accumulation, gate math, cell state and saved activations.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+template <int KQ, int R, bool FLG = false, bool BF = false>
 __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds,
                                                const unsigned* flg = nullptr, const unsigned epoch = 0, const int ncb = 0,
                                                const HoCtl ctl = HoCtl{nullptr, nullptr, 5000000ll, 1u}) {
@@ -176,12 +180,23 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
   constexpr int NM = HKB / 16;
   constexpr int NWR = (R == 1) ? 4 * NM : KQ;     // weights per gate row and thread
   constexpr int HX = (R == 1) ? HKB : HK;          // extent of one h buffer
+  static_assert(!BF || R == 1, "bf16 dot products: one-row tiles only");
   float* hbuf = lds;                       // [2][HX][R]
+  __bf16* hb16 = reinterpret_cast<__bf16*>(lds);   // BF: the same two buffers as bf16 (half the bytes)
   float* panel = lds + 2 * HKB * R;        // [2][h][h] weight staging (two gates at a time)
   float* obuf = panel;                     // [2][6][HKB][R] step outputs; aliases the panel (barriers below)
   float* xbuf = obuf + 2 * 6 * HKB * R;    // [2][4][HKB][R] x-projections of the next step (encoders)
 
   float w[2][NWR];
+  bf16x2_t wp[2][BF ? NWR / 2 : 1];         // BF: the resident weights as bf16 pairs (k, k + 1)
+  auto pack_w = [&]() {
+    if constexpr (BF) {
+#pragma unroll
+      for (int gl = 0; gl < 2; ++gl)
+#pragma unroll
+        for (int j = 0; j < NWR / 2; ++j) wp[gl][j] = bf16x2_t{(__bf16)w[gl][2 * j], (__bf16)w[gl][2 * j + 1]};
+    }
+  };
   // round gl stages gates gl (for the p=0 lanes) and 2+gl (p=1 lanes) side by side, so every
   // lane picks its own gate with an address, not a predicate
   auto load_w = [&](int mode) {
@@ -202,6 +217,7 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
             for (int i = 0; i < 4; ++i) w[gl][4 * m + i] = ok ? v[i] : 0.0f;
           }
         }
+        pack_w();
         return;
       }
     }
@@ -221,6 +237,7 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
       }
       __syncthreads();
     }
+    pack_w();
   };
   load_w(dec ? 1 : 0);
 
@@ -233,7 +250,8 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
   if (dec) {
     for (int idx = tid; idx < HX * R; idx += nt) {
       const int k = idx / R, br = b0 + (idx % R);
-      hbuf[idx] = (k < h && br < B) ? d.h_init[(int64_t)br * d.ld_init + k] : 0.0f;
+      const float v = (k < h && br < B) ? d.h_init[(int64_t)br * d.ld_init + k] : 0.0f;
+      if constexpr (BF) hb16[idx] = (__bf16)v; else hbuf[idx] = v;
     }
   }
 
@@ -314,7 +332,21 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
 #pragma unroll
       for (int r = 0; r < R; ++r) acc[gl][r] = 0.0f;
     if constexpr (R == 1) {
-      if (dec || t > 0) {
+      if constexpr (BF) {
+        if (dec || t > 0) {
+          const bf16x2_t* hb = reinterpret_cast<const bf16x2_t*>(hb16 + cur * HX + 4 * q);
+          bf16x2_t hv[NM][2];
+#pragma unroll
+          for (int m = 0; m < NM; ++m) { hv[m][0] = hb[8 * m]; hv[m][1] = hb[8 * m + 1]; }      // one ds_read_b64 per m
+#pragma unroll
+          for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              acc[0][0] = __builtin_amdgcn_fdot2_f32_bf16(wp[0][2 * m + i], hv[m][i], acc[0][0], false);
+              acc[1][0] = __builtin_amdgcn_fdot2_f32_bf16(wp[1][2 * m + i], hv[m][i], acc[1][0], false);
+            }
+        }
+      } else if (dec || t > 0) {
         const float* hb = hbuf + cur * HX + 4 * q;
         f32x4 hv[NM];
 #pragma unroll
@@ -386,7 +418,10 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
       float* ob = obuf + par * (6 * HKB * R) + my_o;
       ob[0] = a0; ob[HKB * R] = a1;
       ob[(4 - gp) * HKB * R] = gp ? hv : c;        // slot 4 (c) from gp 0, slot 5 (h) from gp 1
-      if (gp == 0 && u < HX) hbuf[(cur ^ 1) * (HX * R) + u * R + myrow] = (b < B) ? hv : 0.0f;
+      if (gp == 0 && u < HX) {
+        const float hn = (b < B) ? hv : 0.0f;
+        if constexpr (BF) hb16[(cur ^ 1) * HX + u] = (__bf16)hn; else hbuf[(cur ^ 1) * (HX * R) + u * R + myrow] = hn;
+      }
     }
     if (!dec) {
 #pragma unroll
@@ -771,7 +806,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_kernel(const SeqLaunch L)
 // are pre-instantiated; any other size combination takes the generic kernel above.
 // KS = 8 (backward, one-row tiles): 4 * Hp threads per workgroup, launched with at most 512 -> 256 VGPRs per thread for
 // the doubled resident weights.
-template <bool BWD, int R, int KS, int K0, int K1, int K2, int K3, int K4 = 0, int K5 = 0>
+template <bool BWD, int R, int KS, int K0, int K1, int K2, int K3, int K4 = 0, int K5 = 0, bool BF = false>
 __global__ __launch_bounds__(KS == 16 ? 1024 : 512) void lstm_seq_small_kernel4(const SeqLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int di = 0;
@@ -787,7 +822,7 @@ __global__ __launch_bounds__(KS == 16 ? 1024 : 512) void lstm_seq_small_kernel4(
 #define MFM_ONE(IDX, KK)                                                         \
   if (KK > 0 && di == IDX) {                                                     \
     if (BWD) small_bwd_body<(KK > 0 ? KK : 2), R, KS>(d, L.T, L.B, tile, lds);   \
-    else small_fwd_body<(KK > 0 ? KK : 2), R>(d, L.T, L.B, tile, lds);           \
+    else small_fwd_body<(KK > 0 ? KK : 2), R, false, BF>(d, L.T, L.B, tile, lds);           \
     return;                                                                      \
   }
   MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3) MFM_ONE(4, K4) MFM_ONE(5, K5)
@@ -998,6 +1033,15 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
     bool fat = false;
     if (const char* e = getenv("MFM_SEQ_KS")) fat = bwd && R == 1 && max_threads / 2 <= 512 && atoi(e) == 8;
     if (fat) done = try_all_fat(L, total, max_threads / 2, lds_bytes, stream, &err);
+    // bf16 plans, forward, one-row tiles: the decoders' recurrent product on v_dot2c_f32_bf16 (opt-in, small_fwd_body<.., BF>)
+    if (!done && !bwd && R == 1 && L.bf16_dot && L.count == 3 && L.d[0].hk4 == 26 && L.d[1].hk4 == 6 && L.d[2].hk4 == 6) {
+      if (lds_bytes > 64 * 1024)
+        err = hipFuncSetAttribute((const void*)lstm_seq_small_kernel4<false, 1, 16, 26, 6, 6, 0, 0, 0, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (err == hipSuccess)
+        hipLaunchKernelGGL((lstm_seq_small_kernel4<false, 1, 16, 26, 6, 6, 0, 0, 0, true>), dim3(total), dim3(max_threads), lds_bytes, stream, L);
+      done = true;
+    }
     if (done) {}
     else if (R == 1) done = try_all<1>(L, bwd, total, max_threads, lds_bytes, stream, &err);
     else if (R == 2) done = try_all<2>(L, bwd, total, max_threads, lds_bytes, stream, &err);

@@ -156,6 +156,7 @@ struct MfmPlan {
   int64_t opt_timeout_us = 50000;   // how long their consumers spin before they give up
   int64_t opt_guard = -1;           // element offset of the guard word in the gradient buffer (-1: none)
   int opt_fault = 0;                // one-shot fault injection (tests)
+  int opt_bf16_dot = 0;             // bf16 plans below the bf16 MFMA kernels' batch size: one-row recurrences on bf16 dot products
   bool ever_handover = false;       // a role-workgroup launch has run on this plan (its status word may be set)
   // device-side state, right behind the plan's loss slots (mfm_plan_state_layout): float offsets relative to `losses`
   static constexpr int ST_STATUS = MFM_LOSS_SLOTS, ST_TICK = MFM_LOSS_SLOTS + 2, ST_DW_TICK = MFM_LOSS_SLOTS + 4;
@@ -658,6 +659,7 @@ static MfmSeqDesc seq_desc(const MfmPlan* P, const SeqBuf& sb, int pbase, const 
   d.h = sb.h; d.is_dec = dec ? 1 : 0;
   if (sb.wpack >= 0 && sb.h <= MFM_SEQ_MAX_RESIDENT_H) d.w_pack = W + sb.wpack;   // bf16 plans: fragments packed by K_PACK
   d.store_bf16 = P->st16 ? 1 : 0;
+  d.bf16_dot = (P->cfg.precision && !P->seq_bf16 && P->opt_bf16_dot) ? 1 : 0;
   return d;
 }
 
@@ -1956,6 +1958,7 @@ extern "C" int mfm_plan_create(const MfmPlanConfig* cfg, const int64_t* param_of
   // MFM_SHARED_DEVICE=1 (several ranks / processes drive this GPU): the default of the "handover" option for plans created
   // from now on; the host side sets the option itself where it can tell (train.py::_mark_shared_device)
   if (const char* e = getenv("MFM_SHARED_DEVICE")) P->opt_handover = atoi(e) == 0;
+  if (const char* e = getenv("MFM_BF16_DOT")) P->opt_bf16_dot = atoi(e) != 0;
   int rc = build(P);
   if (rc != MFM_OK) { delete P; return rc; }
   *out = P;
@@ -2003,6 +2006,7 @@ extern "C" int mfm_plan_set_option(MfmPlan* P, const char* key, int64_t value) {
   }
   else if (!strcmp(key, "handover_timeout_us")) { MFM_REQUIRE(value >= 1 && value <= 10000000, "mfm_plan_set_option: handover_timeout_us %lld", (long long)value); P->opt_timeout_us = value; }
   else if (!strcmp(key, "grad_guard_offset")) { MFM_REQUIRE(value >= -1 && value < P->n_params, "mfm_plan_set_option: grad_guard_offset %lld outside the buffer of %lld elements", (long long)value, (long long)P->n_params); P->opt_guard = value; }
+  else if (!strcmp(key, "bf16_dot")) P->opt_bf16_dot = value != 0;
   else if (!strcmp(key, "inject_fault")) { MFM_REQUIRE(value >= 0 && value <= 2, "mfm_plan_set_option: inject_fault %lld", (long long)value); P->opt_fault = (int)value; }
   else { set_error("mfm_plan_set_option: unknown key '%s'", key); return MFM_ERR_ARG; }
   return MFM_OK;
@@ -2013,6 +2017,7 @@ extern "C" int mfm_plan_get_option(const MfmPlan* P, const char* key, int64_t* v
   else if (!strcmp(key, "handover_timeout_us")) *value = P->opt_timeout_us;
   else if (!strcmp(key, "grad_guard_offset")) *value = P->opt_guard;
   else if (!strcmp(key, "inject_fault")) *value = P->opt_fault;
+  else if (!strcmp(key, "bf16_dot")) *value = P->opt_bf16_dot;
   // read-only: whether the last forward / backward of the plan ran on role workgroups
   else if (!strcmp(key, "proj_roles_active")) *value = P->projfold_state == 1;
   else if (!strcmp(key, "dw_roles_active")) *value = P->dwfold_state == 1;

@@ -113,7 +113,10 @@ typedef struct MfmSeqDesc {
      d_h_init stay fp32).  The recurrent product rounds h_{t-1} / dA_t to bf16 anyway, so what is stored is exactly
      what the MFMA consumed; the x-projection and the saved gate activations are rounded once more (nearest even). */
   int32_t store_bf16;
-  int32_t reserved2_;
+  int32_t bf16_dot;      /* ABI 3, fp32 entry points, forward, small batches (one-row workgroups): the recurrent product runs on
+                            bf16 dot products (v_dot2c_f32_bf16; W and h_{t-1} rounded to bf16, fp32 accumulation) -- the small-batch
+                            counterpart of the bf16 entry points.  Honoured when every LSTM of the call sets it and the launcher
+                            has the variant (the decoders of the canonical sizes); otherwise the fp32 product runs. */
   float* h_last;         /* optional [B, Hp] fp32: forward also writes h_{T-1} here (the latent stack's input stays fp32) */
 } MfmSeqDesc;
 
@@ -376,6 +379,9 @@ int mfm_plan_train_step_staged(MfmPlan* plan, float* params, float* grads, float
  *   "grad_guard_offset"   element offset inside the gradient buffer of the guard word of mfm_adam_flat_guarded (default -1:
  *                         none; a wait that gives up then stores its NaN into grads[0]).  With an offset set, the plan's own
  *                         Adam launches are guarded, and every backward stores a NaN there while the status word is non-zero.
+ *   "bf16_dot"            bf16 plans at batch sizes below the bf16 MFMA recurrences (B < 192): 1 = the one-row recurrences
+ *                         that have the variant take their recurrent product on bf16 dot products (MfmSeqDesc::bf16_dot);
+ *                         default 0 (measured: profiles/r04_bf16_onerow.txt; MFM_BF16_DOT=1 sets the default for new plans).
  *   "inject_fault"        fault injection for tests, one shot: 1 = one projection producer of the next forward does not raise
  *                         its flag; 2 = one BPTT workgroup of the next backward does not stamp its last gate gradients.
  *                         The waiting side must time out, set the status word and poison the guard. */

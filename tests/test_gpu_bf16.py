@@ -496,10 +496,16 @@ def _bf16_engine(cfgs):
     return e, w
 
 
-@pytest.fixture(params=["all-bf16", "default", "all-bf16+panel", "all-bf16+panel160", "all-bf16+panel96", "all-bf16+proj128", "all-bf16+proj64", "all-bf16+fc1r16", "all-bf16+tnsplit", "all-bf16+dwmf4"])
+@pytest.fixture(params=["all-bf16", "default", "default+dot2", "all-bf16+panel", "all-bf16+panel160", "all-bf16+panel96", "all-bf16+proj128", "all-bf16+proj64", "all-bf16+fc1r16", "all-bf16+tnsplit", "all-bf16+dwmf4"])
 def seq_policy(request, monkeypatch):
     """a bf16 plan runs its recurrences on the bf16 MFMA kernels from B = 192 on and on the fp32 VALU kernels below
     (lstm_seq.hip::bf16_seq_pays); 'all-bf16' forces the bf16 kernels at every batch size."""
+    # "dot2": below B = 192 the decoders' one-row forward recurrence takes its product on v_dot2c_f32_bf16 (plan option
+    # "bf16_dot"; opt-in: measured no faster than the fp32 FMAs, profiles/r04_bf16_onerow.txt)
+    if "dot2" in request.param:
+        monkeypatch.setenv("MFM_BF16_DOT", "1")
+    else:
+        monkeypatch.delenv("MFM_BF16_DOT", raising=False)
     if request.param.startswith("all-bf16"):
         monkeypatch.setenv("MFM_BF16_SEQ_MINB", "1")
         monkeypatch.setenv("MFM_BF16_STORE", "1")       # and the bf16-RESIDENT saved activations (default from T*B = 3840)
