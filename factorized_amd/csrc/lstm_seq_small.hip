@@ -1125,7 +1125,7 @@ bool seq_small_foldproj_supported(int T, int B, const int* h, const int* k, int 
   }
   if (slots > PROJ_ROLE_SLOTS) return false;
   const int ks = proj_role_kstride(kmax);
-  return ((size_t)3 * PROJ_ROLE_CB * ks + 16 * PROJ_ROLE_PW) * sizeof(float) <= 160 * 1024;
+  return ((size_t)2 * PROJ_ROLE_CB * ks + 16 * PROJ_ROLE_PW) * sizeof(float) <= 160 * 1024;
 }
 
 int seq_small_foldproj_launch(SeqLaunch& L, const LatentDev& LD, ProjRole& PR, const float* params, hipStream_t stream) {
@@ -1150,7 +1150,7 @@ int seq_small_foldproj_launch(SeqLaunch& L, const LatentDev& LD, ProjRole& PR, c
   for (int i = 0; i < 4; ++i) { L.d[i].block_begin = total; total += L.B; }
   size_t lds_bytes = small_lds_bytes(L, false, 1);
   const size_t lat = ((size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + (size_t)LD.rec_size) * sizeof(float);
-  const size_t role = ((size_t)3 * PROJ_ROLE_CB * PR.kstride + 16 * PROJ_ROLE_PW) * sizeof(float);
+  const size_t role = ((size_t)2 * PROJ_ROLE_CB * PR.kstride + 16 * PROJ_ROLE_PW) * sizeof(float);
   lds_bytes = std::max(lds_bytes, std::max(lat, role));
   if (lds_bytes > 160 * 1024) return MFM_ERR_UNSUPPORTED;
   MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_foldproj_kernel<8, 2, 20, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -22,7 +22,7 @@ namespace mfm {
 
 constexpr int PROJ_ROLE_CB = 32;          // gate columns per block == time-step rows per item (B <= 32)
 constexpr int PROJ_ROLE_SLOTS = 32;       // column-block slots per time-step group (4 Hp / 32 summed over the encoders, padded)
-constexpr int PROJ_ROLE_MAXG = 3;         // 16-byte groups per thread and operand slice (k <= 384)
+constexpr int PROJ_ROLE_MAXG = 4;         // 16-byte groups per thread and operand slice (k <= 512: the YouTube-shape early-fusion encoder has k = 410)
 constexpr int PROJ_ROLE_FLAGS = 16;       // flag words per (encoder, time step)
 constexpr int PROJ_ROLE_PW = 4 * 96 + 4;  // floats per wave in the partial-tile buffer ([reg][96] + skew)
 
@@ -112,8 +112,9 @@ __device__ __forceinline__ void proj_role_body(const SeqLaunch& L, const ProjRol
     const int ks = PR.kstride;
     const int G = ((K + 15) >> 4) << 2;            // 16-byte groups per operand row (k padded to 16 with zeros)
     float* Ws = lds;                               // [32][ks]
-    float* Xs = lds + PROJ_ROLE_CB * ks;           // [2][32][ks]
-    float* Ps = Xs + 2 * PROJ_ROLE_CB * ks;        // [16 waves][PROJ_ROLE_PW]
+    float* Xs = lds + PROJ_ROLE_CB * ks;           // [32][ks]: ONE image -- the next slice waits in registers and is parked behind
+                                                   // the barrier that ends the product's reads (round 4: k = 410 fits the LDS)
+    float* Ps = Xs + PROJ_ROLE_CB * ks;            // [16 waves][PROJ_ROLE_PW]
 
     const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)E.w, 0, 4 * h * K * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)PR.x, 0, (PR.x_rows * PR.ldx) * 4, 0x00020000);
@@ -181,11 +182,10 @@ __device__ __forceinline__ void proj_role_body(const SeqLaunch& L, const ProjRol
     const int pw0 = (((orow >> 4) * 2 + (ocol >> 4)) * 4) * PROJ_ROLE_PW + (orow & 3) * 96 + (ocol & 15) + 16 * ((orow & 15) >> 2);
     float* const out = d.gates;
     const int64_t orow_stride = 4 * (int64_t)Hp;
-    int cur = 0;
     for (int t = grp; t < T; t += PR.groups) {
       const int tn = t + PR.groups;
       if (tn < T) load_x(tn, rx);
-      const float* xa = Xs + cur * (PROJ_ROLE_CB * ks) + (16 * fr + bi) * ks + 4 * q;
+      const float* xa = Xs + (16 * fr + bi) * ks + 4 * q;
       const float* wb = Ws + (16 * fc + bi) * ks + 4 * q;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       for (int g16 = kpart; g16 < NG16; g16 += 4) {
@@ -201,12 +201,11 @@ __device__ __forceinline__ void proj_role_body(const SeqLaunch& L, const ProjRol
         const float v = Ps[pw0] + Ps[pw0 + PROJ_ROLE_PW] + Ps[pw0 + 2 * PROJ_ROLE_PW] + Ps[pw0 + 3 * PROJ_ROLE_PW];
         st_agent(out + ((int64_t)t * B + orow) * orow_stride + col0 + ocol, cvalid ? v + bias : 0.0f);
       }
-      if (tn < T) park(Xs + (cur ^ 1) * (PROJ_ROLE_CB * ks), rx);
+      if (tn < T) park(Xs, rx);                              // (every wave is past its product: the barrier above)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every store of this thread has been acknowledged
       __syncthreads();
       if (tid == 0 && !(PR.fault && r == 0 && t == grp))
         __hip_atomic_store(PR.flags + ((int64_t)e * T + t) * PROJ_ROLE_FLAGS + cbl, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      cur ^= 1;
     }
   }
   // transposed-weight images for the BPTT launches of this step (lstm_seq_dev.h)
