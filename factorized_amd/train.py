@@ -220,3 +220,53 @@ class GraphedModuleStep:
         self.y.copy_(y)
         self.graph.replay()
         return self.loss, self.disc
+
+
+class GraphedStep:
+    """Any training step of a module-path model -- `loss = loss_fn(model, *inputs)`, backward, Adam -- captured once into a
+    hipGraph and replayed: the generic form of GraphedModuleStep for the classes whose outputs do not have the
+    (decoded, reg, missing) shape of the reference's main loop (the ablations M_A-M_D, MFM_missing, seq2seq, basic_missing:
+    reference mfm_model.py:201-467, 766-1017).  `inputs`: example device tensors; step(*tensors) copies into static buffers.
+    These classes issue 150-900 small launches per step from Python; replay removes the host from the step."""
+
+    def __init__(self, model, loss_fn, inputs, lr=1e-3, warmup=3):
+        dev = next(model.parameters()).device
+        self.model = model
+        self.static = [t.detach().clone() for t in inputs]
+        self.lr = torch.tensor(float(lr), device=dev)
+        self.opt = torch.optim.Adam(model.parameters(), lr=self.lr, capturable=True)
+
+        def step():
+            self.opt.zero_grad(set_to_none=False)
+            loss = loss_fn(model, *self.static)
+            loss.backward()
+            self.opt.step()
+            return loss.detach()
+
+        saved = [p.detach().clone() for p in model.parameters()]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        with torch.no_grad():
+            for p, q in zip(model.parameters(), saved):
+                p.copy_(q)
+            for st in self.opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = step()
+
+    def set_lr(self, lr):
+        self.lr.fill_(float(lr))
+
+    def step(self, *tensors):
+        for s, t in zip(self.static, tensors):
+            s.copy_(t)
+        self.graph.replay()
+        return self.loss

@@ -58,6 +58,24 @@ for _ in range(300):
 torch.cuda.synchronize()
 print("%-70s %.3f ms/step" % ("model.engine.train_step(X, y)  (one C call)", 1e3 * (time.perf_counter() - t0) / 300))
 
+# the same loop captured once into a hipGraph (train.GraphedModuleStep: fused plan with device-side epochs / dropout streams,
+# optim.Adam(capturable=True)) and replayed; per-step input copy into the static batch included
+from factorized_amd import train
+for cls_name in ("MFM_KL_EF", "MFM_KL"):
+    from factorized_amd import mfm_model as M
+    model = getattr(M, cls_name)(*cfgs).to("cuda")
+    model.train()
+    gs = train.GraphedModuleStep(model, config, B, T, lr=1e-3)
+    for _ in range(30):
+        gs.step(X, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(300):
+        gs.step(X, y)
+    torch.cuda.synchronize()
+    print("%-70s %.3f ms/step" % ("GraphedModuleStep(%s): the unchanged loop as one hipGraph replay" % cls_name, 1e3 * (time.perf_counter() - t0) / 300))
+    assert torch.isfinite(gs.loss).item() and model.engine.check_status() == 0
+
 if os.environ.get("MFM_DROPIN_PROFILE"):
     import cProfile, pstats
     model = MFM_KL_EF(*cfgs)

@@ -58,11 +58,23 @@ def run(name, steps=40):
             fn()
         torch.cuda.synchronize()
         res.append(1e3 * (time.perf_counter() - t0) / steps)
+    # the same step captured once into a hipGraph and replayed (train.GraphedStep)
+    from factorized_amd import train
+    gs = train.GraphedStep(m, lambda mod, xx: objective(mod.forward(xx)), [x])
+    for _ in range(5):
+        gs.step(x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gs.step(x)
+    torch.cuda.synchronize()
+    res.append(1e3 * (time.perf_counter() - t0) / steps)
+    assert torch.isfinite(gs.loss).item()
     return res, sum(p.numel() for p in m.parameters())
 
 
 if __name__ == "__main__":
-    print("%-14s %10s %14s %12s %12s" % ("class", "params", "train ms/step", "samples/s", "forward ms"))
+    print("%-14s %10s %14s %12s %12s %16s %10s" % ("class", "params", "train ms/step", "samples/s", "forward ms", "graphed ms/step", "graphed/eager"))
     for n in NAMES:
-        (tr, fw), np_ = run(n)
-        print("%-14s %10d %14.3f %12.0f %12.3f" % (n, np_, tr, 32 / tr * 1e3, fw))
+        (tr, fw, gr), np_ = run(n)
+        print("%-14s %10d %14.3f %12.0f %12.3f %16.3f %10.2f" % (n, np_, tr, 32 / tr * 1e3, fw, gr, gr / tr))
