@@ -142,6 +142,7 @@ _SIGS = {
                                              C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(AdamSpan),
                                              C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mfm_plan_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "mfm_plan_set_option_str": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "mfm_plan_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     "mfm_plan_state_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mfm_plan_clear_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -13,6 +13,22 @@ namespace mfm {
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
 
+// ---------------------------------------------------------------- tuning / test switches ("MFM_*")
+// Every switch is looked up through opt_get().  Inside a call of a PLAN (mfm_plan_forward / backward / steps) it answers from
+// the plan's own table: the MFM_* environment as it was when the plan was CREATED, plus whatever mfm_plan_set_option_str
+// changed since -- no getenv on the launch path, and two plans of one process can run with different switches.  Outside a
+// plan call (the granular C entry points: GEMM, recurrences, ...) it reads the environment.
+const char* opt_get(const char* name);
+struct OptTable;                               // name -> value
+OptTable* opt_table_from_env();                // snapshot of every MFM_* variable
+void opt_table_set(OptTable* t, const char* name, const char* value /* null: remove */);
+void opt_table_free(OptTable* t);
+struct OptScope {                              // RAII: opt_get() answers from `t` on this thread while the scope lives
+  const OptTable* prev;
+  explicit OptScope(const OptTable* t);
+  ~OptScope();
+};
+
 #define MFM_HIP_CHECK(expr)                                   \
   do {                                                        \
     hipError_t _e = (expr);                                   \

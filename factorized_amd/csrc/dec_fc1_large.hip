@@ -515,7 +515,7 @@ int fc1_pack_prepare(const DecFc1LargeLaunch& L, Fc1PackArgs* out) {
 
 // true when dec_fc1_large_launch would take the 64-row kernel (the only one that reads the packed images)
 bool dec_fc1_large_uses_wimg(const DecFc1LargeLaunch& L) {
-  if (getenv("MFM_FC1_LARGE_ROWS") && atoi(getenv("MFM_FC1_LARGE_ROWS")) == 16) return false;
+  if (opt_get("MFM_FC1_LARGE_ROWS") && atoi(opt_get("MFM_FC1_LARGE_ROWS")) == 16) return false;
   for (int i = 0; i < L.n_items; ++i)
     if (fl_lds_bytes(L.it[i], FL_R64) > 156 * 1024 || (L.it[i].ld_dxhat & 3) || (L.it[i].Hp >> 3) > 16 ||
         (int64_t)L.rows * L.it[i].ldx >= ((int64_t)1 << 29))
@@ -526,19 +526,19 @@ bool dec_fc1_large_uses_wimg(const DecFc1LargeLaunch& L) {
 int dec_fc1_large_launch(DecFc1LargeLaunch& L, hipStream_t stream) {
   MFM_REQUIRE(L.n_items >= 1 && L.n_items <= 3 && L.rows >= 1, "dec fc1 (large): bad launch");
   // 64-row tiles unless they do not fit the LDS (or MFM_FC1_LARGE_ROWS=16 asks for the 16-row kernel)
-  int RT = (getenv("MFM_FC1_LARGE_ROWS") && atoi(getenv("MFM_FC1_LARGE_ROWS")) == 16) ? FL_ROWS : FL_R64;
+  int RT = (opt_get("MFM_FC1_LARGE_ROWS") && atoi(opt_get("MFM_FC1_LARGE_ROWS")) == 16) ? FL_ROWS : FL_R64;
   for (int i = 0; i < L.n_items; ++i) {
     MFM_REQUIRE(dec_fc1_large_supported(L.it[i]), "dec fc1 (large): item %d is not supported", i);
     if (RT == FL_R64 && (fl_lds_bytes(L.it[i], FL_R64) > 156 * 1024 || (L.it[i].ld_dxhat & 3) || (L.it[i].Hp >> 3) > 16 ||
                          (int64_t)L.rows * L.it[i].ldx >= ((int64_t)1 << 29)))
       RT = FL_ROWS;
   }
-  L.dbg = getenv("MFM_FC1_LARGE_DBG") ? atoi(getenv("MFM_FC1_LARGE_DBG")) : 0;
+  L.dbg = opt_get("MFM_FC1_LARGE_DBG") ? atoi(opt_get("MFM_FC1_LARGE_DBG")) : 0;
   const int n_tiles = (L.rows + RT - 1) / RT;
   // one workgroup per CU; workgroups per decoder in proportion to its cost per row tile: a fixed part (barriers, the
   // tile's loads) plus the matrix part
   const double c0_def = RT == FL_R64 ? 0.25 : 0.5;      // 16-row tiles, measured at B = 2048: 0.25 -> 124, 0.5 -> 93, 1 -> 94, 2 -> 106, 8 -> 119 us
-  const double c0 = getenv("MFM_FC1_LARGE_C0") ? atof(getenv("MFM_FC1_LARGE_C0")) : c0_def;      // tuning override
+  const double c0 = opt_get("MFM_FC1_LARGE_C0") ? atof(opt_get("MFM_FC1_LARGE_C0")) : c0_def;      // tuning override
   auto cost = [c0](const DecFc1LargeItem& I) { return c0 + (double)I.d * I.h / 31200.0; };
   double wsum = 0.0;
   size_t smem = 0;

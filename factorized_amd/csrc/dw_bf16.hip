@@ -275,6 +275,27 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
 
   // ---- add the tile into the gradient buffers.  Accumulator lane: rows (A columns) 4q + r, column bi of fragment j.
   if (L.debug_no_epilogue == 1) return;     // (tuning aid: MFM_DWB_NOEPI=1 measures the streaming part alone)
+  if (L.slabs) {
+    // slab form: the partial tile [MT][npad] of this (M-tile, row range) leaves with plain stores; column npad - 16 holds the
+    // column sums of A (bias gradients).  dw_reduce_kernel adds the row ranges up.
+    float* slab = L.slabs + I.slab_off + (int64_t)local * MT * I.npad;
+#pragma unroll
+    for (int j = 0; j < NFW; ++j) {
+      if (j >= njw) continue;
+      const int n = (wn + 4 * j) * 16 + bi;
+#pragma unroll
+      for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(int64_t)(wm * 16 * MF + i * 16 + 4 * q + r) * I.npad + n] = acc[i][j][r];
+    }
+    if (want_bias && bi == 0) {
+#pragma unroll
+      for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(int64_t)(wm * 16 * MF + i * 16 + 4 * q + r) * I.npad + I.npad - 16] = accb[i][r];
+    }
+    return;
+  }
   const int Hp = I.Hp, h = I.h;
 #pragma unroll
   for (int j = 0; j < NFW; ++j) {
@@ -313,6 +334,49 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
         atomicAdd(I.cb + g * h + u, accb[i][r]);
         if (I.cb2) atomicAdd(I.cb2 + g * h + u, accb[i][r]);
       }
+  }
+}
+
+// Second launch of the slab form: block = one row m of one M-tile (an A column = a gate unit), threads = 4-column groups of the
+// right-hand side; sums that row over the row ranges' slabs (coalesced 16-byte loads, the slabs are hot in L2 / MALL) and adds
+// the result into the gradient tensors -- every element is owned by exactly one thread: no atomics.
+__global__ __launch_bounds__(256) void dw_reduce_kernel(const DwbLaunch L) {
+  const int b = blockIdx.x;
+  int it = 0;
+#pragma unroll
+  for (int i = 1; i < MFM_DWB_MAXI; ++i) it += (i < L.n_items && b >= L.it[i].red_begin) ? 1 : 0;
+  const DwbItem& I = L.it[it];
+  const int MT = L.mt_cols;
+  const int row = b - I.red_begin;                 // A column index inside the item (padded to whole M-tiles)
+  const int mt = row / MT, ml = row - mt * MT;
+  const int m = row;
+  if (m >= I.M) return;
+  const int Hp = I.Hp, h = I.h;
+  const int g = m / Hp, u = m - g * Hp;
+  if (u >= h) return;
+  const int npad = I.npad;
+  const float* base = L.slabs + I.slab_off + ((int64_t)mt * MT + ml) * npad;       // slab of row range 0 (local = mt)
+  const int64_t sstride = (int64_t)I.m_tiles * MT * npad;                           // next row range: local += m_tiles
+  for (int c4 = threadIdx.x; c4 < npad / 4; c4 += 256) {
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < I.splits; ++sp) sum += *reinterpret_cast<const f32x4*>(base + sp * sstride + 4 * c4);
+    const int n = 4 * c4;
+    if (n == npad - 16) {                           // the column sums of A
+      if (I.cb) { I.cb[g * h + u] += sum[0]; if (I.cb2) I.cb2[g * h + u] += sum[0]; }
+      continue;
+    }
+    if (n > npad - 16) continue;
+#pragma unroll
+    for (int o = 0; o < MFM_DWB_MAXOUT; ++o) {
+      if (o < I.nout && n >= I.out[o].n0 && n < I.out[o].n0 + I.out[o].nvalid) {
+        float* dst = I.out[o].c + (int64_t)(g * h + u) * I.out[o].ldc + (n - I.out[o].n0);
+        float* dst2 = I.out[o].c2 ? I.out[o].c2 + (int64_t)(g * h + u) * I.out[o].ldc + (n - I.out[o].n0) : nullptr;
+        const int left = I.out[o].n0 + I.out[o].nvalid - n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < left) { dst[e] += sum[e]; if (dst2) dst2[e] += sum[e]; }
+      }
+    }
   }
 }
 
@@ -392,7 +456,7 @@ static const void* zero_block() {
 int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
   MFM_REQUIRE(L.n_items >= 1 && L.n_items <= MFM_DWB_MAXI && L.rows >= 1, "dw bf16: bad launch");
   if (!L.zeros) L.zeros = zero_block();
-  L.debug_no_epilogue = getenv("MFM_DWB_NOEPI") ? atoi(getenv("MFM_DWB_NOEPI")) : 0;
+  L.debug_no_epilogue = opt_get("MFM_DWB_NOEPI") ? atoi(opt_get("MFM_DWB_NOEPI")) : 0;
   MFM_REQUIRE(L.zeros, "dw bf16: no zero block");
   double wsum = 0.0;
   for (int i = 0; i < L.n_items; ++i) {
@@ -407,7 +471,7 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
   // (measured, MOSI sizes: T*B = 40960 rows 180 vs 173 us -- the streaming part is 24 us shorter, 134 vs 158, but the same
   // number of workgroups now adds 128-column partial tiles: 46 instead of 15 us of atomics -- T*B = 81920 rows 269 vs 309 us:
   // the wide form from 65536 rows on; MFM_DWB_MF=4 / 3 forces one)
-  const int mf_env = getenv("MFM_DWB_MF") ? atoi(getenv("MFM_DWB_MF")) : 0;
+  const int mf_env = opt_get("MFM_DWB_MF") ? atoi(opt_get("MFM_DWB_MF")) : 0;
   bool wide = !L.f32 && mf_env != 3 && (mf_env == 4 || L.rows >= 65536);
   for (int i = 0; i < L.n_items && wide; ++i) {
     int N = 0;
@@ -430,7 +494,7 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
   // "1 x CUs" came out at a few workgroups more than CUs and ran two rounds).  MFM_DWB_TARGET = workgroups / CUs (no fitting).
   const int cus = device_cus();
   const int rounds = L.rows <= 32768 ? 1 : 2;
-  const char* tenv = getenv("MFM_DWB_TARGET");
+  const char* tenv = opt_get("MFM_DWB_TARGET");
   int tiles = 0;
   size_t smem = 0;
   for (double fill = 0.98; ; fill -= 0.04) {
@@ -459,11 +523,30 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
     // stages: as many as fit ~144 KB, the counted wait and the cap (MFM_DWB_STAGES forces a count, clamped)
     int S = (int)((144 * 1024) / ((size_t)NI * DWB_THREADS * 16));
     S = std::min(S, DWB_MAX_WAIT / NI + 2);
-    if (const char* e = getenv("MFM_DWB_STAGES")) S = std::min(S, atoi(e));
+    if (const char* e = opt_get("MFM_DWB_STAGES")) S = std::min(S, atoi(e));
     S = std::max(DWB_MIN_STAGES, std::min(S, DWB_MAX_STAGES));
     I.stages = S;
     smem = std::max(smem, (size_t)S * NI * DWB_THREADS * 16);
   }
+  // slab form: partial tiles into the caller's scratch, summed by a second launch (bf16 form; MFM_DWB_SLABS=0 keeps the atomics)
+  bool slabs = L.slabs != nullptr && !L.f32 && !(opt_get("MFM_DWB_SLABS") && atoi(opt_get("MFM_DWB_SLABS")) == 0);
+  if (slabs) {
+    int64_t off = 0;
+    int red = 0;
+    for (int i = 0; i < L.n_items; ++i) {
+      DwbItem& I = L.it[i];
+      int N = 0;
+      for (int s = 0; s < I.nseg; ++s) N += I.seg[s].ncols;
+      I.npad = N + 16;                                  // (N is a multiple of 16: the bias column starts a 64-byte group)
+      I.slab_off = off;
+      off += (int64_t)I.m_tiles * I.splits * MT * I.npad;
+      I.red_begin = red;
+      red += I.m_tiles * MT;
+    }
+    if (off > L.slab_floats) slabs = false;           // (scratch sized for fewer workgroups than a forced MFM_DWB_TARGET asks for)
+    else { L.mt_cols = MT; L.red_rows = red; }
+  }
+  if (!slabs) L.slabs = nullptr;
   static bool attr = false;
   if (!attr) {
     MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_stream_kernel<false, 3, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -479,7 +562,17 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
   else if (wide) hipLaunchKernelGGL((dw_stream_kernel<false, 4, 8>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
   else hipLaunchKernelGGL((dw_stream_kernel<false, 3, 9>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
   MFM_LAUNCH_CHECK("dw_stream_kernel");
+  if (L.slabs && L.debug_no_epilogue != 1) {
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(L.red_rows), dim3(256), 0, stream, L);
+    MFM_LAUNCH_CHECK("dw_reduce_kernel");
+  }
   return MFM_OK;
+}
+
+int64_t dw_bf16_scratch_floats(int64_t rows) {
+  // one workgroup per CU and round, every partial tile at most 128 x (512 + 16) or 96 x (576 + 16) floats
+  const int64_t rounds = rows <= 32768 ? 1 : 2;
+  return rounds * device_cus() * (int64_t)128 * 528;
 }
 
 }  // namespace mfm

@@ -252,7 +252,7 @@ int dw_onepass_launch(DwLaunch& L, int precision, hipStream_t stream) {
     wsum += (double)I.m_tiles * (1.0 + (I.dx + I.hN + 1) / 128.0);
   }
   double target = 4.0 * device_cus();
-  if (const char* e = getenv("MFM_DW_TARGET")) target = atof(e) * device_cus();
+  if (const char* e = opt_get("MFM_DW_TARGET")) target = atof(e) * device_cus();
 
   int tiles = 0;
   size_t smem = 0;

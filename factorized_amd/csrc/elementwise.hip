@@ -19,6 +19,40 @@ int hip_fail(hipError_t e, const char* what) {
   return MFM_ERR_HIP;
 }
 
+// ---------------------------------------------------------------- option tables (common.h)
+}  // namespace mfm
+#include <stdlib.h>
+#include <string>
+#include <unordered_map>
+extern char** environ;
+namespace mfm {
+struct OptTable { std::unordered_map<std::string, std::string> kv; };
+static thread_local const OptTable* g_opt_scope = nullptr;
+const char* opt_get(const char* name) {
+  if (g_opt_scope) {
+    auto it = g_opt_scope->kv.find(name);
+    return it == g_opt_scope->kv.end() ? nullptr : it->second.c_str();
+  }
+  return ::getenv(name);
+}
+OptTable* opt_table_from_env() {
+  OptTable* t = new OptTable();
+  for (char** e = environ; e && *e; ++e) {
+    if (strncmp(*e, "MFM_", 4) != 0) continue;
+    const char* eq = strchr(*e, '=');
+    if (!eq) continue;
+    t->kv[std::string(*e, eq - *e)] = std::string(eq + 1);
+  }
+  return t;
+}
+void opt_table_set(OptTable* t, const char* name, const char* value) {
+  if (!t || !name) return;
+  if (value) t->kv[name] = value; else t->kv.erase(name);
+}
+void opt_table_free(OptTable* t) { delete t; }
+OptScope::OptScope(const OptTable* t) : prev(g_opt_scope) { g_opt_scope = t; }
+OptScope::~OptScope() { g_opt_scope = prev; }
+
 // ---------------------------------------------------------------- block reduction
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

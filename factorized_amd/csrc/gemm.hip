@@ -333,7 +333,7 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
   // 61 -> 69 TF/s on the projection shape, 86 -> 99 TF/s at 4096^3), but the step's grouped launches mix in small-K
   // and weight-gradient problems that lose more than that (proj launch at B=2048: 457 -> 514 us), and the bf16-operand
   // kernel is faster at 64x64 throughout (profiles/r02_gemm_tiles.txt)
-  if (const char* e = getenv("MFM_GEMM_FR")) {      // tuning override
+  if (const char* e = opt_get("MFM_GEMM_FR")) {      // tuning override
     FR = (e[0] == '4') ? 4 : ((e[0] == '2') ? 2 : 1);
     if (FR == 4 && mse_count > 0) FR = 2;
   }
@@ -342,7 +342,7 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
   for (int i = 0; i < count; ++i)
     base_blocks += (long)cdiv(descs[i].m, BT) * cdiv(descs[i].n, BT) * descs[i].batch;
   long kdepth = 2048;      // K elements one workgroup walks at most (accumulating problems; measured 256..4096 at B=512/2048)
-  if (const char* e = getenv("MFM_GEMM_KDEPTH")) { const long v = atol(e); if (v >= 64) kdepth = v; }   // tuning override
+  if (const char* e = opt_get("MFM_GEMM_KDEPTH")) { const long v = atol(e); if (v >= 64) kdepth = v; }   // tuning override
   bool vec = true;
   for (int i = 0; i < count; ++i) {
     const MfmGemmDesc& d = descs[i];

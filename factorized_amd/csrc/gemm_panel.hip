@@ -242,7 +242,7 @@ static int panel_height(const PanelLaunch& L, int precision, bool force, size_t*
   const int* cand = bf16 ? cand16 : cand32;
   const int ncand = bf16 ? 3 : 2;
   const double a = bf16 ? 128.0 : 59.0;      // fitted: fp32 rounds of 131 / 148 us at 64 / 80 rows, bf16 87 / 104 / 117 us at 96 / 128 / 160
-  const int forced = getenv("MFM_PANEL_BM") ? atoi(getenv("MFM_PANEL_BM")) : 0;
+  const int forced = opt_get("MFM_PANEL_BM") ? atoi(opt_get("MFM_PANEL_BM")) : 0;
   const long cus = device_cus();
   int BM = 0;
   size_t lds = 0;

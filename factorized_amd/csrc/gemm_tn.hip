@@ -172,7 +172,7 @@ bool gemm_tn_supported(const MfmGemmDesc* descs, int count, int max_rows, bool c
   if (count < 1 || count > MFM_GEMM_MAXP) return false;
   for (int i = 0; i < count; ++i) {
     const MfmGemmDesc& d = descs[i];
-    const bool dbg = getenv("MFM_PLAN_DEBUG") != nullptr;
+    const bool dbg = opt_get("MFM_PLAN_DEBUG") != nullptr;
     auto no = [&](const char* why) {
       if (dbg) fprintf(stderr, "[mfm gemm_tn] problem %d of %d declined: %s (m %d n %d k %d batch %d a_sm %lld a_sk %lld b_sk %lld b_sn %lld acc %d)\n", i, count, why,
                        d.m, d.n, d.k, d.batch, (long long)d.a_sm, (long long)d.a_sk, (long long)d.b_sk, (long long)d.b_sn, d.accumulate);
@@ -193,7 +193,7 @@ bool gemm_tn_supported(const MfmGemmDesc* descs, int count, int max_rows, bool c
 int gemm_tn_launch(const MfmGemmDesc* descs, int count, int max_rows, bool c_is_zero, hipStream_t stream) {
   MFM_REQUIRE(gemm_tn_supported(descs, count, max_rows, c_is_zero), "gemm tn: unsupported group (count %d)", count);
   int KC = 160;                                   // rows per chunk; MFM_GEMM_TN_KC=80|160|320 (tuning)
-  if (const char* e = getenv("MFM_GEMM_TN_KC")) { const int v = atoi(e); if (v == 80 || v == 160 || v == 320) KC = v; }
+  if (const char* e = opt_get("MFM_GEMM_TN_KC")) { const int v = atoi(e); if (v == 80 || v == 160 || v == 320) KC = v; }
   GemmGroup g;
   memset(&g, 0, sizeof(g));
   g.count = count;

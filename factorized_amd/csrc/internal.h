@@ -137,10 +137,16 @@ struct DwbItem {
   DwbSeg seg[2]; DwbOut out[MFM_DWB_MAXOUT];
   float* cb; float* cb2;                // optional: column sums of A (bias gradients), indexed like the rows of C
   int tile_begin, m_tiles, splits, rows_per_split, stages, pad_;     // filled by dw_bf16_launch
+  int64_t slab_off; int npad, red_begin;    // slab form (DwbLaunch::slabs): first float of this item's partial tiles, their row length, first row of the reduce launch
 };
-struct DwbLaunch { DwbItem it[MFM_DWB_MAXI]; int n_items, rows; const void* zeros; int debug_no_epilogue; int f32; };   // f32: the buffers hold fp32 (round 3; element counts / strides then count floats)   // zeros: >= 16 bytes of device zeros (null: the launcher's own)
+struct DwbLaunch { DwbItem it[MFM_DWB_MAXI]; int n_items, rows; const void* zeros; int debug_no_epilogue; int f32;
+                   // optional scratch (dw_bf16_scratch_floats()): every workgroup leaves its partial tile there with plain stores and a
+                   // second launch sums the row ranges of each M-tile and adds the result once -- instead of ~7 M atomicAdds into
+                   // the same few hundred KB (round 4); null: the atomics
+                   float* slabs; int64_t slab_floats; int mt_cols, red_rows; };   // f32: the buffers hold fp32 (round 3; element counts / strides then count floats)   // zeros: >= 16 bytes of device zeros (null: the launcher's own)
 int dw_bf16_supported(const DwbItem& I, int f32 = 0);
 int dw_bf16_launch(DwbLaunch& L, hipStream_t stream);
+int64_t dw_bf16_scratch_floats(int64_t rows);      // upper bound of what a launch over `rows` rows needs in DwbLaunch::slabs
 // x [rows, D] fp32 -> bf16 [rows, ldo] with up to three column ranges moved to 16-aligned positions (pad columns zero)
 int x_to_bf16_launch(const float* x, void* out, int64_t rows, int D, int ldo, const int* src0, const int* n, const int* dst0,
                      hipStream_t stream);

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512) void lstm_seq_kernel(const SeqLaunch L) {
 // is under-filled; the MFMA kernels (16 rows per workgroup) are the throughput path.  Override with
 // MFM_SEQ_PATH=mfma|small (tests run both).
 static bool use_small_path(int B) {
-  const char* e = getenv("MFM_SEQ_PATH");
+  const char* e = opt_get("MFM_SEQ_PATH");
   if (e && e[0] == 'm') return false;
   if (e && e[0] == 's') return true;
   return B <= 512;
@@ -371,7 +371,7 @@ static bool use_small_path(int B) {
 // recurrences on those until B reaches MFM_BF16_SEQ_MINB (default 192; measured crossover between B = 128 and 256,
 // profiles/r02_batch_sweep_mosi.txt).  The bf16 entry points of the ABI always run the bf16 kernels.
 bool bf16_seq_pays(int B) {
-  const char* e = getenv("MFM_BF16_SEQ_MINB");
+  const char* e = opt_get("MFM_BF16_SEQ_MINB");
   return B >= (e ? atoi(e) : 192);
 }
 
@@ -392,7 +392,7 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     MFM_REQUIRE(s.gates && s.hs && s.cs && s.w_hh, "lstm_seq[%d]: null buffer", i);
     if (s.is_dec) MFM_REQUIRE(s.w_ih && s.b_ih && s.b_hh && s.h_init, "lstm_seq[%d]: decoder needs w_ih/b/h_init", i);
     if (bwd) MFM_REQUIRE(s.dh_ext, "lstm_seq_bwd[%d]: dh_ext is null", i);
-    const bool force = getenv("MFM_SEQ_STEPWISE") != nullptr;          // testing: every LSTM step by step
+    const bool force = opt_get("MFM_SEQ_STEPWISE") != nullptr;          // testing: every LSTM step by step
     if (s.h > MFM_SEQ_MAX_RESIDENT_H || force) {
       MFM_REQUIRE(!s.store_bf16 && !s.h_last, "lstm_seq[%d]: h = %d takes the step-by-step fp32 path, which has no bf16-resident form", i, s.h);
       wide[nwide++] = s;
@@ -400,7 +400,7 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
   }
   if (fold && !fold->lat && !fold->pr && !fold->dr) {      // (images only: a plain launch)
     if (fold->img_written) *fold->img_written = false;
-    if (nwide || bf16 || !use_small_path(B) || getenv("MFM_SEQ_KS") || getenv("MFM_SEQ_ROWS")) fold = nullptr;
+    if (nwide || bf16 || !use_small_path(B) || opt_get("MFM_SEQ_KS") || opt_get("MFM_SEQ_ROWS")) fold = nullptr;
   } else if (fold && (nwide || bf16 || !use_small_path(B))) return MFM_ERR_UNSUPPORTED;
   if (nwide) {
     int rc = seq_stepwise(wide, nwide, T, B, bwd, stream);
@@ -412,7 +412,7 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
   // (B=2048: encoder recurrences 154 -> 132 us forward, 163 -> 151 us backward).  While everything is
   // resident at once the caller's order is kept: widest-first measured 0.8 % slower per step at B=32.
   bool sorted = false;
-  if ((long)count * B > (long)device_cus() && !getenv("MFM_SEQ_KEEP_ORDER")) {
+  if ((long)count * B > (long)device_cus() && !opt_get("MFM_SEQ_KEEP_ORDER")) {
     std::stable_sort(descs, descs + count, [](const MfmSeqDesc& a, const MfmSeqDesc& b) { return a.h > b.h; });
     sorted = true;
   }

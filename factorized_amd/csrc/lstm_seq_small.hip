@@ -1009,7 +1009,7 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
   // pre-instantiated size tuples have R < 4 variants.
   const int cus = device_cus();
   int R = ((long)L.count * L.B < 6L * cus) ? 1 : 4;
-  if (const char* e = getenv("MFM_SEQ_ROWS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) R = v; }
+  if (const char* e = opt_get("MFM_SEQ_ROWS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) R = v; }
   for (int attempt = 0; attempt < 2; ++attempt) {
     const int tiles = cdiv(L.B, R);
     int total = 0;
@@ -1022,7 +1022,7 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
     L.n_img_blocks = 0;
     // (no idle CU left: the writers still pay -- they run in the launch's last round, ~2 us, against ~9 us of staging saved;
     //  MFM_WT_IMG_FULL=0: only with idle CUs)
-    static const bool img_full = !(getenv("MFM_WT_IMG_FULL") && atoi(getenv("MFM_WT_IMG_FULL")) == 0);
+    const bool img_full = !(opt_get("MFM_WT_IMG_FULL") && atoi(opt_get("MFM_WT_IMG_FULL")) == 0);
     if (!bwd && R == 1 && L.n_img > 0 && (cus - total >= 8 || img_full)) {
       L.img_begin = total; L.n_img_blocks = cus - total >= 8 ? std::min(cus - total, 64) : 32; total += L.n_img_blocks;
     }
@@ -1031,7 +1031,7 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
     // (profiles/r02_seq_ks8.txt) -- the step is a latency chain (LDS hand-over, barrier, reduction), not issue-bound enough
     // for fewer, fatter waves to pay
     bool fat = false;
-    if (const char* e = getenv("MFM_SEQ_KS")) fat = bwd && R == 1 && max_threads / 2 <= 512 && atoi(e) == 8;
+    if (const char* e = opt_get("MFM_SEQ_KS")) fat = bwd && R == 1 && max_threads / 2 <= 512 && atoi(e) == 8;
     if (fat) done = try_all_fat(L, total, max_threads / 2, lds_bytes, stream, &err);
     // bf16 plans, forward, one-row tiles: the decoders' recurrent product on v_dot2c_f32_bf16 (opt-in, small_fwd_body<.., BF>)
     if (!done && !bwd && R == 1 && L.bf16_dot && L.count == 3 && L.d[0].hk4 == 26 && L.d[1].hk4 == 6 && L.d[2].hk4 == 6) {
@@ -1080,9 +1080,9 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
 // hand-overs count on this launch becoming resident workgroup by workgroup in block order; launches of two queues that
 // together exceed the CUs can block each other's producers until the waits give up (status word, poisoned gradient guard).
 bool seq_small_folddw_supported(int T, int B) {
-  if (const char* e = getenv("MFM_DW_FOLD")) { if (atoi(e) == 0) return false; }
-  if (getenv("MFM_SEQ_KS") || getenv("MFM_SEQ_ROWS")) return false;
-  if (const char* e = getenv("MFM_LATENT_FOLD")) { if (atoi(e) == 0) return false; }
+  if (const char* e = opt_get("MFM_DW_FOLD")) { if (atoi(e) == 0) return false; }
+  if (opt_get("MFM_SEQ_KS") || opt_get("MFM_SEQ_ROWS")) return false;
+  if (const char* e = opt_get("MFM_LATENT_FOLD")) { if (atoi(e) == 0) return false; }
   return T >= 1 && B >= 1 && B <= DWR_ROWS && device_cus() - 4 * B >= 32;
 }
 
@@ -1111,9 +1111,9 @@ int seq_small_folddw_launch(SeqLaunch& L, const LatentDev& LD, DwRole& DR, const
 
 // Projection role workgroups for a forward fold launch: shapes the role kernel takes and enough idle CUs
 bool seq_small_foldproj_supported(int T, int B, const int* h, const int* k, int n_enc) {
-  if (const char* e = getenv("MFM_PROJ_FOLD")) { if (atoi(e) == 0) return false; }
-  if (getenv("MFM_SEQ_KS") || getenv("MFM_SEQ_ROWS")) return false;
-  if (const char* e = getenv("MFM_LATENT_FOLD")) { if (atoi(e) == 0) return false; }
+  if (const char* e = opt_get("MFM_PROJ_FOLD")) { if (atoi(e) == 0) return false; }
+  if (opt_get("MFM_SEQ_KS") || opt_get("MFM_SEQ_ROWS")) return false;
+  if (const char* e = opt_get("MFM_LATENT_FOLD")) { if (atoi(e) == 0) return false; }
   if (n_enc != 4 || T < 1 || B < 1 || B > PROJ_ROLE_CB) return false;
   if (device_cus() - 4 * B < PROJ_ROLE_SLOTS) return false;
   int slots = 0, kmax = 0;
@@ -1137,7 +1137,7 @@ int seq_small_foldproj_launch(SeqLaunch& L, const LatentDev& LD, ProjRole& PR, c
   for (int i = 0; i < 4; ++i) { hh[i] = L.d[i].h; kk[i] = PR.e[i].k; }
   if (!seq_small_foldproj_supported(L.T, L.B, hh, kk, 4)) return MFM_ERR_UNSUPPORTED;
   int n_role = (device_cus() - 4 * L.B) / PROJ_ROLE_SLOTS * PROJ_ROLE_SLOTS;
-  if (const char* e = getenv("MFM_PROJ_FOLD_ROLES")) { const int v = atoi(e) / PROJ_ROLE_SLOTS * PROJ_ROLE_SLOTS; if (v >= PROJ_ROLE_SLOTS) n_role = v; }
+  if (const char* e = opt_get("MFM_PROJ_FOLD_ROLES")) { const int v = atoi(e) / PROJ_ROLE_SLOTS * PROJ_ROLE_SLOTS; if (v >= PROJ_ROLE_SLOTS) n_role = v; }
   PR.n_role = n_role; PR.groups = n_role / PROJ_ROLE_SLOTS;
   int kmax = 0, cb = 0;
   for (int i = 0; i < 4; ++i) {
@@ -1160,8 +1160,8 @@ int seq_small_foldproj_launch(SeqLaunch& L, const LatentDev& LD, ProjRole& PR, c
 }
 
 int seq_small_fold_launch(SeqLaunch& L, bool bwd, const LatentDev& LD, const float* params, float* grads, hipStream_t stream) {
-  if (const char* e = getenv("MFM_LATENT_FOLD")) { if (atoi(e) == 0) return MFM_ERR_UNSUPPORTED; }
-  if (getenv("MFM_SEQ_KS") || getenv("MFM_SEQ_ROWS")) return MFM_ERR_UNSUPPORTED;       // tuning overrides keep the plain launches
+  if (const char* e = opt_get("MFM_LATENT_FOLD")) { if (atoi(e) == 0) return MFM_ERR_UNSUPPORTED; }
+  if (opt_get("MFM_SEQ_KS") || opt_get("MFM_SEQ_ROWS")) return MFM_ERR_UNSUPPORTED;       // tuning overrides keep the plain launches
   const int want[4] = {8, 2, 20, 30};
   if (L.count != 4 || !LD.row_path || LD.nch != 4 || LD.pre || LD.B != L.B) return MFM_ERR_UNSUPPORTED;
   for (int i = 0; i < 4; ++i)
@@ -1174,7 +1174,7 @@ int seq_small_fold_launch(SeqLaunch& L, bool bwd, const LatentDev& LD, const flo
   }
   if (max_threads < 1024) max_threads = 1024;       // the chain's work items are tabulated for up to 1024 threads
   L.n_img_blocks = 0;
-  static const bool img_full = !(getenv("MFM_WT_IMG_FULL") && atoi(getenv("MFM_WT_IMG_FULL")) == 0);
+  const bool img_full = !(opt_get("MFM_WT_IMG_FULL") && atoi(opt_get("MFM_WT_IMG_FULL")) == 0);
   if (!bwd && L.n_img > 0 && (device_cus() - total >= 8 || img_full)) {
     L.img_begin = total; L.n_img_blocks = device_cus() - total >= 8 ? std::min(device_cus() - total, 64) : 32; total += L.n_img_blocks;
   }

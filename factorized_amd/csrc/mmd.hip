@@ -259,7 +259,7 @@ int mmd_group_launch(const MmdItem* items, int count, int64_t ldz, int64_t ldg, 
   const int ld = dmax | 1;
   // small batches: 8-row workgroups (4x the workgroups, a quarter of the serial work each); MFM_MMD_ROWS=8|32 overrides
   int MI = (B <= 256) ? 8 : 32;
-  if (const char* e = getenv("MFM_MMD_ROWS")) MI = (atoi(e) == 8) ? 8 : 32;
+  if (const char* e = opt_get("MFM_MMD_ROWS")) MI = (atoi(e) == 8) ? 8 : 32;
   const size_t lds = ((size_t)(2 * MI + 2 * JT) * ld + 2 * (size_t)MI * (JT + 1)) * sizeof(float);
   const void* fn = (MI == 8) ? (const void*)mmd_kernel<8> : (const void*)mmd_kernel<32>;
   if (lds > 64 * 1024) MFM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

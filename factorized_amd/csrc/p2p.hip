@@ -278,7 +278,7 @@ int mfm_p2p_create(int32_t nranks, int32_t rank, int64_t max_elems, void** handl
   p2p_point(h, rank, h->local);
   h->peer[rank] = h->local;
   h->d.err = reinterpret_cast<int*>(static_cast<char*>(h->local) + h->off_err);
-  const char* t = getenv("MFM_P2P_TIMEOUT_MS");
+  const char* t = opt_get("MFM_P2P_TIMEOUT_MS");
   const double ms = t ? atof(t) : 10000.0;
   h->timeout_ticks = (int64_t)(ms * 1e5);               // wall_clock64 ticks at 100 MHz
   h->connected = (nranks == 1);

@@ -149,8 +149,10 @@ struct MfmPlan {
   mfm::ProjPlan pj;                 // its tile image layout, panel height and pipeline depth
   int64_t pj_wimg, pj_bimg;         // scratch: packed bf16 weight tiles, combined biases
   unsigned long long x16_call = ~0ull;   // value of `calls` for which the forward already produced x16
+  int64_t dwb_slabs = -1, dwb_slab_floats = 0;      // st16: scratch for the partial tiles of the one-pass weight-gradient launch (dw_bf16.hip)
   unsigned long long pj_pack_call = ~0ull, fc1_pack_call = ~0ull;   // ... for which the step's pack launch built these images
   unsigned long long fc1_bwd_call = ~0ull;   // value of `calls` for which the forward already produced dH of the decoders (dec_fc1.hip)
+  mfm::OptTable* opts = nullptr;    // the MFM_* switches of this plan (common.h): environment at creation + mfm_plan_set_option_str
   // ---- per-plan switches (mfm_plan_set_option, include/mfm_hip.h)
   int opt_handover = 1;             // in-launch hand-overs (role workgroups) allowed
   int64_t opt_timeout_us = 50000;   // how long their consumers spin before they give up
@@ -207,10 +209,10 @@ static int build(MfmPlan* P) {
     // 0.406 vs 0.471, 0.418 vs 0.521, 0.450 vs 0.603, 0.481 vs 0.706 (round 2: crossover at T*B = 16384; then proj_bf16.hip, the
     // 64-row decoder fc1 and whole rounds of workgroups in the one-pass weight-gradient launch); MFM_BF16_STORE=1 forces it
     // on for every size, =0 off
-    const char* se = getenv("MFM_BF16_STORE");
+    const char* se = opt_get("MFM_BF16_STORE");
     long st_minrows = 3840;
-    if (const char* e = getenv("MFM_BF16_STORE_MINROWS")) st_minrows = atol(e);
-    bool ok = P->seq_bf16 && !getenv("MFM_SEQ_STEPWISE") && (se ? atoi(se) != 0 : TB >= st_minrows);
+    if (const char* e = opt_get("MFM_BF16_STORE_MINROWS")) st_minrows = atol(e);
+    bool ok = P->seq_bf16 && !opt_get("MFM_SEQ_STEPWISE") && (se ? atoi(se) != 0 : TB >= st_minrows);
     const int Dp = round_up(c.d_l, 16) + round_up(c.d_a, 16) + round_up(c.d_v, 16);
     int hmax = 0, np_max = 0;
     for (int e = 0; e < P->n_enc; ++e) {
@@ -225,7 +227,7 @@ static int build(MfmPlan* P) {
     ok = ok && hmax <= MFM_SEQ_MAX_RESIDENT_H && np_max <= 576 && (32 * (96 + np_max) / 8 + 511) / 512 <= 6;
     ok = ok && TB * 4 * round_up(hmax, 16) * 2 < ((int64_t)1 << 31) && TB * Dp * 2 < ((int64_t)1 << 31);
     P->st16 = ok;
-    if (getenv("MFM_PLAN_DEBUG")) fprintf(stderr, "[mfm plan] bf16: recurrences on the bf16 kernels %d, bf16-resident activations %d\n", (int)P->seq_bf16, (int)P->st16);
+    if (opt_get("MFM_PLAN_DEBUG")) fprintf(stderr, "[mfm plan] bf16: recurrences on the bf16 kernels %d, bf16-resident activations %d\n", (int)P->seq_bf16, (int)P->st16);
   }
   const int ESH = P->st16 ? 2 : 1;          // bf16-resident buffers take half the floats
   for (int e = 0; e < P->n_enc; ++e) {
@@ -267,6 +269,9 @@ static int build(MfmPlan* P) {
     P->x16_ld = at;
     P->x16 = carve(cur, TB * P->x16_ld / 2);
     for (int m = 0; m < 3; ++m) P->fc1_wimg[m] = carve(cur, (int64_t)(dec_fc1_large_wimg_bytes(dd[m]) + 3) / 4);
+    // partial tiles of the one-pass weight-gradient launch (slab form, dw_bf16.hip): 69 MB per round of workgroups
+    P->dwb_slab_floats = dw_bf16_scratch_floats(TB);
+    P->dwb_slabs = carve(cur, P->dwb_slab_floats);
     // the projections of this plan: proj_bf16.hip when its panel fits the LDS (MFM_PROJ16=0: gemm_panel / tiled GEMM)
     PanelLaunch PL;
     memset(&PL, 0, sizeof(PL));
@@ -275,13 +280,13 @@ static int build(MfmPlan* P) {
       PanelGroup& G = PL.g[e];
       G.n = 4 * P->enc[e].Hp; G.seg = P->enc[e].Hp; G.seg_valid = P->enc[e].h; G.k_off = P->enc_xoff[e]; G.k_len = P->enc_d[e];
     }
-    const char* pe = getenv("MFM_PROJ16");
+    const char* pe = opt_get("MFM_PROJ16");
     P->proj16 = (!pe || atoi(pe) != 0) && P->n_enc <= MFM_PANEL_MAXG && TB * P->D < ((int64_t)1 << 29) && proj_bf16_plan(PL, &P->pj);
     if (P->proj16) {
       P->pj_wimg = carve(cur, (int64_t)P->pj.ntiles * 2048);
       P->pj_bimg = carve(cur, P->pj.nbias);
     }
-    if (getenv("MFM_PLAN_DEBUG")) fprintf(stderr, "[mfm plan] bf16-resident projections: proj_bf16_kernel %d (%d tiles, %d-row panels, %d stages)\n", (int)P->proj16, P->pj.ntiles, P->pj.BM, P->pj.S);
+    if (opt_get("MFM_PLAN_DEBUG")) fprintf(stderr, "[mfm plan] bf16-resident projections: proj_bf16_kernel %d (%d tiles, %d-row panels, %d stages)\n", (int)P->proj16, P->pj.ntiles, P->pj.BM, P->pj.S);
   }
   // ---- Memory Fusion Network (variants 1, 2): every [T*B, .] tensor of the attention block and the memory recurrence
   P->tot = P->A2 = P->nzy = 0;
@@ -349,9 +354,9 @@ static int build(MfmPlan* P) {
   // encoder fc1 (mfm_model.py:60-61).  Batches beyond the row kernels' range (staged kernels, latent.hip) give the
   // early-fusion encoder's fc1 a stage of its own: the four heads together are the largest weight span (89 KB at the MOSI
   // sizes), alone it is 58 KB, and the LDS that frees doubles the rows a workgroup carries (backward 4 -> 8).
-  const int lat_row_maxb = getenv("MFM_LATENT_ROW_MAXB") ? atoi(getenv("MFM_LATENT_ROW_MAXB")) : 256;   // tuning override
+  const int lat_row_maxb = opt_get("MFM_LATENT_ROW_MAXB") ? atoi(opt_get("MFM_LATENT_ROW_MAXB")) : 256;   // tuning override
   bool split0 = V == 0 && c.B > lat_row_maxb && c.B > 4 * device_cus();   // (up to 4 rows x CUs one round of 4-row workgroups does)
-  if (const char* e = getenv("MFM_LATENT_SPLIT0")) split0 = V == 0 && atoi(e) != 0;
+  if (const char* e = opt_get("MFM_LATENT_SPLIT0")) split0 = V == 0 && atoi(e) != 0;
   for (int e = 0; e < nfc; ++e) {
     if (split0 && e == 3) ++st;
     add_op(P->lat_ops, L, st, e, L.in_off[e], last_off[e], in_n[e], in_n[e], o[pi.enc[e] + FC_W], o[pi.enc[e] + FC_B], 0, -1, 0.f);
@@ -419,7 +424,7 @@ static int build(MfmPlan* P) {
   // rows per workgroup: small batches want many workgroups, large ones fewer atomics
   const size_t LDS_BUDGET = 150 * 1024;
   int R = (c.B <= 64) ? 4 : ((c.B <= 1024) ? 8 : 16);
-  if (const char* e = getenv("MFM_LATENT_ROWS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) R = v; }   // tuning override
+  if (const char* e = opt_get("MFM_LATENT_ROWS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) R = v; }   // tuning override
   if (((size_t)panel + 2 * (size_t)rs) * sizeof(float) <= LDS_BUDGET) {
     L.wpanel = panel;
     while (R > 1 && (2 * (size_t)R * rs + panel) * sizeof(float) > LDS_BUDGET) R >>= 1;
@@ -433,7 +438,7 @@ static int build(MfmPlan* P) {
   {
     bool ok = L.wpanel > 0 && R <= 16;
     for (int i = 0; i < L.nops && ok; ++i) ok = (P->lat_ops[i].K & 3) == 0 && ((P->lat_ops[i].w_off - L.span_off[P->lat_ops[i].stage]) & 3) == 0;
-    if (const char* e = getenv("MFM_LATENT_MFMA")) ok = ok && atoi(e) != 0;
+    if (const char* e = opt_get("MFM_LATENT_MFMA")) ok = ok && atoi(e) != 0;
     L.mfma = ok ? 1 : 0;
   }
   // the forward keeps ONE record per row in LDS (the backward two), so it can take more rows per workgroup: a workgroup's
@@ -442,11 +447,11 @@ static int build(MfmPlan* P) {
     // (measured, profiles/r02_latent_rows.txt: a round of 4-row workgroups 31 us, of 8-row ones 43 us), so the rows double
     // while the launch would otherwise need more than one round of workgroups
     int Rf = R;
-    const int want = getenv("MFM_LATENT_ROWS_FWD") ? atoi(getenv("MFM_LATENT_ROWS_FWD")) : 0;   // tuning override
+    const int want = opt_get("MFM_LATENT_ROWS_FWD") ? atoi(opt_get("MFM_LATENT_ROWS_FWD")) : 0;   // tuning override
     while (Rf < 16 && (want ? Rf < want : cdiv(c.B, Rf) > device_cus()) && ((size_t)2 * Rf * rs + L.wpanel) * sizeof(float) <= LDS_BUDGET)
       Rf <<= 1;
     L.rows_fwd = Rf;
-    if (getenv("MFM_PLAN_DEBUG")) fprintf(stderr, "[mfm plan] latent: rec_size %d floats, weight panel %d floats, rows per workgroup bwd %d fwd %d\n", rs, L.wpanel, R, Rf);
+    if (opt_get("MFM_PLAN_DEBUG")) fprintf(stderr, "[mfm plan] latent: rec_size %d floats, weight panel %d floats, rows per workgroup bwd %d fwd %d\n", rs, L.wpanel, R, Rf);
   }
   // Latency path (latent.hip, row kernels): one row per workgroup while that still fits the chip in one
   // wave of workgroups and every layer meets the vector-load shape requirements.
@@ -462,7 +467,7 @@ static int build(MfmPlan* P) {
       for (int i = L.stage_begin[st]; i < L.stage_begin[st + 1]; ++i) { sn += P->lat_ops[i].N; sk += P->lat_ops[i].K; }
       ok = 4 * sn <= 1024 && 4 * sk <= 1024;      // one work item per thread and stage
     }
-    if (const char* e = getenv("MFM_LATENT_PATH")) { if (!strcmp(e, "staged")) ok = false; }
+    if (const char* e = opt_get("MFM_LATENT_PATH")) { if (!strcmp(e, "staged")) ok = false; }
     L.row_path = ok ? 1 : 0;
   }
   // row path: the work item of thread t in stage s is static, so it is tabulated here once (encoding: latent.hip).
@@ -475,7 +480,7 @@ static int build(MfmPlan* P) {
   L.nch = 1;
   if (L.row_path) {
     bool chains = 4 * c.B <= device_cus();
-    if (const char* e = getenv("MFM_LATENT_CHAINS")) chains = chains && atoi(e) != 0;
+    if (const char* e = opt_get("MFM_LATENT_CHAINS")) chains = chains && atoi(e) != 0;
     L.nch = chains ? 4 : 1;
     int* fw = P->lat_items.data();
     int* bw = fw + TABN;
@@ -540,7 +545,7 @@ static int build(MfmPlan* P) {
     // MFM_LATENT_PRE=1 (opt-in): chain workgroups of 512 threads that request the weights four stages ahead instead of one
     // -- measured no faster (13.5 vs 13.8 us forward: the stages are not waiting for weights), profiles/r02_latent_chains.txt
     L.pre = 0;
-    if (const char* e = getenv("MFM_LATENT_PRE")) L.pre = (atoi(e) != 0 && L.nch > 1 && L.nstages <= 6) ? 1 : 0;
+    if (const char* e = opt_get("MFM_LATENT_PRE")) L.pre = (atoi(e) != 0 && L.nch > 1 && L.nstages <= 6) ? 1 : 0;
     for (int ch = 0; ch < L.nch && L.pre; ++ch)
       for (int st = 0; st < L.nstages; ++st)
         if (L.nitems_fwd_c[ch][st] > 512 || L.nitems_bwd_c[ch][st] > 512) L.pre = 0;
@@ -553,7 +558,7 @@ static int build(MfmPlan* P) {
         for (int st = 0; st < L.nstages; ++st) mx = std::max(mx, std::max(L.nitems_fwd_c[ch][st], L.nitems_bwd_c[ch][st]));
       int in_sum = 0;
       for (int e = 0; e < 4; ++e) in_sum += L.enc_n[e];
-      if (mx <= 512 && in_sum <= 512 && !(getenv("MFM_LATENT_512") && atoi(getenv("MFM_LATENT_512")) == 0)) L.row_threads = 512;
+      if (mx <= 512 && in_sum <= 512 && !(opt_get("MFM_LATENT_512") && atoi(opt_get("MFM_LATENT_512")) == 0)) L.row_threads = 512;
     }
     if (L.nch > 1)       // whole-stage counts (bias-gradient loops of the backward walk all layers of a stage)
       for (int st = 0; st < L.nstages; ++st) {
@@ -587,7 +592,7 @@ static int build(MfmPlan* P) {
   // 1024: 1099 vs 117 -> from B = 48; MFM_MMD_GEMM_MINB moves the threshold (0 = never)
   {
     long minb = 48;
-    if (const char* e = getenv("MFM_MMD_GEMM_MINB")) minb = atol(e);
+    if (const char* e = opt_get("MFM_MMD_GEMM_MINB")) minb = atol(e);
     P->mmd_scr = (V == 2 && minb > 0 && c.B >= minb && c.B <= 8192) ? carve(cur, mmd_scratch_floats(c.B, 4)) : -1;
   }
   if (V != 0) P->dh_last[3] = carve(cur, (int64_t)c.B * P->nzy);     // d loss / d [mu_y | logvar_y] (or z_y)
@@ -695,10 +700,10 @@ static bool mfn_fused_desc(const MfmPlan* P, const float* params, float* W, MfnA
   F.dh2 = W + P->dh2; F.dlog = W + P->dlog; F.dh1 = W + P->dh1;
   F.p1 = c.drop_nn1; F.p2 = c.drop_nn2;
   if (c.precision != 0) return false;
-  const char* on = getenv("MFM_MFN_FUSED");
+  const char* on = opt_get("MFM_MFN_FUSED");
   if (!on || atoi(on) == 0) return false;
   long max_rows = 5120;
-  if (const char* e = getenv("MFM_MFN_FUSED_MAXROWS")) max_rows = atol(e);
+  if (const char* e = opt_get("MFM_MFN_FUSED_MAXROWS")) max_rows = atol(e);
   if ((int64_t)P->T * P->B > max_rows) return false;
   return mfn_att_fused_supported(F);
 }
@@ -719,7 +724,7 @@ static bool mfn_heads_desc(const MfmPlan* P, const float* params, float* W, MfnH
   if (H.nheads == 2) { H.w[1] = PW(P, params, pi.to_lv[3]); H.b[1] = PW(P, params, pi.to_lv[3] + 1); }
   H.zyin = W + P->zyin; H.dz = W + P->dh_last[3]; H.d_hT = W + P->d_hT;
   bool on = c.precision == 0;
-  if (const char* e = getenv("MFM_MFN_HEADS_FOLD")) on = on && atoi(e) != 0;
+  if (const char* e = opt_get("MFM_MFN_HEADS_FOLD")) on = on && atoi(e) != 0;
   H.on = on ? 1 : 0;
   return on;
 }
@@ -757,8 +762,8 @@ static int mfn_forward(MfmPlan* P, const float* params, int train, uint64_t seed
     // (lin_rows.hip: all operands of a workgroup requested at once, 9.2 instead of 13.7 us per launch at T*B = 640;
     // profiles/r02_lin_rows.txt); bf16 plans, larger batches and MFM_LIN_ROWS=0 keep the grouped GEMM
     long lr_max = 5120;
-    if (const char* e = getenv("MFM_LIN_ROWS_MAXROWS")) lr_max = atol(e);
-    const bool lr_on = prec == 0 && TB <= lr_max && !(getenv("MFM_LIN_ROWS") && atoi(getenv("MFM_LIN_ROWS")) == 0);
+    if (const char* e = opt_get("MFM_LIN_ROWS_MAXROWS")) lr_max = atol(e);
+    const bool lr_on = prec == 0 && TB <= lr_max && !(opt_get("MFM_LIN_ROWS") && atoi(opt_get("MFM_LIN_ROWS")) == 0);
     auto rows = [&](const MfmGemmDesc& d, int kind, float* aux, float p, unsigned op_id) {
       LinRowsItem it;
       memset(&it, 0, sizeof(it));
@@ -848,6 +853,7 @@ static int mfn_forward(MfmPlan* P, const float* params, int train, uint64_t seed
 static int forward(MfmPlan* P, const float* params, const float* x, const void* y, int train, uint64_t seed,
                    float* W, float* xhat_out[3], float* yhat_out, float* losses_out, hipStream_t s,
                    float* grads_to_zero = nullptr) {
+  OptScope _opts(P->opts);         // every MFM_* switch below this call: the plan's table, not the environment
   const MfmPlanConfig& c = P->cfg;
   const PIdx& pi = P->pi;
   const int V = c.variant;
@@ -870,9 +876,9 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
   // up to 5120 rows: decoder fc1, the squared error AND (training) dH = dx_hat Wfc run as one launch (dec_fc1.hip) whose
   // column groups add into dH (bf16 plans: operands rounded to bf16 in the kernel); larger T*B, shapes it does not take and
   // MFM_FC1_FUSED=0 use the grouped GEMMs (F4, B0)
-  const bool fc1_env_on = !(getenv("MFM_FC1_FUSED") && atoi(getenv("MFM_FC1_FUSED")) == 0);
+  const bool fc1_env_on = !(opt_get("MFM_FC1_FUSED") && atoi(opt_get("MFM_FC1_FUSED")) == 0);
   long fc1_max_rows = 5120;                        // measured crossover (profiles/r02_dec_fc1.txt)
-  if (const char* e = getenv("MFM_FC1_FUSED_MAXROWS")) fc1_max_rows = atol(e);
+  if (const char* e = opt_get("MFM_FC1_FUSED_MAXROWS")) fc1_max_rows = atol(e);
   const bool fc1_fused = fc1_env_on && TB <= fc1_max_rows && !P->st16;      // (the fused kernel reads fp32 hidden states)
   if (fc1_fused && train) { zs.ptr[3] = W + P->dhs_blk; zs.n[3] = P->dhs_len; }
   P->calls++;
@@ -910,7 +916,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       pjp = &PJD; P->pj_pack_call = P->calls;
     }
     if (st16 && train && !(xhat_out && (xhat_out[0] || xhat_out[1] || xhat_out[2])) &&
-        !(getenv("MFM_FC1_LARGE") && atoi(getenv("MFM_FC1_LARGE")) == 0)) {
+        !(opt_get("MFM_FC1_LARGE") && atoi(opt_get("MFM_FC1_LARGE")) == 0)) {
       DecFc1LargeLaunch FLp;
       memset(&FLp, 0, sizeof(FLp));
       FLp.n_items = 3; FLp.rows = (int)TB;
@@ -958,7 +964,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     // height and declines when its cost model favours the tiled kernel (measured crossover, profiles/r02_gemm_panel.txt:
     // T*B ~ 10240 in both dtypes at the MOSI sizes -- equal at B = 512, panel 135 vs 166 us fp32 and 86 vs 104 us bf16 at
     // B = 640); MFM_PANEL_MINROWS=n forces the panel kernel from n rows on (and the tiled one below)
-    const char* pe = getenv("MFM_PANEL_MINROWS");
+    const char* pe = opt_get("MFM_PANEL_MINROWS");
     const bool panel_forced = pe && TB >= atol(pe);
     const bool panel = (pe ? panel_forced : TB >= 16L * device_cus()) && P->n_enc <= MFM_PANEL_MAXG && (int64_t)TB * P->D < ((int64_t)1 << 29);
     if (panel || (st16 && P->proj16)) {
@@ -991,7 +997,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
   // workgroups of the encoder recurrence launch
   WtImgItem wt_items[MFM_WT_MAX];
   int n_wt_items = 0;
-  if (train && !seq_bf16 && !(getenv("MFM_WT_IMG") && atoi(getenv("MFM_WT_IMG")) == 0)) {
+  if (train && !seq_bf16 && !(opt_get("MFM_WT_IMG") && atoi(opt_get("MFM_WT_IMG")) == 0)) {
     bool all = true;
     for (int i = 0; i < P->n_enc + 3; ++i) all = all && P->wt_img[i] >= 0;
     if (all) {
@@ -1014,7 +1020,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     L.ops = reinterpret_cast<const LatOp*>(W + P->lat_ops_off);
     L.items_fwd = reinterpret_cast<const int*>(W + P->lat_items_off);
     L.items_bwd = L.items_fwd + (size_t)4 * MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
-    if (getenv("MFM_LATENT_DBG")) L.dbg = reinterpret_cast<unsigned long long*>(W + P->dbg_off);
+    if (opt_get("MFM_LATENT_DBG")) L.dbg = reinterpret_cast<unsigned long long*>(W + P->dbg_off);
     for (int e = 0; e < 4; ++e) {
       if (e == 3 && V != 0) { L.enc_h[e] = W + P->zyin; L.enc_ld[e] = P->nzy; continue; }
       L.enc_h[e] = st16 ? W + P->h_last[e] : W + P->enc[e].hs + (int64_t)(T - 1) * B * P->enc[e].Hp;
@@ -1153,7 +1159,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     // bf16-resident training steps: fc1, the squared error, d x_hat and dH in one launch of persistent workgroups
     // (dec_fc1_large.hip); MFM_FC1_LARGE=0 keeps the two grouped GEMMs
     if (st16 && train && !(xhat_out && (xhat_out[0] || xhat_out[1] || xhat_out[2])) &&
-        !(getenv("MFM_FC1_LARGE") && atoi(getenv("MFM_FC1_LARGE")) == 0)) {
+        !(opt_get("MFM_FC1_LARGE") && atoi(opt_get("MFM_FC1_LARGE")) == 0)) {
       DecFc1LargeLaunch FL;
       memset(&FL, 0, sizeof(FL));
       FL.n_items = 3; FL.rows = (int)TB;
@@ -1324,8 +1330,8 @@ static int mfn_backward(MfmPlan* P, const float* params, float* W, float* grads,
   } else {
     // fp32 plans with few rows: the four input-gradient products as row-block launches too (lin_rows.hip, trans = 1)
     long lr_max = 5120;
-    if (const char* e = getenv("MFM_LIN_ROWS_MAXROWS")) lr_max = atol(e);
-    const bool lr_on = prec == 0 && TB <= lr_max && !(getenv("MFM_LIN_ROWS") && atoi(getenv("MFM_LIN_ROWS")) == 0);
+    if (const char* e = opt_get("MFM_LIN_ROWS_MAXROWS")) lr_max = atol(e);
+    const bool lr_on = prec == 0 && TB <= lr_max && !(opt_get("MFM_LIN_ROWS") && atoi(opt_get("MFM_LIN_ROWS")) == 0);
     auto rows = [&](const MfmGemmDesc& d, int kind, float* aux) {
       LinRowsItem it;
       memset(&it, 0, sizeof(it));
@@ -1435,10 +1441,10 @@ static int dw_role_build(MfmPlan* P, const std::vector<MfmGemmDesc>& all, float*
     const int split = cdiv(q.k, DWR_KC);
     q.kps = round_up(cdiv(q.k, split), 4);
     if (d.a >= W + P->lat_grd && d.a < W + P->lat_grd + (int64_t)B * P->lat.rec_size) dep[i] = DWR_DEP_LATENT;
-    if (getenv("MFM_DW_FOLD_NODEP")) dep[i] = DWR_DEP_NONE;       // timing experiment only (wrong gradients): nothing waits
+    if (opt_get("MFM_DW_FOLD_NODEP")) dep[i] = DWR_DEP_NONE;       // timing experiment only (wrong gradients): nothing waits
   }
   int n_role = device_cus() - 4 * B;
-  if (const char* e = getenv("MFM_DW_FOLD_ROLES")) { const int v = atoi(e); if (v >= 1 && v <= n_role) n_role = v; }
+  if (const char* e = opt_get("MFM_DW_FOLD_ROLES")) { const int v = atoi(e); if (v >= 1 && v <= n_role) n_role = v; }
   if (n_role < 1) return MFM_ERR_UNSUPPORTED;
   DR.n_role = n_role;
   const int nslots = 4 * n_role;
@@ -1498,7 +1504,7 @@ static int dw_role_build(MfmPlan* P, const std::vector<MfmGemmDesc>& all, float*
     };
     for (size_t u = 0; u < ua.size(); ++u)
       put((int)(u / n_role), (int)(u % n_role), ua[u], ua[u].chunk, groups[ua[u].grp].dep | DWR_FIRST | DWR_LAST);
-    const bool store_ok = !getenv("MFM_DW_FOLD_ATOMICS");           // (A/B timing: MFM_DW_FOLD_ATOMICS=1 keeps the atomics)
+    const bool store_ok = !opt_get("MFM_DW_FOLD_ATOMICS");           // (A/B timing: MFM_DW_FOLD_ATOMICS=1 keeps the atomics)
     for (size_t j = 0; j < te.size(); ++j) {
       const Group& g = groups[te[j].grp];
       const int split = cdiv(g.k, g.kps);
@@ -1528,6 +1534,7 @@ static int dw_role_build(MfmPlan* P, const std::vector<MfmGemmDesc>& all, float*
 
 static int backward(MfmPlan* P, const float* params, const float* x, const void* y, int stage, float* W,
                     float* grads, hipStream_t s, const ExtGrads* ext = nullptr) {
+  OptScope _opts(P->opts);
   const MfmPlanConfig& c = P->cfg;
   const int V = c.variant;
   const int T = P->T, B = P->B;
@@ -1627,7 +1634,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     L.ops = reinterpret_cast<const LatOp*>(W + P->lat_ops_off);
     L.items_fwd = reinterpret_cast<const int*>(W + P->lat_items_off);
     L.items_bwd = L.items_fwd + (size_t)4 * MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
-    if (getenv("MFM_LATENT_DBG")) L.dbg = reinterpret_cast<unsigned long long*>(W + P->dbg_off);
+    if (opt_get("MFM_LATENT_DBG")) L.dbg = reinterpret_cast<unsigned long long*>(W + P->dbg_off);
     for (int m = 0; m < 3; ++m) {
       L.d_dec_init[m] = gen_on ? W + P->dec_dinit[m] : nullptr;
       L.dec_ld[m] = P->dec_h[m];
@@ -1673,7 +1680,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
                               imgs_on ? W + P->wt_img[2] : nullptr, imgs_on ? W + P->wt_img[3] : nullptr};
       // B <= 32: the idle CUs of this launch run every weight-gradient product of the step (dw_role_dev.h); B5 disappears
       if (!st16 && P->dwfold_state >= 0 && P->dw_table >= 0 && P->opt_handover && seq_small_folddw_supported(T, B) &&
-          !getenv("MFM_DW_ONEPASS_MINROWS") && !getenv("MFM_DW_F32_MINROWS") && !(getenv("MFM_GEMM_TN") && atoi(getenv("MFM_GEMM_TN")) == 0)) {
+          !opt_get("MFM_DW_ONEPASS_MINROWS") && !opt_get("MFM_DW_F32_MINROWS") && !(opt_get("MFM_GEMM_TN") && atoi(opt_get("MFM_GEMM_TN")) == 0)) {
         std::vector<MfmGemmDesc> all = tail;
         latent_products(all, false);
         for (int e = 0; e < 4; ++e) dA_gemms(P, P->enc[e], P->enc_p[e], W, grads, all, x + P->enc_xoff[e], P->D, P->enc_d[e], false);
@@ -1713,11 +1720,11 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     // then leaves the bias gradients to that launch's column sums instead of adding 1180 words per workgroup into the same
     // addresses (10 of its 60 us at B = 2048, profiles/r03_latent_mfma.txt); MFM_LATENT_BIAS_TN=0 keeps the atomics
     bool bias_in_tail = false;
-    if (!enc_bwd_done && !L.row_path && c.precision && B <= 8192 && !(getenv("MFM_GEMM_TN") && atoi(getenv("MFM_GEMM_TN")) == 0) &&
-        !(getenv("MFM_LATENT_BIAS_TN") && atoi(getenv("MFM_LATENT_BIAS_TN")) == 0)) {
-      const long minb = getenv("MFM_GEMM_TN_BF16_MINB") ? atol(getenv("MFM_GEMM_TN_BF16_MINB")) : 192;
+    if (!enc_bwd_done && !L.row_path && c.precision && B <= 8192 && !(opt_get("MFM_GEMM_TN") && atoi(opt_get("MFM_GEMM_TN")) == 0) &&
+        !(opt_get("MFM_LATENT_BIAS_TN") && atoi(opt_get("MFM_LATENT_BIAS_TN")) == 0)) {
+      const long minb = opt_get("MFM_GEMM_TN_BF16_MINB") ? atol(opt_get("MFM_GEMM_TN_BF16_MINB")) : 192;
       long rows16 = 8192;
-      if (const char* e = getenv("MFM_GEMM_TN_MAXROWS_BF16")) rows16 = atol(e);
+      if (const char* e = opt_get("MFM_GEMM_TN_MAXROWS_BF16")) rows16 = atol(e);
       bias_in_tail = B >= minb && B <= rows16;
     }
     L.skip_bias = bias_in_tail ? 1 : 0;
@@ -1755,7 +1762,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
   // LSTMs' sums over the rows on the one-pass kernel (dw_onepass.hip) -- parity-tested, measured slower at B=2048
   {
     long dw_min_rows = 1L << 60;
-    if (const char* e = getenv("MFM_DW_ONEPASS_MINROWS")) dw_min_rows = atol(e);
+    if (const char* e = opt_get("MFM_DW_ONEPASS_MINROWS")) dw_min_rows = atol(e);
     const bool onepass = !st16 && TB >= dw_min_rows && (int64_t)TB * P->D < ((int64_t)1 << 29);
     if (st16) {
       // the batch as bf16, modality slices on 16-column boundaries (what the one-pass kernel streams by LDS-DMA)
@@ -1797,13 +1804,14 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
           dA_gemms(P, P->dec[m], P->dec_p[m], W, grads, tail, W + P->dec_init[m], P->dec_h[m], P->dec_h[m], true, true);
         }
       MFM_REQUIRE(DB.n_items <= MFM_DWB_MAXI, "plan: %d one-pass items", DB.n_items);
+      if (P->dwb_slabs >= 0) { DB.slabs = W + P->dwb_slabs; DB.slab_floats = P->dwb_slab_floats; }
       RUN(K_DEC_DW, dw_bf16_launch(DB, s));
     }
     // fp32 plans at large T*B (round 3): the LSTMs' sums over the rows on the fp32 form of the one-pass kernel
     // (dw_stream_kernel<true>: the batch and the fp32 dA / h buffers streamed by LDS-DMA in memory order, exact fp32 MFMA
     // chains); MFM_DW_F32_MINROWS moves the threshold (0 = off)
     long f32_min_rows = 0;          // measured slower than the grouped GEMM (dw_bf16.hip, launcher note): opt-in
-    if (const char* e = getenv("MFM_DW_F32_MINROWS")) f32_min_rows = atol(e);
+    if (const char* e = opt_get("MFM_DW_F32_MINROWS")) f32_min_rows = atol(e);
     const bool f32pass = !c.precision && !onepass && f32_min_rows > 0 && TB >= f32_min_rows && TB > 1;
     bool f32_done[9] = {false, false, false, false, false, false, false, false, false};
     if (f32pass) {
@@ -1883,18 +1891,18 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     // fp32 plans at small T*B: the chunked kernel (gemm_tn.hip: one load round trip per workgroup instead of a 20-step ring;
     // profiles/r02_gemm_tn.txt); MFM_GEMM_TN=0 / larger row counts / bf16 plans: the grouped GEMM
     long tn_rows = 1024;         // measured crossover: 640 rows 21.7 vs 24.8 us, 1280 rows equal, 2560 rows 67 vs 59 us
-    if (const char* e = getenv("MFM_GEMM_TN_MAXROWS")) tn_rows = atol(e);
-    const bool tn_on = !c.precision && !(getenv("MFM_GEMM_TN") && atoi(getenv("MFM_GEMM_TN")) == 0);
+    if (const char* e = opt_get("MFM_GEMM_TN_MAXROWS")) tn_rows = atol(e);
+    const bool tn_on = !c.precision && !(opt_get("MFM_GEMM_TN") && atoi(opt_get("MFM_GEMM_TN")) == 0);
     // bf16 plans: the products over B rows (the latent stack's 22 Linears on their fp32 records, the decoders' t = 0 products
     // on bf16-resident dA) go to the chunked fp32 kernel too -- 22 small outputs with K = B are all split-K prologue on the grouped kernel (48 us at
     // B = 2048) -- the rest (bf16-resident operands, sums over T*B rows) stays on the grouped bf16 GEMM
     // (bf16-resident plans: that is the whole tail, one launch either way -- B = 192 / 256 / 512 / 1024 / 2048: 9.8 vs 11.8,
     // 10.0 vs 12.9, 11.2 vs 16.2, 16.4 vs 23.8, 22.2 vs 48.5 us; fp32-stored bf16 plans, B < 192, keep the one grouped launch;
     // MFM_GEMM_TN_BF16_MINB moves the threshold)
-    const long tn16_minb = getenv("MFM_GEMM_TN_BF16_MINB") ? atol(getenv("MFM_GEMM_TN_BF16_MINB")) : 192;
-    if (c.precision && B >= tn16_minb && !(getenv("MFM_GEMM_TN") && atoi(getenv("MFM_GEMM_TN")) == 0)) {
+    const long tn16_minb = opt_get("MFM_GEMM_TN_BF16_MINB") ? atol(opt_get("MFM_GEMM_TN_BF16_MINB")) : 192;
+    if (c.precision && B >= tn16_minb && !(opt_get("MFM_GEMM_TN") && atoi(opt_get("MFM_GEMM_TN")) == 0)) {
       long tn_rows16 = 8192;
-      if (const char* e = getenv("MFM_GEMM_TN_MAXROWS_BF16")) tn_rows16 = atol(e);
+      if (const char* e = opt_get("MFM_GEMM_TN_MAXROWS_BF16")) tn_rows16 = atol(e);
       std::vector<MfmGemmDesc> small, rest;
       for (const MfmGemmDesc& d : tail)
         ((!d.c_bf16 && d.k <= tn_rows16 && d.k <= 4L * B && gemm_tn_supported(&d, 1, (int)tn_rows16, true)) ? small : rest).push_back(d);
@@ -1957,8 +1965,8 @@ extern "C" int mfm_plan_create(const MfmPlanConfig* cfg, const int64_t* param_of
   P->timing_mask = 0; P->timing_every = 1; P->pool_used = 0; P->calls = 0; P->grads_prezeroed = nullptr;
   // MFM_SHARED_DEVICE=1 (several ranks / processes drive this GPU): the default of the "handover" option for plans created
   // from now on; the host side sets the option itself where it can tell (train.py::_mark_shared_device)
-  if (const char* e = getenv("MFM_SHARED_DEVICE")) P->opt_handover = atoi(e) == 0;
-  if (const char* e = getenv("MFM_BF16_DOT")) P->opt_bf16_dot = atoi(e) != 0;
+  if (const char* e = opt_get("MFM_SHARED_DEVICE")) P->opt_handover = atoi(e) == 0;
+  if (const char* e = opt_get("MFM_BF16_DOT")) P->opt_bf16_dot = atoi(e) != 0;
   int rc = build(P);
   if (rc != MFM_OK) { delete P; return rc; }
   *out = P;
@@ -1978,6 +1986,7 @@ extern "C" int mfm_plan_set_gauss(MfmPlan* P, const float* gauss) {
 extern "C" void mfm_plan_destroy(MfmPlan* P) {
   if (!P) return;
   for (auto& t : P->pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+  opt_table_free(P->opts);
   delete P;
 }
 
@@ -2009,6 +2018,14 @@ extern "C" int mfm_plan_set_option(MfmPlan* P, const char* key, int64_t value) {
   else if (!strcmp(key, "bf16_dot")) P->opt_bf16_dot = value != 0;
   else if (!strcmp(key, "inject_fault")) { MFM_REQUIRE(value >= 0 && value <= 2, "mfm_plan_set_option: inject_fault %lld", (long long)value); P->opt_fault = (int)value; }
   else { set_error("mfm_plan_set_option: unknown key '%s'", key); return MFM_ERR_ARG; }
+  return MFM_OK;
+}
+extern "C" int mfm_plan_set_option_str(MfmPlan* P, const char* key, const char* value) {
+  if (!P || !key) { set_error("mfm_plan_set_option_str: null argument"); return MFM_ERR_ARG; }
+  MFM_REQUIRE(strncmp(key, "MFM_", 4) == 0, "mfm_plan_set_option_str: '%s' is not an MFM_* switch", key);
+  opt_table_set(P->opts, key, value);
+  // launch forms that were decided by trying (fold launches, role workgroups) are tried again under the new switches
+  P->fold_state = 0; P->projfold_state = 0; P->dwfold_state = 0; P->dw_table_key = -1;
   return MFM_OK;
 }
 extern "C" int mfm_plan_get_option(const MfmPlan* P, const char* key, int64_t* value) {
@@ -2259,6 +2276,7 @@ extern "C" double mfm_plan_bytes_per_step(const MfmPlan* P) {
 // Algorithmic FLOPs of ONE launch of kernel `kid` (recurrent/GEMM kernels only; 0 otherwise).
 extern "C" double mfm_plan_kernel_flops(const MfmPlan* P, int kid) {
   if (!P) return 0.0;
+  OptScope _opts(P->opts);
   const double TB = (double)P->T * P->B;
   double f = 0.0;
   switch (kid) {
@@ -2284,8 +2302,8 @@ extern "C" double mfm_plan_kernel_flops(const MfmPlan* P, int kid) {
       for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m];
       // the fused kernel (dec_fc1.hip; the plan's default up to 5120 rows) also forms dH = dx_hat Wfc in the same launch
       long fc1_max_rows = 5120;
-      if (const char* e = getenv("MFM_FC1_FUSED_MAXROWS")) fc1_max_rows = atol(e);
-      const bool on = !(getenv("MFM_FC1_FUSED") && atoi(getenv("MFM_FC1_FUSED")) == 0);
+      if (const char* e = opt_get("MFM_FC1_FUSED_MAXROWS")) fc1_max_rows = atol(e);
+      const bool on = !(opt_get("MFM_FC1_FUSED") && atoi(opt_get("MFM_FC1_FUSED")) == 0);
       if (on && TB <= (double)fc1_max_rows) f *= 2.0;
       break;
     }

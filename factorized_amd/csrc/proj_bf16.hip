@@ -250,13 +250,13 @@ int proj_bf16_plan(const PanelLaunch& L, ProjPlan* out) {
   const int KP = round_up(L.K, PJ_BK);
   static const int cand[] = {160, 128, 96, 64};
   const long cus = device_cus();
-  const int forced = getenv("MFM_PROJ16_BM") ? atoi(getenv("MFM_PROJ16_BM")) : 0;
+  const int forced = opt_get("MFM_PROJ16_BM") ? atoi(opt_get("MFM_PROJ16_BM")) : 0;
   double best = 0.0;
   for (int i = 0; i < 4; ++i) {
     if (forced && cand[i] != forced) continue;
     const size_t a_lds = ((size_t)cand[i] * (KP + 8) * 2 + 1023) / 1024 * 1024;
     int S = 6;
-    if (const char* e = getenv("MFM_PROJ16_STAGES")) S = std::max(3, std::min(6, atoi(e)));
+    if (const char* e = opt_get("MFM_PROJ16_STAGES")) S = std::max(3, std::min(6, atoi(e)));
     while (S >= 3 && a_lds + (size_t)S * PJ_TILE * 2 + (size_t)nb * 4 > 160 * 1024) --S;
     if (S < 3) continue;
     const long rounds = (cdiv(std::max(L.M, 1), cand[i]) + cus - 1) / cus;
@@ -334,7 +334,7 @@ int proj_bf16_launch(const PanelLaunch& L, const ProjPlan& P, const void* wimg, 
     d.c = reinterpret_cast<__bf16*>(G.c); d.ldc = G.ldc; d.n = G.n; d.kt0 = P.kt0[i]; d.kt1 = P.kt0[i] + P.nkt[i]; d.bias_off = P.bias_off[i];
   }
   D.ngroups = L.ngroups; D.ntiles = P.ntiles; D.nbias = P.nbias; D.S = P.S;
-  D.dbg = getenv("MFM_PROJ16_DBG") ? atoi(getenv("MFM_PROJ16_DBG")) : 0;     // tuning aid: skip parts of the kernel
+  D.dbg = opt_get("MFM_PROJ16_DBG") ? atoi(opt_get("MFM_PROJ16_DBG")) : 0;     // tuning aid: skip parts of the kernel
   if (zs) {
     for (int i = 0; i < MFM_GEMM_ZSPANS; ++i) {
       if (zs->n[i] <= 0) continue;

@@ -300,6 +300,12 @@ class _Plan:
     def set_option(self, key, value):
         _lib.check(_lib.lib().mfm_plan_set_option(self.handle, key.encode(), int(value)), "mfm_plan_set_option(%s)" % key)
 
+    def set_switch(self, name, value):
+        """one of the plan's MFM_* tuning / test switches (a string, or None to remove it): the plan reads its OWN table, filled
+        from the environment when it was created -- never the environment itself -- on every launch"""
+        v = None if value is None else str(value).encode()
+        _lib.check(_lib.lib().mfm_plan_set_option_str(self.handle, name.encode(), v), "mfm_plan_set_option_str(%s)" % name)
+
     def get_option(self, key):
         v = C.c_int64(0)
         _lib.check(_lib.lib().mfm_plan_get_option(self.handle, key.encode(), C.byref(v)), "mfm_plan_get_option(%s)" % key)

@@ -386,6 +386,12 @@ int mfm_plan_train_step_staged(MfmPlan* plan, float* params, float* grads, float
  *                         its flag; 2 = one BPTT workgroup of the next backward does not stamp its last gate gradients.
  *                         The waiting side must time out, set the status word and poison the guard. */
 int mfm_plan_set_option(MfmPlan* plan, const char* key, int64_t value);
+/* The tuning / test switches named MFM_* ("Kernel selection and its overrides") belong to the PLAN: its table is
+ * filled from the environment when the plan is created and consulted -- never the environment -- by every launch the plan
+ * issues.  This call changes one entry afterwards (value NULL removes it); switches that shape the workspace (MFM_BF16_STORE,
+ * MFM_LATENT_*, ...) are read at creation only.  The granular entry points of this header, which have no plan, read the
+ * environment at each call. */
+int mfm_plan_set_option_str(MfmPlan* plan, const char* key, const char* value);
 int mfm_plan_get_option(const MfmPlan* plan, const char* key, int64_t* value);
 
 /* Device-side state of a plan inside its workspace: out[0] byte offset of the plan's own loss slots [MFM_LOSS_SLOTS] floats
