@@ -341,7 +341,9 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
 // right-hand side; sums that row over the row ranges' slabs (coalesced 16-byte loads, the slabs are hot in L2 / MALL) and adds
 // the result into the gradient tensors -- every element is owned by exactly one thread: no atomics.
 __global__ __launch_bounds__(256) void dw_reduce_kernel(const DwbLaunch L) {
-  const int b = blockIdx.x;
+  // two rows per block: threads [0, 128) row 2 b, [128, 256) row 2 b + 1
+  const int b = 2 * blockIdx.x + (threadIdx.x >> 7);
+  if (b >= L.red_rows) return;
   int it = 0;
 #pragma unroll
   for (int i = 1; i < MFM_DWB_MAXI; ++i) it += (i < L.n_items && b >= L.it[i].red_begin) ? 1 : 0;
@@ -357,15 +359,24 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const DwbLaunch L) {
   const int npad = I.npad;
   const float* base = L.slabs + I.slab_off + ((int64_t)mt * MT + ml) * npad;       // slab of row range 0 (local = mt)
   const int64_t sstride = (int64_t)I.m_tiles * MT * npad;                           // next row range: local += m_tiles
-  for (int c4 = threadIdx.x; c4 < npad / 4; c4 += 256) {
-    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    for (int sp = 0; sp < I.splits; ++sp) sum += *reinterpret_cast<const f32x4*>(base + sp * sstride + 4 * c4);
+  const int nsp = I.splits;
+  for (int c4 = threadIdx.x & 127; c4 < npad / 4; c4 += 128) {
     const int n = 4 * c4;
+    if (n > npad - 16) continue;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    const float* p = base + n;
+    int sp = 0;
+    for (; sp + 4 <= nsp; sp += 4) {                  // four independent loads in flight per thread
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p + (sp + 0) * sstride), b2 = *reinterpret_cast<const f32x4*>(p + (sp + 1) * sstride);
+      const f32x4 c = *reinterpret_cast<const f32x4*>(p + (sp + 2) * sstride), d = *reinterpret_cast<const f32x4*>(p + (sp + 3) * sstride);
+      s0 += a; s1 += b2; s2 += c; s3 += d;
+    }
+    for (; sp < nsp; ++sp) s0 += *reinterpret_cast<const f32x4*>(p + sp * sstride);
+    const f32x4 sum = (s0 + s1) + (s2 + s3);
     if (n == npad - 16) {                           // the column sums of A
       if (I.cb) { I.cb[g * h + u] += sum[0]; if (I.cb2) I.cb2[g * h + u] += sum[0]; }
       continue;
     }
-    if (n > npad - 16) continue;
 #pragma unroll
     for (int o = 0; o < MFM_DWB_MAXOUT; ++o) {
       if (o < I.nout && n >= I.out[o].n0 && n < I.out[o].n0 + I.out[o].nvalid) {
@@ -472,7 +483,11 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
   // number of workgroups now adds 128-column partial tiles: 46 instead of 15 us of atomics -- T*B = 81920 rows 269 vs 309 us:
   // the wide form from 65536 rows on; MFM_DWB_MF=4 / 3 forces one)
   const int mf_env = opt_get("MFM_DWB_MF") ? atoi(opt_get("MFM_DWB_MF")) : 0;
-  bool wide = !L.f32 && mf_env != 3 && (mf_env == 4 || L.rows >= 65536);
+  // (slab form: the 128-column tiles' larger partial tiles cost plain stores, not atomics -> wide from 8192 rows on)
+  // measured (profiles/r04_bf16_large_batch.txt): ahead up to T*B = 40960 rows, behind from 81920 (MFM_DWB_SLABS=1 / 0 forces)
+  const char* slab_env = opt_get("MFM_DWB_SLABS");
+  const bool slab_req = L.slabs != nullptr && !L.f32 && (slab_env ? atoi(slab_env) != 0 : L.rows <= 65536);
+  bool wide = !L.f32 && mf_env != 3 && (mf_env == 4 || L.rows >= (slab_req ? 8192 : 65536));
   for (int i = 0; i < L.n_items && wide; ++i) {
     int N = 0;
     for (int s = 0; s < L.it[i].nseg; ++s) N += L.it[i].seg[s].ncols;
@@ -529,7 +544,7 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
     smem = std::max(smem, (size_t)S * NI * DWB_THREADS * 16);
   }
   // slab form: partial tiles into the caller's scratch, summed by a second launch (bf16 form; MFM_DWB_SLABS=0 keeps the atomics)
-  bool slabs = L.slabs != nullptr && !L.f32 && !(opt_get("MFM_DWB_SLABS") && atoi(opt_get("MFM_DWB_SLABS")) == 0);
+  bool slabs = slab_req;
   if (slabs) {
     int64_t off = 0;
     int red = 0;
@@ -563,7 +578,7 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
   else hipLaunchKernelGGL((dw_stream_kernel<false, 3, 9>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
   MFM_LAUNCH_CHECK("dw_stream_kernel");
   if (L.slabs && L.debug_no_epilogue != 1) {
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3(L.red_rows), dim3(256), 0, stream, L);
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((L.red_rows + 1) / 2), dim3(256), 0, stream, L);
     MFM_LAUNCH_CHECK("dw_reduce_kernel");
   }
   return MFM_OK;
