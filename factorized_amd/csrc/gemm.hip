@@ -408,6 +408,11 @@ extern "C" int mfm_gemm_grouped_f32(const MfmGemmDesc* descs, int count, void* s
     mfm::set_error("mfm_gemm_grouped_f32: no problems");
     return MFM_ERR_ARG;
   }
+  for (int i = 0; i < count; ++i)       // (the library uses the reserved bytes internally: a caller's garbage there would be a device pointer)
+    if (descs[i].reserved_[0] != 0 || descs[i].reserved_[1] != 0) {
+      mfm::set_error("mfm_gemm_grouped_f32: problem %d has non-zero reserved_ fields (zero the struct before filling it)", i);
+      return MFM_ERR_ARG;
+    }
   int done = 0;
   while (done < count) {
     int n = count - done;
@@ -426,6 +431,11 @@ extern "C" int mfm_gemm_grouped_bf16(const MfmGemmDesc* descs, int count, void* 
     mfm::set_error("mfm_gemm_grouped_bf16: no problems");
     return MFM_ERR_ARG;
   }
+  for (int i = 0; i < count; ++i)
+    if (descs[i].reserved_[0] != 0 || descs[i].reserved_[1] != 0) {
+      mfm::set_error("mfm_gemm_grouped_bf16: problem %d has non-zero reserved_ fields (zero the struct before filling it)", i);
+      return MFM_ERR_ARG;
+    }
   int done = 0;
   while (done < count) {
     int n = count - done;

@@ -121,8 +121,13 @@ struct DwItem {
   int tile_begin, m_tiles, splits, rows_per_split;     // filled by dw_onepass_launch
 };
 struct DwLaunch { DwItem it[MFM_DW_MAXI]; int n_items, rows; };
+#if MFM_EXPERIMENTAL
 int dw_onepass_supported(const DwItem& I, int precision);
 int dw_onepass_launch(DwLaunch& L, int precision, hipStream_t stream);
+#else
+static inline int dw_onepass_supported(const DwItem&, int) { return 0; }
+static inline int dw_onepass_launch(DwLaunch&, int, hipStream_t) { return MFM_ERR_UNSUPPORTED; }
+#endif
 
 // dw_bf16.hip -- bf16-RESIDENT plans: every sum over the T*B rows that feeds an LSTM's (or a decoder fc1's) weight gradient
 // as one product C[M, N] += A^T [seg0 | seg1] per item, operands streamed by LDS-DMA and read with transposing LDS reads
@@ -182,9 +187,21 @@ struct MfnAttFused {
   float *dh2, *dlog, *dh1;                                             // backward outputs for the weight-gradient GEMMs
   float p1, p2; int train; unsigned long long seed;
 };
+// MFM_EXPERIMENTAL (Makefile: `make MFM_EXPERIMENTAL=1`): the two kernels that were built, parity-tested and measured SLOWER than
+// what they would replace -- mfn_att_fused.hip (profiles/r02_mfn_att_fused.txt) and dw_onepass.hip (r02_dw_onepass.txt) -- are
+// part of the library only in an experimental build; the default build carries neither their code nor their switches.
+#ifndef MFM_EXPERIMENTAL
+#define MFM_EXPERIMENTAL 0
+#endif
+#if MFM_EXPERIMENTAL
 bool mfn_att_fused_supported(const MfnAttFused& L);
 int mfn_att_fused_fwd_launch(const MfnAttFused& L, hipStream_t stream);
 int mfn_att_fused_bwd_launch(const MfnAttFused& L, hipStream_t stream);   // dcx must have been cleared (it is added to)
+#else
+static inline bool mfn_att_fused_supported(const MfnAttFused&) { return false; }
+static inline int mfn_att_fused_fwd_launch(const MfnAttFused&, hipStream_t) { return MFM_ERR_UNSUPPORTED; }
+static inline int mfn_att_fused_bwd_launch(const MfnAttFused&, hipStream_t) { return MFM_ERR_UNSUPPORTED; }
+#endif
 // mfn_mem.hip -- the heads on mfn_last = [h_l, h_a, h_v](T-1) | mem_T (mu_y and, variant 1, logvar_y) folded into the
 // memory recurrence launches: forward as the kernel's tail (mem_T is in its LDS), backward as its head (d mem_T and d h_T
 // from d [mu_y | logvar_y]); two ~6 us GEMM launches less per step.  The heads' weight gradients stay in the tail GEMM.

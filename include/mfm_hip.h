@@ -42,6 +42,10 @@ extern "C" {
 #define MFM_ABI_VERSION 3
 
 int mfm_abi_version(void);
+/* 1 when the library was built with MFM_EXPERIMENTAL=1: it then also carries the two kernels that measured slower than what
+ * they would replace (one-launch MFN attention block, fp32 / bf16 one-pass dW over fp32 buffers) and honours their switches
+ * MFM_MFN_FUSED / MFM_DW_ONEPASS_MINROWS; the default build ignores those switches. */
+int mfm_has_experimental(void);
 const char* mfm_last_error(void);
 /* number of CUs of the current device (for grid heuristics / reporting). */
 int mfm_device_cus(void);
@@ -69,7 +73,7 @@ typedef struct MfmGemmDesc {
    * rounding pass; c_bf16 -> `c` (and c2) receive bf16 (nearest even) instead of fp32 -- plain, non-accumulating
    * products only. */
   int32_t a_bf16, c_bf16;
-  int32_t reserved_[2];
+  int32_t reserved_[2];   /* MUST be zero (memset the struct first): used inside the library; the entry points reject anything else */
 } MfmGemmDesc;
 
 int mfm_gemm_grouped_f32(const MfmGemmDesc* descs /*host*/, int count, void* stream);

@@ -176,6 +176,7 @@ def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
     if "latpre" in variant:
         monkeypatch.setenv("MFM_LATENT_PRE", "1")
     if "dwonepass" in variant:
+        cases.need_experimental()
         monkeypatch.setenv("MFM_DW_ONEPASS_MINROWS", "1")   # dw_onepass_kernel<false>: the LSTM weight gradients in one pass
     else:                                                   # over dA (opt-in: measured slower than the GEMMs)
         monkeypatch.delenv("MFM_DW_ONEPASS_MINROWS", raising=False)

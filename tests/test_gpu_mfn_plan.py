@@ -59,6 +59,7 @@ def att_path(request, monkeypatch):
     # recurrence launches (the fp32 default)
     monkeypatch.delenv("MFM_MFN_HEADS_FOLD", raising=False)
     if request.param == "att-fused":
+        cases.need_experimental()
         monkeypatch.setenv("MFM_MFN_FUSED", "1")
         monkeypatch.setenv("MFM_MFN_FUSED_MAXROWS", "100000000")
     else:
