@@ -25,9 +25,19 @@ namespace {
 
 constexpr int TN_T = 32;          // tile edge
 
+// The kernel's own problem table (round 4): only what a TN product needs, so that MFM_TN_MAXP = 112 problems fit one kernel
+// argument block (12 KB; the grouped GEMM's table is 9.6 KB for 56): the ~90 weight-gradient products of the MFN plans
+// (six LSTMs, three decoders + fc1, eight attention Linears, 22 latent Linears) leave in ONE launch instead of two.
+struct TnProblem {
+  const float* a; const float* b; float* c; float* c2; float* csum;
+  int a_sz, b_sz, c_sz, a_sk, b_sk, ldc, m, n_valid, k, batch, tiles_m, tiles_n, block_begin, k_per_split, a_bf16;
+  float alpha;
+};
+struct TnGroup { TnProblem p[MFM_TN_MAXP]; int begins[MFM_TN_MAXP]; int count; };
+
 // TN_KC rows per chunk (80 / 160 / 320): 16-byte loads per thread and operand = TN_KC / 32
 template <int TN_KC>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmGroup g) {
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const TnGroup g) {
   constexpr int TN_LOADS = TN_KC * (TN_T / 4) / 256;
   extern __shared__ __attribute__((aligned(16))) float tn_lds[];
   float* As = tn_lds;
@@ -40,9 +50,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmGroup g) {
   int pi = 0;
   const int bid = blockIdx.x;
 #pragma unroll
-  for (int i = 1; i < MFM_GEMM_MAXP; ++i) pi += (bid >= g.begins[i]) ? 1 : 0;
-  const GemmProblem& P = g.p[pi];
-  const MfmGemmDesc& d = P.d;
+  for (int i = 1; i < MFM_TN_MAXP; ++i) pi += (bid >= g.begins[i]) ? 1 : 0;
+  const TnProblem& P = g.p[pi];
+  const TnProblem& d = P;
   int local = bid - P.block_begin;
   {
     // workgroups go to the 8 XCDs round-robin by id and every XCD has its own L2: give each XCD one contiguous run of a
@@ -115,8 +125,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmGroup g) {
   // ---- optional: column sums of the A slice (bias gradients riding on their weight gradient's product; internal.h).  The
   // condition is uniform over the workgroup.
   {
-    float* csum;
-    { unsigned long long bits = ((unsigned long long)(unsigned)d.reserved_[1] << 32) | (unsigned)d.reserved_[0]; csum = reinterpret_cast<float*>(bits); }
+    float* csum = d.csum;
     if (csum && tn == 0 && z == 0) {
       __shared__ float cs[4][TN_T];
       const int c = tid & 31, part = tid >> 5;
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmGroup g) {
 // true when every problem is an accumulating (or, with c_is_zero, plain) TN product the kernel takes and the row counts are small enough for the
 // chunking to pay (max_rows: the caller's crossover)
 bool gemm_tn_supported(const MfmGemmDesc* descs, int count, int max_rows, bool c_is_zero) {
-  if (count < 1 || count > MFM_GEMM_MAXP) return false;
+  if (count < 1 || count > MFM_TN_MAXP) return false;
   for (int i = 0; i < count; ++i) {
     const MfmGemmDesc& d = descs[i];
     const bool dbg = opt_get("MFM_PLAN_DEBUG") != nullptr;
@@ -186,6 +195,7 @@ bool gemm_tn_supported(const MfmGemmDesc* descs, int count, int max_rows, bool c
     if (d.c_bf16) return no("bf16 output");
     const int64_t lim = (int64_t)1 << 29;
     if ((int64_t)(d.k - 1) * d.a_sk + d.m >= lim || (int64_t)(d.k - 1) * d.b_sk + d.n >= lim) return false;
+    if (d.a_sz >= lim || d.b_sz >= lim || d.c_sz >= lim || d.ldc >= lim) return no("strides beyond 2^29");
   }
   return true;
 }
@@ -194,27 +204,29 @@ int gemm_tn_launch(const MfmGemmDesc* descs, int count, int max_rows, bool c_is_
   MFM_REQUIRE(gemm_tn_supported(descs, count, max_rows, c_is_zero), "gemm tn: unsupported group (count %d)", count);
   int KC = 160;                                   // rows per chunk; MFM_GEMM_TN_KC=80|160|320 (tuning)
   if (const char* e = opt_get("MFM_GEMM_TN_KC")) { const int v = atoi(e); if (v == 80 || v == 160 || v == 320) KC = v; }
-  GemmGroup g;
+  TnGroup g;
   memset(&g, 0, sizeof(g));
   g.count = count;
   int total = 0;
   for (int i = 0; i < count; ++i) {
-    GemmProblem& P = g.p[i];
-    P.d = descs[i];
-    if (P.d.n_valid <= 0 || P.d.n_valid > P.d.n) P.d.n_valid = P.d.n;
-    P.tiles_m = cdiv(P.d.m, TN_T);
-    P.tiles_n = cdiv(P.d.n, TN_T);
+    const MfmGemmDesc& s = descs[i];
+    TnProblem& P = g.p[i];
+    P.a = s.a; P.b = s.b; P.c = s.c; P.c2 = s.c2; P.csum = gemm_get_colsum_host(s);
+    P.a_sz = (int)s.a_sz; P.b_sz = (int)s.b_sz; P.c_sz = (int)s.c_sz; P.a_sk = (int)s.a_sk; P.b_sk = (int)s.b_sk; P.ldc = (int)s.ldc;
+    P.m = s.m; P.k = s.k; P.batch = s.batch; P.a_bf16 = s.a_bf16; P.alpha = s.alpha;
+    P.n_valid = (s.n_valid <= 0 || s.n_valid > s.n) ? s.n : s.n_valid;
+    P.tiles_m = cdiv(s.m, TN_T);
+    P.tiles_n = cdiv(s.n, TN_T);
     // equal chunks of at most TN_KC rows, multiples of 4 (the MFMA k-step)
-    int split = cdiv(P.d.k, KC);
-    const int kps = round_up(cdiv(P.d.k, split), 4);
-    split = cdiv(P.d.k, kps);
-    P.d.split_k = split;
+    int split = cdiv(s.k, KC);
+    const int kps = round_up(cdiv(s.k, split), 4);
+    split = cdiv(s.k, kps);
     P.k_per_split = kps;
     P.block_begin = total;
     g.begins[i] = total;
-    total += P.tiles_m * P.tiles_n * P.d.batch * split;
+    total += P.tiles_m * P.tiles_n * s.batch * split;
   }
-  for (int i = count; i < MFM_GEMM_MAXP; ++i) g.begins[i] = 0x7fffffff;
+  for (int i = count; i < MFM_TN_MAXP; ++i) g.begins[i] = 0x7fffffff;
   const size_t lds = (size_t)2 * KC * TN_T * sizeof(float);
 #define MFM_TN_GO(KC_)                                                                                             \
   do {                                                                                                             \

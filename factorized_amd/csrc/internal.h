@@ -8,6 +8,7 @@ namespace mfm {
 // gemm.hip
 #define MFM_GEMM_ZSPANS 4
 #define MFM_GEMM_MAXP 56   // problems per launch (the descriptors travel in the kernel-argument segment, ~9.6 KB)
+#define MFM_TN_MAXP 112    // ... of gemm_tn_launch, whose table is compact (gemm_tn.hip)
 struct ZeroSpans { float* ptr[MFM_GEMM_ZSPANS]; int64_t n[MFM_GEMM_ZSPANS]; };   // spans (multiples of 4 floats, 16-byte aligned) a GEMM launch also clears
 // optional per-problem output transform, applied to the finished element v of C (non-accumulating problems):
 //   1  relu + dropout:  aux <- (v > 0) * scale,  v <- max(v, 0) * scale      scale = 0 | 1/(1-p) in train mode, else 1
@@ -34,7 +35,7 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
 int device_cus();
 
 // gemm_tn.hip -- the accumulating weight-gradient products C += A^T B at small row counts: (tile, 160-row chunk) workgroups
-// that request their whole operand slices at once.  descs as for gemm_group_launch (count <= MFM_GEMM_MAXP).
+// that request their whole operand slices at once.  descs as for gemm_group_launch (count <= MFM_TN_MAXP).
 // c_is_zero: the outputs of non-accumulating problems are known to hold zeros (the step's gradient buffer), so adding is storing
 bool gemm_tn_supported(const MfmGemmDesc* descs, int count, int max_rows, bool c_is_zero);
 int gemm_tn_launch(const MfmGemmDesc* descs, int count, int max_rows, bool c_is_zero, hipStream_t stream);

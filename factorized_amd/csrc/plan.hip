@@ -1906,20 +1906,28 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
       std::vector<MfmGemmDesc> small, rest;
       for (const MfmGemmDesc& d : tail)
         ((!d.c_bf16 && d.k <= tn_rows16 && d.k <= 4L * B && gemm_tn_supported(&d, 1, (int)tn_rows16, true)) ? small : rest).push_back(d);
-      for (size_t done = 0; done < small.size(); done += MFM_GEMM_MAXP) {
-        const int cnt = (int)std::min(small.size() - done, (size_t)MFM_GEMM_MAXP);
+      for (size_t done = 0; done < small.size(); done += MFM_TN_MAXP) {
+        const int cnt = (int)std::min(small.size() - done, (size_t)MFM_TN_MAXP);
         RUN(K_ENC_DW, gemm_tn_launch(small.data() + done, cnt, (int)tn_rows16, true, s));
       }
       for (const MfmGemmDesc& d : rest) MFM_REQUIRE(!gemm_get_colsum_host(d), "plan: a product that carries bias column sums did not reach the chunked kernel");
       tail.swap(rest);
     }
     const int ntail = (int)tail.size();
-    for (int done = 0; done < ntail; done += MFM_GEMM_MAXP) {
-      const int cnt = std::min(ntail - done, (int)MFM_GEMM_MAXP);
+    // the chunked kernel takes up to MFM_TN_MAXP products per launch (the MFN plans' ~90 in one), the grouped GEMM MFM_GEMM_MAXP
+    const bool tail_tn = tn_on && ntail <= MFM_TN_MAXP && gemm_tn_supported(tail.data(), ntail, (int)std::min(tn_rows, (long)INT32_MAX), true);
+    const int per = tail_tn ? MFM_TN_MAXP : MFM_GEMM_MAXP;
+    for (int done = 0; done < ntail; done += per) {
+      const int cnt = std::min(ntail - done, per);
       const MfmGemmDesc* td = tail.data() + done;
       // (the gradient buffer was cleared at the start of the step, so the tail's non-accumulating products may add)
       if (tn_on && gemm_tn_supported(td, cnt, (int)std::min(tn_rows, (long)INT32_MAX), true)) RUN(K_ENC_DW, gemm_tn_launch(td, cnt, (int)std::min(tn_rows, (long)INT32_MAX), true, s));
-      else RUN(K_ENC_DW, c.precision ? mfm_gemm_grouped_bf16(td, cnt, s) : mfm_gemm_grouped_f32(td, cnt, s));
+      else {
+        for (int d2 = 0; d2 < cnt; d2 += MFM_GEMM_MAXP) {
+          const int c2 = std::min(cnt - d2, (int)MFM_GEMM_MAXP);
+          RUN(K_ENC_DW, c.precision ? mfm_gemm_grouped_bf16(td + d2, c2, s) : mfm_gemm_grouped_f32(td + d2, c2, s));
+        }
+      }
     }
   }
   return MFM_OK;
