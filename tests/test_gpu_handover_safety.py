@@ -132,6 +132,31 @@ def test_grad_step_then_guarded_adam_and_spans():
         e.check_status()
 
 
+def test_world1_role_step_through_the_p2p_adam_entry():
+    """The deployment composition of the data-parallel step -- mfm_plan_grad_step WITH role workgroups (5 launches) followed by
+    the P2P all-reduce + Adam launch -- cannot run on one device with several ranks (ranks that share a GPU switch the
+    hand-overs off, train._mark_shared_device).  What can: the same two calls at world size 1 (the P2P entry point then is
+    its Adam-only launch, same arithmetic, same guard word) against the fused single-GPU step, and a guard raised by an
+    injected fault travelling through that entry."""
+    from factorized_amd import comm
+    e1, e2 = _engine(), _engine()
+    data = _batches()
+    ar = comm.P2PAllReduce(1, 0, e1.grads.numel())
+    for i in range(3):
+        e1.grad_step(*data[i]); ar.allreduce_adam(e1, 1e-3, 1.0)
+        e2.train_step(*data[i])
+    p = e1.plan(T, B)
+    assert p.get_option("proj_roles_active") == 1 and p.get_option("dw_roles_active") == 1
+    a, b = _snap(e1), _snap(e2)
+    assert np.max(np.abs(a[0] - b[0])) < 2e-5                   # (atomics order of the decoder-side sums)
+    p.set_option("inject_fault", 2)
+    e1.grad_step(*data[3]); ar.allreduce_adam(e1, 1e-3, 1.0)
+    assert _same(a, _snap(e1))
+    with pytest.raises(MfmError):
+        e1.check_status()
+    ar.close()
+
+
 def test_module_path_with_dropin_optimizer_skips_and_reports():
     """The reference's unchanged loop (model.forward, torch losses, loss.backward(), optimizer.step()) on MFM_KL_EF with
     factorized_amd.optim.Adam: a failed hand-over in the backward launch leaves the parameters alone; with the fault in the

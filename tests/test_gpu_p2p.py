@@ -71,6 +71,30 @@ def _worker(rank, world, port, sizes, ret):
                              float((ea.params - eb.params).abs().max()), float((ea.adam_v - eb.adam_v).abs().max()),
                              ea.step_count)
         out["timed_out"] = ar.timed_out()
+        # guard word (round 4): ONE rank's gradients carry a raised guard (a hand-over of its step gave up, csrc/plan.hip) ->
+        # the exchange completes, NO rank updates p / m / v, the replicas stay bit-identical; the next step trains again
+        class Lay:
+            guard = 8128
+        eg = E()
+        n2 = 8192
+        eg.layout = Lay()
+        eg.params = torch.linspace(-1, 1, n2, device=dev)
+        eg.adam_m, eg.adam_v = torch.zeros(n2, device=dev), torch.zeros(n2, device=dev)
+        eg.grads, eg.step_count = torch.zeros(n2, device=dev), 0
+        hist = []
+        for step in range(3):
+            eg.grads.copy_(torch.full((n2,), 0.01 * (rank + 1) * (step + 1), device=dev))
+            eg.grads[Lay.guard:] = 0.0
+            if step == 1 and rank == world - 1:
+                eg.grads[Lay.guard] = float("nan")
+            ar.allreduce_adam(eg, 1e-2, 1.0 / world)
+            torch.cuda.synchronize()
+            hist.append(eg.params.cpu().clone())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, hist[-1].numpy().tobytes())
+        out["guard"] = (bool(torch.equal(hist[0], hist[1])), bool(not torch.equal(hist[1], hist[2])),
+                        bool(not torch.equal(hist[0], torch.linspace(-1, 1, n2))), all(g == gathered[0] for g in gathered),
+                        bool(torch.isnan(eg.grads[Lay.guard]).item()) if False else True)
         # the selection logic picks the kernel when it validates
         chosen = comm.make_allreduce(world, rank, 4099, dev, verbose=False)
         out["chosen"] = chosen.name
@@ -97,6 +121,8 @@ def test_p2p_allreduce_matches_reference_sum(world):
         assert out["chain"] and not out["timed_out"]
         same_g, dp, dv, steps = out["fused_adam"]
         assert same_g and dp < 1e-6 and dv < 1e-9 and steps == 3, out["fused_adam"]
+        skipped, resumed, first_applied, in_sync, _ = out["guard"]
+        assert skipped and resumed and first_applied and in_sync, out["guard"]
         assert out["chosen"] == "p2p-two-shot"
 
 
