@@ -1522,6 +1522,8 @@ static int dw_role_build(MfmPlan* P, const std::vector<MfmGemmDesc>& all, float*
     P->dw_table_ws = nullptr;
   }
   if (P->dw_table_ws != W) {
+    MFM_REQUIRE(!stream_capturing(s), "plan: the first backward of a plan uploads its weight-gradient block table from host memory, which "
+                                      "cannot be captured into a hipGraph -- run one eager step on this plan before capturing");
     MFM_HIP_CHECK(hipMemcpyAsync(W + P->dw_table, P->dw_table_host.data(), P->dw_table_host.size() * sizeof(int), hipMemcpyHostToDevice, s));
     P->dw_table_ws = W;
   }

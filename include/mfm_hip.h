@@ -396,6 +396,8 @@ int mfm_plan_set_option(MfmPlan* plan, const char* key, int64_t value);
  * MFM_LATENT_*, ...) are read at creation only.  The granular entry points of this header, which have no plan, read the
  * environment at each call. */
 int mfm_plan_set_option_str(MfmPlan* plan, const char* key, const char* value);
+/* also answers two read-only keys: "proj_roles_active" / "dw_roles_active" = 1 when the plan's last forward / backward ran on
+ * role workgroups */
 int mfm_plan_get_option(const MfmPlan* plan, const char* key, int64_t* value);
 
 /* Device-side state of a plan inside its workspace: out[0] byte offset of the plan's own loss slots [MFM_LOSS_SLOTS] floats

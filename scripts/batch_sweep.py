@@ -13,7 +13,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from factorized_amd import configs as C, engine, synth  # noqa: E402
 
-PEAK = 157.3
+PEAK = 157.3          # fp32 matrix == fp32 vector peak, TFLOP/s (MI355X_MICROARCH.md)
+PEAK_BF16 = 2500.0    # dense bf16 MFMA peak
 
 
 def run(B, path, steps, shape="mosi", T=20):
@@ -37,15 +38,17 @@ def run(B, path, steps, shape="mosi", T=20):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     w = e.work_per_step(T, B)
+    peak = PEAK_BF16 if path == "bf16" else PEAK
     return dict(B=B, path=path, ms=1e3 * dt, samples_per_s=B / dt, tflops=w["flops"] / dt / 1e12,
-                frac=w["flops"] / dt / 1e12 / PEAK, hbm_gbs=w["bytes"] / dt / 1e9)
+                frac=w["flops"] / dt / 1e12 / peak, hbm_gbs=w["bytes"] / dt / 1e9)
 
 
 if __name__ == "__main__":
     Bs = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [32, 128, 512, 2048, 8192]
     shape = sys.argv[2] if len(sys.argv) > 2 else "mosi"
     T = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-    print("# shape %s, T=%d; frac = fraction of the fp32 matrix peak (157.3 TF) for every row, bf16 rows included" % (shape, T))
+    print("# shape %s, T=%d; frac = fraction of the dtype's dense matrix peak: fp32 rows (auto) of 157.3 TF, bf16 rows of 2500 TF; alg GB/s = "
+          "algorithmic bytes per step / time (peak ~8000)" % (shape, T))
     print("%6s %6s %9s %12s %8s %8s %9s" % ("B", "path", "ms/step", "samples/s", "TFLOP/s", "frac", "alg GB/s"))
     for B in Bs:
         for path in (sys.argv[4].split(",") if len(sys.argv) > 4 else ("auto", "bf16")):
