@@ -24,6 +24,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from factorized_amd import configs as C, metrics, synth  # noqa: E402
 from factorized_amd.mfm_model import MFM, MFM_KL, MFM_KL_EF  # noqa: E402
+from factorized_amd._lib import MfmError  # noqa: E402
 
 
 def main():
@@ -84,6 +85,12 @@ def main():
                 gen = c["lda_xl"] * losses[1] + c["lda_xa"] * losses[2] + c["lda_xv"] * losses[3]
                 acc += (gen if stage == 1 else losses[0]) + c["lda_mmd"] * losses[4]
         train_loss = acc.item() / nb
+        # a hand-over inside a launch of the small-batch step can fail when something else runs on this GPU: the optimizer
+        # skipped those steps, the engine switched to separate launches -- say so and carry on
+        try:
+            eng.check_status()
+        except MfmError as err:
+            print("note:", err)
         model.eval()
         out = eng.forward(xv, yv, train=False, want_xhat=False)
         valid_loss = eng.loss_dict(out["losses"])["disc"]
