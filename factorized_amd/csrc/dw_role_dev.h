@@ -26,7 +26,7 @@ namespace mfm {
 constexpr int DWR_KC = 128;            // rows per chunk
 constexpr int DWR_T = 32;              // tile edge
 constexpr int DWR_MAXP = 56;
-constexpr int DWR_ROWS = 32;           // stamp words per (encoder, time step): B <= 32
+constexpr int DWR_ROWS = 64;           // stamp words per (encoder, time step): B <= 64 (round 4; the projections' role form stays at B <= 32)
 constexpr int DWR_TABLE_CAP = 16384;   // table entries carved in the plan workspace
 
 struct DwRoleProblem {
@@ -59,14 +59,19 @@ bool seq_small_folddw_supported(int T, int B);
 
 __device__ __forceinline__ void dwr_stamp(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// wave-level wait for `n` stamps at f[0..n) (n <= 128)
+// wave-level wait for `n` stamps at f[0..n) (n <= 256)
 __device__ __forceinline__ void dwr_wait(const unsigned* f, int n, unsigned epoch, const HoCtl& ctl) {
   const int lane = threadIdx.x & 63;
   const long long t0 = wall_clock64();
   for (;;) {
     const unsigned v0 = __hip_atomic_load(f + (lane < n ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned v1 = __hip_atomic_load(f + (lane + 64 < n ? lane + 64 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (__builtin_amdgcn_ballot_w64(v0 != epoch || v1 != epoch) == 0ull) return;
+    unsigned v2 = epoch, v3 = epoch;
+    if (n > 128) {      // (uniform)
+      v2 = __hip_atomic_load(f + (lane + 128 < n ? lane + 128 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v3 = __hip_atomic_load(f + (lane + 192 < n ? lane + 192 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (__builtin_amdgcn_ballot_w64(v0 != epoch || v1 != epoch || v2 != epoch || v3 != epoch) == 0ull) return;
     if (wall_clock64() - t0 > ctl.timeout) { ho_give_up(ctl); return; }      // (default ~50 ms: proj_role_dev.h, HoCtl)
     __builtin_amdgcn_s_sleep(8);
   }

@@ -15,7 +15,8 @@ from tests.cases import grad_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-SIZES = [(1, 1), (1, 6), (7, 3), (13, 2), (19, 21), (32, 1), (32, 20), (31, 5)]
+SIZES = [(1, 1), (1, 6), (7, 3), (13, 2), (19, 21), (32, 1), (32, 20), (31, 5),
+         (33, 20), (36, 7), (37, 20), (48, 2)]      # round 4: the weight-gradient role form up to B = 37 at T = 20 (projections: B <= 32)
 
 
 def _engine(cfgs, precision="fp32"):
@@ -95,6 +96,33 @@ def test_role_form_equals_separate_launches_and_oracle(B, T, monkeypatch):
     assert abs(ld1["loss"] - terms["loss"].item()) <= TOL * abs(terms["loss"].item())
     for n, p in m.named_parameters():
         assert grad_err(g1[n], p.grad.numpy()) < TOL, n
+
+
+@pytest.mark.parametrize("B,T", [(33, 20), (40, 20), (48, 7), (48, 1)])
+def test_weight_gradient_roles_beyond_32_rows(B, T, monkeypatch):
+    """Round 4: the weight-gradient role workgroups take up to 64 batch rows (64 stamp words per (encoder, time step), chunks
+    that no longer end on time-step boundaries, two accumulator rounds when the tile sets outnumber the idle CUs).  By default
+    they run only while their work fits behind the BPTT (B <= 37 at T = 20); MFM_DW_FOLD_MAXITER lifts that for the test.  The
+    projections keep their own launch beyond 32 rows."""
+    cfgs = C.canonical_configs(dropout=False)
+    _off(monkeypatch, False)
+    monkeypatch.setenv("MFM_DW_FOLD_MAXITER", "99")
+    e, w, xn, yn, ld1, g1 = _grads(cfgs, B, T)
+    p = e.plan(T, B)
+    assert p.get_option("dw_roles_active") == 1 and p.get_option("proj_roles_active") == 0
+    monkeypatch.delenv("MFM_DW_FOLD_MAXITER")
+    _off(monkeypatch, True)
+    _, _, _, _, ld0, g0 = _grads(cfgs, B, T)
+    assert max(grad_err(g1[n], g0[n]) for n in g0) < 2e-5
+    torch.set_num_threads(4)
+    m = O.build("kl_ef", cfgs)
+    O.load_numpy_weights(m, w)
+    m.train()
+    terms = O.loss_terms(m, torch.from_numpy(xn), torch.from_numpy(yn), cfgs[0])
+    terms["loss"].backward()
+    for n, q in m.named_parameters():
+        assert grad_err(g1[n], q.grad.numpy()) < TOL, n
+    assert e.check_status() == 0
 
 
 @pytest.mark.parametrize("roles", ["32", "64"])
