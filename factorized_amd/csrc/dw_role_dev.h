@@ -77,12 +77,28 @@ __device__ __forceinline__ void dwr_wait(const unsigned* f, int n, unsigned epoc
   }
 }
 
+// non-blocking form: true when all `n` stamps carry `epoch` (wave-uniform; every lane takes part)
+__device__ __forceinline__ bool dwr_ready(const unsigned* f, int n, unsigned epoch) {
+  const int lane = threadIdx.x & 63;
+  const unsigned v0 = __hip_atomic_load(f + (lane < n ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned v1 = __hip_atomic_load(f + (lane + 64 < n ? lane + 64 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned v2 = epoch, v3 = epoch;
+  if (n > 128) {
+    v2 = __hip_atomic_load(f + (lane + 128 < n ? lane + 128 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v3 = __hip_atomic_load(f + (lane + 192 < n ? lane + 192 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return __builtin_amdgcn_ballot_w64(v0 != epoch || v1 != epoch || v2 != epoch || v3 != epoch) == 0ull;
+}
+
 __device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned epoch, float* lds) {
   // One role workgroup = four slots of 256 threads that work on tiles with the SAME A slice (same rows, same 32 columns of
   // the gate-gradient / upstream-gradient operand: the dW_ih, dW_hh and bias tiles of one gate block, the column tiles of one
   // decoder fc1 row block ...): the slice is fetched once per workgroup -- one 16-byte agent-scope load per thread -- instead
-  // of once per tile.  Agent-scope loads come from the memory side, so this is what the launch's HBM traffic is made of:
-  // 44 -> ~15 MB of reads per launch at the canonical sizes (round 4, profiles/r04_traffic_B32.json).
+  // of once per tile (44.4 -> 39.0 MB of HBM-side reads per launch, profiles/r04_traffic_B32.json).
+  // Software pipeline (round 4): a block is a chain of memory round trips (stamp poll, A from the memory side, B from L2),
+  // ~5.5 us when run back to back, and a workgroup has 8-12 of them behind a 41 us BPTT.  So the NEXT block's operands are
+  // requested while the current one is multiplied: B always (it never depends on this launch), A when its stamps are already
+  // there (checked without blocking: the stamp loads are issued at the top of the iteration, read before its first barrier).
   constexpr int BL = DWR_KC * (DWR_T / 4) / 256;       // 16-byte loads per thread for a slot's B slice
   const int tid = threadIdx.x, sub = tid >> 8, t = tid & 255;
   const int lane = t & 63, wave = t >> 6;
@@ -90,75 +106,111 @@ __device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned ep
   const int wm = wave >> 1, wn = wave & 1;
   float* As = lds;                                                 // [DWR_KC][32], shared
   float* Bs = lds + (1 + sub) * (DWR_KC * DWR_T);                  // [DWR_KC][32] per slot
+  int* nready_lds = reinterpret_cast<int*>(lds + 5 * DWR_KC * DWR_T);
   const int r = blockIdx.x - 4 * DR.B;           // role index
   const int nslots = 4 * DR.n_role, slot = 4 * r + sub;
   f32x4 accs[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll 1
-  for (int it = 0; it < DR.n_iter; ++it) {
+
+  struct Item {                      // one table row as this thread's slot sees it (all fields wave-uniform)
+    bool active, gactive;
+    int p, pa, w, tm, z, m0, n0, kbeg, klen, dep, t0;
+  };
+  auto decode = [&](int it) {
+    Item I;
+    if (it >= DR.n_iter) { I.active = I.gactive = false; I.p = I.pa = 0; I.w = 0; I.tm = I.z = I.m0 = I.n0 = I.kbeg = I.klen = 0; I.dep = DWR_DEP_NONE; I.t0 = 0; return I; }
     int4 ent = DR.table[(int64_t)it * nslots + slot];
     int4 ea = DR.table[(int64_t)it * nslots + 4 * r];              // slot 0 describes the workgroup's A slice
     ent.x = __builtin_amdgcn_readfirstlane(ent.x); ent.y = __builtin_amdgcn_readfirstlane(ent.y);
     ent.z = __builtin_amdgcn_readfirstlane(ent.z); ent.w = __builtin_amdgcn_readfirstlane(ent.w);
     ea.x = __builtin_amdgcn_readfirstlane(ea.x); ea.y = __builtin_amdgcn_readfirstlane(ea.y);
     ea.z = __builtin_amdgcn_readfirstlane(ea.z); ea.w = __builtin_amdgcn_readfirstlane(ea.w);
-    const bool active = ent.x >= 0, gactive = ea.x >= 0;
-    const DwRoleProblem& P = DR.p[active ? ent.x : 0];
-    const DwRoleProblem& PA = DR.p[gactive ? ea.x : 0];
-    int la = ea.y;
-    la /= PA.tiles_n;
-    const int tm = la % PA.tiles_m, z = la / PA.tiles_m;           // (the same for every active slot of the workgroup)
-    const int tn = ent.y % P.tiles_n;
-    const int m0 = tm * DWR_T, n0 = tn * DWR_T;
-    const int kbeg = ea.z * PA.kps;
-    const int klen = gactive ? min(PA.k - kbeg, PA.kps) : 0;
-    const int dep = ea.w & 255, t0 = (ea.w >> 8) & 0xffff;
-    f32x4 rb[BL];
-    const float* A = PA.a + (int64_t)z * PA.a_sz;
-    const float* Bm = P.b + (int64_t)z * P.b_sz;
-    const int a_bytes = ((PA.m - 1) + (PA.k - 1) * PA.a_sk + 1) * 4;
+    I.active = ent.x >= 0; I.gactive = ea.x >= 0;
+    I.p = I.active ? ent.x : 0; I.pa = I.gactive ? ea.x : 0; I.w = ent.w;
+    const DwRoleProblem& P = DR.p[I.p];
+    const DwRoleProblem& PA = DR.p[I.pa];
+    int la = ea.y / PA.tiles_n;
+    I.tm = la % PA.tiles_m; I.z = la / PA.tiles_m;                 // (the same for every active slot of the workgroup)
+    I.m0 = I.tm * DWR_T; I.n0 = (ent.y % P.tiles_n) * DWR_T;
+    I.kbeg = ea.z * PA.kps;
+    I.klen = I.gactive ? min(PA.k - I.kbeg, PA.kps) : 0;
+    I.dep = I.gactive ? (ea.w & 255) : DWR_DEP_NONE; I.t0 = (ea.w >> 8) & 0xffff;
+    return I;
+  };
+  // the B operand (batch columns, hidden states, records of the forward) never depends on this launch.  Row kbeg + rr of the
+  // chunk pairs with row kbeg + rr - b_shift of B (the recurrent product sum_t dA_t^T h_{t-1}: rows of the first time step
+  // read zeros)
+  auto issue_b = [&](const Item& I, f32x4 (&rb)[BL]) {
+    const DwRoleProblem& P = DR.p[I.p];
+    const float* Bm = P.b + (int64_t)I.z * P.b_sz;
     const int b_bytes = ((max(P.n_valid, 1) - 1) + (max(P.k - P.b_shift, 1) - 1) * P.b_sk + 1) * 4;
-    const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc((void*)Bm, 0, b_bytes, 0x00020000);
-    // the B operand (batch columns, hidden states, records of the forward) never depends on this launch: requested before
-    // the wait for the A operand's stamps.  Row kbeg + rr of the chunk pairs with row kbeg + rr - b_shift of B (the
-    // recurrent product sum_t dA_t^T h_{t-1}: rows of the first time step read zeros)
-    if (active) {
 #pragma unroll
-      for (int j = 0; j < BL; ++j) {
-        const int idx = t + j * 256;
-        const int rr = idx >> 3, c4 = idx & 7;
-        const int br = kbeg + rr - P.b_shift;
-        const int offb = ((rr < klen) & (br >= 0) & (n0 + 4 * c4 < P.n_valid)) ? (br * P.b_sk + n0 + 4 * c4) * 4 : -16;
-        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bres, offb, 0, 0));
-      }
+    for (int j = 0; j < BL; ++j) {
+      const int idx = t + j * 256;
+      const int rr = idx >> 3, c4 = idx & 7;
+      const int br = I.kbeg + rr - P.b_shift;
+      const int offb = (I.active & (rr < I.klen) & (br >= 0) & (I.n0 + 4 * c4 < P.n_valid)) ? (br * P.b_sk + I.n0 + 4 * c4) * 4 : -16;
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bres, offb, 0, 0));
     }
-    // ONE wave per workgroup polls (many waves re-reading a few flag lines at the memory side wait on each other)
-    if (gactive && dep != DWR_DEP_NONE && tid < 64) {
-      if (dep == DWR_DEP_LATENT) dwr_wait(DR.flags + 4 * DR.T * DWR_ROWS, 4 * DR.B, epoch, DR.ctl);      // [4][B] dense
-      else dwr_wait(DR.flags + ((dep - 1) * DR.T + t0) * DWR_ROWS, DR.B, epoch, DR.ctl);
+  };
+  // A may have been written inside this launch (dA, the latent gradients): agent-scope load (sc1), one per thread
+  auto issue_a = [&](const Item& I) {
+    const DwRoleProblem& PA = DR.p[I.pa];
+    const float* A = PA.a + (int64_t)I.z * PA.a_sz;
+    const int a_bytes = ((PA.m - 1) + (PA.k - 1) * PA.a_sk + 1) * 4;
+    const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+    const int rr = tid >> 3, c4 = tid & 7;
+    const int offa = (I.gactive & (rr < I.klen) & (I.m0 + 4 * c4 < PA.m)) ? ((I.kbeg + rr) * PA.a_sk + I.m0 + 4 * c4) * 4 : -16;
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ares, offa, 0, 16));
+  };
+  auto stamps_of = [&](const Item& I, int& n) -> const unsigned* {
+    if (I.dep == DWR_DEP_LATENT) { n = 4 * DR.B; return DR.flags + 4 * DR.T * DWR_ROWS; }      // [4][B] dense
+    n = DR.B;
+    return DR.flags + ((I.dep - 1) * DR.T + I.t0) * DWR_ROWS;
+  };
+
+  Item cur = decode(0);
+  f32x4 rb[BL], ra = {0.f, 0.f, 0.f, 0.f};
+  issue_b(cur, rb);
+  bool a_pref = false;
+  if (cur.dep == DWR_DEP_NONE) { ra = issue_a(cur); a_pref = true; }
+#pragma unroll 1
+  for (int it = 0; it < DR.n_iter; ++it) {
+    const Item nxt = decode(it + 1);
+    // (1) the stamps of the current block, unless its A slice is already on its way; ONE wave per workgroup polls (many waves
+    //     re-reading a few flag lines at the memory side wait on each other)
+    if (!a_pref) {
+      if (cur.dep != DWR_DEP_NONE && tid < 64) { int n; const unsigned* f = stamps_of(cur, n); dwr_wait(f, n, epoch, DR.ctl); }
+      if (DR.any_dep) __syncthreads();
+      ra = issue_a(cur);
     }
-    if (DR.any_dep) __syncthreads();
+    // (2) are the next block's stamps there already?  (asked now, answered through LDS behind the barrier below)
+    if (tid < 64) {
+      bool ok = true;
+      if (nxt.dep != DWR_DEP_NONE) { int n; const unsigned* f = stamps_of(nxt, n); ok = dwr_ready(f, n, epoch); }
+      if (tid == 0) *nready_lds = ok ? 1 : 0;
+    }
+    // (3) operands of the current block -> LDS images
     {
-      // A may have been written inside this launch (dA, the latent gradients): agent-scope load (sc1), one per thread
+      const DwRoleProblem& PA = DR.p[cur.pa];
       const int rr = tid >> 3, c4 = tid & 7;
-      const int offa = (gactive & (rr < klen) & (m0 + 4 * c4 < PA.m)) ? ((kbeg + rr) * PA.a_sk + m0 + 4 * c4) * 4 : -16;
-      f32x4 ra = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ares, offa, 0, 16));
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        ra[e] = (m0 + 4 * c4 + e < PA.m) ? ra[e] : 0.0f;
+        ra[e] = (cur.m0 + 4 * c4 + e < PA.m) ? ra[e] : 0.0f;
         if (DR.bf16) ra[e] = (float)(__bf16)ra[e];
       }
       const int sw = (4 * c4 + 16 * (rr & 1)) & 31;
       *reinterpret_cast<f32x4*>(As + rr * DWR_T + sw) = ra;
     }
-    if (active) {
+    if (cur.active) {
+      const DwRoleProblem& P = DR.p[cur.p];
 #pragma unroll
       for (int j = 0; j < BL; ++j) {
         const int idx = t + j * 256;
         const int rr = idx >> 3, c4 = idx & 7;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          rb[j][e] = (n0 + 4 * c4 + e < P.n_valid) ? rb[j][e] : 0.0f;
+          rb[j][e] = (cur.n0 + 4 * c4 + e < P.n_valid) ? rb[j][e] : 0.0f;
           if (DR.bf16) rb[j][e] = (float)(__bf16)rb[j][e];
         }
         const int sw = (4 * c4 + 16 * (rr & 1)) & 31;
@@ -166,14 +218,21 @@ __device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned ep
       }
     }
     __syncthreads();
-    if (active) {
-      const bool a1 = (ent.w & DWR_ACC1) != 0;
+    // (4) the next block's operands are requested before the current one is multiplied
+    const bool nready = *nready_lds != 0;
+    issue_b(nxt, rb);
+    a_pref = false;
+    if (nready) { ra = issue_a(nxt); a_pref = true; }
+    // (5) product, epilogue
+    if (cur.active) {
+      const DwRoleProblem& P = DR.p[cur.p];
+      const bool a1 = (cur.w & DWR_ACC1) != 0;
       f32x4 acc = a1 ? accs[1] : accs[0];
-      if (ent.w & DWR_FIRST) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (cur.w & DWR_FIRST) acc = f32x4{0.f, 0.f, 0.f, 0.f};
       const int rot = 16 * (q & 1);
       const float* ap = As + q * DWR_T + ((16 * wm + bi + rot) & 31);
       const float* bp = Bs + q * DWR_T + ((16 * wn + bi + rot) & 31);
-      const int nks = (klen + 3) >> 2;               // rows klen .. 4 nks - 1 of the images are zeros (loaded out of range)
+      const int nks = (cur.klen + 3) >> 2;           // rows klen .. 4 nks - 1 of the images are zeros (loaded out of range)
       int ks = 0;
       for (; ks + 4 <= nks; ks += 4) {
         float a[4], b[4];
@@ -184,17 +243,17 @@ __device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned ep
       }
       for (; ks < nks; ++ks) acc = mma16x16x4(ap[ks * 4 * DWR_T], bp[ks * 4 * DWR_T], acc);
       if (a1) accs[1] = acc; else accs[0] = acc;
-      if (ent.w & DWR_LAST) {
-        float* __restrict__ C = P.c + (int64_t)z * P.c_sz;
-        float* __restrict__ C2 = P.c2 ? P.c2 + (int64_t)z * P.c_sz : nullptr;
-        const int col = n0 + 16 * wn + bi;
+      if (cur.w & DWR_LAST) {
+        float* __restrict__ C = P.c + (int64_t)cur.z * P.c_sz;
+        float* __restrict__ C2 = P.c2 ? P.c2 + (int64_t)cur.z * P.c_sz : nullptr;
+        const int col = cur.n0 + 16 * wn + bi;
         if (col < P.n_valid) {
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-            const int row = m0 + 16 * wm + 4 * q + rr;
+            const int row = cur.m0 + 16 * wm + 4 * q + rr;
             if (row < P.m) {
               const float v = P.alpha * acc[rr];
-              if (ent.w & DWR_STORE) {             // the tile's only contribution, into a buffer that holds zeros: a plain store
+              if (cur.w & DWR_STORE) {             // the tile's only contribution, into a buffer that holds zeros: a plain store
                 C[(int64_t)row * P.ldc + col] = v;
                 if (C2) C2[(int64_t)row * P.ldc + col] = v;
               } else {
@@ -206,7 +265,8 @@ __device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned ep
         }
       }
     }
-    __syncthreads();          // the images are free for the next block
+    __syncthreads();          // the images (and the answer word) are free for the next block
+    cur = nxt;
   }
 }
 

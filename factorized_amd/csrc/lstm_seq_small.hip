@@ -1100,7 +1100,7 @@ int seq_small_folddw_launch(SeqLaunch& L, const LatentDev& LD, DwRole& DR, const
   total += n_role;
   size_t lds_bytes = small_lds_bytes(L, true, 1);
   const size_t lat = ((size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + 2 * (size_t)LD.rec_size) * sizeof(float);
-  const size_t role = (size_t)5 * DWR_KC * DWR_T * sizeof(float);      // one shared A image + four B images
+  const size_t role = (size_t)5 * DWR_KC * DWR_T * sizeof(float) + 64;      // one shared A image + four B images + the pipeline's answer word
   lds_bytes = std::max(lds_bytes, std::max(lat, role));
   if (lds_bytes > 160 * 1024) return MFM_ERR_UNSUPPORTED;
   MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_folddw_kernel<8, 2, 20, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -1495,12 +1495,13 @@ static int dw_role_build(MfmPlan* P, const std::vector<MfmGemmDesc>& all, float*
     if ((int64_t)n_iter * nslots > DWR_TABLE_CAP) return MFM_ERR_UNSUPPORTED;
     // B > 32 (round 4: stamps for up to 64 rows): fewer idle CUs carry more work.  A role workgroup gets through one block per
     // ~5.5 us (a chain of memory round trips) and the BPTT it hides behind lasts ~1.45 us per time step whatever B is: beyond
-    // ~4 + 0.3 T blocks per workgroup the launch ends later than BPTT + separate launch would.  Measured, ms per step, role form
-    // vs separate launch: MOSI T = 20: B = 33 0.174 / 0.182, 36 0.180 / 0.188, 37 0.180 / 0.188, 38 0.184 / 0.189 (11 blocks),
-    // 39 0.219 / 0.190, 40 0.225 / 0.190, 48 0.256 / 0.197; YouTube shape B = 36: T = 35 0.308 / 0.258, T = 10 0.149 / 0.144 (two
+    // ~5 + 0.3 T blocks per workgroup the launch ends later than BPTT + separate launch would.  Measured, ms per step, role form
+    // vs separate launch: MOSI T = 20: B = 33 0.173 / 0.182, 36 0.177 / 0.188, 38 0.181 / 0.189 (11 blocks), 39 0.219 / 0.190,
+    // 40 0.218 / 0.190, 48 0.256 / 0.197 (a block is bound by the ~80 KB it pulls through the CU, not by latency: requesting the
+    // next block's operands during the product gained 1-2 %); YouTube shape B = 36: T = 35 0.308 / 0.258, T = 10 0.149 / 0.144 (two
     // accumulator rounds: excluded by the rule).  B <= 32 always takes the role form (MFM_DW_FOLD_MAXITER overrides)
     if (B > 32 || opt_get("MFM_DW_FOLD_MAXITER")) {
-      int max_iter = 4 + (3 * T) / 10;
+      int max_iter = 5 + (3 * T) / 10;
       if (const char* e = opt_get("MFM_DW_FOLD_MAXITER")) max_iter = atoi(e);
       if (n_iter > max_iter) return MFM_ERR_UNSUPPORTED;
     }

@@ -16,7 +16,7 @@ from tests.cases import grad_err
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 SIZES = [(1, 1), (1, 6), (7, 3), (13, 2), (19, 21), (32, 1), (32, 20), (31, 5),
-         (33, 20), (36, 7), (37, 20), (48, 2)]      # round 4: the weight-gradient role form up to B = 37 at T = 20 (projections: B <= 32)
+         (33, 20), (36, 7), (37, 20), (48, 2)]      # round 4: the weight-gradient role form up to B = 38 at T = 20 (projections: B <= 32)
 
 
 def _engine(cfgs, precision="fp32"):
@@ -102,7 +102,7 @@ def test_role_form_equals_separate_launches_and_oracle(B, T, monkeypatch):
 def test_weight_gradient_roles_beyond_32_rows(B, T, monkeypatch):
     """Round 4: the weight-gradient role workgroups take up to 64 batch rows (64 stamp words per (encoder, time step), chunks
     that no longer end on time-step boundaries, two accumulator rounds when the tile sets outnumber the idle CUs).  By default
-    they run only while their work fits behind the BPTT (B <= 37 at T = 20); MFM_DW_FOLD_MAXITER lifts that for the test.  The
+    they run only while their work fits behind the BPTT (B <= 38 at T = 20); MFM_DW_FOLD_MAXITER lifts that for the test.  The
     projections keep their own launch beyond 32 rows."""
     cfgs = C.canonical_configs(dropout=False)
     _off(monkeypatch, False)
