@@ -70,3 +70,17 @@ def test_ablation_and_missing_modality_classes_keep_reference_state_dict():
         assert list(sd.keys()) == list(rd.keys()), name
         assert all(tuple(sd[k].shape) == tuple(rd[k].shape) for k in sd), name
         m.load_state_dict(rd)
+
+
+def test_flat_layout_guard_word_sits_behind_every_tensor():
+    """The guard word of the guarded optimizers (include/mfm_hip.h, mfm_adam_flat_guarded) is a spare granule of the flat buffer:
+    inside it (so that a data-parallel all-reduce carries it), behind every tensor, outside every staged-training span."""
+    from factorized_amd import configs, engine
+    for variant in ("kl_ef", "kl", "mmd"):
+        cfgs = configs.canonical_configs(dropout=False)
+        lay = engine.FlatLayout(engine.param_shapes(cfgs, variant), variant)
+        assert lay.guard % engine.ALIGN == 0 and lay.total == lay.guard + engine.ALIGN
+        for (off, n, _) in lay.slots:
+            assert off + n <= lay.guard
+        assert max(e for _, _, e in lay.group_spans) <= lay.guard
+        assert lay.numel <= lay.guard
