@@ -270,6 +270,7 @@ struct LatentDev {
   const float* reg_w_ptr;              // optional device scalar: upstream gradient wrt the KLD sum
   float* losses;
   float* grd_out;                      // [B, rec_size] gradient record written by the backward
+  float seed_w; const float* seed_w_ptr;   // weight of grd_seed (device scalar when set: the caller's upstream gradient wrt the regulariser)
   const float* grd_seed;               // optional [B, rec_size]: gradients injected into the record before the backward
                                        // walks the stages (the MMD regulariser's d reg / d z of the non-KL MFM)
   unsigned long long* dbg;             // optional: block 0 / thread 0 writes s_memtime at phase marks

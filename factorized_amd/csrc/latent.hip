@@ -361,7 +361,8 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_kernel(const LatentDev
     f32x4* r4 = reinterpret_cast<f32x4*>(rec);
     f32x4* g4 = reinterpret_cast<f32x4*>(grd);
     const f32x4* sd4 = L.grd_seed ? reinterpret_cast<const f32x4*>(L.grd_seed + (int64_t)row0 * RS) : nullptr;
-    for (int idx = tid; idx < n4; idx += nt) { r4[idx] = s4[idx]; g4[idx] = sd4 ? sd4[idx] : f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const float sw = sd4 ? (L.seed_w_ptr ? *L.seed_w_ptr : L.seed_w) : 0.0f;
+    for (int idx = tid; idx < n4; idx += nt) { r4[idx] = s4[idx]; g4[idx] = sd4 ? sw * sd4[idx] : f32x4{0.f, 0.f, 0.f, 0.f}; }
   }
   lds_barrier();
 

@@ -315,12 +315,13 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
     const f32x4 rv = s4[min(tid, n4 - 1)];
     const f32x4* sd4 = L.grd_seed ? reinterpret_cast<const f32x4*>(L.grd_seed + (int64_t)row * RS) : nullptr;
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 sv = sd4 ? sd4[min(tid, n4 - 1)] : zero;
+    const float sw = sd4 ? (L.seed_w_ptr ? *L.seed_w_ptr : L.seed_w) : 0.0f;
+    const f32x4 sv = sd4 ? sw * sd4[min(tid, n4 - 1)] : zero;
     load_items(L.items_bwd + (size_t)ch * (MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4), L.nstages, tab, tid);
     if (tid < nw) reinterpret_cast<int*>(ops)[tid] = opv;
     if (tid < L.nops) pfxN[tid] = L.ops[tid].pfx_n;
     if (tid < n4) { r4[tid] = rv; g4[tid] = sv; }
-    for (int idx = tid + nt; idx < n4; idx += nt) { r4[idx] = s4[idx]; g4[idx] = sd4 ? sd4[idx] : zero; }
+    for (int idx = tid + nt; idx < n4; idx += nt) { r4[idx] = s4[idx]; g4[idx] = sd4 ? sw * sd4[idx] : zero; }
   }
   lds_barrier();
   const int l = tid & 15;

@@ -1102,7 +1102,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
     RUN(K_LAT_FWD, latent_fwd_launch(L, params, s));
   }
   // MMD regulariser of the non-KL MFM on z_l, z_a, z_v, z_y (mfm_model.py:540-541): value into the reg slot, its
-  // gradient (times lda_mmd) into the latent backward's seed record
+  // gradient (unscaled: the latent backward weighs it with lda_mmd or the upstream gradient) into its seed record
   if (V == 2) {
     const int rs = P->lat.rec_size;
     const int zn[4] = {c.zl, c.za, c.zv, c.zy};
@@ -1113,7 +1113,7 @@ static int forward(MfmPlan* P, const float* params, const float* x, const void* 
       it[e].z = W + P->lat_rec + P->z_seg[e]; it[e].g = P->gauss + goff; it[e].dz = W + P->lat_seed + P->z_seg[e]; it[e].dim = zn[e];
       goff += zn[e];
     }
-    RUN(K_MMD, mmd_group_launch(it, 4, rs, gl, rs, B, losses + 4, c.lda_reg, s, P->mmd_scr >= 0 ? W + P->mmd_scr : nullptr));     // the four terms in one launch (large B: three)
+    RUN(K_MMD, mmd_group_launch(it, 4, rs, gl, rs, B, losses + 4, 1.0f, s, P->mmd_scr >= 0 ? W + P->mmd_scr : nullptr));     // the four terms in one launch (large B: three)
   }
   // F3: decoder recurrences
   {
@@ -1553,8 +1553,6 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
   const int V = c.variant;
   const int T = P->T, B = P->B;
   const int64_t TB = (int64_t)T * B;
-  MFM_REQUIRE(!(ext && V == 2), "plan (MFM / MMD variant): backward for external upstream gradients is not available "
-                                "(the regulariser's gradient is formed inside the plan)");
   if (P->grads_prezeroed != grads) MFM_HIP_CHECK(hipMemsetAsync(grads, 0, (size_t)P->n_params * sizeof(float), s));
   P->grads_prezeroed = nullptr;
   // the guard word of this gradient buffer (plan option "grad_guard_offset"): NaN while the plan's status word is set
@@ -1660,7 +1658,10 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     L.rec = W + P->lat_rec;
     L.y = y;
     L.grd_out = W + P->lat_grd;
-    if (V == 2) L.grd_seed = W + P->lat_seed;        // d (lda_mmd * MMD) / d z, written by the forward
+    if (V == 2) {        // d MMD / d z, written by the forward; its weight: lda_mmd, or the caller's upstream gradient
+      L.grd_seed = W + P->lat_seed;
+      L.seed_w = c.lda_reg; L.seed_w_ptr = ext ? ext->d_reg : nullptr;
+    }
     if (ext) { L.d_yhat_ext = ext->d_yhat; L.reg_w_ptr = ext->d_reg; }
     L.reg_w = c.lda_reg * c.reg_scale;
     L.disc_w = disc_on ? 1.0f : 0.0f;

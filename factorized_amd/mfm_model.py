@@ -1105,9 +1105,12 @@ class _FactorizedMFN(_FusedEngineMixin, nn.Module):
 
     `MFM_KL.forward` is ONE call of the fused plan (variant "kl", like MFM_KL_EF) since round 3 -- its backward takes
     arbitrary upstream gradients (mfm_plan_backward_ext), so the reference's unchanged loop runs on it: `fused_forward =
-    False`, an input that requires grad, or a stream under graph capture select the composed autograd path below.  `MFM`
-    stays on the composed path: the plan forms the MMD regulariser's gradient itself (scaled by config["lda_mmd"]) and
-    cannot honour an arbitrary upstream weight on it; `model.engine.train_step` is its fused form."""
+    False` or an input that requires grad select the composed autograd path below.  Round 4: `MFM.forward` is the fused plan
+    too (variant "mmd"): the forward leaves d MMD / d z unscaled in the plan's seed record and the backward weighs it with
+    whatever upstream gradient the caller's loss puts on the regulariser (`lda_mmd * mmd_loss` in the reference's loops), so the
+    reference's unchanged loop runs on one plan call per direction for all three classes.  The N(0,1) samples loss_MMD draws
+    per forward (reference mfm_model.py:26) come from torch's device generator ([B, zl+za+zv+zy] in one draw), or from
+    `model.mmd_gauss` (four tensors, parity tests)."""
     fused_forward = True
 
     def __init__(self, use_kl, config, NN1Config, NN2Config, gamma1Config, gamma2Config, outConfig):
@@ -1158,10 +1161,13 @@ class _FactorizedMFN(_FusedEngineMixin, nn.Module):
     def forward(self, x):
         _require_cuda(x, "%s.forward" % type(self).__name__)
         # (capturable since ABI 3: the plan's dropout streams and hand-over epochs add device words a captured step advances)
-        if self._use_kl and self.fused_forward and self._fast_ok() and not x.requires_grad:
+        if self.fused_forward and self._fast_ok() and not x.requires_grad:
             if not (x.dtype == torch.float32 and x.is_contiguous()):
                 x = x.contiguous().float()
-            _ = self.engine
+            eng = self.engine
+            if not self._use_kl:
+                g = self.mmd_gauss
+                eng.gauss = None if g is None else torch.cat([t.to(x.device).float() for t in g], dim=1).contiguous()
             if self._flat_leaf is None or self._flat_leaf.device != x.device:
                 self._flat_leaf = torch.zeros((), device=x.device, requires_grad=True)
             x_l_hat, x_a_hat, x_v_hat, y_hat, kld = _KLEFFastFn.apply(x, self, self._flat_leaf)

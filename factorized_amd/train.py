@@ -160,7 +160,7 @@ class GraphedModuleStep:
         dev = next(model.parameters()).device
         self.model, self.cfg = model, cfg
         fused = hasattr(model, "_fast_ok") and model._fast_ok() and (
-            type(model).__name__ == "MFM_KL_EF" or (getattr(model, "fused_forward", False) and getattr(model, "_use_kl", False)))
+            type(model).__name__ == "MFM_KL_EF" or getattr(model, "fused_forward", False))
         self.fused = fused
         d = cfg["input_dims"]
         self.x = torch.zeros(T, B, sum(d), device=dev)

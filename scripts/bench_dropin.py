@@ -58,10 +58,24 @@ for _ in range(300):
 torch.cuda.synchronize()
 print("%-70s %.3f ms/step" % ("model.engine.train_step(X, y)  (one C call)", 1e3 * (time.perf_counter() - t0) / 300))
 
+# eager, the other two classes of train_mfm (fused plan forward / backward since round 3 / 4)
+from factorized_amd import mfm_model as M2
+for cls_name in ("MFM_KL", "MFM"):
+    model = getattr(M2, cls_name)(*cfgs)
+    optimizer = optim.Adam(model.parameters())
+    model = model.to("cuda")
+    model.train()
+    loop(model, optimizer, 30, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop(model, optimizer, 300, True)
+    torch.cuda.synchronize()
+    print("%-70s %.3f ms/step" % ("factorized_amd.optim.Adam, flat gradients, %s" % cls_name, 1e3 * (time.perf_counter() - t0) / 300))
+
 # the same loop captured once into a hipGraph (train.GraphedModuleStep: fused plan with device-side epochs / dropout streams,
 # optim.Adam(capturable=True)) and replayed; per-step input copy into the static batch included
 from factorized_amd import train
-for cls_name in ("MFM_KL_EF", "MFM_KL"):
+for cls_name in ("MFM_KL_EF", "MFM_KL", "MFM"):
     from factorized_amd import mfm_model as M
     model = getattr(M, cls_name)(*cfgs).to("cuda")
     model.train()

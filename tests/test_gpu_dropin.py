@@ -111,6 +111,45 @@ def test_unchanged_reference_loop_mfm_kl_on_the_fused_plan():
     assert np.array_equal(model.mfn_encoder.out_fc1.weight.detach().cpu().numpy(), w0["mfn_encoder.out_fc1.weight"])
 
 
+def test_unchanged_reference_loop_mfm_mmd_on_the_fused_plan():
+    """train_mfm instantiates MFM otherwise (reference mfm_mosi.py:400-401; the class BASELINE.json's north_star names): since
+    round 4 its forward is one call of the fused plan too (variant "mmd") -- the forward leaves d MMD / d z unscaled, the backward
+    weighs it with the upstream gradient the loop's `lda_mmd * mmd_loss` puts on the regulariser.  Reference trajectory with the
+    reference's own N(0,1) samples injected (golden mmd_b32_t20)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import factorized_amd.optim as optim
+    cs = cases.load_case("mmd_b32_t20")
+    cfg, gold = cs["cfg"], cs["gold"]
+    model = _model(cs["cfgs"], True, "MFM")
+    optimizer = optim.Adam(model.parameters())
+    model = model.to("cuda")
+    g = torch.from_numpy(np.ascontiguousarray(gold["mmd_gauss"]))
+    sizes = [cfg["zl_size"], cfg["za_size"], cfg["zv_size"], cfg["zy_size"]]
+    model.mmd_gauss = [t.cuda() for t in torch.split(g, sizes, dim=1)]
+    X, y = torch.from_numpy(cs["x"]).cuda(), torch.from_numpy(cs["y"]).cuda()
+    trace = _reference_loop(model, optimizer, X, y, cfg, cs["steps"])
+    ref = gold["trace"]
+    terr = float(np.max(np.abs(trace - ref) / np.maximum(np.abs(ref), 1e-2)))
+    cases.report("dropin_trace_rel_mfm_mmd", terr)
+    assert terr < 0.5 * TOL, (trace[-1], ref[-1])
+    assert model._grad_views_attached() and optimizer._fallback is None
+    pl = np.stack([cases.summarize(p.detach().cpu().numpy()) for p in model.parameters()])
+    scale = np.maximum(np.abs(gold["param_after_last"][:, :1]), 1e-3)
+    perr = float(np.max(np.abs(pl - gold["param_after_last"]) / scale))
+    assert perr < 0.5 * TOL, perr
+    # a different weight on the regulariser than the plan's own lda_mmd: gradients follow the loop's loss, not the config
+    model.zero_grad()
+    (xl, xa, xv, yh), reg, _ = model.forward(X)
+    (3.0 * reg).backward()
+    g3 = model._grad_flat.clone()
+    model.zero_grad()
+    (xl, xa, xv, yh), reg, _ = model.forward(X)
+    reg.backward()
+    g1 = model._grad_flat.clone()
+    assert torch.allclose(g3, 3.0 * g1, rtol=1e-5, atol=1e-9) and float(g1.abs().max()) > 0
+
+
 @pytest.mark.parametrize("mode", ["frozen", "legacy"])
 def test_unchanged_staged_loop_with_dropin_adam(mode):
     """train_beta_vae's two stage losses through loss.backward(): tensors a stage loss does not reach get no gradient; the
