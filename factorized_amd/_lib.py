@@ -173,6 +173,9 @@ def lib():
                 "factorized_amd: %s is missing. Build the gfx950 HIP library first:\n"
                 "    python -c 'import __graft_entry__ as g; g.build()'   (or factorized_amd/csrc/build.sh)\n"
                 "There is no CPU fallback for this package." % LIB_PATH)
+        # torch first: its ROCm runtime (libamdhip64) must be the one this process initialises -- a process that loads this
+        # library before torch ends up with two HIP runtimes and "no ROCm-capable device" in the second one
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)   # AttributeError if the ABI and the binding drift apart
