@@ -58,24 +58,21 @@ __device__ __forceinline__ void store4_bounded(float* p, int64_t idx, int64_t n,
     if (idx + c < n) p[idx + c] = v[c];
 }
 
-// Staging rows are written and read with system-scope accesses (sc0 sc1: past this GPU's L2 in both
-// directions) on top of the uncached allocation, as two 8-byte halves -- the widest scoped access there is.
-typedef unsigned long long u64;
-__device__ __forceinline__ void store4_sys(float* p, f32x4 v) {
-  u64 lo, hi;
-  const float a[2] = {v[0], v[1]}, b[2] = {v[2], v[3]};
-  __builtin_memcpy(&lo, a, 8);
-  __builtin_memcpy(&hi, b, 8);
-  __hip_atomic_store(reinterpret_cast<u64*>(p), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(reinterpret_cast<u64*>(p) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// Staging rows are written and read with system-scope accesses (sc0 sc1: past this GPU's L2 in both directions) on top of the
+// uncached allocation.  Round 4: as ONE 16-byte instruction each -- raw buffer loads / stores carry the scope bits in their
+// cache-policy operand (bit 0 = sc0, bit 4 = sc1), which HIP's scoped atomics (8 bytes at most: two instructions per float4)
+// cannot express for 16 bytes.  No atomicity is needed: the flags order producer and consumer.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int P2P_SYS = 1 | 16;            // sc0 | sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t p2p_rsrc(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
 }
-__device__ __forceinline__ f32x4 load4_sys(const float* p) {
-  const u64 lo = __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  const u64 hi = __hip_atomic_load(reinterpret_cast<const u64*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  float a[2], b[2];
-  __builtin_memcpy(a, &lo, 8);
-  __builtin_memcpy(b, &hi, 8);
-  return f32x4{a[0], a[1], b[0], b[1]};
+// `base` must be wave-uniform (a staging block: it becomes the descriptor), `elem` is this lane's element offset inside it
+__device__ __forceinline__ void store4_sys(float* base, int64_t elem, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), p2p_rsrc(base), (int)(elem * 4), 0, P2P_SYS);
+}
+__device__ __forceinline__ f32x4 load4_sys(const float* base, int64_t elem) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(p2p_rsrc(base), (int)(elem * 4), 0, P2P_SYS));
 }
 
 // A flag word is 2 * epoch + bad: the low bit of a FIRST-push flag says that the sending rank's gradients carry a raised guard
@@ -170,30 +167,48 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev
 #pragma unroll
     for (int i = 0; i < P2P_MAXR; ++i) {
       const int s = (me + 1 + min(i, W - 1)) % W;
-      if (i < W) store4_sys(d.stage[s] + (int64_t)me * SL + cb + k, v[i]);
+      if (i < W) store4_sys(d.stage[s], (int64_t)me * SL + cb + k, v[i]);
     }
   }
   publish(d.f1, me * P2P_WGS + w, W, epoch, bad_local);
   // ---- reduce my slice's chunk in rank order, push 2: the result -> every rank's result row `me`
   const bool skip = wait_flags(d.f1[me] + w, P2P_WGS, W, epoch, timeout, d.err);
-  for (int64_t k = (int64_t)tid * 4; k < CL && cb + k < SL; k += P2P_THREADS * 4) {
-    const float* src = d.stage[me] + cb + k;
-    f32x4 v[P2P_MAXR];
+  // The result goes to the peers FIRST and the flags right behind it; this rank's own copy and its Adam update -- plain stores,
+  // i.e. dirty L2 lines that the release inside publish() would have to write back before the flags could leave -- come after
+  // (round 4; while the chunk fits two passes of the workgroup: 4096 floats, every gradient buffer of this code base at W >= 2)
+  const bool early = CL <= 2 * P2P_THREADS * 4;
+  f32x4 keep[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  {
+    int pass = 0;
+    for (int64_t k = (int64_t)tid * 4; k < CL && cb + k < SL; k += P2P_THREADS * 4, ++pass) {
+      f32x4 v[P2P_MAXR];
 #pragma unroll
-    for (int r = 0; r < P2P_MAXR; ++r) v[r] = load4_sys(src + (int64_t)min(r, W - 1) * SL);
-    f32x4 acc = v[0];
+      for (int r = 0; r < P2P_MAXR; ++r) v[r] = load4_sys(d.stage[me], cb + k + (int64_t)min(r, W - 1) * SL);
+      f32x4 acc = v[0];
 #pragma unroll
-    for (int r = 1; r < P2P_MAXR; ++r)
-      if (r < W) acc += v[r];
+      for (int r = 1; r < P2P_MAXR; ++r)
+        if (r < W) acc += v[r];
 #pragma unroll
-    for (int i = 1; i < P2P_MAXR; ++i) {
-      const int p = (me + min(i, W - 1)) % W;
-      if (i < W) store4_sys(d.res[p] + (int64_t)me * SL + cb + k, acc);
+      for (int i = 1; i < P2P_MAXR; ++i) {
+        const int p = (me + min(i, W - 1)) % W;
+        if (i < W) store4_sys(d.res[p], (int64_t)me * SL + cb + k, acc);
+      }
+      if (early) { if (pass == 0) keep[0] = acc; else keep[1] = acc; }
+      else {
+        store4_bounded(buf, (int64_t)me * SL + cb + k, n, acc);
+        if (ADAM && !skip) adam4(ad, (int64_t)me * SL + cb + k, n, acc);
+      }
     }
-    store4_bounded(buf, (int64_t)me * SL + cb + k, n, acc);
-    if (ADAM && !skip) adam4(ad, (int64_t)me * SL + cb + k, n, acc);
   }
   publish(d.f2, me * P2P_WGS + w, W, epoch);
+  if (early) {
+    int pass = 0;
+    for (int64_t k = (int64_t)tid * 4; k < CL && cb + k < SL; k += P2P_THREADS * 4, ++pass) {
+      const f32x4 acc = pass == 0 ? keep[0] : keep[1];
+      store4_bounded(buf, (int64_t)me * SL + cb + k, n, acc);
+      if (ADAM && !skip) adam4(ad, (int64_t)me * SL + cb + k, n, acc);
+    }
+  }
   // ---- gather: foreign result rows -> my gradient buffer
   (void)wait_flags(d.f2[me] + w, P2P_WGS, W, epoch, timeout, d.err);
   for (int64_t k = (int64_t)tid * 4; k < CL && cb + k < SL; k += P2P_THREADS * 4) {
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev
 #pragma unroll
     for (int i = 1; i < P2P_MAXR; ++i) {
       const int s = (me + min(i, W - 1)) % W;
-      v[i] = load4_sys(d.res[me] + (int64_t)s * SL + cb + k);
+      v[i] = load4_sys(d.res[me], (int64_t)s * SL + cb + k);
     }
 #pragma unroll
     for (int i = 1; i < P2P_MAXR; ++i) {
