@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libmfm_hip.so")
 MFM_KLEF_NPARAM = 78
 MFM_LOSS_SLOTS = 8
 MFM_MAX_SEQ = 6
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class MfmError(RuntimeError):
@@ -56,6 +56,11 @@ class AdamSpan(C.Structure):
 
 
 MFM_ADAM_MAX_SPANS = 8
+
+
+class LossWeights(C.Structure):
+    _fields_ = [("disc", C.c_float), ("gen_l", C.c_float), ("gen_a", C.c_float), ("gen_v", C.c_float), ("reg", C.c_float),
+                ("write_disc_loss", C.c_int32)]
 
 
 class PlanConfig(C.Structure):
@@ -134,6 +139,11 @@ _SIGS = {
     "mfm_plan_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p]),
     "mfm_plan_backward_ext": (C.c_int, [C.c_void_p] * 11),
+    "mfm_plan_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mfm_plan_backward_weighted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(LossWeights),
+                                             C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mfm_plan_out_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "mfm_plan_host_status": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32))]),
     "mfm_plan_grad_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "mfm_plan_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

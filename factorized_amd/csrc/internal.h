@@ -293,6 +293,8 @@ struct LatentDev {
   const unsigned long long* tick;      // optional device word added to `seed` when the kernel runs (the plan's replay counter:
                                        // a captured hipGraph draws new masks on every replay)
   float reg_w, disc_w, gen_w;
+  float* disc_loss_out;   // backward, optional: the discriminative loss value (L1 / CE mean) is ADDED here (the loss-weighted
+                          // backward of the module path: the forward ran without labels, its slot 0 is still zero)
   int grd_agent;          // grd_out leaves with agent-scope stores (read inside the same launch, dw_role_dev.h)
 };
 int latent_fwd_launch(const LatentDev& L, const float* params, hipStream_t stream);

@@ -372,14 +372,17 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_kernel(const LatentDev
       const int r = idx / L.od, o = idx - r * L.od;
       grd[r * RS + L.yhat_off + o] = L.d_yhat_ext[(int64_t)(row0 + r) * L.od + o];
     }
-  } else if (L.y && L.disc_w != 0.0f) {
+  } else if (L.y && (L.disc_w != 0.0f || L.disc_loss_out)) {
+    float dl = 0.0f;                // this thread's share of the discriminative loss (disc_loss_out)
     if (L.loss_kind == 0) {
       const float* y = reinterpret_cast<const float*>(L.y);
-      const float sc = L.disc_w / ((float)L.B * (float)L.od);
+      const float inv = 1.0f / ((float)L.B * (float)L.od);
+      const float sc = L.disc_w * inv;
       for (int idx = tid; idx < nrows * L.od; idx += nt) {
         const int r = idx / L.od, o = idx - r * L.od;
         const float df = rec[r * RS + L.yhat_off + o] - y[(int64_t)(row0 + r) * L.od + o];
         grd[r * RS + L.yhat_off + o] = (df > 0.0f) ? sc : ((df < 0.0f) ? -sc : 0.0f);
+        dl += fabsf(df) * inv;
       }
     } else {
       const int64_t* y = reinterpret_cast<const int64_t*>(L.y);
@@ -393,7 +396,12 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_kernel(const LatentDev
         const int lab = (int)y[row0 + r];
         for (int o = 0; o < L.od; ++o)
           grd[r * RS + L.yhat_off + o] = sc * (expf(z[o] - mx) / se - (o == lab ? 1.0f : 0.0f));
+        dl += ((logf(se) + mx) - z[lab]) / (float)L.B;
       }
+    }
+    if (L.disc_loss_out) {          // (uniform branch: every wave of the workgroup takes it)
+      dl = wave_sum_dpp(dl);
+      if ((tid & 63) == 0 && dl != 0.0f) atomicAdd(L.disc_loss_out, dl);
     }
   }
   if (L.gen_w != 0.0f) {

@@ -343,15 +343,18 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
     fetch(L.nstages - 1, sa);
   }
   // ---- seeds
+  float dl = 0.0f;                  // this row's share of the discriminative loss (disc_loss_out)
   if (L.d_yhat_ext) {
     for (int o = tid; o < L.od; o += nt) grd[L.yhat_off + o] = L.d_yhat_ext[(int64_t)row * L.od + o];
-  } else if (L.y && L.disc_w != 0.0f) {
+  } else if (L.y && (L.disc_w != 0.0f || L.disc_loss_out)) {
     if (L.loss_kind == 0) {
       const float* y = reinterpret_cast<const float*>(L.y);
-      const float sc = L.disc_w / ((float)L.B * (float)L.od);
+      const float inv = 1.0f / ((float)L.B * (float)L.od);
+      const float sc = L.disc_w * inv;
       for (int o = tid; o < L.od; o += nt) {
         const float df = rec[L.yhat_off + o] - y[(int64_t)row * L.od + o];
         grd[L.yhat_off + o] = (df > 0.0f) ? sc : ((df < 0.0f) ? -sc : 0.0f);
+        dl += fabsf(df) * inv;
       }
     } else if (tid == 0) {
       const int64_t* y = reinterpret_cast<const int64_t*>(L.y);
@@ -363,6 +366,12 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
       for (int o = 0; o < L.od; ++o) se += expf(z[o] - mx);
       const int lab = (int)y[row];
       for (int o = 0; o < L.od; ++o) grd[L.yhat_off + o] = sc * (expf(z[o] - mx) / se - (o == lab ? 1.0f : 0.0f));
+      dl = ((logf(se) + mx) - z[lab]) / (float)L.B;
+    }
+    // (od <= 128: only the first two waves hold a share; the chain workgroups of a row all seed y_hat, one of them reports)
+    if (L.disc_loss_out && (all || ch == 3) && tid < 128) {
+      dl = wave_sum_dpp(dl);
+      if ((tid & 63) == 0 && dl != 0.0f) atomicAdd(L.disc_loss_out, dl);
     }
   }
   if (L.gen_w != 0.0f) {

@@ -158,7 +158,7 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 template <int KQ, int R, bool FLG = false, bool BF = false>
 __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds,
                                                const unsigned* flg = nullptr, const unsigned epoch = 0, const int ncb = 0,
-                                               const HoCtl ctl = HoCtl{nullptr, nullptr, 5000000ll, 1u}) {
+                                               const HoCtl ctl = HoCtl{nullptr, nullptr, nullptr, 5000000ll, 1u}) {
   constexpr int HK = 4 * KQ;                    // padded hidden extent of the matvec
   constexpr int HKB = (HK + 15) / 16 * 16;      // == Hp
   constexpr int NTH = 8 * HKB;                  // threads this LSTM uses (blockDim may be larger)

@@ -160,13 +160,14 @@ struct MfmPlan {
   int opt_fault = 0;                // one-shot fault injection (tests)
   int opt_bf16_dot = 0;             // bf16 plans below the bf16 MFMA kernels' batch size: one-row recurrences on bf16 dot products
   bool ever_handover = false;       // a role-workgroup launch has run on this plan (its status word may be set)
+  unsigned* host_status = nullptr;  // 16 words of host-coherent pinned memory (mfm_plan_host_status): [0] / [1] raised by a consumer that gave up
   // device-side state, right behind the plan's loss slots (mfm_plan_state_layout): float offsets relative to `losses`
   static constexpr int ST_STATUS = MFM_LOSS_SLOTS, ST_TICK = MFM_LOSS_SLOTS + 2, ST_DW_TICK = MFM_LOSS_SLOTS + 4;
   unsigned* status_ptr(float* W) const { return reinterpret_cast<unsigned*>(W + losses + ST_STATUS); }
   unsigned* tick_ptr(float* W) const { return reinterpret_cast<unsigned*>(W + losses + ST_TICK); }      // low word of the u64 replay counter
   unsigned* dw_tick_ptr(float* W) const { return reinterpret_cast<unsigned*>(W + losses + ST_DW_TICK); }
   mfm::HoCtl ho_ctl(float* W, float* poison, unsigned bit) const {
-    return mfm::HoCtl{status_ptr(W), poison, opt_timeout_us * 100ll /* 100 MHz wall clock */, bit};
+    return mfm::HoCtl{status_ptr(W), host_status, poison, opt_timeout_us * 100ll /* 100 MHz wall clock */, bit};
   }
 };
 
@@ -1247,6 +1248,10 @@ static void dA_gemms(const MfmPlan* P, const SeqBuf& sb, int pb, float* W, float
   }
 }
 
+// weights of the loss terms for a backward of  disc * L_disc + gen * sum_m lda_m MSE_m + reg * REG  (the module path's lazy
+// losses, mfm_plan_backward_weighted): gen is a switch (the forward baked lda_m into d x_hat), disc and reg are factors
+struct LossW { float disc; int gen_on; float reg; int write_disc; };
+
 struct ExtGrads {           // upstream gradients supplied by the caller (autograd module path)
   const float* d_xhat[3];
   const float* d_yhat;
@@ -1547,7 +1552,7 @@ static int dw_role_build(MfmPlan* P, const std::vector<MfmGemmDesc>& all, float*
 }
 
 static int backward(MfmPlan* P, const float* params, const float* x, const void* y, int stage, float* W,
-                    float* grads, hipStream_t s, const ExtGrads* ext = nullptr) {
+                    float* grads, hipStream_t s, const ExtGrads* ext = nullptr, const LossW* lw = nullptr) {
   OptScope _opts(P->opts);
   const MfmPlanConfig& c = P->cfg;
   const int V = c.variant;
@@ -1564,7 +1569,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
         hipLaunchKernelGGL(guard_propagate_kernel, dim3(1), dim3(64), 0, s, P->status_ptr(W), guard);
     }
   } guard_at_exit{P, W, guard, s, true};
-  const bool gen_on = (stage != 2), disc_on = (stage != 1);
+  const bool gen_on = lw ? lw->gen_on != 0 : (stage != 2), disc_on = lw ? lw->disc != 0.0f : (stage != 1);
   const bool seq_bf16 = P->seq_bf16;
   const bool st16 = P->st16;
   MFM_REQUIRE(!(ext && st16), "plan: backward for external upstream gradients is not available on a bf16-resident plan "
@@ -1660,11 +1665,12 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
     L.grd_out = W + P->lat_grd;
     if (V == 2) {        // d MMD / d z, written by the forward; its weight: lda_mmd, or the caller's upstream gradient
       L.grd_seed = W + P->lat_seed;
-      L.seed_w = c.lda_reg; L.seed_w_ptr = ext ? ext->d_reg : nullptr;
+      L.seed_w = lw ? lw->reg : c.lda_reg; L.seed_w_ptr = ext ? ext->d_reg : nullptr;
     }
     if (ext) { L.d_yhat_ext = ext->d_yhat; L.reg_w_ptr = ext->d_reg; }
-    L.reg_w = c.lda_reg * c.reg_scale;
-    L.disc_w = disc_on ? 1.0f : 0.0f;
+    L.reg_w = (lw ? lw->reg : c.lda_reg) * c.reg_scale;
+    L.disc_w = lw ? lw->disc : (disc_on ? 1.0f : 0.0f);
+    L.disc_loss_out = (lw && lw->write_disc && y) ? W + P->losses : nullptr;
     L.gen_w = gen_on ? 1.0f : 0.0f;
     // weight gradients of the 22 latent Linears: dW[n][k] = sum_r G[r][out+n] X[r][in+k]
     const int rs = P->lat.rec_size;
@@ -1702,7 +1708,7 @@ static int backward(MfmPlan* P, const float* params, const float* x, const void*
         if (gen_on)
           for (int m = 0; m < 3; ++m) dA_gemms(P, P->dec[m], P->dec_p[m], W, grads, all, W + P->dec_init[m], P->dec_h[m], P->dec_h[m], true, false);
         DwRole DR;
-        const int key = (gen_on ? 1 : 0) | (disc_on ? 2 : 0) | (ext ? 4 : 0);
+        const int key = (gen_on ? 1 : 0) | ((disc_on || L.disc_loss_out) ? 2 : 0) | (ext ? 4 : 0);
         const int brc = dw_role_build(P, all, W, key, s, &DR);
         if (brc == MFM_OK) {
           LatentDev L2 = L;
@@ -2010,6 +2016,7 @@ extern "C" void mfm_plan_destroy(MfmPlan* P) {
   if (!P) return;
   for (auto& t : P->pool) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   opt_table_free(P->opts);
+  if (P->host_status) (void)hipHostFree(P->host_status);
   delete P;
 }
 
@@ -2021,6 +2028,12 @@ extern "C" int mfm_plan_init_workspace(MfmPlan* P, void* workspace, void* stream
   if (!P || !workspace) { set_error("mfm_plan_init_workspace: null argument"); return MFM_ERR_ARG; }
   float* W = (float*)workspace;
   hipStream_t s = (hipStream_t)stream;
+  if (!P->host_status) {           // (not in mfm_plan_create: that one stays free of the HIP runtime)
+    void* hp = nullptr;
+    MFM_HIP_CHECK(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(hp, 0, 64);
+    P->host_status = reinterpret_cast<unsigned*>(hp);
+  }
   MFM_HIP_CHECK(hipMemsetAsync(W, 0, (size_t)P->ws_floats * sizeof(float), s));
   MFM_HIP_CHECK(hipMemcpyAsync(W + P->lat_ops_off, P->lat_ops, sizeof(P->lat_ops), hipMemcpyHostToDevice, s));
   MFM_HIP_CHECK(hipMemcpyAsync(W + P->lat_items_off, P->lat_items.data(), P->lat_items.size() * sizeof(int),
@@ -2072,8 +2085,15 @@ extern "C" int mfm_plan_state_layout(const MfmPlan* P, int64_t* out) {
   out[3] = (P->losses + MfmPlan::ST_DW_TICK) * f;
   return MFM_OK;
 }
+extern "C" int mfm_plan_host_status(MfmPlan* P, uint32_t** out) {
+  if (!P || !out) { set_error("mfm_plan_host_status: null argument"); return MFM_ERR_ARG; }
+  *out = P->host_status;
+  return MFM_OK;
+}
+
 extern "C" int mfm_plan_clear_status(MfmPlan* P, void* workspace, void* stream) {
   if (!P || !workspace) { set_error("mfm_plan_clear_status: null argument"); return MFM_ERR_ARG; }
+  if (P->host_status) { P->host_status[0] = 0; P->host_status[1] = 0; }
   MFM_HIP_CHECK(hipMemsetAsync(P->status_ptr((float*)workspace), 0, sizeof(unsigned), (hipStream_t)stream));
   return MFM_OK;
 }
@@ -2092,6 +2112,40 @@ extern "C" int mfm_plan_backward(MfmPlan* P, const float* params, const float* x
   MFM_REQUIRE(stage >= 0 && stage <= 2, "mfm_plan_backward: stage %d", stage);
   MFM_REQUIRE(y || stage == 1, "mfm_plan_backward: labels required unless stage==1");
   return backward(P, params, x, y, stage, (float*)workspace, grads, (hipStream_t)stream);
+}
+
+extern "C" int mfm_plan_forward_train(MfmPlan* P, const float* params, const float* x, uint64_t seed, void* workspace,
+                                      float* grads_to_zero, void* stream) {
+  if (!P || !params || !x || !workspace) { set_error("mfm_plan_forward_train: null argument"); return MFM_ERR_ARG; }
+  float* xo[3] = {nullptr, nullptr, nullptr};
+  return forward(P, params, x, nullptr, 1, seed, (float*)workspace, xo, nullptr, nullptr, (hipStream_t)stream, grads_to_zero);
+}
+
+extern "C" int mfm_plan_out_layout(const MfmPlan* P, int64_t* out) {
+  if (!P || !out) { set_error("mfm_plan_out_layout: null argument"); return MFM_ERR_ARG; }
+  for (int i = 0; i < 8; ++i) out[i] = -1;
+  if (!P->st16)
+    for (int m = 0; m < 3; ++m) out[m] = P->xhat[m] * (int64_t)sizeof(float);
+  out[3] = P->yhat * (int64_t)sizeof(float);
+  return MFM_OK;
+}
+
+extern "C" int mfm_plan_backward_weighted(MfmPlan* P, const float* params, const float* x, const void* y,
+                                          const MfmLossWeights* w, void* workspace, float* grads, void* stream) {
+  if (!P || !params || !x || !workspace || !grads || !w) { set_error("mfm_plan_backward_weighted: null argument"); return MFM_ERR_ARG; }
+  const MfmPlanConfig& c = P->cfg;
+  const bool gen_on = w->gen_l != 0.0f || w->gen_a != 0.0f || w->gen_v != 0.0f;
+  // the forward's fc1 epilogue left d x_hat_m = 2 lda_m (x_hat_m - x_m) / count_m behind: the reconstruction weights must be
+  // the plan's own, or all zero
+  if (gen_on && (w->gen_l != c.lda_xl || w->gen_a != c.lda_xa || w->gen_v != c.lda_xv)) {
+    set_error("mfm_plan_backward_weighted: reconstruction weights (%g, %g, %g) differ from the plan's (%g, %g, %g)", w->gen_l,
+              w->gen_a, w->gen_v, c.lda_xl, c.lda_xa, c.lda_xv);
+    return MFM_ERR_UNSUPPORTED;
+  }
+  MFM_REQUIRE(y || (w->disc == 0.0f && !w->write_disc_loss), "mfm_plan_backward_weighted: labels required for the discriminative term");
+  MFM_REQUIRE(!P->st16, "mfm_plan_backward_weighted: not available on a bf16-resident plan");
+  LossW lw{w->disc, gen_on ? 1 : 0, w->reg, w->write_disc_loss};
+  return backward(P, params, x, y, 0, (float*)workspace, grads, (hipStream_t)stream, nullptr, &lw);
 }
 
 extern "C" int mfm_plan_backward_ext(MfmPlan* P, const float* params, const float* x, const float* d_xhat_l,

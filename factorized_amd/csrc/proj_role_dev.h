@@ -32,10 +32,13 @@ constexpr int PROJ_ROLE_WT = 7;
 // `timeout` ticks of the 100 MHz wall clock it gives up, ORs `bit` into the plan's sticky STATUS word (the host reads it at its
 // next sync, raises and switches the plan to separate launches; every backward of a plan whose status is non-zero poisons the
 // gradient guard, so the optimizer skips the step: include/mfm_hip.h, plan options) and stores a NaN into `poison`.
-struct HoCtl { unsigned* status; float* poison; long long timeout; unsigned bit; };
+// `host`: two words of host-coherent memory the plan owns (mfm_plan_host_status): the host sees a failure at its next glance at
+// plain memory, without a copy or a synchronisation (word 0: projections, word 1: weight gradients).
+struct HoCtl { unsigned* status; unsigned* host; float* poison; long long timeout; unsigned bit; };
 __device__ __forceinline__ void ho_give_up(const HoCtl& c) {
   if ((threadIdx.x & 63) == 0) {
     if (c.status) __hip_atomic_fetch_or(c.status, c.bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c.host) __hip_atomic_store(c.host + (c.bit >> 1), c.bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (c.poison) __hip_atomic_store(c.poison, __builtin_nanf(""), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }

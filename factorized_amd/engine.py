@@ -296,6 +296,29 @@ class _Plan:
         self.dw_tick = self.workspace[lay[3]: lay[3] + 4].view(torch.int32)
         self.fwd_serial = 0        # forwards run on this workspace so far (autograd path: whose activations it holds)
         self.consumed = False      # the last forward's activations were overwritten by a backward
+        # where the last forward left x_hat_l/a/v and y_hat inside the workspace (mfm_plan_out_layout): what the module path's
+        # lazy outputs are views of (factorized_amd/lazy.py); None on bf16-resident plans, which do not keep x_hat
+        ol = (C.c_int64 * 8)()
+        _lib.check(_lib.lib().mfm_plan_out_layout(handle, ol), "mfm_plan_out_layout")
+        self.out_views = None
+        if min(ol[0], ol[1], ol[2], ol[3]) >= 0:
+            dd = list(cfg["input_dims"]) + [cfg["output_dim"]]
+            shp = [(T, B, dd[0]), (T, B, dd[1]), (T, B, dd[2]), (B, dd[3])]
+            self.out_views = tuple(wf[ol[i] // 4: ol[i] // 4 + int(np.prod(shp[i]))].view(shp[i]) for i in range(4))
+        self.loss0d = self.state[7]          # a spare word: the storage behind the symbolic loss expressions (never read)
+        # host-coherent copy of "a hand-over gave up" (mfm_plan_host_status): polled for free by the optimizers
+        hp = C.POINTER(C.c_uint32)()
+        _lib.check(_lib.lib().mfm_plan_host_status(handle, C.byref(hp)), "mfm_plan_host_status")
+        self.host_words = (C.c_uint32 * 2).from_address(C.addressof(hp.contents)) if hp else None
+        self.handover_now = bool(engine.handover)
+
+    def ensure_handover(self, on):
+        """the module path switches the in-launch hand-overs per call: only a step whose optimizer honours the gradient guard
+        may use them (factorized_amd.optim.Adam does, torch.optim.Adam does not)"""
+        on = bool(on)
+        if self.handover_now != on:
+            self.set_option("handover", 1 if on else 0)
+            self.handover_now = on
 
     def set_option(self, key, value):
         _lib.check(_lib.lib().mfm_plan_set_option(self.handle, key.encode(), int(value)), "mfm_plan_set_option(%s)" % key)
@@ -358,6 +381,7 @@ class MFMEngine:
         self.handover = os.environ.get("MFM_SHARED_DEVICE", "0") in ("", "0")
         self.handover_timeout_us = None      # None = the library's default (50 ms)
         self.handover_failures = 0
+        self._status_message = ""
         # Staged training (train_beta_vae): Adam step counters per tensor group.  "frozen" = torch >= 2 semantics
         # (zero_grad sets .grad to None, Adam skips such parameters: a group without a gradient in the current
         # stage keeps its values and moments); "legacy" = torch 0.4 semantics (zero_grad leaves zero tensors
@@ -402,6 +426,19 @@ class MFMEngine:
         self.handover = bool(on)
         for p in self._plans.values():
             p.set_option("handover", 1 if on else 0)
+            p.handover_now = bool(on)
+
+    def poll_status(self):
+        """Did a hand-over of any plan give up?  A read of host memory (mfm_plan_host_status): no copy, no synchronisation --
+        cheap enough for every optimizer step.  Non-zero: call check_status()."""
+        for p in self._plans.values():
+            hw = p.host_words
+            if hw is not None and (hw[0] | hw[1]):
+                return True
+        return False
+
+    def status_message(self):
+        return self._status_message
 
     def check_status(self, state_host=None, raise_on_error=True):
         """Look at the status words of this engine's plans (synchronises unless `state_host` -- a host copy of one plan's
@@ -421,12 +458,13 @@ class MFMEngine:
         if bad:
             self.handover_failures += 1
             self.set_handover(False)
+            self._status_message = (
+                "an in-launch hand-over of the fused step gave up waiting (status 0x%x: %s): other work on this GPU kept the "
+                "producer workgroups off the device.  The affected steps were NOT applied to the parameters; the engine now "
+                "uses separate launches (set_handover(True) re-enables the role workgroups)."
+                % (bad, " + ".join(n for b, n in ((1, "projections"), (2, "weight gradients")) if bad & b)))
             if raise_on_error:
-                raise _lib.MfmError(
-                    "an in-launch hand-over of the fused step gave up waiting (status 0x%x: %s): other work on this GPU kept the "
-                    "producer workgroups off the device.  The affected steps were NOT applied to the parameters; the engine now "
-                    "uses separate launches (set_handover(True) re-enables the role workgroups)."
-                    % (bad, " + ".join(n for b, n in ((1, "projections"), (2, "weight gradients")) if bad & b)))
+                raise _lib.MfmError(self._status_message)
         return bad
 
     def _gauss_for(self, p, B):
@@ -451,11 +489,13 @@ class MFMEngine:
             assert y.dtype == want, "labels must be %s" % want
 
     # ------------------------------------------------------------------ the three entry points
-    def forward(self, x, y=None, train=False, want_xhat=True):
-        """x [T,B,D] -> dict(x_l_hat, x_a_hat, x_v_hat, y_hat, losses[8] (device tensor))."""
+    def forward(self, x, y=None, train=False, want_xhat=True, handover=None):
+        """x [T,B,D] -> dict(x_l_hat, x_a_hat, x_v_hat, y_hat, losses[8] (device tensor)).  `handover`: override of the engine's
+        hand-over switch for this call (the module path: only under a guard-aware optimizer)."""
         self._check_inputs(x, y)
         T, B, _ = x.shape
         p = self.plan(T, B)
+        p.ensure_handover(self.handover if handover is None else handover)
         d_l, d_a, d_v = self.cfg["input_dims"]
         out = {}
         xh = [None, None, None]
@@ -474,11 +514,30 @@ class MFMEngine:
         out["losses"] = p.losses
         return out
 
+    def forward_train(self, x, p, grads_to_zero=None):
+        """Training-mode forward of the module path's lazy losses (mfm_plan_forward_train): no labels, no output tensors --
+        x_hat / y_hat stay in the plan's workspace (`p.out_views`), the loss slots 1..4 are filled; `grads_to_zero`: a flat
+        gradient buffer cleared inside the first launch."""
+        p.fwd_serial += 1
+        p.consumed = False
+        self._gauss_for(p, x.shape[1])
+        _lib.check(_lib.lib().mfm_plan_forward_train(p.handle, _ptr(self.params), _ptr(x), C.c_uint64(self.seed), _ptr(p.workspace),
+                                                     _ptr(grads_to_zero), _stream()), "mfm_plan_forward_train")
+
+    def backward_weighted(self, x, y, w, p, out=None):
+        """Backward of  w.disc * L_disc(y_hat, y) + sum_m w.gen_m MSE_m + w.reg * reg  on the last forward of plan `p`
+        (mfm_plan_backward_weighted; w: _lib.LossWeights).  `out`: flat buffer to receive the gradients (default self.grads)."""
+        g = self.grads if out is None else out
+        _lib.check(_lib.lib().mfm_plan_backward_weighted(p.handle, _ptr(self.params), _ptr(x), _ptr(y), C.byref(w), _ptr(p.workspace),
+                                                         _ptr(g), _stream()), "mfm_plan_backward_weighted")
+        return g
+
     def backward(self, x, y, stage=0):
         """Backward of the last forward() with the same (T,B); fills self.grads."""
         self._check_inputs(x, y)
         T, B, _ = x.shape
         p = self.plan(T, B)
+        p.ensure_handover(self.handover)
         _lib.check(_lib.lib().mfm_plan_backward(p.handle, _ptr(self.params), _ptr(x), _ptr(y), int(stage),
                                                 _ptr(p.workspace), _ptr(self.grads), _stream()),
                    "mfm_plan_backward")
@@ -530,6 +589,7 @@ class MFMEngine:
             self._check_inputs(x, y)
         T, B, _ = x.shape
         p = self.plan(T, B)
+        p.ensure_handover(self.handover)
         self._gauss_for(p, B)
         gs = self.group_steps
         if stage != 0 or not (gs["shared"] == gs["gen"] == gs["disc"]):
@@ -566,6 +626,7 @@ class MFMEngine:
             self._check_inputs(x, y)
         T, B, _ = x.shape
         p = self.plan(T, B)
+        p.ensure_handover(self.handover)
         self._gauss_for(p, B)
         p.fwd_serial += 1
         p.consumed = True

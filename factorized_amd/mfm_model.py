@@ -382,6 +382,13 @@ class _FusedEngineMixin:
     torch.autograd.grad on parameters)."""
     _engine_variant = "kl_ef"
     fast_grads = True
+    # training-mode forwards return lazy outputs / symbolic loss expressions (factorized_amd/lazy.py): the reference's unchanged
+    # loop then runs on the launches of the fused step alone.  False: ordinary tensors (round-4 behaviour)
+    lazy_losses = True
+    # set by factorized_amd.optim.Adam when it owns this model's parameters: its update honours the gradient guard, so the
+    # in-launch hand-overs of the small-batch step may be used.  Any other optimizer (torch.optim.Adam, SGD, ...) would apply
+    # the gradients of a step whose hand-over gave up: the module path then runs on separate launches, where nothing can fail
+    _guarded = False
 
     def _init_engine_slots(self):
         self._param_names = [n for n, _ in self.named_parameters()]
@@ -417,6 +424,9 @@ class _FusedEngineMixin:
         if not hasattr(self, "_grad_present") or len(self._grad_present) != len(self._plist):
             self._grad_present = np.ones(len(self._plist), dtype=bool)
         self._register_params()
+
+    def _handover_ok(self):
+        return bool(self._guarded) and not os.environ.get("MFM_MODULE_NO_HANDOVER")
 
     def _fast_ok(self):
         """The flat-gradient path bypasses autograd for the parameters: every tensor gets a gradient view and the fused optimizer
@@ -487,10 +497,26 @@ class _FusedEngineMixin:
     def _zero_flat_grads(self, set_to_none=True):
         """optimizer.zero_grad() of factorized_amd.optim.Adam: one launch; set_to_none=True marks every tensor as
         'no gradient yet' (the optimizer skips what the next backward does not reach, like torch with .grad = None)"""
-        self._grad_flat.zero_()
+        if not (set_to_none and self.lazy_losses and self.training and self._fast_ok()):
+            # (set_to_none on a lazily-training model: no launch -- torch would leave `.grad = None` behind, here the views stay
+            # attached and hold the previous step's values until the next forward's first launch clears the buffer; every
+            # backward that follows OVERWRITES it, and `_grad_present` makes the optimizer skip what no backward reached)
+            self._grad_flat.zero_()
         self._grad_fresh = True
         if set_to_none:
             self._grad_present[:] = False
+
+    def _detach_grad_views(self):
+        """hand the gradients back to plain per-tensor autograd (a frozen parameter or a hook appeared after fast-path steps):
+        accumulated values survive as clones, 'nothing yet' becomes None; the flat buffer is dropped"""
+        if self._grad_flat is None or not self._grad_views_attached():
+            return
+        for i, p in enumerate(self._plist):
+            keep = (not self._grad_fresh) and bool(self._grad_present[i]) and p.requires_grad
+            p.grad = p.grad.detach().clone() if keep else None
+        self._grad_flat = None
+        self._grad_fresh = True
+        self._grad_present[:] = True
 
     def _group_masks(self):
         """which tensors each upstream gradient of the factorized model reaches exclusively: d y_hat -> the classifier;
@@ -518,7 +544,8 @@ class _KLEFFn(torch.autograd.Function):
             raise _lib.MfmError("MFM_KL_EF.forward: the input requires grad; the fused plan does not produce d loss / d x "
                                 "(the reference never asks for it) -- detach the batch")
         eng = module.engine
-        out = eng.forward(x, None, train=module.training, want_xhat=True)
+        # (per-tensor gradients: whatever optimizer applies them knows nothing of the gradient guard -> separate launches)
+        out = eng.forward(x, None, train=module.training, want_xhat=True, handover=False)
         kld = out["losses"][4].clone()
         ctx.module = module
         # the plan's workspace for (T,B) holds the activations of the LAST forward only: remember which one
@@ -552,12 +579,68 @@ class _KLEFFn(torch.autograd.Function):
         d_xl, d_xa, d_xv = z(d_xl, (T, B, d_l)), z(d_xa, (T, B, d_a)), z(d_xv, (T, B, d_v))
         d_y = z(d_y, (B, eng.cfg["output_dim"]))
         d_kld = z(d_kld, ()).reshape(1)
+        plan.ensure_handover(False)
         eng.backward_ext(x, d_xl, d_xa, d_xv, d_y, d_kld)
         # one copy of the flat gradient buffer, handed out as per-parameter views (the plan overwrites its own
         # buffer on the next call; 78 separate clones cost ~0.4 ms of host time per step)
         flat = eng.grads.clone()
         lay = eng.layout
         return (None, None) + tuple(flat[o:o + n].view(shp) for o, n, shp in lay.slots)
+
+
+def _check_plan_live(plan, eng, serial, T, B):
+    if eng.plan(T, B) is not plan or plan.fwd_serial != serial:
+        raise RuntimeError("MFM_KL_EF backward: another forward with the same (T=%d, B=%d) ran on this model since "
+                           "the graph was built; its activations replaced this one's in the plan workspace.  Call "
+                           "backward() before the next forward (gradient accumulation over several forwards: "
+                           "backward each one first)" % (T, B))
+    if plan.consumed:
+        raise RuntimeError("MFM_KL_EF backward: this graph was already back-propagated (BPTT overwrites the saved "
+                           "gates in place; retain_graph is not supported on the fused plan)")
+    plan.consumed = True
+
+
+def _into_flat(module, eng, present, run):
+    """run(out) fills a flat gradient buffer; route it into the model's flat gradients (overwrite when nothing accumulated since
+    zero_grad, else add) and keep every `p.grad` a view of that buffer"""
+    flat = module._flat_grads()
+    attached = module._grad_views_attached()
+    if module._grad_fresh or not attached:
+        run(flat)
+        if not attached:
+            module._attach_grad_views()
+            module._grad_present[:] = False
+    else:
+        run(None)
+        flat.add_(eng.grads)
+        # the guard word is a flag, not a sum: a NaN added here would never leave (per-tensor zeroing does not reach the
+        # guard granule) and the guarded optimizer would skip every later step
+        g = eng.layout.guard
+        flat[g:g + 1].copy_(eng.grads[g:g + 1])
+    module._grad_fresh = False
+    module._grad_present |= present
+
+
+def _flat_backward_ext(module, plan, serial, x, d_xl, d_xa, d_xv, d_y, d_kld):
+    """backward of one fused forward for arbitrary upstream gradients (None = that output is unused) into the flat buffer"""
+    eng = module.engine
+    T, B, _ = x.shape
+    _check_plan_live(plan, eng, serial, T, B)
+    d_l, d_a, d_v = eng.cfg["input_dims"]
+    dev = x.device
+    mk = module._group_masks()
+    present = mk["shared"].copy()
+    for key, g in (("l", d_xl), ("a", d_xa), ("v", d_xv), ("disc", d_y)):
+        if g is not None:
+            present |= mk[key]
+
+    def z(t, shape):
+        return torch.zeros(shape, device=dev) if t is None else t.contiguous().float()
+    d_xl, d_xa, d_xv = z(d_xl, (T, B, d_l)), z(d_xa, (T, B, d_a)), z(d_xv, (T, B, d_v))
+    d_y = z(d_y, (B, eng.cfg["output_dim"]))
+    d_kld = z(d_kld, ()).reshape(1)
+    plan.ensure_handover(eng.handover and module._handover_ok())
+    _into_flat(module, eng, present, lambda out: eng.backward_ext(x, d_xl, d_xa, d_xv, d_y, d_kld, out=out))
 
 
 class _KLEFFastFn(torch.autograd.Function):
@@ -571,10 +654,10 @@ class _KLEFFastFn(torch.autograd.Function):
             raise _lib.MfmError("%s.forward: the input requires grad; the fused plan does not produce d loss / d x "
                                 "(the reference never asks for it) -- detach the batch" % type(module).__name__)
         eng = module.engine
-        out = eng.forward(x, None, train=module.training, want_xhat=True)
+        plan = eng.plan(x.shape[0], x.shape[1])
+        out = eng.forward(x, None, train=module.training, want_xhat=True, handover=eng.handover and module._handover_ok())
         kld = out["losses"][4].clone()
         ctx.module = module
-        plan = eng.plan(x.shape[0], x.shape[1])
         ctx.plan, ctx.serial = plan, plan.fwd_serial
         ctx.save_for_backward(x)
         # an output the loss does not use must arrive in backward as None, not as a zero tensor: that is how the stage
@@ -585,47 +668,70 @@ class _KLEFFastFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_xl, d_xa, d_xv, d_y, d_kld):
         (x,) = ctx.saved_tensors
-        module = ctx.module
-        eng = module.engine
-        T, B, _ = x.shape
-        plan = ctx.plan
-        if eng.plan(T, B) is not plan or plan.fwd_serial != ctx.serial:
-            raise RuntimeError("MFM_KL_EF backward: another forward with the same (T=%d, B=%d) ran on this model since "
-                               "the graph was built; its activations replaced this one's in the plan workspace.  Call "
-                               "backward() before the next forward (gradient accumulation over several forwards: "
-                               "backward each one first)" % (T, B))
-        if plan.consumed:
-            raise RuntimeError("MFM_KL_EF backward: this graph was already back-propagated (BPTT overwrites the saved "
-                               "gates in place; retain_graph is not supported on the fused plan)")
-        plan.consumed = True
-        d_l, d_a, d_v = eng.cfg["input_dims"]
-        dev = x.device
-        mk = module._group_masks()
-        present = mk["shared"].copy()
-        for key, g in (("l", d_xl), ("a", d_xa), ("v", d_xv), ("disc", d_y)):
-            if g is not None:
-                present |= mk[key]
-
-        def z(t, shape):
-            return torch.zeros(shape, device=dev) if t is None else t.contiguous().float()
-        d_xl, d_xa, d_xv = z(d_xl, (T, B, d_l)), z(d_xa, (T, B, d_a)), z(d_xv, (T, B, d_v))
-        d_y = z(d_y, (B, eng.cfg["output_dim"]))
-        d_kld = z(d_kld, ()).reshape(1)
-        flat = module._flat_grads()
-        attached = module._grad_views_attached()
-        if module._grad_fresh or not attached:
-            # nothing accumulated since zero_grad (or the gradients were None / somebody else's tensors): the plan writes
-            # the flat buffer directly
-            eng.backward_ext(x, d_xl, d_xa, d_xv, d_y, d_kld, out=flat)
-            if not attached:
-                module._attach_grad_views()
-                module._grad_present[:] = False
-        else:
-            eng.backward_ext(x, d_xl, d_xa, d_xv, d_y, d_kld)
-            flat.add_(eng.grads)
-        module._grad_fresh = False
-        module._grad_present |= present
+        _flat_backward_ext(ctx.module, ctx.plan, ctx.serial, x, d_xl, d_xa, d_xv, d_y, d_kld)
         return None, None, None
+
+
+class _LazyRealFn(torch.autograd.Function):
+    """The outputs of a LAZY forward (factorized_amd/lazy.py) as ordinary tensors of one autograd node -- what a lazy output or
+    loss expression turns into when it is used in a way the symbolic path does not cover.  The plan already ran: forward only
+    clones its buffers; backward is _KLEFFastFn's."""
+
+    @staticmethod
+    def forward(ctx, leaf, step):
+        ctx.module, ctx.plan, ctx.serial = step.module, step.plan, step.serial
+        ctx.save_for_backward(step.x)
+        ctx.set_materialize_grads(False)
+        v = step.plan.out_views
+        return v[0].clone(), v[1].clone(), v[2].clone(), v[3].clone(), step.plan.losses[4].clone()
+
+    @staticmethod
+    def backward(ctx, d_xl, d_xa, d_xv, d_y, d_kld):
+        (x,) = ctx.saved_tensors
+        _flat_backward_ext(ctx.module, ctx.plan, ctx.serial, x, d_xl, d_xa, d_xv, d_y, d_kld)
+        return None, None
+
+
+def _lazy_forward(module, x):
+    """training-mode forward with lazy outputs (factorized_amd/lazy.py), or None when this plan cannot serve them"""
+    from . import lazy
+    eng = module.engine
+    T, B, _ = x.shape
+    plan = eng.plan(T, B)
+    if plan.out_views is None:
+        return None
+    plan.ensure_handover(eng.handover and module._handover_ok())
+    if module._flat_leaf is None or module._flat_leaf.device != x.device:
+        module._flat_leaf = torch.zeros((), device=x.device, requires_grad=True)
+    flat = module._flat_grads()
+    # nothing accumulated since zero_grad: the forward's first launch clears the flat gradient buffer (for free, on its role
+    # workgroups) and the backward writes straight into it -- the launches of engine.train_step, nothing else
+    zero = flat if (module._grad_fresh and module._grad_views_attached()) else None
+    eng.forward_train(x, plan, zero)
+    step = lazy.PlanStep(module, eng, plan, x)
+    v = plan.out_views
+    outs = [lazy.LazyOut(v[0], step, 0), lazy.LazyOut(v[1], step, 1), lazy.LazyOut(v[2], step, 2), lazy.LazyOut(v[3], step, 3)]
+    return outs, lazy.LossExpr(step, {lazy.REG: 1.0}), 0.0
+
+
+def _lazy_backward(step, coef, labels, terms):
+    """loss.backward() of a symbolic loss expression: one mfm_plan_backward_weighted call into the flat gradient buffer"""
+    module, eng, plan, x = step.module, step.eng, step.plan, step.x
+    T, B, _ = x.shape
+    _check_plan_live(plan, eng, step.serial, T, B)
+    mk = module._group_masks()
+    present = mk["shared"].copy()
+    for k, key in ((1, "l"), (2, "a"), (3, "v"), (0, "disc")):
+        if k in terms:
+            present |= mk[key]
+    gen_on = any(coef.get(k, 0.0) != 0.0 for k in (1, 2, 3))
+    w = _lib.LossWeights()
+    w.disc = float(coef.get(0, 0.0))
+    w.gen_l, w.gen_a, w.gen_v = step.lda if gen_on else (0.0, 0.0, 0.0)      # (checked equal by LossExpr._fast_backward_ok)
+    w.reg = float(coef.get(4, 0.0))
+    w.write_disc_loss = 1 if labels is not None else 0
+    plan.ensure_handover(eng.handover and module._handover_ok())
+    _into_flat(module, eng, present, lambda out: eng.backward_weighted(x, labels, w, plan, out=out))
 
 
 class MFM_KL_EF(_FusedEngineMixin, nn.Module):
@@ -675,10 +781,15 @@ class MFM_KL_EF(_FusedEngineMixin, nn.Module):
             x = x.contiguous().float()
         _ = self.engine
         if self._fast_ok():
+            if self.lazy_losses and self.training and torch.is_grad_enabled() and not x.requires_grad:
+                res = _lazy_forward(self, x)
+                if res is not None:
+                    return res
             if self._flat_leaf is None or self._flat_leaf.device != x.device:
                 self._flat_leaf = torch.zeros((), device=x.device, requires_grad=True)
             x_l_hat, x_a_hat, x_v_hat, y_hat, kld = _KLEFFastFn.apply(x, self, self._flat_leaf)
         else:
+            self._detach_grad_views()          # (a frozen parameter / a hook: per-tensor autograd owns the gradients from here)
             x_l_hat, x_a_hat, x_v_hat, y_hat, kld = _KLEFFn.apply(x, self, *self._plist)
         decoded = [x_l_hat, x_a_hat, x_v_hat, y_hat]
         missing_loss = 0.0
@@ -1168,10 +1279,15 @@ class _FactorizedMFN(_FusedEngineMixin, nn.Module):
             if not self._use_kl:
                 g = self.mmd_gauss
                 eng.gauss = None if g is None else torch.cat([t.to(x.device).float() for t in g], dim=1).contiguous()
+            if self.lazy_losses and self.training and torch.is_grad_enabled():
+                res = _lazy_forward(self, x)
+                if res is not None:
+                    return res
             if self._flat_leaf is None or self._flat_leaf.device != x.device:
                 self._flat_leaf = torch.zeros((), device=x.device, requires_grad=True)
             x_l_hat, x_a_hat, x_v_hat, y_hat, kld = _KLEFFastFn.apply(x, self, self._flat_leaf)
             return [x_l_hat, x_a_hat, x_v_hat, y_hat], kld, 0.0
+        self._detach_grad_views()              # composed autograd path: per-tensor gradients
         x_l = x[:, :, :self.d_l]
         x_a = x[:, :, self.d_l:self.d_l + self.d_a]
         x_v = x[:, :, self.d_l + self.d_a:]

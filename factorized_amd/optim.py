@@ -54,6 +54,10 @@ class Adam(torch.optim.Optimizer):
         # capturable=True (torch.optim.Adam's flag): step count and learning rate of the fused update live in device memory
         # (mfm_adam_flat_dev), so a whole training step can be captured into a hipGraph and replayed (train.GraphedModuleStep)
         self._capturable = bool(capturable)
+        # this optimizer honours the gradient guard: the models it owns may run their in-launch hand-overs (a model under
+        # any other optimizer stays on separate launches, mfm_model._FusedEngineMixin._guarded)
+        for group in self.param_groups:
+            self._fused_modules(group)
 
     # ------------------------------------------------------------------ helpers
     def _fused_modules(self, group):
@@ -73,6 +77,7 @@ class Adam(torch.optim.Optimizer):
             seen.add(id(m))
             if all(id(q) in ids for q in m._plist):
                 out.append(m)
+                m._guarded = True
         self._fm_cache[id(group)] = (key, out, [weakref.ref(m) for m in out])
         return out
 
@@ -86,6 +91,12 @@ class Adam(torch.optim.Optimizer):
                 if saved["m"].numel() == eng.layout.total and len(saved["steps"]) == len(eng.layout.slots):
                     st["m"].copy_(saved["m"]); st["v"].copy_(saved["v"])
                     st["steps"][:] = np.asarray(saved["steps"], dtype=np.int64)
+                else:
+                    raise _lib.MfmError(
+                        "factorized_amd.optim.Adam.load_state_dict: the saved fused state (%d elements, %d tensors) does not fit "
+                        "this model's flat layout (%d elements, %d tensors) -- a checkpoint of another model / library version; "
+                        "refusing to restart the moments silently" % (saved["m"].numel(), len(saved["steps"]), eng.layout.total,
+                                                                      len(eng.layout.slots)))
             self._fused[m] = st
         return st
 
@@ -113,6 +124,17 @@ class Adam(torch.optim.Optimizer):
         gflat = getattr(m, "_grad_flat", None)
         if gflat is None or not m._grad_views_attached():
             return False                     # gradients are ordinary per-tensor tensors: the stock optimizer handles them
+        if not m._fast_ok():
+            # a parameter was frozen / got a hook after fast-path steps: the flat path would move it (or skip everything);
+            # hand the gradients back to per-tensor tensors and let the stock optimizer apply torch's rules
+            m._detach_grad_views()
+            return False
+        if eng.poll_status():
+            # a hand-over of this step (or an earlier one) gave up: its gradients carry the NaN guard, the launch below leaves
+            # the parameters alone.  Clear the status, fall back to separate launches for the rest of the run, say so.
+            import warnings
+            eng.check_status(raise_on_error=False)
+            warnings.warn(eng.status_message(), RuntimeWarning, stacklevel=3)
         st = self._state_for(m, eng)
         lr, (b1, b2), eps = group["lr"], group["betas"], group["eps"]
         if torch.is_tensor(lr) and not self._capturable:
@@ -170,6 +192,7 @@ class Adam(torch.optim.Optimizer):
             groups = [dict(params=ps, lr=g["lr"], betas=g["betas"], eps=g["eps"]) for g, ps in rest]
             self._fallback = torch.optim.Adam(groups)
             self._fallback_ids = ids
+            self._migrate_fused_state(rest)
             fb = getattr(self, "_pending_fallback", None)
             if fb is not None:
                 self._fallback.load_state_dict(fb)
@@ -177,6 +200,30 @@ class Adam(torch.optim.Optimizer):
         for fg, (g, _) in zip(self._fallback.param_groups, rest):
             fg["lr"], fg["betas"], fg["eps"] = g["lr"], g["betas"], g["eps"]      # schedulers act on OUR groups
         self._fallback.step()
+
+    def _migrate_fused_state(self, rest):
+        """parameters of a fused model that now go through the stock optimizer (a parameter was frozen / got a hook after
+        fast-path steps): their moments and step counts move along -- Adam must not restart"""
+        for _, ps in rest:
+            for p in ps:
+                m = _owner(p)
+                st = self._fused.get(m) if m is not None else None
+                if st is None or p in self._fallback.state:
+                    continue
+                i = next((k for k, q in enumerate(m._plist) if q is p), None)
+                if i is None:
+                    continue
+                o, n, shp = m.engine.layout.slots[i]
+                steps = int(st["step_dev"].item()) if "step_dev" in st else int(st["steps"][i])
+                if steps == 0:
+                    continue
+                self._fallback.state[p] = dict(step=torch.tensor(float(steps)), exp_avg=st["m"][o:o + n].view(shp).clone(),
+                                               exp_avg_sq=st["v"][o:o + n].view(shp).clone())
+        for _, ps in rest:
+            for p in ps:
+                m = _owner(p)
+                if m is not None and m in self._fused:
+                    del self._fused[m]
 
     def reset_state(self):
         """moments and step counters of every fused model back to zero, in place (a captured graph keeps pointing at them)"""
@@ -200,6 +247,8 @@ class Adam(torch.optim.Optimizer):
                 if "step_dev" in st:
                     steps[:] = int(st["step_dev"].item())
                 fused.append(dict(m=st["m"].detach().clone(), v=st["v"].detach().clone(), steps=steps.tolist()))
+        if self._pending_fused:          # loaded, not stepped yet: what was loaded is still the state
+            fused += [dict(m=f["m"], v=f["v"], steps=list(f["steps"])) for f in self._pending_fused]
         sd["fused"] = fused
         if self._fallback is not None:
             sd["fallback"] = self._fallback.state_dict()

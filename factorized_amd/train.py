@@ -177,7 +177,8 @@ class GraphedModuleStep:
         mse = torch.nn.MSELoss()
 
         def step():
-            self.opt.zero_grad(set_to_none=False)
+            # (fused models: zero_grad() costs no launch -- the forward's first launch clears the flat gradient buffer)
+            self.opt.zero_grad(set_to_none=fused)
             (xl, xa, xv, yh), reg, miss = model.forward(self.x)
             x = self.x
             yhat = yh.squeeze(1) if (not ce and cfg["output_dim"] == 1) else yh
@@ -187,6 +188,9 @@ class GraphedModuleStep:
             loss = disc + gen + cfg["lda_mmd"] * reg + miss
             loss.backward()
             self.opt.step()
+            from .lazy import LossExpr
+            if isinstance(loss, LossExpr):        # symbolic: views of the plan's loss slots, nothing to launch (`.item()` reads them)
+                return loss, disc
             return loss.detach(), disc.detach()
 
         # the warm-up steps below run on the (zero) static batch: keep them from training the model
@@ -206,16 +210,32 @@ class GraphedModuleStep:
                         v.zero_()
             if fused:
                 self.opt.reset_state()
-        torch.cuda.synchronize(dev)
+        self._step_fn = step
+        self.recaptures = 0
+        self._capture()
+
+    def _capture(self):
+        torch.cuda.synchronize(self.x.device)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss, self.disc = step()
+            self.loss, self.disc = self._step_fn()
 
     def set_lr(self, lr):
         self.lr.fill_(float(lr))
 
     def step(self, x, y):
         """One training step on batch (x [T,B,D], y); returns (loss, disc_loss) device scalars (no sync)."""
+        if self.fused and self.model.engine.poll_status():
+            # a hand-over inside a replayed launch gave up (another process / stream kept its producers off the GPU): the guarded
+            # Adam skipped that step.  The captured launches would go on using the hand-overs -- plan options do not reach into a
+            # captured graph -- so: clear the status, switch the engine to separate launches and capture the step again.
+            import warnings
+            eng = self.model.engine
+            eng.check_status(raise_on_error=False)
+            warnings.warn(eng.status_message() + "  (GraphedModuleStep: step re-captured on separate launches)", RuntimeWarning,
+                          stacklevel=2)
+            self.recaptures += 1
+            self._capture()
         self.x.copy_(x)
         self.y.copy_(y)
         self.graph.replay()

@@ -39,7 +39,7 @@ extern "C" {
 #define MFM_ERR_HIP (-2)
 #define MFM_ERR_UNSUPPORTED (-3)
 
-#define MFM_ABI_VERSION 3
+#define MFM_ABI_VERSION 4
 
 int mfm_abi_version(void);
 /* 1 when the library was built with MFM_EXPERIMENTAL=1: it then also carries the two kernels that measured slower than what
@@ -355,6 +355,28 @@ int mfm_plan_backward_ext(MfmPlan* plan, const float* params, const float* x, co
                           const float* d_xhat_a, const float* d_xhat_v, const float* d_yhat,
                           const float* d_reg, void* workspace, float* grads, void* stream);
 
+/* ---- the module path's LAZY losses (round 5).  The reference's loop (mfm_mosi.py:427-441) calls model.forward(batch_X), then
+ * builds  loss = L1(y_hat, y) + sum_m lda_m MSE(x_hat_m, x_m) + lda_mmd * reg  from the outputs and calls loss.backward().
+ * The plan's forward already holds the three MSE terms, the regulariser and lda_m-scaled d x_hat (decoder fc1 epilogue): when
+ * the loop's loss is exactly such a weighted sum (factorized_amd/lazy.py recognises it), no x_hat tensor, no torch loss kernel
+ * and no autograd graph is needed:
+ *   mfm_plan_forward_train     = mfm_plan_forward(train=1, y=NULL, no outputs): x_hat / y_hat stay in the workspace
+ *                                (mfm_plan_out_layout), the loss slots [1..4] are filled, slot [0] stays 0; `grads_to_zero`
+ *                                (optional, the plan's flat layout) is cleared inside the first launch.
+ *   mfm_plan_backward_weighted = backward of  w.disc * L_disc(y_hat, y) + sum_m w.gen_m * MSE_m + w.reg * reg  on the last
+ *                                forward.  w.gen_* must equal the plan's lda_x* or all be 0 (MFM_ERR_UNSUPPORTED otherwise:
+ *                                the caller falls back to mfm_plan_backward_ext); write_disc_loss != 0 adds L_disc into loss
+ *                                slot [0] (the forward ran without labels).  `grads` is overwritten (cleared first unless
+ *                                this step's forward_train already cleared it). */
+typedef struct MfmLossWeights { float disc, gen_l, gen_a, gen_v, reg; int32_t write_disc_loss; } MfmLossWeights;
+int mfm_plan_forward_train(MfmPlan* plan, const float* params, const float* x, uint64_t seed, void* workspace,
+                           float* grads_to_zero, void* stream);
+int mfm_plan_backward_weighted(MfmPlan* plan, const float* params, const float* x, const void* y,
+                               const MfmLossWeights* w /*host*/, void* workspace, float* grads, void* stream);
+/* byte offsets inside the workspace of x_hat_l / x_hat_a / x_hat_v [T,B,d_*] (out[0..2]; -1 on bf16-resident plans, which
+ * do not keep them) and y_hat [B,output_dim] (out[3]) as the last forward left them; out[4..7] reserved (-1) */
+int mfm_plan_out_layout(const MfmPlan* plan, int64_t* out /*[8]*/);
+
 /* forward (train mode) + backward of the joint loss in one enqueue, no optimizer: the data-parallel step
  * all-reduces `grads` next and then calls mfm_adam_flat (factorized_amd/train.py).  Same launches as
  * mfm_plan_train_step minus Adam; the gradient buffer is cleared inside the first launch. */
@@ -406,6 +428,11 @@ int mfm_plan_get_option(const MfmPlan* plan, const char* key, int64_t* value);
  * out[2] byte offset of the replay counter (uint64) and out[3] of the backward replay counter (uint32): device words a
  * captured hipGraph advances on every replay (the dropout streams and the hand-over epochs add them), out[4..7] reserved. */
 int mfm_plan_state_layout(const MfmPlan* plan, int64_t* out /*[8]*/);
+/* The same failure, visible WITHOUT a copy or a synchronisation: two uint32 words of host-coherent pinned memory owned by the
+ * plan (allocated by mfm_plan_init_workspace; NULL before).  A consumer that gives up stores 1 into word [0] (projections) /
+ * 2 into word [1] (weight gradients) with a system-scope store next to the device status word; an optimizer polls them for
+ * free before every update (factorized_amd/optim.py).  mfm_plan_clear_status clears them too. */
+int mfm_plan_host_status(MfmPlan* plan, uint32_t** out /*host pointer*/);
 /* enqueue the clearing of the status word */
 int mfm_plan_clear_status(MfmPlan* plan, void* workspace, void* stream);
 

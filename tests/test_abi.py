@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_text():
     L = _lib.lib()
-    assert L.mfm_abi_version() == 3
+    assert L.mfm_abi_version() == 4
     rc = L.mfm_gemm_grouped_f32(None, 0, None)
     assert rc == -1
     assert b"no problems" in L.mfm_last_error()

@@ -1,0 +1,406 @@
+"""The reference's UNCHANGED loop on the lazy losses (factorized_amd/lazy.py): with two import lines switched, the statements of
+mfm_mosi.py:427-441 / mfm_you.py:470-488 / train_beta_vae's stage losses run on the launches of the fused step alone -- no
+x_hat tensor, no torch loss kernel, no autograd graph -- and follow the reference's own trajectories; every use the symbolic path
+does not cover falls back to ordinary tensors and still matches the oracle."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from factorized_amd import configs, synth
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _model(cfgs, cls="MFM_KL_EF", lazy=True):
+    from factorized_amd import mfm_model as M
+    model = getattr(M, cls)(*cfgs)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    w = synth.make_weights(shapes, seed=1234)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w.items()})
+    model.lazy_losses = lazy
+    return model
+
+
+def _loop(model, optimizer, X, y, config, steps, ce=False, stage_of=None, seen=None):
+    """mfm_mosi.py:424-442 / mfm_you.py:468-488 statement by statement"""
+    l1_loss = nn.CrossEntropyLoss() if ce else nn.L1Loss()
+    l2_loss = nn.MSELoss()
+    d_l, d_a, d_v = config["input_dims"]
+    model.train()
+    trace = []
+    for step in range(steps):
+        optimizer.zero_grad()
+        batch_X, batch_y = X, y
+        decoded, mmd_loss, missing_loss = model.forward(batch_X)
+        [x_l_hat, x_a_hat, x_v_hat, y_hat] = decoded
+        y_hat = y_hat.squeeze(1)
+        mmd_loss = config["lda_mmd"] * mmd_loss
+        x_l = batch_X[:, :, :d_l]
+        x_a = batch_X[:, :, d_l:d_l + d_a]
+        x_v = batch_X[:, :, d_l + d_a:]
+        gen_loss = config["lda_xl"] * l2_loss(x_l_hat, x_l) + config["lda_xa"] * l2_loss(x_a_hat, x_a) + config["lda_xv"] * l2_loss(x_v_hat, x_v)
+        disc_loss = l1_loss(y_hat, batch_y)
+        stage = stage_of(step) if stage_of else 0
+        if stage == 1:
+            loss = gen_loss + mmd_loss
+        elif stage == 2:
+            loss = disc_loss + mmd_loss
+        else:
+            loss = disc_loss + gen_loss + mmd_loss + missing_loss
+        if seen is not None:
+            seen.append((type(loss).__name__, type(x_l_hat).__name__))
+        loss.backward()
+        optimizer.step()
+        trace.append([loss.item(), disc_loss.item(), gen_loss.item(), mmd_loss.item() / config["lda_mmd"]])
+    return np.array(trace)
+
+
+def _check_against_gold(model, trace, gold, key, trace_tol=0.1 * TOL):
+    ref = gold["trace"]
+    terr = float(np.max(np.abs(trace - ref) / np.maximum(np.abs(ref), 1e-2)))
+    cases.report("lazy_trace_rel_%s" % key, terr)
+    assert terr < trace_tol, (trace[-1], ref[-1])
+    pl = np.stack([cases.summarize(p.detach().cpu().numpy()) for p in model.parameters()])
+    scale = np.maximum(np.abs(gold["param_after_last"][:, :1]), 1e-3)
+    perr = float(np.max(np.abs(pl - gold["param_after_last"]) / scale))
+    cases.report("lazy_param_rel_%s" % key, perr)
+    assert perr < 0.5 * TOL, perr
+
+
+@pytest.mark.parametrize("case,cls,which", [("klef_b32_t20", "MFM_KL_EF", "ours"), ("klef_b32_t20", "MFM_KL_EF", "torch"),
+                                            ("klef_you_b32_t50", "MFM_KL_EF", "ours"), ("kl_b32_t20", "MFM_KL", "ours"),
+                                            ("mmd_b32_t20", "MFM", "ours"), ("klef_b33_t7", "MFM_KL_EF", "ours"),
+                                            ("klef_mosei_b64_t20", "MFM_KL_EF", "ours")])
+def test_unchanged_loop_is_symbolic_and_follows_the_reference(case, cls, which):
+    _need_gpu()
+    import factorized_amd.optim as optim
+    from factorized_amd import lazy
+    cs = cases.load_case(case)
+    cfg, gold = cs["cfg"], cs["gold"]
+    model = _model(cs["cfgs"], cls)
+    optimizer = (optim.Adam if which == "ours" else torch.optim.Adam)(model.parameters())        # :403, BEFORE .to(device)
+    model = model.to("cuda")
+    if cls == "MFM":
+        g = torch.from_numpy(np.ascontiguousarray(gold["mmd_gauss"]))
+        sizes = [cfg["zl_size"], cfg["za_size"], cfg["zv_size"], cfg["zy_size"]]
+        model.mmd_gauss = [t.cuda() for t in torch.split(g, sizes, dim=1)]
+    X, y = torch.from_numpy(cs["x"]).cuda(), torch.from_numpy(cs["y"]).cuda()
+    seen = []
+    calls = {"n": 0}
+    from factorized_amd import mfm_model as M
+    orig = M._LazyRealFn.forward
+
+    def counting(ctx, leaf, step):
+        calls["n"] += 1
+        return orig(ctx, leaf, step)
+    M._LazyRealFn.forward = staticmethod(counting)
+    try:
+        trace = _loop(model, optimizer, X, y, cfg, cs["steps"], ce=cs["loss_kind"] == "ce", seen=seen)
+    finally:
+        M._LazyRealFn.forward = staticmethod(orig)
+    assert all(s == ("LossExpr", "LazyOut") for s in seen), seen[:2]
+    assert calls["n"] == 0                                   # nothing materialised: no x_hat tensor, no autograd node
+    _check_against_gold(model, trace, gold, "%s_%s" % (case, which), 0.1 * TOL if cls == "MFM_KL_EF" else 0.5 * TOL)
+    assert model._grad_views_attached()
+    plan = model.engine.plan(cs["T"], cs["B"])
+    if cls == "MFM_KL_EF" and cs["B"] <= 32:
+        # the guard-aware optimizer gets the role-workgroup step; any other optimizer the separate launches
+        on = 1 if which == "ours" else 0
+        assert plan.get_option("proj_roles_active") == on and plan.get_option("dw_roles_active") == on
+    if which == "ours":
+        assert optimizer._fallback is None
+    assert model.engine.check_status() == 0
+
+
+@pytest.mark.parametrize("mode", ["frozen", "legacy"])
+def test_staged_losses_stay_symbolic(mode):
+    """train_beta_vae's stage losses (gen + reg, disc + reg): weights of the absent terms are switches of the weighted backward,
+    the tensors a stage does not reach get no gradient and the drop-in Adam skips them ('frozen') or keeps them moving on
+    their momentum (zero_grad(set_to_none=False), the reference's PyTorch 0.4: 'legacy')"""
+    _need_gpu()
+    import factorized_amd.optim as optim
+    gold = np.load(cases.GOLDEN + "/klef_staged_b32_t20.npz")
+    B, T, n1, n2 = (int(v) for v in gold["meta"])
+    cfgs = configs.canonical_configs(dropout=False)
+    cfg = cfgs[0]
+    model = _model(cfgs)
+    optimizer = optim.Adam(model.parameters())
+    model = model.to("cuda")
+    xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7)
+    X, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
+    if mode == "legacy":
+        zg = optimizer.zero_grad
+        optimizer.zero_grad = lambda: zg(set_to_none=False)
+    seen = []
+    trace = _loop(model, optimizer, X, y, cfg, n1 + n2, stage_of=lambda s: 1 if s < n1 else 2, seen=seen)
+    assert all(s == ("LossExpr", "LazyOut") for s in seen)
+    ref = gold[mode + "_trace"]
+    terr = float(np.max(np.abs(trace - ref) / np.maximum(np.abs(ref), 1e-2)))
+    cases.report("lazy_staged_trace_rel_%s" % mode, terr)
+    assert terr < 0.5 * TOL, (trace[-1], ref[-1])
+    last = np.stack([cases.summarize(p.detach().cpu().numpy()) for p in model.parameters()])
+    sc = np.maximum(np.abs(gold[mode + "_param_after_stage2"][:, :1]), 1e-3)
+    perr = float(np.max(np.abs(last - gold[mode + "_param_after_stage2"]) / sc))
+    cases.report("lazy_staged_param_rel_%s" % mode, perr)
+    assert perr < 0.5 * TOL, perr
+
+
+def _oracle_grads(cs, build):
+    from oracle import mfm_oracle as O
+    m = O.build("kl_ef", cs["cfgs"])
+    O.load_numpy_weights(m, synth.make_weights(O.state_shapes(m), seed=1234))
+    m.train()
+    x, y = torch.from_numpy(cs["x"]), torch.from_numpy(cs["y"])
+    decoded, reg, _ = m.forward(x)
+    loss = build(decoded, reg, x, y)
+    loss.backward()
+    return loss.item(), {n: p.grad.numpy() if p.grad is not None else None for n, p in m.named_parameters()}
+
+
+FALLBACKS = {
+    # a target that is the same numbers in another storage: not provably the batch slice
+    "non_aliasing_target": lambda cfg: (lambda d, r, x, y: F.l1_loss(d[3].squeeze(1), y) + cfg["lda_xl"] * F.mse_loss(d[0], x[:, :, :300].clone())
+                                        + cfg["lda_xa"] * F.mse_loss(d[1], x[:, :, 300:305]) + cfg["lda_xv"] * F.mse_loss(d[2], x[:, :, 305:]) + r),
+    "sum_reduction": lambda cfg: (lambda d, r, x, y: F.l1_loss(d[3].squeeze(1), y) + 1e-3 * F.mse_loss(d[0], x[:, :, :300], reduction="sum")
+                                  + cfg["lda_xa"] * F.mse_loss(d[1], x[:, :, 300:305]) + cfg["lda_xv"] * F.mse_loss(d[2], x[:, :, 305:]) + r),
+    "reused_output": lambda cfg: (lambda d, r, x, y: F.l1_loss(d[3].squeeze(1), y) + cfg["lda_xl"] * F.mse_loss(d[0], x[:, :, :300])
+                                  + cfg["lda_xa"] * F.mse_loss(d[1], x[:, :, 300:305]) + cfg["lda_xv"] * F.mse_loss(d[2], x[:, :, 305:]) + r
+                                  + 0.05 * d[0].abs().mean() + 0.1 * (d[3] ** 2).mean()),
+    "other_weights": lambda cfg: (lambda d, r, x, y: 0.5 * F.l1_loss(d[3].squeeze(1), y) + 0.3 * F.mse_loss(d[0], x[:, :, :300])
+                                  + 0.2 * F.mse_loss(d[1], x[:, :, 300:305]) + 0.7 * F.mse_loss(d[2], x[:, :, 305:]) + 2.0 * r),
+    "tensor_weight": lambda cfg: (lambda d, r, x, y: torch.tensor(0.5, device=y.device) * (F.l1_loss(d[3].squeeze(1), y) + cfg["lda_xl"] * F.mse_loss(d[0], x[:, :, :300])
+                                  + cfg["lda_xa"] * F.mse_loss(d[1], x[:, :, 300:305]) + cfg["lda_xv"] * F.mse_loss(d[2], x[:, :, 305:]) + r)),
+    "only_disc_and_reg_scaled": lambda cfg: (lambda d, r, x, y: 3.0 * F.l1_loss(d[3].squeeze(1), y) + 0.25 * r),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FALLBACKS))
+def test_uses_outside_the_symbolic_path_match_the_oracle(name):
+    """value and all 78 gradients against the CPU oracle evaluating the same expression"""
+    _need_gpu()
+    cs = cases.load_case("klef_b33_t7")
+    cfg = cs["cfg"]
+    build = FALLBACKS[name](cfg)
+    ref_loss, ref_g = _oracle_grads(cs, build)
+    model = _model(cs["cfgs"]).cuda().train()
+    X, y = torch.from_numpy(cs["x"]).cuda(), torch.from_numpy(cs["y"]).cuda()
+    decoded, reg, _ = model.forward(X)
+    loss = build(decoded, reg, X, y)
+    val = loss.item()
+    loss.backward()
+    assert abs(val - ref_loss) < TOL * abs(ref_loss), (val, ref_loss)
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if ref_g[n] is None:
+            continue
+        worst = max(worst, cases.grad_err(p.grad.cpu().numpy(), ref_g[n]))
+    cases.report("lazy_fallback_grad_rel_%s" % name, worst)
+    assert worst < TOL, (name, worst)
+    if name == "only_disc_and_reg_scaled":
+        # (stays symbolic: weights of the discriminative term and the regulariser are free)
+        from factorized_amd import lazy
+        assert isinstance(loss, lazy.LossExpr)
+        assert not model._grad_present[model._param_names.index("decoder_l.fc1.weight")]
+
+
+def test_lazy_equals_eager_tensors_bitwise_trajectory():
+    """lazy_losses on / off: the same launches compute the same numbers (the plan's own d x_hat vs the torch MSE backward differ
+    by rounding only): 20 steps stay within 1e-6"""
+    _need_gpu()
+    import factorized_amd.optim as optim
+    cs = cases.load_case("klef_b32_t20")
+    X, y = torch.from_numpy(cs["x"]).cuda(), torch.from_numpy(cs["y"]).cuda()
+    out = []
+    for lz in (True, False):
+        model = _model(cs["cfgs"], lazy=lz)
+        opt = optim.Adam(model.parameters())
+        model = model.cuda()
+        out.append(_loop(model, opt, X, y, cs["cfg"], 20))
+    err = float(np.max(np.abs(out[0] - out[1]) / np.maximum(np.abs(out[1]), 1e-2)))
+    cases.report("lazy_vs_eager_trace_rel", err)
+    assert err < 1e-5, err
+
+
+def test_accumulation_stale_outputs_and_eval_mode():
+    _need_gpu()
+    import factorized_amd.optim as optim
+    from factorized_amd import lazy
+    cs = cases.load_case("klef_b33_t7")
+    cfg = cs["cfg"]
+    X, y = torch.from_numpy(cs["x"]).cuda(), torch.from_numpy(cs["y"]).cuda()
+    mse, l1 = nn.MSELoss(), nn.L1Loss()
+
+    def loss_of(model):
+        (xl, xa, xv, yh), reg, miss = model.forward(X)
+        return l1(yh.squeeze(1), y) + cfg["lda_xl"] * mse(xl, X[:, :, :300]) + cfg["lda_xa"] * mse(xa, X[:, :, 300:305]) \
+            + cfg["lda_xv"] * mse(xv, X[:, :, 305:]) + cfg["lda_mmd"] * reg + miss
+    single, twice = _model(cs["cfgs"]).cuda().train(), _model(cs["cfgs"]).cuda().train()
+    loss_of(single).backward()
+    for _ in range(2):                       # two backward passes without zero_grad add up (autograd semantics)
+        l = loss_of(twice)
+        assert isinstance(l, lazy.LossExpr)
+        l.backward()
+    for (n, p), q in zip(twice.named_parameters(), single.parameters()):
+        assert cases.grad_err(p.grad.cpu().numpy(), 2.0 * q.grad.cpu().numpy()) < 1e-5, n
+    # an expression / output of an EARLIER forward: loud, not wrong
+    l1_ = loss_of(single)
+    (xl, xa, xv, yh), reg, miss = single.forward(X)
+    with pytest.raises(RuntimeError, match="EARLIER forward"):
+        l1_.backward()
+    with pytest.raises(RuntimeError, match="EARLIER forward"):
+        l1_.item()
+    # a second backward of the same forward: loud as well
+    l2_ = l1(yh.squeeze(1), y) + reg
+    l2_.backward()
+    with pytest.raises(RuntimeError, match="already back-propagated"):
+        l2_.backward()
+    # eval mode / no_grad: ordinary tensors (evaluate / predict of the reference collect outputs)
+    single.eval()
+    with torch.no_grad():
+        (xl, xa, xv, yh), reg, miss = single.forward(X)
+    assert type(xl) is torch.Tensor and type(reg) is torch.Tensor
+    single.train()
+    opt = optim.Adam(single.parameters())
+    opt.zero_grad()
+    assert not single._grad_present.any()
+    loss_of(single).backward()
+    opt.step()
+    assert single._grad_present.all()
+
+
+def test_reading_a_lazy_output_gives_the_numbers():
+    _need_gpu()
+    cs = cases.load_case("klef_b33_t7")
+    gold = cs["gold"]
+    model = _model(cs["cfgs"]).cuda().train()
+    X = torch.from_numpy(cs["x"]).cuda()
+    (xl, xa, xv, yh), reg, _ = model.forward(X)
+    assert tuple(xl.shape) == (cs["T"], cs["B"], 300) and xa.dim() == 3 and yh.size(1) == 1 and xl.is_cuda
+    assert cases.rel_err(xa.detach().cpu().numpy(), gold["x_a_hat"]) < TOL
+    assert cases.rel_err(yh.detach().cpu().numpy().reshape(-1), gold["y_hat"].reshape(-1)) < TOL
+    assert abs(float(reg) - float(gold["fwd_reg"])) < TOL * abs(float(gold["fwd_reg"]))
+    assert cases.rel_err(xl[0].detach().cpu().numpy(), gold["x_l_hat_first"]) < TOL
+
+
+def test_freeze_mid_training_hands_the_gradients_back_to_autograd():
+    """(advisor, round 4) a parameter frozen after fast-path steps: the flat views must not keep feeding the fused optimizer"""
+    _need_gpu()
+    import factorized_amd.optim as optim
+    cs = cases.load_case("klef_b33_t7")
+    cfg = cs["cfg"]
+    X, y = torch.from_numpy(cs["x"]).cuda(), torch.from_numpy(cs["y"]).cuda()
+    model = _model(cs["cfgs"])
+    opt = optim.Adam(model.parameters())
+    model = model.cuda()
+    _loop(model, opt, X, y, cfg, 2)
+    assert model._grad_views_attached()
+    for p in model.decoder_l.parameters():
+        p.requires_grad_(False)
+    frozen = [p.detach().clone() for p in model.decoder_l.parameters()]
+    moving = model.encoder_l.fc1.weight.detach().clone()
+    _loop(model, opt, X, y, cfg, 2)
+    assert not model._grad_views_attached()
+    assert all(torch.equal(a, p) for a, p in zip(frozen, model.decoder_l.parameters()))
+    assert not torch.equal(moving, model.encoder_l.fc1.weight)
+    assert all(p.grad is None for p in model.decoder_l.parameters())
+    # oracle: the same four steps with the same freeze
+    from oracle import mfm_oracle as O
+    m = O.build("kl_ef", cs["cfgs"])
+    O.load_numpy_weights(m, synth.make_weights(O.state_shapes(m), seed=1234))
+    m.train()
+    o = torch.optim.Adam(m.parameters())
+    xc, yc = torch.from_numpy(cs["x"]), torch.from_numpy(cs["y"])
+    for s in range(4):
+        if s == 2:
+            for p in m.decoder_l.parameters():
+                p.requires_grad_(False)
+        O.train_step(m, o, xc, yc, cfg)
+    worst = max(cases.rel_err(p.detach().cpu().numpy(), q.detach().numpy()) for p, q in zip(model.parameters(), m.parameters()))
+    assert worst < TOL, worst
+
+
+@pytest.mark.parametrize("fault", [1, 2])
+def test_stock_optimizer_never_sees_a_faulty_gradient(fault):
+    """torch.optim.Adam knows nothing of the gradient guard: a model under it runs on separate launches, where no hand-over can
+    give up -- an armed fault injection has nothing to bite on, the trajectory is the reference's, the status stays clean"""
+    _need_gpu()
+    cs = cases.load_case("klef_b32_t20")
+    cfg, gold = cs["cfg"], cs["gold"]
+    model = _model(cs["cfgs"])
+    opt = torch.optim.Adam(model.parameters())
+    model = model.cuda()
+    X, y = torch.from_numpy(cs["x"]).cuda(), torch.from_numpy(cs["y"]).cuda()
+    _loop(model, opt, X, y, cfg, 1)
+    plan = model.engine.plan(cs["T"], cs["B"])
+    plan.set_option("handover_timeout_us", 3000)
+    traces = [_loop(model, opt, X, y, cfg, 1)]
+    for _ in range(cs["steps"] - 2):
+        plan.set_option("inject_fault", fault)
+        traces.append(_loop(model, opt, X, y, cfg, 1))
+        assert plan.get_option("proj_roles_active") == 0 and plan.get_option("dw_roles_active") == 0
+    torch.cuda.synchronize()
+    assert not model.engine.poll_status() and model.engine.check_status() == 0
+    trace = np.concatenate(traces)
+    ref = gold["trace"][1:]
+    terr = float(np.max(np.abs(trace - ref) / np.maximum(np.abs(ref), 1e-2)))
+    assert terr < 0.1 * TOL, terr
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+@pytest.mark.parametrize("fault", [1, 2])
+def test_guarded_optimizer_survives_a_fault_without_the_host_looking(fault):
+    """factorized_amd.optim.Adam, the unchanged loop, NO check_status / loss_dict call anywhere: the failed step is skipped
+    (guard), the optimizer notices the host-mapped status word at a later step(), warns, switches to separate launches, and
+    training goes on -- the sticky status no longer stalls the run (advisor, round 4)"""
+    _need_gpu()
+    import factorized_amd.optim as optim
+    cs = cases.load_case("klef_b32_t20")
+    cfg = cs["cfg"]
+    model = _model(cs["cfgs"])
+    opt = optim.Adam(model.parameters())
+    model = model.cuda().train()
+    X, y = torch.from_numpy(cs["x"]).cuda(), torch.from_numpy(cs["y"]).cuda()
+    d_l, d_a, d_v = cfg["input_dims"]
+    mse, l1 = nn.MSELoss(), nn.L1Loss()
+
+    def step():
+        opt.zero_grad()
+        (xl, xa, xv, yh), kld, miss = model.forward(X)
+        loss = l1(yh.squeeze(1), y) + cfg["lda_xl"] * mse(xl, X[:, :, :d_l]) + cfg["lda_xa"] * mse(xa, X[:, :, d_l:d_l + d_a]) \
+            + cfg["lda_xv"] * mse(xv, X[:, :, d_l + d_a:]) + cfg["lda_mmd"] * kld + miss
+        loss.backward()
+        opt.step()
+
+    step(); step()
+    eng = model.engine
+    plan = eng.plan(cs["T"], cs["B"])
+    assert plan.get_option("dw_roles_active") == 1
+    plan.set_option("handover_timeout_us", 3000)
+    torch.cuda.synchronize()
+    before = [q.detach().cpu().numpy().copy() for q in model.parameters()]
+    plan.set_option("inject_fault", fault)
+    step()
+    torch.cuda.synchronize()                 # (the test's own: lets the failure land before the next step polls)
+    assert all(np.array_equal(a, q.detach().cpu().numpy()) for a, q in zip(before, model.parameters()))
+    assert eng.poll_status()
+    with pytest.warns(RuntimeWarning, match="hand-over"):
+        step()                               # polls, reports, falls back (this step still ran under the raised status: skipped too)
+    torch.cuda.synchronize()
+    assert not eng.handover and eng.handover_failures == 1 and not eng.poll_status()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    assert any(not np.array_equal(a, q.detach().cpu().numpy()) for a, q in zip(before, model.parameters()))
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+    assert eng.check_status() == 0
