@@ -385,6 +385,7 @@ class _FusedEngineMixin:
     # training-mode forwards return lazy outputs / symbolic loss expressions (factorized_amd/lazy.py): the reference's unchanged
     # loop then runs on the launches of the fused step alone.  False: ordinary tensors (round-4 behaviour)
     lazy_losses = True
+    _fast_last = True
     # set by factorized_amd.optim.Adam when it owns this model's parameters: its update honours the gradient guard, so the
     # in-launch hand-overs of the small-batch step may be used.  Any other optimizer (torch.optim.Adam, SGD, ...) would apply
     # the gradients of a step whose hand-over gave up: the module path then runs on separate launches, where nothing can fail
@@ -432,12 +433,14 @@ class _FusedEngineMixin:
         """The flat-gradient path bypasses autograd for the parameters: every tensor gets a gradient view and the fused optimizer
         updates it.  That is wrong for a frozen parameter (requires_grad=False must stay without a gradient and untouched) and
         invisible to parameter hooks, so both fall back to the per-tensor autograd path (`fast_grads = False` semantics)."""
-        if not self.fast_grads:
-            return False
-        for p in self._plist:
-            if not p.requires_grad or p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
-                return False
-        return True
+        ok = bool(self.fast_grads)
+        if ok:
+            for p in self._plist:
+                if not p.requires_grad or p._backward_hooks or p._post_accumulate_grad_hooks:
+                    ok = False
+                    break
+        self._fast_last = ok          # (what zero_grad / optimizer.step of the same iteration go by: one walk over the tensors per step)
+        return ok
 
     def _flat_ok(self):
         if self._engine is None:
@@ -497,7 +500,7 @@ class _FusedEngineMixin:
     def _zero_flat_grads(self, set_to_none=True):
         """optimizer.zero_grad() of factorized_amd.optim.Adam: one launch; set_to_none=True marks every tensor as
         'no gradient yet' (the optimizer skips what the next backward does not reach, like torch with .grad = None)"""
-        if not (set_to_none and self.lazy_losses and self.training and self._fast_ok()):
+        if not (set_to_none and self.lazy_losses and self.training and self._fast_last):
             # (set_to_none on a lazily-training model: no launch -- torch would leave `.grad = None` behind, here the views stay
             # attached and hold the previous step's values until the next forward's first launch clears the buffer; every
             # backward that follows OVERWRITES it, and `_grad_present` makes the optimizer skip what no backward reached)

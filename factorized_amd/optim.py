@@ -124,7 +124,7 @@ class Adam(torch.optim.Optimizer):
         gflat = getattr(m, "_grad_flat", None)
         if gflat is None or not m._grad_views_attached():
             return False                     # gradients are ordinary per-tensor tensors: the stock optimizer handles them
-        if not m._fast_ok():
+        if not m._fast_last:
             # a parameter was frozen / got a hook after fast-path steps: the flat path would move it (or skip everything);
             # hand the gradients back to per-tensor tensors and let the stock optimizer apply torch's rules
             m._detach_grad_views()

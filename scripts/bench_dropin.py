@@ -37,6 +37,11 @@ for name, opt_cls, fast, item in (("torch.optim.Adam, per-tensor autograd (round
                                   ("torch.optim.Adam, flat gradients", torch.optim.Adam, True, True),
                                   ("factorized_amd.optim.Adam, flat gradients", optim.Adam, True, True),
                                   ("factorized_amd.optim.Adam, flat gradients, no per-step .item()", optim.Adam, True, False)):
+    # (the per-tensor runs leave cyclic garbage holding device tensors behind: measured, the next configuration's per-step
+    # `.item()` then costs 0.2-0.3 ms more -- a property of this script's history, not of the path)
+    import gc
+    model = optimizer = None
+    gc.collect(); torch.cuda.empty_cache()
     model = MFM_KL_EF(*cfgs)
     model.fast_grads = fast
     optimizer = opt_cls(model.parameters())

@@ -208,8 +208,13 @@ def test_flat_gradients_accumulate_and_match_per_tensor_path():
     for (n, p), q in zip(fast.named_parameters(), single.parameters()):
         assert cases.grad_err(p.grad.cpu().numpy(), 2.0 * q.grad.cpu().numpy()) < 1e-5, n
     opt = optim.Adam(fast.parameters())
+    # zero_grad(): every tensor "no gradient yet" (torch: .grad = None); on a lazily-training model it costs no launch -- the
+    # next forward's first launch clears the buffer, every backward behind it overwrites.  set_to_none=False: zeros in place
     opt.zero_grad()
-    assert fast._grad_views_attached() and float(fast._grad_flat.abs().max()) == 0.0 and not fast._grad_present.any()
+    assert fast._grad_views_attached() and not fast._grad_present.any() and fast._grad_fresh
+    opt.zero_grad(set_to_none=False)
+    assert fast._grad_views_attached() and float(fast._grad_flat.abs().max()) == 0.0
+    opt.zero_grad()
     for p in fast.parameters():
         p.grad = None
     loss_of(fast).backward()
