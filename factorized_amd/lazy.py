@@ -384,6 +384,35 @@ class LossExpr(torch.Tensor):
         return func(*_swap(args), **_swap(kwargs))
 
 
+class SnapshotStep(StepBase):
+    """Loss expressions over a COPY of a plan's loss slots (values only, nothing to back-propagate): what a captured training
+    step hands out -- one copy node inside the graph keeps them valid across interleaved eager forwards on the same plan
+    (train.GraphedModuleStep)."""
+    disc_in_slot = True
+
+    def __init__(self, slots, x):
+        self.slots, self.x = slots, x
+        self.scalar_view = slots[7]
+
+    def check_live(self, what):
+        pass
+
+    def term_real(self, k):
+        return self.slots[k]
+
+    def term_value(self, k):
+        return self.slots[k]
+
+    def backward_weighted(self, coef, labels, terms):
+        raise RuntimeError("this loss belongs to a captured training step: its backward already ran inside the graph")
+
+    def host_slots(self):
+        return [float(v) for v in self.slots[:5].cpu()]
+
+    def device_slots(self):
+        return self.slots
+
+
 # ---------------------------------------------------------------------------------------- the engine binding
 class PlanStep(StepBase):
     """StepBase on the fused plan of an engine-backed module (mfm_model._FusedEngineMixin)."""

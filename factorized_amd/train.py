@@ -175,6 +175,7 @@ class GraphedModuleStep:
             self.opt = torch.optim.Adam(model.parameters(), lr=self.lr, capturable=True)
         disc_fn = torch.nn.CrossEntropyLoss() if ce else torch.nn.L1Loss()
         mse = torch.nn.MSELoss()
+        self._snap = self._snap_step = None
 
         def step():
             # (fused models: zero_grad() costs no launch -- the forward's first launch clears the flat gradient buffer)
@@ -188,9 +189,16 @@ class GraphedModuleStep:
             loss = disc + gen + cfg["lda_mmd"] * reg + miss
             loss.backward()
             self.opt.step()
-            from .lazy import LossExpr
-            if isinstance(loss, LossExpr):        # symbolic: views of the plan's loss slots, nothing to launch (`.item()` reads them)
-                return loss, disc
+            from .lazy import LossExpr, SnapshotStep
+            if isinstance(loss, LossExpr):
+                # symbolic losses: ONE copy node of the plan's 64-byte state block; the returned expressions read the copy
+                # (valid until the next replay, whatever else runs on the plan in between)
+                plan = model.engine.plan(T, B)
+                if self._snap is None:
+                    self._snap = torch.zeros_like(plan.state)
+                    self._snap_step = SnapshotStep(self._snap, self.x)
+                self._snap.copy_(plan.state)
+                return LossExpr(self._snap_step, loss._coef, loss._const), LossExpr(self._snap_step, disc._coef, disc._const)
             return loss.detach(), disc.detach()
 
         # the warm-up steps below run on the (zero) static batch: keep them from training the model
