@@ -66,11 +66,11 @@ __device__ __forceinline__ f32x4 mma16x16x4(float a, float b, f32x4 c) {
 // MFM_FAST_ACT=1 (default): sigmoid/tanh on the hardware transcendentals v_exp_f32 / v_rcp_f32
 // (~1 ulp each; absolute error ~1e-7, far inside the 1e-4 parity budget).  MFM_FAST_ACT=0 uses
 // the ocml expf/tanhf, which cost ~5x more VALU issue slots per LSTM step.
-// Workgroup barrier for LDS hand-offs inside the time loops.  `__syncthreads()` also waits for every
-// outstanding GLOBAL store (s_waitcnt vmcnt(0)); the recurrences store gates/h/c each step and would
-// pay a full store round trip (~1-2 us) per step for data no other wave reads.  Here only the LDS
-// traffic is drained (lgkmcnt) before s_barrier; the "memory" clobber keeps the compiler from moving
-// LDS accesses across it.
+// Workgroup barrier for LDS hand-offs inside the time loops: only the LDS traffic is drained (lgkmcnt) before s_barrier; the
+// "memory" clobber keeps the compiler from moving LDS accesses across it.  Neither this nor `__syncthreads()` waits for
+// outstanding GLOBAL stores on gfx950 (a workgroup-scope release needs no vmcnt wait outside threadgroup-split mode: measured
+// round 4, profiles/r04_handover_safety.txt) -- whoever announces global data to another workgroup behind a barrier must wait for
+// its stores itself: sync_stores() in lstm_seq_small.hip (s_waitcnt vmcnt(0) + barrier).
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }

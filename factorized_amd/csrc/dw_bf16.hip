@@ -160,7 +160,9 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
         // (seen in the ISA of the builtin form).  M0 = LDS byte address of THIS WAVE's lane 0 (the hardware adds 16 x the
         // lane id inside the wave, not the thread id); one wait state after the M0 write.
         const unsigned ldsaddr = (unsigned)(uintptr_t)(lds_void*)(base + i * DWB_THREADS * 16 + wave * 64 * 16);
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(ldsaddr) : "memory", "m0");
+        { unsigned m0_saved;    // M0 is the compiler's to manage (clobbering a reserved register is undefined behaviour): saved and restored here
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                       : "=&s"(m0_saved) : "v"(g), "s"(ldsaddr) : "memory"); }
       }
     }
   };

@@ -93,7 +93,9 @@ __global__ __launch_bounds__(PJ_THREADS + 64) void proj_bf16_kernel(const PjDev 
       for (int j = 0; j < 8; ++j) {
         const __bf16* gj = g + j * 512;
         const unsigned ldsaddr = base + j * 1024;
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gj), "s"(ldsaddr) : "memory", "m0");
+        { unsigned m0_saved;    // M0 is the compiler's to manage (clobbering a reserved register is undefined behaviour): saved and restored here
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                       : "=&s"(m0_saved) : "v"(gj), "s"(ldsaddr) : "memory"); }
       }
     };
     for (int t = 0; t < S - 1; ++t) issue(t);

@@ -189,10 +189,28 @@ class _Fixed(torch.nn.Module):
         return v * self.mask
 
 
-def test_bf16_mfn_dropout_epilogues():
+def _force_relu_pattern(lin, active, known):
+    """forward hook on an oracle Linear that feeds a relu: make the relu take the PLAN's on/off decision wherever it is known
+    (a unit whose pre-activation sits within bf16 rounding of zero flips between the bf16 plan and the fp32 oracle -- on an
+    8 x 8 layer one flipped unit is a quarter of the gradient, and which units sit that close depends on the mask stream, i.e.
+    on the seed).  On where the plan is on: the value moves by < 2 |pre| (rounding-sized), the gradient passes; off: neither."""
+    active, known = torch.from_numpy(active), torch.from_numpy(known)
+
+    def hook(mod, inp, out):
+        on = known & active & (out <= 0)
+        off = known & (~active) & (out > 0)
+        out = out + on.float() * (2.0 * out.abs() + 1e-30).detach()
+        return torch.where(off, -torch.ones_like(out), out)
+    lin.register_forward_hook(hook)
+    return lin
+
+
+@pytest.mark.parametrize("seed", [3, 1234, 7, 11, 99, 2024, 31337, 5])
+def test_bf16_mfn_dropout_epilogues(seed):
     """train mode on a bf16 plan: the relu + dropout masks drawn in the bf16 GEMM epilogues are 0 | 1/(1-p), keep the
     right fraction, are applied to the stored activation, and -- injected into the fp32 oracle together with the latent
-    stack's masks -- give losses / gradients within the bf16 bounds: forward and backward use the same masks."""
+    stack's masks AND its relu on/off pattern (both are in the plan's record) -- give losses / gradients within the bf16
+    rounding bound for EVERY seed of the mask stream: forward and backward use the same masks."""
     _need_gpu()
     P = dict(zl_to_fl_dropout=0.2, za_to_fa_dropout=0.5, zv_to_fv_dropout=0.7, zy_to_fy_dropout=0.3, fy_to_y_dropout=0.4)
     cfgs = configs.canonical_configs(dropout=True, **P)
@@ -200,10 +218,7 @@ def test_bf16_mfn_dropout_epilogues():
     cfg = cfgs[0]
     B, T = 48, 6
     e, w = _engine(cfgs, "kl")
-    # the mask stream decides which relu units sit within bf16 rounding of zero and flip against the fp32 oracle; on the 8 x 8
-    # layer za_to_fa_fc1 one flipped unit is a quarter of the gradient.  Scan of 8 seeds (round 4, after the stream's call
-    # counter got its odd stride): 7 at 0.036-0.048, one (1234) at 0.26 -- a flip, not rounding.  The bound below is for rounding.
-    e.seed = 3
+    e.seed = seed
     xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=5)
     x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
     out = e.forward(x, y, train=True, want_xhat=False)
@@ -237,6 +252,12 @@ def test_bf16_mfn_dropout_epilogues():
     for site, key in sites.items():
         o_, n_ = lay["mask"][site], lay["width"][site]
         setattr(m, key, _Fixed(torch.from_numpy(rec[:, o_:o_ + n_].copy())))
+        # relu behind fc1: the plan's decision is visible where the unit was not dropped (post-dropout activation > 0 <=> on)
+        a_ = lay["act"][site]
+        _force_relu_pattern(getattr(m, site + "_fc1"), rec[:, a_:a_ + n_] > 0, rec[:, o_:o_ + n_] > 0)
+    for site, ch in (("zl_to_fl", "l"), ("za_to_fa", "a"), ("zv_to_fv", "v"), ("zy_to_fy", "y")):
+        f_, n_ = lay["f"][ch], lay["width"][site]            # relu behind fc2 (no dropout): known everywhere
+        _force_relu_pattern(getattr(m, site + "_fc2"), rec[:, f_:f_ + n_] > 0, np.ones((B, n_), dtype=bool))
     torch.set_num_threads(4)
     terms = O.loss_terms(m, torch.from_numpy(xn), torch.from_numpy(yn), cfg)
     terms["loss"].backward()
@@ -258,7 +279,7 @@ def test_bf16_mfn_dropout_epilogues():
         rel = np.linalg.norm(g - r) / nr
         if rel > worst[1]:
             worst = (n, rel)
-    cases.report("bf16_mfn_dropout_grad_relL2", worst[1])
-    assert worst[1] < 0.15, worst
+    cases.report("bf16_mfn_dropout_grad_relL2_seed%d" % seed, worst[1])
+    assert worst[1] < 0.08, worst
     e.forward(x, y, train=True, want_xhat=False)
     assert not np.array_equal(e.mfn_buffers(T, B)["m1"].cpu().numpy(), buf["m1"])

@@ -11,6 +11,8 @@ another process / stream can keep the producers off the device until a consumer'
 
 The failures are INJECTED (plan option "inject_fault": one producer does not raise its flag), then provoked for real with a busy
 co-tenant stream; plus a bounded long run of the role workgroups against the separate launches."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -282,3 +284,96 @@ def test_cotenant_stream_is_survived():
         assert np.abs(pa - pb).max() < 5e-2
     from tests import cases
     cases.report("cotenant_handover_failures", float(raised))
+
+
+@pytest.mark.parametrize("B,T", [(32, 1), (16, 1), (32, 2)])
+def test_counting_loop_short_sequences(B, T):
+    """The loop that found round 4's store / flag race (scripts/handover_flake.py; 22 wrong steps in 1500 at T = 1 before the
+    fix, profiles/r04_handover_safety.txt), now part of every GPU run: 1500 role-workgroup gradient steps per shape against the
+    separate-launch gradients of the same batch -- at T <= 2 the consumers sit right behind their producers, the case where a
+    flag can overtake its data.  Not one tensor of one step may be off."""
+    cfgs = C.canonical_configs(dropout=False)
+    cfg = cfgs[0]
+    xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7)
+    x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
+    ref = _engine(handover=False, timeout_us=50000)
+    ref.grad_step(x, y)
+    torch.cuda.synchronize()
+    rg = ref.grads.clone()
+    scale = {n: max(float(v.abs().max()), 1e-12) for n, v in ref.grad_views().items()}
+    e = _engine(timeout_us=50000)
+    bad, names = 0, {}
+    for r in range(1500):
+        e.grad_step(x, y)
+        d = (e.grads - rg).abs()
+        if float(d.max()) > 1e-5:
+            nb = [n for n, v in e.layout.views(d).items() if float(v.max()) > 1e-4 * scale[n] + 1e-7]
+            if nb:
+                bad += 1
+                for n in nb:
+                    names[n] = names.get(n, 0) + 1
+    assert e.plan(T, B).get_option("dw_roles_active") == 1 and e.plan(T, B).get_option("proj_roles_active") == 1
+    assert bad == 0, (bad, names)
+    assert e.check_status() == 0
+
+
+_COTENANT = r"""
+import os, sys, time, torch
+ready, stop = sys.argv[1], sys.argv[2]
+a = torch.randn(4096, 4096, device="cuda"); b = torch.randn(4096, 4096, device="cuda")
+torch.mm(a, b); torch.cuda.synchronize()
+open(ready, "w").write("1")
+t0 = time.time()
+while not os.path.exists(stop) and time.time() - t0 < 60:
+    for _ in range(8):
+        a = torch.mm(a, b) * 1e-2
+    torch.cuda.synchronize()
+"""
+
+
+def test_cotenant_process_is_survived(tmp_path):
+    """A SECOND PROCESS on the same GPU (the realistic co-tenant of a 0.5 M-parameter model: its queue is scheduled by the
+    hardware against ours, it shares no stream order with us) runs 4096^3 GEMMs back to back while 300 fused steps go through
+    the role workgroups with the default 50 ms time-out.  Either no hand-over fails, or the failure is survived: an MfmError at
+    a loss read, separate launches afterwards, never a NaN or a garbage update, the run finishes on the reference's losses."""
+    import subprocess
+    import sys
+    import time
+    ready, stop = str(tmp_path / "ready"), str(tmp_path / "stop")
+    child = subprocess.Popen([sys.executable, "-c", _COTENANT, ready, stop])
+    try:
+        t0 = time.time()
+        while not os.path.exists(ready):
+            assert child.poll() is None, "co-tenant process died"
+            assert time.time() - t0 < 180, "co-tenant process did not come up"
+            time.sleep(0.1)
+        e = _engine(timeout_us=50000)
+        ref = _engine(timeout_us=50000, handover=False)
+        data = _batches()
+        raised = 0
+        for i in range(300):
+            l = e.train_step(*data[i % 4], lr=1e-4)
+            ref.train_step(*data[i % 4], lr=1e-4)
+            if i % 10 == 9:
+                try:
+                    assert np.isfinite(e.loss_dict(l)["loss"])
+                except MfmError:
+                    raised += 1
+        try:
+            e.check_status()
+        except MfmError:
+            raised += 1
+        torch.cuda.synchronize()
+        assert child.poll() is None, "the co-tenant was meant to be running the whole time"
+    finally:
+        open(stop, "w").write("1")
+        try:
+            child.wait(timeout=60)
+        except Exception:
+            child.kill()
+    assert raised == e.handover_failures and raised <= 1
+    assert np.isfinite(_snap(e)[0]).all()
+    # skipped steps aside (at most the ones between a failure and the loss read that reported it), the run followed the
+    # separate-launch reference
+    la, lb = e.loss_dict(e.train_step(*data[0], lr=1e-4))["loss"], ref.loss_dict(ref.train_step(*data[0], lr=1e-4))["loss"]
+    assert abs(la - lb) < 5e-2 * abs(lb), (la, lb, raised)
