@@ -129,10 +129,16 @@ def main():
     e.set_timing(T, B, 1 << table[dom]["kid"], every=TIMING_EVERY)
 
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides, max over ranks
+    rank_dt = [0.0]
+
     def timed_region():
         barrier()
+        if world > 1 and hasattr(allreduce, "wait_stats"):
+            allreduce.wait_stats(reset=True)
         t0 = time.perf_counter()
         run(args.steps, args.warmup + 10)
+        torch.cuda.synchronize()
+        rank_dt[0] = time.perf_counter() - t0          # this rank's own K steps (before the closing barrier)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -162,6 +168,7 @@ def main():
         e.collect_timing(T, B)
         dt = timed_region()
     in_sync = None
+    flag_wait = allreduce.wait_stats(reset=True) if (world > 1 and hasattr(allreduce, "wait_stats")) else None
     if world > 1:
         import torch.distributed as dist
         # a P2P wait that gave up on any rank invalidates the measurement: switch every rank to RCCL,
@@ -174,6 +181,7 @@ def main():
             train.broadcast_params(e, world)
             e.collect_timing(T, B)
             dt = timed_region()
+            flag_wait = None
         # replicas must still hold identical parameters (same reduced gradients on every rank)
         lo, hi = e.params.clone(), e.params.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -181,7 +189,7 @@ def main():
         in_sync = bool((lo == hi).all().item())
         # cost of the exchange alone (outside the timed region): the collective in use next to
         # torch.distributed's, 50 back-to-back calls on the gradient buffer each
-        coll_us = {}
+        coll_us, coll_rank = {}, {}
         entries = [(allreduce.name, allreduce)]
         if allreduce.name != "rccl":
             entries.append(("rccl", comm.TorchAllReduce()))
@@ -195,7 +203,8 @@ def main():
                 fn(e.grads)
             ev1.record()
             torch.cuda.synchronize()
-            tt = torch.tensor([1e3 * ev0.elapsed_time(ev1) / 50], dtype=torch.float64, device="cuda")
+            coll_rank[name] = round(1e3 * ev0.elapsed_time(ev1) / 50, 1)
+            tt = torch.tensor([coll_rank[name]], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             coll_us[name] = round(float(tt.item()), 1)
     exposed_us = None
@@ -211,10 +220,31 @@ def main():
         barrier()
         t0 = time.perf_counter()
         run_local(args.steps, args.warmup + 10)
+        torch.cuda.synchronize()
+        local_dt = time.perf_counter() - t0
         barrier()
         tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         exposed_us = round(1e6 * (dt - float(tt.item())) / args.steps, 1)
+        # forward + backward alone (no optimizer, no exchange), this rank
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            x, y = data.batch(my_batches[(args.warmup + 10 + i) % len(my_batches)])
+            e.grad_step(x, y, check=False)
+        torch.cuda.synchronize()
+        grad_dt = time.perf_counter() - t0
+        # one line per rank, so that a sub-par scaling result can be read from this run alone: which rank is slow, whether the
+        # time goes into its own step, into waiting for a late peer (flag round 1) or into the exchange itself (round 2)
+        mine = {"rank": rank, "step_us": round(1e6 * rank_dt[0] / args.steps, 1),
+                "grad_step_us": round(1e6 * grad_dt / args.steps, 1),
+                "local_step_us": round(1e6 * local_dt / args.steps, 1),
+                "exposed_collective_us": round(1e6 * (rank_dt[0] - local_dt) / args.steps, 1),
+                "collective_us_per_call": coll_rank, "flag_wait_us": flag_wait,
+                "preflight": stepper.preflight_report, "role_workgroups": bool(e.handover),
+                "handover_failures": e.handover_failures}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     timed = e.collect_timing(T, B)[dom]
     e.set_timing(T, B, 0)
 
@@ -255,7 +285,8 @@ def main():
                        "collective": allreduce.name if allreduce is not None else None,
                        "replicas_in_sync": in_sync,
                        "collective_us_per_call": coll_us if world > 1 else None,
-                       "exposed_collective_us": exposed_us},
+                       "exposed_collective_us": exposed_us,
+                       "per_rank": per_rank if world > 1 else None},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 4),
                          "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 6), "traffic": traffic,

@@ -124,6 +124,7 @@ _SIGS = {
                                                  C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                                  C.c_int64, C.c_void_p]),
     "mfm_p2p_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "mfm_p2p_wait_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
     "mfm_p2p_destroy": (None, [C.c_void_p]),
     "mfm_plan_num_params": (C.c_int, [C.c_int32]),
     "mfm_plan_set_gauss": (C.c_int, [C.c_void_p, C.c_void_p]),

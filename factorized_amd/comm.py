@@ -119,6 +119,15 @@ class P2PAllReduce:
         _lib.check(self._L.mfm_p2p_status(self._h, C.byref(v)), "mfm_p2p_status")
         return bool(v.value)
 
+    def wait_stats(self, reset=True):
+        """How long workgroup 0 of THIS rank spun in the two flag rounds since the last reset: dict(round1_us, round2_us per
+        call, calls).  Round 1 waits for the slowest peer's first push (= how late that rank entered the exchange), round 2 for
+        the slowest owner's result (synchronises; diagnosis of a scaling run)."""
+        v = (C.c_int64 * 3)()
+        _lib.check(self._L.mfm_p2p_wait_stats(self._h, v, 1 if reset else 0), "mfm_p2p_wait_stats")
+        n = max(int(v[2]), 1)
+        return dict(round1_us=round(v[0] / 100.0 / n, 2), round2_us=round(v[1] / 100.0 / n, 2), calls=int(v[2]))
+
     def close(self):
         if self._h is not None:
             self._L.mfm_p2p_destroy(self._h)

@@ -39,6 +39,7 @@ struct P2PDev {
   int* f1[P2P_MAXR];        // per rank: [W][P2P_WGS] epoch of the last complete first push
   int* f2[P2P_MAXR];        // per rank: [W][P2P_WGS] epoch of the last complete result push
   int* err;                 // local error word
+  long long* stats;         // local: [0] ticks workgroup 0 spent in flag round 1, [1] in round 2, [2] calls (mfm_p2p_wait_stats)
   int W, rank;
   int64_t SL, CL;           // slice length, chunk length (floats, multiples of 4)
 };
@@ -80,9 +81,11 @@ __device__ __forceinline__ f32x4 load4_sys(const float* base, int64_t elem) {
 // sees the bits of all ranks before it touches a parameter, so all replicas skip the same steps.
 // thread t < W waits until flags[t] reaches `epoch`; returns (after a block barrier + acquire fence) whether any flag had its
 // low bit set
-__device__ __forceinline__ bool wait_flags(const int* flags, int stride, int W, int epoch, int64_t timeout, int* err) {
+__device__ __forceinline__ bool wait_flags(const int* flags, int stride, int W, int epoch, int64_t timeout, int* err,
+                                           long long* stat = nullptr) {
   __shared__ int any_bad;
-  if (threadIdx.x == 0) any_bad = 0;
+  __shared__ int waited;
+  if (threadIdx.x == 0) { any_bad = 0; waited = 0; }
   __syncthreads();
   if ((int)threadIdx.x < W) {
     const int* f = flags + (int64_t)threadIdx.x * stride;
@@ -98,6 +101,7 @@ __device__ __forceinline__ bool wait_flags(const int* flags, int stride, int W, 
       }
     }
     if (v & 1) any_bad = 1;
+    if (stat) atomicMax(&waited, (int)min((int64_t)0x7fffffff, wall_clock64() - t0));
   }
   // one acquire per workgroup (the wave that polled): it invalidates this CU's vector L1 and the L2's
   // non-coherent lines; the staging block itself is uncached, so this is insurance, not the mechanism
@@ -105,6 +109,9 @@ __device__ __forceinline__ bool wait_flags(const int* flags, int stride, int W, 
   if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 #endif
   __syncthreads();
+  // diagnosis (bench.py --gpus N): how long workgroup 0 of this rank spun in this flag round (100 MHz ticks, summed over calls;
+  // one writer, read by the host between launches)
+  if (stat && threadIdx.x == 0) *stat += waited;
   return any_bad != 0;
 }
 
@@ -172,7 +179,8 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev
   }
   publish(d.f1, me * P2P_WGS + w, W, epoch, bad_local);
   // ---- reduce my slice's chunk in rank order, push 2: the result -> every rank's result row `me`
-  const bool skip = wait_flags(d.f1[me] + w, P2P_WGS, W, epoch, timeout, d.err);
+  long long* stat = (w == 0) ? d.stats : nullptr;
+  const bool skip = wait_flags(d.f1[me] + w, P2P_WGS, W, epoch, timeout, d.err, stat);
   // The result goes to the peers FIRST and the flags right behind it; this rank's own copy and its Adam update -- plain stores,
   // i.e. dirty L2 lines that the release inside publish() would have to write back before the flags could leave -- come after
   // (round 4; while the chunk fits two passes of the workgroup: 4096 floats, every gradient buffer of this code base at W >= 2)
@@ -210,7 +218,8 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev
     }
   }
   // ---- gather: foreign result rows -> my gradient buffer
-  (void)wait_flags(d.f2[me] + w, P2P_WGS, W, epoch, timeout, d.err);
+  (void)wait_flags(d.f2[me] + w, P2P_WGS, W, epoch, timeout, d.err, stat ? stat + 1 : nullptr);
+  if (stat && tid == 0) stat[2] += 1;
   for (int64_t k = (int64_t)tid * 4; k < CL && cb + k < SL; k += P2P_THREADS * 4) {
     f32x4 v[P2P_MAXR];
 #pragma unroll
@@ -227,6 +236,88 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev
       }
     }
   }
+}
+
+// The same exchange when a chunk is ONE pass of the workgroup (CL <= 2048 floats: the 1.9 MB gradient buffer from W = 4 on) --
+// straight-line code whose memory round trips are taken TOGETHER instead of one behind the other (round 5):
+//   * the Adam operands p, m, v of everything this workgroup will update (its chunk of all W slices) are requested right behind
+//     the first push, so they travel while the flags do; the generic kernel asked for them slice by slice behind the second flag
+//     round, each request waiting for the previous slice's stores (no-alias cannot be proven): W - 1 dependent round trips;
+//   * the W - 1 foreign result rows are requested in one batch and updated from registers.
+template <bool ADAM>
+__global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_1pass_kernel(const P2PDev d, float* __restrict__ buf, int64_t n, int epoch,
+                                                                         int64_t timeout, const AdamArgs ad, const int64_t guard_idx) {
+  const int w = blockIdx.x, tid = threadIdx.x;
+  const int W = d.W, me = d.rank;
+  const int bad_local = (ADAM && guard_idx >= 0 && !(buf[guard_idx] == 0.0f)) ? 1 : 0;
+  const int64_t SL = d.SL, CL = d.CL, cb = (int64_t)w * CL;
+  const int64_t k = (int64_t)tid * 4;
+  const bool act = k < CL && cb + k < SL;
+  long long* stat = (w == 0) ? d.stats : nullptr;
+  // slice visited at position i: the own slice at i = 0, then the peers starting at the next rank (spreads the links)
+  auto slice = [&](int i) { return (me + min(i, W - 1)) % W; };
+  f32x4 v[P2P_MAXR];
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < P2P_MAXR; ++i) v[i] = load4_bounded(buf, (int64_t)slice(i) * SL + cb + k, n);
+#pragma unroll
+    for (int i = 0; i < P2P_MAXR; ++i)
+      if (i < W) store4_sys(d.stage[slice(i)], (int64_t)me * SL + cb + k, v[i]);
+  }
+  f32x4 pp[P2P_MAXR], pm[P2P_MAXR], pv[P2P_MAXR];
+  if (ADAM && act) {
+#pragma unroll
+    for (int i = 0; i < P2P_MAXR; ++i) {
+      const int64_t idx = (int64_t)slice(i) * SL + cb + k;
+      pp[i] = load4_bounded(ad.p, idx, n); pm[i] = load4_bounded(ad.m, idx, n); pv[i] = load4_bounded(ad.v, idx, n);
+    }
+  }
+  publish(d.f1, me * P2P_WGS + w, W, epoch, bad_local);
+  const bool skip = wait_flags(d.f1[me] + w, P2P_WGS, W, epoch, timeout, d.err, stat);
+  auto adam_from = [&](int i, f32x4 g4) {
+    const int64_t idx = (int64_t)slice(i) * SL + cb + k;
+    f32x4 p4 = pp[i], m4 = pm[i], v4 = pv[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gg = g4[j] * ad.grad_scale;
+      m4[j] = m4[j] + (1.0f - ad.beta1) * (gg - m4[j]);
+      v4[j] = v4[j] * ad.beta2 + (1.0f - ad.beta2) * gg * gg;
+      const float denom = sqrtf(v4[j]) / ad.bc2_sqrt + ad.eps;
+      p4[j] = p4[j] - ad.step_size * m4[j] / denom;
+    }
+    store4_bounded(ad.p, idx, n, p4); store4_bounded(ad.m, idx, n, m4); store4_bounded(ad.v, idx, n, v4);
+  };
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (act) {
+#pragma unroll
+    for (int r = 0; r < P2P_MAXR; ++r) v[r] = load4_sys(d.stage[me], cb + k + (int64_t)min(r, W - 1) * SL);
+    acc = v[0];
+#pragma unroll
+    for (int r = 1; r < P2P_MAXR; ++r)
+      if (r < W) acc += v[r];
+#pragma unroll
+    for (int i = 1; i < P2P_MAXR; ++i)
+      if (i < W) store4_sys(d.res[slice(i)], (int64_t)me * SL + cb + k, acc);
+  }
+  publish(d.f2, me * P2P_WGS + w, W, epoch);
+  // (own copy and own update behind the flags: plain stores = dirty L2 lines the release above would have had to write back)
+  if (act) {
+    store4_bounded(buf, (int64_t)me * SL + cb + k, n, acc);
+    if (ADAM && !skip) adam_from(0, acc);
+  }
+  (void)wait_flags(d.f2[me] + w, P2P_WGS, W, epoch, timeout, d.err, stat ? stat + 1 : nullptr);
+  if (act) {
+#pragma unroll
+    for (int i = 1; i < P2P_MAXR; ++i) v[i] = load4_sys(d.res[me], (int64_t)slice(i) * SL + cb + k);
+#pragma unroll
+    for (int i = 1; i < P2P_MAXR; ++i) {
+      if (i < W) {
+        store4_bounded(buf, (int64_t)slice(i) * SL + cb + k, n, v[i]);
+        if (ADAM && !skip) adam_from(i, v[i]);
+      }
+    }
+  }
+  if (stat && tid == 0) stat[2] += 1;
 }
 
 __global__ __launch_bounds__(P2P_THREADS) void adam_only_kernel(const float* __restrict__ g, int64_t n, const AdamArgs ad,
@@ -293,6 +384,7 @@ int mfm_p2p_create(int32_t nranks, int32_t rank, int64_t max_elems, void** handl
   p2p_point(h, rank, h->local);
   h->peer[rank] = h->local;
   h->d.err = reinterpret_cast<int*>(static_cast<char*>(h->local) + h->off_err);
+  h->d.stats = reinterpret_cast<long long*>(static_cast<char*>(h->local) + h->off_err + 256);
   const char* t = opt_get("MFM_P2P_TIMEOUT_MS");
   const double ms = t ? atof(t) : 10000.0;
   h->timeout_ticks = (int64_t)(ms * 1e5);               // wall_clock64 ticks at 100 MHz
@@ -362,7 +454,13 @@ static int p2p_launch(void* handle, float* buf, int64_t n, void* stream, const A
     hipLaunchKernelGGL(adam_only_kernel, dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, buf, n, *ad, guard_idx);
   } else {
     h->epoch += 1;
-    if (ad)
+    const bool one_pass = h->d.CL <= (int64_t)P2P_THREADS * 4 && !opt_get("MFM_P2P_GENERIC");
+    if (one_pass && ad)
+      hipLaunchKernelGGL(p2p_allreduce_1pass_kernel<true>, dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, h->d, buf, n, h->epoch, h->timeout_ticks, *ad, guard_idx);
+    else if (one_pass)
+      hipLaunchKernelGGL(p2p_allreduce_1pass_kernel<false>, dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, h->d, buf, n, h->epoch, h->timeout_ticks,
+                         AdamArgs{}, (int64_t)-1);
+    else if (ad)
       hipLaunchKernelGGL(p2p_allreduce_kernel<true>, dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, h->d, buf, n, h->epoch, h->timeout_ticks, *ad, guard_idx);
     else
       hipLaunchKernelGGL(p2p_allreduce_kernel<false>, dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, h->d, buf, n, h->epoch, h->timeout_ticks,
@@ -402,6 +500,17 @@ int mfm_p2p_status(void* handle, int32_t* timed_out) {
   hipError_t e = hipMemcpy(&v, h->d.err, sizeof(int), hipMemcpyDeviceToHost);
   if (e != hipSuccess) return hip_fail(e, "mfm_p2p_status: read-back");
   *timed_out = v;
+  return MFM_OK;
+}
+
+int mfm_p2p_wait_stats(void* handle, int64_t* out, int32_t reset) {
+  P2P* h = static_cast<P2P*>(handle);
+  if (!h || !out) { set_error("mfm_p2p_wait_stats: null argument"); return MFM_ERR_ARG; }
+  long long v[3] = {0, 0, 0};
+  hipError_t e = hipMemcpy(v, h->d.stats, sizeof(v), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && reset) e = hipMemset(h->d.stats, 0, sizeof(v));
+  if (e != hipSuccess) return hip_fail(e, "mfm_p2p_wait_stats");
+  out[0] = v[0]; out[1] = v[1]; out[2] = v[2];
   return MFM_OK;
 }
 

@@ -116,11 +116,63 @@ class DataParallelStep:
                 from . import comm
                 self.allreduce = comm.TorchAllReduce()
             _mark_shared_device(engine)
+        self.preflight_report = None         # dict once the first step ran the pre-flight (world > 1)
+
+    # C1 of the latent kernels' mask stream (csrc/plan.hip: seed * C1 + calls * C2): with C1 odd, the seed that makes call n + 1
+    # draw the masks of call n is seed - C2 / C1 (mod 2^64)
+    _C1, _C2 = 0x9E3779B97F4A7C15, 0xD1B54A32D192ED03
+
+    def _preflight(self, x, y):
+        """The deployment composition -- role-workgroup grad_step (in-launch hand-overs) next to a live P2P mapping -- cannot run
+        on a 1-GPU box (ranks that share a device switch the hand-overs off), so the first multi-GPU job is the first time it
+        runs.  Before it is trusted: three role-workgroup gradient steps against the separate launches on the same batch and
+        the same dropout masks, on every rank; all ranks must agree, else every rank uses the separate launches."""
+        e = self.e
+        rep = dict(ran=False, ok=True, worst=0.0, roles=False)
+        import torch.distributed as dist
+        from . import comm
+        want = bool(getattr(e, "handover", False)) and hasattr(e, "set_handover")
+        ok, worst, roles = True, 0.0, False
+        if want:
+            seed0 = e.seed
+            inv = pow(self._C1, -1, 1 << 64)
+            try:
+                for it in range(3):
+                    e.seed = (seed0 + 1000003 * it) & ((1 << 64) - 1)
+                    e.set_handover(False)
+                    e.grad_step(x, y, check=False)
+                    ref = e.grads.clone()
+                    e.seed = (e.seed - self._C2 * inv) & ((1 << 64) - 1)          # the next call draws the same masks
+                    e.set_handover(True)
+                    e.grad_step(x, y, check=False)
+                    p = e.plan(x.shape[0], x.shape[1])
+                    roles = roles or bool(p.get_option("dw_roles_active")) or bool(p.get_option("proj_roles_active"))
+                    d = float((e.grads - ref).abs().max())
+                    sc = float(ref.abs().max())
+                    worst = max(worst, d / max(sc, 1e-30))
+                    ok = ok and (d <= 1e-5 * sc + 1e-7) and bool(torch.isfinite(e.grads).all())
+                ok = ok and e.check_status(raise_on_error=False) == 0
+            except Exception as ex:          # (keep the collective below aligned across ranks)
+                ok, rep["error"] = False, "%s: %s" % (type(ex).__name__, ex)
+            e.seed = seed0
+        # every rank takes part in the agreement, whatever it did locally
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            ok = comm._agree(ok, getattr(e, "device", "cpu"))
+        if want and not ok:
+            e.set_handover(False)
+            if dp_env()[0] == 0:
+                import sys
+                sys.stderr.write("[factorized_amd.train] pre-flight: role-workgroup grad_step disagreed with the separate launches "
+                                 "on some rank (worst rel %.2e here): every rank uses the separate launches\n" % worst)
+        rep.update(ran=want, ok=ok, worst=worst, roles=roles)
+        self.preflight_report = rep
 
     def step(self, x, y):
         e = self.e
         if self.world == 1:
             return e.train_step(x, y, lr=self.lr, check=False)
+        if self.preflight_report is None:
+            self._preflight(x, y)
         losses = e.grad_step(x, y, check=False)           # fwd + bwd: one enqueue, 10 launches
         fused = getattr(self.allreduce, "allreduce_adam", None)
         if fused is not None and os.environ.get("MFM_DP_FUSED_ADAM", "1") == "1":
@@ -177,7 +229,7 @@ class GraphedModuleStep:
         mse = torch.nn.MSELoss()
         self._snap = self._snap_step = None
 
-        def step():
+        def step(apply=True):
             # (fused models: zero_grad() costs no launch -- the forward's first launch clears the flat gradient buffer)
             self.opt.zero_grad(set_to_none=fused)
             (xl, xa, xv, yh), reg, miss = model.forward(self.x)
@@ -188,7 +240,8 @@ class GraphedModuleStep:
                 + cfg["lda_xv"] * mse(xv, x[:, :, d[0] + d[1]:])
             loss = disc + gen + cfg["lda_mmd"] * reg + miss
             loss.backward()
-            self.opt.step()
+            if apply:
+                self.opt.step()
             from .lazy import LossExpr, SnapshotStep
             if isinstance(loss, LossExpr):
                 # symbolic losses: ONE copy node of the plan's 64-byte state block; the returned expressions read the copy
@@ -243,6 +296,9 @@ class GraphedModuleStep:
             warnings.warn(eng.status_message() + "  (GraphedModuleStep: step re-captured on separate launches)", RuntimeWarning,
                           stacklevel=2)
             self.recaptures += 1
+            # one forward / backward on the separate launches outside the capture (whatever they build lazily is built now;
+            # no optimizer step: the parameters stay where they are), then the new graph
+            self._step_fn(False)
             self._capture()
         self.x.copy_(x)
         self.y.copy_(y)

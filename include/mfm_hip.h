@@ -274,6 +274,10 @@ int mfm_p2p_allreduce_adam_guarded(void* handle, float* grads, float* p, float* 
                                    float lr, float beta1, float beta2, float eps, float grad_scale, int64_t guard_index,
                                    void* stream);
 int mfm_p2p_status(void* handle, int32_t* timed_out /*1 if any wait gave up since create (synchronises)*/);
+/* diagnosis of a sub-par scaling run: ticks (100 MHz wall clock) workgroup 0 of THIS rank spent spinning in flag round 1 (the
+ * peers' first pushes) and round 2 (the owners' results), summed over the exchanges since create / the last reset, and the
+ * number of exchanges: out[0], out[1], out[2] (synchronises; bench.py --gpus N prints them per rank) */
+int mfm_p2p_wait_stats(void* handle, int64_t* out /*[3]*/, int32_t reset);
 void mfm_p2p_destroy(void* handle);
 
 /* ------------------------------------------------------------------------------------------

@@ -150,3 +150,35 @@ def test_capturable_optimizer_state_dict_round_trip():
     assert np.allclose(la, lb, rtol=1e-6), (la, lb)
     ref = cs["gold"]["trace"][5:10, 0]
     assert np.max(np.abs(np.array(lb) - ref) / np.abs(ref)) < 0.1 * TOL
+
+
+def test_graphed_step_recaptures_after_a_failed_handover():
+    """(advisor, round 4) plan options do not reach into a captured graph: after a hand-over time-out the replays would go on
+    using the in-launch hand-overs under a sticky status -- every step skipped, for good.  GraphedModuleStep polls the plan's
+    host-mapped status word before each replay; when it is raised it clears the status, switches the engine to separate
+    launches, captures the step again and says so.  (A captured launch cannot take a fault injection -- that is a host-side
+    kernel argument -- so the failure is planted where a real one leaves it: status word + host word.)"""
+    from factorized_amd import train, _lib
+    cs = cases.load_case("klef_b32_t20")
+    model = _model(cs["cfgs"], "MFM_KL_EF")
+    X, y = torch.from_numpy(cs["x"]).cuda(), torch.from_numpy(cs["y"]).cuda()
+    gs = train.GraphedModuleStep(model, cs["cfg"], cs["B"], cs["T"], lr=1e-3)
+    plan = model.engine.plan(cs["T"], cs["B"])
+    assert plan.get_option("dw_roles_active") == 1
+    for _ in range(3):
+        gs.step(X, y)
+    torch.cuda.synchronize()
+    before = [p.detach().clone() for p in model.parameters()]
+    plan.state.view(torch.int32)[_lib.MFM_LOSS_SLOTS] = 2          # what a weight-gradient consumer that gave up leaves behind
+    torch.cuda.synchronize()
+    plan.host_words[1] = 2
+    # (without the poll: every replay from here on is skipped by the guarded Adam)
+    with pytest.warns(RuntimeWarning, match="re-captured"):
+        loss, disc = gs.step(X, y)
+    assert gs.recaptures == 1 and not model.engine.handover and model.engine.handover_failures == 1
+    for _ in range(3):
+        loss, disc = gs.step(X, y)
+    torch.cuda.synchronize()
+    assert plan.get_option("dw_roles_active") == 0 and plan.get_option("proj_roles_active") == 0
+    assert np.isfinite(float(loss)) and model.engine.check_status() == 0
+    assert any(not torch.equal(a, p) for a, p in zip(before, model.parameters()))
