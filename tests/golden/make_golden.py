@@ -271,7 +271,9 @@ def run_extra(name, B=12, T=6, canonical=False):
 STAGED = [("klef_staged_b32_t20", 32, 20, 4, 4, "kl_ef"), ("kl_staged_b32_t20", 32, 20, 4, 4, "kl"),
           ("mmd_staged_b32_t20", 32, 20, 4, 4, "mmd")]
 # BASELINE config 4 (MOSEI shape, large batch): summaries + loss trace only
-LIGHT = [("klef_mosei_b1024_t20", "kl_ef", C.mosei_configs, {}, 1024, 20, 8)]
+LIGHT = [("klef_mosei_b1024_t20", "kl_ef", C.mosei_configs, {}, 1024, 20, 8),
+         # SURVEY section 8d config 4 says T = 50: the same shape at the sequence length the config names (round 5)
+         ("klef_mosei_b256_t50", "kl_ef", C.mosei_configs, {}, 256, 50, 4)]
 
 
 if __name__ == "__main__":

@@ -662,12 +662,14 @@ def test_bf16_resident_plan_selection_and_stored_dtypes(monkeypatch):
             assert dec["dxhat"].dtype == torch.bfloat16 and dec["dhs"].dtype == torch.bfloat16
 
 
-def test_bf16_large_batch_mosei_loss_curve():
-    """BASELINE config 4's shape at a large batch (B=1024, T=20, 7 regression outputs): bf16 loss curve against the
-    reference's fp32 trace (golden klef_mosei_b1024_t20, light: summaries only)."""
+@pytest.mark.parametrize("gname", ["klef_mosei_b1024_t20", "klef_mosei_b256_t50"])
+def test_bf16_large_batch_mosei_loss_curve(gname):
+    """BASELINE config 4's shape at a large batch (7 regression outputs; B=1024, T=20 and -- the sequence length the config
+    names, SURVEY section 8d -- B=256, T=50): bf16 (bf16-resident plan) and fp32 loss curves against the reference's fp32 trace
+    (goldens klef_mosei_b1024_t20 / klef_mosei_b256_t50, light: summaries only)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    gold = np.load(cases.GOLDEN + "/klef_mosei_b1024_t20.npz")
+    gold = np.load(cases.GOLDEN + "/%s.npz" % gname)
     B, T, steps = (int(v) for v in gold["meta"])
     cfgs = configs.mosei_configs(dropout=False)
     cfg = cfgs[0]
@@ -683,5 +685,49 @@ def test_bf16_large_batch_mosei_loss_curve():
             trace.append([ld["loss"], ld["disc"], ld["gen"], ld["reg"]])
         trace, ref = np.array(trace), gold["trace"]
         dev_ = float(np.max(np.abs(trace - ref) / np.maximum(np.abs(ref), 1e-2)))
-        cases.report("mosei_b1024_trace_rel_%s" % prec, dev_)
+        cases.report("%s_trace_rel_%s" % (gname, prec), dev_)
         assert dev_ < bound, (prec, trace[-1], ref[-1])
+        if prec == "bf16":
+            assert e.seq_buffers(T, B, 0)["bf16_resident"]
+
+
+def test_bf16_resident_mosei_t50_gradients_against_the_oracle():
+    """MOSEI shape x T=50 x large B on the bf16-RESIDENT path (B=256 >= 192): losses and all 78 gradients of one step against
+    the fp32 CPU oracle on the same batch, at the bf16 bounds of the other bf16 gradient tests (relative L2 per tensor)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from factorized_amd import engine
+    from oracle import mfm_oracle as O
+    B, T = 256, 50
+    cfgs = configs.mosei_configs(dropout=False)
+    cfg = cfgs[0]
+    xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7, output_dim=cfg["output_dim"])
+    e = engine.MFMEngine(cfgs, precision="bf16")
+    w = synth.make_weights(e.layout.shapes, seed=1234)
+    e.load_weights(w)
+    torch.set_num_threads(8)
+    m = O.build("kl_ef", cfgs)
+    O.load_numpy_weights(m, w)
+    m.train()
+    terms = O.loss_terms(m, torch.from_numpy(xn), torch.from_numpy(yn), cfg)
+    terms["loss"].backward()
+    x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
+    out = e.forward(x, y, train=True, want_xhat=False)
+    ld = e.loss_dict(out["losses"])
+    assert e.seq_buffers(T, B, 0)["bf16_resident"]
+    for k in ("disc", "gen", "reg", "loss"):
+        ref = float(terms[k].detach())
+        assert abs(ld[k] - ref) <= 2e-3 * max(abs(ref), 1e-2), (k, ld[k], ref)
+    e.backward(x, y, stage=0)
+    gv = e.grad_views()
+    worst = ("", 0.0)
+    for n, p in m.named_parameters():
+        g, r = gv[n].cpu().numpy().astype(np.float64).ravel(), p.grad.numpy().astype(np.float64).ravel()
+        nr = np.linalg.norm(r)
+        if nr < 1e-9:
+            continue
+        rel = np.linalg.norm(g - r) / nr
+        if rel > worst[1]:
+            worst = (n, rel)
+    cases.report("bf16_resident_mosei_b256_t50_grad_relL2", worst[1])
+    assert 1e-5 < worst[1] < 8e-2, worst

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import mfm_oracle as O
-from factorized_amd import synth
+from factorized_amd import configs, synth
 from tests import cases
 
 TOL = 2e-6   # same torch ops on the same host -> essentially bit-equal
@@ -127,3 +127,24 @@ def test_oracle_staged_training_matches_reference(mode, variant, gname):
     p2 = np.stack([cases.summarize(p.detach().numpy()) for p in model.parameters()])
     assert np.allclose(p2, gold[mode + "_param_after_stage2"], rtol=1e-5, atol=1e-6)
     assert np.allclose(np.array(trace), gold[mode + "_trace"], rtol=1e-5, atol=1e-6)
+
+
+def test_oracle_matches_reference_mosei_t50_forward():
+    """BASELINE config 4 at the sequence length it names (MOSEI shape, T=50, B=256; light golden: summaries only): the oracle's
+    loss terms of the first step against the reference's (one forward: the CPU suite stays within minutes)."""
+    gold = np.load(cases.GOLDEN + "/klef_mosei_b256_t50.npz")
+    B, T, _ = (int(v) for v in gold["meta"])
+    assert (B, T) == (256, 50)
+    cfgs = configs.mosei_configs(dropout=False)
+    cfg = cfgs[0]
+    model = O.build("kl_ef", cfgs)
+    O.load_numpy_weights(model, synth.make_weights(O.state_shapes(model), seed=1234))
+    model.train()
+    xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7, output_dim=cfg["output_dim"])
+    torch.set_num_threads(4)
+    with torch.no_grad():
+        terms = O.loss_terms(model, torch.from_numpy(xn), torch.from_numpy(yn), cfg)
+    for k in ("disc", "gen", "gen_l", "gen_a", "gen_v", "reg", "loss"):
+        ref = float(gold["fwd_" + k])
+        assert abs(float(terms[k]) - ref) <= 2e-6 * max(abs(ref), 1.0), (k, float(terms[k]), ref)
+    assert np.allclose(cases.summarize(terms["decoded"][3].numpy()), gold["y_hat_sum"], rtol=1e-5, atol=1e-5)
