@@ -238,45 +238,54 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(const P2PDev
   }
 }
 
-// The same exchange when a chunk is ONE pass of the workgroup (CL <= 2048 floats: the 1.9 MB gradient buffer from W = 4 on) --
-// straight-line code whose memory round trips are taken TOGETHER instead of one behind the other (round 5):
+// The same exchange when a chunk is at most TWO passes of the workgroup and ranks x passes <= 8 (the 1.9 MB gradient buffer at
+// every W from 2 to 8: one pass from W = 4 on, two at W = 2) -- straight-line code whose memory round trips are taken TOGETHER
+// instead of one behind the other (round 5):
 //   * the Adam operands p, m, v of everything this workgroup will update (its chunk of all W slices) are requested right behind
 //     the first push, so they travel while the flags do; the generic kernel asked for them slice by slice behind the second flag
 //     round, each request waiting for the previous slice's stores (no-alias cannot be proven): W - 1 dependent round trips;
 //   * the W - 1 foreign result rows are requested in one batch and updated from registers.
-template <bool ADAM>
-__global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_1pass_kernel(const P2PDev d, float* __restrict__ buf, int64_t n, int epoch,
-                                                                         int64_t timeout, const AdamArgs ad, const int64_t guard_idx) {
+// NP = passes, MAXW = ranks the register arrays are sized for (NP * MAXW = 8 items of p, m, v: 96 registers).
+template <bool ADAM, int NP, int MAXW>
+__global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_flat_kernel(const P2PDev d, float* __restrict__ buf, int64_t n, int epoch,
+                                                                        int64_t timeout, const AdamArgs ad, const int64_t guard_idx) {
+  constexpr int NI = NP * MAXW;
   const int w = blockIdx.x, tid = threadIdx.x;
   const int W = d.W, me = d.rank;
   const int bad_local = (ADAM && guard_idx >= 0 && !(buf[guard_idx] == 0.0f)) ? 1 : 0;
   const int64_t SL = d.SL, CL = d.CL, cb = (int64_t)w * CL;
-  const int64_t k = (int64_t)tid * 4;
-  const bool act = k < CL && cb + k < SL;
   long long* stat = (w == 0) ? d.stats : nullptr;
-  // slice visited at position i: the own slice at i = 0, then the peers starting at the next rank (spreads the links)
+  // item (i, q): slice visited at position i (the own slice at i = 0, then the peers starting at the next rank: spreads the
+  // links), pass q of the chunk
   auto slice = [&](int i) { return (me + min(i, W - 1)) % W; };
-  f32x4 v[P2P_MAXR];
-  if (act) {
+  auto koff = [&](int q) { return (int64_t)tid * 4 + (int64_t)q * P2P_THREADS * 4; };
+  auto act = [&](int q) { return koff(q) < CL && cb + koff(q) < SL; };
+  f32x4 v[NI];
 #pragma unroll
-    for (int i = 0; i < P2P_MAXR; ++i) v[i] = load4_bounded(buf, (int64_t)slice(i) * SL + cb + k, n);
+  for (int i = 0; i < MAXW; ++i)
 #pragma unroll
-    for (int i = 0; i < P2P_MAXR; ++i)
-      if (i < W) store4_sys(d.stage[slice(i)], (int64_t)me * SL + cb + k, v[i]);
-  }
-  f32x4 pp[P2P_MAXR], pm[P2P_MAXR], pv[P2P_MAXR];
-  if (ADAM && act) {
+    for (int q = 0; q < NP; ++q)
+      if (act(q)) v[i * NP + q] = load4_bounded(buf, (int64_t)slice(i) * SL + cb + koff(q), n);
 #pragma unroll
-    for (int i = 0; i < P2P_MAXR; ++i) {
-      const int64_t idx = (int64_t)slice(i) * SL + cb + k;
-      pp[i] = load4_bounded(ad.p, idx, n); pm[i] = load4_bounded(ad.m, idx, n); pv[i] = load4_bounded(ad.v, idx, n);
-    }
+  for (int i = 0; i < MAXW; ++i)
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+      if (i < W && act(q)) store4_sys(d.stage[slice(i)], (int64_t)me * SL + cb + koff(q), v[i * NP + q]);
+  f32x4 pp[NI], pm[NI], pv[NI];
+  if (ADAM) {
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i)
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        if (!act(q)) continue;
+        const int64_t idx = (int64_t)slice(i) * SL + cb + koff(q);
+        pp[i * NP + q] = load4_bounded(ad.p, idx, n); pm[i * NP + q] = load4_bounded(ad.m, idx, n); pv[i * NP + q] = load4_bounded(ad.v, idx, n);
+      }
   }
   publish(d.f1, me * P2P_WGS + w, W, epoch, bad_local);
   const bool skip = wait_flags(d.f1[me] + w, P2P_WGS, W, epoch, timeout, d.err, stat);
-  auto adam_from = [&](int i, f32x4 g4) {
-    const int64_t idx = (int64_t)slice(i) * SL + cb + k;
-    f32x4 p4 = pp[i], m4 = pm[i], v4 = pv[i];
+  auto adam_from = [&](int it, int64_t idx, f32x4 g4) {
+    f32x4 p4 = pp[it], m4 = pm[it], v4 = pv[it];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float gg = g4[j] * ad.grad_scale;
@@ -287,36 +296,53 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_1pass_kernel(const 
     }
     store4_bounded(ad.p, idx, n, p4); store4_bounded(ad.m, idx, n, m4); store4_bounded(ad.v, idx, n, v4);
   };
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (act) {
+  // ---- reduce my slice's chunk in rank order, push 2: the result -> every rank's result row `me`
+  f32x4 acc[NP];
+  {
+    f32x4 r[NI];
 #pragma unroll
-    for (int r = 0; r < P2P_MAXR; ++r) v[r] = load4_sys(d.stage[me], cb + k + (int64_t)min(r, W - 1) * SL);
-    acc = v[0];
+    for (int rk = 0; rk < MAXW; ++rk)
 #pragma unroll
-    for (int r = 1; r < P2P_MAXR; ++r)
-      if (r < W) acc += v[r];
+      for (int q = 0; q < NP; ++q)
+        if (act(q)) r[rk * NP + q] = load4_sys(d.stage[me], cb + koff(q) + (int64_t)min(rk, W - 1) * SL);
 #pragma unroll
-    for (int i = 1; i < P2P_MAXR; ++i)
-      if (i < W) store4_sys(d.res[slice(i)], (int64_t)me * SL + cb + k, acc);
+    for (int q = 0; q < NP; ++q) {
+      acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!act(q)) continue;
+      acc[q] = r[q];
+#pragma unroll
+      for (int rk = 1; rk < MAXW; ++rk)
+        if (rk < W) acc[q] += r[rk * NP + q];
+#pragma unroll
+      for (int i = 1; i < MAXW; ++i)
+        if (i < W) store4_sys(d.res[slice(i)], (int64_t)me * SL + cb + koff(q), acc[q]);
+    }
   }
   publish(d.f2, me * P2P_WGS + w, W, epoch);
   // (own copy and own update behind the flags: plain stores = dirty L2 lines the release above would have had to write back)
-  if (act) {
-    store4_bounded(buf, (int64_t)me * SL + cb + k, n, acc);
-    if (ADAM && !skip) adam_from(0, acc);
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    if (!act(q)) continue;
+    const int64_t idx = (int64_t)me * SL + cb + koff(q);
+    store4_bounded(buf, idx, n, acc[q]);
+    if (ADAM && !skip) adam_from(q, idx, acc[q]);
   }
   (void)wait_flags(d.f2[me] + w, P2P_WGS, W, epoch, timeout, d.err, stat ? stat + 1 : nullptr);
-  if (act) {
+  // ---- gather: foreign result rows -> my gradient buffer (+ Adam from the prefetched operands)
 #pragma unroll
-    for (int i = 1; i < P2P_MAXR; ++i) v[i] = load4_sys(d.res[me], (int64_t)slice(i) * SL + cb + k);
+  for (int i = 1; i < MAXW; ++i)
 #pragma unroll
-    for (int i = 1; i < P2P_MAXR; ++i) {
-      if (i < W) {
-        store4_bounded(buf, (int64_t)slice(i) * SL + cb + k, n, v[i]);
-        if (ADAM && !skip) adam_from(i, v[i]);
-      }
+    for (int q = 0; q < NP; ++q)
+      if (act(q)) v[i * NP + q] = load4_sys(d.res[me], (int64_t)slice(i) * SL + cb + koff(q));
+#pragma unroll
+  for (int i = 1; i < MAXW; ++i)
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      if (i >= W || !act(q)) continue;
+      const int64_t idx = (int64_t)slice(i) * SL + cb + koff(q);
+      store4_bounded(buf, idx, n, v[i * NP + q]);
+      if (ADAM && !skip) adam_from(i * NP + q, idx, v[i * NP + q]);
     }
-  }
   if (stat && tid == 0) stat[2] += 1;
 }
 
@@ -454,12 +480,16 @@ static int p2p_launch(void* handle, float* buf, int64_t n, void* stream, const A
     hipLaunchKernelGGL(adam_only_kernel, dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, buf, n, *ad, guard_idx);
   } else {
     h->epoch += 1;
-    const bool one_pass = h->d.CL <= (int64_t)P2P_THREADS * 4 && !opt_get("MFM_P2P_GENERIC");
-    if (one_pass && ad)
-      hipLaunchKernelGGL(p2p_allreduce_1pass_kernel<true>, dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, h->d, buf, n, h->epoch, h->timeout_ticks, *ad, guard_idx);
-    else if (one_pass)
-      hipLaunchKernelGGL(p2p_allreduce_1pass_kernel<false>, dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, h->d, buf, n, h->epoch, h->timeout_ticks,
-                         AdamArgs{}, (int64_t)-1);
+    // chunks of one / two workgroup passes with ranks x passes <= 8: the flat kernel (every round trip batched)
+    const int np = h->d.CL <= (int64_t)P2P_THREADS * 4 ? 1 : (h->d.CL <= (int64_t)2 * P2P_THREADS * 4 ? 2 : 0);
+    const int flat = opt_get("MFM_P2P_GENERIC") ? 0 : (np == 1 ? 1 : (np == 2 && h->d.W <= 4 ? 2 : 0));
+#define P2P_FLAT_LAUNCH(A, NPV, MW, ADV, GI) \
+    hipLaunchKernelGGL((p2p_allreduce_flat_kernel<A, NPV, MW>), dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, h->d, buf, n, h->epoch, h->timeout_ticks, ADV, GI)
+    if (flat == 1 && ad) P2P_FLAT_LAUNCH(true, 1, 8, *ad, guard_idx);
+    else if (flat == 1) P2P_FLAT_LAUNCH(false, 1, 8, AdamArgs{}, (int64_t)-1);
+    else if (flat == 2 && ad) P2P_FLAT_LAUNCH(true, 2, 4, *ad, guard_idx);
+    else if (flat == 2) P2P_FLAT_LAUNCH(false, 2, 4, AdamArgs{}, (int64_t)-1);
+#undef P2P_FLAT_LAUNCH
     else if (ad)
       hipLaunchKernelGGL(p2p_allreduce_kernel<true>, dim3(P2P_WGS), dim3(P2P_THREADS), 0, st, h->d, buf, n, h->epoch, h->timeout_ticks, *ad, guard_idx);
     else
