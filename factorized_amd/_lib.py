@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmfm_hip.so")
+# (MFM_LIB_PATH: another build of the same library -- instrumented debug builds, scripts/seq_step_timeline.py)
+LIB_PATH = os.environ.get("MFM_LIB_PATH") or os.path.join(_HERE, "libmfm_hip.so")
 
 MFM_KLEF_NPARAM = 78
 MFM_LOSS_SLOTS = 8

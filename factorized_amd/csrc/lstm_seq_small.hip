@@ -42,6 +42,30 @@ __device__ __forceinline__ void sync_stores() {
   __syncthreads();
 }
 
+// Debug build only (make MFM_EXTRA_FLAGS=-DMFM_SEQ_STAMP=k, scripts/seq_step_timeline.sh): a clock on the links of the one-row
+// forward step.  Every wave takes the shader clock at the top of each time step (P0) and at ONE further point k of the step --
+// 1: h_{t-1} has arrived from LDS, 2: the recurrent FMAs are issued, 3: gates / c / h are computed, 4: the step's LDS writes
+// are acknowledged (in front of the barrier), 5: the barrier released this wave, 6: the next step's top (the whole period) --
+// and sums Pk - P0 over the steps t >= 1; at the end lane 0 of wave w of workgroup 0 leaves the average in cs[T-1][0][w]
+// (the build is for timing, its last cell-state row is garbage).  One point per build: two s_memtime per step keep the
+// perturbation at a few cycles (profiles/r05_seq_step_timeline.txt).
+#ifndef MFM_SEQ_STAMP
+#define MFM_SEQ_STAMP 0
+#endif
+// 1: a step's record (forward) / dA (backward) is written to HBM during the NEXT phase of the loop, its LDS read batched with the
+// product's operand reads; 0 (default): read + store right behind the barrier (rounds 1-4).  Built on the timeline's "12 % of a
+// step between the barrier and the next step's top" and MEASURED SLOWER (whole step 0.1664 vs 0.1605 ms): the step is bound by
+// VALU issue between the arrival of h_{t-1} and the last wave's gate math; the window behind the barrier is idle issue time, and
+// work moved out of it into the product costs what it issues.  profiles/r05_seq_step_timeline.txt
+#ifndef MFM_SEQ_LATE_WRITEOUT
+#define MFM_SEQ_LATE_WRITEOUT 0
+#endif
+__device__ __forceinline__ unsigned long long seq_clock() {
+  unsigned long long t;
+  asm volatile("s_memtime %0" : "=s"(t) :: "memory");
+  return t;
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
@@ -319,12 +343,32 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
 
   float c = 0.0f;
   int cur = 0;
+  bool pend = false;          // the previous step's record waits in obuf (uniform)
+#if MFM_SEQ_STAMP
+  unsigned long long st_sum = 0, st_prev = 0;
+#endif
   auto step = [&](const int t) {
     const int par = t & 1;
+#if MFM_SEQ_STAMP
+    const unsigned long long st0 = seq_clock();
+    unsigned long long st1 = st0;
+    if (MFM_SEQ_STAMP == 6 && t >= 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_sum += st0 - st_prev; }
+    st_prev = st0;
+#endif
     float gx0 = gxb[0], gx1 = gxb[1];
     if (!dec) {
       const float* xb = xbuf + par * (4 * HKB * R) + my_o;
       gx0 = xb[0]; gx1 = xb[HKB * R];
+    }
+    // the record of step t - 1 (dropped into obuf in front of the last barrier) leaves for HBM DURING this step: its LDS read is
+    // requested together with h_{t-1}, the stores go out behind the product (round 5: written out right behind the barrier, the
+    // read's round trip sat between the barrier and the next step's h reads -- 12 % of a step, profiles/r05_seq_step_timeline.txt)
+    float rprev[NOS];
+#pragma unroll
+    for (int i = 0; i < NOS; ++i) rprev[i] = 0.0f;
+    if (MFM_SEQ_LATE_WRITEOUT && pend) {
+#pragma unroll
+      for (int i = 0; i < NOS; ++i) rprev[i] = obuf[(par ^ 1) * (6 * HKB * R) + ol[i]];
     }
     float acc[2][R];
 #pragma unroll
@@ -351,6 +395,10 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
         f32x4 hv[NM];
 #pragma unroll
         for (int m = 0; m < NM; ++m) hv[m] = *reinterpret_cast<const f32x4*>(hb + 16 * m);
+#if MFM_SEQ_STAMP == 1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        st1 = seq_clock();
+#endif
 #pragma unroll
         for (int m = 0; m < NM; ++m)
 #pragma unroll
@@ -358,6 +406,9 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
             acc[0][0] = fmaf(w[0][4 * m + i], hv[m][i], acc[0][0]);
             acc[1][0] = fmaf(w[1][4 * m + i], hv[m][i], acc[1][0]);
           }
+#if MFM_SEQ_STAMP == 2
+        asm volatile("s_memtime %0" : "=s"(st1), "+v"(acc[0][0]), "+v"(acc[1][0]) :: "memory");
+#endif
       }
     } else if (dec || t > 0) {
       const float* hb = hbuf + cur * (HK * R) + q * R;
@@ -375,6 +426,14 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
           for (int r = 0; r < R; ++r) acc[gl][r] = fmaf(w[gl][j], hv.v[r], acc[gl][r]);
       }
     }
+    if (MFM_SEQ_LATE_WRITEOUT && pend) {
+#pragma unroll
+      for (int i = 0; i < NOS; ++i) {
+        if (ook[i]) *op[i] = rprev[i];
+        op[i] += ostr[i];
+      }
+    }
+    pend = true;
     // x-projections of step t+2 (clamped re-read at the tail), issued well ahead of their LDS hand-over
     float xn[NXL];
 #pragma unroll
@@ -413,7 +472,10 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
     const float p0 = dpp_xor4(a0), p1 = dpp_xor4(a1);
     const float gf = gp ? p1 : a1, go = gp ? a1 : p1;
     c = fmaf(gf, c, a0 * p0);          // explicit: every instantiation must round the same way
-    const float hv = go * act_tanh(c);
+    float hv = go * act_tanh(c);
+#if MFM_SEQ_STAMP == 3
+    asm volatile("s_memtime %0" : "=s"(st1), "+v"(hv), "+v"(c) :: "memory");
+#endif
     if (uact && rowner) {
       float* ob = obuf + par * (6 * HKB * R) + my_o;
       ob[0] = a0; ob[HKB * R] = a1;
@@ -428,28 +490,61 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
       for (int i = 0; i < NXL; ++i)
         if (xok[i]) xbuf[(par ^ 1) * (4 * HKB * R) + xl[i]] = xpf[i];
     }
+#if MFM_SEQ_STAMP == 4
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    st1 = seq_clock();
+#endif
     lds_barrier();
+#if MFM_SEQ_STAMP == 5
+    st1 = seq_clock();
+#endif
+#if MFM_SEQ_STAMP
+    if (MFM_SEQ_STAMP != 6 && t >= 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_sum += st1 - st0; }
+#endif
+    if (!MFM_SEQ_LATE_WRITEOUT) {
 #pragma unroll
-    for (int i = 0; i < NOS; ++i) {
-      if (ook[i]) *op[i] = obuf[par * (6 * HKB * R) + ol[i]];
-      op[i] += ostr[i];
+      for (int i = 0; i < NOS; ++i) {
+        if (ook[i]) *op[i] = obuf[par * (6 * HKB * R) + ol[i]];
+        op[i] += ostr[i];
+      }
+      pend = false;
     }
 #pragma unroll
     for (int i = 0; i < NXL; ++i) xpf[i] = xn[i];
     cur ^= 1;
   };
+  // the record of the last step taken (still in obuf) -> HBM
+  auto flush = [&](const int t_last) {
+    if (!pend) return;
+#pragma unroll
+    for (int i = 0; i < NOS; ++i) {
+      if (ook[i]) *op[i] = obuf[(t_last & 1) * (6 * HKB * R) + ol[i]];
+      op[i] += ostr[i];
+    }
+    pend = false;
+  };
   // The decoder's step 0 (W_ih on the embedding) is peeled so that the weight reload sits between
   // two clean loops instead of inside one (keeps its temporaries out of the hot loop's registers).
   if (dec) {
     step(0);
+    flush(0);                          // (the record of step 0 lives in the panel about to be refilled)
     if (T > 1) {
-      __syncthreads();                 // the record of step 0 lives in the panel about to be refilled
+      __syncthreads();
       load_w(2);                       // steps >= 1 feed h back as the input: W_ih + W_hh
       for (int t = 1; t < T; ++t) step(t);
+      flush(T - 1);
     }
   } else {
     for (int t = 0; t < T; ++t) step(t);
+    flush(T - 1);
   }
+#if MFM_SEQ_STAMP
+  __syncthreads();
+  if (blockIdx.x == 0 && (tid & 63) == 0 && T > 2) {
+    const int nsteps = (MFM_SEQ_STAMP == 6) ? T - 2 : T - 1;
+    p_cs[(int64_t)(T - 1) * sstep + (tid >> 6)] = (float)((double)st_sum / (double)nsteps);
+  }
+#endif
 }
 
 // --------------------------------------------------------------------------------- backward
@@ -658,12 +753,20 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
     if constexpr (PUB) {
       if (tid == 0 && t + 1 < T) dwr_stamp(stamp + (t + 1) * DWR_ROWS, epoch);
     }
+    // dA_t leaves for HBM from registers BEHIND the product: its LDS read is requested together with the product's operands
+    // (round 5: read + store right behind the barrier put one LDS round trip in front of the product's reads)
+    float wr[NST];
 #pragma unroll
-    for (int i = 0; i < NST; ++i) {
-      if constexpr (PUB) { if (sok[i]) __hip_atomic_store((float*)sp[i], db[sl[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-      else { if (sok[i]) *sp[i] = db[sl[i]]; }
-      sp[i] -= gstep;
-    }
+    for (int i = 0; i < NST; ++i) wr[i] = db[sl[i]];
+    auto write_da = [&]() {
+#pragma unroll
+      for (int i = 0; i < NST; ++i) {
+        if constexpr (PUB) { if (sok[i]) __hip_atomic_store((float*)sp[i], wr[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else { if (sok[i]) *sp[i] = wr[i]; }
+        sp[i] -= gstep;
+      }
+    };
+    if (!MFM_SEQ_LATE_WRITEOUT) write_da();
 #pragma unroll
     for (int i = 0; i < NLD; ++i) pf[i] = pn[i];
     if (matvec && ((t > 0) || dec)) {
@@ -721,6 +824,7 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
       const float sa = sel_row<R>(aa, mrc), sb2 = sel_row<R>(ab, mrc);
       dh_rec = (q & 4) ? sb2 : sa;
     }
+    if (MFM_SEQ_LATE_WRITEOUT) write_da();
     cur ^= 1;
   };
   for (int t = T - 1; t >= 1; --t) step(t);

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Builds the instrumented variants of libmfm_hip.so for scripts/seq_step_timeline.py: lstm_seq_small.hip compiled with
+# -DMFM_SEQ_STAMP=k (k = 1..6, one stamp point per build), linked against the objects of the normal build.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+ROOT="$(dirname "$HERE")"
+C="$ROOT/factorized_amd/csrc"
+OUT="$ROOT/scripts/tmp/stamp"
+mkdir -p "$OUT"
+bash "$C/build.sh" >/dev/null
+OBJS=$(ls "$C"/build/*.o | grep -v lstm_seq_small.o)
+for k in 1 2 3 4 5 6; do
+  (
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$ROOT/include" -I"$C" -DMFM_EXPERIMENTAL=0 -fno-slp-vectorize \
+      -DMFM_SEQ_STAMP=$k -c "$C/lstm_seq_small.hip" -o "$OUT/lstm_seq_small_$k.o"
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS "$OUT/lstm_seq_small_$k.o" -o "$OUT/libmfm_hip_stamp$k.so"
+    rm -f "$OUT/lstm_seq_small_$k.o"
+    echo "built stamp $k"
+  ) &
+done
+wait
