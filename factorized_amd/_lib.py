@@ -81,7 +81,6 @@ class PlanConfig(C.Structure):
 
 _SIGS = {
     "mfm_abi_version": (C.c_int, []),
-    "mfm_has_experimental": (C.c_int, []),
     "mfm_last_error": (C.c_char_p, []),
     "mfm_device_cus": (C.c_int, []),
     "mfm_gemm_grouped_f32": (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.c_void_p]),

@@ -304,7 +304,6 @@ int fill_launch(float* p, int64_t n, float val, hipStream_t stream) {
 }  // namespace mfm
 
 extern "C" int mfm_abi_version(void) { return MFM_ABI_VERSION; }
-extern "C" int mfm_has_experimental(void) { return MFM_EXPERIMENTAL; }
 extern "C" const char* mfm_last_error(void) { return mfm::g_err; }
 
 extern "C" int mfm_mse_fwd_bwd(const float* xhat, const float* x, int64_t ldx, int64_t rows, int32_t d,

@@ -110,26 +110,6 @@ int dec_fc1_large_supported(const DecFc1LargeItem& I);
 size_t dec_fc1_large_wimg_bytes(int d);
 int dec_fc1_large_launch(DecFc1LargeLaunch& L, hipStream_t stream);
 
-// dw_onepass.hip -- all weight gradients of one LSTM as ONE product over the rows (large T*B)
-#define MFM_DW_MAXI 12
-struct DwItem {
-  const float* dA; int ldA, M, Hp, h;          // gate-gradient buffer [rows, ldA]; M = 4 Hp columns walked; column m = gate * Hp + unit
-  const float* x; int64_t ldx; int dx;          // input rows (encoders; null / 0 for decoders)
-  const float* hs; int ldh, hN, shift;          // saved hidden states [rows, ldh]; row r pairs with hs[r - shift] (zero for r < shift)
-  float* c_x; int ldc_x;                        // dW_ih [4h, dx]
-  float* c_h; float* c_h2; int ldc_h;           // dW_hh [4h, hN] (and the decoders' dW_ih)
-  float* c_b; float* c_b2;                      // db_ih, db_hh [4h]
-  int tile_begin, m_tiles, splits, rows_per_split;     // filled by dw_onepass_launch
-};
-struct DwLaunch { DwItem it[MFM_DW_MAXI]; int n_items, rows; };
-#if MFM_EXPERIMENTAL
-int dw_onepass_supported(const DwItem& I, int precision);
-int dw_onepass_launch(DwLaunch& L, int precision, hipStream_t stream);
-#else
-static inline int dw_onepass_supported(const DwItem&, int) { return 0; }
-static inline int dw_onepass_launch(DwLaunch&, int, hipStream_t) { return MFM_ERR_UNSUPPORTED; }
-#endif
-
 // dw_bf16.hip -- bf16-RESIDENT plans: every sum over the T*B rows that feeds an LSTM's (or a decoder fc1's) weight gradient
 // as one product C[M, N] += A^T [seg0 | seg1] per item, operands streamed by LDS-DMA and read with transposing LDS reads
 #define MFM_DWB_MAXI 12
@@ -177,32 +157,6 @@ int mfn_dcs_scatter_launch(const MfnCs& c, const float* dcs, hipStream_t stream)
 int mfn_softmax_fwd_launch(float* att, const float* cstar, float* attended, int64_t rows, int n, hipStream_t stream);
 int mfn_softmax_bwd_launch(const float* datt, const float* att, const float* cstar, float* dlog, float* dcs, int64_t rows,
                            int n, hipStream_t stream);
-// mfn_att_fused.hip -- the whole attention block of the MFN per 16-row tile, one launch per direction (fp32, small T*B)
-struct MfnAttFused {
-  const float* cs[3]; float* dcx[3]; int h[3], Hp[3], off[3];         // the three MFN LSTMs' cell states / their gradients
-  int tot, A2, T, B, nn1, nn2, g1, g2, M;
-  const float *w_att1_1, *b_att1_1, *w_att1_2, *b_att1_2, *w_att2_1, *b_att2_1, *w_att2_2, *b_att2_2;
-  const float *w_gam1, *b_gam1, *w_gam2, *b_gam2;                      // gamma_n_fc1 [g_n, A2 + M]: the first A2 columns
-  float *cstar, *h1, *m1, *att, *attended, *h2, *m2, *a1, *a2, *chat;  // saved by the forward
-  const float *dchat, *du1, *du2;                                      // backward inputs (memory recurrence BPTT)
-  float *dh2, *dlog, *dh1;                                             // backward outputs for the weight-gradient GEMMs
-  float p1, p2; int train; unsigned long long seed;
-};
-// MFM_EXPERIMENTAL (Makefile: `make MFM_EXPERIMENTAL=1`): the two kernels that were built, parity-tested and measured SLOWER than
-// what they would replace -- mfn_att_fused.hip (profiles/r02_mfn_att_fused.txt) and dw_onepass.hip (r02_dw_onepass.txt) -- are
-// part of the library only in an experimental build; the default build carries neither their code nor their switches.
-#ifndef MFM_EXPERIMENTAL
-#define MFM_EXPERIMENTAL 0
-#endif
-#if MFM_EXPERIMENTAL
-bool mfn_att_fused_supported(const MfnAttFused& L);
-int mfn_att_fused_fwd_launch(const MfnAttFused& L, hipStream_t stream);
-int mfn_att_fused_bwd_launch(const MfnAttFused& L, hipStream_t stream);   // dcx must have been cleared (it is added to)
-#else
-static inline bool mfn_att_fused_supported(const MfnAttFused&) { return false; }
-static inline int mfn_att_fused_fwd_launch(const MfnAttFused&, hipStream_t) { return MFM_ERR_UNSUPPORTED; }
-static inline int mfn_att_fused_bwd_launch(const MfnAttFused&, hipStream_t) { return MFM_ERR_UNSUPPORTED; }
-#endif
 // mfn_mem.hip -- the heads on mfn_last = [h_l, h_a, h_v](T-1) | mem_T (mu_y and, variant 1, logvar_y) folded into the
 // memory recurrence launches: forward as the kernel's tail (mem_T is in its LDS), backward as its head (d mem_T and d h_T
 // from d [mu_y | logvar_y]); two ~6 us GEMM launches less per step.  The heads' weight gradients stay in the tail GEMM.

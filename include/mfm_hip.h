@@ -42,10 +42,6 @@ extern "C" {
 #define MFM_ABI_VERSION 4
 
 int mfm_abi_version(void);
-/* 1 when the library was built with MFM_EXPERIMENTAL=1: it then also carries the two kernels that measured slower than what
- * they would replace (one-launch MFN attention block, fp32 / bf16 one-pass dW over fp32 buffers) and honours their switches
- * MFM_MFN_FUSED / MFM_DW_ONEPASS_MINROWS; the default build ignores those switches. */
-int mfm_has_experimental(void);
 const char* mfm_last_error(void);
 /* number of CUs of the current device (for grid heuristics / reporting). */
 int mfm_device_cus(void);

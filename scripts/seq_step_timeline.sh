@@ -11,7 +11,7 @@ bash "$C/build.sh" >/dev/null
 OBJS=$(ls "$C"/build/*.o | grep -v lstm_seq_small.o)
 for k in 1 2 3 4 5 6; do
   (
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$ROOT/include" -I"$C" -DMFM_EXPERIMENTAL=0 -fno-slp-vectorize \
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$ROOT/include" -I"$C" -fno-slp-vectorize \
       -DMFM_SEQ_STAMP=$k -c "$C/lstm_seq_small.hip" -o "$OUT/lstm_seq_small_$k.o"
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS "$OUT/lstm_seq_small_$k.o" -o "$OUT/libmfm_hip_stamp$k.so"
     rm -f "$OUT/lstm_seq_small_$k.o"

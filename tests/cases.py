@@ -77,11 +77,3 @@ def report(key, value):
                 f.write(json.dumps({"key": key, "value": float(value)}) + "\n")
         except OSError:
             pass
-
-
-def need_experimental():
-    """skip unless the library carries the measured-slower kernels (make MFM_EXPERIMENTAL=1; default builds leave them out)"""
-    import pytest
-    from factorized_amd import _lib
-    if not _lib.lib().mfm_has_experimental():
-        pytest.skip("kernel only in MFM_EXPERIMENTAL=1 builds of libmfm_hip.so")

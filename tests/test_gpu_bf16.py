@@ -538,7 +538,6 @@ def seq_policy(request, monkeypatch):
     if "panel" in request.param:
         monkeypatch.setenv("MFM_PROJ16", "0")
         monkeypatch.setenv("MFM_PANEL_MINROWS", "1")    # gemm_panel_kernel<true> for the input projections
-        monkeypatch.setenv("MFM_DW_ONEPASS_MINROWS", "1")   # and dw_onepass_kernel<true> for the LSTM weight gradients
         bm = request.param.split("panel")[1]                # forced panel height (default: the launcher's pick, 128 here)
         if bm:
             monkeypatch.setenv("MFM_PANEL_BM", bm)
@@ -547,7 +546,6 @@ def seq_policy(request, monkeypatch):
     else:
         monkeypatch.delenv("MFM_PANEL_BM", raising=False)
         monkeypatch.delenv("MFM_PANEL_MINROWS", raising=False)
-        monkeypatch.delenv("MFM_DW_ONEPASS_MINROWS", raising=False)
     return request.param
 
 

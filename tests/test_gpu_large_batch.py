@@ -11,7 +11,6 @@ B > 512 ran on kernels no oracle comparison reached).  Kernels named here, by th
                                                        MFM_LATENT_CHAINS=0 -> one per row, MFM_LATENT_PRE=1 -> <true>
   dec_fc1_kernel                                       decoder fc1 + squared error + dH in one launch: fp32, T*B <= 5120 (default at
                                                        the golden sizes; MFM_FC1_FUSED=0 -> the two GEMM launches)
-  dw_onepass_kernel<false|true>                        LSTM weight gradients, one pass over dA: opt-in, MFM_DW_ONEPASS_MINROWS=1
   gemm_tn_kernel<160>                                  all weight gradients as (tile, 160-row chunk) workgroups: fp32, T*B <= 1024
                                                        (MFM_GEMM_TN_MAXROWS; MFM_GEMM_TN=0 -> grouped GEMM)
   gemm_panel_kernel<false|true, wave grid>             row-panel projection GEMM: T*B >= 2 rounds of panels (B >= 1639 fp32
@@ -131,7 +130,7 @@ def test_you_shape_large_batch_matches_oracle(monkeypatch):
     _compare(configs.you_configs(dropout=False), 640, 50, loss_kind="ce", adam_steps=2, tag="you")
 
 
-@pytest.mark.parametrize("variant", ["staged", "fr2", "fr4", "panel", "panel80", "staged+fr2+mfma", "fc1gemm", "dwonepass",
+@pytest.mark.parametrize("variant", ["staged", "fr2", "fr4", "panel", "panel80", "staged+fr2+mfma", "fc1gemm",
                                      "nochains", "latpre", "nofold", "dwgemm", "dwtn", "dwf32", "staged+split0", "staged+quad"])
 @pytest.mark.parametrize("name", cases.KLEF_CASES)
 def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
@@ -175,11 +174,6 @@ def test_forced_large_batch_kernels_on_golden_cases(name, variant, monkeypatch):
         monkeypatch.setenv("MFM_LATENT_CHAINS", "0")
     if "latpre" in variant:
         monkeypatch.setenv("MFM_LATENT_PRE", "1")
-    if "dwonepass" in variant:
-        cases.need_experimental()
-        monkeypatch.setenv("MFM_DW_ONEPASS_MINROWS", "1")   # dw_onepass_kernel<false>: the LSTM weight gradients in one pass
-    else:                                                   # over dA (opt-in: measured slower than the GEMMs)
-        monkeypatch.delenv("MFM_DW_ONEPASS_MINROWS", raising=False)
     # weight gradients: gemm_tn_kernel (row chunks, all operands requested at once) is the default up to T*B = 1024;
     # "dwtn" forces it at every size (T*B up to 4580 here: 29 chunks), "dwgemm" the grouped GEMM at every size
     for k in ("MFM_GEMM_TN", "MFM_GEMM_TN_MAXROWS"):

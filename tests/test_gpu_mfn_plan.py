@@ -43,12 +43,12 @@ def _oracle(variant, cfgs, w, gauss=None):
     return m
 
 
-@pytest.fixture(params=["att-fused", "att-rows", "att-gemm", "heads-gemm"], autouse=True)
+@pytest.fixture(params=["att-rows", "att-gemm", "heads-gemm"], autouse=True)
 def att_path(request, monkeypatch):
     """Every test of this file runs on every form of the MFN attention block: the row-block forward launches (lin_rows_kernel,
     the fp32 default up to T*B = 5120, forced here for any row count: "att-rows"), the grouped GEMMs + row kernels
-    ("att-gemm": MFM_LIN_ROWS=0) and mfn_att_fwd_kernel / mfn_att_bwd_kernel (one launch per direction with every
-    intermediate in LDS; opt-in with MFM_MFN_FUSED=1 because it measured slower, forced here for any row count)."""
+    ("att-gemm": MFM_LIN_ROWS=0).  (A one-launch-per-direction form with every intermediate in LDS was built in round 2,
+    measured slower and removed in round 5: profiles/r02_mfn_att_fused.txt.)"""
     if request.param == "att-rows":
         monkeypatch.setenv("MFM_LIN_ROWS", "1")
         monkeypatch.setenv("MFM_LIN_ROWS_MAXROWS", "100000000")
@@ -58,12 +58,6 @@ def att_path(request, monkeypatch):
     # "heads-gemm": the heads on [h_T | mem_T] as grouped GEMMs (MFM_MFN_HEADS_FOLD=0) instead of inside the memory
     # recurrence launches (the fp32 default)
     monkeypatch.delenv("MFM_MFN_HEADS_FOLD", raising=False)
-    if request.param == "att-fused":
-        cases.need_experimental()
-        monkeypatch.setenv("MFM_MFN_FUSED", "1")
-        monkeypatch.setenv("MFM_MFN_FUSED_MAXROWS", "100000000")
-    else:
-        monkeypatch.setenv("MFM_MFN_FUSED", "0")
     if request.param == "heads-gemm":
         monkeypatch.setenv("MFM_MFN_HEADS_FOLD", "0")
     return request.param
