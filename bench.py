@@ -264,7 +264,7 @@ def main():
         # command (scripts/profile_round.sh -> profiles/r01_traffic.json); only valid for the workload it
         # was measured on, otherwise null.
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r04_traffic_B32.json" if args.dtype == "fp32" else "r04_traffic_B32_bf16.json")
+        tpath = os.path.join(ROOT, "profiles", "r05_traffic_B32.json" if args.dtype == "fp32" else "r05_traffic_B32_bf16.json")
         if os.path.exists(tpath) and args.shape == "mosi" and B == 32 and T == 20 and args.model == "kl_ef":
             try:
                 traffic = json.load(open(tpath)).get(dom, {}).get("total_bytes")
