@@ -411,6 +411,7 @@ class _FusedEngineMixin:
         state["_engine"] = None
         state["_grad_flat"] = None
         state["_flat_leaf"] = None
+        state["_guarded"] = False          # (a weak reference; the optimizer of the restored model marks it again)
         return state
 
     def __setstate__(self, state):
@@ -427,7 +428,10 @@ class _FusedEngineMixin:
         self._register_params()
 
     def _handover_ok(self):
-        return bool(self._guarded) and not os.environ.get("MFM_MODULE_NO_HANDOVER")
+        g = self._guarded
+        if g is not False and g is not True:          # a weak reference to the guard-aware optimizer that owns the parameters:
+            g = g() is not None                       # gone (replaced by another optimizer) -> separate launches again
+        return bool(g) and not os.environ.get("MFM_MODULE_NO_HANDOVER")
 
     def _fast_ok(self):
         """The flat-gradient path bypasses autograd for the parameters: every tensor gets a gradient view and the fused optimizer

@@ -77,7 +77,8 @@ class Adam(torch.optim.Optimizer):
             seen.add(id(m))
             if all(id(q) in ids for q in m._plist):
                 out.append(m)
-                m._guarded = True
+                import weakref as _wr
+                m._guarded = _wr.ref(self)
         self._fm_cache[id(group)] = (key, out, [weakref.ref(m) for m in out])
         return out
 

@@ -283,3 +283,23 @@ def test_stale_step_raises():
         loss.backward()
     with pytest.raises(RuntimeError):
         loss.item()
+
+
+def test_handover_permission_follows_the_guard_aware_optimizer():
+    """only an optimizer that honours the gradient guard lets a model use its in-launch hand-overs (factorized_amd.optim.Adam
+    marks the models it owns with a weak reference; gone or replaced -> separate launches again; a copy starts unmarked)"""
+    import copy
+    import gc
+    from factorized_amd import configs
+    from factorized_amd.mfm_model import MFM_KL_EF
+    import factorized_amd.optim as optim
+    m = MFM_KL_EF(*configs.canonical_configs(dropout=False))
+    assert not m._handover_ok()
+    o = optim.Adam(m.parameters())                 # (before .to(device), like the reference: mfm_mosi.py:403 / :414)
+    assert m._handover_ok()
+    assert not copy.deepcopy(m)._handover_ok()
+    del o
+    gc.collect()
+    assert not m._handover_ok()
+    o2 = torch.optim.Adam(m.parameters())
+    assert not m._handover_ok() and o2 is not None
