@@ -35,7 +35,7 @@ python bench.py --steps 400 --warmup 40 $NB > $O/bench_B32_400.json 2>/dev/null
 python bench.py --dtype bf16 --steps 400 --warmup 40 $NB > $O/bench_B32_bf16.json 2>/dev/null
 for m in kl mmd; do python bench.py --model $m --steps 400 --warmup 40 $NB > $O/bench_B32_$m.json 2>/dev/null; done
 python bench.py --steps 400 --warmup 40 --breakdown $NB 2> $O/breakdown_B32.txt > /dev/null
-python bench.py --shape you --steps 200 --warmup 20 $NB > $O/bench_you_B32_T50.json 2>/dev/null
+python bench.py --shape you --seq 50 --steps 200 --warmup 20 $NB > $O/bench_you_B32_T50.json 2>/dev/null
 python bench.py --shape mosei --seq 50 --batch 1024 --dtype bf16 --steps 30 --warmup 5 $NB > $O/bench_mosei_B1024_T50_bf16.json 2>/dev/null
 python bench.py --dtype bf16 --batch 2048 --steps 50 --warmup 10 $NB > $O/bench_B2048_bf16.json 2>/dev/null
 for B in 8 16 32 48 64 192 512 2048; do python bench.py --batch $B --dtype $([ $B -ge 192 ] && echo bf16 || echo fp32) --steps $([ $B -ge 192 ] && echo 40 || echo 200) --warmup 10 $NB 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('B=%d %s  %.4f ms  %.0f samples/s' % ($B, d['dtype'], d['ms_per_step'], d['value']))"; done > $O/batch_sweep.txt
