@@ -164,6 +164,11 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
     }
     __syncthreads();
   }
+  // The block is sized for the LARGEST LSTM of the launch; the waves beyond this LSTM's Hp / 16 leave here.  A wave
+  // that has ended no longer counts at s_barrier, and the panel columns they would have covered (k in [Hp, HKP))
+  // keep the zeros written above.  (They used to run the gate math on zeros: 47 % of the forward launch's waves at
+  // the MOSI shapes -- VALU and issue slots taken from the waves that carry rows.)
+  if (__builtin_amdgcn_readfirstlane((int)active) == 0) return;
 
   // pointers and slab geometry are formed once (a descriptor field read inside the loop is re-fetched from the
   // kernel-argument segment after every store: the compiler cannot prove the stores do not alias it)
@@ -206,7 +211,7 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = mma_bf16(w[g][kb], hv[kb], acc[g]);
     }
-    {   // every wave runs this block (idle waves compute on zeros and their stores fall outside the slabs)
+    {
       f32x4 gi, gf, gg, go, cv, hv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -307,6 +312,7 @@ __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, cons
 
   for (int idx = tid; idx < 2 * 16 * LROW; idx += blockDim.x) lds[idx] = (__bf16)0.0f;
   __syncthreads();
+  if (__builtin_amdgcn_readfirstlane((int)active) == 0) return;       // idle waves leave (see the forward body)
 
   float* const gates_p = d.gates;
   const float* const cs_p = d.cs;
