@@ -98,7 +98,7 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
   const int u0 = wave * 16;
   const int b = tile * 16 + bi;
   const bool bvalid = active && (b < B);
-  const bool dec = (KIND != 0) && (d.is_dec != 0);
+  constexpr bool dec = KIND != 0;          // a launch holds LSTMs of one kind (seq_bf16_launch)
 
   bf16x8 w[4][KB];
   // MODE 0: W_hh (encoder)   1: W_ih (decoder step 0)   2: W_ih + W_hh (decoder steps >= 1; one rounding)
@@ -181,27 +181,31 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
   const int voff_g = bvalid ? (b * 4 * Hp + u0 + 4 * q) * ES : slab_g;         // idle lanes: out of range
   const int voff_h = bvalid ? (b * Hp + u0 + 4 * q) * 4 : slab_h;
   const int voff_hs = bvalid ? (b * Hp + u0 + 4 * q) * ES : slab_hs;
-  const int gx_bytes = dec ? 0 : slab_g;                                      // decoders have no x-projection to fetch
-  f32x4 gx[4];
-  {
-    const __amdgpu_buffer_rsrc_t r0 = slabv<ST>(gates_p, 0, gx_bytes);
+  f32x4 gx[4] = {bias[0], bias[1], bias[2], bias[3]};      // decoders: no x-projection, the accumulators start from the bias
+  if constexpr (KIND == 0) {
+    const __amdgpu_buffer_rsrc_t r0 = slabv<ST>(gates_p, 0, slab_g);
 #pragma unroll
     for (int g = 0; g < 4; ++g) gx[g] = bldv<ST>(r0, voff_g + g * Hp * ES);
   }
 
+  // The time loop has NO branch and every wave of it is active (see the early return above), and it is entered after
+  // a peeled first step, so that the pending-memory state on the loop's entry edge equals the one on its back edge:
+  // [4 prefetch loads, 6 younger stores].  With the prefetch still the YOUNGEST operation on the entry edge (no peel)
+  // the compiler's merged state makes every step wait vmcnt(0) for its prefetch, i.e. for the acknowledgement of the
+  // previous step's stores -- 2.5-3.4 us per step at B = 2048 where the arithmetic needs ~1.
   float c[4] = {0.f, 0.f, 0.f, 0.f};
   f32x4 h_keep = f32x4{0.f, 0.f, 0.f, 0.f};
   int cur = 0;
-  auto step = [&](const int t) {
+  auto step = [&](const int t, auto rec) {
     f32x4 acc[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = dec ? bias[g] : gx[g];
-    {   // x-projection of step t+1 (the last step re-reads its own slab: unused)
-      const __amdgpu_buffer_rsrc_t rn = slabv<ST>(gates_p, (int64_t)min(t + 1, T - 1) * B * row4, gx_bytes);
+    for (int g = 0; g < 4; ++g) acc[g] = gx[g];
+    if constexpr (KIND == 0) {   // x-projection of step t+1 (the last step re-reads its own slab: unused)
+      const __amdgpu_buffer_rsrc_t rn = slabv<ST>(gates_p, (int64_t)min(t + 1, T - 1) * B * row4, slab_g);
 #pragma unroll
       for (int g = 0; g < 4; ++g) gx[g] = bldv<ST>(rn, voff_g + g * Hp * ES);
     }
-    if (active && (dec || t > 0)) {
+    if constexpr (decltype(rec)::value) {
       const __bf16* hb = lds + cur * (16 * LROW) + bi * LROW + 8 * q;
       bf16x8 hv[KB];
 #pragma unroll
@@ -232,7 +236,7 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
         bstv<ST>(rh, voff_hs, hv);
         h_keep = hv;
       }
-      if (u0 + 4 * q < HKP) {
+      {
         const f32x4 hz = (b < B) ? hv : f32x4{0.f, 0.f, 0.f, 0.f};
         __bf16* hn = lds + (cur ^ 1) * (16 * LROW) + bi * LROW + u0 + 4 * q;
         *reinterpret_cast<bf16x4*>(hn) = __builtin_convertvector(hz, bf16x4);
@@ -241,15 +245,24 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
     lds_barrier();
     cur ^= 1;
   };
-  int t0 = 0;
-  if (KIND != 0 && dec) {
-    step(0);
-    if (T > 1) {                                            // W_ih (step 0) -> W_ih + W_hh (steps >= 1)
+  // the weights are in registers before the loop: a load still pending on the entry edge is waited for inside the
+  // loop on every step, with a count that also covers the previous step's stores
+  auto touch_w = [&]() {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(w[g][kb]));
+  };
+  if constexpr (KIND != 0) {
+    step(0, std::true_type{});                               // W_ih x h_init
+    if (T > 1) {                                             // W_ih (step 0) -> W_ih + W_hh (steps >= 1)
       if (pk) load_packed(0); else load_w(std::integral_constant<int, 2>{});
     }
-    t0 = 1;
+  } else {
+    step(0, std::false_type{});                              // h_{-1} = 0: no recurrent term
   }
-  for (int t = t0; t < T; ++t) step(t);
+  touch_w();
+  for (int t = 1; t < T; ++t) step(t, std::true_type{});
   if (d.h_last) {      // fp32 copy of h_{T-1} (the latent stack / the MFN heads read it; hs itself may be bf16)
     const __amdgpu_buffer_rsrc_t rl = slab(d.h_last, 0, slab_h);
     bst4(rl, voff_h, h_keep);
@@ -272,7 +285,7 @@ __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, cons
   const int u0 = wave * 16;
   const int b = tile * 16 + bi;
   const bool bvalid = active && (b < B);
-  const bool dec = (KIND != 0) && (d.is_dec != 0);
+  constexpr bool dec = KIND != 0;
 
   bf16x8 wT[NKB];
   auto load_wT = [&](auto mode) {
@@ -345,17 +358,21 @@ __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, cons
     const __amdgpu_buffer_rsrc_t rg = slabv<ST>(gates_p, (int64_t)t * B * row4, slab_g);
     n_gi = bldv<ST>(rg, voff_g); n_gf = bldv<ST>(rg, voff_g + Hp * ES); n_gg = bldv<ST>(rg, voff_g + 2 * Hp * ES); n_go = bldv<ST>(rg, voff_g + 3 * Hp * ES);
     n_ct = bld4(slab(cs_p, (int64_t)t * B * Hp, slab_h), voff_h);
-    n_cp = bld4(slab(cs_p, (int64_t)max(t - 1, 0) * B * Hp, t > 0 ? slab_h : 0), voff_h);     // c_{-1} = 0
+    // c_{-1} = 0: an empty range, whose base is never dereferenced.  (NOT max(t - 1, 0): that becomes a saturating
+    // VALU subtract, the descriptor lands in VGPRs and every step pays a readfirstlane waterfall loop for it.)
+    n_cp = bld4(slab(cs_p, ((int64_t)t - 1) * B * Hp, t > 0 ? slab_h : 0), voff_h);
     n_dhe = bldv<ST>(slabv<ST>(dh_p, (int64_t)t * B * Hp, dhe_bytes), voff_dh);
     n_dce = bld4(slab(dc_p ? dc_p : cs_p, (int64_t)t * B * Hp, dce_bytes), voff_h);
   };
   fetch(T - 1);
 
-  auto step = [&](const int t, auto first) {
+  // REC: the step hands dA_t to the recurrent product (every step of a decoder, steps >= 1 of an encoder);
+  // SWAP: decoder step 0, whose product runs through W_ih only
+  auto step = [&](const int t, const int tn, auto rec, auto swap) {
     const f32x4 gi = n_gi, gf = n_gf, gg = n_gg, go = n_go, ct = n_ct, cp = n_cp;
     const f32x4 dh = dh_rec + n_dhe;
     const f32x4 dce = n_dce;
-    fetch(max(t - 1, 0));                      // step 0 re-reads its own slabs: unused
+    fetch(tn);                                 // tn = t - 1; step 0 re-reads its own slabs (unused)
     f32x4 dai, daf, dag, dao;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -372,11 +389,9 @@ __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, cons
       const __amdgpu_buffer_rsrc_t rg = slabv<ST>(gates_p, (int64_t)t * B * row4, slab_g);
       bstv<ST>(rg, voff_g, dai); bstv<ST>(rg, voff_g + Hp * ES, daf); bstv<ST>(rg, voff_g + 2 * Hp * ES, dag); bstv<ST>(rg, voff_g + 3 * Hp * ES, dao);
     }
-
-    const bool need_rec = (t > 0) || dec;
-    if (need_rec) {
+    if constexpr (decltype(rec)::value) {
       __bf16* db = lds + cur * (16 * LROW);
-      if (active && u0 + 4 * q < HKP) {
+      {
         __bf16* dp = db + bi * LROW + u0 + 4 * q;
         *reinterpret_cast<bf16x4*>(dp) = __builtin_convertvector(dai, bf16x4);
         *reinterpret_cast<bf16x4*>(dp + HKP) = __builtin_convertvector(daf, bf16x4);
@@ -384,35 +399,36 @@ __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, cons
         *reinterpret_cast<bf16x4*>(dp + 3 * HKP) = __builtin_convertvector(dao, bf16x4);
       }
       lds_barrier();
-      if constexpr (decltype(first)::value) {
-        if (dec) {                                             // grad wrt the step-0 input goes through W_ih only
-          if (pk) load_packedT(3); else load_wT(std::integral_constant<int, 1>{});
-        }
+      if constexpr (decltype(swap)::value) {                  // grad wrt the step-0 input goes through W_ih only
+        if (pk) load_packedT(3); else load_wT(std::integral_constant<int, 1>{});
       }
       f32x4 a0 = zero4, a1 = zero4, a2 = zero4, a3 = zero4;
-      if (active) {
-        const __bf16* dp = db + bi * LROW + 8 * q;
+      const __bf16* dp = db + bi * LROW + 8 * q;
 #pragma unroll
-        for (int kb = 0; kb < NKB; kb += 4) {
-          bf16x8 v[4];
+      for (int kb = 0; kb < NKB; kb += 4) {
+        bf16x8 v[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const bf16x8*>(dp + (kb + j) * 32);
-          a0 = mma_bf16(wT[kb + 0], v[0], a0);
-          a1 = mma_bf16(wT[kb + 1], v[1], a1);
-          a2 = mma_bf16(wT[kb + 2], v[2], a2);
-          a3 = mma_bf16(wT[kb + 3], v[3], a3);
-        }
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const bf16x8*>(dp + (kb + j) * 32);
+        a0 = mma_bf16(wT[kb + 0], v[0], a0);
+        a1 = mma_bf16(wT[kb + 1], v[1], a1);
+        a2 = mma_bf16(wT[kb + 2], v[2], a2);
+        a3 = mma_bf16(wT[kb + 3], v[3], a3);
       }
       dh_rec = (a0 + a1) + (a2 + a3);
       cur ^= 1;
     }
   };
-  if constexpr (KIND != 0) {
-    for (int t = T - 1; t >= 1; --t) step(t, std::false_type{});
-    step(0, std::true_type{});
-  } else {
-    for (int t = T - 1; t >= 0; --t) step(t, std::false_type{});
+  // Branch-free loop entered after a peeled step with the weights already in registers: the pending-memory state on
+  // the entry edge is the back edge's ([8 prefetch loads, 4 younger stores]), see the forward body.
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+v"(wT[kb]));
+  constexpr std::true_type yes{};
+  constexpr std::false_type no{};
+  if (T >= 2) {
+    step(T - 1, T - 2, yes, no);
+    for (int t = T - 2; t >= 1; --t) step(t, t - 1, yes, no);
   }
+  if constexpr (KIND != 0) step(0, 0, yes, yes); else step(0, 0, no, no);
   if (dec && bvalid && d.d_h_init) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
