@@ -196,6 +196,14 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
   float c[4] = {0.f, 0.f, 0.f, 0.f};
   f32x4 h_keep = f32x4{0.f, 0.f, 0.f, 0.f};
   int cur = 0;
+  auto write_out = [&](const int t, f32x4 gi, f32x4 gf, f32x4 gg, f32x4 go, f32x4 cv, f32x4 hv) {
+    const __amdgpu_buffer_rsrc_t rg = slabv<ST>(gates_p, (int64_t)t * B * row4, slab_g);
+    const __amdgpu_buffer_rsrc_t rc = slab(cs_p, (int64_t)t * B * Hp, slab_h);
+    const __amdgpu_buffer_rsrc_t rh = slabv<ST>(hs_p, (int64_t)t * B * Hp, slab_hs);
+    bstv<ST>(rg, voff_g, gi); bstv<ST>(rg, voff_g + Hp * ES, gf); bstv<ST>(rg, voff_g + 2 * Hp * ES, gg); bstv<ST>(rg, voff_g + 3 * Hp * ES, go);
+    bst4(rc, voff_h, cv);
+    bstv<ST>(rh, voff_hs, hv);
+  };
   auto step = [&](const int t, auto rec) {
     f32x4 acc[4];
 #pragma unroll
@@ -228,19 +236,14 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
         hv[r] = go[r] * act_tanh(c[r]);
       }
       {
-        const __amdgpu_buffer_rsrc_t rg = slabv<ST>(gates_p, (int64_t)t * B * row4, slab_g);
-        const __amdgpu_buffer_rsrc_t rc = slab(cs_p, (int64_t)t * B * Hp, slab_h);
-        const __amdgpu_buffer_rsrc_t rh = slabv<ST>(hs_p, (int64_t)t * B * Hp, slab_hs);
-        bstv<ST>(rg, voff_g, gi); bstv<ST>(rg, voff_g + Hp * ES, gf); bstv<ST>(rg, voff_g + 2 * Hp * ES, gg); bstv<ST>(rg, voff_g + 3 * Hp * ES, go);
-        bst4(rc, voff_h, cv);
-        bstv<ST>(rh, voff_hs, hv);
-        h_keep = hv;
-      }
-      {
         const f32x4 hz = (b < B) ? hv : f32x4{0.f, 0.f, 0.f, 0.f};
         __bf16* hn = lds + (cur ^ 1) * (16 * LROW) + bi * LROW + u0 + 4 * q;
         *reinterpret_cast<bf16x4*>(hn) = __builtin_convertvector(hz, bf16x4);
       }
+      // (tried, scripts/bench_seq_bf16.py, profiles/r05_seq_bf16_study.txt: the record of step t-1 written out in the
+      //  shadow of step t's MFMAs, and the x-projection fetched two steps ahead -- neither moves the launch)
+      write_out(t, gi, gf, gg, go, cv, hv);
+      h_keep = hv;
     }
     lds_barrier();
     cur ^= 1;
