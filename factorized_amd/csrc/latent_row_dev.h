@@ -305,6 +305,33 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
   int nib[MFM_LAT_MAXSTAGES];
 #pragma unroll
   for (int i = 0; i < MFM_LAT_MAXSTAGES; ++i) nib[i] = L.nitems_bwd_c[ch][i];
+  // The seeds' global operands (targets, upstream gradient, the decoders' d h_init) of this thread's element are requested
+  // HERE, with the record: the seed section below used to load them where it needs them -- up to seven dependent round
+  // trips (one per `if (ptr) sum += ptr[...]`) in front of the stage walk, on the critical path of the fold launches.
+  // Unconditional uses (LAT_KEEP) keep the compiler from sinking the loads back into the branches that consume them.
+#define LAT_KEEP(x) asm volatile("" : "+v"(x))
+  // (every load is unconditional -- an absent operand reads params[0] instead: a branch around a load makes the compiler wait
+  //  for everything requested before it)
+  const int fy_ = L.f_n[3];
+  float pre_fy[3], pre_fm[3], pre_y;
+  long long pre_lab;
+  {
+    const bool gen = L.gen_w != 0.0f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const bool on = gen && L.d_dec_init[m] != nullptr;
+      const float* dp = on ? L.d_dec_init[m] + (int64_t)row * L.dec_ld[m] : params;
+      pre_fy[m] = dp[on ? min(tid, fy_ - 1) : 0];
+      pre_fm[m] = dp[on ? fy_ + min(tid, L.f_n[m] - 1) : 0];
+    }
+    const bool ext = L.d_yhat_ext != nullptr;
+    const bool l1 = !ext && L.y && L.loss_kind == 0;
+    const bool ce = !ext && L.y && L.loss_kind != 0;
+    const float* yp = ext ? L.d_yhat_ext : (l1 ? reinterpret_cast<const float*>(L.y) : params);
+    pre_y = yp[(ext || l1) ? (int64_t)row * L.od + min(tid, L.od - 1) : 0];
+    const long long* lp = ce ? reinterpret_cast<const long long*>(L.y) : reinterpret_cast<const long long*>(params);
+    pre_lab = lp[ce ? row : 0];
+  }
   {   // op table, item table and the saved record are requested together (one round trip)
     const int nw = L.nops * (int)(sizeof(LatOp) / 4);
     const int opv = reinterpret_cast<const int*>(L.ops)[min(tid, nw - 1)];
@@ -316,13 +343,33 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
     const f32x4* sd4 = L.grd_seed ? reinterpret_cast<const f32x4*>(L.grd_seed + (int64_t)row * RS) : nullptr;
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     const float sw = sd4 ? (L.seed_w_ptr ? *L.seed_w_ptr : L.seed_w) : 0.0f;
-    const f32x4 sv = sd4 ? sw * sd4[min(tid, n4 - 1)] : zero;
-    load_items(L.items_bwd + (size_t)ch * (MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4), L.nstages, tab, tid);
+    // (no seed record: the saved record is read again and weighted by 0 -- an unconditional load, see above)
+    const f32x4 sraw = (sd4 ? sd4 : s4)[min(tid, n4 - 1)];
+    const int pfv = L.ops[min(tid, L.nops - 1)].pfx_n;
+    // this thread's items of all stages: requested here, stored below (load_items() in two halves, so that every load of the
+    // prologue is in flight before the first wait)
+    const i32x4* isrc = reinterpret_cast<const i32x4*>(L.items_bwd + (size_t)ch * (MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4));
+    i32x4 iv[MFM_LAT_MAXSTAGES];
+#pragma unroll
+    for (int st = 0; st < MFM_LAT_MAXSTAGES; ++st) iv[st] = isrc[min(st, L.nstages - 1) * MFM_LAT_ROW_THREADS + tid];
+    const f32x4 sv = sw * sraw;
+#pragma unroll
+    for (int st = 0; st < MFM_LAT_MAXSTAGES; ++st) tab[st * MFM_LAT_ROW_THREADS + tid] = iv[st];
     if (tid < nw) reinterpret_cast<int*>(ops)[tid] = opv;
-    if (tid < L.nops) pfxN[tid] = L.ops[tid].pfx_n;
+    if (tid < L.nops) pfxN[tid] = pfv;
     if (tid < n4) { r4[tid] = rv; g4[tid] = sv; }
     for (int idx = tid + nt; idx < n4; idx += nt) { r4[idx] = s4[idx]; g4[idx] = sd4 ? sw * sd4[idx] : zero; }
   }
+  // (the unconditional uses come AFTER the record's loads were issued: placed above them they would wait for the seeds first)
+#pragma unroll
+  for (int m = 0; m < 3; ++m) { LAT_KEEP(pre_fy[m]); LAT_KEEP(pre_fm[m]); }
+  LAT_KEEP(pre_y);
+  {
+    int lo = (int)pre_lab, hi = (int)(pre_lab >> 32);
+    LAT_KEEP(lo); LAT_KEEP(hi);
+    pre_lab = ((long long)hi << 32) | (unsigned)lo;
+  }
+#undef LAT_KEEP
   lds_barrier();
   const int l = tid & 15;
   const int wave0 = tid & ~63;
@@ -344,27 +391,27 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
   }
   // ---- seeds
   float dl = 0.0f;                  // this row's share of the discriminative loss (disc_loss_out)
+  // (the element a thread's first pass needs is already in pre_*; later passes -- od / f sizes beyond the block -- load)
   if (L.d_yhat_ext) {
-    for (int o = tid; o < L.od; o += nt) grd[L.yhat_off + o] = L.d_yhat_ext[(int64_t)row * L.od + o];
+    for (int o = tid; o < L.od; o += nt) grd[L.yhat_off + o] = (o == tid) ? pre_y : L.d_yhat_ext[(int64_t)row * L.od + o];
   } else if (L.y && (L.disc_w != 0.0f || L.disc_loss_out)) {
     if (L.loss_kind == 0) {
       const float* y = reinterpret_cast<const float*>(L.y);
       const float inv = 1.0f / ((float)L.B * (float)L.od);
       const float sc = L.disc_w * inv;
       for (int o = tid; o < L.od; o += nt) {
-        const float df = rec[L.yhat_off + o] - y[(int64_t)row * L.od + o];
+        const float df = rec[L.yhat_off + o] - ((o == tid) ? pre_y : y[(int64_t)row * L.od + o]);
         grd[L.yhat_off + o] = (df > 0.0f) ? sc : ((df < 0.0f) ? -sc : 0.0f);
         dl += fabsf(df) * inv;
       }
     } else if (tid == 0) {
-      const int64_t* y = reinterpret_cast<const int64_t*>(L.y);
       const float sc = L.disc_w / (float)L.B;
       const float* z = rec + L.yhat_off;
       float mx = z[0];
       for (int o = 1; o < L.od; ++o) mx = fmaxf(mx, z[o]);
       float se = 0.0f;
       for (int o = 0; o < L.od; ++o) se += expf(z[o] - mx);
-      const int lab = (int)y[row];
+      const int lab = (int)pre_lab;
       for (int o = 0; o < L.od; ++o) grd[L.yhat_off + o] = sc * (expf(z[o] - mx) / se - (o == lab ? 1.0f : 0.0f));
       dl = ((logf(se) + mx) - z[lab]) / (float)L.B;
     }
@@ -379,12 +426,13 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
     for (int j = tid; j < fy; j += nt) {
       float sm = 0.0f;
       for (int m = 0; m < 3; ++m)
-        if (L.d_dec_init[m]) sm += L.d_dec_init[m][(int64_t)row * L.dec_ld[m] + j];
+        if (L.d_dec_init[m]) sm += (j == tid) ? pre_fy[m] : L.d_dec_init[m][(int64_t)row * L.dec_ld[m] + j];
       grd[L.f_off[3] + j] = sm;
     }
     for (int m = 0; m < 3; ++m) {
       if (!L.d_dec_init[m]) continue;
-      for (int j = tid; j < L.f_n[m]; j += nt) grd[L.f_off[m] + j] = L.d_dec_init[m][(int64_t)row * L.dec_ld[m] + fy + j];
+      for (int j = tid; j < L.f_n[m]; j += nt)
+        grd[L.f_off[m] + j] = (j == tid) ? pre_fm[m] : L.d_dec_init[m][(int64_t)row * L.dec_ld[m] + fy + j];
     }
     // the f segments come out of a relu layer (z -> f, second Linear): the record holds gradients wrt
     // PRE-activations throughout (what the bias / weight gradients need), so the seeds are masked here and
