@@ -72,6 +72,14 @@ __device__ __forceinline__ f32x4 bldv(__amdgpu_buffer_rsrc_t r, int off) {
     return bld4(r, off);
   }
 }
+// four stored values as raw registers (8 bytes bf16-resident, 16 bytes fp32) and their conversion
+template <bool ST> struct RawV { typedef f32x4 type; };
+template <> struct RawV<true> { typedef u32x2 type; };
+template <bool ST>
+__device__ __forceinline__ f32x4 cvt_raw(typename RawV<ST>::type v) {
+  if constexpr (ST) return __builtin_convertvector(__builtin_bit_cast(bf16x4, v), f32x4);
+  else return v;
+}
 template <bool ST>
 __device__ __forceinline__ void bstv(__amdgpu_buffer_rsrc_t r, int off, f32x4 v) {
   if constexpr (ST) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4)), r, off, 0, 0);
@@ -178,72 +186,130 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
   const int64_t row4 = 4 * (int64_t)Hp;
   const int slab_g = B * 4 * Hp * ES, slab_h = B * Hp * 4;                   // bytes of one time step (gates; cs)
   const int slab_hs = B * Hp * ES;                                            // (hs)
-  const int voff_g = bvalid ? (b * 4 * Hp + u0 + 4 * q) * ES : slab_g;         // idle lanes: out of range
   const int voff_h = bvalid ? (b * Hp + u0 + 4 * q) * 4 : slab_h;
-  const int voff_hs = bvalid ? (b * Hp + u0 + 4 * q) * ES : slab_hs;
-  f32x4 gx[4] = {bias[0], bias[1], bias[2], bias[3]};      // decoders: no x-projection, the accumulators start from the bias
-  if constexpr (KIND == 0) {
+
+  // ---- COALESCED global traffic (round 5).  A lane's share of a step's record is 8-16 bytes of one batch row per gate, so a
+  // store instruction used to touch 16 cache lines with 32-64 bytes each: 768 line visits per workgroup and step (h = 120)
+  // where the record has 224 lines, and the texture-address unit of the CU, which takes ~3 cycles per line, was busy for
+  // ~3.8 k of the step's 4.4 k cycles (2.2 k of them the stores that every wave has to ISSUE before it reaches the barrier;
+  // scripts/seqb_step_timeline.py, profiles/r05_seq_bf16_study.txt section 7).  But a tile's rows are CONTIGUOUS in every one of
+  // the step's slabs ([B][4 Hp], [B][Hp]: 16 rows back to back), so the record is staged in LDS in row order and leaves as
+  // 16-byte pieces in memory order -- piece i of the tile by thread i: every line visited once, 4 (bf16-resident) store
+  // instructions per wave instead of 6.  The x-projection of the next step comes in the same way (2 loads instead of 4).
+  // Step t: [LDS reads: x-projection(t), record(t-1), h(t-1)] barrier [loads x-projection(t+1); stores record(t-1); product;
+  // gates; LDS writes: h(t), record(t), x-projection(t+1)] barrier.  Two barriers per step (the staging areas are single:
+  // doubled they would cost the second workgroup per CU), one more than before, ~470 cycles.
+  const int nthr = (Hp >> 4) * 64;                        // the waves that are left
+  const int RBg = 4 * Hp * ES, RBc = Hp * 4, RBh = Hp * ES;      // bytes of a row in the gates / c / h slabs
+  const int LBg = RBg + 32, LBc = RBc + 32, LBh = RBh + 32;      // and in LDS (padded: 16 rows on different banks)
+  unsigned char* const sm = reinterpret_cast<unsigned char*>(lds) + 2 * 16 * LROW * 2;
+  unsigned char* const outg = sm;
+  unsigned char* const outc = outg + 16 * LBg;
+  unsigned char* const outh = outc + 16 * LBc;
+  unsigned char* const ing = outh + 16 * LBh;             // encoders only
+  constexpr int NG = ES;                                  // 16-byte pieces of the gates tile per thread: 16 RBg / 16 / nthr = ES
+  int pg_l[NG], pg_g[NG];                                 // LDS / slab byte offsets of this thread's pieces
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
+    const int off = (tid + j * nthr) * 16;
+    const int r = off / RBg;
+    pg_l[j] = r * LBg + (off - r * RBg);
+    pg_g[j] = tile * 16 * RBg + off;                      // (rows past the batch fall beyond the slab: dropped / zero)
+  }
+  const int pc_l = ((tid * 16) / RBc) * LBc + (tid * 16) % RBc, pc_g = tile * 16 * RBc + tid * 16;
+  // h: 16 RBh bytes = nthr pieces of (ES == 2 ? 8 : 16) bytes
+  constexpr int HPB = ST ? 8 : 16;
+  const int ph_l = ((tid * HPB) / RBh) * LBh + (tid * HPB) % RBh, ph_g = tile * 16 * RBh + tid * HPB;
+  // this lane's cells in the staging areas (row bi, units u0 + 4 q ..)
+  const int cg_l = bi * LBg + (u0 + 4 * q) * ES, cc_l = bi * LBc + (u0 + 4 * q) * 4, ch_l = bi * LBh + (u0 + 4 * q) * ES;
+  typedef typename RawV<ST>::type raw_t;                  // 4 stored values (8 or 16 bytes)
+
+  if constexpr (KIND == 0) {      // x-projection of step 0 into the staging area
     const __amdgpu_buffer_rsrc_t r0 = slabv<ST>(gates_p, 0, slab_g);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) gx[g] = bldv<ST>(r0, voff_g + g * Hp * ES);
+    for (int j = 0; j < NG; ++j) *reinterpret_cast<f32x4*>(ing + pg_l[j]) = bld4(r0, pg_g[j]);
+    lds_barrier();
   }
 
-  // The time loop has NO branch and every wave of it is active (see the early return above), and it is entered after
-  // a peeled first step, so that the pending-memory state on the loop's entry edge equals the one on its back edge:
-  // [4 prefetch loads, 6 younger stores].  With the prefetch still the YOUNGEST operation on the entry edge (no peel)
-  // the compiler's merged state makes every step wait vmcnt(0) for its prefetch, i.e. for the acknowledgement of the
-  // previous step's stores -- 2.5-3.4 us per step at B = 2048 where the arithmetic needs ~1.
   float c[4] = {0.f, 0.f, 0.f, 0.f};
   f32x4 h_keep = f32x4{0.f, 0.f, 0.f, 0.f};
   int cur = 0;
-  auto write_out = [&](const int t, f32x4 gi, f32x4 gf, f32x4 gg, f32x4 go, f32x4 cv, f32x4 hv) {
-    const __amdgpu_buffer_rsrc_t rg = slabv<ST>(gates_p, (int64_t)t * B * row4, slab_g);
-    const __amdgpu_buffer_rsrc_t rc = slab(cs_p, (int64_t)t * B * Hp, slab_h);
-    const __amdgpu_buffer_rsrc_t rh = slabv<ST>(hs_p, (int64_t)t * B * Hp, slab_hs);
-    bstv<ST>(rg, voff_g, gi); bstv<ST>(rg, voff_g + Hp * ES, gf); bstv<ST>(rg, voff_g + 2 * Hp * ES, gg); bstv<ST>(rg, voff_g + 3 * Hp * ES, go);
-    bst4(rc, voff_h, cv);
-    bstv<ST>(rh, voff_hs, hv);
-  };
+  // `wo`: bytes of the slabs that receive step t-1's record (0 at the first step: the stores are issued and dropped, so that
+  // every step has the same list of pending memory operations -- see the note on counted waits in the backward body)
   auto step = [&](const int t, auto rec) {
+    // ---- LDS reads
     f32x4 acc[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = gx[g];
-    if constexpr (KIND == 0) {   // x-projection of step t+1 (the last step re-reads its own slab: unused)
-      const __amdgpu_buffer_rsrc_t rn = slabv<ST>(gates_p, (int64_t)min(t + 1, T - 1) * B * row4, slab_g);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) gx[g] = bldv<ST>(rn, voff_g + g * Hp * ES);
+    for (int g = 0; g < 4; ++g) {
+      if constexpr (KIND == 0) acc[g] = cvt_raw<ST>(*reinterpret_cast<const raw_t*>(ing + cg_l + g * Hp * ES));
+      else acc[g] = bias[g];
     }
+    f32x4 og[NG], oc;
+    raw_t oh;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) og[j] = *reinterpret_cast<const f32x4*>(outg + pg_l[j]);
+    oc = *reinterpret_cast<const f32x4*>(outc + pc_l);
+    oh = *reinterpret_cast<const raw_t*>(outh + ph_l);
+    bf16x8 hv[KB];
     if constexpr (decltype(rec)::value) {
       const __bf16* hb = lds + cur * (16 * LROW) + bi * LROW + 8 * q;
-      bf16x8 hv[KB];
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) hv[kb] = *reinterpret_cast<const bf16x8*>(hb + kb * 32);
+    }
+    lds_barrier();
+    // ---- global: next step's x-projection first (it is waited for at the end of this step; the stores stay younger)
+    f32x4 gxn[NG];
+    if constexpr (KIND == 0) {
+      const __amdgpu_buffer_rsrc_t rn = slabv<ST>(gates_p, (int64_t)min(t + 1, T - 1) * B * row4, slab_g);
+#pragma unroll
+      for (int j = 0; j < NG; ++j) gxn[j] = bld4(rn, pg_g[j]);
+    }
+    {
+      const int64_t tp = (int64_t)t - 1;        // (t = 0: empty ranges, whose base is never dereferenced; NOT max(t - 1, 0))
+      const __amdgpu_buffer_rsrc_t rg = slabv<ST>(gates_p, tp * B * row4, t > 0 ? slab_g : 0);
+      const __amdgpu_buffer_rsrc_t rc = slab(cs_p, tp * B * Hp, t > 0 ? slab_h : 0);
+      const __amdgpu_buffer_rsrc_t rh = slabv<ST>(hs_p, tp * B * Hp, t > 0 ? slab_hs : 0);
+#pragma unroll
+      for (int j = 0; j < NG; ++j) bst4(rg, pg_g[j], og[j]);
+      bst4(rc, pc_g, oc);
+      if constexpr (ST) __builtin_amdgcn_raw_buffer_store_b64(oh, rh, ph_g, 0, 0);
+      else bst4(rh, ph_g, oh);
+    }
+    // ---- recurrent product, gates
+    if constexpr (decltype(rec)::value) {
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = mma_bf16(w[g][kb], hv[kb], acc[g]);
     }
-    {
-      f32x4 gi, gf, gg, go, cv, hv;
+    f32x4 gi, gf, gg, go, cv, hn4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        gi[r] = act_sigmoid(acc[0][r]);
-        gf[r] = act_sigmoid(acc[1][r]);
-        gg[r] = act_tanh(acc[2][r]);
-        go[r] = act_sigmoid(acc[3][r]);
-        c[r] = gf[r] * c[r] + gi[r] * gg[r];
-        cv[r] = c[r];
-        hv[r] = go[r] * act_tanh(c[r]);
-      }
-      {
-        const f32x4 hz = (b < B) ? hv : f32x4{0.f, 0.f, 0.f, 0.f};
-        __bf16* hn = lds + (cur ^ 1) * (16 * LROW) + bi * LROW + u0 + 4 * q;
-        *reinterpret_cast<bf16x4*>(hn) = __builtin_convertvector(hz, bf16x4);
-      }
-      // (tried, scripts/bench_seq_bf16.py, profiles/r05_seq_bf16_study.txt: the record of step t-1 written out in the
-      //  shadow of step t's MFMAs, and the x-projection fetched two steps ahead -- neither moves the launch)
-      write_out(t, gi, gf, gg, go, cv, hv);
-      h_keep = hv;
+    for (int r = 0; r < 4; ++r) {
+      gi[r] = act_sigmoid(acc[0][r]);
+      gf[r] = act_sigmoid(acc[1][r]);
+      gg[r] = act_tanh(acc[2][r]);
+      go[r] = act_sigmoid(acc[3][r]);
+      c[r] = gf[r] * c[r] + gi[r] * gg[r];
+      cv[r] = c[r];
+      hn4[r] = go[r] * act_tanh(c[r]);
+    }
+    h_keep = hn4;
+    // ---- LDS writes: h_t for the product, the record for the write-out, the next x-projection
+    {
+      const f32x4 hz = (b < B) ? hn4 : f32x4{0.f, 0.f, 0.f, 0.f};
+      __bf16* hp = lds + (cur ^ 1) * (16 * LROW) + bi * LROW + u0 + 4 * q;
+      *reinterpret_cast<bf16x4*>(hp) = __builtin_convertvector(hz, bf16x4);
+    }
+    auto put = [&](unsigned char* at, f32x4 v) {
+      if constexpr (ST) *reinterpret_cast<bf16x4*>(at) = __builtin_convertvector(v, bf16x4);
+      else *reinterpret_cast<f32x4*>(at) = v;
+    };
+    put(outg + cg_l, gi); put(outg + cg_l + Hp * ES, gf); put(outg + cg_l + 2 * Hp * ES, gg); put(outg + cg_l + 3 * Hp * ES, go);
+    *reinterpret_cast<f32x4*>(outc + cc_l) = cv;
+    put(outh + ch_l, hn4);
+    if constexpr (KIND == 0) {
+#pragma unroll
+      for (int j = 0; j < NG; ++j) *reinterpret_cast<f32x4*>(ing + pg_l[j]) = gxn[j];
     }
     lds_barrier();
     cur ^= 1;
@@ -266,6 +332,16 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
   }
   touch_w();
   for (int t = 1; t < T; ++t) step(t, std::true_type{});
+  {   // the last step's record
+    const __amdgpu_buffer_rsrc_t rg = slabv<ST>(gates_p, (int64_t)(T - 1) * B * row4, slab_g);
+    const __amdgpu_buffer_rsrc_t rc = slab(cs_p, (int64_t)(T - 1) * B * Hp, slab_h);
+    const __amdgpu_buffer_rsrc_t rh = slabv<ST>(hs_p, (int64_t)(T - 1) * B * Hp, slab_hs);
+#pragma unroll
+    for (int j = 0; j < NG; ++j) bst4(rg, pg_g[j], *reinterpret_cast<const f32x4*>(outg + pg_l[j]));
+    bst4(rc, pc_g, *reinterpret_cast<const f32x4*>(outc + pc_l));
+    if constexpr (ST) __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const raw_t*>(outh + ph_l), rh, ph_g, 0, 0);
+    else bst4(rh, ph_g, *reinterpret_cast<const f32x4*>(outh + ph_l));
+  }
   if (d.h_last) {      // fp32 copy of h_{T-1} (the latent stack / the MFN heads read it; hs itself may be bf16)
     const __amdgpu_buffer_rsrc_t rl = slab(d.h_last, 0, slab_h);
     bst4(rl, voff_h, h_keep);
@@ -540,7 +616,12 @@ int seq_bf16_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
       const SeqDev& d = L.d[i];
       if (d.Hp / 16 > max_waves) max_waves = d.Hp / 16;
       const size_t hkp = (size_t)((d.h + 31) / 32) * 32;
-      const size_t need = 2 * 16 * ((bwd ? 4 * hkp : hkp) + 8) * sizeof(__bf16);
+      size_t need = 2 * 16 * ((bwd ? 4 * hkp : hkp) + 8) * sizeof(__bf16);
+      if (!bwd) {      // forward: staging areas of the coalesced record write-out / x-projection fetch (seqb_fwd_body)
+        const size_t es = d.store_bf16 ? 2 : 4;
+        const size_t lbg = 4 * d.Hp * es + 32, lbc = d.Hp * 4 + 32, lbh = d.Hp * es + 32;
+        need += 16 * (lbg + lbc + lbh) + (kind == 0 ? 16 * lbg : 0);
+      }
       if (need > lds_bytes) lds_bytes = need;
     }
     if (K.count == 0) continue;
@@ -550,6 +631,10 @@ int seq_bf16_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
       MFM_REQUIRE((K.d[i].store_bf16 != 0) == st, "lstm_seq (bf16): the LSTMs of one launch must agree on store_bf16");
 #define MFM_SEQB_GO(BWD_, KIND_)                                                                                          \
   do {                                                                                                                    \
+    if (lds_bytes > 64 * 1024) {                                                                                          \
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_bf16_kernel<BWD_, KIND_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
+      MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_bf16_kernel<BWD_, KIND_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+    }                                                                                                                     \
     if (st) hipLaunchKernelGGL((lstm_seq_bf16_kernel<BWD_, KIND_, true>), grid, block, lds_bytes, stream, K);             \
     else hipLaunchKernelGGL((lstm_seq_bf16_kernel<BWD_, KIND_, false>), grid, block, lds_bytes, stream, K);               \
   } while (0)

@@ -42,6 +42,7 @@ for B in 8 16 32 48 64 192 512 2048; do python bench.py --batch $B --dtype $([ $
 python scripts/bench_dropin.py > $O/graphed_steps.txt 2>&1
 MFM_DROPIN_SECTIONS=1 python scripts/bench_dropin.py 2>&1 | tail -1 >> $O/graphed_steps.txt
 python scripts/bench_seq_group.py > $O/seq_group.txt 2>&1
+python scripts/bench_seq_bf16.py 2048 > $O/seq_bf16_B2048.txt 2>&1
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29532 scripts/bench_p2p.py --one-device 2>/dev/null | tail -1 > $O/p2p_one_device.txt
 MFM_P2P_GENERIC=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29542 scripts/bench_p2p.py --one-device 2>/dev/null | tail -1 >> $O/p2p_one_device.txt
 MFM_BENCH_ONE_DEVICE=1 MFM_P2P_TIMEOUT_MS=20000 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 200 --warmup 20 $NB > $O/bench_dp2_one_device.json 2>/dev/null
