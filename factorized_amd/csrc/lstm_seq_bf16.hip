@@ -413,11 +413,8 @@ __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, cons
   const int64_t row4 = 4 * (int64_t)Hp;
   const int slab_g = B * 4 * Hp * ES, slab_h = B * Hp * 4;                   // bytes of one time step (gates; cs, dc_ext)
   const int slab_dh = B * Hp * ES;                                            // (the decoders' dh_ext)
-  const int voff_g = bvalid ? (b * 4 * Hp + u0 + 4 * q) * ES : slab_g;         // idle lanes: out of range
-  const int voff_h = bvalid ? (b * Hp + u0 + 4 * q) * 4 : slab_h;
-  const int voff_dh = bvalid ? (b * Hp + u0 + 4 * q) * ES : slab_dh;
   const int dhe_bytes = dec ? slab_dh : 0;          // per-step external dh exists for decoders only
-  const int dce_bytes = dc_p ? slab_h : 0;          // optional external dc (MFN encoder LSTMs)
+  const bool has_dce = dc_p != nullptr;             // optional external dc (MFN encoder LSTMs)
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
   // encoders receive an external gradient on h_{T-1} only: it seeds the recurrent term
   f32x4 dh_rec = zero4;
@@ -428,30 +425,107 @@ __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, cons
       if (unit < h) dh_rec[r] = dh_p[(int64_t)b * d.ld_dh + unit];
     }
   }
-  float dc[4] = {0.f, 0.f, 0.f, 0.f};
-  int cur = 0;
 
-  // saved activations of the step ABOUT to be processed: requested one step ahead, unconditionally (see slab())
-  f32x4 n_gi, n_gf, n_gg, n_go, n_ct, n_cp, n_dhe, n_dce;
-  auto fetch = [&](const int t) {
-    const __amdgpu_buffer_rsrc_t rg = slabv<ST>(gates_p, (int64_t)t * B * row4, slab_g);
-    n_gi = bldv<ST>(rg, voff_g); n_gf = bldv<ST>(rg, voff_g + Hp * ES); n_gg = bldv<ST>(rg, voff_g + 2 * Hp * ES); n_go = bldv<ST>(rg, voff_g + 3 * Hp * ES);
-    n_ct = bld4(slab(cs_p, (int64_t)t * B * Hp, slab_h), voff_h);
-    // c_{-1} = 0: an empty range, whose base is never dereferenced.  (NOT max(t - 1, 0): that becomes a saturating
-    // VALU subtract, the descriptor lands in VGPRs and every step pays a readfirstlane waterfall loop for it.)
-    n_cp = bld4(slab(cs_p, ((int64_t)t - 1) * B * Hp, t > 0 ? slab_h : 0), voff_h);
-    n_dhe = bldv<ST>(slabv<ST>(dh_p, (int64_t)t * B * Hp, dhe_bytes), voff_dh);
-    n_dce = bld4(slab(dc_p ? dc_p : cs_p, (int64_t)t * B * Hp, dce_bytes), voff_h);
+  // ---- COALESCED global traffic, as in the forward body: a tile's rows are contiguous in every slab, so the saved activations
+  // of a step arrive as 16-byte pieces in memory order (piece i of the tile by thread i) into LDS staging areas and every lane
+  // picks its cells from there; dA leaves the same way.  Per wave and step: ES + 3 loads and ES stores instead of 8 and 4, every
+  // cache line visited once.  c_{t-1} is not fetched twice: the two cell-state areas take turns (this step's c_{t-1} is the
+  // next step's c_t).  bf16-resident: the dA pieces are read straight from the exchange panel of the previous step (the panel
+  // IS bf16 dA, and its two halves alternate).
+  // Step t: [LDS reads: cells of step t, pieces of dA(t+1)] barrier [loads for step t-1; stores dA(t+1); gate gradients;
+  // LDS writes: panel, staging of step t-1] barrier [recurrent product].
+  const int nthr = (Hp >> 4) * 64;
+  const int RBg = 4 * Hp * ES, RBc = Hp * 4, RBh = Hp * ES;
+  const int LBg = RBg + 32, LBc = RBc + 32, LBh = RBh + 32;
+  unsigned char* const sm = reinterpret_cast<unsigned char*>(lds) + 2 * 16 * LROW * 2;
+  unsigned char* const ing = sm;
+  unsigned char* const cbuf0 = ing + 16 * LBg;
+  unsigned char* const cbuf1 = cbuf0 + 16 * LBc;
+  unsigned char* const dheb = cbuf1 + 16 * LBc;
+  unsigned char* const outf = dheb + 16 * LBh;                     // fp32-resident only: dA cells in slab layout
+  unsigned char* const dceb = outf + (ST ? 0 : 16 * LBg);          // only when the launch has a dc_ext (seq_bf16_launch)
+  constexpr int NG = ES;
+  int pg_l[NG], pg_g[NG], po_l[NG];        // gates pieces: staging / slab offsets; where the dA piece is read from
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
+    const int off = (tid + j * nthr) * 16;
+    const int r = off / RBg, rem = off - r * RBg;
+    pg_l[j] = r * LBg + rem;
+    pg_g[j] = tile * 16 * RBg + off;
+    if constexpr (ST) {                    // panel row [4][HKP] bf16 (+ pad): gate g, column c of the slab row
+      const int g = rem / (Hp * 2), cb = rem - g * (Hp * 2);
+      po_l[j] = r * (LROW * 2) + g * (HKP * 2) + cb;
+    } else {
+      po_l[j] = pg_l[j];
+    }
+  }
+  const int pc_l = ((tid * 16) / RBc) * LBc + (tid * 16) % RBc, pc_g = tile * 16 * RBc + tid * 16;
+  constexpr int HPB = ST ? 8 : 16;
+  const int ph_l = ((tid * HPB) / RBh) * LBh + (tid * HPB) % RBh, ph_g = tile * 16 * RBh + tid * HPB;
+  const int cg_l = bi * LBg + (u0 + 4 * q) * ES, cc_l = bi * LBc + (u0 + 4 * q) * 4, ch_l = bi * LBh + (u0 + 4 * q) * ES;
+  typedef typename RawV<ST>::type raw_t;
+
+  // the pieces of one step into the staging areas (sizes 0: the loads return zeros -- c_{-1}, absent operands)
+  struct Pieces { f32x4 g[NG]; f32x4 c; raw_t dh; f32x4 dc; };
+  auto request = [&](const int t, Pieces& P) {
+    if (has_dce) P.dc = bld4(slab(dc_p, (int64_t)max(t, 0) * B * Hp, t >= 0 ? slab_h : 0), pc_g);     // (first: see seq_bf16_launch)
+    const __amdgpu_buffer_rsrc_t rg = slabv<ST>(gates_p, (int64_t)t * B * row4, t >= 0 ? slab_g : 0);
+#pragma unroll
+    for (int j = 0; j < NG; ++j) P.g[j] = bld4(rg, pg_g[j]);
+    P.c = bld4(slab(cs_p, ((int64_t)t - 1) * B * Hp, t >= 1 ? slab_h : 0), pc_g);                      // c_{t-1}
+    const __amdgpu_buffer_rsrc_t rd = slabv<ST>(dh_p, (int64_t)t * B * Hp, t >= 0 ? dhe_bytes : 0);
+    if constexpr (ST) P.dh = __builtin_amdgcn_raw_buffer_load_b64(rd, ph_g, 0, 0);
+    else P.dh = bld4(rd, ph_g);
   };
-  fetch(T - 1);
+  auto deposit = [&](const Pieces& P, unsigned char* cdst) {
+#pragma unroll
+    for (int j = 0; j < NG; ++j) *reinterpret_cast<f32x4*>(ing + pg_l[j]) = P.g[j];
+    *reinterpret_cast<f32x4*>(cdst + pc_l) = P.c;
+    *reinterpret_cast<raw_t*>(dheb + ph_l) = P.dh;
+    if (has_dce) *reinterpret_cast<f32x4*>(dceb + pc_l) = P.dc;
+  };
+  {   // step T-1: its activations, c_{T-1} and c_{T-2}
+    Pieces P;
+    request(T - 1, P);
+    const f32x4 ct = bld4(slab(cs_p, (int64_t)(T - 1) * B * Hp, slab_h), pc_g);
+    deposit(P, cbuf1);
+    *reinterpret_cast<f32x4*>(cbuf0 + pc_l) = ct;
+    lds_barrier();
+  }
+  float dc[4] = {0.f, 0.f, 0.f, 0.f};
+  int cur = 0, ci = 0;               // panel half of this step; cell-state area that holds c_t (the other one: c_{t-1})
 
   // REC: the step hands dA_t to the recurrent product (every step of a decoder, steps >= 1 of an encoder);
   // SWAP: decoder step 0, whose product runs through W_ih only
-  auto step = [&](const int t, const int tn, auto rec, auto swap) {
-    const f32x4 gi = n_gi, gf = n_gf, gg = n_gg, go = n_go, ct = n_ct, cp = n_cp;
-    const f32x4 dh = dh_rec + n_dhe;
-    const f32x4 dce = n_dce;
-    fetch(tn);                                 // tn = t - 1; step 0 re-reads its own slabs (unused)
+  auto step = [&](const int t, auto rec, auto swap) {
+    unsigned char* const ca = ci ? cbuf1 : cbuf0;
+    unsigned char* const cb = ci ? cbuf0 : cbuf1;
+    // ---- LDS reads: this lane's cells of step t, this thread's pieces of dA(t+1)
+    const f32x4 gi = cvt_raw<ST>(*reinterpret_cast<const raw_t*>(ing + cg_l));
+    const f32x4 gf = cvt_raw<ST>(*reinterpret_cast<const raw_t*>(ing + cg_l + Hp * ES));
+    const f32x4 gg = cvt_raw<ST>(*reinterpret_cast<const raw_t*>(ing + cg_l + 2 * Hp * ES));
+    const f32x4 go = cvt_raw<ST>(*reinterpret_cast<const raw_t*>(ing + cg_l + 3 * Hp * ES));
+    const f32x4 ct = *reinterpret_cast<const f32x4*>(ca + cc_l);
+    const f32x4 cp = *reinterpret_cast<const f32x4*>(cb + cc_l);
+    const f32x4 dh = dh_rec + cvt_raw<ST>(*reinterpret_cast<const raw_t*>(dheb + ch_l));
+    f32x4 dce = zero4;
+    if (has_dce) dce = *reinterpret_cast<const f32x4*>(dceb + cc_l);
+    f32x4 og[NG];
+    {
+      const unsigned char* src = ST ? reinterpret_cast<const unsigned char*>(lds + (cur ^ 1) * (16 * LROW)) : outf;
+#pragma unroll
+      for (int j = 0; j < NG; ++j) og[j] = *reinterpret_cast<const f32x4*>(src + po_l[j]);
+    }
+    lds_barrier();
+    // ---- global: the loads first (they are waited for before the second barrier; the stores stay younger)
+    Pieces P;
+    request(t - 1, P);
+    {
+      const __amdgpu_buffer_rsrc_t ro = slabv<ST>(gates_p, ((int64_t)t + 1) * B * row4, t + 1 < T ? slab_g : 0);
+#pragma unroll
+      for (int j = 0; j < NG; ++j) bst4(ro, pg_g[j], og[j]);
+    }
+    // ---- gate gradients
     f32x4 dai, daf, dag, dao;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -464,20 +538,23 @@ __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, cons
       dao[r] = dot * go[r] * (1.0f - go[r]);
       dc[r] = dct * gf[r];
     }
+    // ---- LDS writes: the panel (bf16 dA: the product's operand, and what a bf16-resident plan stores), the fp32 cells
+    // otherwise, the staging of step t-1
+    __bf16* db = lds + cur * (16 * LROW);
     {
-      const __amdgpu_buffer_rsrc_t rg = slabv<ST>(gates_p, (int64_t)t * B * row4, slab_g);
-      bstv<ST>(rg, voff_g, dai); bstv<ST>(rg, voff_g + Hp * ES, daf); bstv<ST>(rg, voff_g + 2 * Hp * ES, dag); bstv<ST>(rg, voff_g + 3 * Hp * ES, dao);
+      __bf16* dp = db + bi * LROW + u0 + 4 * q;
+      *reinterpret_cast<bf16x4*>(dp) = __builtin_convertvector(dai, bf16x4);
+      *reinterpret_cast<bf16x4*>(dp + HKP) = __builtin_convertvector(daf, bf16x4);
+      *reinterpret_cast<bf16x4*>(dp + 2 * HKP) = __builtin_convertvector(dag, bf16x4);
+      *reinterpret_cast<bf16x4*>(dp + 3 * HKP) = __builtin_convertvector(dao, bf16x4);
     }
+    if constexpr (!ST) {
+      *reinterpret_cast<f32x4*>(outf + cg_l) = dai; *reinterpret_cast<f32x4*>(outf + cg_l + Hp * ES) = daf;
+      *reinterpret_cast<f32x4*>(outf + cg_l + 2 * Hp * ES) = dag; *reinterpret_cast<f32x4*>(outf + cg_l + 3 * Hp * ES) = dao;
+    }
+    deposit(P, ca);                        // c_{t-2} takes the place of c_t
+    lds_barrier();
     if constexpr (decltype(rec)::value) {
-      __bf16* db = lds + cur * (16 * LROW);
-      {
-        __bf16* dp = db + bi * LROW + u0 + 4 * q;
-        *reinterpret_cast<bf16x4*>(dp) = __builtin_convertvector(dai, bf16x4);
-        *reinterpret_cast<bf16x4*>(dp + HKP) = __builtin_convertvector(daf, bf16x4);
-        *reinterpret_cast<bf16x4*>(dp + 2 * HKP) = __builtin_convertvector(dag, bf16x4);
-        *reinterpret_cast<bf16x4*>(dp + 3 * HKP) = __builtin_convertvector(dao, bf16x4);
-      }
-      lds_barrier();
       if constexpr (decltype(swap)::value) {                  // grad wrt the step-0 input goes through W_ih only
         if (pk) load_packedT(3); else load_wT(std::integral_constant<int, 1>{});
       }
@@ -494,20 +571,27 @@ __device__ __forceinline__ void seqb_bwd_body(const SeqDev& d, const int T, cons
         a3 = mma_bf16(wT[kb + 3], v[3], a3);
       }
       dh_rec = (a0 + a1) + (a2 + a3);
-      cur ^= 1;
     }
+    cur ^= 1;
+    ci ^= 1;
   };
   // Branch-free loop entered after a peeled step with the weights already in registers: the pending-memory state on
-  // the entry edge is the back edge's ([8 prefetch loads, 4 younger stores]), see the forward body.
+  // the entry edge is the back edge's, see the forward body.
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+v"(wT[kb]));
   constexpr std::true_type yes{};
   constexpr std::false_type no{};
   if (T >= 2) {
-    step(T - 1, T - 2, yes, no);
-    for (int t = T - 2; t >= 1; --t) step(t, t - 1, yes, no);
+    step(T - 1, yes, no);
+    for (int t = T - 2; t >= 1; --t) step(t, yes, no);
   }
-  if constexpr (KIND != 0) step(0, 0, yes, yes); else step(0, 0, no, no);
+  if constexpr (KIND != 0) step(0, yes, yes); else step(0, no, no);
+  {   // dA of step 0
+    const unsigned char* src = ST ? reinterpret_cast<const unsigned char*>(lds + (cur ^ 1) * (16 * LROW)) : outf;
+    const __amdgpu_buffer_rsrc_t ro = slabv<ST>(gates_p, 0, slab_g);
+#pragma unroll
+    for (int j = 0; j < NG; ++j) bst4(ro, pg_g[j], *reinterpret_cast<const f32x4*>(src + po_l[j]));
+  }
   if (dec && bvalid && d.d_h_init) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -617,10 +701,11 @@ int seq_bf16_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
       if (d.Hp / 16 > max_waves) max_waves = d.Hp / 16;
       const size_t hkp = (size_t)((d.h + 31) / 32) * 32;
       size_t need = 2 * 16 * ((bwd ? 4 * hkp : hkp) + 8) * sizeof(__bf16);
-      if (!bwd) {      // forward: staging areas of the coalesced record write-out / x-projection fetch (seqb_fwd_body)
+      {   // staging areas of the coalesced traffic (seqb_fwd_body / seqb_bwd_body)
         const size_t es = d.store_bf16 ? 2 : 4;
         const size_t lbg = 4 * d.Hp * es + 32, lbc = d.Hp * 4 + 32, lbh = d.Hp * es + 32;
-        need += 16 * (lbg + lbc + lbh) + (kind == 0 ? 16 * lbg : 0);
+        if (!bwd) need += 16 * (lbg + lbc + lbh) + (kind == 0 ? 16 * lbg : 0);
+        else need += 16 * (lbg + 2 * lbc + lbh) + (d.store_bf16 ? 0 : 16 * lbg) + (d.dc_ext ? 16 * lbc : 0);
       }
       if (need > lds_bytes) lds_bytes = need;
     }
