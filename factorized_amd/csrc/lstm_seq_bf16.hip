@@ -31,6 +31,19 @@ namespace mfm {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// Debug build only (-DMFM_SEQB_STAMP=k, scripts/seqb_step_timeline.sh): a clock on the links of the forward step -- every wave
+// adds up, over the steps t >= 1, the shader-clock distance from the top of the step to point k (ISSUE time: s_memtime does
+// not wait for the vector pipes) and leaves the average in the last step's cell-state record (row 16 tile, unit = wave).
+// Points: 1 LDS reads returned, 2 first barrier passed, 3 global loads + stores issued, 4 recurrent product issued, 5 gates /
+// c / h computed, 6 LDS writes done (incl. the wait for the prefetched x-projection), 7 second barrier passed.
+#ifndef MFM_SEQB_STAMP
+#define MFM_SEQB_STAMP 0
+#endif
+#if MFM_SEQB_STAMP
+#define SEQB_PT(k, ...) do { if (MFM_SEQB_STAMP == (k)) { __VA_ARGS__; stamp1 = __builtin_readcyclecounter(); } } while (0)
+#else
+#define SEQB_PT(k, ...) do { } while (0)
+#endif
 
 __device__ __forceinline__ f32x4 ld4b(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4b(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
@@ -236,7 +249,14 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
   int cur = 0;
   // `wo`: bytes of the slabs that receive step t-1's record (0 at the first step: the stores are issued and dropped, so that
   // every step has the same list of pending memory operations -- see the note on counted waits in the backward body)
+#if MFM_SEQB_STAMP
+  unsigned long long stamp0 = 0, stamp1 = 0, stamp_sum = 0;
+#endif
   auto step = [&](const int t, auto rec) {
+#if MFM_SEQB_STAMP
+    stamp0 = __builtin_readcyclecounter();
+    stamp1 = stamp0;
+#endif
     // ---- LDS reads
     f32x4 acc[4];
 #pragma unroll
@@ -256,7 +276,9 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) hv[kb] = *reinterpret_cast<const bf16x8*>(hb + kb * 32);
     }
+    SEQB_PT(1, asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"));
     lds_barrier();
+    SEQB_PT(2, asm volatile("" ::: "memory"));
     // ---- global: next step's x-projection first (it is waited for at the end of this step; the stores stay younger)
     f32x4 gxn[NG];
     if constexpr (KIND == 0) {
@@ -275,6 +297,7 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
       if constexpr (ST) __builtin_amdgcn_raw_buffer_store_b64(oh, rh, ph_g, 0, 0);
       else bst4(rh, ph_g, oh);
     }
+    SEQB_PT(3, asm volatile("" ::: "memory"));
     // ---- recurrent product, gates
     if constexpr (decltype(rec)::value) {
 #pragma unroll
@@ -282,6 +305,7 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = mma_bf16(w[g][kb], hv[kb], acc[g]);
     }
+    SEQB_PT(4, asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])));
     f32x4 gi, gf, gg, go, cv, hn4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -294,6 +318,7 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
       hn4[r] = go[r] * act_tanh(c[r]);
     }
     h_keep = hn4;
+    SEQB_PT(5, asm volatile("" : "+v"(hn4), "+v"(gi), "+v"(gf), "+v"(gg), "+v"(go)));
     // ---- LDS writes: h_t for the product, the record for the write-out, the next x-projection
     {
       const f32x4 hz = (b < B) ? hn4 : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -311,7 +336,12 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
 #pragma unroll
       for (int j = 0; j < NG; ++j) *reinterpret_cast<f32x4*>(ing + pg_l[j]) = gxn[j];
     }
+    SEQB_PT(6, asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"));
     lds_barrier();
+    SEQB_PT(7, asm volatile("" ::: "memory"));
+#if MFM_SEQB_STAMP
+    if (t >= 1) stamp_sum += stamp1 - stamp0;
+#endif
     cur ^= 1;
   };
   // the weights are in registers before the loop: a load still pending on the entry edge is waited for inside the
@@ -332,6 +362,10 @@ __device__ __forceinline__ void seqb_fwd_body(const SeqDev& d, const int T, cons
   }
   touch_w();
   for (int t = 1; t < T; ++t) step(t, std::true_type{});
+#if MFM_SEQB_STAMP
+  if (T > 1) *reinterpret_cast<float*>(outc + (wave >> 2) * 0 + 0 * LBc + wave * 4) = (float)stamp_sum / (float)(T - 1);   // row 0, unit = wave
+  lds_barrier();
+#endif
   {   // the last step's record
     const __amdgpu_buffer_rsrc_t rg = slabv<ST>(gates_p, (int64_t)(T - 1) * B * row4, slab_g);
     const __amdgpu_buffer_rsrc_t rc = slab(cs_p, (int64_t)(T - 1) * B * Hp, slab_h);

@@ -11,8 +11,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-POINTS = {1: "x-projection consumed, next requested", 2: "h_{t-1} read from LDS", 3: "recurrent product done",
-          4: "gates, c, h computed", 5: "h_t to LDS + global stores issued", 6: "LDS write acknowledged", 7: "barrier passed"}
+POINTS = {1: "LDS reads returned (x-proj, record, h)", 2: "first barrier passed", 3: "global loads + stores issued",
+          4: "recurrent product issued", 5: "gates, c, h computed", 6: "LDS writes done (+ prefetch waited for)", 7: "second barrier passed"}
 
 CHILD = r"""
 import json, os, sys
