@@ -750,10 +750,13 @@ int seq_bf16_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
       MFM_REQUIRE((K.d[i].store_bf16 != 0) == st, "lstm_seq (bf16): the LSTMs of one launch must agree on store_bf16");
 #define MFM_SEQB_GO(BWD_, KIND_)                                                                                          \
   do {                                                                                                                    \
-    if (lds_bytes > 64 * 1024) {                                                                                          \
+    static bool big_lds = false;                 /* (once per instantiation and process: not a stream operation) */       \
+    if (lds_bytes > 64 * 1024 && !big_lds) {                                                                              \
       MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_bf16_kernel<BWD_, KIND_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
       MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_bf16_kernel<BWD_, KIND_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      big_lds = true;                                                                                                     \
     }                                                                                                                     \
+    MFM_REQUIRE(lds_bytes <= 160 * 1024, "lstm_seq (bf16): %zu bytes of LDS", lds_bytes);                                 \
     if (st) hipLaunchKernelGGL((lstm_seq_bf16_kernel<BWD_, KIND_, true>), grid, block, lds_bytes, stream, K);             \
     else hipLaunchKernelGGL((lstm_seq_bf16_kernel<BWD_, KIND_, false>), grid, block, lds_bytes, stream, K);               \
   } while (0)
