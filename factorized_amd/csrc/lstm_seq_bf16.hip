@@ -14,7 +14,10 @@
 //     step and the resident weights from 120 to 64 VGPRs;
 //   * the exchange panel is [16 rows][K] bf16 with K contiguous, so a lane's MFMA B fragment (8 consecutive
 //     k of one batch row) is ONE ds_read_b128 and its four new h values are ONE ds_write_b64; rows are
-//     padded by 16 bytes, which spreads the 16 rows of a fragment read over all 64 banks.
+//     padded by 16 bytes, which spreads the 16 rows of a fragment read over all 64 banks;
+//   * round 5: the step's global traffic is COALESCED through LDS staging (a tile's 16 rows are contiguous in every
+//     slab): see the note in seqb_fwd_body; the waves a launch has beyond an LSTM's Hp / 16 leave after the prologue;
+//     the time loops are branch-free and entered after a peeled step so that every vmcnt wait is a counted one.
 // The k index of a fragment element is (k-block, lane >> 4, j); A and B fragments are built with the same
 // convention, and the MFMA sums over all of k, so the result does not depend on the hardware's internal
 // k order.
@@ -57,12 +60,11 @@ __device__ __forceinline__ f32x4 mma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// Global traffic of the time loops goes through BUFFER instructions on one-time-step slabs: a lane that has nothing
-// to load or store (batch row >= B, idle wave) is given an offset at the end of the slab, which the hardware
-// range check turns into "load 0" / "drop the store".  So no memory instruction of a step sits under a branch, and
-// the compiler can count: the wait for the NEXT step's prefetched activations becomes vmcnt(#younger stores) instead
-// of vmcnt(0) -- with branches around them every step waited for its own stores to be acknowledged (~1 us each:
-// the first version of this file ran 1.95 us per step at h = 120, this one ~0.7).
+// Global traffic of the time loops goes through BUFFER instructions on one-time-step slabs: a piece that has nothing
+// to load or store (batch row >= B, the first / last step's absent neighbour) falls beyond the end of the slab (or the
+// slab is given 0 bytes), which the hardware range check turns into "load 0" / "drop the store".  So no memory
+// instruction of a step sits under a branch, every step issues the same list of them, and the compiler can count: the
+// wait for the NEXT step's prefetched pieces is vmcnt(#younger stores) instead of vmcnt(0).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t slab(const float* base, int64_t elem_off, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)(base + elem_off), 0, bytes, 0x00020000);
