@@ -12,7 +12,7 @@ from factorized_amd import _lib, configs, engine, synth  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 cfgs = configs.canonical_configs()
-e = engine.MFMEngine(cfgs)
+e = engine.MFMEngine(cfgs, precision=os.environ.get("MFM_PHASES_PRECISION", "fp32"))
 e.load_weights(synth.make_weights(e.layout.shapes))
 xn, yn = synth.make_batch(cfgs[0]["input_dims"], B, 20)
 x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
