@@ -58,6 +58,7 @@ class P2PAllReduce:
             h = C.c_void_p()
             _lib.check(L.mfm_p2p_create(world, rank, self.max_elems, C.byref(h)), "mfm_p2p_create")
             self._h = h
+            self._pid = os.getpid()
             if world > 1:
                 nb = L.mfm_p2p_handle_bytes()
                 buf = C.create_string_buffer(nb)
@@ -130,7 +131,8 @@ class P2PAllReduce:
 
     def close(self):
         if self._h is not None:
-            self._L.mfm_p2p_destroy(self._h)
+            if getattr(self, "_pid", None) == os.getpid():     # (not from a forked child: see engine._Plan.__del__)
+                self._L.mfm_p2p_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -275,6 +275,7 @@ class _Plan:
         _lib.check(_lib.lib().mfm_plan_create(C.byref(pc), offs, engine.layout.total, C.byref(handle)),
                    "mfm_plan_create")
         self.handle = handle
+        self._pid = os.getpid()          # a forked child (DataLoader worker, multiprocessing.Manager) must not tear the plan down
         self.T, self.B = T, B
         nbytes = _lib.lib().mfm_plan_workspace_bytes(handle)
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=engine.device)
@@ -335,10 +336,13 @@ class _Plan:
         return int(v.value)
 
     def __del__(self):
+        # Only the process that created the plan destroys it: in a forked child the HIP runtime the handle points into is not
+        # usable (a garbage collection there used to end the child with a segmentation fault inside mfm_plan_destroy --
+        # seen as an EOFError of multiprocessing.Manager() in a process that holds live engines).
         try:
-            if self.handle:
+            if self.handle and getattr(self, "_pid", None) == os.getpid():
                 _lib.lib().mfm_plan_destroy(self.handle)
-                self.handle = None
+            self.handle = None
         except Exception:
             pass
 

@@ -186,3 +186,36 @@ def test_mfn_model_input_gradient_matches_oracle():
     err = rel_err(xd.grad.cpu().numpy(), xr.grad.numpy())
     cases.report("mfm_kl_dx_rel", err)
     assert err < TOL
+
+
+def test_forked_child_does_not_tear_down_the_parents_plans():
+    """A reference driver forks with live engines around (DataLoader workers, multiprocessing.Manager): the child inherits
+    the Python objects but not a usable HIP runtime, and a garbage collection there must not run mfm_plan_destroy on the
+    parent's handles (it used to end the child with a segmentation fault)."""
+    import gc
+    import os
+    _need_gpu()
+    from factorized_amd import configs, engine
+    cfgs = configs.canonical_configs(dropout=False)
+    e = engine.MFMEngine(cfgs)
+    e.load_weights(synth.make_weights(e.layout.shapes))
+    xn, yn = synth.make_batch(cfgs[0]["input_dims"], 8, 5)
+    x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
+    e.train_step(x, y)
+    torch.cuda.synchronize()
+    plan = e.plan(5, 8)
+    assert plan.handle
+    pid = os.fork()
+    if pid == 0:                                   # child: drop every plan and collect; no HIP call may happen
+        try:
+            for p in list(getattr(e, "_plans", {}).values()):
+                p.__del__()
+            gc.collect()
+        finally:
+            os._exit(0)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
+    # the parent's plan is untouched
+    e.train_step(x, y)
+    torch.cuda.synchronize()
+    assert e.check_status() == 0 and plan.handle
