@@ -140,7 +140,7 @@ def _dp_trace(ret, world, variant):
 def test_hip_data_parallel_step_equals_oracle_on_global_batch(world, fused):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()       # not a fork: the parent holds live GPU state (a GC in a forked child frees it there)
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), fused, ret), nprocs=world, join=True)
     for r in range(world):
@@ -190,7 +190,7 @@ def test_hip_data_parallel_step_mfn_variants(variant, world, fused):
     section 6), which is what the oracle forms here."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()       # not a fork: the parent holds live GPU state (a GC in a forked child frees it there)
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), fused, ret, variant, "fp32"), nprocs=world, join=True)
     for r in range(world):
@@ -239,7 +239,7 @@ def test_hip_data_parallel_step_bf16(variant, world, fused):
     within 8e-2 relative L2 of the fp32 oracle on the global batch, loss curve within 2e-3, replicas bit-identical."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()       # not a fork: the parent holds live GPU state (a GC in a forked child frees it there)
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), fused, ret, variant, "bf16"), nprocs=world, join=True)
     for r in range(world):

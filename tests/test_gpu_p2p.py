@@ -109,7 +109,7 @@ def _worker(rank, world, port, sizes, ret):
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_p2p_allreduce_matches_reference_sum(world):
     sizes = [477294, 4, 1, 1003, 262144]        # the MFM_KL_EF gradient buffer, tiny, ragged and aligned sizes
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()       # not a fork: the parent holds live GPU state (a GC in a forked child frees it there)
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), sizes, ret), nprocs=world, join=True)
     for r in range(world):
@@ -147,7 +147,7 @@ def _lonely(rank, world, port, ret):
 
 
 def test_p2p_missing_peer_times_out_instead_of_hanging():
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()       # not a fork: the parent holds live GPU state (a GC in a forked child frees it there)
     ret = mgr.dict()
     mp.spawn(_lonely, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert ret["timed_out"] is True
