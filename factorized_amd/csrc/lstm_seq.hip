@@ -366,13 +366,15 @@ static bool use_small_path(int B) {
 }
 
 // bf16 MFMA recurrences (lstm_seq_bf16.hip) work on 16-row batch tiles: 128 x 16 cells of gate math per workgroup and
-// step (~2 us per step at h = 120, VALU-bound), whatever B is.  Below ~190 rows the chip is better used by the
-// fp32 VALU kernels' one-row workgroups (0.8 us per step, and exact fp32 products), so a bf16 plan keeps its
-// recurrences on those until B reaches MFM_BF16_SEQ_MINB (default 192; measured crossover between B = 128 and 256,
-// profiles/r02_batch_sweep_mosi.txt).  The bf16 entry points of the ABI always run the bf16 kernels.
+// step (~1.4 us per step at h = 120 since the round-5 coalescing, 2.1 before), whatever B is.  Below ~128 rows the chip is
+// better used by the fp32 VALU kernels' one-row workgroups (0.8 us per step, and exact fp32 products), so a bf16 plan keeps
+// its recurrences on those until B reaches MFM_BF16_SEQ_MINB (default 128, with bf16-resident activations from the same
+// size, plan_build.hip; round 2-4: 192).  Measured, MOSI sizes, ms per step, MFMA + resident vs one-row fp32 kernels:
+// B = 112: 0.2735 vs 0.2631, 128: 0.2749 vs 0.2785, 144: 0.2786 vs 0.3247, 160: 0.2803 vs 0.3419, 176: 0.2838 vs 0.3612.
+// The bf16 entry points of the ABI always run the bf16 kernels.
 bool bf16_seq_pays(int B) {
   const char* e = opt_get("MFM_BF16_SEQ_MINB");
-  return B >= (e ? atoi(e) : 192);
+  return B >= (e ? atoi(e) : 128);
 }
 
 struct FoldArgs { const LatentDev* lat; const float* params; float* grads; ProjRole* pr; DwRole* dr; const float* const* wt_imgs;

@@ -65,13 +65,14 @@ int build(MfmPlan* P) {
   // weight-gradient kernel takes (dw_bf16.hip); MFM_BF16_STORE=0 keeps the round-2 form (fp32 buffers, rounding on load).
   P->seq_bf16 = c.precision && bf16_seq_pays(c.B);
   {
-    // default from T*B = 3840 rows (B = 192 at T = 20: where the bf16 recurrences start).  Measured at the MOSI sizes
+    // default from T*B = 2560 rows (B = 128 at T = 20: where the bf16 recurrences start since round 5; at B = 144 the bf16
+    // recurrences WITHOUT bf16-resident buffers are 0.3193 ms, with them 0.2786).  Rounds 2-4: 3840.  Measured at the MOSI sizes
     // (bf16-resident vs fp32-stored, ms per step; B = 192 / 256 / 384 / 512 / 768 / 1024): 0.366 vs 0.377, 0.377 vs 0.418,
     // 0.406 vs 0.471, 0.418 vs 0.521, 0.450 vs 0.603, 0.481 vs 0.706 (round 2: crossover at T*B = 16384; then proj_bf16.hip, the
     // 64-row decoder fc1 and whole rounds of workgroups in the one-pass weight-gradient launch); MFM_BF16_STORE=1 forces it
     // on for every size, =0 off
     const char* se = opt_get("MFM_BF16_STORE");
-    long st_minrows = 3840;
+    long st_minrows = 2560;
     if (const char* e = opt_get("MFM_BF16_STORE_MINROWS")) st_minrows = atol(e);
     bool ok = P->seq_bf16 && !opt_get("MFM_SEQ_STEPWISE") && (se ? atoi(se) != 0 : TB >= st_minrows);
     const int Dp = round_up(c.d_l, 16) + round_up(c.d_a, 16) + round_up(c.d_v, 16);

@@ -498,9 +498,9 @@ def _bf16_engine(cfgs):
 
 @pytest.fixture(params=["all-bf16", "default", "default+dot2", "all-bf16+panel", "all-bf16+panel160", "all-bf16+panel96", "all-bf16+proj128", "all-bf16+proj64", "all-bf16+fc1r16", "all-bf16+tnsplit", "all-bf16+dwmf4"])
 def seq_policy(request, monkeypatch):
-    """a bf16 plan runs its recurrences on the bf16 MFMA kernels from B = 192 on and on the fp32 VALU kernels below
+    """a bf16 plan runs its recurrences on the bf16 MFMA kernels from B = 128 on and on the fp32 VALU kernels below
     (lstm_seq.hip::bf16_seq_pays); 'all-bf16' forces the bf16 kernels at every batch size."""
-    # "dot2": below B = 192 the decoders' one-row forward recurrence takes its product on v_dot2c_f32_bf16 (plan option
+    # "dot2": below B = 128 the decoders' one-row forward recurrence takes its product on v_dot2c_f32_bf16 (plan option
     # "bf16_dot"; opt-in: measured no faster than the fp32 FMAs, profiles/r04_bf16_onerow.txt)
     if "dot2" in request.param:
         monkeypatch.setenv("MFM_BF16_DOT", "1")
@@ -631,7 +631,7 @@ def test_bf16_loss_curve_tracks_fp32_reference(name, seq_policy):
 
 
 def test_bf16_resident_plan_selection_and_stored_dtypes(monkeypatch):
-    """which bf16 plans keep their saved activations as bf16 (default: from T*B = 3840 rows), and that the buffers really
+    """which bf16 plans keep their saved activations as bf16 (default: from T*B = 2560 rows), and that the buffers really
     hold bf16: hs[T-1] is the bf16 rounding of the fp32 h_{T-1} copy the latent stack reads, the gates are activations"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -640,7 +640,7 @@ def test_bf16_resident_plan_selection_and_stored_dtypes(monkeypatch):
     monkeypatch.delenv("MFM_BF16_SEQ_MINB", raising=False)
     cfgs = configs.canonical_configs(dropout=False)
     cfg = cfgs[0]
-    for prec, B, T, want in (("bf16", 32, 20, False), ("bf16", 128, 20, False), ("bf16", 192, 20, True), ("bf16", 1024, 20, True), ("fp32", 1024, 20, False)):
+    for prec, B, T, want in (("bf16", 32, 20, False), ("bf16", 112, 20, False), ("bf16", 128, 20, True), ("bf16", 192, 20, True), ("bf16", 1024, 20, True), ("fp32", 1024, 20, False)):
         e = engine.MFMEngine(cfgs, precision=prec)
         e.load_weights(synth.make_weights(e.layout.shapes, seed=1234))
         xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7)
@@ -648,7 +648,7 @@ def test_bf16_resident_plan_selection_and_stored_dtypes(monkeypatch):
         e.forward(x, y, train=True, want_xhat=False)
         sb = e.seq_buffers(T, B, 3)                      # the early-fusion encoder
         assert sb["bf16_resident"] == want, (prec, B)
-        assert sb["bf16_recurrence"] == (prec == "bf16" and B >= 192)
+        assert sb["bf16_recurrence"] == (prec == "bf16" and B >= 128)
         if want:
             assert sb["hs"].dtype == torch.bfloat16 and sb["gates"].dtype == torch.bfloat16 and sb["cs"].dtype == torch.float32
             h = sb["h"]

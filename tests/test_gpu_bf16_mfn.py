@@ -1,7 +1,7 @@
 """bf16 plans of MFM_KL / MFM (round-2 review: `MFMEngine(cfgs, precision="bf16", variant="kl" | "mmd")` was a supported
 plan with no numeric evidence).  On a bf16 plan the Memory Fusion Network's attention products run on the bf16-operand
 grouped GEMM with their relu+dropout-mask / tanh / mask / accumulate epilogues, the heads on [h_T | mem_T] as accumulating
-bf16 GEMM segments, and -- from B = 192, or always under MFM_BF16_SEQ_MINB=1 -- all six encoder recurrences on the bf16
+bf16 GEMM segments, and -- from B = 128, or always under MFM_BF16_SEQ_MINB=1 -- all six encoder recurrences on the bf16
 MFMA kernels (the three MFN LSTMs with their per-step cell-state gradient input `dc_ext`).
 
 Bounds are those of tests/test_gpu_bf16.py ("matched loss curve vs fp32, not 1e-4"): loss terms
