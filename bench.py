@@ -293,7 +293,7 @@ def main():
                          "note": ("fp32 matrix peak == fp32 vector peak on gfx950 (157.3 TF); at B<=512 the "
                                   "recurrent products run on the VALU small-tile kernels, above on the MFMA")
                          if args.dtype == "fp32" else
-                         ("dense bf16 MFMA peak; GEMMs and, from B=192, the recurrences feed v_mfma_f32_16x16x32_bf16 (below: fp32 one-row "
+                         ("dense bf16 MFMA peak; GEMMs and, from B=128, the recurrences feed v_mfma_f32_16x16x32_bf16 (below: fp32 one-row "
                           "VALU recurrences; decoder fc1 up to 5120 rows: bf16-rounded operands on the fp32 MFMA)"),
                          "kernel_us": round(1e3 * k_ms, 2), "kernel_us_event_bracket": round(1e3 * k_raw_ms, 2),
                          "empty_bracket_us": round(1e3 * ev_ms, 2), "kernel_launches_timed": timed["count"],
