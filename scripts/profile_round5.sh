@@ -45,6 +45,6 @@ python scripts/bench_seq_group.py > $O/seq_group.txt 2>&1
 python scripts/bench_seq_bf16.py 2048 > $O/seq_bf16_B2048.txt 2>&1
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29532 scripts/bench_p2p.py --one-device 2>/dev/null | tail -1 > $O/p2p_one_device.txt
 MFM_P2P_GENERIC=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29542 scripts/bench_p2p.py --one-device 2>/dev/null | tail -1 >> $O/p2p_one_device.txt
-MFM_BENCH_ONE_DEVICE=1 MFM_P2P_TIMEOUT_MS=20000 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 200 --warmup 20 $NB > $O/bench_dp2_one_device.json 2>/dev/null
+MFM_BENCH_ONE_DEVICE=1 MFM_P2P_TIMEOUT_MS=20000 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 200 --warmup 20 $NB 2>/dev/null | grep "^{" > $O/bench_dp2_one_device.json
 rm -rf $O/*/*.db $O/*/*.db.tmp $O/*/*.csv
 ls -la $O; head -14 $O/kernel_stats_h32.txt; head -30 $O/roofline_table_h32.txt; cut -c1-260 $O/bench_B32_400.json; cat $O/batch_sweep.txt; cat $O/graphed_steps.txt | tail -14
