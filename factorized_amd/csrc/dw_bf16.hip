@@ -510,7 +510,12 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
   // us at 0.5 / 0.75 / 1 / 2 x CUs workgroups: 56 / 59 / 89 / 99, 94 / 73 / 106 / 107, 175 / 122 / 145 / 125, 335 / 229 / 267 / 173:
   // "1 x CUs" came out at a few workgroups more than CUs and ran two rounds).  MFM_DWB_TARGET = workgroups / CUs (no fitting).
   const int cus = device_cus();
-  const int rounds = L.rows <= 32768 ? 1 : 2;
+  // Round 5 (after the recurrences got shorter the launch was measured again, MFM_DWB_TARGET sweep, ms per step, 1 / 2 / 3 rounds):
+  // 128-column tiles (MOSI sizes):  T*B = 40960: 0.5646 / 0.5870 / 0.5833,  81920: 0.9817 / 1.0073 / 1.0238 -> ONE round
+  // (half the partial tiles: 35 instead of 71 MB of slabs written and read back);  96-column tiles (MOSEI / YouTube sizes,
+  // right-hand sides wider than 512): T*B = 51200: 0.8451 / 0.8313 / 0.8411, 102400: 1.3404 / 1.2998 / 1.3144 -> two rounds
+  // above 32768 rows, as before.
+  const int rounds = (L.rows <= 32768 || wide) ? 1 : 2;                 // (81920 rows run the atomics form: measured with it)
   const char* tenv = opt_get("MFM_DWB_TARGET");
   int tiles = 0;
   size_t smem = 0;
