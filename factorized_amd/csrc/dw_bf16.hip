@@ -490,10 +490,12 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
   const char* slab_env = opt_get("MFM_DWB_SLABS");
   const bool slab_req = L.slabs != nullptr && !L.f32 && (slab_env ? atoi(slab_env) != 0 : L.rows <= 65536);
   bool wide = !L.f32 && mf_env != 3 && (mf_env == 4 || L.rows >= (slab_req ? 8192 : 65536));
+  bool wide9 = false;
   for (int i = 0; i < L.n_items && wide; ++i) {
     int N = 0;
     for (int s = 0; s < L.it[i].nseg; ++s) N += L.it[i].seg[s].ncols;
-    wide = N <= 16 * 4 * 8 && (DWB_KC * (128 + N) / 8 + DWB_THREADS - 1) / DWB_THREADS <= DWB_MAXNI;
+    wide = N <= 16 * 4 * 9 && (DWB_KC * (128 + N) / 8 + DWB_THREADS - 1) / DWB_THREADS <= DWB_MAXNI;
+    if (N > 16 * 4 * 8) wide9 = true;              // right-hand sides of 513-576 columns: the (4, 9) instantiation
   }
   const int MT = wide ? 128 : DWB_MT;
   for (int i = 0; i < L.n_items; ++i) {
@@ -512,9 +514,10 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
   const int cus = device_cus();
   // Round 5 (after the recurrences got shorter the launch was measured again, MFM_DWB_TARGET sweep, ms per step, 1 / 2 / 3 rounds):
   // 128-column tiles (MOSI sizes):  T*B = 40960: 0.5646 / 0.5870 / 0.5833,  81920: 0.9817 / 1.0073 / 1.0238 -> ONE round
-  // (half the partial tiles: 35 instead of 71 MB of slabs written and read back);  96-column tiles (MOSEI / YouTube sizes,
-  // right-hand sides wider than 512): T*B = 51200: 0.8451 / 0.8313 / 0.8411, 102400: 1.3404 / 1.2998 / 1.3144 -> two rounds
-  // above 32768 rows, as before.
+  // (half the partial tiles: 35 instead of 71 MB of slabs written and read back).  The MOSEI / YouTube sizes (right-hand sides of
+  // 544 columns) then got a (4, 9) instantiation of the 128-column form -- 232 VGPRs, no spills -- instead of 96-column tiles in
+  // two rounds: MOSEI T = 50 B = 1024 0.833 -> 0.811 ms, YouTube T = 50 B = 2048 1.300 -> 1.258 ms, MOSEI T = 20 B = 2048
+  // 0.656 -> 0.631 ms.  96-column tiles (right-hand sides beyond 576 columns) keep two rounds above 32768 rows.
   const int rounds = (L.rows <= 32768 || wide) ? 1 : 2;                 // (81920 rows run the atomics form: measured with it)
   const char* tenv = opt_get("MFM_DWB_TARGET");
   int tiles = 0;
@@ -573,6 +576,7 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
   if (!attr) {
     MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_stream_kernel<false, 3, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_stream_kernel<false, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_stream_kernel<false, 4, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_stream_kernel<true, 3, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
@@ -581,6 +585,7 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
   // GEMM) against 626 us for the grouped GEMM: its main loop keeps the fp32 matrix pipe ~43 % busy (one ds_read_b32 and its
   // wait per three MFMAs; batching a k-step's reads ahead of its MFMAs made it 779 us) -> opt-in, MFM_DW_F32_MINROWS
   if (L.f32) hipLaunchKernelGGL((dw_stream_kernel<true, 3, 9>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
+  else if (wide && wide9) hipLaunchKernelGGL((dw_stream_kernel<false, 4, 9>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
   else if (wide) hipLaunchKernelGGL((dw_stream_kernel<false, 4, 8>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
   else hipLaunchKernelGGL((dw_stream_kernel<false, 3, 9>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
   MFM_LAUNCH_CHECK("dw_stream_kernel");
@@ -592,9 +597,9 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
 }
 
 int64_t dw_bf16_scratch_floats(int64_t rows) {
-  // one workgroup per CU and round, every partial tile at most 128 x (512 + 16) or 96 x (576 + 16) floats
+  // one workgroup per CU and round, every partial tile at most 128 x (576 + 16) floats
   const int64_t rounds = rows <= 32768 ? 1 : 2;
-  return rounds * device_cus() * (int64_t)128 * 528;
+  return rounds * device_cus() * (int64_t)128 * 592;
 }
 
 }  // namespace mfm
