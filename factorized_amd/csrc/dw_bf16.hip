@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 
 #include "internal.h"
 
@@ -46,6 +47,9 @@ constexpr int DWB_KC = 32;                      // rows per chunk = one MFMA k-b
 constexpr int DWB_MIN_STAGES = 3, DWB_MAX_STAGES = 12;    // chunks of LDS an item rotates through (DwbItem::stages)
 constexpr int DWB_MAX_WAIT = 24;                           // largest counted vmcnt wait: (stages - 2) x instructions per chunk
 constexpr int DWB_MAXNI = 6;                    // LDS-DMA instructions per thread and chunk
+#ifndef DWB_STAGGER
+#define DWB_STAGGER 1                           // bf16 form: half of the waves issue the next chunk's DMA after their MFMAs (see the chunk loop)
+#endif
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lds_base, int off, int row16_bytes) {
   // two transposing reads: rows [0,16) and [16,32) of the chunk, 4 k each for this lane
@@ -63,31 +67,52 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* lds_base, int off
 // MF: A fragments per wave (the workgroup owns MT = 32 MF columns of A), NFW: N fragments per wave (N <= 64 NFW).  (3, 9) is the
 // general form; (4, 8) -- 128-column M-tiles, N <= 512 -- re-reads the right-hand side once per 128 instead of once per 96
 // columns of A and has no half-empty last tile for M = 128 / 256 / 512 (the launcher picks it when every item fits).
-template <bool F32, int MF, int NFW>
-__global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch L) {
-  constexpr int MT = 2 * 16 * MF;
-  constexpr int ES = F32 ? 4 : 2;                 // bytes per operand element
-  constexpr int EPP = 16 / ES;                    // elements per 16-byte DMA piece
-  constexpr int KC = F32 ? 16 : DWB_KC;           // rows per chunk
-  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-
-  // ---- XCD-aware order: workgroup b runs on XCD b % 8; the M-tiles of one (item, row range) become consecutive
-  // workgroups of ONE XCD, so the right-hand side they all stream is fetched from HBM once and then hits that L2
+// ---- which tile a workgroup owns.  XCD-aware order: workgroup b runs on XCD b % 8; the tiles of one (item, row range) -- every
+// M-tile of every column part -- become consecutive workgroups of ONE XCD, so the operands they share are fetched from HBM once
+// and then hit that L2.
+struct DwbTile { int item, mt, sp, local; };
+__device__ __forceinline__ DwbTile dwb_tile(const DwbLaunch& L) {
   int v;
   {
     const int nb = (int)gridDim.x, x = (int)blockIdx.x % 8, j = (int)blockIdx.x / 8;
     const int per = nb / 8, rem = nb % 8;
     v = x * per + (x < rem ? x : rem) + j;
   }
-  int it = 0;
+  int head = 0;                                    // (entries with part > 0 carry tile_begin = INT_MAX: never picked here)
 #pragma unroll
-  for (int i = 1; i < MFM_DWB_MAXI; ++i) it += (i < L.n_items && v >= L.it[i].tile_begin) ? 1 : 0;
-  const DwbItem& I = L.it[it];
-  const int local = v - I.tile_begin;
-  const int mt = local % I.m_tiles, sp = local / I.m_tiles;
+  for (int i = 1; i < MFM_DWB_MAXI; ++i) head = (i < L.n_items && v >= L.it[i].tile_begin) ? i : head;
+  const DwbItem& H = L.it[head];
+  const int vv = v - H.tile_begin, per = H.parts * H.m_tiles;
+  DwbTile t;
+  t.sp = vv / per;
+  const int rem = vv - t.sp * per, part = rem / H.m_tiles;
+  t.mt = rem - part * H.m_tiles;
+  // (integer division runs on the vector ALU: back into scalar registers, or everything derived from the entry -- the LDS
+  // addresses that go into M0 -- would be vector values)
+  t.sp = __builtin_amdgcn_readfirstlane(t.sp);
+  t.mt = __builtin_amdgcn_readfirstlane(t.mt);
+  t.item = __builtin_amdgcn_readfirstlane(head + part);
+  t.local = t.sp * H.m_tiles + t.mt;               // index of the partial tile inside its entry (slab form)
+  return t;
+}
+
+template <bool F32, int MF, int NFW>
+__device__ __forceinline__ void dw_stream_body(const DwbLaunch& L, const DwbItem& I, const int mt, const int sp, const int local) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  constexpr int MT = 2 * 16 * MF;
+  constexpr int ES = F32 ? 4 : 2;                 // bytes per operand element
+  constexpr int EPP = 16 / ES;                    // elements per 16-byte DMA piece
+  constexpr int KC = F32 ? 16 : DWB_KC;           // rows per chunk
+#ifdef MFM_DWB_STAMP
+  const long long st_kernel = __builtin_readcyclecounter();
+#endif
   const int m0 = mt * MT;
   const int r_begin = sp * I.rows_per_split, r_end = min(L.rows, r_begin + I.rows_per_split);
-  const int n_chunks = (r_end - r_begin + KC - 1) / KC;
+  // rows per chunk: KC x (k-blocks per chunk).  A chunk costs ~0.9 k cycles of waits and barriers plus ~0.5 k per DMA instruction
+  // whatever its width, so narrow items (a decoder's [32 rows][128 + 32 columns] is 10 KB) take 64 or 128 rows per chunk.
+  const int kpc = F32 ? 1 : I.kpc;
+  const int KR = KC * kpc;
+  const int n_chunks = (r_end - r_begin + KR - 1) / KR;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -96,7 +121,7 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
 
   // ---- chunk image in LDS, in DMA piece order (16 bytes per piece, lane-linear): A [32][96] | seg0 [32][n0] | seg1 [32][n1]
   const int n0 = I.seg[0].ncols, n1 = (I.nseg > 1) ? I.seg[1].ncols : 0;
-  const int pa = KC * MT / EPP, p0 = KC * n0 / EPP, p1 = KC * n1 / EPP;            // pieces; each a multiple of 64
+  const int pa = KR * MT / EPP, p0 = KR * n0 / EPP, p1 = KR * n1 / EPP;            // pieces; each a multiple of 64
   const int P = pa + p0 + p1;
   const int NI = (P + DWB_THREADS - 1) / DWB_THREADS;
   const int stage_bytes = NI * DWB_THREADS * 16;
@@ -111,12 +136,22 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
   // must read as zero -- rows of A at or beyond r_end, rows of h_{t-1} before the first time step, rows past the end of a
   // segment, columns past a row's end, idle lanes of the last instruction -- is pointed at a 16-byte block of zeros.
   const unsigned char* src[DWB_MAXNI];
-  int inc[DWB_MAXNI], row0[DWB_MAXNI], lo[DWB_MAXNI], hi[DWB_MAXNI];      // valid when lo <= row0 + 32 chunk < hi
+  // a piece is valid while its row, row0 + (rows per chunk) x chunk, lies in [0, hi): kept as the chunk range [first, first + count)
+  // packed into one register, vld = first | count << 16 (a row range has < 65536 chunks)
+  int inc[DWB_MAXNI];
+  unsigned vld[DWB_MAXNI];
+  auto chunk_range = [&](int row0, int hi) -> unsigned {
+    // chunks c with 0 <= row0 + KR c < hi
+    const int first = row0 >= 0 ? 0 : (-row0 + KR - 1) / KR;
+    const int end = hi > row0 ? (hi - row0 + KR - 1) / KR : 0;              // first chunk with row >= hi
+    const int count = end > first ? min(end - first, 65535) : 0;
+    return (unsigned)min(first, 65535) | ((unsigned)count << 16);
+  };
   const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(L.zeros);
 #pragma unroll
   for (int i = 0; i < DWB_MAXNI; ++i) {
     const int p = i * DWB_THREADS + tid;
-    src[i] = zsrc; inc[i] = 0; row0[i] = 0; lo[i] = 1; hi[i] = 0;          // never valid
+    src[i] = zsrc; inc[i] = 0; vld[i] = 0;                      // never valid
     // F32: the column groups of odd slab rows are rotated by 4 pieces (16 floats): LDS position c of row `row` holds source
     // group (c + 4 (row & 1)) mod groups-per-row (bank spreading for the b32 fragment reads, see the kernel comment)
     const unsigned char* abase = reinterpret_cast<const unsigned char*>(I.a);
@@ -126,7 +161,7 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
       const int cg = F32 ? (cpos + 4 * (row & 1)) % GPR : (cpos + bf_rot(MT, row)) % GPR;
       if (m0 + cg * EPP < I.lda) {                        // columns past the row end: zeros, not the next row's data
         src[i] = abase + ((int64_t)(r_begin + row) * I.lda + m0 + cg * EPP) * ES;
-        inc[i] = KC * I.lda * ES; row0[i] = r_begin + row; lo[i] = 0; hi[i] = r_end;
+        inc[i] = KR * I.lda * ES; vld[i] = chunk_range(r_begin + row, r_end);
       }
     } else if (p < P) {
       // (both segments' fields are read with uniform indices and selected per lane: a divergent index into the kernel
@@ -140,10 +175,10 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
       const int cg = F32 ? (cpos + 4 * (row & 1)) % gpr : (cpos + bf_rot(sn, row)) % gpr;
       // row r of the chunk pairs with row r - shift of the segment
       src[i] = sp + ((int64_t)(r_begin + row - ssh) * sld + sc0 + cg * EPP) * ES;
-      inc[i] = KC * sld * ES; row0[i] = r_begin + row - ssh; lo[i] = 0; hi[i] = srows;
+      inc[i] = KR * sld * ES; vld[i] = chunk_range(r_begin + row - ssh, srows);
     }
     // pin the plan in registers HERE: nothing of it may still be "in flight" for the compiler when the loop starts
-    asm volatile("" : "+v"(src[i]), "+v"(inc[i]), "+v"(row0[i]), "+v"(lo[i]), "+v"(hi[i]));
+    asm volatile("" : "+v"(src[i]), "+v"(inc[i]), "+v"(vld[i]));
   }
   // live = false: the same NI instructions with every lane on the zero block -- the pipeline's tail keeps its instruction
   // count, so the counted vmcnt waits stay valid
@@ -152,14 +187,13 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
 #pragma unroll
     for (int i = 0; i < DWB_MAXNI; ++i) {
       if (i < NI) {                                       // NI is uniform: every wave issues the same NI instructions
-        const int row = row0[i] + chunk * KC;
-        const bool ok = live && row >= lo[i] && row < hi[i];
+        const bool ok = live && (unsigned)(chunk - (int)(vld[i] & 0xffffu)) < (vld[i] >> 16);
         const unsigned char* g = ok ? src[i] + (int64_t)chunk * inc[i] : zsrc;
         // inline asm on purpose: the compiler tracks an LDS-DMA builtin as a pending LDS write and drains it with
         // vmcnt(0) before the next LDS read -- i.e. right behind the issue, which serialises the three-stage pipeline
         // (seen in the ISA of the builtin form).  M0 = LDS byte address of THIS WAVE's lane 0 (the hardware adds 16 x the
         // lane id inside the wave, not the thread id); one wait state after the M0 write.
-        const unsigned ldsaddr = (unsigned)(uintptr_t)(lds_void*)(base + i * DWB_THREADS * 16 + wave * 64 * 16);
+        const unsigned ldsaddr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)(base + i * DWB_THREADS * 16 + wave * 64 * 16));
         { unsigned m0_saved;    // M0 is the compiler's to manage (clobbering a reserved register is undefined behaviour): saved and restored here
           asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                        : "=&s"(m0_saved) : "v"(g), "s"(ldsaddr) : "memory"); }
@@ -190,6 +224,7 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
     const int nf = wn + 4 * j;
     int n = nf * 16;
     if (nf < NF) njw = j + 1;
+    else n = 0;                                // (read ahead unconditionally below: a fragment this wave does not own reads fragment 0)
     if (n < n0) {
       b_off[j] = pa * 16 + (F32 ? f32_pos(n0, n) * 4 : bf_pos(n0, n + rcol) * 2);
       b_r16[j] = F32 ? 4 * n0 * 4 : 16 * n0 * 2;
@@ -202,17 +237,22 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
   }
   njw = __builtin_amdgcn_readfirstlane(njw);
 
-  f32x4 acc[MF][NFW], accb[MF];
+  // column sums of A (the bias gradients): the four waves that share an A fragment row (wn = 0..3) take BPW of its MF fragments
+  // each -- wave wn the fragments wn BPW .. wn BPW + BPW - 1 -- instead of wave 0 all of them (8 instead of 32 accumulator
+  // registers in the 256-column body, and the extra MFMAs spread over the waves)
+  constexpr int BPW = (MF + 3) / 4;
+  f32x4 acc[MF][NFW], accb[BPW];
+#pragma unroll
+  for (int b = 0; b < BPW; ++b) accb[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < MF; ++i) {
-    accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NFW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
-  const bool want_bias = (I.cb != nullptr) && (wn == 0);          // wave-uniform
+  const bool want_bias = I.cb != nullptr;                         // wave-uniform
 
   // ---- pipeline: S - 1 chunks in flight while chunk c is multiplied.  S (DwbItem::stages) grows as the chunk image
   // shrinks: what bounds a narrow item (a decoder: 8 KB per chunk) is the DMA latency per chunk divided by the chunks in
@@ -221,6 +261,15 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
   const int wait_n = (S - 2) * NI;                          // instructions that may stay outstanding when chunk c is needed
   for (int k = 0; k < S - 1; ++k) issue(k, k, k < n_chunks);
   int stage = 0, nxt = S - 1;
+#ifdef MFM_DWB_STAMP
+  // debug build (scripts/dwb_chunk_timeline.sh): shader-clock time per phase of the chunk loop, summed over the chunks, wave 0
+  long long st_wait = 0, st_bar = 0, st_issue = 0, st_math = 0;
+  const long long st_begin = __builtin_readcyclecounter();
+#define DWB_PT(acc) do { asm volatile("" ::: "memory"); const long long now_ = __builtin_readcyclecounter(); acc += now_ - st_last; st_last = now_; } while (0)
+  long long st_last = st_begin;
+#else
+#define DWB_PT(acc) do { } while (0)
+#endif
   for (int c = 0; c < n_chunks; ++c) {
     // chunk c is the oldest outstanding group: wait until only the S - 2 younger groups' instructions remain
     switch (wait_n) {
@@ -231,8 +280,19 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
 #undef MFM_DWB_W
       default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
+    DWB_PT(st_wait);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave's DMA of chunk c landed; chunk c-1 is consumed
-    issue(c + S - 1, nxt, c + S - 1 < n_chunks);
+    DWB_PT(st_bar);
+    // The next chunk's DMA.  Issuing costs a wave ~0.2 k cycles per instruction (scripts/dwb_chunk_timeline.sh; early-fusion item,
+    // per chunk: wait 0.5 k, barrier 0.4 k, issue 0.9 k, fragments + MFMA 1.4 k cycles), during which it stands still.  Measured:
+    // the instructions dealt out between the MFMA groups of every wave: launch 150 -> 178 us (the stall moves into the MFMA
+    // sequence); DWB_STAGGER -- waves 0-3 issue before their fragments + MFMAs, waves 4-7 after theirs, so each SIMD's two waves
+    // are in different phases: 151 -> 148 us, kept.
+    const int dma_chunk = c + S - 1, dma_stage = nxt;
+    const bool dma_live = dma_chunk < n_chunks;
+    if constexpr (F32 || !DWB_STAGGER) issue(dma_chunk, dma_stage, dma_live);
+    else { if (wm == 0) issue(dma_chunk, dma_stage, dma_live); }
+    DWB_PT(st_issue);
     const unsigned char* st = dsm + stage * stage_bytes;
     nxt = stage;
     stage = (stage + 1 == S) ? 0 : stage + 1;
@@ -244,7 +304,12 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
         for (int i = 0; i < MF; ++i) af[i] = *reinterpret_cast<const float*>(st + a_off[i] + ks * (4 * MT * 4));
         if (want_bias) {
 #pragma unroll
-          for (int i = 0; i < MF; ++i) accb[i] = mma16x16x4(af[i], 1.0f, accb[i]);
+          for (int w = 0; w < 4; ++w)
+            if (wn == w) {                                  // scalar branch
+#pragma unroll
+              for (int b = 0; b < BPW; ++b)
+                if (w * BPW + b < MF) accb[b] = mma16x16x4(af[w * BPW + b], 1.0f, accb[b]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < NFW; ++j) {
@@ -256,24 +321,48 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
         }
       }
     } else {
-      bf16x8 af[MF];
+#pragma unroll 1
+      for (int kb = 0; kb < kpc; ++kb) {                    // the chunk's 32-row k-blocks
+        bf16x8 af[MF];
 #pragma unroll
-      for (int i = 0; i < MF; ++i) af[i] = tr_frag(st, a_off[i], 16 * MT * 2);
-      if (want_bias) {
+        for (int i = 0; i < MF; ++i) af[i] = tr_frag(st + kb * (32 * MT * 2), a_off[i], 16 * MT * 2);
+        // right-hand-side fragments one ahead of their MFMAs: group j's block requests group j + 1's fragment before it multiplies
+        // (a wave reads at most one fragment it does not use; the reads younger than the awaited one are all in the same block, so
+        // the waits stay counted across the scalar branches).  Before: read -> wait -> multiply per group, ~1.6 k cycles per
+        // k-block of 32 MFMAs.
+        bf16x8 bfn = tr_frag(st + kb * 2 * b_r16[0], b_off[0], b_r16[0]);
 #pragma unroll
-        for (int i = 0; i < MF; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
-      }
+        for (int j = 0; j < NFW; ++j) {
+          if (j < njw) {                                    // scalar branch: njw is wave-uniform
+            const bf16x8 bf = bfn;
+            if (j + 1 < NFW) bfn = tr_frag(st + kb * 2 * b_r16[j + 1], b_off[j + 1], b_r16[j + 1]);
 #pragma unroll
-      for (int j = 0; j < NFW; ++j) {
-        if (j < njw) {                                      // scalar branch: njw is wave-uniform
-          const bf16x8 bf = tr_frag(st, b_off[j], b_r16[j]);
+            for (int i = 0; i < MF; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+          }
+        }
+        // (behind the products: ahead of them the block made every wave wait for all of its A fragments before the first
+        // right-hand-side fragment was even requested)
+        if (want_bias) {
 #pragma unroll
-          for (int i = 0; i < MF; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+          for (int w = 0; w < 4; ++w)
+            if (wn == w) {                                  // scalar branch
+#pragma unroll
+              for (int b = 0; b < BPW; ++b)
+                if (w * BPW + b < MF) accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[w * BPW + b], ones, accb[b], 0, 0, 0);
+            }
         }
       }
+      if constexpr (DWB_STAGGER) { if (wm != 0) issue(dma_chunk, dma_stage, dma_live); }
     }
+    DWB_PT(st_math);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the trailing dummies must land before the workgroup's LDS is released
+#ifdef MFM_DWB_STAMP
+  if (tid == 0 && (blockIdx.x % 29) == 0)
+    printf("dwb wg %3d item M=%3d N=%3d mt=%d kpc=%d chunks %3d S=%d NI=%d | prologue %6lld | per chunk: wait %5lld barrier %5lld issue %5lld math %5lld | total %7lld\n",
+           (int)blockIdx.x, I.M, n0 + n1, MT, kpc, n_chunks, S, NI, st_begin - st_kernel, st_wait / n_chunks, st_bar / n_chunks,
+           st_issue / n_chunks, st_math / n_chunks, (long long)__builtin_readcyclecounter() - st_kernel);
+#endif
 
   // ---- add the tile into the gradient buffers.  Accumulator lane: rows (A columns) 4q + r, column bi of fragment j.
   if (L.debug_no_epilogue == 1) return;     // (tuning aid: MFM_DWB_NOEPI=1 measures the streaming part alone)
@@ -292,9 +381,12 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
     }
     if (want_bias && bi == 0) {
 #pragma unroll
-      for (int i = 0; i < MF; ++i)
+      for (int b = 0; b < BPW; ++b) {
+        const int i = wn * BPW + b;
+        if (i >= MF) continue;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) slab[(int64_t)(wm * 16 * MF + i * 16 + 4 * q + r) * I.npad + I.npad - 16] = accb[i][r];
+        for (int r = 0; r < 4; ++r) slab[(int64_t)(wm * 16 * MF + i * 16 + 4 * q + r) * I.npad + I.npad - 16] = accb[b][r];
+      }
     }
     return;
   }
@@ -326,17 +418,41 @@ __global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch 
   }
   if (want_bias && bi == 0) {
 #pragma unroll
-    for (int i = 0; i < MF; ++i)
+    for (int b = 0; b < BPW; ++b) {
+      const int i = wn * BPW + b;
+      if (i >= MF) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * 16 * MF + i * 16 + 4 * q + r;
         if (m >= I.M) continue;
         const int g = m / Hp, u = m - g * Hp;
         if (u >= h) continue;
-        atomicAdd(I.cb + g * h + u, accb[i][r]);
-        if (I.cb2) atomicAdd(I.cb2 + g * h + u, accb[i][r]);
+        atomicAdd(I.cb + g * h + u, accb[b][r]);
+        if (I.cb2) atomicAdd(I.cb2 + g * h + u, accb[b][r]);
       }
+    }
   }
+}
+
+template <bool F32, int MF, int NFW>
+__global__ __launch_bounds__(DWB_THREADS) void dw_stream_kernel(const DwbLaunch L) {
+  const DwbTile t = dwb_tile(L);
+  dw_stream_body<F32, MF, NFW>(L, L.it[t.item], t.mt, t.sp, t.local);
+}
+
+// Two tile shapes in one launch (round 5): an entry's `mt` says which body its workgroups run.  What bounds the main loop is the
+// bytes a CU takes in per row, (MT + N) x 2 (profiles/r04_bf16_large_batch.txt), and the accumulators of a workgroup hold ~74 k
+// elements either way: a 256 x 256 tile moves 512 columns per row for them, a 128 x 512 one 640.  The launcher picks per item and
+// splits a right-hand side of more than 256 columns into column parts.
+template <int NFW128>                       // N fragments per wave of the 128-column body: 8 (N <= 512) or 9
+__global__ __launch_bounds__(DWB_THREADS) void dw_stream_mixed_kernel(const DwbLaunch L_arg) {
+  // The descriptor is read straight from the kernel-argument segment: with both bodies inlined the compiler no longer removed
+  // its private copy of the by-value argument (3.5 KB of scratch per lane, every field a scratch load).
+  typedef __attribute__((address_space(4))) const DwbLaunch kernarg_launch;
+  const DwbLaunch& L = *(const DwbLaunch*)(kernarg_launch*)__builtin_amdgcn_kernarg_segment_ptr();
+  const DwbTile t = dwb_tile(L);
+  if (L.it[t.item].mt == 256) dw_stream_body<false, 8, 4>(L, L.it[t.item], t.mt, t.sp, t.local);
+  else dw_stream_body<false, 4, NFW128>(L, L.it[t.item], t.mt, t.sp, t.local);
 }
 
 // Second launch of the slab form: block = one row m of one M-tile (an A column = a gate unit), threads = 4-column groups of the
@@ -350,7 +466,7 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const DwbLaunch L) {
 #pragma unroll
   for (int i = 1; i < MFM_DWB_MAXI; ++i) it += (i < L.n_items && b >= L.it[i].red_begin) ? 1 : 0;
   const DwbItem& I = L.it[it];
-  const int MT = L.mt_cols;
+  const int MT = I.mt;
   const int row = b - I.red_begin;                 // A column index inside the item (padded to whole M-tiles)
   const int mt = row / MT, ml = row - mt * MT;
   const int m = row;
@@ -466,19 +582,48 @@ static const void* zero_block() {
   return z[dev];
 }
 
-int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
-  MFM_REQUIRE(L.n_items >= 1 && L.n_items <= MFM_DWB_MAXI && L.rows >= 1, "dw bf16: bad launch");
-  if (!L.zeros) L.zeros = zero_block();
-  L.debug_no_epilogue = opt_get("MFM_DWB_NOEPI") ? atoi(opt_get("MFM_DWB_NOEPI")) : 0;
-  MFM_REQUIRE(L.zeros, "dw bf16: no zero block");
+static int item_cols(const DwbItem& I) {
+  int N = 0;
+  for (int s = 0; s < I.nseg; ++s) N += I.seg[s].ncols;
+  return N;
+}
+// What a workgroup pays per 32-row chunk, relative.  128- / 256-column tile forms (round 5, scripts/dwb_chunk_timeline.sh, shader
+// clocks per chunk at MOSI sizes, B = 2048): N = 32 / 112 (2 DMA instructions per thread) 1.81 k / 1.84 k, N = 336 (4) 2.75 k,
+// N = 480 (5) 3.28 k; 256-column tiles: N = 112 (3) 2.41 k, N = 240 (4) 2.97 k -- i.e. ~0.9 k + 0.48 k per DMA instruction (8 KB
+// into the CU at ~16 B/clk), whatever the MFMA count.  The older model (1 + N / 128, kept for the 96-column form) gave narrow
+// items too few workgroups: theirs ran 250 k cycles while the early-fusion item's finished after 180 k.
+// kpc: 32-row k-blocks per chunk; the cost is per 32 rows.  Infinite when the chunk needs more than DWB_MAXNI instructions.
+static double chunk_cost(int mt, int N, bool wide, int kpc = 1) {
+  if (!wide) return 1.0 + N / 128.0;
+  const int NI = (DWB_KC * kpc * (mt + N) / 8 + DWB_THREADS - 1) / DWB_THREADS;
+  if (NI > DWB_MAXNI) return 1e30;
+  return (1.9 + NI) / kpc;
+}
+// rows per chunk of an item (128-column forms): what costs least per row, as long as a row range keeps >= 8 chunks
+static int best_kpc(int mt, int N, bool wide, int rows) {
+  int best = 1;
+  const char* e = opt_get("MFM_DWB_KPC");
+  const int cap = e ? atoi(e) : 4;
+  for (int k = 2; k <= cap && wide; k *= 2)
+    if (chunk_cost(mt, N, wide, k) < chunk_cost(mt, N, wide, best) && rows >= 8 * DWB_KC * k) best = k;
+  return best;
+}
+
+int dw_bf16_launch(DwbLaunch& Lu, hipStream_t stream) {
+  MFM_REQUIRE(Lu.n_items >= 1 && Lu.n_items <= MFM_DWB_MAXI && Lu.rows >= 1, "dw bf16: bad launch");
+  if (!Lu.zeros) Lu.zeros = zero_block();
+  Lu.debug_no_epilogue = opt_get("MFM_DWB_NOEPI") ? atoi(opt_get("MFM_DWB_NOEPI")) : 0;
+  MFM_REQUIRE(Lu.zeros, "dw bf16: no zero block");
+  DwbLaunch L = Lu;                       // working copy: entries may be split into column parts below
+  for (int i = 0; i < L.n_items; ++i) { L.it[i].parts = 1; L.it[i].part = 0; }
   double wsum = 0.0;
   for (int i = 0; i < L.n_items; ++i) {
     DwbItem& I = L.it[i];
     MFM_REQUIRE(dw_bf16_supported(I, L.f32), "dw one-pass: item %d is not supported", i);
     const int64_t es = L.f32 ? 4 : 2;
-    MFM_REQUIRE((int64_t)DWB_KC * I.lda * es < ((int64_t)1 << 31), "dw one-pass: A row stride too large");
+    MFM_REQUIRE((int64_t)4 * DWB_KC * I.lda * es < ((int64_t)1 << 31), "dw one-pass: A row stride too large");
     for (int s = 0; s < I.nseg; ++s)
-      MFM_REQUIRE((int64_t)DWB_KC * I.seg[s].ld * es < ((int64_t)1 << 31) && I.seg[s].shift >= 0, "dw one-pass: segment %d row stride too large", s);
+      MFM_REQUIRE((int64_t)4 * DWB_KC * I.seg[s].ld * es < ((int64_t)1 << 31) && I.seg[s].shift >= 0, "dw one-pass: segment %d row stride too large", s);
   }
   // tile shape: 128-column M-tiles with <= 512 right-hand-side columns when every item fits (bf16 form only), else 96 / 576
   // (measured, MOSI sizes: T*B = 40960 rows 180 vs 173 us -- the streaming part is 24 us shorter, 134 vs 158, but the same
@@ -497,13 +642,65 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
     wide = N <= 16 * 4 * 9 && (DWB_KC * (128 + N) / 8 + DWB_THREADS - 1) / DWB_THREADS <= DWB_MAXNI;
     if (N > 16 * 4 * 8) wide9 = true;              // right-hand sides of 513-576 columns: the (4, 9) instantiation
   }
-  const int MT = wide ? 128 : DWB_MT;
+  for (int i = 0; i < L.n_items; ++i) L.it[i].mt = wide ? 128 : DWB_MT;
+  // Tile shape per item (round 5, 128-column form only; MFM_DWB_MIXED=0 keeps one shape): the main loop is bound by the bytes a
+  // CU takes in, (MT + N) x 2 per row and tile -- a 256 x <= 256 tile (8 x 4 fragments per wave, the same 32-36 accumulator
+  // tiles) moves fewer columns than 128 x N when the item is tall and wide: the early-fusion encoder, M = 512 N = 480: 4 x 608
+  // -> 2 M-tiles x 2 column parts x 496; a decoder, M = 448 N = 112: 4 x 240 -> 2 x 368.  Taken when it saves >= 5 %.
+  bool mixed = false;
+  {
+    const char* me = opt_get("MFM_DWB_MIXED");
+    if (wide && !(me && atoi(me) == 0)) {
+      DwbLaunch X = L;
+      X.n_items = 0;
+      for (int i = 0; i < L.n_items; ++i) {
+        const DwbItem& I = L.it[i];
+        const int n0 = I.seg[0].ncols, n1 = I.nseg > 1 ? I.seg[1].ncols : 0, N = n0 + n1;
+        const int k = (N + 255) / 256, nf = N / 16;
+        const double c128 = (I.M + 127) / 128 * chunk_cost(128, N, true, best_kpc(128, N, true, L.rows));
+        double c256 = 0.0;
+        for (int p = 0; p < k; ++p) {
+          const int np = 16 * (nf / k + (p < nf % k ? 1 : 0));
+          c256 += (I.M + 255) / 256 * chunk_cost(256, np, true, best_kpc(256, np, true, L.rows));
+        }
+        const int left = L.n_items - i - 1;
+        const bool take = I.M > 128 && c256 <= c128 * 0.95 && X.n_items + k + left <= MFM_DWB_MAXI;
+        if (!take) { X.it[X.n_items++] = I; continue; }
+        mixed = true;
+        int cs = 0;
+        for (int p = 0; p < k; ++p) {
+          const int ce = cs + 16 * (nf / k + (p < nf % k ? 1 : 0));
+          DwbItem& J = X.it[X.n_items++];
+          J = I;
+          J.mt = 256; J.parts = k; J.part = p;
+          if (p > 0) { J.cb = nullptr; J.cb2 = nullptr; }          // the column sums of A: the first part's
+          J.nseg = 0; J.nout = 0;
+          if (cs < n0) { DwbSeg& S = J.seg[J.nseg++]; S = I.seg[0]; S.col0 += cs; S.ncols = std::min(ce, n0) - cs; }
+          if (ce > n0) { DwbSeg& S = J.seg[J.nseg++]; S = I.seg[1]; S.col0 += std::max(cs, n0) - n0; S.ncols = ce - std::max(cs, n0); }
+          for (int o = 0; o < I.nout; ++o) {
+            const int lo = std::max(I.out[o].n0, cs), hi = std::min(I.out[o].n0 + I.out[o].nvalid, ce);
+            if (lo >= hi) continue;
+            DwbOut& O = J.out[J.nout++];
+            O = I.out[o];
+            O.n0 = lo - cs; O.nvalid = hi - lo; O.c = I.out[o].c + (lo - I.out[o].n0);
+            O.c2 = I.out[o].c2 ? I.out[o].c2 + (lo - I.out[o].n0) : nullptr;
+          }
+          cs = ce;
+        }
+      }
+      if (mixed) L = X;
+    }
+  }
+  for (int i = 0; i < L.n_items; i += L.it[i].parts) {       // rows per chunk: one value per item (the parts share the row ranges)
+    int kpc = 4;
+    for (int p = 0; p < L.it[i].parts; ++p) kpc = std::min(kpc, L.f32 ? 1 : best_kpc(L.it[i + p].mt, item_cols(L.it[i + p]), wide, L.rows));
+    for (int p = 0; p < L.it[i].parts; ++p) L.it[i + p].kpc = kpc;
+  }
+  auto item_cost = [&](const DwbItem& I) { return chunk_cost(I.mt, item_cols(I), wide, I.kpc); };
   for (int i = 0; i < L.n_items; ++i) {
     DwbItem& I = L.it[i];
-    I.m_tiles = (I.M + MT - 1) / MT;
-    int N = 0;
-    for (int s = 0; s < I.nseg; ++s) N += I.seg[s].ncols;
-    wsum += (double)I.m_tiles * (1.0 + N / 128.0);
+    I.m_tiles = (I.M + I.mt - 1) / I.mt;
+    wsum += (double)I.m_tiles * item_cost(I);
   }
   // one workgroup per CU (the chunk stages fill the LDS), so the launch runs in whole ROUNDS of workgroups: row ranges sized
   // so that it fills `rounds` rounds and not one workgroup more -- a range's cost taken as (fixed part + N / 128) per chunk
@@ -525,17 +722,22 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
   for (double fill = 0.98; ; fill -= 0.04) {
     const double target = tenv ? atof(tenv) * cus : fill * rounds * cus;
     tiles = 0;
-    for (int i = 0; i < L.n_items; ++i) {
-      DwbItem& I = L.it[i];
-      int N = 0;
-      for (int s = 0; s < I.nseg; ++s) N += I.seg[s].ncols;
-      int splits = (int)(target * (1.0 + N / 128.0) / wsum + 0.5);
-      const int max_splits = std::max(1, L.rows / (4 * DWB_KC));
+    for (int i = 0; i < L.n_items; i += L.it[i].parts) {         // an item = `parts` consecutive entries with one set of row ranges
+      const int k = L.it[i].parts;
+      double c = 0.0;
+      for (int p = 0; p < k; ++p) c += item_cost(L.it[i + p]) / k;
+      int splits = (int)(target * c / wsum + 0.5);
+      const int KR = DWB_KC * L.it[i].kpc;
+      const int max_splits = std::max(1, L.rows / (4 * KR));
       splits = std::max(1, std::min(splits, max_splits));
-      I.rows_per_split = ((L.rows + splits - 1) / splits + DWB_KC - 1) / DWB_KC * DWB_KC;
-      I.splits = (L.rows + I.rows_per_split - 1) / I.rows_per_split;
-      I.tile_begin = tiles;
-      tiles += I.m_tiles * I.splits;
+      const int rps = ((L.rows + splits - 1) / splits + KR - 1) / KR * KR;
+      for (int p = 0; p < k; ++p) {
+        DwbItem& I = L.it[i + p];
+        I.rows_per_split = rps;
+        I.splits = (L.rows + rps - 1) / rps;
+        I.tile_begin = p == 0 ? tiles : INT_MAX;
+      }
+      tiles += k * L.it[i].m_tiles * L.it[i].splits;
     }
     if (tenv || tiles <= rounds * cus || fill < 0.3) break;
   }
@@ -543,8 +745,9 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
     DwbItem& I = L.it[i];
     int N = 0;
     for (int s = 0; s < I.nseg; ++s) N += I.seg[s].ncols;
-    const int P = DWB_KC * (MT + N) / 8;
+    const int P = DWB_KC * I.kpc * (I.mt + N) / 8;
     const int NI = (P + DWB_THREADS - 1) / DWB_THREADS;
+    MFM_REQUIRE(NI <= DWB_MAXNI, "dw one-pass: %d DMA instructions per chunk", NI);
     // stages: as many as fit ~144 KB, the counted wait and the cap (MFM_DWB_STAGES forces a count, clamped)
     int S = (int)((144 * 1024) / ((size_t)NI * DWB_THREADS * 16));
     S = std::min(S, DWB_MAX_WAIT / NI + 2);
@@ -564,12 +767,12 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
       for (int s = 0; s < I.nseg; ++s) N += I.seg[s].ncols;
       I.npad = N + 16;                                  // (N is a multiple of 16: the bias column starts a 64-byte group)
       I.slab_off = off;
-      off += (int64_t)I.m_tiles * I.splits * MT * I.npad;
+      off += (int64_t)I.m_tiles * I.splits * I.mt * I.npad;
       I.red_begin = red;
-      red += I.m_tiles * MT;
+      red += I.m_tiles * I.mt;
     }
     if (off > L.slab_floats) slabs = false;           // (scratch sized for fewer workgroups than a forced MFM_DWB_TARGET asks for)
-    else { L.mt_cols = MT; L.red_rows = red; }
+    else L.red_rows = red;
   }
   if (!slabs) L.slabs = nullptr;
   static bool attr = false;
@@ -578,6 +781,8 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
     MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_stream_kernel<false, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_stream_kernel<false, 4, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_stream_kernel<true, 3, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_stream_mixed_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MFM_HIP_CHECK(hipFuncSetAttribute((const void*)dw_stream_mixed_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
   MFM_REQUIRE(smem <= 160 * 1024, "dw one-pass: %zu bytes of LDS", smem);
@@ -585,6 +790,8 @@ int dw_bf16_launch(DwbLaunch& L, hipStream_t stream) {
   // GEMM) against 626 us for the grouped GEMM: its main loop keeps the fp32 matrix pipe ~43 % busy (one ds_read_b32 and its
   // wait per three MFMAs; batching a k-step's reads ahead of its MFMAs made it 779 us) -> opt-in, MFM_DW_F32_MINROWS
   if (L.f32) hipLaunchKernelGGL((dw_stream_kernel<true, 3, 9>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
+  else if (mixed && wide9) hipLaunchKernelGGL(dw_stream_mixed_kernel<9>, dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
+  else if (mixed) hipLaunchKernelGGL(dw_stream_mixed_kernel<8>, dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
   else if (wide && wide9) hipLaunchKernelGGL((dw_stream_kernel<false, 4, 9>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
   else if (wide) hipLaunchKernelGGL((dw_stream_kernel<false, 4, 8>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
   else hipLaunchKernelGGL((dw_stream_kernel<false, 3, 9>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);

@@ -122,8 +122,13 @@ struct DwbItem {
   int nseg, nout;
   DwbSeg seg[2]; DwbOut out[MFM_DWB_MAXOUT];
   float* cb; float* cb2;                // optional: column sums of A (bias gradients), indexed like the rows of C
-  int tile_begin, m_tiles, splits, rows_per_split, stages, pad_;     // filled by dw_bf16_launch
+  int tile_begin, m_tiles, splits, rows_per_split, stages, mt;       // filled by dw_bf16_launch (mt: A columns per workgroup tile)
   int64_t slab_off; int npad, red_begin;    // slab form (DwbLaunch::slabs): first float of this item's partial tiles, their row length, first row of the reduce launch
+  // column parts (round 5, filled by dw_bf16_launch): an item whose right-hand side is split over `parts` consecutive entries, each
+  // owning a column range of [seg0 | seg1]; the entries share tile_begin / m_tiles / splits and their workgroups are dealt out
+  // row range by row range (all parts and M-tiles of one row range are neighbours on one XCD).  part > 0: tile_begin = INT_MAX.
+  int parts, part;
+  int kpc, pad2_;                       // 32-row k-blocks per chunk (filled by dw_bf16_launch: narrow items take 64 / 128 rows per chunk)
 };
 struct DwbLaunch { DwbItem it[MFM_DWB_MAXI]; int n_items, rows; const void* zeros; int debug_no_epilogue; int f32;
                    // optional scratch (dw_bf16_scratch_floats()): every workgroup leaves its partial tile there with plain stores and a
