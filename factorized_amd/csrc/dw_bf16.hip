@@ -201,6 +201,11 @@ __device__ __forceinline__ void dw_stream_body(const DwbLaunch& L, const DwbItem
     }
   };
 
+  // the first S - 1 chunks leave NOW: the fragment offsets and the accumulators below are set up while they are in flight
+  const int S = I.stages;
+  const int wait_n = (S - 2) * NI;                          // instructions that may stay outstanding when chunk c is needed
+  for (int k = 0; k < S - 1; ++k) issue(k, k, k < n_chunks);
+
   // ---- fragment read offsets inside a stage (bytes)
   // bf16: lane (bi, q) reads row 4q + bi/4, columns c .. c+3 with c = col0 + 4 (bi%4) (transposing read; second read +16 rows)
   // F32:  lane (bi, q) reads element [row q (+ 4 per k-step)][column col0 + bi], the column group rotated like the DMA did
@@ -257,9 +262,7 @@ __device__ __forceinline__ void dw_stream_body(const DwbLaunch& L, const DwbItem
   // ---- pipeline: S - 1 chunks in flight while chunk c is multiplied.  S (DwbItem::stages) grows as the chunk image
   // shrinks: what bounds a narrow item (a decoder: 8 KB per chunk) is the DMA latency per chunk divided by the chunks in
   // flight, not bandwidth -- with 3 stages the 22 narrow M-tiles of the MOSI plan spent ~1 us per 8-24 KB chunk.
-  const int S = I.stages;
-  const int wait_n = (S - 2) * NI;                          // instructions that may stay outstanding when chunk c is needed
-  for (int k = 0; k < S - 1; ++k) issue(k, k, k < n_chunks);
+  // (the first S - 1 chunks were requested right behind the DMA plan, ahead of the fragment offsets: see there)
   int stage = 0, nxt = S - 1;
 #ifdef MFM_DWB_STAMP
   // debug build (scripts/dwb_chunk_timeline.sh): shader-clock time per phase of the chunk loop, summed over the chunks, wave 0
@@ -634,7 +637,10 @@ int dw_bf16_launch(DwbLaunch& Lu, hipStream_t stream) {
   // measured (profiles/r04_bf16_large_batch.txt): ahead up to T*B = 40960 rows, behind from 81920 (MFM_DWB_SLABS=1 / 0 forces)
   const char* slab_env = opt_get("MFM_DWB_SLABS");
   const bool slab_req = L.slabs != nullptr && !L.f32 && (slab_env ? atoi(slab_env) != 0 : L.rows <= 65536);
-  bool wide = !L.f32 && mf_env != 3 && (mf_env == 4 || L.rows >= (slab_req ? 8192 : 65536));
+  // (round 5, with the per-item shapes / 64-128-row chunks / cost model below: ahead from the smallest bf16-resident plan on,
+  // bench.py --dtype bf16, ms per step, 128-column form forced vs 96-column form: B = 128 0.2717 vs 0.2752, 192 0.2827 vs 0.2853,
+  // 256 0.2925 vs 0.2975, 384 0.3151 vs 0.3276 -> from 2048 rows)
+  bool wide = !L.f32 && mf_env != 3 && (mf_env == 4 || L.rows >= (slab_req ? 2048 : 65536));
   bool wide9 = false;
   for (int i = 0; i < L.n_items && wide; ++i) {
     int N = 0;

@@ -375,11 +375,14 @@ def test_bf16_resident_flags_refused_by_fp32_entry_point(eng):
 
 
 @pytest.mark.parametrize("h,dx,rows,shift", [(120, 325, 640, 32), (120, 410, 640, 32), (32, 300, 640, 32), (8, 5, 100, 5), (80, 20, 4580, 229),
-                                             (104, 0, 640, 32), (24, 0, 37, 37), (120, 325, 20480, 1024), (36, 37, 171, 19)])
+                                             (104, 0, 640, 32), (24, 0, 37, 37), (120, 325, 20480, 1024), (36, 37, 171, 19),
+                                             (8, 5, 2100, 5), (104, 0, 1500, 37)])
 @pytest.mark.parametrize("mf", [3, 4])
 def test_bf16_resident_weight_gradients_one_pass(eng, h, dx, rows, shift, mf, monkeypatch):
     """(mf: 96- / 128-column M-tiles, dw_stream_kernel<false, 3, 9> / <false, 4, 8>; dx = 410: a right-hand side of 544 columns,
-    <false, 4, 9>)
+    <false, 4, 9>.  mf = 4 also lets the launcher pick per item: h = 120 / 104 / 80 / 36 run 256-column tiles -- h = 120, dx = 325
+    as two column parts -- in dw_stream_mixed_kernel, and the narrow items take 64 / 128 rows per chunk: rows = 2100 and 1500 end
+    in a ragged chunk of that size)
     dw_bf16_kernel: dW_ih, dW_hh (+ the decoders' second target), db from bf16-resident dA / x / h in ONE pass: LDS-DMA
     slabs in memory order, transposing LDS reads, ragged row ranges and the t = 0 rows of h_{t-1} as zero-filled DMA lanes.
     Products of bf16 values are exact, so the fp64 reference over the stored values must match to fp32 summation error."""
