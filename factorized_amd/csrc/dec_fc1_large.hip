@@ -332,6 +332,20 @@ __device__ __forceinline__ void fc1_large64_body(const DecFc1LargeLaunch& L, con
   for (int j = 0; j < 2; ++j) { const int c = tid + j * FL_THREADS; hr[j] = c / per_row; hk[j] = (c - hr[j] * per_row) << 3; }
   const int rrow = 4 * q + (bi >> 2), rcol = 4 * (bi & 3);      // transposing-read coordinates
   float lsum = 0.0f;
+  // d x_hat leaves from its LDS tile as whole 16-byte pieces in memory order (round 5): an accumulator lane holds 4 columns of
+  // one row, so the direct store touched 16 rows per instruction -- 12 instructions per wave and tile, 1,536 cache-line visits
+  // for a tile of ~300 lines, ~3 cycles each on the CU's address path (profiles/r05_seq_bf16_study.txt section 7)
+  constexpr int FL_DXP = 6;                         // pieces per thread: 64 rows x ld / 8 <= 6 x 512 (ld <= 384)
+  const int dx_ppr = I.ld_dxhat >> 3;               // 16-byte pieces per row (ld is a multiple of 8 here: see the launcher)
+  int dxp_lds[FL_DXP], dxp_g[FL_DXP], dxp_row[FL_DXP];
+#pragma unroll
+  for (int j = 0; j < FL_DXP; ++j) {
+    const int c = tid + j * FL_THREADS;
+    const int r = c / dx_ppr, k8 = (c - r * dx_ppr) << 3;
+    dxp_row[j] = r < FL_R64 ? r : 0x40000000;       // (beyond the tile: never below L.rows)
+    dxp_lds[j] = (r < FL_R64 ? r * LDX + min(k8, LDX - 8) : 0) * 2;
+    dxp_g[j] = (r * I.ld_dxhat + k8) * 2;
+  }
 
   // every global access is a buffer instruction whose offset is out of range for lanes without data: nothing sits under a
   // lane-divergent branch, and the next tile's hidden rows and targets are requested while the current tile is multiplied
@@ -397,14 +411,21 @@ __device__ __forceinline__ void fc1_large64_body(const DecFc1LargeLaunch& L, con
             }
             request_x(tile + nwg, i, rt);           // (the register is free again: the next tile's target)
             const bf16x4 dxb = __builtin_convertvector(dx, bf16x4);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, dxb), dxres,
-                                                  (n0[i] < I.ld_dxhat && row < L.rows) ? (unsigned)((row * I.ld_dxhat + n0[i]) * 2) : FL_OOB, 0, 0);
             *reinterpret_cast<bf16x4*>(Dx + (rt * 16 + bi) * LDX + n0[i]) = dxb;
           }
         }
       }
     }
     lds_barrier();
+    // the tile's d x_hat to memory (the next tile's product 1 overwrites Dx only behind the next barrier)
+    if (!(L.dbg & 1)) {
+      u32x4 pv[FL_DXP];
+#pragma unroll
+      for (int j = 0; j < FL_DXP; ++j) pv[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(Dx) + dxp_lds[j]);
+#pragma unroll
+      for (int j = 0; j < FL_DXP; ++j)
+        __builtin_amdgcn_raw_buffer_store_b128(pv[j], dxres, (row0 + dxp_row[j] < L.rows) ? (unsigned)(row0 * I.ld_dxhat * 2 + dxp_g[j]) : FL_OOB, 0, 0);
+    }
     // ---- product 2: wave (rt, half) owns dH fragments rows 16 rt .., hidden fragments half * JH .. of the tile
     if (!(L.dbg & 2)) {
       const int rt = wave & 3, half = wave >> 2;
@@ -489,6 +510,8 @@ size_t dec_fc1_large_wimg_bytes(int d) {
   return (size_t)NB2 * 32 * FL_LDW * 2;
 }
 
+// columns of the d x_hat tile in LDS (the 64-row kernel copies ld_dxhat of them per row to memory)
+static int fl_dx_cols(const DecFc1LargeItem& I) { return ((I.d + 15) / 16 * 16 + 31) / 32 * 32 + 8; }
 static size_t fl_lds_bytes(const DecFc1LargeItem& I, int rows_per_tile) {
   const int NF1 = (I.d + 15) / 16, NB2 = (NF1 * 16 + 31) / 32;
   if (rows_per_tile == FL_R64) return ((size_t)NB2 * 32 * FL_LDW + (size_t)FL_R64 * FL_LDW + (size_t)FL_R64 * (NB2 * 32 + 8)) * 2;
@@ -517,7 +540,7 @@ int fc1_pack_prepare(const DecFc1LargeLaunch& L, Fc1PackArgs* out) {
 bool dec_fc1_large_uses_wimg(const DecFc1LargeLaunch& L) {
   if (opt_get("MFM_FC1_LARGE_ROWS") && atoi(opt_get("MFM_FC1_LARGE_ROWS")) == 16) return false;
   for (int i = 0; i < L.n_items; ++i)
-    if (fl_lds_bytes(L.it[i], FL_R64) > 156 * 1024 || (L.it[i].ld_dxhat & 3) || (L.it[i].Hp >> 3) > 16 ||
+    if (fl_lds_bytes(L.it[i], FL_R64) > 156 * 1024 || (L.it[i].ld_dxhat & 7) || L.it[i].ld_dxhat > fl_dx_cols(L.it[i]) || (L.it[i].Hp >> 3) > 16 ||
         (int64_t)L.rows * L.it[i].ldx >= ((int64_t)1 << 29))
       return false;
   return true;
@@ -529,7 +552,7 @@ int dec_fc1_large_launch(DecFc1LargeLaunch& L, hipStream_t stream) {
   int RT = (opt_get("MFM_FC1_LARGE_ROWS") && atoi(opt_get("MFM_FC1_LARGE_ROWS")) == 16) ? FL_ROWS : FL_R64;
   for (int i = 0; i < L.n_items; ++i) {
     MFM_REQUIRE(dec_fc1_large_supported(L.it[i]), "dec fc1 (large): item %d is not supported", i);
-    if (RT == FL_R64 && (fl_lds_bytes(L.it[i], FL_R64) > 156 * 1024 || (L.it[i].ld_dxhat & 3) || (L.it[i].Hp >> 3) > 16 ||
+    if (RT == FL_R64 && (fl_lds_bytes(L.it[i], FL_R64) > 156 * 1024 || (L.it[i].ld_dxhat & 7) || L.it[i].ld_dxhat > fl_dx_cols(L.it[i]) || (L.it[i].Hp >> 3) > 16 ||
                          (int64_t)L.rows * L.it[i].ldx >= ((int64_t)1 << 29)))
       RT = FL_ROWS;
   }

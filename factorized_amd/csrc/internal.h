@@ -134,7 +134,7 @@ struct DwbLaunch { DwbItem it[MFM_DWB_MAXI]; int n_items, rows; const void* zero
                    // optional scratch (dw_bf16_scratch_floats()): every workgroup leaves its partial tile there with plain stores and a
                    // second launch sums the row ranges of each M-tile and adds the result once -- instead of ~7 M atomicAdds into
                    // the same few hundred KB (round 4); null: the atomics
-                   float* slabs; int64_t slab_floats; int mt_cols, red_rows; };   // f32: the buffers hold fp32 (round 3; element counts / strides then count floats)   // zeros: >= 16 bytes of device zeros (null: the launcher's own)
+                   float* slabs; int64_t slab_floats; int red_rows, pad_; };   // f32: the buffers hold fp32 (round 3; element counts / strides then count floats)   // zeros: >= 16 bytes of device zeros (null: the launcher's own)
 int dw_bf16_supported(const DwbItem& I, int f32 = 0);
 int dw_bf16_launch(DwbLaunch& L, hipStream_t stream);
 int64_t dw_bf16_scratch_floats(int64_t rows);      // upper bound of what a launch over `rows` rows needs in DwbLaunch::slabs
