@@ -78,7 +78,7 @@ bool gemm_panel_pays(const PanelLaunch& L, int precision, bool force);
 
 // proj_bf16.hip -- the same projections for a bf16-RESIDENT plan: weights packed once per step into a bf16 tile image
 // (proj_bf16_pack_launch), tiles by LDS-DMA, bf16 results by 8-byte stores, the padded bf16 image of x as a side output
-struct ProjPlan { int ntiles, nbias, BM, S; size_t lds; int tile0[MFM_PANEL_MAXG], kt0[MFM_PANEL_MAXG], nkt[MFM_PANEL_MAXG], nchunks[MFM_PANEL_MAXG], bias_off[MFM_PANEL_MAXG]; };
+struct ProjPlan { int ntiles, nbias, BM, S, ns; size_t lds; int tile0[MFM_PANEL_MAXG], kt0[MFM_PANEL_MAXG], nkt[MFM_PANEL_MAXG], nchunks[MFM_PANEL_MAXG], bias_off[MFM_PANEL_MAXG]; };
 int proj_bf16_plan(const PanelLaunch& L, ProjPlan* out);      // 1: supported (only the groups' shapes, M and K are read)
 // scratch: wimg = ntiles * 8192 bytes (16-byte aligned), bimg = nbias floats
 int proj_bf16_pack_launch(const PanelLaunch& L, const ProjPlan& P, void* wimg, float* bimg, hipStream_t stream);

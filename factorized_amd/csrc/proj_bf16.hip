@@ -46,6 +46,7 @@ struct PjDev {
   const __bf16* wimg; const float* bimg;
   __bf16* x16; int x16_ld; int xsrc0[3], xn[3], xdst0[3];
   PjGroupDev g[PJ_MAXG]; int ngroups, ntiles, nbias, S, dbg;
+  int ns, tb[9];                 // column splits (few row panels): workgroup (panel, y) runs the jobs whose tiles are [tb[y], tb[y + 1])
   float* zero_ptr[MFM_GEMM_ZSPANS]; int64_t zero_n[MFM_GEMM_ZSPANS];
 };
 __global__ __launch_bounds__(256) void proj_pack_kernel(const PjPackDev L) {
@@ -75,20 +76,24 @@ __global__ __launch_bounds__(PJ_THREADS + 64) void proj_bf16_kernel(const PjDev 
   __bf16* Ap = reinterpret_cast<__bf16*>(smem);                                        // [BM][LDA]
   const unsigned a_bytes_lds = (unsigned)(((size_t)BM * LDA * 2 + 1023) / 1024 * 1024);
   unsigned char* Bt = smem + a_bytes_lds;                                              // [S][8192]
-  const int S = L.S, ntiles = L.ntiles;
+  const int S = L.S;
   float* Bias = reinterpret_cast<float*>(Bt + (size_t)S * (PJ_TILE * 2));             // [nbias]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (wave-uniform, and the compiler must know: M0 is scalar)
-  const int m0 = blockIdx.x * BM;
+  // few row panels (small T*B): `ns` workgroups share a panel, each with a contiguous range of the jobs -- it streams only that
+  // range's weight tiles (a workgroup that walks all 61 tiles of the MOSI plan takes ~22 us for them whatever its panel height)
+  const int ns = L.ns, panel = (int)blockIdx.x / ns, ysplit = (int)blockIdx.x - panel * ns;
+  const int tb = L.tb[ysplit], te = L.tb[ysplit + 1];
+  const int m0 = panel * BM;
 
   if (wave == 8) {
     // ---- the requesting wave.  A tile is 8 instructions of 64 lanes x 16 bytes; the LDS address of a lane is
     // M0 + 16 x lane.  Tiles past the end re-request the last tile into a slot nobody reads any more, so that every
     // iteration issues the same number of instructions and the counted wait stays valid.
     auto issue = [&](int t) {
-      const int tt = min(t, ntiles - 1);
+      const int tt = min(t, te - 1);
       const __bf16* g = L.wimg + (int64_t)tt * PJ_TILE + lane * 8;
-      const unsigned base = (unsigned)(uintptr_t)(lds_void*)(Bt + (t % S) * (PJ_TILE * 2));
+      const unsigned base = (unsigned)(uintptr_t)(lds_void*)(Bt + ((t - tb) % S) * (PJ_TILE * 2));
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const __bf16* gj = g + j * 512;
@@ -98,9 +103,9 @@ __global__ __launch_bounds__(PJ_THREADS + 64) void proj_bf16_kernel(const PjDev 
                        : "=&s"(m0_saved) : "v"(gj), "s"(ldsaddr) : "memory"); }
       }
     };
-    for (int t = 0; t < S - 1; ++t) issue(t);
+    for (int t = tb; t < tb + S - 1; ++t) issue(t);
     asm volatile("s_barrier" ::: "memory");                  // (the compute waves' barrier after the panel)
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = tb; t < te; ++t) {
       // tile t is the oldest outstanding one: wait until only the 8 (S - 2) instructions of the younger tiles remain
       switch (S) {
         case 6: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(PJ_THREADS + 64) void proj_bf16_kernel(const PjDev 
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   // ---- side output: the padded bf16 image of these rows (modality slices on 16-column boundaries, pads zero)
-  if (L.x16 && !(L.dbg & 1)) {
+  if (L.x16 && ysplit == 0 && !(L.dbg & 1)) {
     const int cpr = L.x16_ld >> 3;
     for (int idx = tid; idx < BM * cpr; idx += PJ_THREADS) {
       const int r = idx / cpr, c8 = (idx - r * cpr) * 8;
@@ -176,6 +181,7 @@ __global__ __launch_bounds__(PJ_THREADS + 64) void proj_bf16_kernel(const PjDev 
   for (int gi = 0; gi < L.ngroups; ++gi) {
     const PjGroupDev G = L.g[gi];
     for (int n0 = 0; n0 < G.n; n0 += PJ_BN) {
+      if (t < tb || t >= te) { t += G.kt1 - G.kt0; continue; }      // another split's job
       const int colw = n0 + wn * 32;                       // this wave's first column of the chunk
       const bool wave_live = colw < G.n;
       f32x4 acc[FM][FN];
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(PJ_THREADS + 64) void proj_bf16_kernel(const PjDev 
       for (int kt = G.kt0; kt < G.kt1; ++kt, ++t) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // tile t landed (the requesting wave waited for it)
         if (wave_live && !(L.dbg & 4)) {
-          const unsigned char* B = Bt + (t % S) * (PJ_TILE * 2);
+          const unsigned char* B = Bt + ((t - tb) % S) * (PJ_TILE * 2);
           bf16x8 wf[FN], xf[FM];
 #pragma unroll
           for (int fn = 0; fn < FN; ++fn) {
@@ -261,9 +267,15 @@ int proj_bf16_plan(const PanelLaunch& L, ProjPlan* out) {
     if (const char* e = opt_get("MFM_PROJ16_STAGES")) S = std::max(3, std::min(6, atoi(e)));
     while (S >= 3 && a_lds + (size_t)S * PJ_TILE * 2 + (size_t)nb * 4 > 160 * 1024) --S;
     if (S < 3) continue;
-    const long rounds = (cdiv(std::max(L.M, 1), cand[i]) + cus - 1) / cus;
-    const double cost = (double)rounds * (100.0 + cand[i]);
-    if (out->BM == 0 || cost < best) { out->BM = cand[i]; out->S = S; out->lds = a_lds + (size_t)S * PJ_TILE * 2 + (size_t)nb * 4; best = cost; }
+    // column splits (round 5): with few row panels, ns workgroups share a panel and stream 1 / ns of the tiles each
+    const long npanels = cdiv(std::max(L.M, 1), cand[i]);
+    int jobs = 0;
+    for (int g = 0; g < L.ngroups; ++g) jobs += out->nchunks[g];
+    int ns = (int)std::max<long>(1, std::min<long>(std::min(8, jobs), cus / npanels));
+    if (const char* e = opt_get("MFM_PROJ16_NS")) ns = std::max(1, std::min(std::min(8, jobs), atoi(e)));
+    const long rounds = (npanels * ns + cus - 1) / cus;
+    const double cost = (double)rounds * (100.0 / ns + cand[i]);
+    if (out->BM == 0 || cost < best) { out->BM = cand[i]; out->S = S; out->ns = ns; out->lds = a_lds + (size_t)S * PJ_TILE * 2 + (size_t)nb * 4; best = cost; }
   }
   return out->BM != 0;
 }
@@ -344,7 +356,27 @@ int proj_bf16_launch(const PanelLaunch& L, const ProjPlan& P, const void* wimg, 
       D.zero_ptr[i] = zs->ptr[i]; D.zero_n[i] = zs->n[i];
     }
   }
-  const dim3 grid(cdiv(L.M, P.BM)), block(PJ_THREADS + 64);
+  // column splits: the jobs (group, 128-column chunk) are dealt to `ns` workgroups per panel in contiguous ranges of about equal
+  // tile counts (MFM_PROJ16_NS forces a count when the plan is built, 1 = off)
+  const int npanels = cdiv(L.M, P.BM);
+  {
+    int jobs = 0;
+    for (int i = 0; i < L.ngroups; ++i) jobs += P.nchunks[i];
+    const int ns = std::max(1, std::min(P.ns, std::min(jobs, 8)));           // chosen with the panel height (proj_bf16_plan)
+    D.ns = ns; D.tb[0] = 0;
+    int y = 1, t = 0;
+    for (int i = 0; i < L.ngroups && y < ns; ++i)
+      for (int c = 0; c < P.nchunks[i] && y < ns; ++c) {
+        t += P.nkt[i];
+        // close split y - 1 behind this job when it has reached its share (and enough jobs remain for the other splits)
+        int left = 0;
+        for (int i2 = i; i2 < L.ngroups; ++i2) left += (i2 == i) ? P.nchunks[i2] - c - 1 : P.nchunks[i2];
+        if (t * ns >= y * P.ntiles || left <= ns - y) { D.tb[y++] = t; }
+      }
+    for (; y <= ns; ++y) D.tb[y] = P.ntiles;
+    for (int k = 0; k < ns; ++k) MFM_REQUIRE(D.tb[k] < D.tb[k + 1], "proj bf16: empty column split %d of %d", k, ns);
+  }
+  const dim3 grid(npanels * D.ns), block(PJ_THREADS + 64);
 #define MFM_PJ_GO(FM_)                                                                                              \
   do {                                                                                                              \
     auto* fn = proj_bf16_kernel<FM_>;                                                                               \
