@@ -21,7 +21,16 @@
 //     consecutive workgroups of one XCD;
 //   * out-of-range DMA lanes write zeros (probed), so ragged row ranges and the t = 0 rows of h_{t-1} need no branches:
 //     their offsets are simply outside the buffer resource.
-// 512 threads = 8 waves as 2 (3 A fragments each) x 4 (N fragments, strided, <= 9 each): 27 accumulator tiles per wave.
+// 512 threads = 8 waves as 2 (MF A fragments each) x 4 (N fragments, strided, <= NFW each); tile shapes (MF, NFW): (3, 9) 96 x <= 576
+// columns, (4, 8) / (4, 9) 128 x <= 512 / 576, (8, 4) 256 x <= 256 -- 27 to 36 accumulator tiles per wave.
+//
+// Round 5 (profiles/r05_dw_stream_study.txt): a clock on the chunk loop's phases (scripts/dwb_chunk_timeline.sh) showed that the
+// launch is not memory bound -- a chunk costs ~0.9 k cycles of waits and barriers plus ~0.5 k per DMA instruction, and its fragment
+// reads keep the LDS busy ~2.5 x as long as its MFMAs keep the matrix pipe.  Hence: the launcher prices a chunk per DMA instruction
+// (narrow items had been starved), picks the tile shape PER ITEM (dw_stream_mixed_kernel runs 128- and 256-column bodies in one
+// launch; a right-hand side of more than 256 columns is split into column parts whose workgroups stay neighbours on one XCD),
+// gives narrow items 64 or 128 rows per chunk, staggers the DMA issue of the two waves of a SIMD, requests fragments one group ahead
+// and spreads the bias sums over the waves.  B = 2048: 137 + 20 us -> 100 + 16 us.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
