@@ -121,7 +121,8 @@ __device__ __forceinline__ void dw_stream_body(const DwbLaunch& L, const DwbItem
   // whatever its width, so narrow items (a decoder's [32 rows][128 + 32 columns] is 10 KB) take 64 or 128 rows per chunk.
   const int kpc = F32 ? 1 : I.kpc;
   const int KR = KC * kpc;
-  const int n_chunks = (r_end - r_begin + KR - 1) / KR;
+  const int kr_shift = F32 ? 4 : (kpc == 4 ? 7 : kpc == 2 ? 6 : 5);          // KR is a power of two: no integer divisions by it
+  const int n_chunks = (r_end - r_begin + KR - 1) >> kr_shift;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,7 +139,11 @@ __device__ __forceinline__ void dw_stream_body(const DwbLaunch& L, const DwbItem
   // bf16 images whose rows are a multiple of 256 bytes (128 / 256 columns) would put the 16 rows of a transposing fragment
   // read on the same banks: their 16-byte pieces are rotated by 2 (row & 7) positions on the way in (the DMA source address
   // is free), and the fragment reads below undo it
-  auto bf_rot = [](int width, int row) { return ((width & 127) == 0) ? (2 * (row & 7)) % (width >> 3) : 0; };
+  // (such a width has >= 16 pieces per row, so 2 (row & 7) <= 14 needs no reduction.  The set-up below avoids run-time integer
+  // divisions where it can -- ~40 of them, ~40 VALU instructions each, made the prologue 10 k cycles: a third of a workgroup's
+  // life at T*B = 2560 rows)
+  auto bf_rot = [](int width, int row) { return ((width & 127) == 0) ? 2 * (row & 7) : 0; };
+  auto wrap = [](int x, int n) { return x >= n ? x - n : x; };               // x mod n for 0 <= x < 2 n
 
   // ---- per-thread DMA plan: piece p = i * 512 + tid -> (image, row of the chunk, 8-column group).  Plain global addresses
   // (global_load_dwordx4 ... lds), one 64-bit pointer per piece advanced by a per-piece stride each chunk; a piece that
@@ -151,12 +156,13 @@ __device__ __forceinline__ void dw_stream_body(const DwbLaunch& L, const DwbItem
   unsigned vld[DWB_MAXNI];
   auto chunk_range = [&](int row0, int hi) -> unsigned {
     // chunks c with 0 <= row0 + KR c < hi
-    const int first = row0 >= 0 ? 0 : (-row0 + KR - 1) / KR;
-    const int end = hi > row0 ? (hi - row0 + KR - 1) / KR : 0;              // first chunk with row >= hi
+    const int first = row0 >= 0 ? 0 : (-row0 + KR - 1) >> kr_shift;
+    const int end = hi > row0 ? (hi - row0 + KR - 1) >> kr_shift : 0;       // first chunk with row >= hi
     const int count = end > first ? min(end - first, 65535) : 0;
     return (unsigned)min(first, 65535) | ((unsigned)count << 16);
   };
   const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(L.zeros);
+  const unsigned magic0 = (1u << 20) / (unsigned)max(n0 / EPP, 1) + 1u, magic1 = (1u << 20) / (unsigned)max(n1 / EPP, 1) + 1u;
 #pragma unroll
   for (int i = 0; i < DWB_MAXNI; ++i) {
     const int p = i * DWB_THREADS + tid;
@@ -167,7 +173,7 @@ __device__ __forceinline__ void dw_stream_body(const DwbLaunch& L, const DwbItem
     if (p < pa) {
       constexpr int GPR = MT / EPP;
       const int row = p / GPR, cpos = p % GPR;
-      const int cg = F32 ? (cpos + 4 * (row & 1)) % GPR : (cpos + bf_rot(MT, row)) % GPR;
+      const int cg = F32 ? (cpos + 4 * (row & 1)) % GPR : wrap(cpos + bf_rot(MT, row), GPR);
       if (m0 + cg * EPP < I.lda) {                        // columns past the row end: zeros, not the next row's data
         src[i] = abase + ((int64_t)(r_begin + row) * I.lda + m0 + cg * EPP) * ES;
         inc[i] = KR * I.lda * ES; vld[i] = chunk_range(r_begin + row, r_end);
@@ -180,8 +186,9 @@ __device__ __forceinline__ void dw_stream_body(const DwbLaunch& L, const DwbItem
       const int sld = s1 ? I.seg[1].ld : I.seg[0].ld, sn = s1 ? n1 : n0, sc0 = s1 ? I.seg[1].col0 : I.seg[0].col0;
       const int ssh = s1 ? I.seg[1].shift : I.seg[0].shift, srows = s1 ? I.seg[1].rows : I.seg[0].rows;
       const int pp = p - pa - (s1 ? p0 : 0), gpr = sn / EPP;
-      const int row = pp / gpr, cpos = pp % gpr;
-      const int cg = F32 ? (cpos + 4 * (row & 1)) % gpr : (cpos + bf_rot(sn, row)) % gpr;
+      // pp / gpr by a multiply: exact while pp x gpr < 2^20 (pp < 128 x 72 pieces of a chunk, gpr <= 144)
+      const int row = (int)(((unsigned)pp * (s1 ? magic1 : magic0)) >> 20), cpos = pp - row * gpr;
+      const int cg = F32 ? (cpos + 4 * (row & 1)) % gpr : wrap(cpos + bf_rot(sn, row), gpr);
       // row r of the chunk pairs with row r - shift of the segment
       src[i] = sp + ((int64_t)(r_begin + row - ssh) * sld + sc0 + cg * EPP) * ES;
       inc[i] = KR * sld * ES; vld[i] = chunk_range(r_begin + row - ssh, srows);
@@ -225,7 +232,7 @@ __device__ __forceinline__ void dw_stream_body(const DwbLaunch& L, const DwbItem
   };
   auto bf_pos = [&](int width, int col) {            // bf16 element index of (row rrow, column col) in a [32][width] slab
     const int gpr = width >> 3, rot = bf_rot(width, rrow);
-    return rrow * width + (((col >> 3) - rot + gpr) % gpr) * 8 + (col & 7);
+    return rrow * width + wrap((col >> 3) - rot + gpr, gpr) * 8 + (col & 7);
   };
   int a_off[MF];
 #pragma unroll
