@@ -129,13 +129,17 @@ __global__ __launch_bounds__(PJ_THREADS + 64) void proj_bf16_kernel(const PjDev 
     const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)L.x, 0, x_bytes, 0x00020000);
     const int gpr = KP / 4;
     const int total = BM * gpr;
+    // idx / gpr by a multiply (exact while idx x gpr < 2^24; the product stays below 2^32 for BM <= 255): a run-time integer
+    // division is ~40 VALU instructions, and this loop had two per 16-byte piece -- ~56 per thread ahead of the first MFMA
+    const unsigned gmagic = (1u << 24) / (unsigned)gpr + 1u;
+    auto div_gpr = [&](int idx) { return (int)(((unsigned)idx * gmagic) >> 24); };
     constexpr int U = 14;                         // 16-byte loads in flight per thread (HBM latency x 64 B/clk wants ~100 KB)
     for (int base = tid; base < ((L.dbg & 8) ? 0 : total); base += PJ_THREADS * U) {
       f32x4 v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int idx = min(base + u * PJ_THREADS, total - 1);
-        const int r = idx / gpr, k = (idx - r * gpr) * 4;
+        const int r = div_gpr(idx), k = (idx - r * gpr) * 4;
         const int off = (int)(((int64_t)min(m0 + r, L.M - 1) * L.lda + min(k, L.K - 1)) * 4);
         v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
       }
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(PJ_THREADS + 64) void proj_bf16_kernel(const PjDev 
       for (int u = 0; u < U; ++u) {
         const int idx = base + u * PJ_THREADS;
         if (idx < total) {
-          const int r = idx / gpr, k = (idx - r * gpr) * 4;
+          const int r = div_gpr(idx), k = (idx - r * gpr) * 4;
           f32x4 w = v[u];
 #pragma unroll
           for (int e = 0; e < 4; ++e) w[e] = (m0 + r < L.M && k + e < L.K) ? w[e] : 0.0f;
@@ -157,8 +161,9 @@ __global__ __launch_bounds__(PJ_THREADS + 64) void proj_bf16_kernel(const PjDev 
   // ---- side output: the padded bf16 image of these rows (modality slices on 16-column boundaries, pads zero)
   if (L.x16 && ysplit == 0 && !(L.dbg & 1)) {
     const int cpr = L.x16_ld >> 3;
+    const unsigned cmagic = (1u << 24) / (unsigned)cpr + 1u;
     for (int idx = tid; idx < BM * cpr; idx += PJ_THREADS) {
-      const int r = idx / cpr, c8 = (idx - r * cpr) * 8;
+      const int r = (int)(((unsigned)idx * cmagic) >> 24), c8 = (idx - r * cpr) * 8;
       if (m0 + r >= L.M) continue;
       int s = 0;
       if (c8 >= L.xdst0[1]) s = 1;
