@@ -30,6 +30,7 @@
 //   alone on its CU and a dependent load per reduction step would cost an L2 round trip each.
 #include <hip/hip_runtime.h>
 #include "internal.h"
+#include "lstamp.h"
 
 namespace mfm {
 
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(FC1_THREADS) void dec_fc1_kernel(const DecFc1Launch
   __shared__ __attribute__((aligned(16))) float Dx[FC1_ROWS * FC1_LD];              // d x_hat of this column group
   __shared__ __attribute__((aligned(16))) float Pt[(FC1_WAVES / 2) * FC1_ROWS * FC1_LD];  // partial dH tiles (two waves each)
   __shared__ float red[FC1_WAVES];
+  LSTAMP(2, 0);
   // which decoder, row tile, column group
   int m = 0;
 #pragma unroll
@@ -108,6 +110,7 @@ __global__ __launch_bounds__(FC1_THREADS) void dec_fc1_kernel(const DecFc1Launch
   }
   if (hr < FC1_ROWS) *reinterpret_cast<f32x4*>(Ht + hr * FC1_LD + hk) = hreg;
   lds_barrier();
+  LSTAMP(2, 1);
 
   // ---- product 1 (branch-free: blocks >= J were requested as zeros and meet a clamped hidden block; units >= h of a
   //      weight row belong to the next row -- finite values -- and meet zeros of the hidden tile)
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(FC1_THREADS) void dec_fc1_kernel(const DecFc1Launch
     for (int w = 0; w < FC1_WAVES; ++w) s += red[w];
     atomicAdd(I.loss, s * I.inv_count);
   }
+  LSTAMP(2, 2);
   if (!L.with_bwd) return;
 
   // ---- product 2: dH[16, Hp] (+)= dx_hat[16, group columns] Wfc[group columns, h]
@@ -192,6 +196,7 @@ __global__ __launch_bounds__(FC1_THREADS) void dec_fc1_kernel(const DecFc1Launch
       for (int e = 0; e < 4; ++e) atomicAdd(o + e, s[e]);
     }
   }
+  LSTAMP_W(2, 15);
 }
 
 // MFM_ERR_UNSUPPORTED: a shape this kernel does not take (the caller falls back to the two GEMM launches)
@@ -214,6 +219,7 @@ int dec_fc1_launch(DecFc1Launch& L, bool dhs_zeroed, hipStream_t stream) {
     I.tile_begin = tiles;
     tiles += row_tiles * I.col_groups;
   }
+  LSTAMP_BIND();
   hipLaunchKernelGGL(dec_fc1_kernel, dim3(tiles), dim3(FC1_THREADS), 0, stream, L);
   MFM_LAUNCH_CHECK("dec_fc1_kernel");
   return MFM_OK;

@@ -20,6 +20,7 @@
 #include "internal.h"
 #include "lstm_seq_dev.h"
 #include "proj_role_dev.h"
+#include "lstamp.h"
 
 namespace mfm {
 
@@ -90,7 +91,26 @@ __device__ __forceinline__ bool dwr_ready(const unsigned* f, int n, unsigned epo
   return __builtin_amdgcn_ballot_w64(v0 != epoch || v1 != epoch || v2 != epoch || v3 != epoch) == 0ull;
 }
 
-__device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned epoch, float* lds) {
+// One (iteration, slot) entry of the block table, resolved against the problem descriptors ONCE per launch (round 6).  The launch
+// clock (profiles/r06_launch_timeline.txt) put 2.6 of the 6.6 us a table iteration takes into bookkeeping: two table loads from
+// memory, then a chain of dependent scalar loads of the by-value problem descriptors for the operand addresses -- per iteration,
+// in front of the loads they describe.  Now the workgroup copies the descriptors from the kernel-argument segment into LDS,
+// thread e builds the record of entry e = 4 * iteration + slot, and an iteration starts with six LDS reads.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+struct DwRec {
+  unsigned long long a, b, c, c2;                           // A slice (workgroup), B and C / C2 of this slot, gate block included
+  int a_bytes, a_sk, m, m0, kbeg, klen, dept0, w;           // dept0 = dep | t0 << 8; w = table flags | DWR_ACTIVE | DWR_GACTIVE
+  int b_bytes, b_sk, b_row0, n0, n_valid, ldc; float alpha; int pm;     // b_row0 = kbeg - b_shift; pm = rows of C
+};
+static_assert(sizeof(DwRec) == 96 && sizeof(DwRoleProblem) == 96, "dw role records: 24 dwords each");
+static_assert(alignof(SeqLaunch) == 8 && alignof(LatentDev) == 8 && alignof(DwRole) == 8 && sizeof(SeqLaunch) % 8 == 0 && sizeof(LatentDev) % 8 == 0,
+              "dw role records: the kernel-argument offset of the DwRole descriptor (lstm_seq_small_folddw_kernel)");
+constexpr int DWR_MAXREC = 128;                             // entries per workgroup: DWR_TABLE_CAP / (4 * 32 role workgroups at least)
+constexpr int DWR_ACTIVE = 1 << 28, DWR_GACTIVE = 1 << 29;
+constexpr int DWR_LDS_FLOATS = 5 * DWR_KC * DWR_T + 16 + DWR_MAXREC * 24 + DWR_MAXP * 24;    // images, answer word, records, descriptors
+
+// `karg_dr`: the DwRole descriptor in the kernel-argument segment (read with per-lane indices: never through the by-value copy)
+__device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned epoch, float* lds, const int* __restrict__ karg_dr) {
   // One role workgroup = four slots of 256 threads that work on tiles with the SAME A slice (same rows, same 32 columns of
   // the gate-gradient / upstream-gradient operand: the dW_ih, dW_hh and bias tiles of one gate block, the column tiles of one
   // decoder fc1 row block ...): the slice is fetched once per workgroup -- one 16-byte agent-scope load per thread -- instead
@@ -107,60 +127,92 @@ __device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned ep
   float* As = lds;                                                 // [DWR_KC][32], shared
   float* Bs = lds + (1 + sub) * (DWR_KC * DWR_T);                  // [DWR_KC][32] per slot
   int* nready_lds = reinterpret_cast<int*>(lds + 5 * DWR_KC * DWR_T);
+  int* recs = reinterpret_cast<int*>(lds + 5 * DWR_KC * DWR_T + 16);              // [n_iter][4] DwRec
+  int* probs = recs + DWR_MAXREC * 24;                                             // [count] DwRoleProblem (build only)
   const int r = blockIdx.x - 4 * DR.B;           // role index
-  const int nslots = 4 * DR.n_role, slot = 4 * r + sub;
+  const int nslots = 4 * DR.n_role;
+  const int n_iter = DR.n_iter;
   f32x4 accs[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
-  struct Item {                      // one table row as this thread's slot sees it (all fields wave-uniform)
+  // ---- records
+  {
+    const int nw = DR.count * 24;
+    for (int i = tid; i < nw; i += 1024) probs[i] = karg_dr[i];              // (DwRole::p is the descriptor's first member)
+    int4 ent = {-1, 0, 0, 0}, ea = {-1, 0, 0, 0};
+    const int it = tid >> 2;
+    if (tid < 4 * n_iter) {
+      ent = DR.table[(int64_t)it * nslots + 4 * r + (tid & 3)];
+      ea = DR.table[(int64_t)it * nslots + 4 * r];                           // slot 0 describes the workgroup's A slice
+    }
+    __syncthreads();
+    if (tid < 4 * n_iter) {
+      const bool active = ent.x >= 0, gactive = ea.x >= 0;
+      const DwRoleProblem& P = reinterpret_cast<const DwRoleProblem*>(probs)[active ? ent.x : 0];
+      const DwRoleProblem& PA = reinterpret_cast<const DwRoleProblem*>(probs)[gactive ? ea.x : 0];
+      const int la = ea.y / PA.tiles_n;
+      const int tm = la % PA.tiles_m, z = la / PA.tiles_m;                   // (the same for every active slot of the workgroup)
+      const int kbeg = ea.z * PA.kps;
+      DwRec R;
+      R.a = (unsigned long long)(PA.a + (int64_t)z * PA.a_sz);
+      R.b = (unsigned long long)(P.b + (int64_t)z * P.b_sz);
+      R.c = (unsigned long long)(P.c + (int64_t)z * P.c_sz);
+      R.c2 = P.c2 ? (unsigned long long)(P.c2 + (int64_t)z * P.c_sz) : 0ull;
+      R.a_bytes = ((PA.m - 1) + (PA.k - 1) * PA.a_sk + 1) * 4; R.a_sk = PA.a_sk; R.m = PA.m; R.m0 = tm * DWR_T;
+      R.kbeg = kbeg; R.klen = gactive ? min(PA.k - kbeg, PA.kps) : 0;
+      R.dept0 = gactive ? ((ea.w & 255) | (((ea.w >> 8) & 0xffff) << 8)) : DWR_DEP_NONE;
+      R.w = (ent.w & 0x0fffffff) | (active ? DWR_ACTIVE : 0) | (gactive ? DWR_GACTIVE : 0);
+      // row kbeg + rr of the chunk pairs with row kbeg + rr - b_shift of B (the recurrent product sum_t dA_t^T h_{t-1}: rows of
+      // the first time step read zeros)
+      R.b_bytes = ((max(P.n_valid, 1) - 1) + (max(P.k - P.b_shift, 1) - 1) * P.b_sk + 1) * 4; R.b_sk = P.b_sk;
+      R.b_row0 = kbeg - P.b_shift; R.n0 = (ent.y % P.tiles_n) * DWR_T; R.n_valid = P.n_valid; R.ldc = P.ldc; R.alpha = P.alpha; R.pm = P.m;
+      *reinterpret_cast<DwRec*>(recs + tid * 24) = R;
+    }
+    __syncthreads();
+  }
+  struct Item {                      // one record as this thread's slot sees it (every field wave-uniform, in scalar registers)
     bool active, gactive;
-    int p, pa, w, tm, z, m0, n0, kbeg, klen, dep, t0;
+    unsigned long long a, b, c, c2;
+    int a_bytes, a_sk, m, m0, kbeg, klen, dep, t0, w, b_bytes, b_sk, b_row0, n0, n_valid, ldc, pm;
+    float alpha;
   };
+  auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
   auto decode = [&](int it) {
     Item I;
-    if (it >= DR.n_iter) { I.active = I.gactive = false; I.p = I.pa = 0; I.w = 0; I.tm = I.z = I.m0 = I.n0 = I.kbeg = I.klen = 0; I.dep = DWR_DEP_NONE; I.t0 = 0; return I; }
-    int4 ent = DR.table[(int64_t)it * nslots + slot];
-    int4 ea = DR.table[(int64_t)it * nslots + 4 * r];              // slot 0 describes the workgroup's A slice
-    ent.x = __builtin_amdgcn_readfirstlane(ent.x); ent.y = __builtin_amdgcn_readfirstlane(ent.y);
-    ent.z = __builtin_amdgcn_readfirstlane(ent.z); ent.w = __builtin_amdgcn_readfirstlane(ent.w);
-    ea.x = __builtin_amdgcn_readfirstlane(ea.x); ea.y = __builtin_amdgcn_readfirstlane(ea.y);
-    ea.z = __builtin_amdgcn_readfirstlane(ea.z); ea.w = __builtin_amdgcn_readfirstlane(ea.w);
-    I.active = ent.x >= 0; I.gactive = ea.x >= 0;
-    I.p = I.active ? ent.x : 0; I.pa = I.gactive ? ea.x : 0; I.w = ent.w;
-    const DwRoleProblem& P = DR.p[I.p];
-    const DwRoleProblem& PA = DR.p[I.pa];
-    int la = ea.y / PA.tiles_n;
-    I.tm = la % PA.tiles_m; I.z = la / PA.tiles_m;                 // (the same for every active slot of the workgroup)
-    I.m0 = I.tm * DWR_T; I.n0 = (ent.y % P.tiles_n) * DWR_T;
-    I.kbeg = ea.z * PA.kps;
-    I.klen = I.gactive ? min(PA.k - I.kbeg, PA.kps) : 0;
-    I.dep = I.gactive ? (ea.w & 255) : DWR_DEP_NONE; I.t0 = (ea.w >> 8) & 0xffff;
+    int v[24];
+    if (it < n_iter) {
+      const i32x4_t* rp = reinterpret_cast<const i32x4_t*>(recs + (4 * it + sub) * 24);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) { const i32x4_t x = rp[j]; v[4 * j] = rfl(x[0]); v[4 * j + 1] = rfl(x[1]); v[4 * j + 2] = rfl(x[2]); v[4 * j + 3] = rfl(x[3]); }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 24; ++j) v[j] = 0;
+    }
+    auto u64 = [&](int i) { return (unsigned long long)(unsigned)v[i] | ((unsigned long long)(unsigned)v[i + 1] << 32); };
+    I.a = u64(0); I.b = u64(2); I.c = u64(4); I.c2 = u64(6);
+    I.a_bytes = v[8]; I.a_sk = v[9]; I.m = v[10]; I.m0 = v[11]; I.kbeg = v[12]; I.klen = v[13];
+    I.dep = v[14] & 255; I.t0 = (v[14] >> 8) & 0xffff; I.w = v[15];
+    I.b_bytes = v[16]; I.b_sk = v[17]; I.b_row0 = v[18]; I.n0 = v[19]; I.n_valid = v[20]; I.ldc = v[21];
+    I.alpha = __builtin_bit_cast(float, v[22]); I.pm = v[23];
+    I.active = (I.w & DWR_ACTIVE) != 0; I.gactive = (I.w & DWR_GACTIVE) != 0;
     return I;
   };
-  // the B operand (batch columns, hidden states, records of the forward) never depends on this launch.  Row kbeg + rr of the
-  // chunk pairs with row kbeg + rr - b_shift of B (the recurrent product sum_t dA_t^T h_{t-1}: rows of the first time step
-  // read zeros)
+  // the B operand (batch columns, hidden states, records of the forward) never depends on this launch
   auto issue_b = [&](const Item& I, f32x4 (&rb)[BL]) {
-    const DwRoleProblem& P = DR.p[I.p];
-    const float* Bm = P.b + (int64_t)I.z * P.b_sz;
-    const int b_bytes = ((max(P.n_valid, 1) - 1) + (max(P.k - P.b_shift, 1) - 1) * P.b_sk + 1) * 4;
-    const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc((void*)Bm, 0, b_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc((void*)I.b, 0, I.b_bytes, 0x00020000);
 #pragma unroll
     for (int j = 0; j < BL; ++j) {
       const int idx = t + j * 256;
       const int rr = idx >> 3, c4 = idx & 7;
-      const int br = I.kbeg + rr - P.b_shift;
-      const int offb = (I.active & (rr < I.klen) & (br >= 0) & (I.n0 + 4 * c4 < P.n_valid)) ? (br * P.b_sk + I.n0 + 4 * c4) * 4 : -16;
+      const int br = I.b_row0 + rr;
+      const int offb = (I.active & (rr < I.klen) & (br >= 0) & (I.n0 + 4 * c4 < I.n_valid)) ? (br * I.b_sk + I.n0 + 4 * c4) * 4 : -16;
       rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bres, offb, 0, 0));
     }
   };
   // A may have been written inside this launch (dA, the latent gradients): agent-scope load (sc1), one per thread
   auto issue_a = [&](const Item& I) {
-    const DwRoleProblem& PA = DR.p[I.pa];
-    const float* A = PA.a + (int64_t)I.z * PA.a_sz;
-    const int a_bytes = ((PA.m - 1) + (PA.k - 1) * PA.a_sk + 1) * 4;
-    const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc((void*)I.a, 0, I.a_bytes, 0x00020000);
     const int rr = tid >> 3, c4 = tid & 7;
-    const int offa = (I.gactive & (rr < I.klen) & (I.m0 + 4 * c4 < PA.m)) ? ((I.kbeg + rr) * PA.a_sk + I.m0 + 4 * c4) * 4 : -16;
+    const int offa = (I.gactive & (rr < I.klen) & (I.m0 + 4 * c4 < I.m)) ? ((I.kbeg + rr) * I.a_sk + I.m0 + 4 * c4) * 4 : -16;
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ares, offa, 0, 16));
   };
   auto stamps_of = [&](const Item& I, int& n) -> const unsigned* {
@@ -175,7 +227,8 @@ __device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned ep
   bool a_pref = false;
   if (cur.dep == DWR_DEP_NONE) { ra = issue_a(cur); a_pref = true; }
 #pragma unroll 1
-  for (int it = 0; it < DR.n_iter; ++it) {
+  for (int it = 0; it < n_iter; ++it) {
+    LSTAMP(4, 16 + it);
     const Item nxt = decode(it + 1);
     // (1) the stamps of the current block, unless its A slice is already on its way; ONE wave per workgroup polls (many waves
     //     re-reading a few flag lines at the memory side wait on each other)
@@ -184,33 +237,38 @@ __device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned ep
       if (DR.any_dep) __syncthreads();
       ra = issue_a(cur);
     }
+#if MFM_LAUNCH_STAMP
+#define DWR_SUB(k) do { if (it == 5) LSTAMP(4, k); if (it == 1) LSTAMP(4, 6 + k); } while (0)
+#else
+#define DWR_SUB(k) ((void)0)
+#endif
+    DWR_SUB(1);
     // (2) are the next block's stamps there already?  (asked now, answered through LDS behind the barrier below)
     if (tid < 64) {
       bool ok = true;
       if (nxt.dep != DWR_DEP_NONE) { int n; const unsigned* f = stamps_of(nxt, n); ok = dwr_ready(f, n, epoch); }
       if (tid == 0) *nready_lds = ok ? 1 : 0;
     }
+    DWR_SUB(2);
     // (3) operands of the current block -> LDS images
     {
-      const DwRoleProblem& PA = DR.p[cur.pa];
       const int rr = tid >> 3, c4 = tid & 7;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        ra[e] = (cur.m0 + 4 * c4 + e < PA.m) ? ra[e] : 0.0f;
+        ra[e] = (cur.m0 + 4 * c4 + e < cur.m) ? ra[e] : 0.0f;
         if (DR.bf16) ra[e] = (float)(__bf16)ra[e];
       }
       const int sw = (4 * c4 + 16 * (rr & 1)) & 31;
       *reinterpret_cast<f32x4*>(As + rr * DWR_T + sw) = ra;
     }
     if (cur.active) {
-      const DwRoleProblem& P = DR.p[cur.p];
 #pragma unroll
       for (int j = 0; j < BL; ++j) {
         const int idx = t + j * 256;
         const int rr = idx >> 3, c4 = idx & 7;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          rb[j][e] = (cur.n0 + 4 * c4 + e < P.n_valid) ? rb[j][e] : 0.0f;
+          rb[j][e] = (cur.n0 + 4 * c4 + e < cur.n_valid) ? rb[j][e] : 0.0f;
           if (DR.bf16) rb[j][e] = (float)(__bf16)rb[j][e];
         }
         const int sw = (4 * c4 + 16 * (rr & 1)) & 31;
@@ -218,14 +276,15 @@ __device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned ep
       }
     }
     __syncthreads();
+    DWR_SUB(3);
     // (4) the next block's operands are requested before the current one is multiplied
     const bool nready = *nready_lds != 0;
     issue_b(nxt, rb);
     a_pref = false;
     if (nready) { ra = issue_a(nxt); a_pref = true; }
+    DWR_SUB(4);
     // (5) product, epilogue
     if (cur.active) {
-      const DwRoleProblem& P = DR.p[cur.p];
       const bool a1 = (cur.w & DWR_ACC1) != 0;
       f32x4 acc = a1 ? accs[1] : accs[0];
       if (cur.w & DWR_FIRST) acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -244,28 +303,30 @@ __device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned ep
       for (; ks < nks; ++ks) acc = mma16x16x4(ap[ks * 4 * DWR_T], bp[ks * 4 * DWR_T], acc);
       if (a1) accs[1] = acc; else accs[0] = acc;
       if (cur.w & DWR_LAST) {
-        float* __restrict__ C = P.c + (int64_t)cur.z * P.c_sz;
-        float* __restrict__ C2 = P.c2 ? P.c2 + (int64_t)cur.z * P.c_sz : nullptr;
+        float* __restrict__ C = reinterpret_cast<float*>(cur.c);
+        float* __restrict__ C2 = reinterpret_cast<float*>(cur.c2);
         const int col = cur.n0 + 16 * wn + bi;
-        if (col < P.n_valid) {
+        if (col < cur.n_valid) {
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
             const int row = cur.m0 + 16 * wm + 4 * q + rr;
-            if (row < P.m) {
-              const float v = P.alpha * acc[rr];
+            if (row < cur.pm) {
+              const float v = cur.alpha * acc[rr];
               if (cur.w & DWR_STORE) {             // the tile's only contribution, into a buffer that holds zeros: a plain store
-                C[(int64_t)row * P.ldc + col] = v;
-                if (C2) C2[(int64_t)row * P.ldc + col] = v;
+                C[(int64_t)row * cur.ldc + col] = v;
+                if (C2) C2[(int64_t)row * cur.ldc + col] = v;
               } else {
-                atomicAdd(C + (int64_t)row * P.ldc + col, v);
-                if (C2) atomicAdd(C2 + (int64_t)row * P.ldc + col, v);
+                atomicAdd(C + (int64_t)row * cur.ldc + col, v);
+                if (C2) atomicAdd(C2 + (int64_t)row * cur.ldc + col, v);
               }
             }
           }
         }
       }
     }
+    DWR_SUB(5);
     __syncthreads();          // the images (and the answer word) are free for the next block
+    DWR_SUB(6);
     cur = nxt;
   }
 }

@@ -3,6 +3,7 @@
 #include <stdarg.h>
 
 #include "internal.h"
+#include "lstamp.h"
 
 namespace mfm {
 
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float bc2_sqrt, float grad_scale, const float* __restrict__ guard) {
   // guard word (mfm_adam_flat_guarded): anything but 0.0f -- the plan stores a NaN -- means the gradients of this step cannot
   // be trusted; p, m and v stay as they are (uniform branch, one cached load per thread)
+  LSTAMP(5, 0);
   if (guard && !(guard[0] == 0.0f)) return;
   const int64_t n4 = n >> 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -151,6 +153,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     m[i] = mm; v[i] = vv;
     p[i] = p[i] - step_size * mm / (sqrtf(vv) / bc2_sqrt + eps);
   }
+  LSTAMP_W(5, 15);
 }
 
 int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1,
@@ -164,6 +167,7 @@ int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, int ste
   int64_t nb = ((n >> 2) + 255) / 256;
   if (nb < 1) nb = 1;
   if (nb > 2048) nb = 2048;
+  LSTAMP_BIND();
   hipLaunchKernelGGL(adam_kernel, dim3((int)nb), dim3(256), 0, stream, p, g, m, v, n, beta1, beta2, eps, step_size,
                      bc2_sqrt, grad_scale, guard);
   MFM_LAUNCH_CHECK("adam_kernel");

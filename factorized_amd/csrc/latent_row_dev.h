@@ -3,6 +3,7 @@
 // row's chain right behind its last time step, and ahead of its BPTT).  Test infrastructure does not include this file.
 #pragma once
 #include "internal.h"
+#include "lstamp.h"
 
 namespace mfm {
 
@@ -90,11 +91,19 @@ __device__ __forceinline__ void load_items(const int* __restrict__ items, int ns
 // `row`, `ch`: the batch row and (L.nch == 4) the modality chain of this workgroup.  `own_input`: the workgroup is the
 // encoder recurrence of (row, ch) that has just written its last hidden state (fold launch, lstm_seq_small.hip): only
 // that input may be read -- the other encoders' workgroups may still be running.
+// `mode` (round 6; the launch clock put 3.3 us between the last time step and the first stage: the 96 KB item table, the op
+// table and a re-read of the row's own h_T from global memory behind a store wait): 0 = the whole body; 1 = PRELOAD only --
+// everything of the prologue that depends on nothing of this launch (op table, item table, target) goes to LDS and returns, no
+// barrier: the fold launch calls it before the time loop, whose buffers lie behind this body's LDS region
+// (latent_fwd_lds_floats); 2 = the rest, with the chain's input taken from `h_lds` (the recurrence's last hidden state, LDS).
+__host__ __device__ static inline int latent_fwd_lds_floats(int rec_size) { return MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + rec_size; }
 template <bool PRE>
 __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const float* __restrict__ params, const int row, const int ch,
-                                                    float* lds, const bool own_input) {
+                                                    float* lds, const bool own_input, const int mode = 0,
+                                                    const float* h_lds = nullptr) {
   __shared__ LatOp ops[MFM_LAT_MAXOPS];
   __shared__ float red[2][16];
+  __shared__ float ysave[2][128];
   i32x4* tab = reinterpret_cast<i32x4*>(lds);                        // [MAXSTAGES][1024] items
   float* rec = lds + MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
   // nch == 4: this workgroup runs ONE modality chain (l, a, v or y) of its row -- the chains are independent inside the
@@ -110,23 +119,33 @@ __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const fl
   int ylab = 0;
   {
     const int nw = L.nops * (int)(sizeof(LatOp) / 4);
-    const int opv = reinterpret_cast<const int*>(L.ops)[min(tid, nw - 1)];
     const int e0 = L.enc_n[0], e1 = e0 + L.enc_n[1], e2 = e1 + L.enc_n[2], e3 = e2 + L.enc_n[3];
     const int tt = min(tid, e3 - 1);
     const int m = (tt >= e0) + (tt >= e1) + (tt >= e2);
     const int kk = tt - (m == 0 ? 0 : (m == 1 ? e0 : (m == 2 ? e1 : e2)));
-    const float* src = m == 0 ? L.enc_h[0] : (m == 1 ? L.enc_h[1] : (m == 2 ? L.enc_h[2] : L.enc_h[3]));
-    const int64_t ld = m == 0 ? L.enc_ld[0] : (m == 1 ? L.enc_ld[1] : (m == 2 ? L.enc_ld[2] : L.enc_ld[3]));
     const int io = m == 0 ? L.in_off[0] : (m == 1 ? L.in_off[1] : (m == 2 ? L.in_off[2] : L.in_off[3]));
     const bool in_ok = !own_input || m == ch;
-    const float hv = in_ok ? src[(int64_t)row * ld + kk] : 0.0f;
-    if (L.y) {      // the target is needed only by the loss at the very end: fetch it now, not there
-      if (L.loss_kind == 0) yv = reinterpret_cast<const float*>(L.y)[(int64_t)row * L.od + min(tid, L.od - 1)];
-      else ylab = (int)reinterpret_cast<const int64_t*>(L.y)[row];
+    if (mode != 2) {
+      const int opv = reinterpret_cast<const int*>(L.ops)[min(tid, nw - 1)];
+      const float* src = m == 0 ? L.enc_h[0] : (m == 1 ? L.enc_h[1] : (m == 2 ? L.enc_h[2] : L.enc_h[3]));
+      const int64_t ld = m == 0 ? L.enc_ld[0] : (m == 1 ? L.enc_ld[1] : (m == 2 ? L.enc_ld[2] : L.enc_ld[3]));
+      float hv = 0.0f;
+      if (mode == 0) hv = in_ok ? src[(int64_t)row * ld + kk] : 0.0f;
+      if (L.y) {      // the target is needed only by the loss at the very end: fetch it now, not there
+        if (L.loss_kind == 0) yv = reinterpret_cast<const float*>(L.y)[(int64_t)row * L.od + min(tid, L.od - 1)];
+        else ylab = (int)reinterpret_cast<const int64_t*>(L.y)[row];
+      }
+      load_items(L.items_fwd + (size_t)ch * (MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4), L.nstages, tab, tid);
+      if (tid < nw) reinterpret_cast<int*>(ops)[tid] = opv;
+      if (mode == 0 && tid < e3) rec[io + kk] = hv;
+      if (mode == 1) {
+        if (tid < 128) { ysave[0][tid] = yv; ysave[1][tid] = __builtin_bit_cast(float, ylab); }
+        return;
+      }
+    } else {
+      if (tid < e3) rec[io + kk] = in_ok ? h_lds[kk] : 0.0f;
+      yv = ysave[0][min(tid, 127)]; ylab = __builtin_bit_cast(int, ysave[1][0]);
     }
-    load_items(L.items_fwd + (size_t)ch * (MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4), L.nstages, tab, tid);
-    if (tid < nw) reinterpret_cast<int*>(ops)[tid] = opv;
-    if (tid < e3) rec[io + kk] = hv;
   }
   // Descriptor fields the epilogue needs are fetched NOW (scalar loads, first touch of those kernarg lines)
   // and pinned in SGPRs: read where they are used they cost the tail of the kernel a chain of cold misses.
@@ -158,11 +177,15 @@ __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const fl
   mark(L, 0);
   lds_barrier();
   mark(L, 1);
+  LSTAMP(0, 16);
   auto stage = [&](int s, Slot& cur, Slot& nxt) {
     // A wave with no item in this stage nor in the next skips the body.  Inside the body every load is
     // unconditional (the last stage requests its own weights again): a load under a branch would make the
     // compiler's in-order vmcnt accounting conservative and the wait for `cur` would also cover `nxt`.
     const int sn = min(s + 1, L.nstages - 1);
+#if MFM_LAUNCH_STAMP
+    if (s == 2) LSTAMP(0, 26);
+#endif
     if (wave0 < (PRE ? nif[s] : max(nif[s], nif[sn]))) {
       const int in_off = cur.e[2] & 0xFFFF, K = (cur.e[2] >> 16) & 0xFF;
       f32x4 xv[8];
@@ -170,8 +193,14 @@ __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const fl
 #pragma unroll
         for (int j = 0; j < 8; ++j) xv[j] = *reinterpret_cast<const f32x4*>(rec + in_off + min(4 * q + 16 * j, K - 4));
       }
+#if MFM_LAUNCH_STAMP
+      if (s == 2 && threadIdx.x < 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); LSTAMP(0, 27); }
+#endif
       if constexpr (!PRE) fetch(sn, nxt);
       mark(L, 2 + 2 * s);
+#if MFM_LAUNCH_STAMP
+      if (s == 2 && threadIdx.x < 64) { LSTAMP(0, 28); asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); LSTAMP(0, 29); }
+#endif
       if (wave0 < nif[s]) {
         float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
@@ -206,8 +235,12 @@ __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const fl
         }
       }
     }
+#if MFM_LAUNCH_STAMP
+    if (s == 2) LSTAMP(0, 30);
+#endif
     lds_barrier();
     mark(L, 3 + 2 * s);
+    LSTAMP(0, 17 + s);
   };
   if constexpr (PRE) {
     Slot sl[LAT_PRE_SLOTS];
@@ -260,6 +293,7 @@ __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const fl
     if ((tid & 63) == 0) { red[0][tid >> 6] = kld; red[1][tid >> 6] = disc; }
   }
   lds_barrier();
+  LSTAMP(0, 25);
   if (tid == 0 && e_losses) {
     if (e_haslv) atomicAdd(e_losses + 4, -0.5f * (red[0][0] + red[0][1]));
     if (L.y && ych) {
@@ -371,6 +405,7 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
   }
 #undef LAT_KEEP
   lds_barrier();
+  LSTAMP(4, 16);
   const int l = tid & 15;
   const int wave0 = tid & ~63;
   struct Slot { f32x4 w[8]; i32x4 e; };
@@ -452,6 +487,7 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
   }
   lds_barrier();
   mark(L, 24);
+  LSTAMP(4, 17);
 
   auto stage = [&](int s, Slot& cur, Slot& nxt) {
     const int sn = max(s - 1, 0);
@@ -495,6 +531,7 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
     mark(L, 26 + 3 * s);
     lds_barrier();
     mark(L, 27 + 3 * s);
+    LSTAMP(4, 18 + s);
   };
   if constexpr (PRE) {
 #pragma unroll

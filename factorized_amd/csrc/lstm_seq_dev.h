@@ -16,6 +16,7 @@ struct SeqDev {
   int h, Hp, hk4, is_dec, block_begin;
   int store_bf16;          // bf16 path: gates / hs / the decoders' dh_ext are __bf16 buffers (MfmSeqDesc::store_bf16)
   const float* wt_img;     // fp32 one-row BPTT, optional: this step's transposed weights in thread order (proj_role_dev.h), or null
+  const float* wf_img;     // fp32 one-row forward, decoders, optional: W_ih + W_hh of this step in the forward's thread order, or null
 };
 // Transposed-weight images for the one-row BPTT kernels of the same step (lstm_seq_small.hip, small_bwd_body<.., KS = 16>):
 // img[s][tid], s = which * 4 NG + g * NG + i, holds W[g h + 16 i + (tid & 15)][2 (tid >> 4) + which] (w_ih set: W_ih + W_hh,
@@ -56,7 +57,38 @@ __device__ __forceinline__ void wt_img_write(const WtImgItem* items, const int n
   }
 }
 
+// Forward-order image of a decoder's steps >= 1 weights (round 6; the launch clock, profiles/r06_launch_timeline.txt, put the
+// decoders' mid-launch reload of W_ih + W_hh at 6.4 us: two strided 16-byte gathers per register quad and an add, behind step
+// 0): img4[(gl * NM + m) * NTH + tid] = (W_ih + W_hh)[(2 gp + gl) h + u][16 m + 4 q .. + 3] with q = tid & 3, gp = (tid >> 2) & 1,
+// u = tid >> 3, NM = HKB / 16, NTH = 8 HKB -- exactly the registers w[gl][4 m ..] of small_fwd_body<KQ, 1>, so the reload is 2 NM
+// coalesced 16-byte loads per thread.  Zero outside the valid units.  Written like the transposed images (role workgroups of
+// the encoder launch), read by the decoder launch behind it.  h % 4 == 0 only.
+__device__ __forceinline__ void wf_img_write(const WtImgItem* items, const int n, const int r, const int nr) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+#pragma unroll 1
+  for (int w = 0; w < n; ++w) {
+    const WtImgItem& I = items[w];
+    const int NM = I.HKB >> 4, NTH = 8 * I.HKB, h = I.h;
+    const int total = 2 * NM * NTH;
+    f32x4* out = reinterpret_cast<f32x4*>(I.img);
+    for (int idx = r * nt + tid; idx < total; idx += nr * nt) {
+      const int s = idx / NTH, t2 = idx - s * NTH;
+      const int gl = s / NM, m = s - gl * NM;
+      const int q = t2 & 3, gp = (t2 >> 2) & 1, u = t2 >> 3;
+      const int k0 = 16 * m + 4 * q;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (u < h && k0 < h) {
+        const int64_t o = ((int64_t)(2 * gp + gl) * h + u) * h + k0;
+        v = *reinterpret_cast<const f32x4*>(I.w_hh + o) + *reinterpret_cast<const f32x4*>(I.w_ih + o);
+      }
+      out[idx] = v;
+    }
+  }
+}
+
 int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream);
+struct DecChain;
+int seq_small_dec_chain_launch(SeqLaunch& L, DecChain& C, hipStream_t stream);
 struct LatentDev;
 int seq_small_fold_launch(SeqLaunch& L, bool bwd, const LatentDev& LD, const float* params, float* grads, hipStream_t stream);
 // lstm_seq_bf16.hip: bf16 MFMA operands, fp32 accumulate / cell state / saved activations

@@ -54,8 +54,9 @@ __global__ __launch_bounds__(KS == 16 ? 1024 : 512) void lstm_seq_small_kernel4(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int di = 0;
   const int bid = blockIdx.x;
+  LSTAMP(BWD ? 3 : 1, 0);
   if constexpr (!BWD) {      // blocks behind the recurrence rows: this step's transposed-weight images (lstm_seq_dev.h)
-    if (L.n_img > 0 && bid >= L.img_begin) { wt_img_write(L.img, L.n_img, bid - L.img_begin, L.n_img_blocks); return; }
+    if (L.n_img > 0 && bid >= L.img_begin) { wt_img_write(L.img, L.n_img, bid - L.img_begin, L.n_img_blocks); LSTAMP(1, 15); return; }
   }
 #pragma unroll 1
   for (int i = 1; i < L.count; ++i)
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(KS == 16 ? 1024 : 512) void lstm_seq_small_kernel4(
   if (KK > 0 && di == IDX) {                                                     \
     if (BWD) small_bwd_body<(KK > 0 ? KK : 2), R, KS>(d, L.T, L.B, tile, lds);   \
     else small_fwd_body<(KK > 0 ? KK : 2), R, false, BF>(d, L.T, L.B, tile, lds);           \
+    LSTAMP(BWD ? 3 : 1, 15);                                                     \
     return;                                                                      \
   }
   MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3) MFM_ONE(4, K4) MFM_ONE(5, K5)
@@ -168,7 +170,8 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_foldproj_kernel(const Seq
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int bid = blockIdx.x;
   const unsigned epoch = ho_epoch(PR.epoch, PR.tick);
-  if (bid < PR.n_role) { proj_role_body(L, PR, epoch, lds); return; }
+  LSTAMP(0, 0);
+  if (bid < PR.n_role) { proj_role_body(L, PR, epoch, lds); LSTAMP(0, 15); return; }
   int di = 0;
 #pragma unroll 1
   for (int i = 1; i < L.count; ++i)
@@ -177,20 +180,39 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_foldproj_kernel(const Seq
   const int tile = bid - d.block_begin;
   const unsigned* flg = PR.flags + (int64_t)di * L.T * PROJ_ROLE_FLAGS;
   const int ncb = PR.e[di].ncb;
+  // PR.lat_pre (every encoder loads its weights straight into registers: no LDS weight panel): the chain's tables go to LDS NOW,
+  // while the row waits for its first projections anyway; the recurrence's buffers lie behind the chain's region, and the chain
+  // takes h_T from the recurrence's LDS buffer instead of reading it back from memory behind a store wait
+  const bool pre = PR.lat_pre != 0;
+  float* seq_lds = lds;
+  if (pre) {
+    latent_fwd_row_body<false>(LD, params, tile, di, lds, true, 1);
+    seq_lds = lds + latent_fwd_lds_floats(LD.rec_size);
+  }
+  const float* h_lds = nullptr;
 #define MFM_ONE(IDX, KK) \
-  if (KK > 0 && di == IDX) small_fwd_body<(KK > 0 ? KK : 2), 1, true>(d, L.T, L.B, tile, lds, flg, epoch, ncb, PR.ctl);
+  if (KK > 0 && di == IDX) h_lds = small_fwd_body<(KK > 0 ? KK : 2), 1, true>(d, L.T, L.B, tile, seq_lds, flg, epoch, ncb, PR.ctl);
   MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3)
 #undef MFM_ONE
   // the loss slots are cleared by the producers of t = 0: all of them have passed before this row's chain adds to them
+  // (the four flag sets are requested together: one round trip)
   if (threadIdx.x < 64) {
-#pragma unroll 1
-    for (int e = 0; e < 4; ++e) {
-      const unsigned* f0 = PR.flags + (int64_t)e * L.T * PROJ_ROLE_FLAGS;
-      proj_flags_wait(f0, proj_flags_load(f0, PR.e[e].ncb), epoch, PR.e[e].ncb, PR.ctl);
-    }
+    unsigned fv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) fv[e] = proj_flags_load(PR.flags + (int64_t)e * L.T * PROJ_ROLE_FLAGS, PR.e[e].ncb);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) proj_flags_wait(PR.flags + (int64_t)e * L.T * PROJ_ROLE_FLAGS, fv[e], epoch, PR.e[e].ncb, PR.ctl);
   }
-  sync_stores();           // every store of the last time step has been acknowledged: h_T of this row is readable
-  latent_fwd_row_body<false>(LD, params, tile, di, lds, true);
+  LSTAMP(0, 9);
+  if (pre) {
+    LSTAMP(0, 8);
+    latent_fwd_row_body<false>(LD, params, tile, di, lds, true, 2, h_lds);      // (its first barrier orders the flag wait above)
+  } else {
+    sync_stores();           // every store of the last time step has been acknowledged: h_T of this row is readable
+    LSTAMP(0, 8);
+    latent_fwd_row_body<false>(LD, params, tile, di, lds, true);
+  }
+  LSTAMP_W(0, 15);
 }
 
 // Backward fold launch with weight-gradient role workgroups (dw_role_dev.h): blocks [0, 4 B) are the fold launch's
@@ -201,7 +223,15 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_folddw_kernel(const SeqLa
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int bid = blockIdx.x;
   const unsigned epoch = ho_epoch(DR.epoch, DR.tick);
-  if (bid >= 4 * L.B) { dw_role_body(DR, epoch, lds); return; }
+  LSTAMP(4, 0);
+  if (bid >= 4 * L.B) {
+    // (the DwRole descriptor as it lies in the kernel-argument segment, behind L and LD: dw_role_dev.h reads it with per-lane indices)
+    typedef __attribute__((address_space(4))) const char kchar;
+    const char* kargs = (const char*)(kchar*)__builtin_amdgcn_kernarg_segment_ptr();
+    dw_role_body(DR, epoch, lds, reinterpret_cast<const int*>(kargs + sizeof(SeqLaunch) + sizeof(LatentDev)));
+    LSTAMP_W(4, 15);
+    return;
+  }
   // a plan whose status word is set (a hand-over of this or of an earlier step gave up: the forward's projections may be
   // garbage) must not train: the guard word of the gradient buffer makes the optimizer skip (and travels through the all-reduce)
   if (bid == 0 && threadIdx.x == 0 && DR.ctl.status && DR.ctl.poison && *DR.ctl.status != 0u)
@@ -213,7 +243,9 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_folddw_kernel(const SeqLa
   const SeqDev& d = L.d[di];
   const int tile = bid - d.block_begin;          // == batch row (one-row tiles)
   latent_bwd_row_body<false>(LD, params, grads, tile, di, lds);
+  LSTAMP(4, 9);
   sync_stores();           // d h_T of this (row, encoder) is in memory (and the LDS is free) before the BPTT reads it
+  LSTAMP(4, 8);
   if (threadIdx.x == 0) dwr_stamp(DR.flags + 4 * L.T * DWR_ROWS + di * L.B + tile, epoch);
   unsigned* stamp = DR.flags + (int64_t)di * L.T * DWR_ROWS + tile;
   const bool fault = DR.fault != 0 && bid == 0;
@@ -221,15 +253,46 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_folddw_kernel(const SeqLa
   if (KK > 0 && di == IDX) small_bwd_body<(KK > 0 ? KK : 2), 1, 16, true>(d, L.T, L.B, tile, lds, stamp, epoch, fault);
   MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3)
 #undef MFM_ONE
+  LSTAMP_W(4, 15);
 }
 
-static size_t small_lds_bytes(const SeqLaunch& L, bool bwd, int R) {
+// The decoder chain of a training step (dec_chain_dev.h): blocks [i B, (i + 1) B) = the rows of decoder i; recurrence, then the
+// row's fc1 + squared error + dH, then its BPTT.  The same SeqDev serves both recurrences (wf_img: forward, wt_img / dh_ext /
+// d_h_init: backward).
+template <int K0, int K1, int K2>
+__global__ __launch_bounds__(1024) void lstm_dec_chain_kernel(const SeqLaunch L, const DecChain C) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int di = 0;
+  const int bid = blockIdx.x;
+  LSTAMP(1, 0);
+#pragma unroll 1
+  for (int i = 1; i < L.count; ++i)
+    if (bid >= L.d[i].block_begin) di = i;
+  const SeqDev& d = L.d[di];
+  const int tile = bid - d.block_begin;          // == batch row (one-row tiles)
+#define MFM_ONE(IDX, KK) \
+  if (KK > 0 && di == IDX) small_fwd_body<(KK > 0 ? KK : 2), 1>(d, L.T, L.B, tile, lds);
+  MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2)
+#undef MFM_ONE
+  sync_stores();           // the row's hidden states are in memory (and the LDS is free)
+  dec_fc1_row_body(C.fc[di], L.T, L.B, tile, lds, C.bf16 != 0);
+  sync_stores();           // dH of this row is in memory (and the LDS is free) before the BPTT reads it
+  LSTAMP(3, 0);
+#define MFM_ONE(IDX, KK) \
+  if (KK > 0 && di == IDX) small_bwd_body<(KK > 0 ? KK : 2), 1, 16>(d, L.T, L.B, tile, lds);
+  MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2)
+#undef MFM_ONE
+  LSTAMP(3, 15);
+}
+
+// `no_panel` (forward, one-row tiles, every h % 4 == 0): the weights go straight into registers, the panel is not needed
+static size_t small_lds_bytes(const SeqLaunch& L, bool bwd, int R, bool no_panel = false) {
   size_t lds_bytes = 0;
   for (int i = 0; i < L.count; ++i) {
     const SeqDev& d = L.d[i];
     const size_t HK = (size_t)d.hk4 * 4;
     const size_t HKB = (HK + 15) / 16 * 16;
-    const size_t hh = (size_t)d.h * d.h;
+    const size_t hh = no_panel ? 0 : (size_t)d.h * d.h;
     // forward: h ring + max(weight panel, output record + x-projection record); backward: dA ring +
     // saved-activation record + weight panel (see the bodies)
     const size_t rec = (2 * 6 + 2 * 4) * HKB * R;
@@ -241,6 +304,7 @@ static size_t small_lds_bytes(const SeqLaunch& L, bool bwd, int R) {
 }
 
 int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
+  LSTAMP_BIND();
   int max_threads = 64;
   for (int i = 0; i < L.count; ++i)
     if (8 * L.d[i].Hp > max_threads) max_threads = 8 * L.d[i].Hp;
@@ -335,6 +399,7 @@ int seq_small_folddw_launch(SeqLaunch& L, const LatentDev& LD, DwRole& DR, const
   for (int i = 0; i < 4; ++i)
     if (L.d[i].hk4 != want[i] || L.d[i].is_dec) return MFM_ERR_UNSUPPORTED;
   if (!seq_small_folddw_supported(L.T, L.B)) return MFM_ERR_UNSUPPORTED;
+  LSTAMP_BIND();
   const int n_role = DR.n_role;          // the block table was laid out for this many role workgroups
   if (n_role < 1 || n_role > device_cus() - 4 * L.B) return MFM_ERR_UNSUPPORTED;
   DR.T = L.T; DR.B = L.B;
@@ -343,12 +408,44 @@ int seq_small_folddw_launch(SeqLaunch& L, const LatentDev& LD, DwRole& DR, const
   total += n_role;
   size_t lds_bytes = small_lds_bytes(L, true, 1);
   const size_t lat = ((size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + 2 * (size_t)LD.rec_size) * sizeof(float);
-  const size_t role = (size_t)5 * DWR_KC * DWR_T * sizeof(float) + 64;      // one shared A image + four B images + the pipeline's answer word
+  const size_t role = (size_t)DWR_LDS_FLOATS * sizeof(float);      // one shared A image + four B images + the pipeline's answer word + the block records
+  if (DR.n_iter * 4 > DWR_MAXREC) return MFM_ERR_UNSUPPORTED;
   lds_bytes = std::max(lds_bytes, std::max(lat, role));
   if (lds_bytes > 160 * 1024) return MFM_ERR_UNSUPPORTED;
   MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_folddw_kernel<8, 2, 20, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL((lstm_seq_small_folddw_kernel<8, 2, 20, 30>), dim3(total), dim3(1024), lds_bytes, stream, L, LD, DR, params, grads);
   MFM_LAUNCH_CHECK("lstm_seq_small_folddw_kernel");
+  return MFM_OK;
+}
+
+// MFM_OK: launched.  MFM_ERR_UNSUPPORTED: not a case the chain kernel takes (the caller issues the three launches).
+int seq_small_dec_chain_launch(SeqLaunch& L, DecChain& C, hipStream_t stream) {
+  LSTAMP_BIND();
+  // opt-in (MFM_DEC_CHAIN=1): measured slower than the three launches at the MOSI sizes (the row's fc1 products are bound by the
+  // fp32 MFMA rate of ONE CU; profiles/r06_dec_chain.txt)
+  if (!(opt_get("MFM_DEC_CHAIN") && atoi(opt_get("MFM_DEC_CHAIN")) == 1)) return MFM_ERR_UNSUPPORTED;
+  if (opt_get("MFM_SEQ_KS") || opt_get("MFM_SEQ_ROWS")) return MFM_ERR_UNSUPPORTED;
+  const int want[3] = {26, 6, 6};
+  if (L.count != 3 || L.T < 2 || L.T > 16 * DCH_MAXRT || L.bf16_dot) return MFM_ERR_UNSUPPORTED;
+  if (!((long)L.count * L.B < 6L * device_cus())) return MFM_ERR_UNSUPPORTED;          // one-row tiles only
+  int max_threads = 64, total = 0;
+  size_t fc_lds = 0;
+  for (int i = 0; i < 3; ++i) {
+    const SeqDev& d = L.d[i];
+    const DecFc1Item& I = C.fc[i];
+    if (d.hk4 != want[i] || !d.is_dec || (d.h & 3) != 0 || !d.wt_img || !d.wf_img || !d.dh_ext) return MFM_ERR_UNSUPPORTED;
+    if (I.d < 1 || I.d > DCH_MAXD || I.Hp != d.Hp || I.h != d.h || I.Hp > 16 * DCH_MAXJ || !I.dhs || !I.hs || !I.w || !I.bias || !I.x) return MFM_ERR_UNSUPPORTED;
+    if ((int64_t)I.d * I.h >= ((int64_t)1 << 28)) return MFM_ERR_UNSUPPORTED;
+    if (8 * d.Hp > max_threads) max_threads = 8 * d.Hp;
+    L.d[i].block_begin = total; total += L.B;
+    fc_lds = std::max(fc_lds, dch_lds_floats(L.T, I.Hp, I.d) * sizeof(float));
+  }
+  L.n_img = 0; L.n_img_blocks = 0;
+  const size_t lds_bytes = std::max(fc_lds, std::max(small_lds_bytes(L, false, 1, true), small_lds_bytes(L, true, 1)));
+  if (lds_bytes > 160 * 1024) return MFM_ERR_UNSUPPORTED;
+  MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_dec_chain_kernel<26, 6, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL((lstm_dec_chain_kernel<26, 6, 6>), dim3(total), dim3(max_threads), lds_bytes, stream, L, C);
+  MFM_LAUNCH_CHECK("lstm_dec_chain_kernel");
   return MFM_OK;
 }
 
@@ -379,6 +476,7 @@ int seq_small_foldproj_launch(SeqLaunch& L, const LatentDev& LD, ProjRole& PR, c
   int hh[4], kk[4];
   for (int i = 0; i < 4; ++i) { hh[i] = L.d[i].h; kk[i] = PR.e[i].k; }
   if (!seq_small_foldproj_supported(L.T, L.B, hh, kk, 4)) return MFM_ERR_UNSUPPORTED;
+  LSTAMP_BIND();
   int n_role = (device_cus() - 4 * L.B) / PROJ_ROLE_SLOTS * PROJ_ROLE_SLOTS;
   if (const char* e = opt_get("MFM_PROJ_FOLD_ROLES")) { const int v = atoi(e) / PROJ_ROLE_SLOTS * PROJ_ROLE_SLOTS; if (v >= PROJ_ROLE_SLOTS) n_role = v; }
   PR.n_role = n_role; PR.groups = n_role / PROJ_ROLE_SLOTS;
@@ -395,7 +493,22 @@ int seq_small_foldproj_launch(SeqLaunch& L, const LatentDev& LD, ProjRole& PR, c
   const size_t lat = ((size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + (size_t)LD.rec_size) * sizeof(float);
   const size_t role = ((size_t)2 * PROJ_ROLE_CB * PR.kstride + 16 * PROJ_ROLE_PW) * sizeof(float);
   lds_bytes = std::max(lds_bytes, std::max(lat, role));
+  // chain tables preloaded in front of the time loop: chain region + recurrence buffers side by side (lstm_seq_small_foldproj_kernel)
+  PR.lat_pre = 0;
+  if (!(opt_get("MFM_LATENT_PRELOAD") && atoi(opt_get("MFM_LATENT_PRELOAD")) == 0)) {
+    bool direct = true;
+    for (int i = 0; i < 4; ++i) direct = direct && (L.d[i].h & 3) == 0;
+    const size_t side = (size_t)latent_fwd_lds_floats(LD.rec_size) * sizeof(float) + small_lds_bytes(L, false, 1, true);
+    if (direct && side <= 160 * 1024) { PR.lat_pre = 1; lds_bytes = std::max(side, role); }
+  }
   if (lds_bytes > 160 * 1024) return MFM_ERR_UNSUPPORTED;
+  PR.n_warm = 0;
+  if (!(opt_get("MFM_LATENT_WARM") && atoi(opt_get("MFM_LATENT_WARM")) == 0)) {
+    for (int s = 0; s < LD.nstages && s < 8; ++s) {
+      if (LD.span_len[s] < 4 || (((uintptr_t)(params + LD.span_off[s])) & 15) != 0) continue;
+      PR.warm[PR.n_warm] = params + LD.span_off[s]; PR.warm_n4[PR.n_warm] = LD.span_len[s] >> 2; ++PR.n_warm;
+    }
+  }
   MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_foldproj_kernel<8, 2, 20, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL((lstm_seq_small_foldproj_kernel<8, 2, 20, 30>), dim3(total), dim3(1024), lds_bytes, stream, L, LD, PR, params);
   MFM_LAUNCH_CHECK("lstm_seq_small_foldproj_kernel");

@@ -34,6 +34,8 @@
 #include "lstm_seq_dev.h"
 #include "proj_role_dev.h"
 #include "dw_role_dev.h"
+#include "dec_chain_dev.h"
+#include "lstamp.h"
 
 namespace mfm {
 
@@ -183,8 +185,9 @@ __device__ __forceinline__ void stage_gates2(const SeqDev& d, int mode, int g, f
 // v_dot2c_f32_bf16 -- W packed as bf16 pairs in half the registers, h_{t-1} exchanged through LDS as bf16 (what the bf16 MFMA
 // kernels feed their matrix cores: same rounding points), fp32 accumulation, gate math, cell state and saved activations.
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// Returns where the row's LAST hidden state lies in LDS (one-row fp32 tiles: [HKB] floats, pad units exact zeros; else null).
 template <int KQ, int R, bool FLG = false, bool BF = false>
-__device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds,
+__device__ __forceinline__ const float* small_fwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds,
                                                const unsigned* flg = nullptr, const unsigned epoch = 0, const int ncb = 0,
                                                const HoCtl ctl = HoCtl{nullptr, nullptr, nullptr, 5000000ll, 1u}) {
   constexpr int HK = 4 * KQ;                    // padded hidden extent of the matvec
@@ -229,6 +232,19 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
   // lane picks its own gate with an address, not a predicate
   auto load_w = [&](int mode) {
     if constexpr (R == 1) {
+      if (mode == 2 && d.wf_img) {          // this step's W_ih + W_hh, already in register order (lstm_seq_dev.h)
+        const f32x4* img = reinterpret_cast<const f32x4*>(d.wf_img) + (tid < NTH ? tid : 0);
+#pragma unroll
+        for (int gl = 0; gl < 2; ++gl)
+#pragma unroll
+          for (int m = 0; m < NM; ++m) {
+            const f32x4 v = img[(gl * NM + m) * NTH];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[gl][4 * m + i] = (tid < NTH) ? v[i] : 0.0f;
+          }
+        pack_w();
+        return;
+      }
       if ((h & 3) == 0) {
         const float* wa = (mode == 0) ? d.w_hh : d.w_ih;
 #pragma unroll
@@ -268,6 +284,7 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
     pack_w();
   };
   load_w(dec ? 1 : 0);
+  LSTAMP_W(dec ? 1 : 0, 1);
 
   // decoder: constant bias per lane; encoder: x projection (bias folded in by the GEMM) via xbuf
   float gxb[2] = {0.f, 0.f};
@@ -344,6 +361,7 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
   const int my_o = (2 * gp * HKB + ucl) * R + myrow;       // this lane's slots: 2gp, 2gp+1 and 4+gp
   const float sc0 = gp ? 2.0f : 1.0f;                      // gate 0 of the pair: sigmoid(i) / tanh(g)
   __syncthreads();
+  LSTAMP(dec ? 1 : 0, 2);
 
   float c = 0.0f;
   int cur = 0;
@@ -353,6 +371,10 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
 #endif
   auto step = [&](const int t) {
     const int par = t & 1;
+#if MFM_LAUNCH_STAMP
+    if (t == (dec ? 2 : 1)) LSTAMP(dec ? 1 : 0, 5);
+    if (t == T - 1) LSTAMP(dec ? 1 : 0, 6);
+#endif
 #if MFM_SEQ_STAMP
     const unsigned long long st0 = seq_clock();
     unsigned long long st1 = st0;
@@ -532,9 +554,11 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
   if (dec) {
     step(0);
     flush(0);                          // (the record of step 0 lives in the panel about to be refilled)
+    LSTAMP(1, 3);
     if (T > 1) {
       __syncthreads();
       load_w(2);                       // steps >= 1 feed h back as the input: W_ih + W_hh
+      LSTAMP_W(1, 4);
       for (int t = 1; t < T; ++t) step(t);
       flush(T - 1);
     }
@@ -542,6 +566,7 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
     for (int t = 0; t < T; ++t) step(t);
     flush(T - 1);
   }
+  LSTAMP(dec ? 1 : 0, 7);
 #if MFM_SEQ_STAMP
   __syncthreads();
   if (blockIdx.x == 0 && (tid & 63) == 0 && T > 2) {
@@ -549,6 +574,8 @@ __device__ __forceinline__ void small_fwd_body(const SeqDev& d, const int T, con
     p_cs[(int64_t)(T - 1) * sstep + (tid >> 6)] = (float)((double)st_sum / (double)nsteps);
   }
 #endif
+  if constexpr (R == 1 && !BF) return hbuf + cur * HX;
+  else return nullptr;
 }
 
 // --------------------------------------------------------------------------------- backward
@@ -651,6 +678,7 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
     }
   };
   load_wT(dec ? 2 : 0);
+  LSTAMP_W(dec ? 3 : 4, 1);
 
   const int64_t row4 = 4 * (int64_t)Hp;
   const int64_t gstep = (int64_t)B * row4, sstep = (int64_t)B * Hp;
@@ -716,9 +744,15 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
   float dh_rec = 0.0f, dc = 0.0f;
   int cur = 0;
   __syncthreads();
+  LSTAMP(dec ? 3 : 4, 2);
 
   auto step = [&](const int t, const bool matvec = true) {
     const int par = t & 1;
+#if MFM_LAUNCH_STAMP
+    if (t == T - 2) LSTAMP(dec ? 3 : 4, 5);
+    if (t == 1) LSTAMP(dec ? 3 : 4, 6);
+    if (t == 0) LSTAMP(dec ? 3 : 4, 3);
+#endif
     const float* sb = sbuf + par * (NV * HKB * R) + my_s;
     const float gi = sb[0], gf = sb[HKB * R], gg = sb[2 * HKB * R], go = sb[3 * HKB * R], cp = sb[4 * HKB * R];
     float ext = ext0, dce = 0.0f;
@@ -859,6 +893,7 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
       for (int k = 0; k < S; ++k) sum += panel[k * h + tid];
       d.d_h_init[(int64_t)b0 * d.ld_dinit + tid] = sum;
     }
+    LSTAMP(3, 7);
     return;
   }
   if (dec) load_wT(1);                 // grad wrt the step-0 input goes through W_ih only (peeled)
@@ -868,6 +903,7 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
     sync_stores();                     // every dA store of every wave has been acknowledged
     if (tid == 0 && !skip_final_stamp) dwr_stamp(stamp, epoch);      // (skipped only by the fault injection of the tests)
   }
+  LSTAMP(dec ? 3 : 4, 7);
 }
 
 }  // namespace mfm

@@ -2,6 +2,7 @@
 // entry points (forward, backward in its three forms, grad_step, train_step, train_step_staged), layout queries, timing.
 // The chains themselves: plan_forward.hip, plan_backward.hip, plan_mfn.hip; tables: plan_build.hip.
 #include "plan_internal.h"
+#include "lstamp.h"
 
 using namespace mfm;
 
@@ -423,7 +424,14 @@ extern "C" double mfm_plan_kernel_flops(const MfmPlan* P, int kid) {
         for (int i = 0; i < P->lat.nops; ++i) f += 2.0 * P->B * P->lat_ops[i].N * P->lat_ops[i].K;  // latent dW
       }
       break;
-    case K_DEC_FWD: case K_DEC_BWD: for (int m = 0; m < 3; ++m) f += TB * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m]; break;
+    case K_DEC_FWD: case K_DEC_BWD:
+      for (int m = 0; m < 3; ++m) f += TB * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m];
+      // the decoder chain launch (dec_chain_dev.h) carries the recurrence, fc1 + dH and the BPTT under the forward's id
+      if (P->dec_chain_state == 1) {
+        if (kid == K_DEC_BWD) f = 0.0;
+        else { f *= 2.0; for (int m = 0; m < 3; ++m) f += 2.0 * TB * 2.0 * P->dec_h[m] * P->dec_d[m]; }
+      }
+      break;
     case K_FC1_FWD: {
       for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m];
       // the fused kernel (dec_fc1.hip; the plan's default up to 5120 rows) also forms dH = dx_hat Wfc in the same launch
@@ -470,3 +478,32 @@ extern "C" double mfm_plan_kernel_flops(const MfmPlan* P, int kid) {
   }
   return f;
 }
+
+#if MFM_LAUNCH_STAMP
+// stamp build only (lstamp.h): the device buffer of the launch clock and its read-out (not part of the product ABI)
+namespace mfm {
+unsigned long long* lstamp_buffer() {
+  static unsigned long long* buf = nullptr;
+  if (!buf) {
+    const size_t bytes = (size_t)LST_KERNELS * LST_BLOCKS * LST_POINTS * sizeof(unsigned long long);
+    if (hipMalloc(&buf, bytes) != hipSuccess) return nullptr;
+    (void)hipMemset(buf, 0, bytes);
+  }
+  return buf;
+}
+}  // namespace mfm
+extern "C" int mfm_debug_lstamp_dims(int* kernels, int* blocks, int* points) {
+  *kernels = LST_KERNELS; *blocks = LST_BLOCKS; *points = LST_POINTS;
+  return MFM_OK;
+}
+// copies the stamps to `dst` (host) and clears the device buffer; synchronises the device
+extern "C" int mfm_debug_lstamp_read(unsigned long long* dst) {
+  unsigned long long* b = lstamp_buffer();
+  if (!b || !dst) return MFM_ERR_ARG;
+  const size_t bytes = (size_t)LST_KERNELS * LST_BLOCKS * LST_POINTS * sizeof(unsigned long long);
+  MFM_HIP_CHECK(hipDeviceSynchronize());
+  MFM_HIP_CHECK(hipMemcpy(dst, b, bytes, hipMemcpyDeviceToHost));
+  MFM_HIP_CHECK(hipMemset(b, 0, bytes));
+  return MFM_OK;
+}
+#endif
