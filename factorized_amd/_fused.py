@@ -361,6 +361,7 @@ def _lazy_forward(module, x):
     """training-mode forward with lazy outputs (factorized_amd/lazy.py), or None when this plan cannot serve them"""
     from . import lazy
     eng = module.engine
+    eng._check_inputs(x, None)          # (shape / dtype / device / contiguity: the kernels index x with the plan's D)
     T, B, _ = x.shape
     plan = eng.plan(T, B)
     if plan.out_views is None:

@@ -48,6 +48,8 @@ struct DwRole {
   const unsigned* tick;                // device part: the plan's backward replay counter
   HoCtl ctl;                           // time-out, status word, poison (= the gradient guard: the optimizer skips the step)
   int fault;                           // fault injection (tests): the BPTT workgroup of (encoder 0, row 0) does not stamp t = 0
+  int lat_split;                       // the rows' latent chains hand d h_T to their BPTT through LDS and send their stores out
+                                       // while the BPTT's weights travel (lstm_seq_small_folddw_kernel)
 };
 // dep codes of a table entry
 constexpr int DWR_DEP_NONE = 0, DWR_DEP_LATENT = 5;     // 1..4: encoder e = dep - 1

@@ -94,9 +94,6 @@ struct DecFc1Item {
 };
 struct DecFc1Launch { DecFc1Item it[3]; int n_items, rows, with_bwd, bf16; };   // bf16: operands rounded to bf16 (RNE) first
 int dec_fc1_launch(DecFc1Launch& L, bool dhs_zeroed, hipStream_t stream);
-// dec_chain_dev.h / lstm_seq_small.hip -- the decoder chain of a training step at small batches in one launch; the same items
-// (tile fields unused).  bf16: operands rounded to bf16 (RNE) first, as dec_fc1.hip does
-struct DecChain { DecFc1Item fc[3]; int bf16; };
 
 // dec_fc1_large.hip -- bf16-resident plans, large T*B: decoder fc1 + squared error + d x_hat + dH in one launch of
 // persistent workgroups (the W image stays in LDS; H in, d x_hat and dH out are bf16 buffers)
@@ -258,6 +255,8 @@ struct LatentDev {
   float* disc_loss_out;   // backward, optional: the discriminative loss value (L1 / CE mean) is ADDED here (the loss-weighted
                           // backward of the module path: the forward ran without labels, its slot 0 is still zero)
   int grd_agent;          // grd_out leaves with agent-scope stores (read inside the same launch, dw_role_dev.h)
+  int bias_tab, bias_n;   // row path: the last stage slot of the backward item table lists every thread's bias-gradient element
+                          // (bias_n: the largest number of entries a workgroup kind has; it must not exceed the block size)
 };
 int latent_fwd_launch(const LatentDev& L, const float* params, hipStream_t stream);
 // lstm_seq.hip / lstm_seq_small.hip -- the encoder recurrences of MFM_KL_EF with their rows' latent chains folded in
@@ -268,8 +267,6 @@ int seq_fwd_img_launch(const MfmSeqDesc* descs, int count, int T, int B, const s
                        hipStream_t stream);
 int seq_bwd_img_launch(const MfmSeqDesc* descs, int count, int T, int B, const float* const* wt_imgs, hipStream_t stream);
 int seq_fwd_wf_launch(const MfmSeqDesc* descs, int count, int T, int B, const float* const* wf_imgs, hipStream_t stream);
-int seq_dec_chain_launch(const MfmSeqDesc* descs, int count, int T, int B, const float* const* wt_imgs, const float* const* wf_imgs,
-                         DecChain& chain, hipStream_t stream);
 int latent_bwd_launch(const LatentDev& L, const float* params, float* grads, hipStream_t stream);
 
 }  // namespace mfm

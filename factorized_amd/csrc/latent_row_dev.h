@@ -324,9 +324,14 @@ __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const fl
   mark(L, 20);
 }
 
+// `mode` (round 6, the launch clock: 3.1 us of stores and atomics between the last stage and the BPTT that only needs d h_T):
+// 0 = the whole body; 1 = everything up to the last stage -- the gradient record stays in LDS behind this body's tables
+// (latent_bwd_grd_floats: the BPTT takes d h_T from there); 2 = what nothing in the workgroup waits for: bias gradients, d h_T and
+// the gradient record to memory.  The fold launch runs 2 between the BPTT's weight requests and their first use.
+__host__ __device__ static inline int latent_bwd_grd_floats(int rec_size) { return MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + rec_size; }
 template <bool PRE>
 __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const float* __restrict__ params, float* __restrict__ grads,
-                                                    const int row, const int ch, float* lds) {
+                                                    const int row, const int ch, float* lds, const int mode = 0) {
   __shared__ LatOp ops[MFM_LAT_MAXOPS];
   __shared__ int pfxN[MFM_LAT_MAXOPS];
   const int RS = L.rec_size;
@@ -336,6 +341,7 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
   const int nch = L.nch;                           // 4: one modality chain of the row per workgroup (see the forward)
   const bool all = nch == 1;
   const int tid = threadIdx.x, nt = blockDim.x;
+  if (mode != 2) {
   int nib[MFM_LAT_MAXSTAGES];
 #pragma unroll
   for (int i = 0; i < MFM_LAT_MAXSTAGES; ++i) nib[i] = L.nitems_bwd_c[ch][i];
@@ -385,7 +391,8 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
     const i32x4* isrc = reinterpret_cast<const i32x4*>(L.items_bwd + (size_t)ch * (MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4));
     i32x4 iv[MFM_LAT_MAXSTAGES];
 #pragma unroll
-    for (int st = 0; st < MFM_LAT_MAXSTAGES; ++st) iv[st] = isrc[min(st, L.nstages - 1) * MFM_LAT_ROW_THREADS + tid];
+    for (int st = 0; st < MFM_LAT_MAXSTAGES; ++st)        // (the last slot: the bias-gradient table, LatentDev::bias_tab)
+      iv[st] = isrc[(st == MFM_LAT_MAXSTAGES - 1 ? st : min(st, L.nstages - 1)) * MFM_LAT_ROW_THREADS + tid];
     const f32x4 sv = sw * sraw;
 #pragma unroll
     for (int st = 0; st < MFM_LAT_MAXSTAGES; ++st) tab[st * MFM_LAT_ROW_THREADS + tid] = iv[st];
@@ -546,10 +553,16 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
       if (s >= 1) stage(s - 1, sb, sa);
     }
   }
+  }      // mode != 2
+  if (mode == 1) return;
 
   // ---- bias gradients of all layers in one go (the record keeps every pre-activation gradient).  Inside
   // the stage loop these atomics would sit between two weight prefetches in the in-order vmcnt queue, and
   // every wait for weights would also wait for them.  Weight gradients: grouped GEMM over the two records.
+  if (L.bias_tab && L.bias_n <= nt) {
+    const i32x4 be = tab[(MFM_LAT_MAXSTAGES - 1) * MFM_LAT_ROW_THREADS + min(tid, MFM_LAT_ROW_THREADS - 1)];
+    if (tid < L.bias_n && be[0] >= 0) atomicAdd(grads + (unsigned)be[0], grd[be[1]]);
+  } else
   for (int st = 0; st < L.nstages; ++st) {
     const int ob = L.stage_begin[st], oe = L.stage_begin[st + 1];
     const int totn = L.nitems_fwd[st] >> 2;

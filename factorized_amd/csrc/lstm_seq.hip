@@ -378,7 +378,7 @@ bool bf16_seq_pays(int B) {
 }
 
 struct FoldArgs { const LatentDev* lat; const float* params; float* grads; ProjRole* pr; DwRole* dr; const float* const* wt_imgs;
-                  const WtImgItem* img_items; int n_img_items; bool* img_written; const float* const* wf_imgs; DecChain* chain; };
+                  const WtImgItem* img_items; int n_img_items; bool* img_written; const float* const* wf_imgs; };
 
 static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bool bwd, hipStream_t stream, bool bf16 = false,
                       const FoldArgs* fold = nullptr) {
@@ -402,10 +402,7 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
   }
   if (fold && !fold->lat && !fold->pr && !fold->dr) {      // (images only: a plain launch)
     if (fold->img_written) *fold->img_written = false;
-    if (nwide || bf16 || !use_small_path(B) || opt_get("MFM_SEQ_KS") || opt_get("MFM_SEQ_ROWS")) {
-      if (fold->chain) return MFM_ERR_UNSUPPORTED;
-      fold = nullptr;
-    }
+    if (nwide || bf16 || !use_small_path(B) || opt_get("MFM_SEQ_KS") || opt_get("MFM_SEQ_ROWS")) fold = nullptr;
   } else if (fold && (nwide || bf16 || !use_small_path(B))) return MFM_ERR_UNSUPPORTED;
   if (nwide) {
     int rc = seq_stepwise(wide, nwide, T, B, bwd, stream);
@@ -439,8 +436,9 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     d.w_pack = bf16 ? s.w_pack : nullptr;
     d.h_last = bf16 ? s.h_last : nullptr;
     d.store_bf16 = s.store_bf16;
-    d.wt_img = (fold && fold->wt_imgs && (bwd || fold->chain) && !sorted && !nwide && count == count_in) ? fold->wt_imgs[i] : nullptr;
+    d.wt_img = (fold && fold->wt_imgs && bwd && !sorted && !nwide && count == count_in) ? fold->wt_imgs[i] : nullptr;
     d.wf_img = (fold && fold->wf_imgs && !bwd && !sorted && !nwide && count == count_in && s.is_dec && (s.h & 3) == 0) ? fold->wf_imgs[i] : nullptr;
+    d.wf1_img = d.wf_img ? fold->wf_imgs[count_in + i] : nullptr;        // (second half of the list: W_ih alone)
     MFM_REQUIRE(bf16 || (!s.store_bf16 && !s.h_last), "lstm_seq[%d]: store_bf16 / h_last are taken by the bf16 entry points only", i);
     d.h = s.h; d.Hp = round_up(s.h, 16);
     d.hk4 = round_up(cdiv(s.h, 4), 2);
@@ -459,14 +457,13 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     L.n_img = fold->n_img_items;
     for (int i = 0; i < L.n_img; ++i) L.img[i] = fold->img_items[i];
   }
-  if (fold && fold->chain) return seq_small_dec_chain_launch(L, *fold->chain, stream);
   if (fold && !fold->lat && fold->img_items) {      // forward launch with image-writer blocks behind the rows
     const int rc = seq_small_launch(L, false, stream);
     if (rc == MFM_OK && fold->img_written) *fold->img_written = L.n_img > 0;
     return rc;
   }
   if (fold && !fold->lat) {          // images only: the plain one-row launch (one-row tiles: checked by the caller's conditions)
-    if ((long)L.count * L.B >= 6L * device_cus()) for (int i = 0; i < L.count; ++i) { L.d[i].wt_img = nullptr; L.d[i].wf_img = nullptr; }
+    if ((long)L.count * L.B >= 6L * device_cus()) for (int i = 0; i < L.count; ++i) { L.d[i].wt_img = nullptr; L.d[i].wf_img = nullptr; L.d[i].wf1_img = nullptr; }
     return seq_small_launch(L, bwd, stream);
   }
   if (fold && fold->pr) return seq_small_foldproj_launch(L, *fold->lat, *fold->pr, fold->params, stream);
@@ -508,13 +505,13 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
 int seq_fold_launch(const MfmSeqDesc* descs, int count, int T, int B, bool bwd, const LatentDev& lat, const float* params,
                     float* grads, hipStream_t stream, const float* const* wt_imgs, const WtImgItem* img_items, int n_img_items,
                     bool* img_written) {
-  FoldArgs f = {&lat, params, grads, nullptr, nullptr, wt_imgs, img_items, n_img_items, img_written, nullptr, nullptr};
+  FoldArgs f = {&lat, params, grads, nullptr, nullptr, wt_imgs, img_items, n_img_items, img_written, nullptr};
   return seq_launch(descs, count, T, B, bwd, stream, false, &f);
 }
 // the forward fold launch with projection role workgroups in front (proj_role_dev.h)
 int seq_foldproj_launch(const MfmSeqDesc* descs, int count, int T, int B, const LatentDev& lat, const float* params, ProjRole& pr,
                         hipStream_t stream) {
-  FoldArgs f = {&lat, params, nullptr, &pr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+  FoldArgs f = {&lat, params, nullptr, &pr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
   return seq_launch(descs, count, T, B, false, stream, false, &f);
 }
 
@@ -525,29 +522,24 @@ namespace mfm {
 // *written: whether they did (one-row tiles and idle CUs left)
 int seq_fwd_img_launch(const MfmSeqDesc* descs, int count, int T, int B, const WtImgItem* items, int n_items, bool* written,
                        hipStream_t stream) {
-  FoldArgs f = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, items, n_items, written, nullptr, nullptr};
+  FoldArgs f = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, items, n_items, written, nullptr};
   return seq_launch(descs, count, T, B, false, stream, false, &f);
 }
 // plain BPTT launch whose one-row workgroups take their transposed weights from this step's images (proj_role_dev.h)
 int seq_bwd_img_launch(const MfmSeqDesc* descs, int count, int T, int B, const float* const* wt_imgs, hipStream_t stream) {
-  FoldArgs f = {nullptr, nullptr, nullptr, nullptr, nullptr, wt_imgs, nullptr, 0, nullptr, nullptr, nullptr};
+  FoldArgs f = {nullptr, nullptr, nullptr, nullptr, nullptr, wt_imgs, nullptr, 0, nullptr, nullptr};
   return seq_launch(descs, count, T, B, true, stream, false, &f);
 }
-// plain forward launch whose one-row decoder workgroups take W_ih + W_hh (steps >= 1) from this step's forward images
+// plain forward launch whose one-row decoder workgroups take W_ih + W_hh (steps >= 1) and W_ih (step 0) from this step's
+// forward images: wf_imgs[0 .. count) the sums, wf_imgs[count .. 2 count) W_ih
 int seq_fwd_wf_launch(const MfmSeqDesc* descs, int count, int T, int B, const float* const* wf_imgs, hipStream_t stream) {
-  FoldArgs f = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, wf_imgs, nullptr};
-  return seq_launch(descs, count, T, B, false, stream, false, &f);
-}
-// the decoder chain of a training step in one launch (dec_chain_dev.h): recurrence, fc1 + squared error + dH, BPTT
-int seq_dec_chain_launch(const MfmSeqDesc* descs, int count, int T, int B, const float* const* wt_imgs, const float* const* wf_imgs,
-                         DecChain& chain, hipStream_t stream) {
-  FoldArgs f = {nullptr, nullptr, nullptr, nullptr, nullptr, wt_imgs, nullptr, 0, nullptr, wf_imgs, &chain};
+  FoldArgs f = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, wf_imgs};
   return seq_launch(descs, count, T, B, false, stream, false, &f);
 }
 // the backward fold launch with weight-gradient role workgroups behind the BPTT workgroups (dw_role_dev.h)
 int seq_folddw_launch(const MfmSeqDesc* descs, int count, int T, int B, const LatentDev& lat, const float* params, float* grads,
                       DwRole& dr, hipStream_t stream, const float* const* wt_imgs) {
-  FoldArgs f = {&lat, params, grads, nullptr, &dr, wt_imgs, nullptr, 0, nullptr, nullptr, nullptr};
+  FoldArgs f = {&lat, params, grads, nullptr, &dr, wt_imgs, nullptr, 0, nullptr, nullptr};
   return seq_launch(descs, count, T, B, true, stream, false, &f);
 }
 }  // namespace mfm

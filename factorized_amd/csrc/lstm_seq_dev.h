@@ -17,6 +17,7 @@ struct SeqDev {
   int store_bf16;          // bf16 path: gates / hs / the decoders' dh_ext are __bf16 buffers (MfmSeqDesc::store_bf16)
   const float* wt_img;     // fp32 one-row BPTT, optional: this step's transposed weights in thread order (proj_role_dev.h), or null
   const float* wf_img;     // fp32 one-row forward, decoders, optional: W_ih + W_hh of this step in the forward's thread order, or null
+  const float* wf1_img;    // the same for W_ih alone (the decoders' step 0), or null
 };
 // Transposed-weight images for the one-row BPTT kernels of the same step (lstm_seq_small.hip, small_bwd_body<.., KS = 16>):
 // img[s][tid], s = which * 4 NG + g * NG + i, holds W[g h + 16 i + (tid & 15)][2 (tid >> 4) + which] (w_ih set: W_ih + W_hh,
@@ -62,7 +63,8 @@ __device__ __forceinline__ void wt_img_write(const WtImgItem* items, const int n
 // 0): img4[(gl * NM + m) * NTH + tid] = (W_ih + W_hh)[(2 gp + gl) h + u][16 m + 4 q .. + 3] with q = tid & 3, gp = (tid >> 2) & 1,
 // u = tid >> 3, NM = HKB / 16, NTH = 8 HKB -- exactly the registers w[gl][4 m ..] of small_fwd_body<KQ, 1>, so the reload is 2 NM
 // coalesced 16-byte loads per thread.  Zero outside the valid units.  Written like the transposed images (role workgroups of
-// the encoder launch), read by the decoder launch behind it.  h % 4 == 0 only.
+// the encoder launch), read by the decoder launch behind it.  h % 4 == 0 only.  An item without w_hh: the image of W_ih alone
+// (step 0: 3.0 -> 1.5 us for h = 104, the same strided gather without the add).
 __device__ __forceinline__ void wf_img_write(const WtImgItem* items, const int n, const int r, const int nr) {
   const int tid = threadIdx.x, nt = blockDim.x;
 #pragma unroll 1
@@ -79,7 +81,8 @@ __device__ __forceinline__ void wf_img_write(const WtImgItem* items, const int n
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (u < h && k0 < h) {
         const int64_t o = ((int64_t)(2 * gp + gl) * h + u) * h + k0;
-        v = *reinterpret_cast<const f32x4*>(I.w_hh + o) + *reinterpret_cast<const f32x4*>(I.w_ih + o);
+        v = *reinterpret_cast<const f32x4*>(I.w_ih + o);
+        if (I.w_hh) v = *reinterpret_cast<const f32x4*>(I.w_hh + o) + v;
       }
       out[idx] = v;
     }
@@ -87,8 +90,6 @@ __device__ __forceinline__ void wf_img_write(const WtImgItem* items, const int n
 }
 
 int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream);
-struct DecChain;
-int seq_small_dec_chain_launch(SeqLaunch& L, DecChain& C, hipStream_t stream);
 struct LatentDev;
 int seq_small_fold_launch(SeqLaunch& L, bool bwd, const LatentDev& LD, const float* params, float* grads, hipStream_t stream);
 // lstm_seq_bf16.hip: bf16 MFMA operands, fp32 accumulate / cell state / saved activations

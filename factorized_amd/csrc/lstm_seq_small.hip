@@ -242,47 +242,31 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_folddw_kernel(const SeqLa
     if (bid >= L.d[i].block_begin) di = i;
   const SeqDev& d = L.d[di];
   const int tile = bid - d.block_begin;          // == batch row (one-row tiles)
-  latent_bwd_row_body<false>(LD, params, grads, tile, di, lds);
-  LSTAMP(4, 9);
-  sync_stores();           // d h_T of this (row, encoder) is in memory (and the LDS is free) before the BPTT reads it
-  LSTAMP(4, 8);
-  if (threadIdx.x == 0) dwr_stamp(DR.flags + 4 * L.T * DWR_ROWS + di * L.B + tile, epoch);
   unsigned* stamp = DR.flags + (int64_t)di * L.T * DWR_ROWS + tile;
+  unsigned* lat_stamp = DR.flags + 4 * L.T * DWR_ROWS + di * L.B + tile;
   const bool fault = DR.fault != 0 && bid == 0;
+  if (DR.lat_split) {
+    // the chain up to its last stage; the BPTT takes d h_T from the chain's gradient record in LDS (which lies behind everything the
+    // BPTT keeps in LDS: seq_small_folddw_launch), and the chain's stores / atomics go out while the BPTT's weights travel
+    latent_bwd_row_body<false>(LD, params, grads, tile, di, lds, 1);        // (ends behind a barrier)
+    LSTAMP(4, 9);
+    const float* dh_lds = lds + latent_bwd_grd_floats(LD.rec_size) + LD.in_off[di];
 #define MFM_ONE(IDX, KK) \
-  if (KK > 0 && di == IDX) small_bwd_body<(KK > 0 ? KK : 2), 1, 16, true>(d, L.T, L.B, tile, lds, stamp, epoch, fault);
-  MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3)
+    if (KK > 0 && di == IDX) small_bwd_body_x<(KK > 0 ? KK : 2), 1, 16, true, LatentDev>(d, L.T, L.B, tile, lds, stamp, epoch, fault, LD, params, grads, di, dh_lds, lat_stamp);
+    MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3)
 #undef MFM_ONE
+  } else {
+    latent_bwd_row_body<false>(LD, params, grads, tile, di, lds);
+    LSTAMP(4, 9);
+    sync_stores();           // d h_T of this (row, encoder) is in memory (and the LDS is free) before the BPTT reads it
+    LSTAMP(4, 8);
+    if (threadIdx.x == 0) dwr_stamp(lat_stamp, epoch);
+#define MFM_ONE(IDX, KK) \
+    if (KK > 0 && di == IDX) small_bwd_body<(KK > 0 ? KK : 2), 1, 16, true>(d, L.T, L.B, tile, lds, stamp, epoch, fault);
+    MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2) MFM_ONE(3, K3)
+#undef MFM_ONE
+  }
   LSTAMP_W(4, 15);
-}
-
-// The decoder chain of a training step (dec_chain_dev.h): blocks [i B, (i + 1) B) = the rows of decoder i; recurrence, then the
-// row's fc1 + squared error + dH, then its BPTT.  The same SeqDev serves both recurrences (wf_img: forward, wt_img / dh_ext /
-// d_h_init: backward).
-template <int K0, int K1, int K2>
-__global__ __launch_bounds__(1024) void lstm_dec_chain_kernel(const SeqLaunch L, const DecChain C) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  int di = 0;
-  const int bid = blockIdx.x;
-  LSTAMP(1, 0);
-#pragma unroll 1
-  for (int i = 1; i < L.count; ++i)
-    if (bid >= L.d[i].block_begin) di = i;
-  const SeqDev& d = L.d[di];
-  const int tile = bid - d.block_begin;          // == batch row (one-row tiles)
-#define MFM_ONE(IDX, KK) \
-  if (KK > 0 && di == IDX) small_fwd_body<(KK > 0 ? KK : 2), 1>(d, L.T, L.B, tile, lds);
-  MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2)
-#undef MFM_ONE
-  sync_stores();           // the row's hidden states are in memory (and the LDS is free)
-  dec_fc1_row_body(C.fc[di], L.T, L.B, tile, lds, C.bf16 != 0);
-  sync_stores();           // dH of this row is in memory (and the LDS is free) before the BPTT reads it
-  LSTAMP(3, 0);
-#define MFM_ONE(IDX, KK) \
-  if (KK > 0 && di == IDX) small_bwd_body<(KK > 0 ? KK : 2), 1, 16>(d, L.T, L.B, tile, lds);
-  MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2)
-#undef MFM_ONE
-  LSTAMP(3, 15);
 }
 
 // `no_panel` (forward, one-row tiles, every h % 4 == 0): the weights go straight into registers, the panel is not needed
@@ -410,42 +394,19 @@ int seq_small_folddw_launch(SeqLaunch& L, const LatentDev& LD, DwRole& DR, const
   const size_t lat = ((size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + 2 * (size_t)LD.rec_size) * sizeof(float);
   const size_t role = (size_t)DWR_LDS_FLOATS * sizeof(float);      // one shared A image + four B images + the pipeline's answer word + the block records
   if (DR.n_iter * 4 > DWR_MAXREC) return MFM_ERR_UNSUPPORTED;
+  // the chain's gradient record must survive into the BPTT's prologue: it has to lie behind everything the BPTT keeps in LDS, and
+  // every encoder must take its transposed weights from this step's images (no staging panel)
+  DR.lat_split = 0;
+  if (!(opt_get("MFM_LATENT_SPLIT") && atoi(opt_get("MFM_LATENT_SPLIT")) == 0)) {
+    bool imgs = true;
+    for (int i = 0; i < 4; ++i) imgs = imgs && L.d[i].wt_img != nullptr;
+    if (imgs && lds_bytes <= (size_t)latent_bwd_grd_floats(LD.rec_size) * sizeof(float)) DR.lat_split = 1;
+  }
   lds_bytes = std::max(lds_bytes, std::max(lat, role));
   if (lds_bytes > 160 * 1024) return MFM_ERR_UNSUPPORTED;
   MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_folddw_kernel<8, 2, 20, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL((lstm_seq_small_folddw_kernel<8, 2, 20, 30>), dim3(total), dim3(1024), lds_bytes, stream, L, LD, DR, params, grads);
   MFM_LAUNCH_CHECK("lstm_seq_small_folddw_kernel");
-  return MFM_OK;
-}
-
-// MFM_OK: launched.  MFM_ERR_UNSUPPORTED: not a case the chain kernel takes (the caller issues the three launches).
-int seq_small_dec_chain_launch(SeqLaunch& L, DecChain& C, hipStream_t stream) {
-  LSTAMP_BIND();
-  // opt-in (MFM_DEC_CHAIN=1): measured slower than the three launches at the MOSI sizes (the row's fc1 products are bound by the
-  // fp32 MFMA rate of ONE CU; profiles/r06_dec_chain.txt)
-  if (!(opt_get("MFM_DEC_CHAIN") && atoi(opt_get("MFM_DEC_CHAIN")) == 1)) return MFM_ERR_UNSUPPORTED;
-  if (opt_get("MFM_SEQ_KS") || opt_get("MFM_SEQ_ROWS")) return MFM_ERR_UNSUPPORTED;
-  const int want[3] = {26, 6, 6};
-  if (L.count != 3 || L.T < 2 || L.T > 16 * DCH_MAXRT || L.bf16_dot) return MFM_ERR_UNSUPPORTED;
-  if (!((long)L.count * L.B < 6L * device_cus())) return MFM_ERR_UNSUPPORTED;          // one-row tiles only
-  int max_threads = 64, total = 0;
-  size_t fc_lds = 0;
-  for (int i = 0; i < 3; ++i) {
-    const SeqDev& d = L.d[i];
-    const DecFc1Item& I = C.fc[i];
-    if (d.hk4 != want[i] || !d.is_dec || (d.h & 3) != 0 || !d.wt_img || !d.wf_img || !d.dh_ext) return MFM_ERR_UNSUPPORTED;
-    if (I.d < 1 || I.d > DCH_MAXD || I.Hp != d.Hp || I.h != d.h || I.Hp > 16 * DCH_MAXJ || !I.dhs || !I.hs || !I.w || !I.bias || !I.x) return MFM_ERR_UNSUPPORTED;
-    if ((int64_t)I.d * I.h >= ((int64_t)1 << 28)) return MFM_ERR_UNSUPPORTED;
-    if (8 * d.Hp > max_threads) max_threads = 8 * d.Hp;
-    L.d[i].block_begin = total; total += L.B;
-    fc_lds = std::max(fc_lds, dch_lds_floats(L.T, I.Hp, I.d) * sizeof(float));
-  }
-  L.n_img = 0; L.n_img_blocks = 0;
-  const size_t lds_bytes = std::max(fc_lds, std::max(small_lds_bytes(L, false, 1, true), small_lds_bytes(L, true, 1)));
-  if (lds_bytes > 160 * 1024) return MFM_ERR_UNSUPPORTED;
-  MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_dec_chain_kernel<26, 6, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL((lstm_dec_chain_kernel<26, 6, 6>), dim3(total), dim3(max_threads), lds_bytes, stream, L, C);
-  MFM_LAUNCH_CHECK("lstm_dec_chain_kernel");
   return MFM_OK;
 }
 

@@ -34,7 +34,6 @@
 #include "lstm_seq_dev.h"
 #include "proj_role_dev.h"
 #include "dw_role_dev.h"
-#include "dec_chain_dev.h"
 #include "lstamp.h"
 
 namespace mfm {
@@ -232,8 +231,9 @@ __device__ __forceinline__ const float* small_fwd_body(const SeqDev& d, const in
   // lane picks its own gate with an address, not a predicate
   auto load_w = [&](int mode) {
     if constexpr (R == 1) {
-      if (mode == 2 && d.wf_img) {          // this step's W_ih + W_hh, already in register order (lstm_seq_dev.h)
-        const f32x4* img = reinterpret_cast<const f32x4*>(d.wf_img) + (tid < NTH ? tid : 0);
+      const float* fimg = mode == 2 ? d.wf_img : (mode == 1 ? d.wf1_img : nullptr);
+      if (fimg) {          // this step's W_ih + W_hh (or W_ih), already in register order (lstm_seq_dev.h)
+        const f32x4* img = reinterpret_cast<const f32x4*>(fimg) + (tid < NTH ? tid : 0);
 #pragma unroll
         for (int gl = 0; gl < 2; ++gl)
 #pragma unroll
@@ -589,10 +589,17 @@ __device__ __forceinline__ const float* small_fwd_body(const SeqDev& d, const in
 // PUB (encoders of the fold launch with weight-gradient role workgroups, dw_role_dev.h): dA_t leaves with agent-scope stores
 // and one step later, once those stores are acknowledged, stamp[t * DWR_ROWS] <- epoch tells the role workgroups that this
 // row's dA of the time steps >= t is in memory.
-template <int KQ, int R, int KS = 16, bool PUB = false>
-__device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds,
-                                               unsigned* stamp = nullptr, const unsigned epoch = 0,
-                                               const bool skip_final_stamp = false) {
+// LAT = LatentDev (fold launch with the latent chain in front, round 6): once the transposed weights are REQUESTED and before
+// anything of them is used, the chain's stores and atomics that nothing in this workgroup waits for are issued (latent_bwd_row_body,
+// mode 2) -- they go out while the weights travel; `dh_lds`: the encoder's d h_T in LDS (the chain's gradient record) instead of
+// memory; `late_stamp`: raised behind the prologue's barrier once every store of the workgroup so far has been acknowledged (the
+// chain's gradient record is readable by the weight-gradient role workgroups).  (Plain reference parameters on purpose: a lambda
+// that captured the by-value LatentDev kernel argument made the compiler copy the descriptor to scratch, 1.1 KB per lane.)
+template <int KQ, int R, int KS, bool PUB, class LAT>
+__device__ __forceinline__ void small_bwd_body_x(const SeqDev& d, const int T, const int B, const int tile, float* lds,
+                                                 unsigned* stamp, const unsigned epoch, const bool skip_final_stamp,
+                                                 const LAT& lat, const float* lat_params, float* lat_grads, const int lat_ch,
+                                                 const float* dh_lds, unsigned* late_stamp) {
   constexpr int HK = 4 * KQ;                       // padded hidden extent
   constexpr int HKB = (HK + 15) / 16 * 16;         // per-gate extent of the dA panel (multiple of 16) == Hp
   static_assert(KS == 16 || (KS == 8 && R == 1), "8 k-slices: one-row tiles only");
@@ -625,13 +632,10 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
     // proj_role_dev.h): coalesced loads straight into the registers instead of two staging rounds through LDS
     if constexpr (KS == 16 && R == 1) {
       if (d.wt_img && mode != 1) {
+        // (threads beyond NTH own no unit and share no reduction group with one that does: what they hold is never used)
         const float* img = d.wt_img + (tid < NTH ? tid : 0);
 #pragma unroll
         for (int i = 0; i < NW; ++i) { wa[i] = img[(int64_t)i * NTH]; wb[i] = img[(int64_t)(NW + i) * NTH]; }
-        if (tid >= NTH) {
-#pragma unroll
-          for (int i = 0; i < NW; ++i) { wa[i] = 0.0f; wb[i] = 0.0f; }
-        }
         return;
       }
     }
@@ -678,6 +682,7 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
     }
   };
   load_wT(dec ? 2 : 0);
+  if constexpr (std::is_same<LAT, LatentDev>::value) latent_bwd_row_body<false>(lat, lat_params, lat_grads, tile, lat_ch, lds, 2);
   LSTAMP_W(dec ? 3 : 4, 1);
 
   const int64_t row4 = 4 * (int64_t)Hp;
@@ -740,10 +745,12 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
   const int my_s = muc * R + mrc;
   float ct = d.cs[((int64_t)(T - 1) * B + min(b, B - 1)) * Hp + muc];
   float ext0 = 0.0f;
-  if (!dec && mu < h) ext0 = d.dh_ext[(int64_t)min(b, B - 1) * d.ld_dh + mu];   // dL/dh_T only
+  if (!dec && mu < h) ext0 = dh_lds ? dh_lds[mu] : d.dh_ext[(int64_t)min(b, B - 1) * d.ld_dh + mu];   // dL/dh_T only
   float dh_rec = 0.0f, dc = 0.0f;
   int cur = 0;
+  if (late_stamp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (uniform) every store of this wave so far has been acknowledged
   __syncthreads();
+  if (late_stamp && tid == 0) dwr_stamp(late_stamp, epoch);
   LSTAMP(dec ? 3 : 4, 2);
 
   auto step = [&](const int t, const bool matvec = true) {
@@ -904,6 +911,13 @@ __device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, con
     if (tid == 0 && !skip_final_stamp) dwr_stamp(stamp, epoch);      // (skipped only by the fault injection of the tests)
   }
   LSTAMP(dec ? 3 : 4, 7);
+}
+
+template <int KQ, int R, int KS = 16, bool PUB = false>
+__device__ __forceinline__ void small_bwd_body(const SeqDev& d, const int T, const int B, const int tile, float* lds,
+                                               unsigned* stamp = nullptr, const unsigned epoch = 0,
+                                               const bool skip_final_stamp = false) {
+  small_bwd_body_x<KQ, R, KS, PUB, int>(d, T, B, tile, lds, stamp, epoch, skip_final_stamp, 0, nullptr, nullptr, 0, nullptr, nullptr);
 }
 
 }  // namespace mfm

@@ -424,14 +424,7 @@ extern "C" double mfm_plan_kernel_flops(const MfmPlan* P, int kid) {
         for (int i = 0; i < P->lat.nops; ++i) f += 2.0 * P->B * P->lat_ops[i].N * P->lat_ops[i].K;  // latent dW
       }
       break;
-    case K_DEC_FWD: case K_DEC_BWD:
-      for (int m = 0; m < 3; ++m) f += TB * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m];
-      // the decoder chain launch (dec_chain_dev.h) carries the recurrence, fc1 + dH and the BPTT under the forward's id
-      if (P->dec_chain_state == 1) {
-        if (kid == K_DEC_BWD) f = 0.0;
-        else { f *= 2.0; for (int m = 0; m < 3; ++m) f += 2.0 * TB * 2.0 * P->dec_h[m] * P->dec_d[m]; }
-      }
-      break;
+    case K_DEC_FWD: case K_DEC_BWD: for (int m = 0; m < 3; ++m) f += TB * 2.0 * 4.0 * P->dec_h[m] * P->dec_h[m]; break;
     case K_FC1_FWD: {
       for (int m = 0; m < 3; ++m) f += TB * 2.0 * P->dec_h[m] * P->dec_d[m];
       // the fused kernel (dec_fc1.hip; the plan's default up to 5120 rows) also forms dH = dx_hat Wfc in the same launch

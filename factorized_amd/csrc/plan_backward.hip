@@ -226,17 +226,6 @@ int backward(MfmPlan* P, const float* params, const float* x, const void* y, int
   // launch behind the encoder BPTT (49 problems at the canonical wiring) instead of three launches on the chain
   std::vector<MfmGemmDesc> tail;
   if (gen_on) {
-    // the caller's own upstream gradients after a forward that already ran the decoders' BPTT (chain launch): that BPTT turned
-    // the saved gate activations into dA in place -- the recurrences run again to bring them back (the slow path's price)
-    if (ext && P->dec_bwd_call == P->calls) {
-      MfmSeqDesc q[3];
-      for (int m = 0; m < 3; ++m) {
-        q[m] = seq_desc(P, P->dec[m], P->dec_p[m], params, W, true);
-        q[m].h_init = W + P->dec_init[m]; q[m].ld_init = P->dec_h[m];
-      }
-      RUN(K_DEC_FWD, mfm_lstm_seq_fwd(q, 3, T, B, s));
-      P->dec_bwd_call = ~0ull;
-    }
     // B0: through decoder fc1
     std::vector<MfmGemmDesc> g;
     for (int m = 0; m < 3; ++m) {
@@ -281,8 +270,8 @@ int backward(MfmPlan* P, const float* params, const float* x, const void* y, int
     // dH is already there when this step's forward ran the fused fc1 kernel and the gradient is the plan's own d x_hat
     const bool dh_done = !ext && P->fc1_bwd_call == P->calls;
     if (!dh_done) RUN(K_FC1_BWD, gemm_group_launch(g.data(), (int)g.size(), s, nullptr, nullptr, 0, c.precision));
-    // B1: decoder BPTT (already done when this step's forward ran the decoder chain launch, dec_chain_dev.h)
-    if (ext || P->dec_bwd_call != P->calls) {
+    // B1: decoder BPTT
+    {
       MfmSeqDesc q[3];
       for (int m = 0; m < 3; ++m) {
         q[m] = seq_desc(P, P->dec[m], P->dec_p[m], params, W, true);

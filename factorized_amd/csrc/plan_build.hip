@@ -404,6 +404,34 @@ int build(MfmPlan* P) {
           }
         }
       }
+    // bias gradients (round 6): thread t of a chain workgroup adds ONE element -- x = its offset in the gradient buffer (-1: none),
+    // y = its place in the gradient record -- tabulated in the LAST stage slot of the backward table (free while nstages < 8)
+    // instead of a search through the op table per element at the end of the backward chain
+    L.bias_tab = 0;
+    if (L.nstages < MFM_LAT_MAXSTAGES) {
+      bool fits = true;
+      for (int ch = 0; ch < L.nch && fits; ++ch) {
+        int cnt = 0;
+        for (int t = 0; t < NT; ++t) { int* e = bw + (((size_t)ch * MFM_LAT_MAXSTAGES + MFM_LAT_MAXSTAGES - 1) * NT + t) * 4; e[0] = -1; e[1] = e[2] = e[3] = 0; }
+        for (int i = 0; i < L.nops && fits; ++i) {
+          const LatOp& op = P->lat_ops[i];
+          if (L.nch > 1 && op.chain != ch) continue;
+          for (int n = 0; n < op.N; ++n) {
+            if (cnt >= NT || op.b_off + n >= (1ll << 31)) { fits = false; break; }
+            int* e = bw + (((size_t)ch * MFM_LAT_MAXSTAGES + MFM_LAT_MAXSTAGES - 1) * NT + cnt) * 4;
+            e[0] = (int)(op.b_off + n); e[1] = op.out_off + n;
+            ++cnt;
+          }
+        }
+      }
+      L.bias_tab = fits ? 1 : 0;
+    }
+    L.bias_n = 0;
+    for (int ch = 0; ch < L.nch && L.bias_tab; ++ch) {
+      int cnt = 0;
+      for (int i = 0; i < L.nops; ++i) if (L.nch == 1 || P->lat_ops[i].chain == ch) cnt += P->lat_ops[i].N;
+      L.bias_n = std::max(L.bias_n, cnt);
+    }
     // MFM_LATENT_PRE=1 (opt-in): chain workgroups of 512 threads that request the weights four stages ahead instead of one
     // -- measured no faster (13.5 vs 13.8 us forward: the stages are not waiting for weights), profiles/r02_latent_chains.txt
     L.pre = 0;
@@ -439,7 +467,7 @@ int build(MfmPlan* P) {
       if (hh > MFM_SEQ_MAX_RESIDENT_H) continue;
       const int64_t HKB = round_up(4 * round_up(cdiv(hh, 4), 2), 16);
       P->wt_img[i] = carve(cur, 4 * HKB * HKB);
-      if (i >= P->n_enc && V == 0 && (hh & 3) == 0) P->wf_img[i - P->n_enc] = carve(cur, 4 * HKB * HKB);
+      if (i >= P->n_enc && V == 0 && (hh & 3) == 0) { P->wf_img[i - P->n_enc] = carve(cur, 4 * HKB * HKB); P->wf_img[3 + i - P->n_enc] = carve(cur, 4 * HKB * HKB); }
     }
   }
   if (V == 0 && c.B <= DWR_ROWS) {

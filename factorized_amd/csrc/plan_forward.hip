@@ -266,12 +266,14 @@ int forward(MfmPlan* P, const float* params, const float* x, const void* y, int 
     if (n_wt_items == 7) { for (int i = 0; i < 7; ++i) PR.wt[i] = wt_items[i]; PR.n_wt = 7; }
     // the decoders' steps >= 1 weights in the forward's register order: their launch reloads them with coalesced loads
     if (!(opt_get("MFM_WF_IMG") && atoi(opt_get("MFM_WF_IMG")) == 0)) {
-      for (int m = 0; m < 3; ++m) {
-        if (P->wf_img[m] < 0 || T < 2) continue;
+      for (int k = 0; k < 6; ++k) {           // W_ih (the step-0 weights) first: the decoder launch asks for them first
+        const int m = k % 3;
+        const bool sum = k >= 3;
+        if (P->wf_img[m] < 0 || P->wf_img[3 + m] < 0 || T < 2) continue;
         WtImgItem& I = PR.wf[PR.n_wf++];
         const int pb = P->dec_p[m];
-        I.w_hh = params + P->off[pb + W_HH]; I.w_ih = params + P->off[pb + W_IH];
-        I.img = W + P->wf_img[m]; I.h = P->dec[m].h;
+        I.w_hh = sum ? params + P->off[pb + W_HH] : nullptr; I.w_ih = params + P->off[pb + W_IH];
+        I.img = W + P->wf_img[sum ? m : 3 + m]; I.h = P->dec[m].h;
         I.HKB = round_up(4 * round_up(cdiv(P->dec[m].h, 4), 2), 16);
       }
     }
@@ -284,7 +286,7 @@ int forward(MfmPlan* P, const float* params, const float* x, const void* y, int 
     int rc;
     { Timer _t(P, s, K_ENC_FWD); rc = seq_foldproj_launch(q, 4, T, B, L, params, PR, s); }
     if (rc == MFM_OK) { folded = true; P->projfold_state = 1; P->fold_state = 1; P->ever_handover = true; if (PR.n_wt) P->wt_call = P->calls;
-                        if (PR.n_wf == 3) P->wf_call = P->calls; }
+                        if (PR.n_wf == 6) P->wf_call = P->calls; }
     else if (rc == MFM_ERR_UNSUPPORTED) {
       P->projfold_state = -1;
       const int rc0 = run_f0();
@@ -337,56 +339,22 @@ int forward(MfmPlan* P, const float* params, const float* x, const void* y, int 
     }
     RUN(K_MMD, mmd_group_launch(it, 4, rs, gl, rs, B, losses + 4, 1.0f, s, P->mmd_scr >= 0 ? W + P->mmd_scr : nullptr));     // the four terms in one launch (large B: three)
   }
-  // F3 + F4 + B0 + B1 of a training step at small batches: ONE launch, one workgroup per (decoder, row) -- recurrence, the row's
-  // fc1 + squared error + dH, its BPTT (dec_chain_dev.h).  The backward then starts at the latent stack.  A backward that
-  // turns the reconstruction terms off (staged training) simply does not read what the BPTT left.
-  bool chain_done = false;
-  if (train && V == 0 && !seq_bf16 && !st16 && fc1_fused && P->dec_chain_state >= 0 && P->wf_call == P->calls && P->wt_call == P->calls) {
-    MfmSeqDesc q[3];
-    DecChain DC;
-    memset(&DC, 0, sizeof(DC));
-    DC.bf16 = c.precision;
-    const float lda[3] = {c.lda_xl, c.lda_xa, c.lda_xv};
-    for (int m = 0; m < 3; ++m) {
-      const SeqBuf& sb = P->dec[m];
-      const int pb = P->dec_p[m];
-      q[m] = seq_desc(P, sb, pb, params, W, true);
-      q[m].h_init = W + P->dec_init[m]; q[m].ld_init = P->dec_h[m];
-      q[m].dh_ext = W + P->dec_dhs[m]; q[m].ld_dh = sb.Hp;
-      q[m].d_h_init = W + P->dec_dinit[m]; q[m].ld_dinit = P->dec_h[m];
-      const double cnt = (double)TB * P->dec_d[m];
-      DecFc1Item& I = DC.fc[m];
-      I.hs = W + sb.hs; I.w = params + P->off[pb + FC_W]; I.bias = params + P->off[pb + FC_B];
-      I.x = x + P->dec_xoff[m]; I.ldx = P->D;
-      I.xhat = (xhat_out && xhat_out[m]) ? xhat_out[m] : W + P->xhat[m];
-      I.dxhat = W + P->dxhat[m]; I.dhs = W + P->dec_dhs[m]; I.loss = losses + 1 + m;
-      I.d = P->dec_d[m]; I.h = sb.h; I.Hp = sb.Hp;
-      I.inv_count = (float)(1.0 / cnt); I.grad_scale = (float)(2.0 * lda[m] / cnt);
-    }
-    const int ne = P->n_enc;
-    const float* wt[3] = {W + P->wt_img[ne], W + P->wt_img[ne + 1], W + P->wt_img[ne + 2]};
-    const float* wf[3] = {W + P->wf_img[0], W + P->wf_img[1], W + P->wf_img[2]};
-    int rc;
-    { Timer _t(P, s, K_DEC_FWD); rc = seq_dec_chain_launch(q, 3, T, B, wt, wf, DC, s); }
-    if (rc == MFM_OK) { chain_done = true; P->dec_chain_state = 1; P->fc1_bwd_call = P->calls; P->dec_bwd_call = P->calls; }
-    else if (rc == MFM_ERR_UNSUPPORTED) P->dec_chain_state = -1;
-    else return rc;
-  }
   // F3: decoder recurrences
-  if (!chain_done) {
+  {
     MfmSeqDesc q[3];
     for (int m = 0; m < 3; ++m) {
       q[m] = seq_desc(P, P->dec[m], P->dec_p[m], params, W, true);
       q[m].h_init = W + P->dec_init[m]; q[m].ld_init = P->dec_h[m];
     }
     const bool wf_on = !seq_bf16 && P->wf_call == P->calls;
-    const float* wf[3] = {wf_on ? W + P->wf_img[0] : nullptr, wf_on ? W + P->wf_img[1] : nullptr, wf_on ? W + P->wf_img[2] : nullptr};
+    const float* wf[6];
+    for (int k = 0; k < 6; ++k) wf[k] = wf_on ? W + P->wf_img[k] : nullptr;
     if (wf_on) RUN(K_DEC_FWD, seq_fwd_wf_launch(q, 3, T, B, wf, s));
     else RUN(K_DEC_FWD, seq_bf16 ? mfm_lstm_seq_fwd_bf16(q, 3, T, B, s) : mfm_lstm_seq_fwd(q, 3, T, B, s));
   }
   // F4: decoder fc1 -> x_hat
   float* xh[3];
-  if (!chain_done) {
+  {
     MfmGemmDesc g[3];
     memset(g, 0, sizeof(g));
     for (int m = 0; m < 3; ++m) {

@@ -94,10 +94,8 @@ struct MfmPlan {
   int64_t pf_flags = -1;            // their flag words [4][T][16] (u32)
   int64_t wt_img[mfm::MFM_WT_MAX] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};     // transposed-weight images: encoders in plan order, then the 3 decoders (lstm_seq_dev.h)
   unsigned long long wt_call = ~0ull;       // value of `calls` whose forward wrote them
-  int64_t wf_img[3] = {-1, -1, -1};         // forward-order images of the decoders' W_ih + W_hh (lstm_seq_dev.h, wf_img_write)
+  int64_t wf_img[6] = {-1, -1, -1, -1, -1, -1};     // forward-order images of the decoders' W_ih + W_hh, then of W_ih (lstm_seq_dev.h, wf_img_write)
   unsigned long long wf_call = ~0ull;       // value of `calls` whose encoder launch wrote them
-  int dec_chain_state = 0;                  // decoder chain launch (dec_chain_dev.h): 0 not tried, 1 in use, -1 not applicable
-  unsigned long long dec_bwd_call = ~0ull;  // value of `calls` whose forward already ran the decoders' BPTT (chain launch)
   int dwfold_state = 0;             // weight-gradient role workgroups in the backward fold launch (dw_role_dev.h): 0 / 1 / -1
   int64_t dw_flags = -1, dw_table = -1;     // stamps [4][T][32] + [4][B]; block table [DWR_TABLE_CAP] int4
   std::vector<int> dw_table_host;   // the table as uploaded (4 ints per block)

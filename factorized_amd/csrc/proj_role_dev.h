@@ -67,7 +67,7 @@ struct ProjRole {
   ProjRoleEnc e[4];
   ZeroSpans zs;                           // cleared with plain stores (read by later launches only)
   WtImgItem wt[PROJ_ROLE_WT]; int n_wt;   // transposed-weight images to produce (training steps)
-  WtImgItem wf[3]; int n_wf;              // forward-order images of the decoders' steps >= 1 weights (lstm_seq_dev.h)
+  WtImgItem wf[6]; int n_wf;              // forward-order images of the decoders' weights: W_ih (step 0), W_ih + W_hh (lstm_seq_dev.h)
 };
 
 // LDS row stride of the operand images: k padded to 16, then to an odd number of 16-byte groups (the 16 rows of a fragment

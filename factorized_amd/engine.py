@@ -485,12 +485,21 @@ class MFMEngine:
         _lib.check(_lib.lib().mfm_plan_set_gauss(p.handle, _ptr(g)), "mfm_plan_set_gauss")
 
     def _check_inputs(self, x, y):
-        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
-        assert x.shape[2] == sum(self.cfg["input_dims"])
+        """the kernels take raw pointers and index the batch with the plan's sizes: anything that does not fit is refused here
+        (exceptions, not asserts: they must survive python -O)"""
+        D = sum(self.cfg["input_dims"])
+        if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous()):
+            raise _lib.MfmError("batch must be a contiguous float32 CUDA tensor [T, B, %d]; got %s" % (
+                D, "%s %s %s" % (tuple(x.shape), x.dtype, x.device) if torch.is_tensor(x) else type(x)))
+        if x.shape[2] != D:
+            raise _lib.MfmError("batch has %d features per time step, the model's input_dims sum to %d" % (x.shape[2], D))
+        if self.device.index is not None and x.device != self.device:
+            raise _lib.MfmError("batch lives on %s, the engine on %s" % (x.device, self.device))
         if y is not None:
-            assert y.is_cuda and y.is_contiguous() and y.shape[0] == x.shape[1]
             want = torch.int64 if self.cfg.get("loss", "l1") == "ce" else torch.float32
-            assert y.dtype == want, "labels must be %s" % want
+            if not (y.is_cuda and y.device == x.device and y.is_contiguous() and y.shape[0] == x.shape[1] and y.dtype == want):
+                raise _lib.MfmError("labels must be a contiguous %s tensor on %s with %d rows; got %s %s %s" % (
+                    want, x.device, x.shape[1], tuple(y.shape), y.dtype, y.device))
 
     # ------------------------------------------------------------------ the three entry points
     def forward(self, x, y=None, train=False, want_xhat=True, handover=None):

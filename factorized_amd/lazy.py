@@ -184,24 +184,30 @@ class LazyOut(torch.Tensor):
             return target.dtype == torch.float32 and tuple(target.shape) == shp
         return (not self._squeezed) and target.dtype == torch.int64 and tuple(target.shape) == shp[:1]
 
+    def _claim_disc(self, kind, target, squeezed):
+        """y_hat meets its criterion: the step has ONE discriminative slot, so only one (criterion, labels, squeeze) combination
+        can stay symbolic.  A second, different one (another label tensor, the other criterion) goes through the ordinary path --
+        the outputs materialise and both losses are evaluated by torch -- instead of silently re-pointing the first."""
+        st = self._step
+        if st.disc is not None and not (st.disc[0] == kind and st.disc[1] is target and st.disc[2] == squeezed):
+            return False
+        st.check_live("a lazy output")
+        st.disc = (kind, target, squeezed)
+        return True
+
     def _l1(self, target, size_average=None, reduce=None, reduction="mean", weight=None):
         if reduction != "mean" or size_average is not None or reduce is not None or weight is not None \
-                or not self._labels_ok(target, 0):
+                or not self._labels_ok(target, 0) or not self._claim_disc(0, target, self._squeezed):
             return NotImplemented
-        st = self._step
-        st.check_live("a lazy output")
-        st.disc = (0, target, self._squeezed)
-        return LossExpr(st, {DISC: 1.0})
+        return LossExpr(self._step, {DISC: 1.0})
 
     def _ce(self, target, weight=None, size_average=None, ignore_index=-100, reduce=None, reduction="mean",
             label_smoothing=0.0):
         if (reduction != "mean" or size_average is not None or reduce is not None or weight is not None
-                or ignore_index != -100 or label_smoothing != 0.0 or not self._labels_ok(target, 1)):
+                or ignore_index != -100 or label_smoothing != 0.0 or not self._labels_ok(target, 1)
+                or not self._claim_disc(1, target, False)):
             return NotImplemented
-        st = self._step
-        st.check_live("a lazy output")
-        st.disc = (1, target, False)
-        return LossExpr(st, {DISC: 1.0})
+        return LossExpr(self._step, {DISC: 1.0})
 
     def _squeeze(self, *dims, **kw):
         if self._idx != 3 or kw or len(dims) != 1 or not isinstance(dims[0], int) or self._squeezed:
@@ -440,7 +446,10 @@ class PlanStep(StepBase):
         if self.real is None:
             self.check_live("a lazy output")
             from . import mfm_model
-            self.real = mfm_model._LazyRealFn.apply(self.module._flat_leaf, self)
+            # (grad mode ON whatever the caller's is: the materialised outputs are cached for the rest of the step, and a read under
+            #  torch.no_grad() -- an accuracy / NaN check in front of loss.backward() -- must not leave them without a grad_fn)
+            with torch.enable_grad():
+                self.real = mfm_model._LazyRealFn.apply(self.module._flat_leaf, self)
         return self.real
 
     def backward_weighted(self, coef, labels, terms):

@@ -37,6 +37,41 @@ def _owner(p):
     return _owner_of(p)
 
 
+# Who may keep the in-launch hand-overs on is decided PER STEP by the optimizer that actually steps the model: this class marks
+# the models it owns in every step(); any OTHER torch optimizer that steps parameters of a fused model -- an optimizer swap, an
+# LR finder, per-stage optimizers built while the first one is still referenced -- takes the permission away before its
+# update (a global step pre-hook: it knows nothing of the gradient guard and would apply a step whose hand-over gave up).
+_FOREIGN = {}
+
+
+def _foreign_step_hook(opt, args, kwargs):
+    if isinstance(opt, Adam) or getattr(opt, "_mfm_inner", False):
+        return
+    key = id(opt)
+    n = sum(len(g["params"]) for g in opt.param_groups)
+    hit = _FOREIGN.get(key)
+    if hit is None or hit[0] != n or hit[1]() is not opt:
+        import weakref
+        mods, seen = [], set()
+        for g in opt.param_groups:
+            for p in g["params"]:
+                m = _owner(p)
+                if m is not None and id(m) not in seen:
+                    seen.add(id(m))
+                    mods.append(weakref.ref(m))
+        if len(_FOREIGN) > 64:
+            _FOREIGN.clear()
+        hit = _FOREIGN[key] = (n, weakref.ref(opt), mods)
+    for r in hit[2]:
+        m = r()
+        if m is not None:
+            m._guarded = False
+
+
+import importlib as _il
+_il.import_module("torch.optim.optimizer").register_optimizer_step_pre_hook(_foreign_step_hook)
+
+
 class Adam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, capturable=False):
         if weight_decay != 0 or amsgrad:
@@ -120,8 +155,28 @@ class Adam(torch.optim.Optimizer):
             st["lr_host"] = lr
         return st["step_dev"], st["lr_dev"]
 
+    def _migrate_back(self, m, st, eng):
+        """a model returns to the flat path after steps through the stock optimizer (a parameter was frozen and is trainable
+        again): moments and step counts the stock optimizer holds for its tensors come back into the flat state"""
+        fb = self._fallback
+        if fb is None:
+            return
+        for i, p in enumerate(m._plist):
+            s = fb.state.get(p)
+            if not s:
+                continue
+            o, n, shp = eng.layout.slots[i]
+            st["m"][o:o + n].view(shp).copy_(s["exp_avg"])
+            st["v"][o:o + n].view(shp).copy_(s["exp_avg_sq"])
+            st["steps"][i] = int(float(s["step"]))
+            del fb.state[p]
+        if "step_dev" in st:
+            st["step_dev"].fill_(int(st["steps"].max()))
+
     def _fused_step(self, m, group):
         eng = m.engine
+        import weakref
+        m._guarded = weakref.ref(self)          # (per step: the optimizer that steps the model answers for the guard)
         gflat = getattr(m, "_grad_flat", None)
         if gflat is None or not m._grad_views_attached():
             return False                     # gradients are ordinary per-tensor tensors: the stock optimizer handles them
@@ -137,6 +192,8 @@ class Adam(torch.optim.Optimizer):
             eng.check_status(raise_on_error=False)
             warnings.warn(eng.status_message(), RuntimeWarning, stacklevel=3)
         st = self._state_for(m, eng)
+        if self._fallback is not None and self._fallback.state:
+            self._migrate_back(m, st, eng)
         lr, (b1, b2), eps = group["lr"], group["betas"], group["eps"]
         if torch.is_tensor(lr) and not self._capturable:
             lr = float(lr)
@@ -192,6 +249,7 @@ class Adam(torch.optim.Optimizer):
         if self._fallback is None or self._fallback_ids != ids:
             groups = [dict(params=ps, lr=g["lr"], betas=g["betas"], eps=g["eps"]) for g, ps in rest]
             self._fallback = torch.optim.Adam(groups)
+            self._fallback._mfm_inner = True        # (steps on behalf of this class: not a foreign optimizer)
             self._fallback_ids = ids
             self._migrate_fused_state(rest)
             fb = getattr(self, "_pending_fallback", None)
@@ -220,11 +278,8 @@ class Adam(torch.optim.Optimizer):
                     continue
                 self._fallback.state[p] = dict(step=torch.tensor(float(steps)), exp_avg=st["m"][o:o + n].view(shp).clone(),
                                                exp_avg_sq=st["v"][o:o + n].view(shp).clone())
-        for _, ps in rest:
-            for p in ps:
-                m = _owner(p)
-                if m is not None and m in self._fused:
-                    del self._fused[m]
+        # (the flat state stays: when the model returns to the flat path, _migrate_back brings the moments home instead of
+        #  restarting them from zero)
 
     def reset_state(self):
         """moments and step counters of every fused model back to zero, in place (a captured graph keeps pointing at them)"""

@@ -336,6 +336,37 @@ def test_freeze_mid_training_hands_the_gradients_back_to_autograd():
     e4 = err()
     cases.report("freeze_mid_training_param_rel", e4)
     assert e4 < e2 + 2e-5, (e2, e4)
+    # (advisor, round 5) trainable again: the model returns to the flat path and the moments / step counts come home from the stock
+    # optimizer instead of restarting from zero (a restart would show up as ~1e-3)
+    for mod in (model, m):
+        for p in mod.decoder_l.parameters():
+            p.requires_grad_(True)
+    _loop(model, opt, X, y, cfg, 2)
+    for _ in range(2):
+        O.train_step(m, o, xc, yc, cfg)
+    assert model._grad_views_attached()
+    assert not opt._fallback.state
+    fs = opt._fused[model]["steps"]
+    assert int(fs.max()) == 6 and int(fs.min()) == 4          # (the frozen layer missed two steps, like torch's per-tensor counts)
+    e6 = err()
+    cases.report("unfreeze_param_rel", e6)
+    assert e6 < e2 + 4e-5, (e2, e6)
+
+
+def test_lazy_forward_refuses_a_batch_that_does_not_fit_the_plan():
+    """(advisor, round 5) the lazy forward hands raw pointers to kernels that index the batch with the plan's feature width: a
+    batch of another width, dtype or layout is refused with a message, not read out of bounds"""
+    _need_gpu()
+    from factorized_amd._lib import MfmError
+    cs = cases.load_case("klef_b33_t7")
+    model = _model(cs["cfgs"]).cuda().train()
+    X = torch.from_numpy(cs["x"]).cuda()
+    T, B, D = X.shape
+    model.forward(X)
+    for bad in (torch.zeros(T, B, D + 3, device="cuda"), torch.zeros(T, B, D - 1, device="cuda"), X.double(),
+                X.transpose(0, 1), X[:, :, :D].cpu()):
+        with pytest.raises(MfmError):
+            model.forward(bad)
 
 
 @pytest.mark.parametrize("fault", [1, 2])

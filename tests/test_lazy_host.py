@@ -303,3 +303,81 @@ def test_handover_permission_follows_the_guard_aware_optimizer():
     assert not m._handover_ok()
     o2 = torch.optim.Adam(m.parameters())
     assert not m._handover_ok() and o2 is not None
+
+
+def test_a_foreign_optimizer_step_takes_the_handover_permission_away():
+    """the permission is granted per step by the optimizer that steps the model.  A stock optimizer built over the same
+    parameters WHILE the guard-aware one is still alive (optimizer swap, LR finder) clears it in its step; the guard-aware
+    optimizer's next step grants it again."""
+    from factorized_amd import configs
+    from factorized_amd.mfm_model import MFM_KL_EF
+    import factorized_amd.optim as optim
+    m = MFM_KL_EF(*configs.canonical_configs(dropout=False))
+    o = optim.Adam(m.parameters())
+    assert m._handover_ok()
+    sgd = torch.optim.SGD(m.parameters(), lr=0.0)
+    assert m._handover_ok()                      # building it changes nothing ...
+    for p in m.parameters():
+        p.grad = torch.zeros_like(p)
+    sgd.step()                                   # ... stepping the model with it does
+    assert not m._handover_ok()
+    assert o is not None
+
+
+def test_second_criterion_on_y_hat_does_not_repoint_the_first(monkeypatch):
+    """the step has one discriminative slot; l1_loss(y_hat, y) followed by l1_loss(y_hat, y_other) must leave the first
+    expression on y (the second call takes the ordinary path)."""
+    from factorized_amd import lazy
+
+    class St(lazy.StepBase):
+        loss_kind = 0
+        real = None
+        def __init__(self):
+            self.x = torch.zeros(2, 3, 4)
+            self.scalar_view = torch.zeros(())
+        def check_live(self, what):
+            pass
+        def realize(self):
+            self.real = [None, None, None, torch.ones(3, 1, requires_grad=True), torch.zeros(())]
+            return self.real
+    st = St()
+    y_hat = lazy.LazyOut(torch.zeros(3, 1), st, 3)
+    ya, yb = torch.zeros(3, 1), torch.full((3, 1), 5.0)
+    l1 = torch.nn.functional.l1_loss(y_hat, ya)
+    assert isinstance(l1, lazy.LossExpr) and st.disc[1] is ya
+    l2 = torch.nn.functional.l1_loss(y_hat, yb)          # a different label tensor: materialises, evaluated by torch
+    assert not isinstance(l2, lazy.LossExpr) and st.disc[1] is ya
+    assert float(l2.detach()) == pytest.approx(4.0)
+    assert isinstance(torch.nn.functional.l1_loss(y_hat, ya), (lazy.LossExpr, torch.Tensor))
+
+
+def test_outputs_read_under_no_grad_still_backpropagate():
+    """realize() caches the materialised outputs; a read under torch.no_grad() must not cache them without grad_fn."""
+    from factorized_amd import lazy
+    seen = {}
+
+    class St(lazy.PlanStep):
+        def __init__(self):
+            self.real = None
+            self.module = type("M", (), {"_flat_leaf": torch.zeros((), requires_grad=True)})()
+        def check_live(self, what):
+            pass
+    import factorized_amd.mfm_model as mm
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, leaf, step):
+            seen["grad_mode"] = torch.is_grad_enabled()
+            return leaf * 1.0
+        @staticmethod
+        def backward(ctx, g):
+            return g, None
+    old = mm._LazyRealFn
+    mm._LazyRealFn = Fn
+    try:
+        st = St()
+        with torch.no_grad():
+            r = st.realize()
+        assert r.requires_grad and r.grad_fn is not None
+    finally:
+        mm._LazyRealFn = old
