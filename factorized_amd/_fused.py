@@ -362,6 +362,8 @@ def _lazy_forward(module, x):
     from . import lazy
     eng = module.engine
     eng._check_inputs(x, None)          # (shape / dtype / device / contiguity: the kernels index x with the plan's D)
+    if x.shape[0] < 1 or x.shape[1] < 1:
+        raise _lib.MfmError("empty batch %s" % (tuple(x.shape),))
     T, B, _ = x.shape
     plan = eng.plan(T, B)
     if plan.out_views is None:

@@ -531,6 +531,7 @@ class MFMEngine:
         """Training-mode forward of the module path's lazy losses (mfm_plan_forward_train): no labels, no output tensors --
         x_hat / y_hat stay in the plan's workspace (`p.out_views`), the loss slots 1..4 are filled; `grads_to_zero`: a flat
         gradient buffer cleared inside the first launch."""
+        self._check_inputs(x, None)
         p.fwd_serial += 1
         p.consumed = False
         self._gauss_for(p, x.shape[1])
