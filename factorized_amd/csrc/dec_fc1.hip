@@ -220,7 +220,7 @@ int dec_fc1_launch(DecFc1Launch& L, bool dhs_zeroed, hipStream_t stream) {
     tiles += row_tiles * I.col_groups;
   }
   LSTAMP_BIND();
-  hipLaunchKernelGGL(dec_fc1_kernel, dim3(tiles), dim3(FC1_THREADS), 0, stream, L);
+  MFM_LAUNCH_TIMED(dec_fc1_kernel, dim3(tiles), dim3(FC1_THREADS), 0, stream, L);
   MFM_LAUNCH_CHECK("dec_fc1_kernel");
   return MFM_OK;
 }

@@ -591,15 +591,15 @@ int dec_fc1_large_launch(DecFc1LargeLaunch& L, hipStream_t stream) {
       const int rc = fc1_pack_prepare(L, &A);
       if (rc != MFM_OK) return rc;
       if (A.n > 0) {
-        hipLaunchKernelGGL(fc1_pack_kernel, dim3((A.begin[A.n] + 255) / 256), dim3(256), 0, stream, A);
+        MFM_LAUNCH_TIMED(fc1_pack_kernel, dim3((A.begin[A.n] + 255) / 256), dim3(256), 0, stream, A);
         MFM_LAUNCH_CHECK("fc1_pack_kernel");
       }
     }
   } else {
     for (int i = 0; i < L.n_items; ++i) L.it[i].wimg = nullptr;
   }
-  if (RT == FL_R64) hipLaunchKernelGGL(dec_fc1_large64_kernel, dim3(total), dim3(FL_THREADS), smem, stream, L);
-  else hipLaunchKernelGGL(dec_fc1_large_kernel, dim3(total), dim3(FL_THREADS), smem, stream, L);
+  if (RT == FL_R64) MFM_LAUNCH_TIMED(dec_fc1_large64_kernel, dim3(total), dim3(FL_THREADS), smem, stream, L);
+  else MFM_LAUNCH_TIMED(dec_fc1_large_kernel, dim3(total), dim3(FL_THREADS), smem, stream, L);
   MFM_LAUNCH_CHECK("dec_fc1_large_kernel");
   return MFM_OK;
 }

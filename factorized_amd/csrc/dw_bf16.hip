@@ -563,7 +563,7 @@ int x_to_bf16_launch(const float* x, void* out, int64_t rows, int D, int ldo, co
   for (int s = 0; s < 3; ++s) { A.src0[s] = src0[s]; A.n[s] = n[s]; A.dst0[s] = dst0[s]; }
   const int64_t total = rows * (ldo / 8);
   const int blocks = (int)std::min<int64_t>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(x_to_bf16_kernel, dim3(blocks), dim3(256), 0, stream, A);
+  MFM_LAUNCH_TIMED(x_to_bf16_kernel, dim3(blocks), dim3(256), 0, stream, A);
   MFM_LAUNCH_CHECK("x_to_bf16_kernel");
   return MFM_OK;
 }
@@ -811,15 +811,15 @@ int dw_bf16_launch(DwbLaunch& Lu, hipStream_t stream) {
   // STATUS of the fp32 form: parity-green (tests/test_gpu_large_batch.py), but at B = 2048 it runs 666 us (+ 94 us of tail
   // GEMM) against 626 us for the grouped GEMM: its main loop keeps the fp32 matrix pipe ~43 % busy (one ds_read_b32 and its
   // wait per three MFMAs; batching a k-step's reads ahead of its MFMAs made it 779 us) -> opt-in, MFM_DW_F32_MINROWS
-  if (L.f32) hipLaunchKernelGGL((dw_stream_kernel<true, 3, 9>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
-  else if (mixed && wide9) hipLaunchKernelGGL(dw_stream_mixed_kernel<9>, dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
-  else if (mixed) hipLaunchKernelGGL(dw_stream_mixed_kernel<8>, dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
-  else if (wide && wide9) hipLaunchKernelGGL((dw_stream_kernel<false, 4, 9>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
-  else if (wide) hipLaunchKernelGGL((dw_stream_kernel<false, 4, 8>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
-  else hipLaunchKernelGGL((dw_stream_kernel<false, 3, 9>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
+  if (L.f32) MFM_LAUNCH_TIMED((dw_stream_kernel<true, 3, 9>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
+  else if (mixed && wide9) MFM_LAUNCH_TIMED(dw_stream_mixed_kernel<9>, dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
+  else if (mixed) MFM_LAUNCH_TIMED(dw_stream_mixed_kernel<8>, dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
+  else if (wide && wide9) MFM_LAUNCH_TIMED((dw_stream_kernel<false, 4, 9>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
+  else if (wide) MFM_LAUNCH_TIMED((dw_stream_kernel<false, 4, 8>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
+  else MFM_LAUNCH_TIMED((dw_stream_kernel<false, 3, 9>), dim3(tiles), dim3(DWB_THREADS), smem, stream, L);
   MFM_LAUNCH_CHECK("dw_stream_kernel");
   if (L.slabs && L.debug_no_epilogue != 1) {
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3((L.red_rows + 1) / 2), dim3(256), 0, stream, L);
+    MFM_LAUNCH_TIMED(dw_reduce_kernel, dim3((L.red_rows + 1) / 2), dim3(256), 0, stream, L);
     MFM_LAUNCH_CHECK("dw_reduce_kernel");
   }
   return MFM_OK;

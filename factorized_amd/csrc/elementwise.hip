@@ -9,6 +9,8 @@ namespace mfm {
 
 // ---------------------------------------------------------------- error plumbing (host)
 static thread_local char g_err[512] = "";
+thread_local LaunchEvents* tls_launch_events = nullptr;
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -113,7 +115,7 @@ int mse_group_launch(const MseItem* items, int count, hipStream_t stream) {
     if (nb > 1024) nb = 1024;
     total += nb;
   }
-  hipLaunchKernelGGL(mse_kernel, dim3(total), dim3(256), 0, stream, g);
+  MFM_LAUNCH_TIMED(mse_kernel, dim3(total), dim3(256), 0, stream, g);
   MFM_LAUNCH_CHECK("mse_kernel");
   return MFM_OK;
 }
@@ -168,7 +170,7 @@ int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, int ste
   if (nb < 1) nb = 1;
   if (nb > 2048) nb = 2048;
   LSTAMP_BIND();
-  hipLaunchKernelGGL(adam_kernel, dim3((int)nb), dim3(256), 0, stream, p, g, m, v, n, beta1, beta2, eps, step_size,
+  MFM_LAUNCH_TIMED(adam_kernel, dim3((int)nb), dim3(256), 0, stream, p, g, m, v, n, beta1, beta2, eps, step_size,
                      bc2_sqrt, grad_scale, guard);
   MFM_LAUNCH_CHECK("adam_kernel");
   return MFM_OK;
@@ -287,7 +289,7 @@ int adam_spans_launch(float* p, const float* g, float* m, float* v, const MfmAda
   int64_t nb = (n4 + 255) / 256;
   if (nb < 1) nb = 1;
   if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(adam_spans_kernel, dim3((int)nb), dim3(256), 0, stream, p, g, m, v, n4, S, beta1, beta2, eps, grad_scale, guard);
+  MFM_LAUNCH_TIMED(adam_spans_kernel, dim3((int)nb), dim3(256), 0, stream, p, g, m, v, n4, S, beta1, beta2, eps, grad_scale, guard);
   MFM_LAUNCH_CHECK("adam_spans_kernel");
   return MFM_OK;
 }
@@ -300,7 +302,7 @@ int fill_launch(float* p, int64_t n, float val, hipStream_t stream) {
   int nb = (int)((n + 255) / 256);
   if (nb < 1) nb = 1;
   if (nb > 1024) nb = 1024;
-  hipLaunchKernelGGL(fill_kernel, dim3(nb), dim3(256), 0, stream, p, n, val);
+  MFM_LAUNCH_TIMED(fill_kernel, dim3(nb), dim3(256), 0, stream, p, n, val);
   MFM_LAUNCH_CHECK("fill_kernel");
   return MFM_OK;
 }
@@ -346,10 +348,10 @@ extern "C" int mfm_adam_flat_dev(float* p, const float* g, float* m, float* v, i
   int64_t nb = ((n >> 2) + 255) / 256;
   if (nb > 2048) nb = 2048;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_dev_kernel, dim3((int)nb), dim3(256), 0, s, p, g, m, v, n, beta1, beta2, eps, grad_scale,
+  MFM_LAUNCH_TIMED(adam_dev_kernel, dim3((int)nb), dim3(256), 0, s, p, g, m, v, n, beta1, beta2, eps, grad_scale,
                      (const int*)step_dev, lr_dev, guard);
   MFM_LAUNCH_CHECK("adam_dev_kernel");
-  hipLaunchKernelGGL(adam_step_tick_kernel, dim3(1), dim3(64), 0, s, (int*)step_dev, guard);
+  MFM_LAUNCH_TIMED(adam_step_tick_kernel, dim3(1), dim3(64), 0, s, (int*)step_dev, guard);
   MFM_LAUNCH_CHECK("adam_step_tick_kernel");
   return MFM_OK;
 }

@@ -388,14 +388,14 @@ int gemm_group_launch(const MfmGemmDesc* descs, int count, hipStream_t stream, c
   for (int i = count; i < MFM_GEMM_MAXP; ++i) g.begins[i] = 0x7fffffff;
   if (bf16) return gemm_bf16_launch_kernel(g, FR, total, stream);
   if (FR == 4) {
-    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<4, true>), dim3(total), dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<4, false>), dim3(total), dim3(256), 0, stream, g);
+    if (vec) MFM_LAUNCH_TIMED((gemm_f32_kernel<4, true>), dim3(total), dim3(256), 0, stream, g);
+    else MFM_LAUNCH_TIMED((gemm_f32_kernel<4, false>), dim3(total), dim3(256), 0, stream, g);
   } else if (FR == 2) {
-    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<2, true>), dim3(total), dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<2, false>), dim3(total), dim3(256), 0, stream, g);
+    if (vec) MFM_LAUNCH_TIMED((gemm_f32_kernel<2, true>), dim3(total), dim3(256), 0, stream, g);
+    else MFM_LAUNCH_TIMED((gemm_f32_kernel<2, false>), dim3(total), dim3(256), 0, stream, g);
   } else {
-    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<1, true>), dim3(total), dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<1, false>), dim3(total), dim3(256), 0, stream, g);
+    if (vec) MFM_LAUNCH_TIMED((gemm_f32_kernel<1, true>), dim3(total), dim3(256), 0, stream, g);
+    else MFM_LAUNCH_TIMED((gemm_f32_kernel<1, false>), dim3(total), dim3(256), 0, stream, g);
   }
   MFM_LAUNCH_CHECK("gemm_f32_kernel");
   return MFM_OK;

@@ -251,9 +251,9 @@ __global__ __launch_bounds__(256, (FR == 1) ? 4 : 2) void gemm_bf16_kernel(const
 }
 
 int gemm_bf16_launch_kernel(const GemmGroup& g, int FR, int total, hipStream_t stream) {
-  if (FR == 4) hipLaunchKernelGGL((gemm_bf16_kernel<4>), dim3(total), dim3(256), 0, stream, g);
-  else if (FR == 2) hipLaunchKernelGGL((gemm_bf16_kernel<2>), dim3(total), dim3(256), 0, stream, g);
-  else hipLaunchKernelGGL((gemm_bf16_kernel<1>), dim3(total), dim3(256), 0, stream, g);
+  if (FR == 4) MFM_LAUNCH_TIMED((gemm_bf16_kernel<4>), dim3(total), dim3(256), 0, stream, g);
+  else if (FR == 2) MFM_LAUNCH_TIMED((gemm_bf16_kernel<2>), dim3(total), dim3(256), 0, stream, g);
+  else MFM_LAUNCH_TIMED((gemm_bf16_kernel<1>), dim3(total), dim3(256), 0, stream, g);
   MFM_LAUNCH_CHECK("gemm_bf16_kernel");
   return MFM_OK;
 }

@@ -299,7 +299,7 @@ int gemm_panel_launch(PanelLaunch& L, const ZeroSpans* zs, int precision, bool f
   do {                                                                                                            \
     auto* fn = gemm_panel_kernel<B16, WM_, WN_, FM_, FN_>;                                                        \
     MFM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
-    hipLaunchKernelGGL(fn, grid, block, lds, stream, L);                                                          \
+    MFM_LAUNCH_TIMED(fn, grid, block, lds, stream, L);                                                          \
   } while (0)
   if (bf16) {
     if (BM == 128) MFM_PANEL_GO(true, 4, 2, 2, 4);

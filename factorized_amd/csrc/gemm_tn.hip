@@ -232,7 +232,7 @@ int gemm_tn_launch(const MfmGemmDesc* descs, int count, int max_rows, bool c_is_
   do {                                                                                                             \
     auto* fn = gemm_tn_kernel<KC_>;                                                                                \
     if (lds > 64 * 1024) MFM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(fn, dim3(total), dim3(256), lds, stream, g);                                                \
+    MFM_LAUNCH_TIMED(fn, dim3(total), dim3(256), lds, stream, g);                                                \
   } while (0)
   if (KC == 80) MFM_TN_GO(80);
   else if (KC == 320) MFM_TN_GO(320);

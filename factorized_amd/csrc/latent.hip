@@ -612,10 +612,10 @@ int latent_fwd_launch(const LatentDev& L, const float* params, hipStream_t strea
     const size_t lds1 = ((size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + L.rec_size) * sizeof(float);
     if (L.pre) {
       if (int rc1 = set_lds_limit((const void*)latent_fwd_row_kernel<true>, lds1)) return rc1;
-      hipLaunchKernelGGL(latent_fwd_row_kernel<true>, dim3(L.B * L.nch), dim3(LAT_PRE_THREADS), lds1, stream, L, params);
+      MFM_LAUNCH_TIMED(latent_fwd_row_kernel<true>, dim3(L.B * L.nch), dim3(LAT_PRE_THREADS), lds1, stream, L, params);
     } else {
       if (int rc1 = set_lds_limit((const void*)latent_fwd_row_kernel<false>, lds1)) return rc1;
-      hipLaunchKernelGGL(latent_fwd_row_kernel<false>, dim3(L.B * L.nch), dim3(L.row_threads), lds1, stream, L, params);
+      MFM_LAUNCH_TIMED(latent_fwd_row_kernel<false>, dim3(L.B * L.nch), dim3(L.row_threads), lds1, stream, L, params);
     }
     MFM_LAUNCH_CHECK("latent_fwd_row_kernel");
     return MFM_OK;
@@ -626,9 +626,9 @@ int latent_fwd_launch(const LatentDev& L, const float* params, hipStream_t strea
   int rc = set_lds_limit(L.wpanel > 0 ? (const void*)latent_fwd_kernel<true> : (const void*)latent_fwd_kernel<false>, lds);
   if (rc != MFM_OK) return rc;
   if (L.wpanel > 0)
-    hipLaunchKernelGGL(latent_fwd_kernel<true>, dim3(cdiv(L.B, R)), dim3(LAT_THREADS), lds, stream, L, params);
+    MFM_LAUNCH_TIMED(latent_fwd_kernel<true>, dim3(cdiv(L.B, R)), dim3(LAT_THREADS), lds, stream, L, params);
   else
-    hipLaunchKernelGGL(latent_fwd_kernel<false>, dim3(cdiv(L.B, R)), dim3(LAT_THREADS), lds, stream, L, params);
+    MFM_LAUNCH_TIMED(latent_fwd_kernel<false>, dim3(cdiv(L.B, R)), dim3(LAT_THREADS), lds, stream, L, params);
   MFM_LAUNCH_CHECK("latent_fwd_kernel");
   return MFM_OK;
 }
@@ -637,10 +637,10 @@ int latent_bwd_launch(const LatentDev& L, const float* params, float* grads, hip
     const size_t lds1 = ((size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + 2 * (size_t)L.rec_size) * sizeof(float);
     if (L.pre) {
       if (int rc1 = set_lds_limit((const void*)latent_bwd_row_kernel<true>, lds1)) return rc1;
-      hipLaunchKernelGGL(latent_bwd_row_kernel<true>, dim3(L.B * L.nch), dim3(LAT_PRE_THREADS), lds1, stream, L, params, grads);
+      MFM_LAUNCH_TIMED(latent_bwd_row_kernel<true>, dim3(L.B * L.nch), dim3(LAT_PRE_THREADS), lds1, stream, L, params, grads);
     } else {
       if (int rc1 = set_lds_limit((const void*)latent_bwd_row_kernel<false>, lds1)) return rc1;
-      hipLaunchKernelGGL(latent_bwd_row_kernel<false>, dim3(L.B * L.nch), dim3(L.row_threads), lds1, stream, L, params, grads);
+      MFM_LAUNCH_TIMED(latent_bwd_row_kernel<false>, dim3(L.B * L.nch), dim3(L.row_threads), lds1, stream, L, params, grads);
     }
     MFM_LAUNCH_CHECK("latent_bwd_row_kernel");
     return MFM_OK;
@@ -651,9 +651,9 @@ int latent_bwd_launch(const LatentDev& L, const float* params, float* grads, hip
   int rc = set_lds_limit(L.wpanel > 0 ? (const void*)latent_bwd_kernel<true> : (const void*)latent_bwd_kernel<false>, lds);
   if (rc != MFM_OK) return rc;
   if (L.wpanel > 0)
-    hipLaunchKernelGGL(latent_bwd_kernel<true>, dim3(cdiv(L.B, R)), dim3(LAT_THREADS), lds, stream, L, params, grads);
+    MFM_LAUNCH_TIMED(latent_bwd_kernel<true>, dim3(cdiv(L.B, R)), dim3(LAT_THREADS), lds, stream, L, params, grads);
   else
-    hipLaunchKernelGGL(latent_bwd_kernel<false>, dim3(cdiv(L.B, R)), dim3(LAT_THREADS), lds, stream, L, params, grads);
+    MFM_LAUNCH_TIMED(latent_bwd_kernel<false>, dim3(cdiv(L.B, R)), dim3(LAT_THREADS), lds, stream, L, params, grads);
   MFM_LAUNCH_CHECK("latent_bwd_kernel");
   return MFM_OK;
 }

@@ -210,7 +210,7 @@ int lin_rows_launch(const LinRowsItem* items, int count, int M, int train, unsig
   do {                                                                                                            \
     auto* fn = lin_rows_kernel<PA_, PW_>;                                                                         \
     if (lds > 64 * 1024) MFM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL(fn, dim3(total), dim3(LR_THREADS), lds, stream, L);                                        \
+    MFM_LAUNCH_TIMED(fn, dim3(total), dim3(LR_THREADS), lds, stream, L);                                        \
   } while (0)
   if (k4 <= 32) MFM_LR_GO(2, 4);
   else if (k4 <= 64) MFM_LR_GO(4, 8);

@@ -490,11 +490,11 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     if (K.count == 0) continue;
     const dim3 grid(ktotal), block(64 * max_waves);
     if (bwd) {
-      if (kind) hipLaunchKernelGGL((lstm_seq_kernel<true, 1>), grid, block, lds_bytes, stream, K);
-      else hipLaunchKernelGGL((lstm_seq_kernel<true, 0>), grid, block, lds_bytes, stream, K);
+      if (kind) MFM_LAUNCH_TIMED((lstm_seq_kernel<true, 1>), grid, block, lds_bytes, stream, K);
+      else MFM_LAUNCH_TIMED((lstm_seq_kernel<true, 0>), grid, block, lds_bytes, stream, K);
     } else {
-      if (kind) hipLaunchKernelGGL((lstm_seq_kernel<false, 1>), grid, block, lds_bytes, stream, K);
-      else hipLaunchKernelGGL((lstm_seq_kernel<false, 0>), grid, block, lds_bytes, stream, K);
+      if (kind) MFM_LAUNCH_TIMED((lstm_seq_kernel<false, 1>), grid, block, lds_bytes, stream, K);
+      else MFM_LAUNCH_TIMED((lstm_seq_kernel<false, 0>), grid, block, lds_bytes, stream, K);
     }
     MFM_LAUNCH_CHECK(bwd ? "lstm_seq_bwd_kernel" : "lstm_seq_fwd_kernel");
   }

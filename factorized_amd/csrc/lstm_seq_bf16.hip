@@ -711,7 +711,7 @@ extern "C" int mfm_lstm_pack_bf16(const MfmSeqDesc* descs, int count, void* stre
     const int rc = lstm_pack_prepare(descs + done, std::min(count - done, MFM_MAX_SEQ * 2), &L);
     if (rc != MFM_OK) return rc;
     if (L.count == 0) continue;
-    hipLaunchKernelGGL(lstm_pack_bf16_kernel, dim3((unsigned)((L.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, L);
+    MFM_LAUNCH_TIMED(lstm_pack_bf16_kernel, dim3((unsigned)((L.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, L);
     MFM_LAUNCH_CHECK("lstm_pack_bf16_kernel");
   }
   return MFM_OK;
@@ -759,8 +759,8 @@ int seq_bf16_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
       big_lds = true;                                                                                                     \
     }                                                                                                                     \
     MFM_REQUIRE(lds_bytes <= 160 * 1024, "lstm_seq (bf16): %zu bytes of LDS", lds_bytes);                                 \
-    if (st) hipLaunchKernelGGL((lstm_seq_bf16_kernel<BWD_, KIND_, true>), grid, block, lds_bytes, stream, K);             \
-    else hipLaunchKernelGGL((lstm_seq_bf16_kernel<BWD_, KIND_, false>), grid, block, lds_bytes, stream, K);               \
+    if (st) MFM_LAUNCH_TIMED((lstm_seq_bf16_kernel<BWD_, KIND_, true>), grid, block, lds_bytes, stream, K);             \
+    else MFM_LAUNCH_TIMED((lstm_seq_bf16_kernel<BWD_, KIND_, false>), grid, block, lds_bytes, stream, K);               \
   } while (0)
     if (bwd) {
       if (kind) MFM_SEQB_GO(true, 1); else MFM_SEQB_GO(true, 0);

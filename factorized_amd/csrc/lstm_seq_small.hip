@@ -91,9 +91,9 @@ static bool try_launch4(const SeqLaunch& L, bool bwd, int total, int threads, si
     if (*err != hipSuccess) return true;
   }
   if (bwd)
-    hipLaunchKernelGGL((lstm_seq_small_kernel4<true, R, KS, K0, K1, K2, K3, K4, K5>), dim3(total), dim3(threads), lds_bytes, stream, L);
+    MFM_LAUNCH_TIMED((lstm_seq_small_kernel4<true, R, KS, K0, K1, K2, K3, K4, K5>), dim3(total), dim3(threads), lds_bytes, stream, L);
   else
-    hipLaunchKernelGGL((lstm_seq_small_kernel4<false, R, KS, K0, K1, K2, K3, K4, K5>), dim3(total), dim3(threads), lds_bytes, stream, L);
+    MFM_LAUNCH_TIMED((lstm_seq_small_kernel4<false, R, KS, K0, K1, K2, K3, K4, K5>), dim3(total), dim3(threads), lds_bytes, stream, L);
   return true;
 }
 
@@ -330,7 +330,7 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
         err = hipFuncSetAttribute((const void*)lstm_seq_small_kernel4<false, 1, 16, 26, 6, 6, 0, 0, 0, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (err == hipSuccess)
-        hipLaunchKernelGGL((lstm_seq_small_kernel4<false, 1, 16, 26, 6, 6, 0, 0, 0, true>), dim3(total), dim3(max_threads), lds_bytes, stream, L);
+        MFM_LAUNCH_TIMED((lstm_seq_small_kernel4<false, 1, 16, 26, 6, 6, 0, 0, 0, true>), dim3(total), dim3(max_threads), lds_bytes, stream, L);
       done = true;
     }
     if (done) {}
@@ -358,9 +358,9 @@ int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   }
   if (bwd)
-    hipLaunchKernelGGL(lstm_seq_small_kernel<true>, dim3(total), dim3(max_threads), lds_bytes, stream, L);
+    MFM_LAUNCH_TIMED(lstm_seq_small_kernel<true>, dim3(total), dim3(max_threads), lds_bytes, stream, L);
   else
-    hipLaunchKernelGGL(lstm_seq_small_kernel<false>, dim3(total), dim3(max_threads), lds_bytes, stream, L);
+    MFM_LAUNCH_TIMED(lstm_seq_small_kernel<false>, dim3(total), dim3(max_threads), lds_bytes, stream, L);
   MFM_LAUNCH_CHECK(bwd ? "lstm_seq_small_bwd_kernel" : "lstm_seq_small_fwd_kernel");
   return MFM_OK;
 }
@@ -405,7 +405,7 @@ int seq_small_folddw_launch(SeqLaunch& L, const LatentDev& LD, DwRole& DR, const
   lds_bytes = std::max(lds_bytes, std::max(lat, role));
   if (lds_bytes > 160 * 1024) return MFM_ERR_UNSUPPORTED;
   MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_folddw_kernel<8, 2, 20, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL((lstm_seq_small_folddw_kernel<8, 2, 20, 30>), dim3(total), dim3(1024), lds_bytes, stream, L, LD, DR, params, grads);
+  MFM_LAUNCH_TIMED((lstm_seq_small_folddw_kernel<8, 2, 20, 30>), dim3(total), dim3(1024), lds_bytes, stream, L, LD, DR, params, grads);
   MFM_LAUNCH_CHECK("lstm_seq_small_folddw_kernel");
   return MFM_OK;
 }
@@ -471,7 +471,7 @@ int seq_small_foldproj_launch(SeqLaunch& L, const LatentDev& LD, ProjRole& PR, c
     }
   }
   MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_foldproj_kernel<8, 2, 20, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL((lstm_seq_small_foldproj_kernel<8, 2, 20, 30>), dim3(total), dim3(1024), lds_bytes, stream, L, LD, PR, params);
+  MFM_LAUNCH_TIMED((lstm_seq_small_foldproj_kernel<8, 2, 20, 30>), dim3(total), dim3(1024), lds_bytes, stream, L, LD, PR, params);
   MFM_LAUNCH_CHECK("lstm_seq_small_foldproj_kernel");
   return MFM_OK;
 }
@@ -502,10 +502,10 @@ int seq_small_fold_launch(SeqLaunch& L, bool bwd, const LatentDev& LD, const flo
   if (lds_bytes > 160 * 1024) return MFM_ERR_UNSUPPORTED;
   if (bwd) {
     MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_fold_kernel<true, 8, 2, 20, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL((lstm_seq_small_fold_kernel<true, 8, 2, 20, 30>), dim3(total), dim3(max_threads), lds_bytes, stream, L, LD, params, grads);
+    MFM_LAUNCH_TIMED((lstm_seq_small_fold_kernel<true, 8, 2, 20, 30>), dim3(total), dim3(max_threads), lds_bytes, stream, L, LD, params, grads);
   } else {
     MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_fold_kernel<false, 8, 2, 20, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL((lstm_seq_small_fold_kernel<false, 8, 2, 20, 30>), dim3(total), dim3(max_threads), lds_bytes, stream, L, LD, params, grads);
+    MFM_LAUNCH_TIMED((lstm_seq_small_fold_kernel<false, 8, 2, 20, 30>), dim3(total), dim3(max_threads), lds_bytes, stream, L, LD, params, grads);
   }
   MFM_LAUNCH_CHECK("lstm_seq_small_fold_kernel");
   return MFM_OK;

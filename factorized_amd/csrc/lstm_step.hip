@@ -89,8 +89,8 @@ int launch_cells(CellGroup& g, bool bwd, hipStream_t s) {
     g.it[i].block_begin = total;
     total += (int)(((int64_t)g.B * g.it[i].Hp + 255) / 256);
   }
-  if (bwd) hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(total), dim3(256), 0, s, g);
-  else hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(total), dim3(256), 0, s, g);
+  if (bwd) MFM_LAUNCH_TIMED(lstm_cell_bwd_kernel, dim3(total), dim3(256), 0, s, g);
+  else MFM_LAUNCH_TIMED(lstm_cell_fwd_kernel, dim3(total), dim3(256), 0, s, g);
   MFM_LAUNCH_CHECK(bwd ? "lstm_cell_bwd_kernel" : "lstm_cell_fwd_kernel");
   return MFM_OK;
 }
@@ -143,7 +143,7 @@ int seq_stepwise(const MfmSeqDesc* descs, int count, int T, int B, bool bwd, hip
     const MfmSeqDesc& d = descs[i];
     if (d.is_dec) {
       const int64_t n = (int64_t)4 * d.h * d.h;
-      hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, d.w_ih, d.w_hh, scratch + off_ws[i], n);
+      MFM_LAUNCH_TIMED(add2_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, d.w_ih, d.w_hh, scratch + off_ws[i], n);
     }
     if (bwd) {
       const size_t Hp = round_up(d.h, 16);

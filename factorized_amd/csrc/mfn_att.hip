@@ -143,7 +143,7 @@ int mfn_cstar_launch(const MfnCs& c, float* cstar, hipStream_t stream) {
   int off = 0;
   for (int m = 0; m < 3; ++m) { S.cs[m] = c.cs[m]; S.h[m] = c.h[m]; S.Hp[m] = round_up(c.h[m], 16); S.off[m] = off; off += c.h[m]; }
   S.tot = off; S.T = c.T; S.B = c.B;
-  hipLaunchKernelGGL(mfn_cstar_kernel, dim3(grid_for((int64_t)c.T * c.B * 2 * off)), dim3(256), 0, stream, S, cstar);
+  MFM_LAUNCH_TIMED(mfn_cstar_kernel, dim3(grid_for((int64_t)c.T * c.B * 2 * off)), dim3(256), 0, stream, S, cstar);
   MFM_LAUNCH_CHECK("mfn_cstar_kernel");
   return MFM_OK;
 }
@@ -156,14 +156,14 @@ int mfn_dcs_scatter_launch(const MfnCs& c, const float* dcs, hipStream_t stream)
     S.dcx[m] = c.dcx[m]; S.h[m] = c.h[m]; S.Hp[m] = round_up(c.h[m], 16); S.off[m] = off; off += c.h[m]; hps += S.Hp[m];
   }
   S.tot = off; S.T = c.T; S.B = c.B;
-  hipLaunchKernelGGL(mfn_dcs_scatter_kernel, dim3(grid_for((int64_t)c.T * c.B * hps)), dim3(256), 0, stream, S, dcs);
+  MFM_LAUNCH_TIMED(mfn_dcs_scatter_kernel, dim3(grid_for((int64_t)c.T * c.B * hps)), dim3(256), 0, stream, S, dcs);
   MFM_LAUNCH_CHECK("mfn_dcs_scatter_kernel");
   return MFM_OK;
 }
 
 int mfn_softmax_fwd_launch(float* att, const float* cstar, float* attended, int64_t rows, int n, hipStream_t stream) {
   MFM_REQUIRE(n >= 1 && n <= 64 * SM_MAXPER, "mfn softmax: row width %d > %d", n, 64 * SM_MAXPER);
-  hipLaunchKernelGGL(mfn_softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, att, cstar, attended, rows, n);
+  MFM_LAUNCH_TIMED(mfn_softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, att, cstar, attended, rows, n);
   MFM_LAUNCH_CHECK("mfn_softmax_fwd_kernel");
   return MFM_OK;
 }
@@ -171,7 +171,7 @@ int mfn_softmax_fwd_launch(float* att, const float* cstar, float* attended, int6
 int mfn_softmax_bwd_launch(const float* datt, const float* att, const float* cstar, float* dlog, float* dcs, int64_t rows,
                            int n, hipStream_t stream) {
   MFM_REQUIRE(n >= 1 && n <= 64 * SM_MAXPER, "mfn softmax: row width %d > %d", n, 64 * SM_MAXPER);
-  hipLaunchKernelGGL(mfn_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, datt, att, cstar, dlog,
+  MFM_LAUNCH_TIMED(mfn_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, datt, att, cstar, dlog,
                      dcs, rows, n);
   MFM_LAUNCH_CHECK("mfn_softmax_bwd_kernel");
   return MFM_OK;

@@ -431,8 +431,8 @@ int mfm::mfn_mem_fwd_launch(const MfmMemDesc* desc, const MfnHeadsDev* heads, hi
                 "mfn_mem: heads descriptor");
     P.hd = *heads;
   }
-  if (threads <= 512) hipLaunchKernelGGL(mfn_mem_fwd_kernel<512>, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
-  else hipLaunchKernelGGL(mfn_mem_fwd_kernel<1024>, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
+  if (threads <= 512) MFM_LAUNCH_TIMED(mfn_mem_fwd_kernel<512>, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
+  else MFM_LAUNCH_TIMED(mfn_mem_fwd_kernel<1024>, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
   MFM_LAUNCH_CHECK("mfn_mem_fwd_kernel");
   return MFM_OK;
 }
@@ -453,8 +453,8 @@ int mfm::mfn_mem_bwd_launch(const MfmMemDesc* desc, const MfnHeadsDev* heads, hi
     MFM_REQUIRE(heads->nheads >= 1 && heads->nheads <= 2 && heads->dz && heads->d_hT && heads->w[0], "mfn_mem: heads descriptor (backward)");
     P.hd = *heads;
   }
-  if (threads <= 512) hipLaunchKernelGGL(mfn_mem_bwd_kernel<512>, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
-  else hipLaunchKernelGGL(mfn_mem_bwd_kernel<1024>, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
+  if (threads <= 512) MFM_LAUNCH_TIMED(mfn_mem_bwd_kernel<512>, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
+  else MFM_LAUNCH_TIMED(mfn_mem_bwd_kernel<1024>, dim3(desc->B), dim3(threads), lds, (hipStream_t)stream, P);
   MFM_LAUNCH_CHECK("mfn_mem_bwd_kernel");
   return MFM_OK;
 }

@@ -214,7 +214,7 @@ static int mmd_gemm_form(const MmdItem* items, int count, int64_t ldz, int64_t l
   if (rc != MFM_OK) return rc;
   const float loss_scale = 1.0f / ((float)B * (float)B);
   const dim3 grid(std::min(cdiv(B, 4), 2 * device_cus()), count);
-  hipLaunchKernelGGL(mmd_k_kernel, grid, dim3(256), 2 * (size_t)B * sizeof(float), stream, K, B, ldb, ldz, lddz, loss, loss_scale, dz_scale);
+  MFM_LAUNCH_TIMED(mmd_k_kernel, grid, dim3(256), 2 * (size_t)B * sizeof(float), stream, K, B, ldb, ldz, lddz, loss, loss_scale, dz_scale);
   MFM_LAUNCH_CHECK("mmd_k_kernel");
   bool any_dz = false;
   for (int e = 0; e < count; ++e) any_dz = any_dz || items[e].dz;
@@ -265,9 +265,9 @@ int mmd_group_launch(const MmdItem* items, int count, int64_t ldz, int64_t ldg, 
   if (lds > 64 * 1024) MFM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const dim3 grid(cdiv(B, MI), count);
   if (MI == 8)
-    hipLaunchKernelGGL(mmd_kernel<8>, grid, dim3(256), lds, stream, G, B, loss, 1.0f / ((float)B * (float)B), ldz, ldg, lddz, dz_scale);
+    MFM_LAUNCH_TIMED(mmd_kernel<8>, grid, dim3(256), lds, stream, G, B, loss, 1.0f / ((float)B * (float)B), ldz, ldg, lddz, dz_scale);
   else
-    hipLaunchKernelGGL(mmd_kernel<32>, grid, dim3(256), lds, stream, G, B, loss, 1.0f / ((float)B * (float)B), ldz, ldg, lddz, dz_scale);
+    MFM_LAUNCH_TIMED(mmd_kernel<32>, grid, dim3(256), lds, stream, G, B, loss, 1.0f / ((float)B * (float)B), ldz, ldg, lddz, dz_scale);
   MFM_LAUNCH_CHECK("mmd_kernel");
   return MFM_OK;
 }

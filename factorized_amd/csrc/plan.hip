@@ -397,7 +397,19 @@ extern "C" double mfm_plan_bytes_per_step(const MfmPlan* P) {
   double sh = 0.0;
   for (int e = 0; e < P->n_enc; ++e) sh += P->enc_h[e];
   for (int m = 0; m < 3; ++m) sh += P->dec_h[m];
-  const double per_sample = 2.0 * P->T * P->D * 4.0 + 4.0 + 2.0 * P->T * 6.0 * sh * 4.0;
+  // SURVEY.md section 8d per sample: the batch read twice, the label, the saved LSTM state (i, f, g, o, c, h per unit and time
+  // step) written once and read once; per step: parameter traffic (forward read, backward read, gradient write, Adam 4 R + 3 W).
+  // bf16-RESIDENT plans (round 6: the fp32 formula over-stated them, 896 MB where the layout moves ~575 MB at B = 2048) keep the
+  // gates and the hidden states as bf16 (5 of the 6 saved values per unit: the cell state stays fp32), read the batch once as fp32
+  // and once as its bf16 image, and add the bf16 d x_hat / dH streams of the decoders (written and read once each)
+  double per_sample;
+  if (P->st16) {
+    double dd = 0.0, dh = 0.0;
+    for (int m = 0; m < 3; ++m) { dd += P->dec_d[m]; dh += P->dec_h[m]; }
+    per_sample = P->T * P->D * (4.0 + 2.0 + 2.0) + 4.0 + 2.0 * P->T * sh * (5.0 * 2.0 + 4.0) + 2.0 * P->T * (dd + dh) * 2.0;
+  } else {
+    per_sample = 2.0 * P->T * P->D * 4.0 + 4.0 + 2.0 * P->T * 6.0 * sh * 4.0;
+  }
   return per_sample * P->B + 10.0 * (double)P->n_params * 4.0;
 }
 // Algorithmic FLOPs of ONE launch of kernel `kid` (recurrent/GEMM kernels only; 0 otherwise).

@@ -209,7 +209,7 @@ int backward(MfmPlan* P, const float* params, const float* x, const void* y, int
     MfmPlan* P; float* W; float* guard; hipStream_t s; bool armed;      // only on plans that ever used a hand-over
     ~GuardAtExit() {
       if (armed && guard && P->ever_handover)
-        hipLaunchKernelGGL(guard_propagate_kernel, dim3(1), dim3(64), 0, s, P->status_ptr(W), guard);
+        MFM_LAUNCH_TIMED(guard_propagate_kernel, dim3(1), dim3(64), 0, s, P->status_ptr(W), guard);
     }
   } guard_at_exit{P, W, guard, s, true};
   const bool gen_on = lw ? lw->gen_on != 0 : (stage != 2), disc_on = lw ? lw->disc != 0.0f : (stage != 1);
@@ -367,7 +367,7 @@ int backward(MfmPlan* P, const float* params, const float* x, const void* y, int
             P->dwfold_state = 1; P->ever_handover = true;
             guard_at_exit.armed = false;
             if (stream_capturing(s)) {
-              hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, s, (unsigned long long*)nullptr, P->dw_tick_ptr(W));
+              MFM_LAUNCH_TIMED(tick_kernel, dim3(1), dim3(64), 0, s, (unsigned long long*)nullptr, P->dw_tick_ptr(W));
               MFM_LAUNCH_CHECK("tick_kernel");
             }
             return MFM_OK;

@@ -428,7 +428,7 @@ int forward(MfmPlan* P, const float* params, const float* x, const void* y, int 
   (void)pi;
   // captured into a hipGraph: every replay advances the device half of the call counter (dropout streams, hand-over epochs)
   if (capturing) {
-    hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned long long*>(P->tick_ptr(W)), (unsigned*)nullptr);
+    MFM_LAUNCH_TIMED(tick_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned long long*>(P->tick_ptr(W)), (unsigned*)nullptr);
     MFM_LAUNCH_CHECK("tick_kernel");
   }
   return MFM_OK;

@@ -150,7 +150,9 @@ inline unsigned epoch_base(uint64_t calls) { return (unsigned)calls * 0x9E3779B1
 
 struct Timer {
   MfmPlan* P; hipStream_t s; int kid; TimingPair* tp;
-  Timer(MfmPlan* P_, hipStream_t s_, int kid_) : P(P_), s(s_), kid(kid_), tp(nullptr) {
+  LaunchEvents le; LaunchEvents* prev;
+  Timer(MfmPlan* P_, hipStream_t s_, int kid_) : P(P_), s(s_), kid(kid_), tp(nullptr), prev(nullptr) {
+    le.launches = -1;
     if (!(P->timing_mask & (1 << kid))) return;
     // sampled: a bracket is two extra packets on the stream (~4.6 us per bracket); timing every step would put that
     // into every step of bench.py's timed region, so only every `timing_every`-th call of the plan is bracketed
@@ -164,8 +166,17 @@ struct Timer {
     tp = &P->pool[P->pool_used++];
     tp->kid = kid;
     (void)hipEventRecord(tp->a, s);
+    // a single launch inside this region takes both events as its own dispatch timestamps (common.h, MFM_LAUNCH_TIMED)
+    le.a = tp->a; le.b = tp->b; le.launches = 0;
+    prev = tls_launch_events;
+    tls_launch_events = &le;
   }
-  ~Timer() { if (tp) (void)hipEventRecord(tp->b, s); }
+  ~Timer() {
+    if (!tp) return;
+    tls_launch_events = prev;
+    // no launch went through the macro: the plain bracket; several did: from the first kernel's own begin to behind the last
+    if (le.launches != 1) (void)hipEventRecord(tp->b, s);
+  }
 };
 
 #define RUN(kid, expr)                        \

@@ -306,7 +306,7 @@ int proj_bf16_pack_launch(const PanelLaunch& L, const ProjPlan& P, void* wimg, f
   const int rc = proj_pack_prepare(L, P, wimg, bimg, &D);
   if (rc != MFM_OK) return rc;
   const int64_t total = (int64_t)P.ntiles * (PJ_TILE / 8) + P.nbias;
-  hipLaunchKernelGGL(proj_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, D);
+  MFM_LAUNCH_TIMED(proj_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, D);
   MFM_LAUNCH_CHECK("proj_pack_kernel");
   return MFM_OK;
 }
@@ -322,7 +322,7 @@ int pack_all_launch(const PackLaunch* lstm, const PjPackDev* proj, const Fc1Pack
   if (n1 + n2 + n3 == 0) return MFM_OK;
   MFM_REQUIRE(n1 + n2 + n3 < ((int64_t)1 << 30), "pack: too many blocks");
   A.b1 = (int)n1; A.b2 = (int)(n1 + n2);
-  hipLaunchKernelGGL(pack_all_kernel, dim3((unsigned)(n1 + n2 + n3)), dim3(256), 0, stream, A);
+  MFM_LAUNCH_TIMED(pack_all_kernel, dim3((unsigned)(n1 + n2 + n3)), dim3(256), 0, stream, A);
   MFM_LAUNCH_CHECK("pack_all_kernel");
   return MFM_OK;
 }
@@ -386,7 +386,7 @@ int proj_bf16_launch(const PanelLaunch& L, const ProjPlan& P, const void* wimg, 
   do {                                                                                                              \
     auto* fn = proj_bf16_kernel<FM_>;                                                                               \
     MFM_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds));    \
-    hipLaunchKernelGGL(fn, grid, block, P.lds, stream, D);                                                          \
+    MFM_LAUNCH_TIMED(fn, grid, block, P.lds, stream, D);                                                          \
   } while (0)
   switch (P.BM) {
     case 160: MFM_PJ_GO(5); break;

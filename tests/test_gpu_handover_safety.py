@@ -20,6 +20,7 @@ import torch
 from factorized_amd import configs as C
 from factorized_amd import synth
 from factorized_amd._lib import MfmError
+from tests import cases
 
 pytestmark = pytest.mark.gpu
 B, T = 32, 20
@@ -371,6 +372,10 @@ def test_cotenant_process_is_survived(tmp_path):
             child.wait(timeout=60)
         except Exception:
             child.kill()
+    # "never fails" and "fails and recovers" must be told apart: the observed count goes on record with every GPU run
+    # (profiles/*parity_worst.jsonl: cotenant_handover_failures, cotenant_steps)
+    cases.report("cotenant_handover_failures", float(e.handover_failures))
+    cases.report("cotenant_steps", 300.0)
     assert raised == e.handover_failures and raised <= 1
     assert np.isfinite(_snap(e)[0]).all()
     # skipped steps aside (at most the ones between a failure and the loss read that reported it), the run followed the
