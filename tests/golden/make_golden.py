@@ -273,7 +273,10 @@ STAGED = [("klef_staged_b32_t20", 32, 20, 4, 4, "kl_ef"), ("kl_staged_b32_t20", 
 # BASELINE config 4 (MOSEI shape, large batch): summaries + loss trace only
 LIGHT = [("klef_mosei_b1024_t20", "kl_ef", C.mosei_configs, {}, 1024, 20, 8),
          # SURVEY section 8d config 4 says T = 50: the same shape at the sequence length the config names (round 5)
-         ("klef_mosei_b256_t50", "kl_ef", C.mosei_configs, {}, 256, 50, 4)]
+         ("klef_mosei_b256_t50", "kl_ef", C.mosei_configs, {}, 256, 50, 4),
+         # BASELINE config 3 (YouTube shape: cross-entropy head, D = 410, T = 50) at a batch where a bf16 plan is bf16-resident
+         # (12,800 rows): the one combination round 5 timed but compared with nothing (round 6)
+         ("klef_you_b256_t50", "kl_ef", C.you_configs, {}, 256, 50, 4)]
 
 
 if __name__ == "__main__":

@@ -553,19 +553,82 @@ def seq_policy(request, monkeypatch):
     return request.param
 
 
-# The tensors whose bf16 gradient error is the largest in every case: the first layer of the z_y -> f_y MLP.  f_y feeds all
-# three decoders and the classifier, so d f_y is a sum of four back-propagated terms of mixed sign (the three reconstruction
-# chains' rounding errors do not cancel the way their values do); measured 3.8e-2 (fp32-stored) / 6.1e-2 (bf16-resident) at
-# B = 229, everything else stays below 2.2e-2.
-NOISY_BF16_TENSORS = ("zy_to_fy_fc1.", "zy_to_fy_fc2.")
+# Per-tensor bounds of the bf16 gradients (round 6; the round-5 review: one `< 8e-2` for every tensor with 6.4e-2 measured).
+#
+# WHY some tensors are noisy.  The discriminative loss seeds d y_hat = +-1/B per row (L1), so the weight gradients of the y path
+# (z_y -> f_y MLP, classifier) are sums over the batch rows of SIGNED terms that cancel: at B = 229 the net gradient of
+# zy_to_fy_fc1 / fc2 is 1/17 / 1/47 of the sum of the rows' norms (~sqrt(B) .. 3 sqrt(B); oracle, per-row autograd).  Rounding the
+# shared operands to bf16 moves every row's term coherently by ~2^-9, and the cancellation amplifies that relative to what is
+# left.  It is a property of the PROBLEM at bf16 operand precision, not of the kernels' accumulation: the fp32 oracle evaluated
+# with nothing but its weights, its batch, the hidden states between LSTM steps and the Linears' outputs rounded to bf16 -- fp32 arithmetic
+# throughout -- is already off by ~6e-2 on zy_to_fy_fc1 at B = 229 (the kernels: 6.4e-2) and by ~1e-2 on everything else
+# (_conditioning below computes exactly that).
+#
+# THE BOUND, per tensor n:   rel_L2(n) <= 2 * cond(n) + 1.5e-2,   cond(n) = that ablation's relative L2 error of tensor n.
+# The factor 2 covers what the ablation leaves out (hidden states, gate gradients and d x_hat rounded at every step); the
+# additive term is the bf16 level of a well-conditioned tensor (measured worst 2.2e-2 against 2 * 0.4e-2 + 1.5e-2).  Measured
+# ratio rel / bound: worst 0.49 (profiles/*parity_worst.jsonl, bf16_grad_bound_ratio_*): a margin of ~2x everywhere, and a tensor
+# that gets worse for a reason other than conditioning shows up against ITS bound instead of hiding under the noisiest one's.
+NOISY_BF16_TENSORS = ("zy_to_fy_fc1.", "zy_to_fy_fc2.")          # (kept for the reports: the two the old common bound was set by)
+
+
+def _conditioning(cfgs, w, x, y, cfg, loss_kind, variant="kl_ef"):
+    """name -> relative L2 distance between the fp32 oracle's gradient and the SAME fp32 computation with weights and batch
+    rounded to bf16 first: how far bf16 operands alone move each tensor."""
+    def grads(rounded):
+        m = O.build(variant, cfgs)
+        ww = {k: (torch.from_numpy(np.asarray(v)).to(torch.bfloat16).float().numpy() if rounded else v) for k, v in w.items()}
+        O.load_numpy_weights(m, ww)
+        m.train()
+        if rounded:
+            # the hidden state of every LSTM step passes through bf16 as well (what a bf16 plan exchanges between steps and, when
+            # bf16-resident, saves): the cast's backward rounds d h the same way
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.LSTMCell):
+                    mod.register_forward_hook(lambda _m, _i, out: (out[0].to(torch.bfloat16).float(), out[1]))
+                elif isinstance(mod, torch.nn.Linear):          # ... and so does every Linear's output (the next product's operand)
+                    mod.register_forward_hook(lambda _m, _i, out: out.to(torch.bfloat16).float())
+        xx = x.to(torch.bfloat16).float() if rounded else x
+        O.loss_terms(m, xx, y, cfg, loss_kind)["loss"].backward()
+        return {n: p.grad.numpy().astype(np.float64).ravel() for n, p in m.named_parameters() if p.grad is not None}
+    g0, g1 = grads(False), grads(True)
+    return {n: float(np.linalg.norm(g1[n] - g0[n]) / max(np.linalg.norm(g0[n]), 1e-30)) for n in g0}, g0
+
+
+def _check_bf16_gradients(gv, ref, cond, tag):
+    """every tensor against ITS bound; returns (worst rel, worst rel of the well-conditioned rest, worst cosine, worst rel / bound)"""
+    worst_g, worst_c, worst_rest, worst_ratio = ("", 0.0), ("", 1.0), ("", 0.0), ("", 0.0)
+    for n, r in ref.items():
+        g = gv[n].cpu().numpy().astype(np.float64).ravel()
+        nr = np.linalg.norm(r)
+        if nr < 1e-9:
+            continue
+        rel = float(np.linalg.norm(g - r) / nr)
+        cos = float(g @ r / (np.linalg.norm(g) * nr + 1e-300))
+        bound = 2.0 * cond[n] + 1.5e-2
+        if rel > worst_g[1]:
+            worst_g = (n, rel)
+        if cos < worst_c[1]:
+            worst_c = (n, cos)
+        if not n.startswith(NOISY_BF16_TENSORS) and rel > worst_rest[1]:
+            worst_rest = (n, rel)
+        if rel / bound > worst_ratio[1]:
+            worst_ratio = (n, rel / bound)
+        assert rel <= bound, (tag, n, rel, bound, cond[n])
+    cases.report("bf16_grad_relL2_%s" % tag, worst_g[1])
+    cases.report("bf16_grad_relL2_rest_%s" % tag, worst_rest[1])
+    cases.report("bf16_grad_one_minus_cos_%s" % tag, 1.0 - worst_c[1])
+    cases.report("bf16_grad_bound_ratio_%s" % tag, worst_ratio[1])
+    assert worst_g[1] < 0.2, worst_g              # (whatever the conditioning says: a gradient 20 % off is not a gradient)
+    return worst_g, worst_rest, worst_c, worst_ratio
 
 
 @pytest.mark.parametrize("name", ["klef_b32_t20", "klef_b33_t7", "klef_b1_t20", "klef_b5_t1", "klef_b229_t20",
                                   "klef_you_b32_t50", "klef_mosei_b64_t20", "klef_odd_b19_t9"])
 def test_bf16_forward_and_gradients_near_fp32_reference(name, seq_policy):
     """bounds (measured worst case in brackets): loss terms within 1e-3 relative of the
-    reference's fp32 golden [7e-5]; parameter gradients within 3e-2 of the oracle's in relative L2 norm, the two z_y -> f_y
-    layers (NOISY_BF16_TENSORS) within 8e-2 [6.1e-2 at B=229, bf16-resident]; cosine > 0.995 [1 - 7.4e-4]."""
+    reference's fp32 golden [7e-5]; every parameter gradient within ITS bound 2 cond(n) + 1.5e-2 of the oracle's in relative L2
+    norm (cond: what bf16 operands alone do to that tensor, see above) [worst rel / bound 0.49]; cosine > 0.995 [1 - 7.4e-4]."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     cs = cases.load_case(name)
@@ -583,32 +646,10 @@ def test_bf16_forward_and_gradients_near_fp32_reference(name, seq_policy):
     assert worst_l < 1e-3, (ld, worst_l)
     assert rel_err(out["y_hat"].cpu().numpy(), gold["y_hat"]) < 5e-2
     assert rel_err(out["x_a_hat"].cpu().numpy(), gold["x_a_hat"]) < 5e-2
-    m = O.build("kl_ef", cs["cfgs"])
-    O.load_numpy_weights(m, w)
-    m.train()
     torch.set_num_threads(4)
-    O.loss_terms(m, x, y, cfg, cs["loss_kind"])["loss"].backward()
+    cond, ref = _conditioning(cs["cfgs"], w, x, y, cfg, cs["loss_kind"])
     e.backward(xd, yd, stage=0)
-    gv = e.grad_views()
-    worst_g, worst_c, worst_rest = ("", 0.0), ("", 1.0), ("", 0.0)
-    for n, p in m.named_parameters():
-        g, r = gv[n].cpu().numpy().astype(np.float64).ravel(), p.grad.numpy().astype(np.float64).ravel()
-        nr = np.linalg.norm(r)
-        if nr < 1e-9:
-            continue
-        rel = np.linalg.norm(g - r) / nr
-        cos = float(g @ r / (np.linalg.norm(g) * nr + 1e-300))
-        if rel > worst_g[1]:
-            worst_g = (n, rel)
-        if cos < worst_c[1]:
-            worst_c = (n, cos)
-        if not n.startswith(NOISY_BF16_TENSORS) and rel > worst_rest[1]:
-            worst_rest = (n, rel)
-    cases.report("bf16_grad_relL2_%s_%s" % (name, seq_policy), worst_g[1])
-    cases.report("bf16_grad_relL2_rest_%s_%s" % (name, seq_policy), worst_rest[1])
-    cases.report("bf16_grad_one_minus_cos_%s_%s" % (name, seq_policy), 1.0 - worst_c[1])
-    assert worst_g[1] < 8e-2, worst_g
-    assert worst_rest[1] < 3e-2, worst_rest
+    worst_g, worst_rest, worst_c, _ = _check_bf16_gradients(e.grad_views(), ref, cond, "%s_%s" % (name, seq_policy))
     assert worst_c[1] > 0.995, worst_c
     # not accidentally the fp32 path
     assert worst_g[1] > 1e-5
@@ -664,7 +705,7 @@ def test_bf16_resident_plan_selection_and_stored_dtypes(monkeypatch):
             assert dec["dxhat"].dtype == torch.bfloat16 and dec["dhs"].dtype == torch.bfloat16
 
 
-@pytest.mark.parametrize("gname", ["klef_mosei_b1024_t20", "klef_mosei_b256_t50"])
+@pytest.mark.parametrize("gname", ["klef_mosei_b1024_t20", "klef_mosei_b256_t50", "klef_you_b256_t50"])
 def test_bf16_large_batch_mosei_loss_curve(gname):
     """BASELINE config 4's shape at a large batch (7 regression outputs; B=1024, T=20 and -- the sequence length the config
     names, SURVEY section 8d -- B=256, T=50): bf16 (bf16-resident plan) and fp32 loss curves against the reference's fp32 trace
@@ -673,9 +714,10 @@ def test_bf16_large_batch_mosei_loss_curve(gname):
         pytest.skip("no GPU")
     gold = np.load(cases.GOLDEN + "/%s.npz" % gname)
     B, T, steps = (int(v) for v in gold["meta"])
-    cfgs = configs.mosei_configs(dropout=False)
+    cfgs = (configs.you_configs if "_you_" in gname else configs.mosei_configs)(dropout=False)      # (round 6: the YouTube shape too)
     cfg = cfgs[0]
-    xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7, output_dim=cfg["output_dim"])
+    xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7, output_dim=cfg["output_dim"],
+                              classes=cfg["output_dim"] if cfg.get("loss", "l1") == "ce" else 0)
     x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
     for prec, bound in (("fp32", 2e-4), ("bf16", 1e-3)):          # measured: bf16 3.2e-5
         from factorized_amd import engine
@@ -693,43 +735,35 @@ def test_bf16_large_batch_mosei_loss_curve(gname):
             assert e.seq_buffers(T, B, 0)["bf16_resident"]
 
 
-def test_bf16_resident_mosei_t50_gradients_against_the_oracle():
-    """MOSEI shape x T=50 x large B on the bf16-RESIDENT path (B=256 >= 192): losses and all 78 gradients of one step against
-    the fp32 CPU oracle on the same batch, at the bf16 bounds of the other bf16 gradient tests (relative L2 per tensor)."""
+@pytest.mark.parametrize("shape", ["mosei", "you"])
+def test_bf16_resident_t50_gradients_against_the_oracle(shape):
+    """T=50 x large B on the bf16-RESIDENT path (B=256: 12,800 rows), MOSEI shape (7 regression outputs) and -- round 6, BASELINE
+    config 3 -- YouTube shape (cross-entropy head, D = 410): losses against the reference's golden (klef_mosei_b256_t50 /
+    klef_you_b256_t50) and the oracle, all 78 gradients of one step against the fp32 CPU oracle on the same batch, every tensor
+    against its own bound (see _conditioning)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from factorized_amd import engine
-    from oracle import mfm_oracle as O
     B, T = 256, 50
-    cfgs = configs.mosei_configs(dropout=False)
+    cfgs = (configs.mosei_configs if shape == "mosei" else configs.you_configs)(dropout=False)
     cfg = cfgs[0]
-    xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7, output_dim=cfg["output_dim"])
+    loss_kind = cfg.get("loss", "l1")
+    gold = np.load(cases.GOLDEN + "/klef_%s_b256_t50.npz" % shape)
+    xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7, output_dim=cfg["output_dim"],
+                              classes=cfg["output_dim"] if loss_kind == "ce" else 0)
     e = engine.MFMEngine(cfgs, precision="bf16")
     w = synth.make_weights(e.layout.shapes, seed=1234)
     e.load_weights(w)
     torch.set_num_threads(8)
-    m = O.build("kl_ef", cfgs)
-    O.load_numpy_weights(m, w)
-    m.train()
-    terms = O.loss_terms(m, torch.from_numpy(xn), torch.from_numpy(yn), cfg)
-    terms["loss"].backward()
+    cond, ref = _conditioning(cfgs, w, torch.from_numpy(xn), torch.from_numpy(yn), cfg, loss_kind)
     x, y = torch.from_numpy(xn).cuda(), torch.from_numpy(yn).cuda()
     out = e.forward(x, y, train=True, want_xhat=False)
     ld = e.loss_dict(out["losses"])
     assert e.seq_buffers(T, B, 0)["bf16_resident"]
     for k in ("disc", "gen", "reg", "loss"):
-        ref = float(terms[k].detach())
-        assert abs(ld[k] - ref) <= 2e-3 * max(abs(ref), 1e-2), (k, ld[k], ref)
+        r = float(gold["fwd_" + k])                     # the REFERENCE's own fp32 value of the same step
+        assert abs(ld[k] - r) <= 2e-3 * max(abs(r), 1e-2), (k, ld[k], r)
     e.backward(x, y, stage=0)
-    gv = e.grad_views()
-    worst = ("", 0.0)
-    for n, p in m.named_parameters():
-        g, r = gv[n].cpu().numpy().astype(np.float64).ravel(), p.grad.numpy().astype(np.float64).ravel()
-        nr = np.linalg.norm(r)
-        if nr < 1e-9:
-            continue
-        rel = np.linalg.norm(g - r) / nr
-        if rel > worst[1]:
-            worst = (n, rel)
-    cases.report("bf16_resident_mosei_b256_t50_grad_relL2", worst[1])
-    assert 1e-5 < worst[1] < 8e-2, worst
+    worst_g, _, _, _ = _check_bf16_gradients(e.grad_views(), ref, cond, "resident_%s_b256_t50" % shape)
+    cases.report("bf16_resident_%s_b256_t50_grad_relL2" % shape, worst_g[1])
+    assert worst_g[1] > 1e-5          # not accidentally the fp32 path

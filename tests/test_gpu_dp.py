@@ -236,7 +236,7 @@ def test_hip_data_parallel_step_mfn_variants(variant, world, fused):
 def test_hip_data_parallel_step_bf16(variant, world, fused):
     """BASELINE config 2 is bf16 data parallel: a bf16 plan through DataParallelStep (reg_scale = W in the plan, P2P
     exchange of the fp32 gradients, grad_scale = 1/W in Adam).  Gates as for every bf16 path: averaged step-0 gradient
-    within 8e-2 relative L2 of the fp32 oracle on the global batch, loss curve within 2e-3, replicas bit-identical."""
+    within 4e-2 relative L2 of the fp32 oracle on the global batch [1.6e-2], loss curve within 2e-3, replicas bit-identical."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     mgr = mp.get_context("spawn").Manager()       # not a fork: the parent holds live GPU state (a GC in a forked child frees it there)
@@ -262,7 +262,7 @@ def test_hip_data_parallel_step_bf16(variant, world, fused):
         if rel > worst[1]:
             worst = (n, rel)
     cases.report("dp_bf16_grad0_relL2_%s_W%d" % (variant, world), worst[1])
-    assert 1e-5 < worst[1] < 8e-2, worst
+    assert 1e-5 < worst[1] < 4e-2, worst          # (measured worst 1.6e-2, B = 64 global: the ill-conditioned tensors of test_gpu_bf16.py need B >= ~200)
 
 
 @pytest.mark.parametrize("n,extra", [(2, []), (8, []), (2, ["--dtype", "bf16"]), (2, ["--model", "mmd"])])

@@ -129,21 +129,24 @@ def test_oracle_staged_training_matches_reference(mode, variant, gname):
     assert np.allclose(np.array(trace), gold[mode + "_trace"], rtol=1e-5, atol=1e-6)
 
 
-def test_oracle_matches_reference_mosei_t50_forward():
-    """BASELINE config 4 at the sequence length it names (MOSEI shape, T=50, B=256; light golden: summaries only): the oracle's
-    loss terms of the first step against the reference's (one forward: the CPU suite stays within minutes)."""
-    gold = np.load(cases.GOLDEN + "/klef_mosei_b256_t50.npz")
+@pytest.mark.parametrize("shape", ["mosei", "you"])
+def test_oracle_matches_reference_t50_forward(shape):
+    """BASELINE configs 4 / 3 at the sequence length they name (MOSEI shape: 7 regression outputs; YouTube shape: cross-entropy
+    head, D = 410; T=50, B=256; light goldens: summaries only): the oracle's loss terms of the first step against the
+    reference's (one forward: the CPU suite stays within minutes)."""
+    gold = np.load(cases.GOLDEN + "/klef_%s_b256_t50.npz" % shape)
     B, T, _ = (int(v) for v in gold["meta"])
     assert (B, T) == (256, 50)
-    cfgs = configs.mosei_configs(dropout=False)
+    cfgs = (configs.mosei_configs if shape == "mosei" else configs.you_configs)(dropout=False)
     cfg = cfgs[0]
     model = O.build("kl_ef", cfgs)
     O.load_numpy_weights(model, synth.make_weights(O.state_shapes(model), seed=1234))
     model.train()
-    xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7, output_dim=cfg["output_dim"])
+    lk = cfg.get("loss", "l1")
+    xn, yn = synth.make_batch(cfg["input_dims"], B, T, seed=7, output_dim=cfg["output_dim"], classes=cfg["output_dim"] if lk == "ce" else 0)
     torch.set_num_threads(4)
     with torch.no_grad():
-        terms = O.loss_terms(model, torch.from_numpy(xn), torch.from_numpy(yn), cfg)
+        terms = O.loss_terms(model, torch.from_numpy(xn), torch.from_numpy(yn), cfg, lk)
     for k in ("disc", "gen", "gen_l", "gen_a", "gen_v", "reg", "loss"):
         ref = float(gold["fwd_" + k])
         assert abs(float(terms[k]) - ref) <= 2e-6 * max(abs(ref), 1.0), (k, float(terms[k]), ref)
