@@ -107,6 +107,11 @@ static bool try_all(const SeqLaunch& L, bool bwd, int total, int threads, size_t
          try_launch4<R, 16, 30, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||      // single-LSTM launches
          try_launch4<R, 16, 26, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||
          try_launch4<R, 16, 8, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||
+         // (round 6: h = 24 / 8 / 80 alone.  scripts/bench_seq_group.py used to time these through the generic 4-row kernel -- the
+         //  "h = 24 costs what h = 104 costs" of the round-5 review was that kernel, not the one-row bodies the plan runs)
+         try_launch4<R, 16, 6, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||
+         try_launch4<R, 16, 2, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||
+         try_launch4<R, 16, 20, 0, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||
          // MFM / MFM_KL on the module path (mfm_model.py::seq_group): encoders 32/8/80 + MFN LSTM 88, MFN 64/48
          try_launch4<R, 16, 8, 2, 20, 22>(L, bwd, total, threads, lds_bytes, stream, err) ||
          try_launch4<R, 16, 16, 12, 0, 0>(L, bwd, total, threads, lds_bytes, stream, err) ||

@@ -878,15 +878,33 @@ __device__ __forceinline__ void small_bwd_body_x(const SeqDev& d, const int T, c
     // whole transposed register layout for this one product costs ~7 us (four staging rounds); instead the
     // 4h rows of W_ih are streamed once with 16-byte loads (thread = 4 consecutive units x one row slice)
     // and the slices are summed through LDS.
+    // (round 6, the launch clock: 4 us between the top of step 0 and the end of this product.)  The W_ih rows do not depend on
+    // step 0: they are requested BEFORE its pointwise part -- the resident transposed weights are dead by now, their registers
+    // take the rows -- and multiplied behind it.
     const int dcur = cur;
-    step(0, false);
-    const float* db = dabuf + dcur * (4 * HKB * R);
     const int h4 = h >> 2;
     const int S = min(min(32, nt / h4), h);         // row slices (S*h partial sums must fit the h*h panel)
     const int u4 = tid % h4, sl = tid / h4;
+    constexpr int NPRE = (4 * HKB + 31) / 32;       // rows per thread at S = 32 (fewer slices: the loop below takes the rest)
+    f32x4 wpre[NPRE];
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int r = min(sl + i * S, 4 * h - 1);
+      wpre[i] = *reinterpret_cast<const f32x4*>(d.w_ih + (int64_t)r * h + 4 * min(u4, h4 - 1));
+    }
+    step(0, false);
+    const float* db = dabuf + dcur * (4 * HKB * R);
     if (sl < S) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int r = sl; r < 4 * h; r += S) {
+#pragma unroll
+      for (int i = 0; i < NPRE; ++i) {
+        const int r = sl + i * S;
+        const int rc = min(r, 4 * h - 1);
+        const int gg = rc / h, j = rc - gg * h;
+        const float a = (r < 4 * h) ? db[gg * HKB + j] : 0.0f;
+        acc += a * wpre[i];
+      }
+      for (int r = sl + NPRE * S; r < 4 * h; r += S) {
         const int gg = r / h, j = r - gg * h;
         const f32x4 w4 = *reinterpret_cast<const f32x4*>(d.w_ih + (int64_t)r * h + 4 * u4);
         acc += db[gg * HKB + j] * w4;
