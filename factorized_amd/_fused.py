@@ -25,6 +25,10 @@ def _owner_of(p):
     return ent[1]()
 
 
+# MFM_MODULE_NO_HANDOVER=1: the module path never uses the in-launch hand-overs (read once: the forward asks on every call)
+_NO_HANDOVER = bool(os.environ.get("MFM_MODULE_NO_HANDOVER"))
+
+
 class _FusedEngineMixin:
     """Gives a model class the `engine` property: an MFMEngine (the one-call fused plan) whose flat parameter buffer
     IS the module's parameter storage -- every nn.Parameter becomes a view into it on first CUDA use, so
@@ -89,7 +93,7 @@ class _FusedEngineMixin:
         g = self._guarded
         if g is not False and g is not True:          # a weak reference to the guard-aware optimizer that owns the parameters:
             g = g() is not None                       # gone (replaced by another optimizer) -> separate launches again
-        return bool(g) and not os.environ.get("MFM_MODULE_NO_HANDOVER")
+        return bool(g) and not _NO_HANDOVER
 
     def _fast_ok(self):
         """The flat-gradient path bypasses autograd for the parameters: every tensor gets a gradient view and the fused optimizer
@@ -387,16 +391,29 @@ def _lazy_backward(step, coef, labels, terms):
     module, eng, plan, x = step.module, step.eng, step.plan, step.x
     T, B, _ = x.shape
     _check_plan_live(plan, eng, step.serial, T, B)
+    # (host time counts: the unchanged loop is host-bound against a 0.15 ms device step -- the mask of a given set of terms and
+    #  the weight struct of a given expression are built once and reused)
     mk = module._group_masks()
-    present = mk["shared"].copy()
-    for k, key in ((1, "l"), (2, "a"), (3, "v"), (0, "disc")):
-        if k in terms:
-            present |= mk[key]
+    tkey = tuple(sorted(terms))
+    present = mk.get(tkey)
+    if present is None:
+        present = mk["shared"].copy()
+        for k, key in ((1, "l"), (2, "a"), (3, "v"), (0, "disc")):
+            if k in terms:
+                present |= mk[key]
+        mk[tkey] = present
     gen_on = any(coef.get(k, 0.0) != 0.0 for k in (1, 2, 3))
-    w = _lib.LossWeights()
-    w.disc = float(coef.get(0, 0.0))
-    w.gen_l, w.gen_a, w.gen_v = step.lda if gen_on else (0.0, 0.0, 0.0)      # (checked equal by LossExpr._fast_backward_ok)
-    w.reg = float(coef.get(4, 0.0))
-    w.write_disc_loss = 1 if labels is not None else 0
+    wkey = (float(coef.get(0, 0.0)), gen_on, float(coef.get(4, 0.0)), labels is not None)
+    cache = module.__dict__.setdefault("_lw_cache", {})
+    w = cache.get(wkey)
+    if w is None:
+        if len(cache) > 16:
+            cache.clear()
+        w = _lib.LossWeights()
+        w.disc = wkey[0]
+        w.gen_l, w.gen_a, w.gen_v = step.lda if gen_on else (0.0, 0.0, 0.0)      # (checked equal by LossExpr._fast_backward_ok)
+        w.reg = wkey[2]
+        w.write_disc_loss = 1 if labels is not None else 0
+        cache[wkey] = w
     plan.ensure_handover(eng.handover and module._handover_ok())
     _into_flat(module, eng, present, lambda out: eng.backward_weighted(x, labels, w, plan, out=out))

@@ -427,10 +427,12 @@ class PlanStep(StepBase):
         self.module, self.eng, self.plan, self.x = module, eng, plan, x
         self.serial = plan.fwd_serial
         self.x_version = x._version
-        self.dims = tuple(eng.cfg["input_dims"])
-        c = eng.cfg
-        self.lda = (float(c["lda_xl"]), float(c["lda_xa"]), float(c["lda_xv"]))
-        self.loss_kind = 1 if c.get("loss", "l1") == "ce" else 0
+        st = plan.__dict__.get("_lazy_static")
+        if st is None:               # (per plan, not per step)
+            c = eng.cfg
+            st = plan._lazy_static = (tuple(c["input_dims"]), (float(c["lda_xl"]), float(c["lda_xa"]), float(c["lda_xv"])),
+                                      1 if c.get("loss", "l1") == "ce" else 0)
+        self.dims, self.lda, self.loss_kind = st
         self.views = plan.out_views
         self.scalar_view = plan.loss0d
 
