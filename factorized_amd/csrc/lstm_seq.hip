@@ -453,7 +453,7 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
   L.bf16_dot = 1;
   for (int i = 0; i < count; ++i) L.bf16_dot &= (descs[i].bf16_dot != 0);
   if (fold && fold->img_written) *fold->img_written = false;
-  if (fold && fold->img_items && !bwd && !bf16 && !sorted && !nwide && fold->n_img_items <= MFM_WT_MAX && use_small_path(B)) {
+  if (fold && fold->img_items && !bwd && !bf16 && !sorted && !nwide && fold->n_img_items <= MFM_IMG_MAX && use_small_path(B)) {
     L.n_img = fold->n_img_items;
     for (int i = 0; i < L.n_img; ++i) L.img[i] = fold->img_items[i];
   }

@@ -24,23 +24,26 @@ struct SeqDev {
 // the decoders' steps >= 1), zero outside the valid units.  Written by workgroups that have nothing else to do in a FORWARD
 // launch of the step -- the projection role workgroups once their items are done (proj_role_dev.h), or a few blocks appended to
 // the recurrence launch -- and read by the BPTT launches, which come later in the stream: nothing has to be signalled.
-struct WtImgItem { const float* w_hh; const float* w_ih; float* img; int h, HKB; };
+struct WtImgItem { const float* w_hh; const float* w_ih; float* img; int h, HKB; int fwd; };     // fwd: a forward-order image (below)
 constexpr int MFM_WT_MAX = MFM_MAX_SEQ + 3;
+constexpr int MFM_IMG_MAX = MFM_WT_MAX + 6;      // + the decoders' forward-order images (W_ih, W_ih + W_hh)
 struct SeqLaunch {
   SeqDev d[MFM_MAX_SEQ];
   int count, T, B;
   // forward launches, optional: blocks [img_begin, img_begin + n_img_blocks) write the images of `img` and leave
   int n_img, img_begin, n_img_blocks;
-  WtImgItem img[MFM_WT_MAX];
+  WtImgItem img[MFM_IMG_MAX];
   int bf16_dot;            // one-row forward kernels: recurrent product on bf16 dot products (MfmSeqDesc::bf16_dot on every LSTM)
 };
 
-// writer r of nr (any block size)
+__device__ __forceinline__ void wf_img_write(const WtImgItem* items, const int n, const int r, const int nr);
+// writer r of nr (any block size); items marked `fwd` are written in the forward's register order (wf_img_write)
 __device__ __forceinline__ void wt_img_write(const WtImgItem* items, const int n, const int r, const int nr) {
   const int tid = threadIdx.x, nt = blockDim.x;
 #pragma unroll 1
   for (int w = 0; w < n; ++w) {
     const WtImgItem& I = items[w];
+    if (I.fwd) { wf_img_write(&I, 1, r, nr); continue; }
     const int NG = I.HKB >> 4, NTH = 8 * I.HKB, h = I.h;
     const int total = 8 * NG * NTH;
     for (int idx = r * nt + tid; idx < total; idx += nr * nt) {

@@ -467,7 +467,7 @@ int build(MfmPlan* P) {
       if (hh > MFM_SEQ_MAX_RESIDENT_H) continue;
       const int64_t HKB = round_up(4 * round_up(cdiv(hh, 4), 2), 16);
       P->wt_img[i] = carve(cur, 4 * HKB * HKB);
-      if (i >= P->n_enc && V == 0 && (hh & 3) == 0) { P->wf_img[i - P->n_enc] = carve(cur, 4 * HKB * HKB); P->wf_img[3 + i - P->n_enc] = carve(cur, 4 * HKB * HKB); }
+      if (i >= P->n_enc && (hh & 3) == 0) { P->wf_img[i - P->n_enc] = carve(cur, 4 * HKB * HKB); P->wf_img[3 + i - P->n_enc] = carve(cur, 4 * HKB * HKB); }
     }
   }
   if (V == 0 && c.B <= DWR_ROWS) {

@@ -205,8 +205,8 @@ int forward(MfmPlan* P, const float* params, const float* x, const void* y, int 
   if (!proj_in_fold) { const int rc0 = run_f0(); if (rc0 != MFM_OK) return rc0; }
   // training steps: this step's transposed-weight images for the one-row BPTT kernels (lstm_seq_dev.h), written by idle
   // workgroups of the encoder recurrence launch
-  WtImgItem wt_items[MFM_WT_MAX];
-  int n_wt_items = 0;
+  WtImgItem wt_items[MFM_IMG_MAX];
+  int n_wt_items = 0, n_wf_items = 0;
   if (train && !seq_bf16 && !(opt_get("MFM_WT_IMG") && atoi(opt_get("MFM_WT_IMG")) == 0)) {
     bool all = true;
     for (int i = 0; i < P->n_enc + 3; ++i) all = all && P->wt_img[i] >= 0;
@@ -221,6 +221,23 @@ int forward(MfmPlan* P, const float* params, const float* x, const void* y, int 
         I.w_ih = dec ? params + P->off[pb + W_IH] : nullptr;       // decoders, steps >= 1: W_ih + W_hh (mfm_model.py:85)
         I.img = W + P->wt_img[i]; I.h = sb.h;
         I.HKB = round_up(4 * round_up(cdiv(sb.h, 4), 2), 16);
+        I.fwd = 0;
+      }
+      // launches without projection role workgroups (MFM_KL / MFM, B > 32): the decoders' forward-order images (lstm_seq_dev.h)
+      // ride on the same image-writer blocks, behind the transposed ones
+      if (T >= 2 && !(opt_get("MFM_WF_IMG") && atoi(opt_get("MFM_WF_IMG")) == 0) && (long)3 * B < 6L * device_cus()) {
+        bool ok = true;
+        for (int k = 0; k < 6; ++k) ok = ok && P->wf_img[k] >= 0;
+        for (int k = 0; k < 6 && ok; ++k) {
+          const int m = k % 3;
+          const bool sum = k >= 3;
+          WtImgItem& I = wt_items[n_wt_items + n_wf_items++];
+          const int pb = P->dec_p[m];
+          I.w_hh = sum ? params + P->off[pb + W_HH] : nullptr; I.w_ih = params + P->off[pb + W_IH];
+          I.img = W + P->wf_img[sum ? m : 3 + m]; I.h = P->dec[m].h;
+          I.HKB = round_up(4 * round_up(cdiv(P->dec[m].h, 4), 2), 16);
+          I.fwd = 1;
+        }
       }
     }
   }
@@ -298,9 +315,9 @@ int forward(MfmPlan* P, const float* params, const float* x, const void* y, int 
     for (int e = 0; e < 4; ++e) q[e] = seq_desc(P, P->enc[e], P->enc_p[e], params, W, false);
     int rc;
     bool wrote = false;
-    if (P->fold_state == 1) { Timer _t(P, s, K_ENC_FWD); rc = seq_fold_launch(q, 4, T, B, false, L, params, nullptr, s, nullptr, n_wt_items ? wt_items : nullptr, n_wt_items, &wrote); }
-    else rc = seq_fold_launch(q, 4, T, B, false, L, params, nullptr, s, nullptr, n_wt_items ? wt_items : nullptr, n_wt_items, &wrote);
-    if (rc == MFM_OK) { folded = true; P->fold_state = 1; if (wrote) P->wt_call = P->calls; }
+    if (P->fold_state == 1) { Timer _t(P, s, K_ENC_FWD); rc = seq_fold_launch(q, 4, T, B, false, L, params, nullptr, s, nullptr, n_wt_items ? wt_items : nullptr, n_wt_items + n_wf_items, &wrote); }
+    else rc = seq_fold_launch(q, 4, T, B, false, L, params, nullptr, s, nullptr, n_wt_items ? wt_items : nullptr, n_wt_items + n_wf_items, &wrote);
+    if (rc == MFM_OK) { folded = true; P->fold_state = 1; if (wrote) { P->wt_call = P->calls; if (n_wf_items == 6) P->wf_call = P->calls; } }
     else if (rc == MFM_ERR_UNSUPPORTED) P->fold_state = (P->fold_state == 0) ? -1 : P->fold_state;
     else return rc;
   }
@@ -313,8 +330,8 @@ int forward(MfmPlan* P, const float* params, const float* x, const void* y, int 
     }
     if (!seq_bf16 && n_wt_items && e0 == 0 && n == P->n_enc) {
       bool wrote = false;
-      RUN(K_ENC_FWD, seq_fwd_img_launch(q, n, T, B, wt_items, n_wt_items, &wrote, s));
-      if (wrote) P->wt_call = P->calls;
+      RUN(K_ENC_FWD, seq_fwd_img_launch(q, n, T, B, wt_items, n_wt_items + n_wf_items, &wrote, s));
+      if (wrote) { P->wt_call = P->calls; if (n_wf_items == 6) P->wf_call = P->calls; }
     } else RUN(K_ENC_FWD, seq_bf16 ? mfm_lstm_seq_fwd_bf16(q, n, T, B, s) : mfm_lstm_seq_fwd(q, n, T, B, s));
   }
   if (V != 0) {
