@@ -468,13 +468,6 @@ int seq_small_foldproj_launch(SeqLaunch& L, const LatentDev& LD, ProjRole& PR, c
     if (direct && side <= 160 * 1024) { PR.lat_pre = 1; lds_bytes = std::max(side, role); }
   }
   if (lds_bytes > 160 * 1024) return MFM_ERR_UNSUPPORTED;
-  PR.n_warm = 0;
-  if (!(opt_get("MFM_LATENT_WARM") && atoi(opt_get("MFM_LATENT_WARM")) == 0)) {
-    for (int s = 0; s < LD.nstages && s < 8; ++s) {
-      if (LD.span_len[s] < 4 || (((uintptr_t)(params + LD.span_off[s])) & 15) != 0) continue;
-      PR.warm[PR.n_warm] = params + LD.span_off[s]; PR.warm_n4[PR.n_warm] = LD.span_len[s] >> 2; ++PR.n_warm;
-    }
-  }
   MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_foldproj_kernel<8, 2, 20, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   MFM_LAUNCH_TIMED((lstm_seq_small_foldproj_kernel<8, 2, 20, 30>), dim3(total), dim3(1024), lds_bytes, stream, L, LD, PR, params);
   MFM_LAUNCH_CHECK("lstm_seq_small_foldproj_kernel");

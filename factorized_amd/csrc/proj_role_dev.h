@@ -58,10 +58,6 @@ struct ProjRole {
   HoCtl ctl;                              // consumer side: time-out, status word, poison
   int fault;                              // fault injection (tests): role workgroup 0 does not raise its first flag
   int lat_pre;                            // the rows' latent chains preload their tables in front of the time loop (lstm_seq_small.hip)
-  // L2 warm-up (round 6): once a role workgroup has nothing left to do it reads its share of the latent stack's parameter spans,
-  // so that the rows' chains at the end of this launch find their weights in their XCD's L2 (Adam rewrote them a step ago: a
-  // chain stage cost the ~1 us a miss takes, six times in a row on the launch's critical path).  Pure hint: values are dropped.
-  const float* warm[8]; int warm_n4[8]; int n_warm;
   float* loss_ptr; int loss_n;            // loss slots: cleared with agent-scope stores before any flag of t = 0 is raised
   int bf16;                               // bf16 plans: x and W_ih rounded to bf16 (RNE) on the way into LDS, fp32 accumulation
   ProjRoleEnc e[4];
@@ -233,18 +229,6 @@ __device__ __forceinline__ void proj_role_body(const SeqLaunch& L, const ProjRol
     f32x4* p = reinterpret_cast<f32x4*>(PR.zs.ptr[s]);
     const int64_t n4 = PR.zs.n[s] >> 2;
     for (int64_t i = (int64_t)r * 1024 + tid; i < n4; i += (int64_t)PR.n_role * 1024) p[i] = z4;
-  }
-  // L2 warm-up: workgroups are dealt to the 8 XCDs round robin, so role workgroup r shares an L2 with the role workgroups
-  // r % 8 + 8 j -- the j-th of them takes every (n_role / 8)-th 16 KB piece of the spans (a wrong guess only loses the hint)
-  if (PR.n_warm > 0) {
-    const int nx = max(PR.n_role >> 3, 1), jx = (r >> 3) % nx;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int s = 0; s < PR.n_warm; ++s) {
-      const f32x4* p = reinterpret_cast<const f32x4*>(PR.warm[s]);
-      for (int i = jx * 1024 + tid; i < PR.warm_n4[s]; i += nx * 1024) acc += p[i];
-    }
-    asm volatile("" ::"v"(acc));
   }
 }
 

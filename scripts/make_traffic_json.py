@@ -18,6 +18,23 @@ GEMM_ORDER = {4: ["proj_gemm", "fc1_mse_gemm", "fc1_bwd_gemm", "dw_gemm"], 2: ["
 
 
 def classify(name):
+    # bf16 plans at large batches (bf16 MFMA recurrences, bf16-resident activations; keys = the plan's timer names, bench.py's `dom`)
+    if "lstm_seq_bf16_kernel<false, 0" in name:
+        return "enc_seq_fwd"
+    if "lstm_seq_bf16_kernel<true, 0" in name:
+        return "enc_seq_bwd"
+    if "lstm_seq_bf16_kernel<false, 1" in name:
+        return "dec_seq_fwd"
+    if "lstm_seq_bf16_kernel<true, 1" in name:
+        return "dec_seq_bwd"
+    if "dw_stream_mixed_kernel" in name or "dw_stream_kernel" in name or "dw_reduce_kernel" in name:
+        return "lstm_dw_stream"        # (two launches per step under one timer id: their bytes are summed)
+    if "proj_bf16_kernel" in name:
+        return "proj_gemm"
+    if "dec_fc1_large" in name:
+        return "fc1_mse_gemm"
+    if "pack_all_kernel" in name:
+        return "bf16_weight_pack"
     if "lstm_seq_small_foldproj_kernel" in name:        # ... with the projection role workgroups in front (B <= 32)
         return "enc_seq_fwd"
     if "lstm_seq_small_folddw_kernel" in name:          # ... with the weight-gradient role workgroups behind (B <= 32)
@@ -73,17 +90,19 @@ def per_kernel(path, counter):
         step.append((k, value))
         if k == "adam":
             flush()
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+    nsteps = max(len(acc.get("adam", [])), 1)
+    # (a key that several launches of a step share -- lstm_dw_stream -- is summed per step; everything else occurs once)
+    return {k: sum(v) / (nsteps if k == "lstm_dw_stream" else len(v)) for k, v in acc.items()}
 
 
-def main(fetch_db, write_db):
+def main(fetch_db, write_db, workload="mosi B=32 T=20"):
     rd = per_kernel(fetch_db, "FETCH_SIZE")
     wr = per_kernel(write_db, "WRITE_SIZE")
     out = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes of "
                        "bench.py, B=32 T=20; scripts/profile_round.sh + scripts/make_traffic_json.py); read = 2 x "
                        "FETCH_SIZE KiB (gfx950 correction, MI355X_MICROARCH.md section HBM), write = WRITE_SIZE KiB "
                        "(uncalibrated)",
-           "workload": "mosi B=32 T=20"}
+           "workload": workload}
     for k in sorted(set(rd) | set(wr)):
         r = int(round(2.0 * rd.get(k, 0.0) * 1024))
         w = int(round(wr.get(k, 0.0) * 1024))
@@ -93,4 +112,4 @@ def main(fetch_db, write_db):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], *(sys.argv[3:4]))
