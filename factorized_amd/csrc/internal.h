@@ -255,6 +255,7 @@ struct LatentDev {
   float* disc_loss_out;   // backward, optional: the discriminative loss value (L1 / CE mean) is ADDED here (the loss-weighted
                           // backward of the module path: the forward ran without labels, its slot 0 is still zero)
   int grd_agent;          // grd_out leaves with agent-scope stores (read inside the same launch, dw_role_dev.h)
+  int64_t n_params;       // floats in the parameter buffer (row path: the weight requests are buffer loads that drop what lies outside)
   int bias_tab, bias_n;   // row path: the last stage slot of the backward item table lists every thread's bias-gradient element
                           // (bias_n: the largest number of entries a workgroup kind has; it must not exceed the block size)
 };

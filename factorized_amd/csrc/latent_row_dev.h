@@ -166,12 +166,19 @@ __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const fl
   const int q = tid & 3;
   const int wave0 = tid & ~63;
   struct Slot { f32x4 w[8]; float bias; i32x4 e; };
+  // (round 6) The weight requests are buffer loads: a k-block beyond the layer's K is asked for at an offset outside the
+  // parameter buffer -- it still counts as one of the stage's eight requests (the counted waits stay exact) but returns zeros
+  // without touching the cache.  Clamped re-reads of the last block used to occupy the CU's address path like real ones: a stage
+  // whose layers have K = 32 issued four times the requests it needed, and the request issue is most of a stage.
+  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)params, 0, (int)min((int64_t)0x7fffffff, L.n_params * 4), 0x00020000);
   auto fetch = [&](int s, Slot& t) {          // weights + bias of this thread's item in stage s
     t.e = tab[s * MFM_LAT_ROW_THREADS + tid];
     const int K = (t.e[2] >> 16) & 0xFF;
-    const float* wr = params + (unsigned)t.e[0];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t.w[j] = *reinterpret_cast<const f32x4*>(wr + min(4 * q + 16 * j, K - 4));
+    for (int j = 0; j < 8; ++j) {
+      const int k0 = 4 * q + 16 * j;
+      t.w[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, k0 < K ? (int)(((unsigned)t.e[0] + k0) * 4u) : 0x7FFFFFF0, 0, 0));
+    }
     t.bias = params[(unsigned)t.e[1]];
   };
   mark(L, 0);
@@ -350,9 +357,28 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
   // trips (one per `if (ptr) sum += ptr[...]`) in front of the stage walk, on the critical path of the fold launches.
   // Unconditional uses (LAT_KEEP) keep the compiler from sinking the loads back into the branches that consume them.
 #define LAT_KEEP(x) asm volatile("" : "+v"(x))
+  // Descriptor fields of the seed section are fetched NOW and pinned in scalar registers (round 6; the launch clock: 3.0 us
+  // between "tables in LDS" and "seeds done" for a few hundred instructions -- every first touch of a kernel-argument line read
+  // where it is used is a scalar-cache miss in front of the stage walk; the forward body has done the same since round 2).
+#define PIN_S(x) asm volatile("" : "+s"(x))
+  int s_fn[4], s_fo[4], s_mu[4], s_lv[4], s_zn[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    s_fn[m] = L.f_n[m]; s_fo[m] = L.f_off[m]; s_mu[m] = L.mu_off[m]; s_lv[m] = L.lv_off[m]; s_zn[m] = L.z_n[m];
+    PIN_S(s_fn[m]); PIN_S(s_fo[m]); PIN_S(s_mu[m]); PIN_S(s_lv[m]); PIN_S(s_zn[m]);
+  }
+  int s_yoff = L.yhat_off, s_od = L.od, s_B = L.B, s_kind = L.loss_kind, s_haslv = L.has_logvar;
+  float s_genw = L.gen_w, s_discw = L.disc_w, s_regw = L.reg_w;
+  PIN_S(s_yoff); PIN_S(s_od); PIN_S(s_B); PIN_S(s_kind); PIN_S(s_haslv); PIN_S(s_genw); PIN_S(s_discw); PIN_S(s_regw);
+  const float* s_ddi[3]; int64_t s_dld[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) { s_ddi[m] = L.d_dec_init[m]; s_dld[m] = L.dec_ld[m]; PIN_S(s_ddi[m]); PIN_S(s_dld[m]); }
+  const void* s_y = L.y; const float* s_dyext = L.d_yhat_ext; float* s_dlo = L.disc_loss_out; const float* s_rwp = L.reg_w_ptr;
+  PIN_S(s_y); PIN_S(s_dyext); PIN_S(s_dlo); PIN_S(s_rwp);
+#undef PIN_S
   // (every load is unconditional -- an absent operand reads params[0] instead: a branch around a load makes the compiler wait
   //  for everything requested before it)
-  const int fy_ = L.f_n[3];
+  const int fy_ = s_fn[3];
   float pre_fy[3], pre_fm[3], pre_y;
   long long pre_lab;
   {
@@ -416,12 +442,16 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
   const int l = tid & 15;
   const int wave0 = tid & ~63;
   struct Slot { f32x4 w[8]; i32x4 e; };
+  // (rows beyond the layer's N: requested outside the parameter buffer -- zeros, no cache access; see the forward)
+  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)params, 0, (int)min((int64_t)0x7fffffff, L.n_params * 4), 0x00020000);
   auto fetch = [&](int s, Slot& t) {
     t.e = tab[s * MFM_LAT_ROW_THREADS + tid];
     const int K = t.e[1] & 0xFF, N = (t.e[1] >> 8) & 0xFF;
-    const float* wr = params + (unsigned)t.e[0];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t.w[j] = *reinterpret_cast<const f32x4*>(wr + min(l + 16 * j, N - 1) * K);
+    for (int j = 0; j < 8; ++j) {
+      const int n = l + 16 * j;
+      t.w[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, n < N ? (int)(((unsigned)t.e[0] + n * K) * 4u) : 0x7FFFFFF0, 0, 0));
+    }
   };
   Slot sa, sb, sl[PRE ? LAT_PRE_SLOTS : 1];
   // PRE: walk position p = 0 .. 5 is stage nstages-1-p; slot p % 4; the first four positions are requested here
@@ -434,62 +464,66 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
   // ---- seeds
   float dl = 0.0f;                  // this row's share of the discriminative loss (disc_loss_out)
   // (the element a thread's first pass needs is already in pre_*; later passes -- od / f sizes beyond the block -- load)
-  if (L.d_yhat_ext) {
-    for (int o = tid; o < L.od; o += nt) grd[L.yhat_off + o] = (o == tid) ? pre_y : L.d_yhat_ext[(int64_t)row * L.od + o];
-  } else if (L.y && (L.disc_w != 0.0f || L.disc_loss_out)) {
-    if (L.loss_kind == 0) {
-      const float* y = reinterpret_cast<const float*>(L.y);
-      const float inv = 1.0f / ((float)L.B * (float)L.od);
-      const float sc = L.disc_w * inv;
-      for (int o = tid; o < L.od; o += nt) {
-        const float df = rec[L.yhat_off + o] - ((o == tid) ? pre_y : y[(int64_t)row * L.od + o]);
-        grd[L.yhat_off + o] = (df > 0.0f) ? sc : ((df < 0.0f) ? -sc : 0.0f);
+  if (s_dyext) {
+    for (int o = tid; o < s_od; o += nt) grd[s_yoff + o] = (o == tid) ? pre_y : s_dyext[(int64_t)row * s_od + o];
+  } else if (s_y && (s_discw != 0.0f || s_dlo)) {
+    if (s_kind == 0) {
+      const float* y = reinterpret_cast<const float*>(s_y);
+      const float inv = 1.0f / ((float)s_B * (float)s_od);
+      const float sc = s_discw * inv;
+      for (int o = tid; o < s_od; o += nt) {
+        const float df = rec[s_yoff + o] - ((o == tid) ? pre_y : y[(int64_t)row * s_od + o]);
+        grd[s_yoff + o] = (df > 0.0f) ? sc : ((df < 0.0f) ? -sc : 0.0f);
         dl += fabsf(df) * inv;
       }
     } else if (tid == 0) {
-      const float sc = L.disc_w / (float)L.B;
-      const float* z = rec + L.yhat_off;
+      const float sc = s_discw / (float)s_B;
+      const float* z = rec + s_yoff;
       float mx = z[0];
-      for (int o = 1; o < L.od; ++o) mx = fmaxf(mx, z[o]);
+      for (int o = 1; o < s_od; ++o) mx = fmaxf(mx, z[o]);
       float se = 0.0f;
-      for (int o = 0; o < L.od; ++o) se += expf(z[o] - mx);
+      for (int o = 0; o < s_od; ++o) se += expf(z[o] - mx);
       const int lab = (int)pre_lab;
-      for (int o = 0; o < L.od; ++o) grd[L.yhat_off + o] = sc * (expf(z[o] - mx) / se - (o == lab ? 1.0f : 0.0f));
-      dl = ((logf(se) + mx) - z[lab]) / (float)L.B;
+      for (int o = 0; o < s_od; ++o) grd[s_yoff + o] = sc * (expf(z[o] - mx) / se - (o == lab ? 1.0f : 0.0f));
+      dl = ((logf(se) + mx) - z[lab]) / (float)s_B;
     }
     // (od <= 128: only the first two waves hold a share; the chain workgroups of a row all seed y_hat, one of them reports)
-    if (L.disc_loss_out && (all || ch == 3) && tid < 128) {
+    if (s_dlo && (all || ch == 3) && tid < 128) {
       dl = wave_sum_dpp(dl);
-      if ((tid & 63) == 0 && dl != 0.0f) atomicAdd(L.disc_loss_out, dl);
+      if ((tid & 63) == 0 && dl != 0.0f) atomicAdd(s_dlo, dl);
     }
   }
-  if (L.gen_w != 0.0f) {
-    const int fy = L.f_n[3];
+  if (s_genw != 0.0f) {
+    const int fy = s_fn[3];
     for (int j = tid; j < fy; j += nt) {
       float sm = 0.0f;
+#pragma unroll
       for (int m = 0; m < 3; ++m)
-        if (L.d_dec_init[m]) sm += (j == tid) ? pre_fy[m] : L.d_dec_init[m][(int64_t)row * L.dec_ld[m] + j];
-      grd[L.f_off[3] + j] = sm;
+        if (s_ddi[m]) sm += (j == tid) ? pre_fy[m] : s_ddi[m][(int64_t)row * s_dld[m] + j];
+      grd[s_fo[3] + j] = sm;
     }
+#pragma unroll
     for (int m = 0; m < 3; ++m) {
-      if (!L.d_dec_init[m]) continue;
-      for (int j = tid; j < L.f_n[m]; j += nt)
-        grd[L.f_off[m] + j] = (j == tid) ? pre_fm[m] : L.d_dec_init[m][(int64_t)row * L.dec_ld[m] + fy + j];
+      if (!s_ddi[m]) continue;
+      for (int j = tid; j < s_fn[m]; j += nt)
+        grd[s_fo[m] + j] = (j == tid) ? pre_fm[m] : s_ddi[m][(int64_t)row * s_dld[m] + fy + j];
     }
     // the f segments come out of a relu layer (z -> f, second Linear): the record holds gradients wrt
     // PRE-activations throughout (what the bias / weight gradients need), so the seeds are masked here and
     // every later contribution is masked where it is accumulated (stage loop)
+#pragma unroll
     for (int m = 0; m < 4; ++m)
-      for (int j = tid; j < L.f_n[m]; j += nt)
-        if (!(rec[L.f_off[m] + j] > 0.0f)) grd[L.f_off[m] + j] = 0.0f;
+      for (int j = tid; j < s_fn[m]; j += nt)
+        if (!(rec[s_fo[m] + j] > 0.0f)) grd[s_fo[m] + j] = 0.0f;
   }
-  const float reg_w = L.reg_w_ptr ? *L.reg_w_ptr : L.reg_w;
-  if (L.has_logvar && (L.reg_w_ptr || reg_w != 0.0f)) {
+  const float reg_w = s_rwp ? *s_rwp : s_regw;
+  if (s_haslv && (s_rwp || reg_w != 0.0f)) {
+#pragma unroll
     for (int m = 0; m < 4; ++m)
-      for (int j = tid; j < L.z_n[m]; j += nt) {
-        const float mu = rec[L.mu_off[m] + j], lv = rec[L.lv_off[m] + j];
-        grd[L.mu_off[m] + j] = reg_w * mu;
-        grd[L.lv_off[m] + j] = reg_w * (-0.5f) * (1.0f - expf(lv));
+      for (int j = tid; j < s_zn[m]; j += nt) {
+        const float mu = rec[s_mu[m] + j], lv = rec[s_lv[m] + j];
+        grd[s_mu[m] + j] = reg_w * mu;
+        grd[s_lv[m] + j] = reg_w * (-0.5f) * (1.0f - expf(lv));
       }
   }
   lds_barrier();

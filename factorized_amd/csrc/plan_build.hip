@@ -318,7 +318,7 @@ int build(MfmPlan* P) {
   // Latency path (latent.hip, row kernels): one row per workgroup while that still fits the chip in one
   // wave of workgroups and every layer meets the vector-load shape requirements.
   {
-    bool ok = c.B <= lat_row_maxb && !split0 && (size_t)2 * rs * sizeof(float) <= 24 * 1024 && P->n_params < (1ll << 31);
+    bool ok = c.B <= lat_row_maxb && !split0 && (size_t)2 * rs * sizeof(float) <= 24 * 1024 && P->n_params < (1ll << 29);      // (byte offsets of the buffer loads: 32 bits)
     ok = ok && (in_n[0] + in_n[1] + in_n[2] + in_n[3] <= MFM_LAT_ROW_THREADS);     // prologue: one input element per thread
     for (int i = 0; i < L.nops && ok; ++i) {
       const LatOp& op = P->lat_ops[i];
@@ -407,6 +407,7 @@ int build(MfmPlan* P) {
     // bias gradients (round 6): thread t of a chain workgroup adds ONE element -- x = its offset in the gradient buffer (-1: none),
     // y = its place in the gradient record -- tabulated in the LAST stage slot of the backward table (free while nstages < 8)
     // instead of a search through the op table per element at the end of the backward chain
+    L.n_params = P->n_params;
     L.bias_tab = 0;
     if (L.nstages < MFM_LAT_MAXSTAGES) {
       bool fits = true;
