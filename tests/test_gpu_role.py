@@ -217,3 +217,31 @@ def test_shared_device_switch_restores_separate_launches(monkeypatch):
     e.set_timing(T, B, 0)
     launches = {k: v["count"] for k, v in tab.items() if v["count"]}
     assert launches.get("proj_gemm", 0) == 2 and launches.get("dw_gemm", 0) == 2, launches
+
+
+@pytest.mark.parametrize("switch", ["MFM_WF_IMG", "MFM_LATENT_PRELOAD", "MFM_LATENT_SPLIT"])
+@pytest.mark.parametrize("B,T", [(32, 20), (7, 3), (19, 21), (1, 2), (48, 5)])
+def test_round6_forms_equal_the_forms_they_replaced(monkeypatch, switch, B, T):
+    """Round 6 changed three things inside the small-batch launches, each with a switch that restores the previous form: the
+    decoders' weights from forward-order images (MFM_WF_IMG=0: strided gathers + add), the latent forward chain's tables
+    preloaded in front of the time loop with h_T taken from LDS (MFM_LATENT_PRELOAD=0: loaded behind the last step, h_T read back
+    from memory), the latent backward chain handing d h_T over through LDS with its stores behind the BPTT's weight requests
+    (MFM_LATENT_SPLIT=0: stores first, d h_T from memory).  Same arithmetic in the same order: losses identical, gradients equal
+    to rounding order of the atomic sums, both forms within 1e-4 of the CPU oracle."""
+    cfgs = C.canonical_configs(dropout=False)
+    monkeypatch.delenv(switch, raising=False)
+    _, w, xn, yn, ld1, g1 = _grads(cfgs, B, T)
+    monkeypatch.setenv(switch, "0")
+    _, _, _, _, ld0, g0 = _grads(cfgs, B, T)
+    monkeypatch.delenv(switch, raising=False)
+    for k in ("disc", "gen", "reg", "loss"):
+        assert abs(ld1[k] - ld0[k]) <= 1e-6 * max(abs(ld0[k]), 1.0), (k, ld1[k], ld0[k])
+    m = O.build("kl_ef", cfgs)
+    O.load_numpy_weights(m, w)
+    m.train()
+    O.loss_terms(m, torch.from_numpy(xn), torch.from_numpy(yn), cfgs[0])["loss"].backward()
+    for n, p in m.named_parameters():
+        r = p.grad.numpy()
+        assert grad_err(g1[n], r) < TOL, (switch, "new form", n)
+        assert grad_err(g0[n], r) < TOL, (switch, "old form", n)
+        assert grad_err(g1[n], g0[n]) < 1e-5, (switch, "new vs old", n)
