@@ -263,7 +263,7 @@ def main():
         work = e.work_per_step(T, B)
         peak = FP32_MATRIX_PEAK_TFLOPS if args.dtype == "fp32" else BF16_MATRIX_PEAK_TFLOPS
         # HBM bytes per launch of the dominant kernel: measured in a SEPARATE rocprofv3 --pmc pass of this
-        # command (scripts/profile_round.sh -> profiles/r01_traffic.json); only valid for the workload it
+        # command (scripts/profile_round6.sh -> profiles/r06_traffic_B*.json); only valid for the workload it
         # was measured on, otherwise null.
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r06_traffic_B%d%s.json" % (B, "" if args.dtype == "fp32" else "_bf16"))

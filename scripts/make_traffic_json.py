@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """HBM bytes per launch of every kernel of the fused step, from two rocprofv3 --pmc passes of bench.py
-(FETCH_SIZE and WRITE_SIZE, collected separately: scripts/profile_round.sh).
+(FETCH_SIZE and WRITE_SIZE, collected separately: scripts/profile_round6.sh).
 
 Usage: scripts/make_traffic_json.py pmc_fetch_results.db pmc_write_results.db > profiles/r01_traffic.json
 
@@ -99,7 +99,7 @@ def main(fetch_db, write_db, workload="mosi B=32 T=20"):
     rd = per_kernel(fetch_db, "FETCH_SIZE")
     wr = per_kernel(write_db, "WRITE_SIZE")
     out = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes of "
-                       "bench.py, B=32 T=20; scripts/profile_round.sh + scripts/make_traffic_json.py); read = 2 x "
+                       "bench.py, B=32 T=20; scripts/profile_round6.sh + scripts/make_traffic_json.py); read = 2 x "
                        "FETCH_SIZE KiB (gfx950 correction, MI355X_MICROARCH.md section HBM), write = WRITE_SIZE KiB "
                        "(uncalibrated)",
            "workload": workload}

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel roofline table from one profile round (scripts/profile_round.sh):
+"""Per-kernel roofline table from one profile round (scripts/profile_round6.sh):
   kernel-trace db  -> average duration per launch
   pmc_fetch/write  -> HBM bytes per launch (read = 2 x FETCH_SIZE KiB on gfx950, write = WRITE_SIZE KiB)
   pmc_sq           -> SQ_BUSY_CYCLES, SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU / MFMA / LDS per launch
