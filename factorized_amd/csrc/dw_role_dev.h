@@ -112,25 +112,6 @@ constexpr int DWR_ACTIVE = 1 << 28, DWR_GACTIVE = 1 << 29;
 constexpr int DWR_LDS_FLOATS = 5 * DWR_KC * DWR_T + 16 + DWR_MAXREC * 24 + DWR_MAXP * 24;    // images, answer word, records, descriptors
 
 // `karg_dr`: the DwRole descriptor in the kernel-argument segment (read with per-lane indices: never through the by-value copy)
-// the non-blocking form in two halves: the stamp loads are ISSUED at one point of the iteration and looked at later (round 6: the
-// launch clock showed wave 0 waiting 0.8 us per iteration for these loads with every other wave behind it at the next barrier)
-struct DwrProbe { unsigned v0, v1, v2, v3; };
-__device__ __forceinline__ DwrProbe dwr_issue(const unsigned* f, int n, unsigned epoch) {
-  const int lane = threadIdx.x & 63;
-  DwrProbe p;
-  p.v0 = __hip_atomic_load(f + (lane < n ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  p.v1 = __hip_atomic_load(f + (lane + 64 < n ? lane + 64 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  p.v2 = epoch; p.v3 = epoch;
-  if (n > 128) {
-    p.v2 = __hip_atomic_load(f + (lane + 128 < n ? lane + 128 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    p.v3 = __hip_atomic_load(f + (lane + 192 < n ? lane + 192 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  return p;
-}
-__device__ __forceinline__ bool dwr_eval(const DwrProbe& p, unsigned epoch) {
-  return __builtin_amdgcn_ballot_w64(p.v0 != epoch || p.v1 != epoch || p.v2 != epoch || p.v3 != epoch) == 0ull;
-}
-
 __device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned epoch, float* lds, const int* __restrict__ karg_dr) {
   // One role workgroup = four slots of 256 threads that work on tiles with the SAME A slice (same rows, same 32 columns of
   // the gate-gradient / upstream-gradient operand: the dW_ih, dW_hh and bias tiles of one gate block, the column tiles of one
@@ -138,11 +119,12 @@ __device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned ep
   // of once per tile (44.4 -> 39.0 MB of HBM-side reads per launch, profiles/r04_traffic_B32.json).
   // Software pipeline (round 4): a block is a chain of memory round trips (stamp poll, A from the memory side, B from L2),
   // ~5.5 us when run back to back, and a workgroup has 8-12 of them behind a 41 us BPTT.  So the NEXT block's operands are
-  // requested while the current one is multiplied: B always (it never depends on this launch), A SPECULATIVELY (round 6): the
-  // next block's stamp loads are issued at the top of the iteration and looked at behind the product; the A slice requested in
-  // between is the real one if those stamps -- loaded before it was requested -- already carried the epoch, and is requested
-  // again behind a blocking wait if not.  (Until round 6 wave 0 waited for the stamp loads before the first barrier of the
-  // iteration, every other wave behind it: 0.8 of the 4.7 us an iteration took while the BPTT hands over a chunk every 3.8.)
+  // requested while the current one is multiplied: B always (it never depends on this launch), A when its stamps are already
+  // there (checked without blocking: the stamp loads are issued at the top of the iteration, read before its first barrier).
+  // (Round 6 tried requesting A speculatively and looking at the stamps behind the product: no gain -- 48.6 us either way -- and
+  // unsound as written: a flag load and a data load of one wave may be SERVICED out of order, so "the stamps I asked for earlier
+  // carried the epoch" does not make a data load issued before they returned a load of final data.  The stamps are looked at
+  // before A is requested.)
   constexpr int BL = DWR_KC * (DWR_T / 4) / 256;       // 16-byte loads per thread for a slot's B slice
   const int tid = threadIdx.x, sub = tid >> 8, t = tid & 255;
   const int lane = t & 63, wave = t >> 6;
@@ -267,9 +249,12 @@ __device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned ep
 #define DWR_SUB(k) ((void)0)
 #endif
     DWR_SUB(1);
-    // (2) are the next block's stamps there already?  (asked now, looked at behind the product)
-    DwrProbe probe = {epoch, epoch, epoch, epoch};
-    if (tid < 64 && nxt.dep != DWR_DEP_NONE) { int n; const unsigned* f = stamps_of(nxt, n); probe = dwr_issue(f, n, epoch); }
+    // (2) are the next block's stamps there already?  (asked now, answered through LDS behind the barrier below)
+    if (tid < 64) {
+      bool ok = true;
+      if (nxt.dep != DWR_DEP_NONE) { int n; const unsigned* f = stamps_of(nxt, n); ok = dwr_ready(f, n, epoch); }
+      if (tid == 0) *nready_lds = ok ? 1 : 0;
+    }
     DWR_SUB(2);
     // (3) operands of the current block -> LDS images
     {
@@ -298,9 +283,11 @@ __device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned ep
     }
     __syncthreads();
     DWR_SUB(3);
-    // (4) the next block's operands are requested before the current one is multiplied (A: speculatively, see above)
+    // (4) the next block's operands are requested before the current one is multiplied
+    const bool nready = *nready_lds != 0;
     issue_b(nxt, rb);
-    ra = issue_a(nxt);
+    a_pref = false;
+    if (nready) { ra = issue_a(nxt); a_pref = true; }
     DWR_SUB(4);
     // (5) product, epilogue
     if (cur.active) {
@@ -344,12 +331,7 @@ __device__ __forceinline__ void dw_role_body(const DwRole& DR, const unsigned ep
       }
     }
     DWR_SUB(5);
-    if (tid < 64) {           // (the stamp loads of (2) have long arrived)
-      const bool ok = dwr_eval(probe, epoch);
-      if (tid == 0) *nready_lds = ok ? 1 : 0;
-    }
-    __syncthreads();          // the images are free for the next block; the answer word is written
-    a_pref = *nready_lds != 0;
+    __syncthreads();          // the images (and the answer word) are free for the next block
     DWR_SUB(6);
     cur = nxt;
   }
