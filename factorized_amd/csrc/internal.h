@@ -255,11 +255,23 @@ struct LatentDev {
   float* disc_loss_out;   // backward, optional: the discriminative loss value (L1 / CE mean) is ADDED here (the loss-weighted
                           // backward of the module path: the forward ran without labels, its slot 0 is still zero)
   int grd_agent;          // grd_out leaves with agent-scope stores (read inside the same launch, dw_role_dev.h)
+  int bwd_split;          // backward, 1: the stages from tail_from up, the discriminative and KLD seeds already ran (HEAD blocks of the
+                          // decoder BPTT launch, latent_row_dev.h mode 3) and left their gradient record in grd_seed (seed_w = 1):
+                          // this launch adds the decoders' seeds and walks the stages below tail_from
+  int tail_from;          // first stage nothing of the decoders waits for (behind the z -> f MLPs): the classifier, the logvar heads,
+                          // the losses -- the fold launch may leave them to tail blocks of the decoder launch (latent_row_dev.h, mode 3)
   int64_t n_params;       // floats in the parameter buffer (row path: the weight requests are buffer loads that drop what lies outside)
   int bias_tab, bias_n;   // row path: the last stage slot of the backward item table lists every thread's bias-gradient element
                           // (bias_n: the largest number of entries a workgroup kind has; it must not exceed the block size)
 };
 int latent_fwd_launch(const LatentDev& L, const float* params, hipStream_t stream);
+int latent_fwd_tail_launch(const LatentDev& L, const float* params, hipStream_t stream);      // latent.hip: mode-3 tails alone
+// lstm_seq_small.hip / lstm_seq.hip -- the decoder recurrences with the latent forward chains' tails on idle CUs
+bool seq_small_dectail_supported(int T, int B, const int* dec_h, const LatentDev& LD);
+int seq_dec_bwd_head_launch(const MfmSeqDesc* descs, int count, int T, int B, const float* const* wt_imgs, const LatentDev& lat,
+                            const float* params, float* grads, hipStream_t stream);
+int seq_dec_tail_launch(const MfmSeqDesc* descs, int count, int T, int B, const float* const* wf_imgs, const LatentDev& lat,
+                        const float* params, hipStream_t stream);
 // lstm_seq.hip / lstm_seq_small.hip -- the encoder recurrences of MFM_KL_EF with their rows' latent chains folded in
 int seq_fold_launch(const MfmSeqDesc* descs, int count, int T, int B, bool bwd, const LatentDev& lat, const float* params,
                     float* grads, hipStream_t stream, const float* const* wt_imgs = nullptr, const struct WtImgItem* img_items = nullptr,

@@ -585,6 +585,21 @@ __global__ __launch_bounds__(LAT_THREADS) void latent_bwd_kernel(const LatentDev
 }
 
 // The row kernels' bodies live in latent_row_dev.h (shared with the fold launches of lstm_seq_small.hip)
+// the tails of the forward chains (mode 3 of the row body) as a launch of their own: what runs when the encoder launch left the
+// tails behind and the decoder launch could not carry them after all
+__global__ __launch_bounds__(LAT_THREADS) void latent_fwd_tail_kernel(const LatentDev L, const float* __restrict__ params) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int r = blockIdx.x;
+  latent_fwd_row_body<false>(L, params, r % L.B, r / L.B, lds, true, 3);
+}
+int latent_fwd_tail_launch(const LatentDev& L, const float* params, hipStream_t stream) {
+  const size_t lds1 = (size_t)latent_fwd_lds_floats(L.rec_size) * sizeof(float);
+  MFM_HIP_CHECK(hipFuncSetAttribute((const void*)latent_fwd_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+  MFM_LAUNCH_TIMED(latent_fwd_tail_kernel, dim3(L.B * L.nch), dim3(LAT_THREADS), lds1, stream, L, params);
+  MFM_LAUNCH_CHECK("latent_fwd_tail_kernel");
+  return MFM_OK;
+}
+
 template <bool PRE>
 __global__ __launch_bounds__(PRE ? LAT_PRE_THREADS : LAT_THREADS) void latent_fwd_row_kernel(const LatentDev L, const float* __restrict__ params) {
   extern __shared__ __attribute__((aligned(16))) float lds[];

@@ -96,11 +96,15 @@ __device__ __forceinline__ void load_items(const int* __restrict__ items, int ns
 // everything of the prologue that depends on nothing of this launch (op table, item table, target) goes to LDS and returns, no
 // barrier: the fold launch calls it before the time loop, whose buffers lie behind this body's LDS region
 // (latent_fwd_lds_floats); 2 = the rest, with the chain's input taken from `h_lds` (the recurrence's last hidden state, LDS).
+// `stage_hi` (mode 2, round 6): stop behind stage stage_hi - 1 -- the decoders' inputs and the chain's part of the record go to
+// memory, the classifier / logvar stages, the losses and y_hat are left to mode 3: a TAIL block of the decoder launch (any idle
+// CU there; lstm_seq_small_dectail_kernel) that reloads the record and finishes the chain while the decoders run.  The launch
+// clock put those stages + losses at 2.4 us of the encoder launch's critical path; nothing in the decoder launch waits for them.
 __host__ __device__ static inline int latent_fwd_lds_floats(int rec_size) { return MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + rec_size; }
 template <bool PRE>
 __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const float* __restrict__ params, const int row, const int ch,
                                                     float* lds, const bool own_input, const int mode = 0,
-                                                    const float* h_lds = nullptr) {
+                                                    const float* h_lds = nullptr, const int stage_hi = MFM_LAT_MAXSTAGES) {
   __shared__ LatOp ops[MFM_LAT_MAXOPS];
   __shared__ float red[2][16];
   __shared__ float ysave[2][128];
@@ -125,7 +129,21 @@ __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const fl
     const int kk = tt - (m == 0 ? 0 : (m == 1 ? e0 : (m == 2 ? e1 : e2)));
     const int io = m == 0 ? L.in_off[0] : (m == 1 ? L.in_off[1] : (m == 2 ? L.in_off[2] : L.in_off[3]));
     const bool in_ok = !own_input || m == ch;
-    if (mode != 2) {
+    if (mode == 3) {        // tail block: tables, target, and this chain's part of the record as the fold launch left it
+      const int opv = reinterpret_cast<const int*>(L.ops)[min(tid, nw - 1)];
+      if (L.y) {
+        if (L.loss_kind == 0) yv = reinterpret_cast<const float*>(L.y)[(int64_t)row * L.od + min(tid, L.od - 1)];
+        else ylab = (int)reinterpret_cast<const int64_t*>(L.y)[row];
+      }
+      const int lo4 = all ? 0 : (L.ch_lo[ch] >> 2), hi4 = all ? (L.rec_size >> 2) : (L.ch_hi[ch] >> 2);
+      const f32x4* s4 = reinterpret_cast<const f32x4*>(L.rec + (int64_t)row * L.rec_size);
+      f32x4* r4 = reinterpret_cast<f32x4*>(rec);
+      const f32x4 rv = s4[min(lo4 + tid, hi4 - 1)];
+      load_items(L.items_fwd + (size_t)ch * (MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4), L.nstages, tab, tid);
+      if (tid < nw) reinterpret_cast<int*>(ops)[tid] = opv;
+      if (lo4 + tid < hi4) r4[lo4 + tid] = rv;
+      for (int idx = lo4 + tid + nt; idx < hi4; idx += nt) r4[idx] = s4[idx];
+    } else if (mode != 2) {
       const int opv = reinterpret_cast<const int*>(L.ops)[min(tid, nw - 1)];
       const float* src = m == 0 ? L.enc_h[0] : (m == 1 ? L.enc_h[1] : (m == 2 ? L.enc_h[2] : L.enc_h[3]));
       const int64_t ld = m == 0 ? L.enc_ld[0] : (m == 1 ? L.enc_ld[1] : (m == 2 ? L.enc_ld[2] : L.enc_ld[3]));
@@ -260,14 +278,19 @@ __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const fl
     }
   } else {
     Slot sa, sb;
-    fetch(0, sa);
-    for (int s = 0; s < L.nstages; s += 2) {
+    const int s0 = (mode == 3) ? min(L.tail_from, L.nstages) : 0, s1 = min(L.nstages, (mode == 2) ? stage_hi : L.nstages);
+    if (s0 < s1) fetch(s0, sa);
+    for (int s = s0; s < s1; s += 2) {
       stage(s, sa, sb);
-      if (s + 1 < L.nstages) stage(s + 1, sb, sa);
+      if (s + 1 < s1) stage(s + 1, sb, sa);
     }
   }
+  const bool head_only = !PRE && mode == 2 && stage_hi < L.nstages;       // the tail block does the rest
+  const bool tail_only = !PRE && mode == 3;
 
   // ---- losses (one partial per workgroup, one atomic each)
+  const bool ych = all || ch == 3;                // the workgroup that holds the classifier's outputs
+  if (!head_only) {
   float kld = 0.0f;
   if (e_haslv) {
 #pragma unroll
@@ -280,7 +303,6 @@ __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const fl
     }
   }
   float disc = 0.0f;
-  const bool ych = all || ch == 3;                // the workgroup that holds the classifier's outputs
   if (L.y && ych) {
     if (e_kind == 0) {
       if (tid < e_od) disc += fabsf(rec[e_yoff + tid] - yv);
@@ -308,18 +330,19 @@ __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const fl
       atomicAdd(e_losses + 0, (red[1][0] + red[1][1]) * inv);
     }
   }
+  }      // !head_only
   // ---- outputs: plain stores, nothing in this kernel waits for them
   const int fy = e_fn[3];
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
-    if (!e_dec[m]) continue;
+    if (!e_dec[m] || tail_only) continue;
     const int hd = fy + e_fn[m];
     // decoder input [f_y | f_m]: the y chain owns the first part (for all three decoders), chain m the second
     const int j0 = (all || ch == 3) ? 0 : fy, j1 = (all || ch == m) ? hd : fy;
     for (int j = j0 + tid; j < j1; j += nt)
       e_dec[m][(int64_t)row * e_ld[m] + j] = (j < fy) ? rec[e_fo[3] + j] : rec[e_fo[m] + (j - fy)];
   }
-  if (e_yout && ych)
+  if (e_yout && ych && !head_only)
     for (int o = tid; o < e_od; o += nt) e_yout[(int64_t)row * e_od + o] = rec[e_yoff + o];
   if (e_rec) {
     // the saved record: this workgroup's range of it (the whole row, or its chain's contiguous segments)
@@ -335,6 +358,10 @@ __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const fl
 // 0 = the whole body; 1 = everything up to the last stage -- the gradient record stays in LDS behind this body's tables
 // (latent_bwd_grd_floats: the BPTT takes d h_T from there); 2 = what nothing in the workgroup waits for: bias gradients, d h_T and
 // the gradient record to memory.  The fold launch runs 2 between the BPTT's weight requests and their first use.
+// 3 (round 6) = a HEAD block of the decoder BPTT launch: the part of the backward chain that does not wait for the decoders -- the
+// discriminative and KLD seeds and the stages from LatentDev::tail_from up (classifier, logvar heads) -- whose gradient record
+// goes to grd_out; the chain of the encoder launch then starts from that record (LatentDev::bwd_split), adds the decoders' seeds
+// and walks the remaining stages: 2.4 us of stages and most of the seed section leave the launch whose BPTT the chain gates.
 __host__ __device__ static inline int latent_bwd_grd_floats(int rec_size) { return MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + rec_size; }
 template <bool PRE>
 __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const float* __restrict__ params, float* __restrict__ grads,
@@ -367,8 +394,9 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
     s_fn[m] = L.f_n[m]; s_fo[m] = L.f_off[m]; s_mu[m] = L.mu_off[m]; s_lv[m] = L.lv_off[m]; s_zn[m] = L.z_n[m];
     PIN_S(s_fn[m]); PIN_S(s_fo[m]); PIN_S(s_mu[m]); PIN_S(s_lv[m]); PIN_S(s_zn[m]);
   }
+  const bool head = !PRE && mode == 3, rest = !PRE && mode != 3 && L.bwd_split != 0;
   int s_yoff = L.yhat_off, s_od = L.od, s_B = L.B, s_kind = L.loss_kind, s_haslv = L.has_logvar;
-  float s_genw = L.gen_w, s_discw = L.disc_w, s_regw = L.reg_w;
+  float s_genw = head ? 0.0f : L.gen_w, s_discw = L.disc_w, s_regw = L.reg_w;
   PIN_S(s_yoff); PIN_S(s_od); PIN_S(s_B); PIN_S(s_kind); PIN_S(s_haslv); PIN_S(s_genw); PIN_S(s_discw); PIN_S(s_regw);
   const float* s_ddi[3]; int64_t s_dld[3];
 #pragma unroll
@@ -382,7 +410,7 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
   float pre_fy[3], pre_fm[3], pre_y;
   long long pre_lab;
   {
-    const bool gen = L.gen_w != 0.0f;
+    const bool gen = L.gen_w != 0.0f && !head;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
       const bool on = gen && L.d_dec_init[m] != nullptr;
@@ -459,12 +487,14 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
 #pragma unroll
     for (int p = 0; p < LAT_PRE_SLOTS; ++p) fetch(max(L.nstages - 1 - p, 0), sl[p]);
   } else {
-    fetch(L.nstages - 1, sa);
+    fetch((rest ? L.tail_from : L.nstages) - 1, sa);
   }
   // ---- seeds
   float dl = 0.0f;                  // this row's share of the discriminative loss (disc_loss_out)
   // (the element a thread's first pass needs is already in pre_*; later passes -- od / f sizes beyond the block -- load)
-  if (s_dyext) {
+  if (rest) {
+    // (the head block seeded y_hat and the KLD terms and walked the classifier / logvar stages)
+  } else if (s_dyext) {
     for (int o = tid; o < s_od; o += nt) grd[s_yoff + o] = (o == tid) ? pre_y : s_dyext[(int64_t)row * s_od + o];
   } else if (s_y && (s_discw != 0.0f || s_dlo)) {
     if (s_kind == 0) {
@@ -500,7 +530,7 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
 #pragma unroll
       for (int m = 0; m < 3; ++m)
         if (s_ddi[m]) sm += (j == tid) ? pre_fy[m] : s_ddi[m][(int64_t)row * s_dld[m] + j];
-      grd[s_fo[3] + j] = sm;
+      grd[s_fo[3] + j] = rest ? grd[s_fo[3] + j] + sm : sm;          // (rest: on top of the classifier's contribution)
     }
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
@@ -517,7 +547,7 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
         if (!(rec[s_fo[m] + j] > 0.0f)) grd[s_fo[m] + j] = 0.0f;
   }
   const float reg_w = s_rwp ? *s_rwp : s_regw;
-  if (s_haslv && (s_rwp || reg_w != 0.0f)) {
+  if (!rest && s_haslv && (s_rwp || reg_w != 0.0f)) {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
       for (int j = tid; j < s_zn[m]; j += nt) {
@@ -582,10 +612,18 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
       if (p + LAT_PRE_SLOTS < LAT_PRE_STAGES) fetch(max(L.nstages - 1 - (p + LAT_PRE_SLOTS), 0), sl[p % LAT_PRE_SLOTS]);
     }
   } else {
-    for (int s = L.nstages - 1; s >= 0; s -= 2) {
+    const int lo = head ? L.tail_from : 0;
+    for (int s = (rest ? L.tail_from : L.nstages) - 1; s >= lo; s -= 2) {
       stage(s, sa, sb);
-      if (s >= 1) stage(s - 1, sb, sa);
+      if (s - 1 >= lo) stage(s - 1, sb, sa);
     }
+  }
+  if (head) {        // the gradient record so far (this chain's range) -> memory, for the encoder launch's chain
+    const int lo4 = all ? 0 : (L.ch_lo[ch] >> 2), hi4 = all ? (RS >> 2) : (L.ch_hi[ch] >> 2);
+    f32x4* d4 = reinterpret_cast<f32x4*>(L.grd_out + (int64_t)row * RS);
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(grd);
+    for (int idx = lo4 + tid; idx < hi4; idx += nt) d4[idx] = s4[idx];
+    return;
   }
   }      // mode != 2
   if (mode == 1) return;

@@ -378,7 +378,7 @@ bool bf16_seq_pays(int B) {
 }
 
 struct FoldArgs { const LatentDev* lat; const float* params; float* grads; ProjRole* pr; DwRole* dr; const float* const* wt_imgs;
-                  const WtImgItem* img_items; int n_img_items; bool* img_written; const float* const* wf_imgs; };
+                  const WtImgItem* img_items; int n_img_items; bool* img_written; const float* const* wf_imgs; int dec_tail; };
 
 static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bool bwd, hipStream_t stream, bool bf16 = false,
                       const FoldArgs* fold = nullptr) {
@@ -400,7 +400,9 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
       wide[nwide++] = s;
     } else descs[count++] = s;
   }
-  if (fold && !fold->lat && !fold->pr && !fold->dr) {      // (images only: a plain launch)
+  if (fold && fold->dec_tail) {
+    if (nwide || bf16 || !use_small_path(B) || opt_get("MFM_SEQ_KS") || opt_get("MFM_SEQ_ROWS")) return MFM_ERR_UNSUPPORTED;
+  } else if (fold && !fold->lat && !fold->pr && !fold->dr) {      // (images only: a plain launch)
     if (fold->img_written) *fold->img_written = false;
     if (nwide || bf16 || !use_small_path(B) || opt_get("MFM_SEQ_KS") || opt_get("MFM_SEQ_ROWS")) fold = nullptr;
   } else if (fold && (nwide || bf16 || !use_small_path(B))) return MFM_ERR_UNSUPPORTED;
@@ -437,6 +439,7 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     d.h_last = bf16 ? s.h_last : nullptr;
     d.store_bf16 = s.store_bf16;
     d.wt_img = (fold && fold->wt_imgs && bwd && !sorted && !nwide && count == count_in) ? fold->wt_imgs[i] : nullptr;
+    if (fold && fold->dec_tail == 2 && (sorted || count != count_in)) return MFM_ERR_UNSUPPORTED;
     d.wf_img = (fold && fold->wf_imgs && !bwd && !sorted && !nwide && count == count_in && s.is_dec && (s.h & 3) == 0) ? fold->wf_imgs[i] : nullptr;
     d.wf1_img = d.wf_img ? fold->wf_imgs[count_in + i] : nullptr;        // (second half of the list: W_ih alone)
     MFM_REQUIRE(bf16 || (!s.store_bf16 && !s.h_last), "lstm_seq[%d]: store_bf16 / h_last are taken by the bf16 entry points only", i);
@@ -457,6 +460,8 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
     L.n_img = fold->n_img_items;
     for (int i = 0; i < L.n_img; ++i) L.img[i] = fold->img_items[i];
   }
+  if (fold && fold->dec_tail == 2) return seq_small_decbwd_head_launch(L, *fold->lat, fold->params, fold->grads, stream);
+  if (fold && fold->dec_tail) return seq_small_dectail_launch(L, *fold->lat, fold->params, stream);
   if (fold && !fold->lat && fold->img_items) {      // forward launch with image-writer blocks behind the rows
     const int rc = seq_small_launch(L, false, stream);
     if (rc == MFM_OK && fold->img_written) *fold->img_written = L.n_img > 0;
@@ -505,13 +510,13 @@ static int seq_launch(const MfmSeqDesc* descs_in, int count_in, int T, int B, bo
 int seq_fold_launch(const MfmSeqDesc* descs, int count, int T, int B, bool bwd, const LatentDev& lat, const float* params,
                     float* grads, hipStream_t stream, const float* const* wt_imgs, const WtImgItem* img_items, int n_img_items,
                     bool* img_written) {
-  FoldArgs f = {&lat, params, grads, nullptr, nullptr, wt_imgs, img_items, n_img_items, img_written, nullptr};
+  FoldArgs f = {&lat, params, grads, nullptr, nullptr, wt_imgs, img_items, n_img_items, img_written, nullptr, 0};
   return seq_launch(descs, count, T, B, bwd, stream, false, &f);
 }
 // the forward fold launch with projection role workgroups in front (proj_role_dev.h)
 int seq_foldproj_launch(const MfmSeqDesc* descs, int count, int T, int B, const LatentDev& lat, const float* params, ProjRole& pr,
                         hipStream_t stream) {
-  FoldArgs f = {&lat, params, nullptr, &pr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+  FoldArgs f = {&lat, params, nullptr, &pr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0};
   return seq_launch(descs, count, T, B, false, stream, false, &f);
 }
 
@@ -522,24 +527,36 @@ namespace mfm {
 // *written: whether they did (one-row tiles and idle CUs left)
 int seq_fwd_img_launch(const MfmSeqDesc* descs, int count, int T, int B, const WtImgItem* items, int n_items, bool* written,
                        hipStream_t stream) {
-  FoldArgs f = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, items, n_items, written, nullptr};
+  FoldArgs f = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, items, n_items, written, nullptr, 0};
   return seq_launch(descs, count, T, B, false, stream, false, &f);
+}
+// decoder recurrences + the tail blocks of the latent forward chains (lstm_seq_small_dectail_kernel)
+int seq_dec_tail_launch(const MfmSeqDesc* descs, int count, int T, int B, const float* const* wf_imgs, const LatentDev& lat,
+                        const float* params, hipStream_t stream) {
+  FoldArgs f = {&lat, params, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, wf_imgs, 1};
+  return seq_launch(descs, count, T, B, false, stream, false, &f);
+}
+// decoder BPTTs + the head blocks of the latent backward chains (lstm_seq_small_decbwd_head_kernel)
+int seq_dec_bwd_head_launch(const MfmSeqDesc* descs, int count, int T, int B, const float* const* wt_imgs, const LatentDev& lat,
+                            const float* params, float* grads, hipStream_t stream) {
+  FoldArgs f = {&lat, params, grads, nullptr, nullptr, wt_imgs, nullptr, 0, nullptr, nullptr, 2};
+  return seq_launch(descs, count, T, B, true, stream, false, &f);
 }
 // plain BPTT launch whose one-row workgroups take their transposed weights from this step's images (proj_role_dev.h)
 int seq_bwd_img_launch(const MfmSeqDesc* descs, int count, int T, int B, const float* const* wt_imgs, hipStream_t stream) {
-  FoldArgs f = {nullptr, nullptr, nullptr, nullptr, nullptr, wt_imgs, nullptr, 0, nullptr, nullptr};
+  FoldArgs f = {nullptr, nullptr, nullptr, nullptr, nullptr, wt_imgs, nullptr, 0, nullptr, nullptr, 0};
   return seq_launch(descs, count, T, B, true, stream, false, &f);
 }
 // plain forward launch whose one-row decoder workgroups take W_ih + W_hh (steps >= 1) and W_ih (step 0) from this step's
 // forward images: wf_imgs[0 .. count) the sums, wf_imgs[count .. 2 count) W_ih
 int seq_fwd_wf_launch(const MfmSeqDesc* descs, int count, int T, int B, const float* const* wf_imgs, hipStream_t stream) {
-  FoldArgs f = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, wf_imgs};
+  FoldArgs f = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, wf_imgs, 0};
   return seq_launch(descs, count, T, B, false, stream, false, &f);
 }
 // the backward fold launch with weight-gradient role workgroups behind the BPTT workgroups (dw_role_dev.h)
 int seq_folddw_launch(const MfmSeqDesc* descs, int count, int T, int B, const LatentDev& lat, const float* params, float* grads,
                       DwRole& dr, hipStream_t stream, const float* const* wt_imgs) {
-  FoldArgs f = {&lat, params, grads, nullptr, &dr, wt_imgs, nullptr, 0, nullptr, nullptr};
+  FoldArgs f = {&lat, params, grads, nullptr, &dr, wt_imgs, nullptr, 0, nullptr, nullptr, 0};
   return seq_launch(descs, count, T, B, true, stream, false, &f);
 }
 }  // namespace mfm

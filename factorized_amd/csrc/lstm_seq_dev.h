@@ -94,6 +94,8 @@ __device__ __forceinline__ void wf_img_write(const WtImgItem* items, const int n
 
 int seq_small_launch(SeqLaunch& L, bool bwd, hipStream_t stream);
 struct LatentDev;
+int seq_small_dectail_launch(SeqLaunch& L, const LatentDev& LD, const float* params, hipStream_t stream);
+int seq_small_decbwd_head_launch(SeqLaunch& L, const LatentDev& LD, const float* params, float* grads, hipStream_t stream);
 int seq_small_fold_launch(SeqLaunch& L, bool bwd, const LatentDev& LD, const float* params, float* grads, hipStream_t stream);
 // lstm_seq_bf16.hip: bf16 MFMA operands, fp32 accumulate / cell state / saved activations
 int seq_bf16_launch(SeqLaunch& L, bool bwd, hipStream_t stream);

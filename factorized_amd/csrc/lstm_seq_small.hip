@@ -211,7 +211,8 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_foldproj_kernel(const Seq
   LSTAMP(0, 9);
   if (pre) {
     LSTAMP(0, 8);
-    latent_fwd_row_body<false>(LD, params, tile, di, lds, true, 2, h_lds);      // (its first barrier orders the flag wait above)
+    // (its first barrier orders the flag wait above)
+    latent_fwd_row_body<false>(LD, params, tile, di, lds, true, 2, h_lds, PR.lat_tail ? LD.tail_from : MFM_LAT_MAXSTAGES);
   } else {
     sync_stores();           // every store of the last time step has been acknowledged: h_T of this row is readable
     LSTAMP(0, 8);
@@ -272,6 +273,62 @@ __global__ __launch_bounds__(1024) void lstm_seq_small_folddw_kernel(const SeqLa
 #undef MFM_ONE
   }
   LSTAMP_W(4, 15);
+}
+
+// Decoder recurrences with TAIL blocks (round 6): blocks [0, 3 B) are kernel4<false>'s rows of the three decoders; blocks
+// [tail_begin, tail_begin + 4 B) finish the latent forward chains the encoder launch left behind the z -> f MLPs -- classifier,
+// logvar heads, KLD and discriminative loss, y_hat, the rest of the saved record (latent_row_dev.h, mode 3).  Nothing in this
+// launch waits for them; they run on CUs the 96 decoder rows leave idle.
+template <int K0, int K1, int K2>
+__global__ __launch_bounds__(1024) void lstm_seq_small_dectail_kernel(const SeqLaunch L, const LatentDev LD, const float* __restrict__ params,
+                                                                      const int tail_begin) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int bid = blockIdx.x;
+  LSTAMP(1, 0);
+  if (bid >= tail_begin) {
+    const int r = bid - tail_begin;
+    latent_fwd_row_body<false>(LD, params, r % L.B, r / L.B, lds, true, 3);
+    LSTAMP(1, 15);
+    return;
+  }
+  int di = 0;
+#pragma unroll 1
+  for (int i = 1; i < L.count; ++i)
+    if (bid >= L.d[i].block_begin) di = i;
+  const SeqDev& d = L.d[di];
+  const int tile = bid - d.block_begin;
+#define MFM_ONE(IDX, KK) \
+  if (KK > 0 && di == IDX) small_fwd_body<(KK > 0 ? KK : 2), 1>(d, L.T, L.B, tile, lds);
+  MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2)
+#undef MFM_ONE
+  LSTAMP(1, 15);
+}
+
+// Decoder BPTTs with HEAD blocks (round 6): blocks [0, 3 B) are kernel4<true>'s rows; blocks [head_begin, head_begin + 4 B) run the
+// part of the latent BACKWARD chains that does not wait for the decoders (latent_row_dev.h, mode 3) on CUs the 96 rows leave idle.
+template <int K0, int K1, int K2>
+__global__ __launch_bounds__(1024) void lstm_seq_small_decbwd_head_kernel(const SeqLaunch L, const LatentDev LD, const float* __restrict__ params,
+                                                                          float* __restrict__ grads, const int head_begin) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int bid = blockIdx.x;
+  LSTAMP(3, 0);
+  if (bid >= head_begin) {
+    const int r = bid - head_begin;
+    latent_bwd_row_body<false>(LD, params, grads, r % L.B, r / L.B, lds, 3);
+    LSTAMP(3, 15);
+    return;
+  }
+  int di = 0;
+#pragma unroll 1
+  for (int i = 1; i < L.count; ++i)
+    if (bid >= L.d[i].block_begin) di = i;
+  const SeqDev& d = L.d[di];
+  const int tile = bid - d.block_begin;
+#define MFM_ONE(IDX, KK) \
+  if (KK > 0 && di == IDX) small_bwd_body<(KK > 0 ? KK : 2), 1, 16>(d, L.T, L.B, tile, lds);
+  MFM_ONE(0, K0) MFM_ONE(1, K1) MFM_ONE(2, K2)
+#undef MFM_ONE
+  LSTAMP(3, 15);
 }
 
 // `no_panel` (forward, one-row tiles, every h % 4 == 0): the weights go straight into registers, the panel is not needed
@@ -415,6 +472,69 @@ int seq_small_folddw_launch(SeqLaunch& L, const LatentDev& LD, DwRole& DR, const
   return MFM_OK;
 }
 
+// Can the decoder launch of this plan carry the tail blocks?  (asked by the encoder launch before it leaves the tails behind)
+bool seq_small_dectail_supported(int T, int B, const int* dec_h, const LatentDev& LD) {
+  if (const char* e = opt_get("MFM_LATENT_TAIL")) { if (atoi(e) == 0) return false; }
+  if (opt_get("MFM_SEQ_KS") || opt_get("MFM_SEQ_ROWS") || opt_get("MFM_BF16_DOT")) return false;
+  const int want[3] = {26, 6, 6};
+  for (int i = 0; i < 3; ++i)
+    if (round_up(cdiv(dec_h[i], 4), 2) != want[i]) return false;
+  if (!LD.row_path || LD.nch != 4 || LD.pre || LD.B != B || LD.tail_from < 1 || LD.tail_from >= LD.nstages) return false;
+  return T >= 1 && 3 * B + 4 * B <= device_cus();
+}
+
+// MFM_OK: launched (decoder rows + tail blocks).  MFM_ERR_UNSUPPORTED: the caller runs the tails as a launch of their own.
+int seq_small_dectail_launch(SeqLaunch& L, const LatentDev& LD, const float* params, hipStream_t stream) {
+  LSTAMP_BIND();
+  const int want[3] = {26, 6, 6};
+  if (L.count != 3 || L.bf16_dot) return MFM_ERR_UNSUPPORTED;
+  int hh[3];
+  for (int i = 0; i < 3; ++i) {
+    if (L.d[i].hk4 != want[i] || !L.d[i].is_dec) return MFM_ERR_UNSUPPORTED;
+    hh[i] = L.d[i].h;
+  }
+  if (!seq_small_dectail_supported(L.T, L.B, hh, LD)) return MFM_ERR_UNSUPPORTED;
+  int total = 0, max_threads = 1024;          // (the chain's work items are tabulated for 1024 threads)
+  bool direct = true;
+  for (int i = 0; i < 3; ++i) { L.d[i].block_begin = total; total += L.B; direct = direct && (L.d[i].h & 3) == 0 && L.d[i].wf_img && L.d[i].wf1_img; }
+  const int tail_begin = total;
+  total += 4 * L.B;
+  L.n_img = 0; L.n_img_blocks = 0;
+  const size_t lat = (size_t)latent_fwd_lds_floats(LD.rec_size) * sizeof(float);
+  const size_t lds_bytes = std::max(lat, small_lds_bytes(L, false, 1, direct));
+  if (lds_bytes > 160 * 1024) return MFM_ERR_UNSUPPORTED;
+  MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_dectail_kernel<26, 6, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  MFM_LAUNCH_TIMED((lstm_seq_small_dectail_kernel<26, 6, 6>), dim3(total), dim3(max_threads), lds_bytes, stream, L, LD, params, tail_begin);
+  MFM_LAUNCH_CHECK("lstm_seq_small_dectail_kernel");
+  return MFM_OK;
+}
+
+// MFM_OK: launched (decoder BPTT rows + head blocks).  MFM_ERR_UNSUPPORTED: the caller runs the plain BPTT launch, the encoder
+// launch its whole chain.
+int seq_small_decbwd_head_launch(SeqLaunch& L, const LatentDev& LD, const float* params, float* grads, hipStream_t stream) {
+  LSTAMP_BIND();
+  if (const char* e = opt_get("MFM_LATENT_BWD_HEAD")) { if (atoi(e) == 0) return MFM_ERR_UNSUPPORTED; }
+  const int want[3] = {26, 6, 6};
+  if (L.count != 3) return MFM_ERR_UNSUPPORTED;
+  int hh[3];
+  for (int i = 0; i < 3; ++i) {
+    if (L.d[i].hk4 != want[i] || !L.d[i].is_dec || !L.d[i].wt_img) return MFM_ERR_UNSUPPORTED;
+    hh[i] = L.d[i].h;
+  }
+  if (!seq_small_dectail_supported(L.T, L.B, hh, LD) || !LD.grd_out) return MFM_ERR_UNSUPPORTED;
+  int total = 0;
+  for (int i = 0; i < 3; ++i) { L.d[i].block_begin = total; total += L.B; }
+  const int head_begin = total;
+  total += 4 * L.B;
+  const size_t lat = ((size_t)MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4 + 2 * (size_t)LD.rec_size) * sizeof(float);
+  const size_t lds_bytes = std::max(lat, small_lds_bytes(L, true, 1));
+  if (lds_bytes > 160 * 1024) return MFM_ERR_UNSUPPORTED;
+  MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_decbwd_head_kernel<26, 6, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  MFM_LAUNCH_TIMED((lstm_seq_small_decbwd_head_kernel<26, 6, 6>), dim3(total), dim3(1024), lds_bytes, stream, L, LD, params, grads, head_begin);
+  MFM_LAUNCH_CHECK("lstm_seq_small_decbwd_head_kernel");
+  return MFM_OK;
+}
+
 // Projection role workgroups for a forward fold launch: shapes the role kernel takes and enough idle CUs
 bool seq_small_foldproj_supported(int T, int B, const int* h, const int* k, int n_enc) {
   if (const char* e = opt_get("MFM_PROJ_FOLD")) { if (atoi(e) == 0) return false; }
@@ -467,6 +587,7 @@ int seq_small_foldproj_launch(SeqLaunch& L, const LatentDev& LD, ProjRole& PR, c
     const size_t side = (size_t)latent_fwd_lds_floats(LD.rec_size) * sizeof(float) + small_lds_bytes(L, false, 1, true);
     if (direct && side <= 160 * 1024) { PR.lat_pre = 1; lds_bytes = std::max(side, role); }
   }
+  if (!PR.lat_pre) PR.lat_tail = 0;          // (the head / tail split is a form of the preloaded chain)
   if (lds_bytes > 160 * 1024) return MFM_ERR_UNSUPPORTED;
   MFM_HIP_CHECK(hipFuncSetAttribute((const void*)lstm_seq_small_foldproj_kernel<8, 2, 20, 30>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   MFM_LAUNCH_TIMED((lstm_seq_small_foldproj_kernel<8, 2, 20, 30>), dim3(total), dim3(1024), lds_bytes, stream, L, LD, PR, params);

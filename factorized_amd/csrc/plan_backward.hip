@@ -225,6 +225,35 @@ int backward(MfmPlan* P, const float* params, const float* x, const void* y, int
   // every weight-gradient product only feeds the optimizer: they are collected here and issued as ONE grouped
   // launch behind the encoder BPTT (49 problems at the canonical wiring) instead of three launches on the chain
   std::vector<MfmGemmDesc> tail;
+  LatentDev Lbase = P->lat;
+  {
+    LatentDev& L = Lbase;
+    L.ops = reinterpret_cast<const LatOp*>(W + P->lat_ops_off);
+    L.items_fwd = reinterpret_cast<const int*>(W + P->lat_items_off);
+    L.items_bwd = L.items_fwd + (size_t)4 * MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
+    if (opt_get("MFM_LATENT_DBG")) L.dbg = reinterpret_cast<unsigned long long*>(W + P->dbg_off);
+    for (int m = 0; m < 3; ++m) {
+      L.d_dec_init[m] = gen_on ? W + P->dec_dinit[m] : nullptr;
+      L.dec_ld[m] = P->dec_h[m];
+    }
+    for (int e = 0; e < 4; ++e) {
+      L.dh_last[e] = W + P->dh_last[e];
+      L.dh_ld[e] = (e == 3 && V != 0) ? P->nzy : P->enc_h[e];
+    }
+    L.rec = W + P->lat_rec;
+    L.y = y;
+    L.grd_out = W + P->lat_grd;
+    if (V == 2) {        // d MMD / d z, written by the forward; its weight: lda_mmd, or the caller's upstream gradient
+      L.grd_seed = W + P->lat_seed;
+      L.seed_w = lw ? lw->reg : c.lda_reg; L.seed_w_ptr = ext ? ext->d_reg : nullptr;
+    }
+    if (ext) { L.d_yhat_ext = ext->d_yhat; L.reg_w_ptr = ext->d_reg; }
+    L.reg_w = (lw ? lw->reg : c.lda_reg) * c.reg_scale;
+    L.disc_w = lw ? lw->disc : (disc_on ? 1.0f : 0.0f);
+    L.disc_loss_out = (lw && lw->write_disc && y) ? W + P->losses : nullptr;
+    L.gen_w = gen_on ? 1.0f : 0.0f;
+  }
+  bool bwd_head_done = false;
   if (gen_on) {
     // B0: through decoder fc1
     std::vector<MfmGemmDesc> g;
@@ -282,7 +311,21 @@ int backward(MfmPlan* P, const float* params, const float* x, const void* y, int
       const bool imgs_on = !seq_bf16 && P->wt_call == P->calls;
       const int ne = P->n_enc;
       const float* dimg[3] = {imgs_on ? W + P->wt_img[ne] : nullptr, imgs_on ? W + P->wt_img[ne + 1] : nullptr, imgs_on ? W + P->wt_img[ne + 2] : nullptr};
-      if (imgs_on) RUN(K_DEC_BWD, seq_bwd_img_launch(q, 3, T, B, dimg, s));
+      // MFM_KL_EF at small batches: the part of the latent backward chains that does not wait for the decoders -- seeds of the
+      // discriminative and KLD terms, classifier and logvar stages -- runs on this launch's idle CUs (head blocks); the chain in
+      // front of the encoder BPTT then starts from their record (LatentDev::bwd_split)
+      bool dec_bwd_done = false;
+      if (imgs_on && V == 0 && P->n_enc == 4 && P->fold_state == 1 && !Lbase.pre && Lbase.row_path) {
+        LatentDev LH = Lbase;
+        LH.gen_w = 0.0f;
+        for (int m = 0; m < 3; ++m) LH.d_dec_init[m] = nullptr;
+        int rc;
+        { Timer _t(P, s, K_DEC_BWD); rc = seq_dec_bwd_head_launch(q, 3, T, B, dimg, LH, params, grads, s); }
+        if (rc == MFM_OK) { dec_bwd_done = true; bwd_head_done = true; }
+        else if (rc != MFM_ERR_UNSUPPORTED) return rc;
+      }
+      if (dec_bwd_done) {}
+      else if (imgs_on) RUN(K_DEC_BWD, seq_bwd_img_launch(q, 3, T, B, dimg, s));
       else RUN(K_DEC_BWD, seq_bf16 ? mfm_lstm_seq_bwd_bf16(q, 3, T, B, s) : mfm_lstm_seq_bwd(q, 3, T, B, s));
     }
     // (B2: the decoder weight gradients only feed Adam; they share the encoders' launch at the end)
@@ -290,31 +333,9 @@ int backward(MfmPlan* P, const float* params, const float* x, const void* y, int
   // B3: latent stack
   bool enc_bwd_done = false;
   {
-    LatentDev L = P->lat;
-    L.ops = reinterpret_cast<const LatOp*>(W + P->lat_ops_off);
-    L.items_fwd = reinterpret_cast<const int*>(W + P->lat_items_off);
-    L.items_bwd = L.items_fwd + (size_t)4 * MFM_LAT_MAXSTAGES * MFM_LAT_ROW_THREADS * 4;
-    if (opt_get("MFM_LATENT_DBG")) L.dbg = reinterpret_cast<unsigned long long*>(W + P->dbg_off);
-    for (int m = 0; m < 3; ++m) {
-      L.d_dec_init[m] = gen_on ? W + P->dec_dinit[m] : nullptr;
-      L.dec_ld[m] = P->dec_h[m];
-    }
-    for (int e = 0; e < 4; ++e) {
-      L.dh_last[e] = W + P->dh_last[e];
-      L.dh_ld[e] = (e == 3 && V != 0) ? P->nzy : P->enc_h[e];
-    }
-    L.rec = W + P->lat_rec;
-    L.y = y;
-    L.grd_out = W + P->lat_grd;
-    if (V == 2) {        // d MMD / d z, written by the forward; its weight: lda_mmd, or the caller's upstream gradient
-      L.grd_seed = W + P->lat_seed;
-      L.seed_w = lw ? lw->reg : c.lda_reg; L.seed_w_ptr = ext ? ext->d_reg : nullptr;
-    }
-    if (ext) { L.d_yhat_ext = ext->d_yhat; L.reg_w_ptr = ext->d_reg; }
-    L.reg_w = (lw ? lw->reg : c.lda_reg) * c.reg_scale;
-    L.disc_w = lw ? lw->disc : (disc_on ? 1.0f : 0.0f);
-    L.disc_loss_out = (lw && lw->write_disc && y) ? W + P->losses : nullptr;
-    L.gen_w = gen_on ? 1.0f : 0.0f;
+    LatentDev L = Lbase;
+    L.bwd_split = bwd_head_done ? 1 : 0;
+    if (bwd_head_done) { L.grd_seed = W + P->lat_grd; L.seed_w = 1.0f; L.seed_w_ptr = nullptr; }      // the head blocks' record
     // weight gradients of the 22 latent Linears: dW[n][k] = sum_r G[r][out+n] X[r][in+k]
     const int rs = P->lat.rec_size;
     auto latent_products = [&](std::vector<MfmGemmDesc>& out, bool colsum) {

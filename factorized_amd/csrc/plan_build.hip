@@ -240,6 +240,7 @@ int build(MfmPlan* P) {
   for (int e = 0; e < 4; ++e)
     add_op(P->lat_ops, L, st, e, f1_off[e], L.f_off[e], fn[e], fn[e], o[pi.zf2[e]], o[pi.zf2[e] + 1], 1, -1, 0.f);
   ++st;
+  L.tail_from = st;        // f_l, f_a, f_v, f_y are final: everything behind this stage feeds the losses only
   // classifier (mfm_model.py:657); its first stage also carries the logvar heads
   add_op(P->lat_ops, L, st, 3, L.f_off[3], c1_off, c.fy, c.fy, o[pi.y_f1], o[pi.y_f1 + 1], 1, mc_off, c.drop_y);
   if (V != 2)

@@ -300,10 +300,17 @@ int forward(MfmPlan* P, const float* params, const float* x, const void* y, int 
       PR.e[e].w = params + P->off[pb + W_IH]; PR.e[e].b_ih = params + P->off[pb + B_IH]; PR.e[e].b_hh = params + P->off[pb + B_HH];
       PR.e[e].k_off = P->enc_xoff[e]; PR.e[e].k = P->enc_d[e];
     }
+    // the chains' stages behind the z -> f MLPs (classifier, logvar heads, losses, y_hat) are left to tail blocks of the decoder
+    // launch when that launch can carry them (latent_row_dev.h, mode 3)
+    {
+      const int dech[3] = {P->dec[0].h, P->dec[1].h, P->dec[2].h};
+      PR.lat_tail = seq_small_dectail_supported(T, B, dech, L) ? 1 : 0;
+    }
     int rc;
     { Timer _t(P, s, K_ENC_FWD); rc = seq_foldproj_launch(q, 4, T, B, L, params, PR, s); }
     if (rc == MFM_OK) { folded = true; P->projfold_state = 1; P->fold_state = 1; P->ever_handover = true; if (PR.n_wt) P->wt_call = P->calls;
-                        if (PR.n_wf == 6) P->wf_call = P->calls; }
+                        if (PR.n_wf == 6) P->wf_call = P->calls;
+                        if (PR.lat_tail) P->lat_tail_call = P->calls; }
     else if (rc == MFM_ERR_UNSUPPORTED) {
       P->projfold_state = -1;
       const int rc0 = run_f0();
@@ -366,7 +373,16 @@ int forward(MfmPlan* P, const float* params, const float* x, const void* y, int 
     const bool wf_on = !seq_bf16 && P->wf_call == P->calls;
     const float* wf[6];
     for (int k = 0; k < 6; ++k) wf[k] = wf_on ? W + P->wf_img[k] : nullptr;
-    if (wf_on) RUN(K_DEC_FWD, seq_fwd_wf_launch(q, 3, T, B, wf, s));
+    bool dec_done = false;
+    if (P->lat_tail_call == P->calls) {          // the encoder launch left the chains' tails behind: they ride on this launch
+      int rc;
+      { Timer _t(P, s, K_DEC_FWD); rc = seq_dec_tail_launch(q, 3, T, B, wf_on ? wf : nullptr, L, params, s); }
+      if (rc == MFM_OK) dec_done = true;
+      else if (rc == MFM_ERR_UNSUPPORTED) RUN(K_LAT_FWD, latent_fwd_tail_launch(L, params, s));      // (a launch of their own)
+      else return rc;
+    }
+    if (dec_done) {}
+    else if (wf_on) RUN(K_DEC_FWD, seq_fwd_wf_launch(q, 3, T, B, wf, s));
     else RUN(K_DEC_FWD, seq_bf16 ? mfm_lstm_seq_fwd_bf16(q, 3, T, B, s) : mfm_lstm_seq_fwd(q, 3, T, B, s));
   }
   // F4: decoder fc1 -> x_hat

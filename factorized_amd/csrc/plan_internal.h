@@ -96,6 +96,7 @@ struct MfmPlan {
   unsigned long long wt_call = ~0ull;       // value of `calls` whose forward wrote them
   int64_t wf_img[6] = {-1, -1, -1, -1, -1, -1};     // forward-order images of the decoders' W_ih + W_hh, then of W_ih (lstm_seq_dev.h, wf_img_write)
   unsigned long long wf_call = ~0ull;       // value of `calls` whose encoder launch wrote them
+  unsigned long long lat_tail_call = ~0ull; // value of `calls` whose encoder launch left the latent chains' tails to the decoder launch
   int dwfold_state = 0;             // weight-gradient role workgroups in the backward fold launch (dw_role_dev.h): 0 / 1 / -1
   int64_t dw_flags = -1, dw_table = -1;     // stamps [4][T][32] + [4][B]; block table [DWR_TABLE_CAP] int4
   std::vector<int> dw_table_host;   // the table as uploaded (4 ints per block)

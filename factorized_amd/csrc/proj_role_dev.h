@@ -58,6 +58,7 @@ struct ProjRole {
   HoCtl ctl;                              // consumer side: time-out, status word, poison
   int fault;                              // fault injection (tests): role workgroup 0 does not raise its first flag
   int lat_pre;                            // the rows' latent chains preload their tables in front of the time loop (lstm_seq_small.hip)
+  int lat_tail;                           // ... and stop behind the z -> f MLPs: tail blocks of the decoder launch finish them
   float* loss_ptr; int loss_n;            // loss slots: cleared with agent-scope stores before any flag of t = 0 is raised
   int bf16;                               // bf16 plans: x and W_ih rounded to bf16 (RNE) on the way into LDS, fp32 accumulation
   ProjRoleEnc e[4];

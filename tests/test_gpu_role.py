@@ -245,3 +245,33 @@ def test_round6_forms_equal_the_forms_they_replaced(monkeypatch, switch, B, T):
         assert grad_err(g1[n], r) < TOL, (switch, "new form", n)
         assert grad_err(g0[n], r) < TOL, (switch, "old form", n)
         assert grad_err(g1[n], g0[n]) < 1e-5, (switch, "new vs old", n)
+
+
+@pytest.mark.parametrize("switch", ["MFM_LATENT_TAIL", "MFM_LATENT_BWD_HEAD"])
+@pytest.mark.parametrize("B,T", [(32, 20), (7, 3), (19, 21), (1, 2), (36, 5)])
+def test_chain_tails_on_the_decoder_launches_equal_the_whole_chains(monkeypatch, switch, B, T):
+    """Round 6: the latent chains' stages that nothing of the decoders waits for run on idle CUs of the DECODER launches -- forward:
+    classifier, logvar heads, losses, y_hat as tail blocks of the decoder recurrence launch (MFM_LATENT_TAIL=0: inside the encoder
+    launch); backward: the discriminative / KLD seeds and the classifier / logvar stages as head blocks of the decoder BPTT launch
+    (MFM_LATENT_BWD_HEAD=0: in front of the encoder BPTT).  Same arithmetic: losses, y_hat and gradients equal to rounding order,
+    both forms within 1e-4 of the CPU oracle (B = 36: beyond the projection role form, the plain launches)."""
+    cfgs = C.canonical_configs(dropout=False)
+    monkeypatch.delenv(switch, raising=False)
+    e1, w, xn, yn, ld1, g1 = _grads(cfgs, B, T)
+    monkeypatch.setenv(switch, "0")
+    e0, _, _, _, ld0, g0 = _grads(cfgs, B, T)
+    monkeypatch.delenv(switch, raising=False)
+    for k in ("disc", "gen", "reg", "loss"):
+        assert abs(ld1[k] - ld0[k]) <= 1e-6 * max(abs(ld0[k]), 1.0), (k, ld1[k], ld0[k])
+    m = O.build("kl_ef", cfgs)
+    O.load_numpy_weights(m, w)
+    m.train()
+    terms = O.loss_terms(m, torch.from_numpy(xn), torch.from_numpy(yn), cfgs[0])
+    terms["loss"].backward()
+    ref_loss = float(terms["loss"].detach())
+    assert abs(ld1["loss"] - ref_loss) <= TOL * abs(ref_loss)
+    for n, p in m.named_parameters():
+        r = p.grad.numpy()
+        assert grad_err(g1[n], r) < TOL, (switch, "split form", n)
+        assert grad_err(g0[n], r) < TOL, (switch, "whole chain", n)
+        assert grad_err(g1[n], g0[n]) < 1e-5, (switch, "split vs whole", n)
