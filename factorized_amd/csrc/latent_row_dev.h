@@ -105,6 +105,9 @@ template <bool PRE>
 __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const float* __restrict__ params, const int row, const int ch,
                                                     float* lds, const bool own_input, const int mode = 0,
                                                     const float* h_lds = nullptr, const int stage_hi = MFM_LAT_MAXSTAGES) {
+#if MFM_LAUNCH_STAMP
+  const int LST_KF = mode == 3 ? 1 : 0;        // a tail block is a block of the decoder forward launch
+#endif
   __shared__ LatOp ops[MFM_LAT_MAXOPS];
   __shared__ float red[2][16];
   __shared__ float ysave[2][128];
@@ -202,14 +205,14 @@ __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const fl
   mark(L, 0);
   lds_barrier();
   mark(L, 1);
-  LSTAMP(0, 16);
+  LSTAMP(LST_KF, 16);
   auto stage = [&](int s, Slot& cur, Slot& nxt) {
     // A wave with no item in this stage nor in the next skips the body.  Inside the body every load is
     // unconditional (the last stage requests its own weights again): a load under a branch would make the
     // compiler's in-order vmcnt accounting conservative and the wait for `cur` would also cover `nxt`.
     const int sn = min(s + 1, L.nstages - 1);
 #if MFM_LAUNCH_STAMP
-    if (s == 2) LSTAMP(0, 26);
+    if (s == 2) LSTAMP(LST_KF, 26);
 #endif
     if (wave0 < (PRE ? nif[s] : max(nif[s], nif[sn]))) {
       const int in_off = cur.e[2] & 0xFFFF, K = (cur.e[2] >> 16) & 0xFF;
@@ -219,12 +222,12 @@ __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const fl
         for (int j = 0; j < 8; ++j) xv[j] = *reinterpret_cast<const f32x4*>(rec + in_off + min(4 * q + 16 * j, K - 4));
       }
 #if MFM_LAUNCH_STAMP
-      if (s == 2 && threadIdx.x < 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); LSTAMP(0, 27); }
+      if (s == 2 && threadIdx.x < 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); LSTAMP(LST_KF, 27); }
 #endif
       if constexpr (!PRE) fetch(sn, nxt);
       mark(L, 2 + 2 * s);
 #if MFM_LAUNCH_STAMP
-      if (s == 2 && threadIdx.x < 64) { LSTAMP(0, 28); asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); LSTAMP(0, 29); }
+      if (s == 2 && threadIdx.x < 64) { LSTAMP(LST_KF, 28); asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); LSTAMP(LST_KF, 29); }
 #endif
       if (wave0 < nif[s]) {
         float a0 = 0.0f, a1 = 0.0f;
@@ -261,11 +264,11 @@ __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const fl
       }
     }
 #if MFM_LAUNCH_STAMP
-    if (s == 2) LSTAMP(0, 30);
+    if (s == 2) LSTAMP(LST_KF, 30);
 #endif
     lds_barrier();
     mark(L, 3 + 2 * s);
-    LSTAMP(0, 17 + s);
+    LSTAMP(LST_KF, 17 + s);
   };
   if constexpr (PRE) {
     Slot sl[LAT_PRE_SLOTS];
@@ -322,7 +325,7 @@ __device__ __forceinline__ void latent_fwd_row_body(const LatentDev& L, const fl
     if ((tid & 63) == 0) { red[0][tid >> 6] = kld; red[1][tid >> 6] = disc; }
   }
   lds_barrier();
-  LSTAMP(0, 25);
+  LSTAMP(LST_KF, 25);
   if (tid == 0 && e_losses) {
     if (e_haslv) atomicAdd(e_losses + 4, -0.5f * (red[0][0] + red[0][1]));
     if (L.y && ych) {
@@ -366,6 +369,9 @@ __host__ __device__ static inline int latent_bwd_grd_floats(int rec_size) { retu
 template <bool PRE>
 __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const float* __restrict__ params, float* __restrict__ grads,
                                                     const int row, const int ch, float* lds, const int mode = 0) {
+#if MFM_LAUNCH_STAMP
+  const int LST_KB = mode == 3 ? 3 : 4;        // a head block is a block of the decoder BPTT launch
+#endif
   __shared__ LatOp ops[MFM_LAT_MAXOPS];
   __shared__ int pfxN[MFM_LAT_MAXOPS];
   const int RS = L.rec_size;
@@ -466,7 +472,7 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
   }
 #undef LAT_KEEP
   lds_barrier();
-  LSTAMP(4, 16);
+  LSTAMP(LST_KB, 16);
   const int l = tid & 15;
   const int wave0 = tid & ~63;
   struct Slot { f32x4 w[8]; i32x4 e; };
@@ -558,7 +564,7 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
   }
   lds_barrier();
   mark(L, 24);
-  LSTAMP(4, 17);
+  LSTAMP(LST_KB, 17);
 
   auto stage = [&](int s, Slot& cur, Slot& nxt) {
     const int sn = max(s - 1, 0);
@@ -602,7 +608,7 @@ __device__ __forceinline__ void latent_bwd_row_body(const LatentDev& L, const fl
     mark(L, 26 + 3 * s);
     lds_barrier();
     mark(L, 27 + 3 * s);
-    LSTAMP(4, 18 + s);
+    LSTAMP(LST_KB, 18 + s);
   };
   if constexpr (PRE) {
 #pragma unroll

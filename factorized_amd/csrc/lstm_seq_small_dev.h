@@ -892,7 +892,9 @@ __device__ __forceinline__ void small_bwd_body_x(const SeqDev& d, const int T, c
       const int r = min(sl + i * S, 4 * h - 1);
       wpre[i] = *reinterpret_cast<const f32x4*>(d.w_ih + (int64_t)r * h + 4 * min(u4, h4 - 1));
     }
+    LSTAMP(3, 8);
     step(0, false);
+    LSTAMP(3, 9);
     const float* db = dabuf + dcur * (4 * HKB * R);
     if (sl < S) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -912,7 +914,9 @@ __device__ __forceinline__ void small_bwd_body_x(const SeqDev& d, const int T, c
       float* pr = panel + sl * h + 4 * u4;
       pr[0] = acc[0]; pr[1] = acc[1]; pr[2] = acc[2]; pr[3] = acc[3];
     }
+    LSTAMP(3, 10);
     lds_barrier();
+    LSTAMP(3, 11);
     if (tid < h && d.d_h_init && b0 < B) {
       float sum = 0.0f;
       for (int k = 0; k < S; ++k) sum += panel[k * h + tid];

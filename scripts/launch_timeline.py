@@ -41,6 +41,16 @@ PT = {
 for _s in range(8):
     PT[0][17 + _s] = "  latent fwd: stage %d done" % _s
     PT[4][18 + _s] = "  latent bwd: stage %d done" % _s
+    PT[1][17 + _s] = "  latent fwd (tail block): stage %d done" % _s
+    PT[3][18 + _s] = "  latent bwd (head block): stage %d done" % _s
+PT[1][16] = "  latent fwd (tail block): tables + record in LDS"
+PT[1][25] = "  latent fwd (tail block): losses reduced"
+PT[3][8] = "  step 0: W_ih rows requested"
+PT[3][9] = "  step 0: pointwise part done (dA_0 in LDS)"
+PT[3][10] = "  step 0: dA_0 W_ih partial sums written (in front of the barrier)"
+PT[3][11] = "  step 0: barrier passed"
+PT[3][16] = "  latent bwd (head block): tables + records in LDS"
+PT[3][17] = "  latent bwd (head block): seeds done"
 PT[0][26] = "    stage 2: top"
 PT[0][27] = "    stage 2: input segment read from LDS"
 PT[0][28] = "    stage 2: next stage's weights requested"
@@ -52,7 +62,7 @@ PT[4][16] = "  latent bwd: tables + records in LDS"
 PT[4][17] = "  latent bwd: seeds done"
 SUB = ["A issued (stamps waited for if not prefetched)", "next block's stamps asked", "operands parked in LDS + barrier", "next operands requested",
        "product + epilogue done", "closing barrier"]
-ORDER = {0: [0, 1, 2, 5, 6, 7, 9, 8, 16, 17, 18, 26, 27, 28, 29, 30, 19, 20, 21, 22, 23, 24, 25, 15], 1: [0, 1, 2, 3, 4, 5, 6, 7, 15], 2: [0, 3, 4, 1, 5, 6, 7, 2, 8, 9, 15], 3: [0, 1, 2, 5, 6, 3, 7, 15],
+ORDER = {0: [0, 1, 2, 5, 6, 7, 9, 8, 16, 17, 18, 26, 27, 28, 29, 30, 19, 20, 21, 22, 23, 24, 25, 15], 1: [0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 15], 2: [0, 3, 4, 1, 5, 6, 7, 2, 8, 9, 15], 3: [0, 1, 2, 5, 6, 3, 8, 9, 10, 11, 7, 16, 17, 25, 24, 23, 22, 21, 20, 19, 18, 15],
          4: [0, 16, 17, 25, 24, 23, 22, 21, 20, 19, 18, 9, 8, 1, 2, 5, 6, 3, 7, 15], 5: [0, 15]}
 
 CHILD_STEP = r"""
@@ -144,9 +154,9 @@ def main():
     dec_names = ["dec l (h=104)", "dec a (h=24)", "dec v (h=24)"]
     classes = {
         0: [("projection role workgroups", 0, n_role_p)] + [(enc_names[i], n_role_p + i * B, n_role_p + (i + 1) * B) for i in range(4)],
-        1: [(dec_names[i], i * B, (i + 1) * B) for i in range(3)] + [("image writers", 3 * B, nb)],
+        1: [(dec_names[i], i * B, (i + 1) * B) for i in range(3)] + [("latent forward tail blocks (classifier, logvar heads, losses)", 3 * B, nb)],
         2: [(dec_names[i], i * B, (i + 1) * B) for i in range(3)] + [("other tiles", 3 * B, nb)],
-        3: [(dec_names[i], i * B, (i + 1) * B) for i in range(3)],
+        3: [(dec_names[i], i * B, (i + 1) * B) for i in range(3)] + [("latent backward head blocks (disc / KLD seeds, classifier, logvar stages)", 3 * B, nb)],
         4: [(enc_names[i], i * B, (i + 1) * B) for i in range(4)] + [("weight-gradient role workgroups", 4 * B, nb)],
         5: [("all blocks", 0, nb)],
     }
@@ -189,7 +199,7 @@ def main():
                     continue
                 print("     %-52s %8.2f  [%7.2f .. %7.2f]" % (labels.get(p, "point %d" % p), np.nanmedian(col), np.nanmin(col), np.nanmax(col)))
             # prologue + T x step + tail for the recurrences
-            if k in (0, 1, 3, 4) and not name.startswith(("projection", "weight", "image")):
+            if k in (0, 1, 3, 4) and not name.startswith(("projection", "weight", "image", "latent")):
                 g = lambda p: np.nanmedian(blk[:, p] - first[k])
                 if k in (0, 1):
                     t_a = 1 if k == 0 else 2

@@ -35,6 +35,10 @@ def classify(name):
         return "fc1_mse_gemm"
     if "pack_all_kernel" in name:
         return "bf16_weight_pack"
+    if "lstm_seq_small_dectail_kernel" in name:         # decoder rows + the latent chain's tail blocks (B <= 32)
+        return "dec_seq_fwd"
+    if "lstm_seq_small_decbwd_head_kernel" in name:     # decoder BPTT rows + the latent backward chain's head blocks (B <= 32)
+        return "dec_seq_bwd"
     if "lstm_seq_small_foldproj_kernel" in name:        # ... with the projection role workgroups in front (B <= 32)
         return "enc_seq_fwd"
     if "lstm_seq_small_folddw_kernel" in name:          # ... with the weight-gradient role workgroups behind (B <= 32)
