@@ -886,11 +886,17 @@ __device__ __forceinline__ void small_bwd_body_x(const SeqDev& d, const int T, c
     const int S = min(min(32, nt / h4), h);         // row slices (S*h partial sums must fit the h*h panel)
     const int u4 = tid % h4, sl = tid / h4;
     constexpr int NPRE = (4 * HKB + 31) / 32;       // rows per thread at S = 32 (fewer slices: the loop below takes the rest)
+    // (round 6, the launch clock again: 4.2 us from the requests to the last wave's partial sums, and the same with half of the
+    // rows parked in LDS beforehand or with every line of W_ih touched in the prologue -- not memory: the loop divided every row
+    // index by h to find its (gate, unit), ~30 VALU instructions x 13 rows x 13 waves on 4 SIMDs.)  Rows advance by S <= h:
+    // the (gate, unit) pair and the row pointer advance by additions.
     f32x4 wpre[NPRE];
+    const float* const wp0 = d.w_ih + (int64_t)min(sl, 4 * h - 1) * h + 4 * min(u4, h4 - 1);
+    const int64_t wstep = (int64_t)S * h;
 #pragma unroll
     for (int i = 0; i < NPRE; ++i) {
-      const int r = min(sl + i * S, 4 * h - 1);
-      wpre[i] = *reinterpret_cast<const f32x4*>(d.w_ih + (int64_t)r * h + 4 * min(u4, h4 - 1));
+      const float* wp = (sl + i * S < 4 * h) ? wp0 + i * wstep : wp0;
+      wpre[i] = *reinterpret_cast<const f32x4*>(wp);
     }
     LSTAMP(3, 8);
     step(0, false);
@@ -898,13 +904,13 @@ __device__ __forceinline__ void small_bwd_body_x(const SeqDev& d, const int T, c
     const float* db = dabuf + dcur * (4 * HKB * R);
     if (sl < S) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      int dj = sl, dg = 0;                            // row sl + i S = gate dg, unit dj  (sl < S <= h)
 #pragma unroll
       for (int i = 0; i < NPRE; ++i) {
-        const int r = sl + i * S;
-        const int rc = min(r, 4 * h - 1);
-        const int gg = rc / h, j = rc - gg * h;
-        const float a = (r < 4 * h) ? db[gg * HKB + j] : 0.0f;
+        const float a = (sl + i * S < 4 * h) ? db[min(dg, 3) * HKB + dj] : 0.0f;
         acc += a * wpre[i];
+        dj += S;
+        if (dj >= h) { dj -= h; ++dg; }
       }
       for (int r = sl + NPRE * S; r < 4 * h; r += S) {
         const int gg = r / h, j = r - gg * h;
@@ -918,9 +924,13 @@ __device__ __forceinline__ void small_bwd_body_x(const SeqDev& d, const int T, c
     lds_barrier();
     LSTAMP(3, 11);
     if (tid < h && d.d_h_init && b0 < B) {
-      float sum = 0.0f;
-      for (int k = 0; k < S; ++k) sum += panel[k * h + tid];
-      d.d_h_init[(int64_t)b0 * d.ld_dinit + tid] = sum;
+      float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+      int k = 0;
+      for (; k + 4 <= S; k += 4) {
+        s0 += panel[k * h + tid]; s1 += panel[(k + 1) * h + tid]; s2 += panel[(k + 2) * h + tid]; s3 += panel[(k + 3) * h + tid];
+      }
+      for (; k < S; ++k) s0 += panel[k * h + tid];
+      d.d_h_init[(int64_t)b0 * d.ld_dinit + tid] = (s0 + s1) + (s2 + s3);
     }
     LSTAMP(3, 7);
     return;
