@@ -766,9 +766,11 @@ __device__ __forceinline__ void small_bwd_body_x(const SeqDev& d, const int T, c
     if (dec) ext = sb[5 * HKB * R];
     if (has_dc) dce = sb[6 * HKB * R];
     ext0 = 0.0f;
+    // (the peeled decoder step 0 -- matvec == false, a constant of that call site -- prefetches nothing: its fetch would queue
+    // behind the W_ih rows requested in front of it and hold the step's own stores back)
     float pn[NLD];
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) pn[i] = fetch(i, max(t - 2, 0));
+    for (int i = 0; i < NLD; ++i) pn[i] = matvec ? fetch(i, max(t - 2, 0)) : 0.0f;
     const float dh = dh_rec + ext;
     const float tc = act_tanh(ct);
     const float dot = dh * tc;
@@ -923,7 +925,22 @@ __device__ __forceinline__ void small_bwd_body_x(const SeqDev& d, const int T, c
     LSTAMP(3, 10);
     lds_barrier();
     LSTAMP(3, 11);
-    if (tid < h && d.d_h_init && b0 < B) {
+    if (h <= 128 && nt >= 1024 && S == 32) {
+      // 8 groups of 128 threads sum 4 slices each (one batch of LDS reads), the first h threads the 8 group sums
+      const int grp = tid >> 7, u = tid & 127;
+      float* const p2 = panel + S * h;                          // (S + 8) h <= 2 h^2: h >= 32 here (S == 32 <= h)
+      if (u < h) {
+        const float* pp = panel + (4 * grp) * h + u;
+        p2[grp * h + u] = (pp[0] + pp[h]) + (pp[2 * h] + pp[3 * h]);
+      }
+      lds_barrier();
+      if (tid < h && d.d_h_init && b0 < B) {
+        float s8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s8[k] = p2[k * h + tid];
+        d.d_h_init[(int64_t)b0 * d.ld_dinit + tid] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+      }
+    } else if (tid < h && d.d_h_init && b0 < B) {
       float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
       int k = 0;
       for (; k + 4 <= S; k += 4) {
