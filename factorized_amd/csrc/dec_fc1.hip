@@ -13,10 +13,10 @@
 // uses every element exactly once per product.  The weight-gradient products dWfc = dx_hat^T H and dbfc stay in the
 // step's tail GEMM launch (they only feed the optimizer).
 //
-// Decomposition: one workgroup = 16 rows x one group of <= 8 output fragments (16 columns each) of one decoder.  At the
-// reference's B=32 decoder l (300 columns) has only 40 row tiles, so its columns are spread over 4 workgroups each
-// (160 of 256 CUs instead of 40); their contributions to dH are partial sums over the columns and are ADDED to dH with
-// atomics -- the caller puts the dH block into the step's zero spans.  (A single column group stores instead.)
+// Decomposition: one workgroup = 16 rows x one group of <= 8 output fragments (16 columns each) of one decoder.  Decoder l
+// (300 columns, 19 fragments) takes 3 column groups per row tile; their contributions to dH are partial sums over the
+// columns and are ADDED to dH with atomics -- the caller puts the dH block into the step's zero spans.  (A single column group
+// stores instead.)
 //
 // 512 threads = 8 waves; MFMA 16x16x4 fp32 tiles.
 //   product 1: wave w owns output fragment w of the group; the reduction over hidden units walks 16-wide blocks: lane
@@ -211,8 +211,13 @@ int dec_fc1_launch(DecFc1Launch& L, bool dhs_zeroed, hipStream_t stream) {
     MFM_REQUIRE(!L.with_bwd || I.dhs, "dec fc1: item %d: backward without a dH buffer", i);
     if (I.Hp > 16 * FC1_MAXF || (int64_t)I.d * I.h >= ((int64_t)1 << 28)) return MFM_ERR_UNSUPPORTED;
     const int NF1 = (I.d + 15) >> 4;
-    // few row tiles: spread the columns (5 fragments per workgroup); many: full groups of 8
-    int fpg = (row_tiles <= 64 && dhs_zeroed) ? 5 : FC1_MAXF;
+    // (rounds 3-5: 5 fragments per group, "spread the columns" -- decoder l on 160 workgroups.  Round 6, the launch clock: the
+    // partial dH tiles of a row tile's column groups are added with memory-side atomics, and those, not the products, end the
+    // launch: the single-group tiles of the narrow decoders leave 2.4 us after their first product, the four-group tiles 3.9
+    // (median) to 5.4 us.  Step time against fragments per group: 3 0.1484, 4 0.1467, 5 0.1454, 7 0.1453, 8 0.1442 ms; ten waves
+    // with groups of 10 were built and are slower, 0.1467.  MFM_FC1_FPG overrides.)
+    int fpg = FC1_MAXF;
+    if (const char* e = opt_get("MFM_FC1_FPG")) { const int v = atoi(e); if (v >= 1 && v <= FC1_MAXF && dhs_zeroed) fpg = v; }
     if (NF1 > fpg && !(dhs_zeroed || !L.with_bwd)) return MFM_ERR_UNSUPPORTED;      // several groups add into dH
     I.frags_per_group = std::min(fpg, NF1);
     I.col_groups = (NF1 + I.frags_per_group - 1) / I.frags_per_group;

@@ -152,10 +152,19 @@ def main():
     n_role_p = (cus - 4 * B) // 32 * 32
     enc_names = ["enc l (h=32)", "enc a (h=8)", "enc v (h=80)", "enc ef (h=120)"]
     dec_names = ["dec l (h=104)", "dec a (h=24)", "dec v (h=24)"]
+    # dec_fc1.hip: 16-row tiles x column groups of 8 fragments, decoder after decoder (canonical MOSI widths)
+    fc1_classes, _rt, _t0 = [], -(-T * B // 16), 0
+    for _nm, _d in zip(("l (300 columns)", "a (5 columns)", "v (20 columns)"), (300, 5, 20)):
+        _nf = -(-_d // 16)
+        _fpg = min(8, _nf)
+        _cg = -(-_nf // _fpg)
+        fc1_classes.append(("fc1 of decoder %s: %d row tiles x %d column groups%s" % (_nm, _rt, _cg, " (dH added with atomics)" if _cg > 1 else " (dH stored)"),
+                            _t0, min(_t0 + _rt * _cg, nb)))
+        _t0 += _rt * _cg
     classes = {
         0: [("projection role workgroups", 0, n_role_p)] + [(enc_names[i], n_role_p + i * B, n_role_p + (i + 1) * B) for i in range(4)],
         1: [(dec_names[i], i * B, (i + 1) * B) for i in range(3)] + [("latent forward tail blocks (classifier, logvar heads, losses)", 3 * B, nb)],
-        2: [(dec_names[i], i * B, (i + 1) * B) for i in range(3)] + [("other tiles", 3 * B, nb)],
+        2: fc1_classes,
         3: [(dec_names[i], i * B, (i + 1) * B) for i in range(3)] + [("latent backward head blocks (disc / KLD seeds, classifier, logvar stages)", 3 * B, nb)],
         4: [(enc_names[i], i * B, (i + 1) * B) for i in range(4)] + [("weight-gradient role workgroups", 4 * B, nb)],
         5: [("all blocks", 0, nb)],
