@@ -20,7 +20,7 @@ struct SeqDev {
   const float* wf1_img;    // the same for W_ih alone (the decoders' step 0), or null
 };
 // Transposed-weight images for the one-row BPTT kernels of the same step (lstm_seq_small.hip, small_bwd_body<.., KS = 16>):
-// img[s][tid], s = which * 4 NG + g * NG + i, holds W[g h + 16 i + (tid & 15)][2 (tid >> 4) + which] (w_ih set: W_ih + W_hh,
+// img4[s / 4][tid][s % 4], s = which * 4 NG + g * NG + i, holds W[g h + 16 i + (tid & 15)][2 (tid >> 4) + which] (w_ih set: W_ih + W_hh,
 // the decoders' steps >= 1), zero outside the valid units.  Written by workgroups that have nothing else to do in a FORWARD
 // launch of the step -- the projection role workgroups once their items are done (proj_role_dev.h), or a few blocks appended to
 // the recurrence launch -- and read by the BPTT launches, which come later in the stream: nothing has to be signalled.
@@ -44,19 +44,33 @@ __device__ __forceinline__ void wt_img_write(const WtImgItem* items, const int n
   for (int w = 0; w < n; ++w) {
     const WtImgItem& I = items[w];
     if (I.fwd) { wf_img_write(&I, 1, r, nr); continue; }
+    // (round 6: four consecutive slots of a thread side by side -- img4[(s / 4) NTH + tid][s % 4] -- so that the BPTT takes its
+    // 2 NW registers with NW / 2 16-byte loads instead of 2 NW 4-byte ones; 4 NG slots per `which`: a quad never straddles it)
     const int NG = I.HKB >> 4, NTH = 8 * I.HKB, h = I.h;
-    const int total = 8 * NG * NTH;
-    for (int idx = r * nt + tid; idx < total; idx += nr * nt) {
-      const int s = idx / NTH, t2 = idx - s * NTH;
-      const int which = s / (4 * NG), rem = s - which * 4 * NG;
-      const int g = rem / NG, i = rem - g * NG;
-      const int j = 16 * i + (t2 & 15), u = 2 * (t2 >> 4) + which;
-      float v = 0.0f;
-      if (j < h && u < h) {
-        v = I.w_hh[((int64_t)g * h + j) * h + u];
-        if (I.w_ih) v += I.w_ih[((int64_t)g * h + j) * h + u];
+    const int total = 2 * NG * NTH;
+    f32x4* out = reinterpret_cast<f32x4*>(I.img);
+    // 64-quad pieces (one wave, 1 KB) dealt round-robin over the WRITERS first, then over a writer's waves: the largest image
+    // is 256 pieces, and dealt thread by thread they all landed on the first 16 of 128 role workgroups
+    const int nwv = nt >> 6;
+    for (int c = (tid >> 6) * nr + r; c * 64 < total; c += nwv * nr) {
+      const int idx = c * 64 + (tid & 63);
+      if (idx >= total) break;
+      const int s4 = idx / NTH, t2 = idx - s4 * NTH;
+      f32x4 v4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = 4 * s4 + e;
+        const int which = s / (4 * NG), rem = s - which * 4 * NG;
+        const int g = rem / NG, i = rem - g * NG;
+        const int j = 16 * i + (t2 & 15), u = 2 * (t2 >> 4) + which;
+        float v = 0.0f;
+        if (j < h && u < h) {
+          v = I.w_hh[((int64_t)g * h + j) * h + u];
+          if (I.w_ih) v += I.w_ih[((int64_t)g * h + j) * h + u];
+        }
+        v4[e] = v;
       }
-      I.img[idx] = v;
+      out[idx] = v4;
     }
   }
 }

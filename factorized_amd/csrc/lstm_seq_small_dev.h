@@ -633,9 +633,14 @@ __device__ __forceinline__ void small_bwd_body_x(const SeqDev& d, const int T, c
     if constexpr (KS == 16 && R == 1) {
       if (d.wt_img && mode != 1) {
         // (threads beyond NTH own no unit and share no reduction group with one that does: what they hold is never used)
-        const float* img = d.wt_img + (tid < NTH ? tid : 0);
+        static_assert(NW % 4 == 0, "transposed-weight image: quads of slots");
+        const f32x4* img = reinterpret_cast<const f32x4*>(d.wt_img) + (tid < NTH ? tid : 0);
 #pragma unroll
-        for (int i = 0; i < NW; ++i) { wa[i] = img[(int64_t)i * NTH]; wb[i] = img[(int64_t)(NW + i) * NTH]; }
+        for (int i = 0; i < NW / 4; ++i) {
+          const f32x4 va = img[(int64_t)i * NTH], vb = img[(int64_t)(NW / 4 + i) * NTH];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { wa[4 * i + e] = va[e]; wb[4 * i + e] = vb[e]; }
+        }
         return;
       }
     }
